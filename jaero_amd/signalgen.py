@@ -1,0 +1,129 @@
+"""Synthetic Aero test signals (real 16-bit PCM at 48 kHz), as specified in SURVEY.md section 8(d).
+
+The reference has no modulator; these follow the signal definitions its demodulators lock to
+(probed in SURVEY.md 8(d) "Generator validity"):
+
+* OQPSK 10.5 kbps: even bits on I, odd bits on Q, +-1 symbols at fb/2 symbols/s per arm, continuous-time
+  root-raised-cosine alpha=1 pulse (the closed form of RootRaisedCosine::design, JAERO/DSP.h:316-338, evaluated
+  at fractional sample offsets because Fs/(fb/2) = 9.142857 is not an integer), Q arm delayed half a symbol,
+  x = I cos(2 pi fc n/Fs) - Q sin(2 pi fc n/Fs).
+* MSK 600/1200 bps: CPFSK with modulation index 0.5 (+-fb/4), the hard decisions of the demodulator output
+  equal the FSK data bits directly.
+
+Everything here is numpy on the host (used by tests, the oracle legs and small benches).  `oqpsk_torch`
+produces the same waveform family on a torch device for large resident bench inputs.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SEED_BASE = 0x4A410000  # seed = 0x4A41_0000 + channel
+
+
+def rrc_pulse(t: np.ndarray, T: float, alpha: float = 1.0) -> np.ndarray:
+    """Continuous-time RRC impulse response sampled at offsets t (in samples); T = samples/symbol."""
+    t = np.asarray(t, dtype=np.float64)
+    out = np.empty_like(t)
+    x = 4.0 * alpha * t / T
+    centre = np.abs(t) < 1e-12
+    sing = np.abs(1.0 - x * x) < 1e-10
+    reg = ~(centre | sing)
+    out[centre] = (4.0 * alpha + np.pi - np.pi * alpha) / (np.pi * np.sqrt(T))
+    out[sing] = alpha * ((np.pi - 2.0) * np.cos(np.pi / (4.0 * alpha)) + (np.pi + 2.0) * np.sin(np.pi / (4.0 * alpha))) / (
+        np.pi * np.sqrt(2.0 * T)
+    )
+    tr = t[reg]
+    out[reg] = (
+        4.0 * alpha / (np.pi * np.sqrt(T))
+        * (np.cos((1.0 + alpha) * np.pi * tr / T) + T / (4.0 * alpha * tr) * np.sin((1.0 - alpha) * np.pi * tr / T))
+        / (1.0 - (4.0 * alpha * tr / T) ** 2)
+    )
+    return out
+
+
+def _shape(symbols: np.ndarray, n: np.ndarray, T: float, delay: float, span: int = 6) -> np.ndarray:
+    """sum_k a_k h(n - delay - kT) over the 2*span+1 nearest symbols."""
+    t = n - delay
+    k0 = np.floor(t / T).astype(np.int64)
+    acc = np.zeros(n.shape, dtype=np.float64)
+    nsym = symbols.shape[0]
+    for j in range(-span, span + 2):
+        k = k0 + j
+        ok = (k >= 0) & (k < nsym)
+        a = np.where(ok, symbols[np.clip(k, 0, nsym - 1)], 0.0)
+        acc += a * rrc_pulse(t - k * T, T, 1.0)
+    return acc
+
+
+def oqpsk(nsamples: int, *, fb: float = 10500.0, Fs: float = 48000.0, fc: float = 8000.0, ebno_db: float | None = 10.0,
+          peak: float = 0.3, seed: int = SEED_BASE, bits: np.ndarray | None = None, start_sample: int = 0):
+    """Returns (pcm int16[nsamples], bits uint8[...]) for a continuous 10.5k-style OQPSK channel."""
+    rng = np.random.default_rng(seed)
+    T = Fs / (fb / 2.0)
+    nsym = int(np.ceil((start_sample + nsamples) / T)) + 16
+    if bits is None:
+        bits = rng.integers(0, 2, size=2 * nsym, dtype=np.uint8)
+    else:
+        # deterministic noise stream regardless of supplied bits
+        rng.integers(0, 2, size=2 * nsym, dtype=np.uint8)
+    a_i = 2.0 * bits[0::2][:nsym].astype(np.float64) - 1.0
+    a_q = 2.0 * bits[1::2][:nsym].astype(np.float64) - 1.0
+    n = np.arange(start_sample, start_sample + nsamples, dtype=np.float64)
+    i_t = _shape(a_i, n, T, 0.0)
+    q_t = _shape(a_q, n, T, T / 2.0)
+    ph = 2.0 * np.pi * fc * n / Fs
+    x = i_t * np.cos(ph) - q_t * np.sin(ph)
+    p = float(np.mean(x * x)) if nsamples else 1.0
+    if ebno_db is not None:
+        sigma2 = p * Fs / (2.0 * fb * 10.0 ** (ebno_db / 10.0))
+        x = x + rng.normal(0.0, np.sqrt(sigma2), size=nsamples)
+    scale = peak / (3.0 * np.sqrt(p)) if p > 0 else 1.0  # 3-sigma-ish headroom, deterministic (no data-dependent max)
+    pcm = np.clip(np.round(x * scale * 32768.0), -32768, 32767).astype(np.int16)
+    return pcm, bits
+
+
+def msk(nsamples: int, *, fb: float = 1200.0, Fs: float = 48000.0, fc: float = 1000.0, ebno_db: float | None = 10.0,
+        peak: float = 0.3, seed: int = SEED_BASE, bits: np.ndarray | None = None):
+    """Returns (pcm int16[nsamples], bits uint8[...]) for a continuous MSK (CPFSK h=0.5) channel."""
+    rng = np.random.default_rng(seed)
+    sps = Fs / fb
+    nbits = int(np.ceil(nsamples / sps)) + 4
+    if bits is None:
+        bits = rng.integers(0, 2, size=nbits, dtype=np.uint8)
+    else:
+        rng.integers(0, 2, size=nbits, dtype=np.uint8)
+    n = np.arange(nsamples, dtype=np.float64)
+    k = np.minimum((n / sps).astype(np.int64), bits.shape[0] - 1)
+    dev = (2.0 * bits[k].astype(np.float64) - 1.0) * (fb / 4.0)  # +-fb/4 Hz
+    ph = 2.0 * np.pi * np.cumsum((fc + dev) / Fs)
+    x = np.cos(ph)
+    p = 0.5
+    if ebno_db is not None:
+        sigma2 = p * Fs / (2.0 * fb * 10.0 ** (ebno_db / 10.0))
+        x = x + rng.normal(0.0, np.sqrt(sigma2), size=nsamples)
+    pcm = np.clip(np.round(x * peak * 32768.0), -32768, 32767).astype(np.int16)
+    return pcm, bits
+
+
+def channel_bank(kind: str, nch: int, nsamples: int, *, ebno_db: float | None = 10.0, seed0: int = SEED_BASE, **kw):
+    """[nch, nsamples] int16 bank with per-channel carrier offsets as in SURVEY.md 8(d) configs 2/3.
+
+    Returns (pcm, carriers, bits_list).  OQPSK: carrier 8000 + U(-100,100) Hz; MSK: 1000 + U(-50,50) Hz.
+    """
+    pcm = np.empty((nch, nsamples), dtype=np.int16)
+    carriers = np.empty(nch, dtype=np.float64)
+    bits_list = []
+    for c in range(nch):
+        r = np.random.default_rng(seed0 + c + 0x1000000)
+        if kind == "oqpsk":
+            fc = 8000.0 + r.uniform(-100.0, 100.0)
+            p, b = oqpsk(nsamples, fc=fc, ebno_db=ebno_db, seed=seed0 + c, **kw)
+        elif kind == "msk":
+            fc = 1000.0 + r.uniform(-50.0, 50.0)
+            p, b = msk(nsamples, fc=fc, ebno_db=ebno_db, seed=seed0 + c, **kw)
+        else:
+            raise ValueError(kind)
+        pcm[c] = p
+        carriers[c] = fc
+        bits_list.append(b)
+    return pcm, carriers, bits_list

@@ -1,0 +1,74 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY.  CPU restatement of the reference's demodulator hot path.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it; the product path
+ * (jaero_amd/, libjaero_hip.so) must never include, link or call anything in oracle/.  See jaero_oracle.c. */
+#ifndef JAERO_ORACLE_H
+#define JAERO_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { JO_KIND_MSK = 0, JO_KIND_OQPSK = 1 };
+
+typedef struct
+{
+    int kind;                    /* JO_KIND_* */
+    int coarsefreqest_fft_power; /* Settings::coarsefreqest_fft_power */
+    double freq_center;          /* Hz */
+    double lockingbw;            /* Hz */
+    double fb;                   /* bps */
+    double Fs;                   /* Hz */
+    double signalthreshold;
+} jo_settings;
+
+typedef struct jo_demod jo_demod;
+
+/* = constructor + setSettings(settings) + start() of OqpskDemodulator / MskDemodulator */
+jo_demod *jo_demod_create(const jo_settings *s);
+void jo_demod_destroy(jo_demod *d);
+/* = setSettings on a live object (JAERO/oqpskdemodulator.cpp:175-289, JAERO/mskdemodulator.cpp:135-263) */
+void jo_demod_set_settings(jo_demod *d, const jo_settings *s);
+/* = setAFC / setSQL / setCPUReduce */
+void jo_demod_set_flags(jo_demod *d, int afc, int sql, int cpu_reduce);
+/* = DCDstatSlot */
+void jo_demod_set_dcd(jo_demod *d, int dcd);
+/* = CenterFreqChangedSlot */
+void jo_demod_center_freq_changed(jo_demod *d, double freq_center);
+/* = writeData(const char*, len) with len = 2*nsamples */
+long jo_demod_write(jo_demod *d, const int16_t *pcm, long nsamples);
+
+/* captured outputs (drained by the calls below) */
+/* soft bits exactly as passed to processDemodulatedSoftBits, concatenated */
+long jo_demod_take_soft(jo_demod *d, int16_t *dst, long cap);
+/* one row of 6 doubles per FreqOffsetEstimateSlot: [n, freq_est(mixer2), freq_center(mixer_center), mse, ebno, signal] */
+long jo_demod_take_status(jo_demod *d, double *dst, long caprows);
+/* soft symbols: (re,im) of pt_qpsk / pt_msk after the residual rotation, one per symbol pair,
+ * plus the mse value after that symbol: rows of 3 doubles.  Enabled by jo_demod_capture_symbols(d,1). */
+void jo_demod_capture_symbols(jo_demod *d, int on);
+long jo_demod_take_symbols(jo_demod *d, double *dst, long caprows);
+/* pending soft bits not yet emitted (RxDataBits.size()) */
+int jo_demod_pending_soft(jo_demod *d);
+/* current values */
+double jo_demod_get_mse(jo_demod *d);
+double jo_demod_get_freq_est(jo_demod *d);
+double jo_demod_get_freq_center(jo_demod *d);
+
+/* stand-alone pieces for unit tests */
+/* RootRaisedCosine::design (JAERO/DSP.h:316-338); returns number of points written */
+int jo_rrc_design(double alpha, int firsize, double samplerate, double symbol_freq, double *points);
+/* CISWT table (JAERO/DSP.cpp:11-30): 19999 (re,im) pairs */
+void jo_cis_table(double *dst_re_im);
+/* FFTWrapper<double>::transform semantics on top of the same radix-2 FFT as oracle/ref/shim/jfft.h */
+void jo_fft(double *re_im, int n, int inverse);
+/* CoarseFreqEstimate stand-alone: create/setSettings, process one nfft buffer, returns emitted estimate */
+typedef struct jo_coarse jo_coarse;
+jo_coarse *jo_coarse_create(int power, double lockingbw, double fb, double Fs);
+void jo_coarse_destroy(jo_coarse *c);
+void jo_coarse_bigchange(jo_coarse *c);
+double jo_coarse_process(jo_coarse *c, const double *re_im);
+void jo_coarse_get_y(jo_coarse *c, double *y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,273 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+ctypes binding of oracle/liboracle.so (the plain-C restatement of the reference's demodulator path and of
+libcorrect's Viterbi) plus a runner for oracle/_ref/jaero_ref (the UNMODIFIED reference sources built against
+Qt 5.9.7 with shim headers).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
+module; the product package jaero_amd/ never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboracle.so")
+REF_BIN = os.path.join(HERE, "_ref", "jaero_ref")
+
+KIND_MSK, KIND_OQPSK = 0, 1
+
+
+class Settings(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int),
+        ("coarsefreqest_fft_power", C.c_int),
+        ("freq_center", C.c_double),
+        ("lockingbw", C.c_double),
+        ("fb", C.c_double),
+        ("Fs", C.c_double),
+        ("signalthreshold", C.c_double),
+    ]
+
+
+def oqpsk_settings(freq_center=8000.0, lockingbw=10500.0, fb=10500.0, Fs=48000.0, power=14, threshold=0.65):
+    return Settings(KIND_OQPSK, power, freq_center, lockingbw, fb, Fs, threshold)
+
+
+def msk_settings(freq_center=1000.0, lockingbw=1800.0, fb=1200.0, Fs=48000.0, power=13, threshold=0.5):
+    return Settings(KIND_MSK, power, freq_center, lockingbw, fb, Fs, threshold)
+
+
+def build(force: bool = False) -> None:
+    """Compile liboracle.so (and _ref when the reference tree is present)."""
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(
+        os.path.getmtime(os.path.join(HERE, f)) for f in ("jaero_oracle.c", "viterbi_oracle.c", "jaero_oracle.h")
+    ):
+        subprocess.check_call(["make", "-C", HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/JAERO") and os.path.exists("/opt/conda/bin/moc"):
+        if force or not os.path.exists(REF_BIN):
+            subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.jo_demod_create.restype = C.c_void_p
+        L.jo_demod_create.argtypes = [C.POINTER(Settings)]
+        L.jo_demod_destroy.argtypes = [C.c_void_p]
+        L.jo_demod_set_settings.argtypes = [C.c_void_p, C.POINTER(Settings)]
+        L.jo_demod_set_flags.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.jo_demod_set_dcd.argtypes = [C.c_void_p, C.c_int]
+        L.jo_demod_center_freq_changed.argtypes = [C.c_void_p, C.c_double]
+        L.jo_demod_write.restype = C.c_long
+        L.jo_demod_write.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        for name in ("jo_demod_take_soft", "jo_demod_take_status", "jo_demod_take_symbols"):
+            f = getattr(L, name)
+            f.restype = C.c_long
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        L.jo_demod_capture_symbols.argtypes = [C.c_void_p, C.c_int]
+        L.jo_demod_pending_soft.argtypes = [C.c_void_p]
+        for name in ("jo_demod_get_mse", "jo_demod_get_freq_est", "jo_demod_get_freq_center"):
+            f = getattr(L, name)
+            f.restype = C.c_double
+            f.argtypes = [C.c_void_p]
+        L.jo_rrc_design.argtypes = [C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p]
+        L.jo_cis_table.argtypes = [C.c_void_p]
+        L.jo_fft.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.jo_coarse_create.restype = C.c_void_p
+        L.jo_coarse_create.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double]
+        L.jo_coarse_destroy.argtypes = [C.c_void_p]
+        L.jo_coarse_bigchange.argtypes = [C.c_void_p]
+        L.jo_coarse_process.restype = C.c_double
+        L.jo_coarse_process.argtypes = [C.c_void_p, C.c_void_p]
+        L.jo_coarse_get_y.argtypes = [C.c_void_p, C.c_void_p]
+        L.jo_codec_create.restype = C.c_void_p
+        L.jo_codec_create.argtypes = [C.c_int]
+        L.jo_codec_destroy.argtypes = [C.c_void_p]
+        L.jo_codec_reset.argtypes = [C.c_void_p]
+        L.jo_decode_continuous.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.jo_decode_soft.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.jo_encode_bits.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class Demod:
+    """One reference-semantics demodulator object (OqpskDemodulator or MskDemodulator)."""
+
+    def __init__(self, settings: Settings, afc=False, sql=False, cpu_reduce=False, capture_symbols=False):
+        self.L = lib()
+        self.h = self.L.jo_demod_create(C.byref(settings))
+        self.L.jo_demod_set_flags(self.h, int(afc), int(sql), int(cpu_reduce))
+        self.L.jo_demod_set_dcd(self.h, 0)
+        self.L.jo_demod_capture_symbols(self.h, int(capture_symbols))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.jo_demod_destroy(self.h)
+            self.h = None
+
+    def set_settings(self, s: Settings):
+        self.L.jo_demod_set_settings(self.h, C.byref(s))
+
+    def set_flags(self, afc, sql, cpu_reduce):
+        self.L.jo_demod_set_flags(self.h, int(afc), int(sql), int(cpu_reduce))
+
+    def set_dcd(self, dcd):
+        self.L.jo_demod_set_dcd(self.h, int(dcd))
+
+    def center_freq_changed(self, f):
+        self.L.jo_demod_center_freq_changed(self.h, float(f))
+
+    def write(self, pcm: np.ndarray):
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        self.L.jo_demod_write(self.h, pcm.ctypes.data, pcm.shape[0])
+
+    def take_soft(self) -> np.ndarray:
+        out = []
+        buf = np.empty(1 << 16, dtype=np.int16)
+        while True:
+            n = self.L.jo_demod_take_soft(self.h, buf.ctypes.data, buf.shape[0])
+            out.append(buf[:n].copy())
+            if n < buf.shape[0]:
+                break
+        return np.concatenate(out)
+
+    def take_status(self) -> np.ndarray:
+        out = []
+        buf = np.empty((4096, 6), dtype=np.float64)
+        while True:
+            n = self.L.jo_demod_take_status(self.h, buf.ctypes.data, buf.shape[0])
+            out.append(buf[:n].copy())
+            if n < buf.shape[0]:
+                break
+        return np.concatenate(out)
+
+    def take_symbols(self) -> np.ndarray:
+        out = []
+        buf = np.empty((1 << 14, 3), dtype=np.float64)
+        while True:
+            n = self.L.jo_demod_take_symbols(self.h, buf.ctypes.data, buf.shape[0])
+            out.append(buf[:n].copy())
+            if n < buf.shape[0]:
+                break
+        return np.concatenate(out)
+
+    @property
+    def mse(self):
+        return self.L.jo_demod_get_mse(self.h)
+
+    @property
+    def freq_est(self):
+        return self.L.jo_demod_get_freq_est(self.h)
+
+    @property
+    def freq_center(self):
+        return self.L.jo_demod_get_freq_center(self.h)
+
+    @property
+    def pending(self):
+        return self.L.jo_demod_pending_soft(self.h)
+
+
+def run_demod(settings: Settings, pcm: np.ndarray, chunk: int = 4096, afc=False, cpu_reduce=False,
+              dcd_at: int = -1, capture_symbols=False, center_at: int = -1, center_hz: float = 0.0):
+    """Convenience: feed pcm in `chunk`-sample writes, return dict(soft, status[, symbols])."""
+    d = Demod(settings, afc=afc, cpu_reduce=cpu_reduce, capture_symbols=capture_symbols)
+    n = pcm.shape[0]
+    s = 0
+    while s < n:
+        if dcd_at >= 0 and s >= dcd_at:
+            d.set_dcd(1)
+            dcd_at = -1
+        if center_at >= 0 and s >= center_at:
+            d.center_freq_changed(center_hz)
+            center_at = -1
+        m = min(chunk, n - s)
+        d.write(pcm[s:s + m])
+        s += m
+    out = {"soft": d.take_soft(), "status": d.take_status(), "pending": d.pending, "mse": d.mse,
+           "freq_est": d.freq_est, "freq_center": d.freq_center}
+    if capture_symbols:
+        out["symbols"] = d.take_symbols()
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- _ref runner
+def have_ref() -> bool:
+    return os.path.exists(REF_BIN) and os.access(REF_BIN, os.X_OK)
+
+
+def run_ref(kind: str, pcm: np.ndarray, **kv):
+    """Run the unmodified reference demodulator (one process = one channel).  kv -> key=value driver options."""
+    assert have_ref(), "oracle/_ref/jaero_ref not built (needs /root/reference + /opt/conda Qt; see oracle/Makefile)"
+    with tempfile.TemporaryDirectory() as td:
+        inp = os.path.join(td, "in.s16")
+        np.ascontiguousarray(pcm, dtype=np.int16).tofile(inp)
+        outp = os.path.join(td, "out")
+        args = [REF_BIN, kind, inp, outp] + [f"{k}={v}" for k, v in kv.items()]
+        subprocess.check_call(args)
+        soft = np.fromfile(outp + ".soft", dtype=np.int16)
+        status = np.fromfile(outp + ".status", dtype=np.float64).reshape(-1, 6)
+    return {"soft": soft, "status": status}
+
+
+def time_ref(kind: str, pcm_path: str, **kv) -> float:
+    out = subprocess.check_output([REF_BIN, "time", kind, pcm_path] + [f"{k}={v}" for k, v in kv.items()])
+    return float(out.split()[0])
+
+
+def ref_tool(mode: str, data: np.ndarray, out_dtype, **kv) -> np.ndarray:
+    assert have_ref()
+    with tempfile.TemporaryDirectory() as td:
+        inp = os.path.join(td, "in.bin")
+        np.ascontiguousarray(data).tofile(inp)
+        outp = os.path.join(td, "out.bin")
+        subprocess.check_call([REF_BIN, mode, inp, outp] + [f"{k}={v}" for k, v in kv.items()])
+        return np.fromfile(outp, dtype=out_dtype)
+
+
+# ----------------------------------------------------------------------------------------------- Viterbi
+class Codec:
+    """JConvolutionalCodec restatement (K=7 r=1/2 {109,79}, padding 24 as AeroL uses)."""
+
+    def __init__(self, paddinglength=24):
+        self.L = lib()
+        self.h = self.L.jo_codec_create(paddinglength)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.jo_codec_destroy(self.h)
+            self.h = None
+
+    def reset(self):
+        self.L.jo_codec_reset(self.h)
+
+    def decode_continuous(self, soft: np.ndarray) -> np.ndarray:
+        soft = np.ascontiguousarray(soft, dtype=np.uint8)
+        out = np.zeros(soft.shape[0] // 2 + 8, dtype=np.uint8)
+        n = self.L.jo_decode_continuous(self.h, soft.ctypes.data, soft.shape[0], out.ctypes.data)
+        return out[:n]
+
+    def decode_soft(self, soft: np.ndarray) -> np.ndarray:
+        soft = np.ascontiguousarray(soft, dtype=np.uint8)
+        out = np.zeros(soft.shape[0] // 2 + 8, dtype=np.uint8)
+        n = self.L.jo_decode_soft(self.h, soft.ctypes.data, soft.shape[0], out.ctypes.data)
+        return out[:n]
+
+
+def encode_bits(msg_bytes: np.ndarray) -> np.ndarray:
+    """libcorrect-style encode of whole bytes; returns coded bits (0/1), 2*(8*len+8) of them."""
+    msg_bytes = np.ascontiguousarray(msg_bytes, dtype=np.uint8)
+    out = np.zeros(2 * (8 * msg_bytes.shape[0] + 8) + 16, dtype=np.uint8)
+    n = lib().jo_encode_bits(msg_bytes.ctypes.data, msg_bytes.shape[0], out.ctypes.data)
+    return out[:n]
