@@ -1,0 +1,159 @@
+/* jaero_hip.h -- C ABI of libjaero_hip.so: the MI355X (gfx950) batched Aero demodulator.
+ *
+ * This is the drop-in boundary for the reference's demodulator hot path.  One `jaero_ctx` is a BANK of
+ * `nchannels` independent demodulators of the same kind and rate living on one GPU; every entry point below
+ * replaces one member of the reference's per-object QIODevice surface (citations are relative to
+ * /root/reference/).  Plain pointers and sizes only -- no Qt, torch or HIP types in the signatures
+ * (streams are passed as `void*` = hipStream_t, NULL = the default stream).
+ *
+ *   reference (one object per channel)                               this ABI (one call, all channels)
+ *   ---------------------------------------------------------------  -----------------------------------------
+ *   OqpskDemodulator(parent)+setSettings(Settings)+start()           jaero_create
+ *     JAERO/oqpskdemodulator.cpp:8-117,175-289,312-315
+ *   MskDemodulator(parent)+setSettings(Settings)+start()             jaero_create (kind = JAERO_KIND_MSK)
+ *     JAERO/mskdemodulator.cpp:9-84,135-263,296-299
+ *   setSettings on a live object                                     jaero_set_settings
+ *   setAFC / setSQL / setCPUReduce                                   jaero_set_flags
+ *     JAERO/oqpskdemodulator.cpp:149-163, JAERO/mskdemodulator.cpp:105-118
+ *   DCDstatSlot(bool)            JAERO/oqpskdemodulator.cpp:679-684   jaero_set_dcd
+ *   CenterFreqChangedSlot(double) JAERO/oqpskdemodulator.cpp:291-310  jaero_center_freq_changed
+ *   writeData(const char*,qint64) JAERO/oqpskdemodulator.cpp:334-627, jaero_write
+ *                                 JAERO/mskdemodulator.cpp:313-488
+ *   signal processDemodulatedSoftBits(QVector<short>)                jaero_read_softbits / jaero_softbits_view
+ *     JAERO/oqpskdemodulator.h:66, emitted at oqpskdemodulator.cpp:583-591, mskdemodulator.cpp:472-477
+ *   signals Plottables / MSESignal / EbNoMeasurmentSignal / SignalStatus   jaero_read_status (+ status log)
+ *     emitted together at JAERO/oqpskdemodulator.cpp:670-675, JAERO/mskdemodulator.cpp:510-517
+ *   FreqOffsetEstimateSlot + CoarseFreqEstimate::ProcessBasebandData  internal (runs inside jaero_write at the
+ *     JAERO/oqpskdemodulator.cpp:414-428,629-677; coarsefreqestimate.cpp:90-137   same sample the reference does)
+ *   JConvolutionalCodec::Decode_Continuous / Decode_soft              jaero_viterbi_* (batched, stateless blocks)
+ *     JAERO/jconvolutionalcodec.cpp:151-201,90-119
+ *   stop() / destructor                                               jaero_destroy
+ *
+ * Conventions: every function returns 0 on success or a negative JAERO_E* code (the reference has no error
+ * channel; this is additive).  The caller owns every buffer it passes; the library owns all device state.  One host
+ * thread per ctx.  jaero_write is asynchronous on the given stream; the read_* calls synchronise that stream.
+ * There is NO CPU fallback: if no gfx950 device is usable jaero_create fails with JAERO_ENODEV.
+ */
+#ifndef JAERO_HIP_H
+#define JAERO_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JAERO_ABI_VERSION 1
+
+/* demodulator kinds (burst kinds are reserved for the next round: SURVEY.md 8 row a3) */
+#define JAERO_KIND_MSK 0
+#define JAERO_KIND_OQPSK 1
+
+/* error codes */
+#define JAERO_OK 0
+#define JAERO_EINVAL (-1)   /* bad argument / unsupported settings combination        */
+#define JAERO_ENODEV (-2)   /* no usable HIP device                                    */
+#define JAERO_ENOMEM (-3)   /* device or host allocation failed                        */
+#define JAERO_EHIP (-4)     /* a HIP runtime call failed (see jaero_last_error)        */
+#define JAERO_EOVERFLOW (-5)/* soft-bit / log capacity exceeded since the last read    */
+#define JAERO_ENOTSUP (-6)  /* kind / rate not implemented                             */
+
+/* jaero_create flags */
+#define JAERO_FLAG_EBNO 1u            /* run the EbNo meters (OQPSKEbNoMeasure/MSKEbNoMeasure, diagnostic only)   */
+#define JAERO_FLAG_STATUS_LOG 2u      /* keep one status row per FreqOffsetEstimateSlot call (tests)              */
+#define JAERO_FLAG_CAPTURE_SYMBOLS 4u /* keep the soft symbol (pt_qpsk / pt_msk) + mse of every symbol (tests)     */
+
+/* PCM layouts accepted by jaero_write */
+#define JAERO_PCM_CHANNEL_MAJOR 0 /* pcm[ch * nsamples + i]  : one contiguous mono stream per channel            */
+#define JAERO_PCM_FRAME_MAJOR 1   /* pcm[i * nchannels + ch] : interleaved frames, like multichannel PCM audio   */
+
+/* Mirrors OqpskDemodulator::Settings / MskDemodulator::Settings
+ * (JAERO/oqpskdemodulator.h:20-39, JAERO/mskdemodulator.h:24-45). */
+typedef struct jaero_settings
+{
+    int kind;                    /* JAERO_KIND_*                                   */
+    int coarsefreqest_fft_power; /* 2^power point coarse-frequency FFT (13 or 14)  */
+    double freq_center;          /* Hz                                             */
+    double lockingbw;            /* Hz                                             */
+    double fb;                   /* bit rate: 10500 (OQPSK), 600 / 1200 (MSK)      */
+    double Fs;                   /* sample rate, 48000                             */
+    double signalthreshold;      /* mse threshold                                  */
+} jaero_settings;
+
+/* What the reference emits from FreqOffsetEstimateSlot, per channel. */
+typedef struct jaero_status
+{
+    double mse;         /* MSESignal                               */
+    double ebno;        /* EbNoMeasurmentSignal (0 unless JAERO_FLAG_EBNO) */
+    double freq_est;    /* Plottables arg 1 = mixer2.GetFreqHz()   */
+    double freq_center; /* Plottables arg 2 = mixer_center.GetFreqHz() */
+    int signal;         /* SignalStatus                            */
+    int n_estimates;    /* number of FreqOffsetEstimateSlot calls so far */
+} jaero_status;
+
+typedef struct jaero_ctx jaero_ctx;
+
+/* Create a bank of nchannels demodulators on HIP device `device`.  All channels must agree on kind, fb, Fs and
+ * coarsefreqest_fft_power (they share kernels and ring geometry); freq_center, lockingbw and signalthreshold are
+ * per channel.  If `per_channel_stride` is 0, settings[0] is used for every channel.
+ * max_write_samples bounds nsamples of one jaero_write (sizes staging buffers); softbit_capacity is the number of
+ * soft bits each channel can hold between reads (0 = default: enough for 2*max_write_samples). */
+int jaero_create(int device, int nchannels, const jaero_settings *settings, int per_channel_stride,
+                 unsigned flags, int max_write_samples, int softbit_capacity, jaero_ctx **out);
+void jaero_destroy(jaero_ctx *ctx);
+
+/* channel = -1 applies to every channel */
+int jaero_set_settings(jaero_ctx *ctx, int channel, const jaero_settings *s);
+int jaero_set_flags(jaero_ctx *ctx, int channel, int afc, int sql, int cpu_reduce);
+int jaero_set_dcd(jaero_ctx *ctx, int channel, int dcd);
+int jaero_center_freq_changed(jaero_ctx *ctx, int channel, double freq_center_hz);
+
+/* = writeData for every channel: nsamples of real int16 PCM per channel.  `pcm` is a host pointer
+ * (is_device_ptr = 0; copied with hipMemcpyAsync) or a device pointer on the ctx's device (is_device_ptr = 1). */
+int jaero_write(jaero_ctx *ctx, const int16_t *pcm, int nsamples, int layout, int is_device_ptr, void *stream);
+
+/* Drain the soft bits channel `channel` produced (values 0..255 as the reference's QVector<short>), oldest first.
+ * *n receives the count copied (<= cap).  Grouping into 32 (OQPSK) / 12 (MSK) emissions is the caller's. */
+int jaero_read_softbits(jaero_ctx *ctx, int channel, int16_t *dst, int cap, int *n);
+/* Batched drain: dst[ch * cap_per_channel + k], counts[ch].  Resets every channel's buffer. */
+int jaero_read_softbits_all(jaero_ctx *ctx, int16_t *dst, int cap_per_channel, int *counts);
+/* Device-side view for zero-copy consumers (RCCL gather, a downstream device decoder): int16 [nch][capacity]
+ * and int32 counts[nch] on the ctx's device.  jaero_discard_softbits resets the counts on `stream`. */
+int jaero_softbits_view(jaero_ctx *ctx, void **dev_softbits, void **dev_counts, int *capacity);
+int jaero_discard_softbits(jaero_ctx *ctx, void *stream);
+
+int jaero_read_status(jaero_ctx *ctx, int channel, jaero_status *st);
+/* status log rows of 6 doubles [n, freq_est, freq_center, mse, ebno, signal] (JAERO_FLAG_STATUS_LOG) */
+int jaero_read_status_log(jaero_ctx *ctx, int channel, double *rows, int caprows, int *nrows);
+/* soft symbols rows of 3 doubles [re, im, mse] (JAERO_FLAG_CAPTURE_SYMBOLS) */
+int jaero_read_symbols(jaero_ctx *ctx, int channel, double *rows, int caprows, int *nrows);
+
+/* Batched K=7 r=1/2 {109,79} soft Viterbi (libcorrect semantics as used by JConvolutionalCodec).
+ * jaero_viterbi_decode_soft: nblocks independent blocks of nsoft soft bytes each (0..255, 128 = erasure);
+ *   = correct_convolutional_decode_soft per block; bits_out[b * (nsoft/2) + k] one byte per decoded bit
+ *   (the first nsoft/2 - 6 are decoded data, the rest 0).
+ * jaero_viterbi_continuous: = JConvolutionalCodec::Decode_Continuous for nstreams independent streams, one
+ *   block of nsoft soft bytes each per call; the 62-byte overlap of each stream is kept in the ctx-less state
+ *   buffer `overlap` (nstreams*64 bytes, zero it for a fresh stream, first byte pair = length).
+ * Both take host pointers (is_device_ptr=0) or device pointers (1). */
+int jaero_viterbi_decode_soft(int device, const uint8_t *soft, int nblocks, int nsoft, uint8_t *bits_out,
+                              int is_device_ptr, void *stream);
+int jaero_viterbi_continuous(int device, const uint8_t *soft, int nstreams, int nsoft, int paddinglength,
+                             uint8_t *overlap_state, uint8_t *bits_out, int *nbits_out, int is_device_ptr, void *stream);
+
+/* introspection */
+int jaero_abi_version(void);
+int jaero_num_channels(const jaero_ctx *ctx);
+const char *jaero_strerror(int code);
+const char *jaero_last_error(void);
+/* Time (ms) the GPU spent in each kernel class over the jaero_write calls since the last reset, measured with HIP
+ * events on the launch stream; enabled by jaero_profile_enable(ctx,1).  which: 0 = sample-loop kernel,
+ * 1 = coarse-frequency kernel, 2 = PCM transpose.  *launches receives the launch count. */
+int jaero_profile_enable(jaero_ctx *ctx, int on);
+int jaero_profile_read(jaero_ctx *ctx, int which, double *total_ms, int *launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JAERO_HIP_H */

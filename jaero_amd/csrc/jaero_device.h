@@ -1,0 +1,161 @@
+// jaero_device.h -- shared device-side definitions for libjaero_hip.so (gfx950 only).
+//
+// Data layout in HBM (one jaero_ctx = one bank of channels on one GPU; nchp = nch rounded up to 64):
+//   * channel c lives in wave-group g = c/64, lane l = c%64; one wavefront demodulates 64 channels, one channel per
+//     lane, because every stage after the matched filter is a per-sample scalar recurrence (AGC -> timing PLL ->
+//     carrier loop) that cannot be spread over lanes.
+//   * scalar state: SoA  S[field][nchp] (double), I[field][nchp] (int): a wave's load of one field is one 512 B row.
+//   * sample-rate rings (AGC, EbNo, MSK delay lines): [group][slot][lane]   -> coalesced 512 B rows, slot advances
+//     once per sample for all lanes.
+//   * symbol-rate rings (marg, dt, pointmean, msema): [channel][slot]       -> per-lane positions (symbol instants
+//     are not aligned between channels).
+//   * coarse-frequency ring: [channel][nfft] packed {int16 pcm, uint16 NCO table index}; the coarse kernel rebuilds
+//     the reference's complex double bbcycbuff entry exactly as CIS[index] * (pcm/32768.0).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define JD_WTSIZE 19999
+#define JD_WAVE 64
+
+// ---- double state fields (S) ----
+enum
+{
+    S_M2_PTR, S_M2_STEP, S_M2_FREQ,
+    S_MC_PTR, S_MC_STEP, S_MC_FREQ,
+    S_ST_PTR, S_ST_STEP, S_ST_FREQ, S_ST_LAST,
+    S_AGC_SUM,
+    S_EB_ESUM, S_EB_E2SUM, S_EB_EBNO,
+    S_D1,                       // delays: abval^2 of previous sample
+    S_D41_1, S_D41_2, S_D41_3,  // delayt41 history of st_diff   (x[n-1..n-3])
+    S_D42_1, S_D42_2, S_D42_3,  // delayt42 history of st_d1out
+    S_D8_1, S_D8_2,             // delayt8 history of st_eta (OQPSK)
+    S_RES_X1, S_RES_X2, S_RES_Y1, S_RES_Y2,
+    S_LF_X1, S_LF_X2, S_LF_Y1, S_LF_Y2,
+    S_SIG2L_RE, S_SIG2L_IM, S_PTD_RE, S_PTD_IM,
+    S_MARG_SUM, S_PM_SUM, S_MSEMA_SUM, S_MSE,
+    S_DIFF_LAST,
+    S_LOCKINGBW, S_THRESH,
+    S_NFIELDS
+};
+// ---- int state fields (I) ----
+enum
+{
+    I_AGC_POS, I_EB_POS, I_BB_PTR, I_COARSE_CNT,
+    I_MARG_POS, I_DT_POS, I_PM_POS, I_MSEMA_POS,
+    I_YUI, I_SIG2L_INIT, I_FLAGS, I_COUNTDOWN, I_COUNTDOWN2, I_EMPTYING, I_NEST,
+    I_SOFT_CNT, I_SYM_CNT, I_LOG_CNT, I_OVERFLOW,
+    I_DLY_POS,   // MSK: shared slot of delayedsmpl / delayt8 rings
+    I_NFIELDS
+};
+#define JF_AFC 1
+#define JF_SQL 2
+#define JF_CPUREDUCE 4
+#define JF_DCD 8
+
+struct JGeom
+{
+    int kind, nch, nchp, ngroups;
+    double Fs, fb;
+    int Fs_int;
+    int fir_n;      // 55 (OQPSK) / 2*SPS (MSK)
+    int agc_len;    // round(4*Fs) OQPSK, round(Fs) MSK
+    int ebno_len;   // 2*Fs
+    int nfft, nfft_log2;
+    int marg_len, dt_len, pm_len, msema_len; // dt_len = length+1 (ring size)
+    double ee;
+    double w4, w8;  // OQPSK fractional-delay weights (Delay<double>::update weighting)
+    int sps, sps2;  // MSK: SamplesPerSymbol, SamplesPerSymbol/2
+    double res_b0, res_b1, res_b2, res_a1, res_a2;
+    double lf_b0, lf_b1, lf_b2, lf_a1, lf_a2;
+    double stref_freq;
+    double correctionfactor;
+    unsigned flags;
+    int soft_cap, sym_cap, log_cap;
+};
+
+struct JPtrs
+{
+    double *S;
+    int *I;
+    double *agc_ring;    // [ng][agc_len][64]
+    double *eb_e, *eb_e2;// [ng][ebno_len][64]
+    uint32_t *bbring;    // [nchp][nfft]
+    double *y;           // [nchp][nfft]
+    double *marg;        // [nchp][marg_len]
+    double2 *dt;         // [nchp][dt_len]
+    double *pm;          // [nchp][pm_len]
+    double *msema;       // [nchp][msema_len]
+    double *firsave;     // [ng][2][fir_n][64]
+    double2 *dly;        // MSK delayedsmpl ring [ng][sps+1][64]
+    double *dly8;        // MSK delayt8 ring     [ng][sps2+1][64]
+    int16_t *soft;       // [nchp][soft_cap]
+    double *sym;         // [nchp][sym_cap][3]
+    double *slog;        // [nchp][log_cap][6]
+    const double2 *cis;  // [19999]
+    const double *taps2; // [2*fir_n] taps repeated twice
+};
+
+__device__ __forceinline__ int jd_cisidx(double wtptr)
+{
+    int t = (int)wtptr;
+    if (t >= JD_WTSIZE) t = 0;
+    if (t < 0) t = JD_WTSIZE - 1;
+    return t;
+}
+// WaveTable::WTnextFrame (JAERO/DSP.cpp:70-77) without last_WTptr bookkeeping
+__device__ __forceinline__ void jd_wt_next(double &ptr, double &step)
+{
+    if (step < 0) step = 0;
+    ptr += step;
+    while (((int)ptr) >= JD_WTSIZE) ptr -= JD_WTSIZE;
+}
+// WaveTable::SetFreq(double) (JAERO/DSP.cpp:151-156)
+__device__ __forceinline__ void jd_wt_setfreq(double &freq, double &step, double f, double samplerate)
+{
+    freq = f;
+    if (freq < 0) freq = 0;
+    step = (freq) * ((double)JD_WTSIZE) / samplerate;
+}
+// WaveTable::IncresePhaseDeg -> SetPhaseDeg (JAERO/DSP.cpp:169-180)
+__device__ __forceinline__ void jd_wt_inc_phase_deg(double &ptr, double phase_deg)
+{
+    phase_deg += (360.0 * ptr / ((double)JD_WTSIZE));
+    phase_deg = fmod(phase_deg, 360.0);
+    while (phase_deg < 0) phase_deg += 360.0;
+    ptr = (phase_deg / 360.0) * ((double)JD_WTSIZE);
+}
+// WaveTable::AdvanceFractionOfWave (JAERO/DSP.h:56)
+__device__ __forceinline__ void jd_wt_advance_fraction(double &ptr, double f)
+{
+    ptr += f * JD_WTSIZE;
+    while (ptr >= JD_WTSIZE) ptr -= JD_WTSIZE;
+    while (ptr < 0) ptr += JD_WTSIZE;
+}
+// WaveTable::IfHavePassedPoint (JAERO/DSP.cpp:222-238); frac receives FractionOfSampleItPassesBy
+__device__ __forceinline__ bool jd_wt_passed(double last_ptr, double ptr, double step, double fraction_of_wave, double &frac)
+{
+    double pt = (fraction_of_wave * JD_WTSIZE);
+    double tl = last_ptr - pt;
+    double tp = ptr - pt;
+    if (tl < 0.0) tl += JD_WTSIZE;
+    if (tp < 0.0) tp += JD_WTSIZE;
+    if ((tl > (3.0 * JD_WTSIZE / 4.0)) && (tp < (1.0 * JD_WTSIZE / 4.0)))
+    {
+        frac = tp / step;
+        return true;
+    }
+    return false;
+}
+// Qt 5.9 qRound (qglobal.h:525-526)
+__device__ __forceinline__ int jd_qround(double d)
+{
+    return d >= 0.0 ? (int)(d + 0.5) : (int)(d - (double)((int)(d - 1)) + 0.5) + (int)(d - 1);
+}
+__device__ __forceinline__ int jd_softbit(double v)
+{
+    int ibit = jd_qround(v);
+    if (ibit > 255) ibit = 255;
+    if (ibit < 0) ibit = 0;
+    return ibit;
+}

@@ -1,0 +1,978 @@
+// jaero_hip.hip -- libjaero_hip.so: C ABI (include/jaero_hip.h) + host-side bank scheduler for the gfx950 kernels.
+//
+// Host responsibilities (everything numerical happens in the kernels):
+//   * own the per-bank device state (layout: jaero_device.h),
+//   * split each jaero_write at the samples where the reference runs its coarse-frequency estimate synchronously
+//     inside writeData (bbcycbuff_ptr % (bbnfft/4) == 0, JAERO/oqpskdemodulator.cpp:416) -- a host mirror of the two
+//     integer counters involved (bbcycbuff_ptr, coarseCounter) predicts those samples exactly, so no device->host
+//     round trip is needed in steady state,
+//   * launch [sample kernel] [coarse kernel] [sample kernel] ... on the caller's stream.
+// No CPU fallback exists: without a HIP device jaero_create fails.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/jaero_hip.h"
+#include "jaero_device.h"
+#include "k_oqpsk.h"
+#include "k_msk.h"
+#include "k_coarse.h"
+#include "k_viterbi.h"
+
+static thread_local std::string g_last_error;
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+#define HIPCHK(x)                                                                                        \
+    do {                                                                                                 \
+        hipError_t _e = (x);                                                                             \
+        if (_e != hipSuccess) return fail(JAERO_EHIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct ProfSlot { double ms = 0; int launches = 0; };
+
+struct jaero_ctx
+{
+    int device = 0;
+    JGeom g{};
+    JPtrs p{};
+    unsigned flags = 0;
+    int max_write = 0;
+    std::vector<void *> allocs;
+    // device helpers
+    int16_t *d_pcm_frames = nullptr; // [max_write][nchp] staging for channel-major / host input
+    int16_t *d_pcm_raw = nullptr;    // [nch*max_write] staging for host input
+    double2 *d_scratch = nullptr;
+    double2 *d_tw = nullptr;
+    int *d_chanlist = nullptr;
+    int coarse_grid = 0;
+    jaero_status *d_status = nullptr;
+    int16_t *d_pack = nullptr; size_t pack_elems = 0;
+    // host mirrors
+    std::vector<jaero_settings> settings;
+    std::vector<int> h_flags, h_bbptr, h_cnt;
+    long long nB_total = 0; // B-parts executed so far (uniform ring slots derive from it)
+    int pending = 0;        // A-part of the next sample already done
+    std::vector<int> h_list;
+    // profiling
+    bool prof = false;
+    ProfSlot slots[3];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    struct EvUse { int which; int idx; };
+    std::vector<EvUse> ev_used;
+    size_t ev_next = 0;
+    hipStream_t last_stream = nullptr;
+};
+
+// ------------------------------------------------------------------------------------------ small kernels
+__global__ void k_transpose_pcm(const int16_t *__restrict__ src /*[nch][n]*/, int16_t *__restrict__ dst /*[n][nchp]*/, int nch,
+                                int nchp, int n)
+{
+    __shared__ int16_t tile[64][65];
+    const int c0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6; // 256 threads: 4 rows per pass
+    for (int r = ty; r < 64; r += 4)
+    {
+        const int c = c0 + r, i = i0 + tx;
+        tile[r][tx] = (c < nch && i < n) ? src[(size_t)c * n + i] : (int16_t)0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4)
+    {
+        const int i = i0 + r, c = c0 + tx;
+        if (i < n && c < nchp) dst[(size_t)i * nchp + c] = tile[tx][r];
+    }
+}
+
+__global__ void k_center_freq(const JGeom g, const JPtrs p, int ch_first, int nch_apply, double freq_center_in)
+{
+    // CenterFreqChangedSlot (oqpskdemodulator.cpp:291-310, mskdemodulator.cpp:265-282); one block per channel
+    const int ch = ch_first + blockIdx.x;
+    if (blockIdx.x >= nch_apply) return;
+    const int nchp = g.nchp;
+    if (threadIdx.x == 0)
+    {
+        double fc = freq_center_in;
+        const double fb = g.fb, Fs = g.Fs;
+        if (g.kind == 1)
+        {
+            if (fc < (0.5 * fb)) fc = 0.5 * fb;
+            if (fc > (Fs / 2.0 - 0.5 * fb)) fc = Fs / 2.0 - 0.5 * fb;
+        }
+        else
+        {
+            if (fc < (0.75 * fb)) fc = 0.75 * fb;
+            if (fc > (Fs / 2.0 - 0.75 * fb)) fc = Fs / 2.0 - 0.75 * fb;
+        }
+        double *S = p.S + ch;
+        const int flags = p.I[(size_t)I_FLAGS * nchp + ch];
+        const double lbw = S[(size_t)S_LOCKINGBW * nchp];
+        // mixer_center.SetFreq(freq_center,Fs)  (DSP.cpp:142-149)
+        double mc_freq = fc;
+        if (mc_freq < 0) mc_freq = 0;
+        double mc_step = (mc_freq) * ((double)JD_WTSIZE) / ((float)Fs);
+        double mc_ptr = S[(size_t)S_MC_PTR * nchp];
+        while (((int)mc_ptr) >= JD_WTSIZE) mc_ptr -= JD_WTSIZE;
+        double m2_freq = S[(size_t)S_M2_FREQ * nchp], m2_step = S[(size_t)S_M2_STEP * nchp];
+        if (flags & JF_AFC) jd_wt_setfreq(m2_freq, m2_step, mc_freq, Fs);
+        if ((m2_freq - mc_freq) > (lbw / 2.0)) jd_wt_setfreq(m2_freq, m2_step, mc_freq + (lbw / 2.0), Fs);
+        if ((m2_freq - mc_freq) < (-lbw / 2.0)) jd_wt_setfreq(m2_freq, m2_step, mc_freq - (lbw / 2.0), Fs);
+        S[(size_t)S_MC_FREQ * nchp] = mc_freq; S[(size_t)S_MC_STEP * nchp] = mc_step; S[(size_t)S_MC_PTR * nchp] = mc_ptr;
+        S[(size_t)S_M2_FREQ * nchp] = m2_freq; S[(size_t)S_M2_STEP * nchp] = m2_step;
+    }
+    uint32_t *ring = p.bbring + (size_t)ch * g.nfft;
+    for (int i = threadIdx.x; i < g.nfft; i += blockDim.x) ring[i] = 0; // bbcycbuff[j]=0
+}
+
+__global__ void k_status(const JGeom g, const JPtrs p, int ch_first, int n, jaero_status *out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int ch = ch_first + k, nchp = g.nchp;
+    jaero_status st;
+    st.mse = p.S[(size_t)S_MSE * nchp + ch];
+    st.ebno = p.S[(size_t)S_EB_EBNO * nchp + ch];
+    st.freq_est = p.S[(size_t)S_M2_FREQ * nchp + ch];
+    st.freq_center = p.S[(size_t)S_MC_FREQ * nchp + ch];
+    st.signal = (st.mse > p.S[(size_t)S_THRESH * nchp + ch]) ? 0 : 1;
+    st.n_estimates = p.I[(size_t)I_NEST * nchp + ch];
+    out[k] = st;
+}
+
+__global__ void k_pack_soft(const JGeom g, const JPtrs p, int16_t *dst, int capc)
+{
+    const int ch = blockIdx.x;
+    const int cnt = min(p.I[(size_t)I_SOFT_CNT * g.nchp + ch], capc);
+    const int16_t *src = p.soft + (size_t)ch * g.soft_cap;
+    for (int k = threadIdx.x; k < cnt; k += blockDim.x) dst[(size_t)ch * capc + k] = src[k];
+}
+
+__global__ void k_fill_int(int *p, int n, int v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------ helpers
+template <class T>
+static int dalloc(jaero_ctx *c, T **ptr, size_t count, bool zero = true)
+{
+    void *q = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(JAERO_ENOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    if (zero) { e = hipMemset(q, 0, bytes); if (e != hipSuccess) return fail(JAERO_EHIP, "hipMemset failed: %s", hipGetErrorString(e)); }
+    c->allocs.push_back(q);
+    *ptr = (T *)q;
+    return 0;
+}
+
+// RootRaisedCosine::design (JAERO/DSP.h:316-338)
+static std::vector<double> rrc_design(double alpha, int firsize, double samplerate, double symbol_freq)
+{
+    if ((firsize % 2) == 0) firsize += 1;
+    std::vector<double> P(firsize);
+    double T = (samplerate) / (symbol_freq);
+    for (int i = 0; i < firsize; i++)
+    {
+        if (i == ((firsize - 1) / 2)) P[i] = (4.0 * alpha + M_PI - M_PI * alpha) / (M_PI * sqrt(T));
+        else
+        {
+            double fi = (((double)i) - ((double)(firsize - 1)) / 2.0);
+            if (fabs(1.0 - pow(4.0 * alpha * fi / T, 2)) < 0.0000000001)
+                P[i] = (alpha * ((M_PI - 2.0) * cos(M_PI / (4.0 * alpha)) + (M_PI + 2.0) * sin(M_PI / (4.0 * alpha))) / (M_PI * sqrt(2.0 * T)));
+            else
+                P[i] = (4.0 * alpha / (M_PI * sqrt(T)) * (cos((1.0 + alpha) * M_PI * fi / T) + T / (4.0 * alpha * fi) * sin((1.0 - alpha) * M_PI * fi / T)) / (1.0 - pow(4.0 * alpha * fi / T, 2)));
+        }
+    }
+    return P;
+}
+
+// weighting used by Delay<double>::update (JAERO/DSP.h:357-374) for ring position 0
+static double delay_weight(double fractdelay)
+{
+    int size = (int)ceil(fractdelay) + 1;
+    double dptr = 0.0 - fractdelay;
+    while (floor(dptr) < 0) dptr += (double)size;
+    int iptr = (int)floor(dptr);
+    return dptr - (double)iptr;
+}
+
+static int validate_settings(const jaero_settings &s)
+{
+    if (s.kind != JAERO_KIND_MSK && s.kind != JAERO_KIND_OQPSK) return fail(JAERO_ENOTSUP, "kind %d not implemented (burst kinds: next round)", s.kind);
+    if (s.Fs != 48000) return fail(JAERO_ENOTSUP, "only Fs=48000 is implemented (got %g)", s.Fs);
+    if (s.kind == JAERO_KIND_OQPSK && s.fb != 10500) return fail(JAERO_ENOTSUP, "OQPSK: only fb=10500 is implemented (8400 C-channel: SURVEY 8f4)");
+    if (s.kind == JAERO_KIND_MSK && s.fb != 600 && s.fb != 1200) return fail(JAERO_ENOTSUP, "MSK: fb must be 600 or 1200");
+    if (s.coarsefreqest_fft_power != 13 && s.coarsefreqest_fft_power != 14) return fail(JAERO_ENOTSUP, "coarsefreqest_fft_power must be 13 or 14");
+    if (!(s.lockingbw > 0) || !(s.freq_center >= 0)) return fail(JAERO_EINVAL, "bad lockingbw/freq_center");
+    return 0;
+}
+
+// per-channel scalar initial state = constructor + setSettings of the reference
+static void init_channel_scalars(const jaero_ctx *c, const jaero_settings &s, std::vector<double> &S, std::vector<int> &I, int ch, bool fresh)
+{
+    const int nchp = c->g.nchp;
+    auto SS = [&](int f) -> double & { return S[(size_t)f * nchp + ch]; };
+    auto II = [&](int f) -> int & { return I[(size_t)f * nchp + ch]; };
+    double fc = s.freq_center;
+    if (fc > ((s.Fs / 2.0) - (s.lockingbw / 2.0))) fc = ((s.Fs / 2.0) - (s.lockingbw / 2.0));
+    const double step_fc = (fc < 0 ? 0 : fc) * ((double)JD_WTSIZE) / ((float)(double)(int)s.Fs);
+    SS(S_M2_FREQ) = fc < 0 ? 0 : fc; SS(S_M2_STEP) = step_fc;
+    SS(S_MC_FREQ) = fc < 0 ? 0 : fc; SS(S_MC_STEP) = step_fc;
+    const double stf = (s.kind == JAERO_KIND_OQPSK) ? s.fb : s.fb / 2;
+    SS(S_ST_FREQ) = stf; SS(S_ST_STEP) = stf * ((double)JD_WTSIZE) / ((float)(double)(int)s.Fs);
+    SS(S_LOCKINGBW) = s.lockingbw; SS(S_THRESH) = s.signalthreshold;
+    if (fresh)
+    {
+        SS(S_M2_PTR) = 0; SS(S_MC_PTR) = 0; SS(S_ST_PTR) = 0; SS(S_ST_LAST) = 0;
+        SS(S_MSE) = (s.kind == JAERO_KIND_OQPSK) ? 100.0 : 10.0;
+        SS(S_DIFF_LAST) = -1.0;
+        II(I_COUNTDOWN) = 4; II(I_COUNTDOWN2) = 5; II(I_EMPTYING) = 1;
+    }
+    if (s.kind == JAERO_KIND_MSK) SS(S_MSE) = 10.0; // setSettings resets mse (mskdemodulator.cpp:180)
+}
+
+static void fill_geometry(JGeom &g, const jaero_settings &s, int nch, unsigned flags)
+{
+    memset(&g, 0, sizeof g);
+    g.kind = s.kind; g.nch = nch; g.nchp = (nch + 63) / 64 * 64; g.ngroups = g.nchp / 64;
+    g.Fs = s.Fs; g.fb = s.fb; g.Fs_int = (int)s.Fs;
+    g.nfft_log2 = s.coarsefreqest_fft_power; g.nfft = 1 << g.nfft_log2;
+    g.ebno_len = (int)(2 * s.Fs);
+    g.flags = flags;
+    if (s.kind == JAERO_KIND_OQPSK)
+    {
+        g.fir_n = 55;
+        g.agc_len = (int)round(4 * s.Fs);
+        g.marg_len = 800; g.dt_len = 401; g.pm_len = 400; g.msema_len = 400;
+        g.ee = 0.4;
+        double T = s.Fs / (s.fb / 2);
+        g.w4 = delay_weight(T / 4.0); g.w8 = delay_weight(T / 8.0);
+        g.res_b0 = 0.00032714218939589035; g.res_b1 = 0; g.res_b2 = 0.00032714218939589035;
+        g.res_a1 = -0.39005299948210803; g.res_a2 = 0.99934571562120822;
+        g.lf_b0 = 0.0010275610653672064; g.lf_b1 = 0.0020551221307344128; g.lf_b2 = 0.0010275610653672064;
+        g.lf_a1 = -1.9207386815577139; g.lf_a2 = 0.92509247310306331;
+        g.stref_freq = s.fb;
+        g.sps = 1; g.sps2 = 1;
+    }
+    else
+    {
+        g.sps = (int)(s.Fs / s.fb); g.sps2 = g.sps / 2;
+        g.fir_n = 2 * g.sps;
+        g.agc_len = (int)round(1 * s.Fs);
+        g.marg_len = g.sps; g.dt_len = g.sps / 2 + 1; g.pm_len = 1; g.msema_len = 600;
+        if (s.fb >= 1200)
+        {
+            g.correctionfactor = 0.6;
+            g.res_a1 = -1.993312819378528; g.res_a2 = 0.999476538254407;
+            g.res_b0 = 2.617308727964618e-04; g.res_b1 = 0; g.res_b2 = -2.617308727964618e-04;
+            g.ee = 0.025;
+        }
+        else
+        {
+            g.correctionfactor = 1.0;
+            g.res_a1 = -1.998196509168551; g.res_a2 = 0.999738234875681;
+            g.res_b0 = 1.308825621597620e-04; g.res_b1 = 0; g.res_b2 = -1.308825621597620e-04;
+            g.ee = 0.025;
+        }
+        g.stref_freq = s.fb / 2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ create / destroy
+extern "C" int jaero_abi_version(void) { return JAERO_ABI_VERSION; }
+extern "C" const char *jaero_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char *jaero_strerror(int code)
+{
+    switch (code)
+    {
+    case JAERO_OK: return "ok";
+    case JAERO_EINVAL: return "invalid argument";
+    case JAERO_ENODEV: return "no usable HIP device";
+    case JAERO_ENOMEM: return "out of memory";
+    case JAERO_EHIP: return "HIP runtime error";
+    case JAERO_EOVERFLOW: return "output capacity exceeded";
+    case JAERO_ENOTSUP: return "not supported";
+    default: return "unknown error";
+    }
+}
+extern "C" int jaero_num_channels(const jaero_ctx *ctx) { return ctx ? ctx->g.nch : 0; }
+
+extern "C" void jaero_destroy(jaero_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (void *q : c->allocs) hipFree(q);
+    for (auto &e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    delete c;
+}
+
+extern "C" int jaero_create(int device, int nchannels, const jaero_settings *settings, int per_channel_stride, unsigned flags,
+                            int max_write_samples, int softbit_capacity, jaero_ctx **out)
+{
+    if (!out || !settings || nchannels <= 0 || max_write_samples <= 0) return fail(JAERO_EINVAL, "jaero_create: bad arguments");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(JAERO_ENODEV, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(JAERO_ENODEV, "device %d out of range (%d devices)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(JAERO_ENODEV, "device %d is %s; libjaero_hip is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+
+    auto sat = [&](int ch) -> const jaero_settings & {
+        return per_channel_stride ? *(const jaero_settings *)((const char *)settings + (size_t)ch * per_channel_stride) : settings[0];
+    };
+    const jaero_settings &s0 = sat(0);
+    int rc = validate_settings(s0);
+    if (rc) return rc;
+    for (int ch = 1; ch < nchannels; ch++)
+    {
+        const jaero_settings &s = sat(ch);
+        if (s.kind != s0.kind || s.fb != s0.fb || s.Fs != s0.Fs || s.coarsefreqest_fft_power != s0.coarsefreqest_fft_power)
+            return fail(JAERO_EINVAL, "channel %d: kind/fb/Fs/fft_power must match channel 0 within one bank", ch);
+        if ((rc = validate_settings(s))) return rc;
+    }
+
+    jaero_ctx *c = new jaero_ctx();
+    c->device = device;
+    c->flags = flags;
+    c->max_write = max_write_samples;
+    fill_geometry(c->g, s0, nchannels, flags);
+    JGeom &g = c->g;
+    if (softbit_capacity <= 0)
+        softbit_capacity = (int)ceil(2.0 * max_write_samples * g.fb / g.Fs) + 64;
+    g.soft_cap = (softbit_capacity + 1) & ~1;
+    g.sym_cap = (flags & JAERO_FLAG_CAPTURE_SYMBOLS) ? g.soft_cap / 2 + 8 : 0;
+    g.log_cap = (flags & JAERO_FLAG_STATUS_LOG) ? (int)ceil(g.soft_cap * g.Fs / g.fb / (g.nfft / 4)) + 16 : 0;
+    const int nchp = g.nchp, ng = g.ngroups;
+
+#define DA(ptr, count)                                              \
+    do { if ((rc = dalloc(c, &(ptr), (size_t)(count)))) { jaero_destroy(c); return rc; } } while (0)
+    DA(c->p.S, (size_t)S_NFIELDS * nchp);
+    DA(c->p.I, (size_t)I_NFIELDS * nchp);
+    DA(c->p.agc_ring, (size_t)ng * g.agc_len * 64);
+    if (flags & JAERO_FLAG_EBNO) { DA(c->p.eb_e, (size_t)ng * g.ebno_len * 64); DA(c->p.eb_e2, (size_t)ng * g.ebno_len * 64); }
+    DA(c->p.bbring, (size_t)nchp * g.nfft);
+    DA(c->p.y, (size_t)nchp * g.nfft);
+    DA(c->p.marg, (size_t)nchp * g.marg_len);
+    DA(c->p.dt, (size_t)nchp * g.dt_len);
+    DA(c->p.pm, (size_t)nchp * g.pm_len);
+    DA(c->p.msema, (size_t)nchp * g.msema_len);
+    DA(c->p.firsave, (size_t)ng * 2 * g.fir_n * 64);
+    if (g.kind == JAERO_KIND_MSK) { DA(c->p.dly, (size_t)ng * (g.sps + 1) * 64); DA(c->p.dly8, (size_t)ng * (g.sps2 + 1) * 64); }
+    DA(c->p.soft, (size_t)nchp * g.soft_cap);
+    if (g.sym_cap) DA(c->p.sym, (size_t)nchp * g.sym_cap * 3);
+    if (g.log_cap) DA(c->p.slog, (size_t)nchp * g.log_cap * 6);
+    DA(c->d_pcm_frames, (size_t)max_write_samples * nchp);
+    DA(c->d_pcm_raw, (size_t)max_write_samples * nchannels);
+    DA(c->d_chanlist, nchp);
+    DA(c->d_status, nchp);
+    c->coarse_grid = nchannels < 512 ? nchannels : 512;
+    DA(c->d_scratch, (size_t)c->coarse_grid * 2 * g.nfft);
+    DA(c->d_tw, g.nfft);
+    double2 *d_cis = nullptr;
+    double *d_taps = nullptr;
+    DA(d_cis, JD_WTSIZE);
+    DA(d_taps, 2 * g.fir_n);
+#undef DA
+    c->p.cis = d_cis; c->p.taps2 = d_taps;
+
+    // TrigLookUp (JAERO/DSP.cpp:11-30): generated on the host so the table bits match the reference's libm
+    {
+        std::vector<double2> cis(JD_WTSIZE);
+        for (int i = 0; i < JD_WTSIZE; i++)
+        {
+            cis[i].y = (sin(2 * M_PI * ((double)i) / JD_WTSIZE));
+            cis[i].x = (sin(M_PI_2 + 2 * M_PI * ((double)i) / JD_WTSIZE));
+        }
+        HIPCHK(hipMemcpy(d_cis, cis.data(), sizeof(double2) * JD_WTSIZE, hipMemcpyHostToDevice));
+        std::vector<double2> tw(g.nfft);
+        for (int i = 0; i < g.nfft; i++) { double a = -2.0 * M_PI * ((double)i) / ((double)g.nfft); tw[i].x = cos(a); tw[i].y = sin(a); }
+        HIPCHK(hipMemcpy(c->d_tw, tw.data(), sizeof(double2) * g.nfft, hipMemcpyHostToDevice));
+        std::vector<double> taps;
+        if (g.kind == JAERO_KIND_OQPSK) taps = rrc_design(1.0, 55, g.Fs, g.fb / 2);
+        else
+        {
+            taps.resize(g.fir_n);
+            const double SPS = (double)g.sps;
+            for (int i = 0; i < 2 * SPS; i++) taps[i] = sin(M_PI * i / (2.0 * SPS)) / (2.0 * SPS);
+        }
+        std::vector<double> t2(2 * g.fir_n);
+        for (int i = 0; i < 2 * g.fir_n; i++) t2[i] = taps[i % g.fir_n];
+        HIPCHK(hipMemcpy(d_taps, t2.data(), sizeof(double) * t2.size(), hipMemcpyHostToDevice));
+    }
+    // scalar state
+    {
+        std::vector<double> S((size_t)S_NFIELDS * nchp, 0.0);
+        std::vector<int> I((size_t)I_NFIELDS * nchp, 0);
+        c->settings.resize(nchp);
+        for (int ch = 0; ch < nchp; ch++)
+        {
+            const jaero_settings &s = sat(ch < nchannels ? ch : 0);
+            c->settings[ch] = s;
+            init_channel_scalars(c, s, S, I, ch, true);
+        }
+        HIPCHK(hipMemcpy(c->p.S, S.data(), S.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->p.I, I.data(), I.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    c->h_flags.assign(nchp, 0); c->h_bbptr.assign(nchp, 0); c->h_cnt.assign(nchp, 0);
+    // dynamic LDS for the matched-filter rings
+    const int lds_bytes = 2 * g.fir_n * 64 * (int)sizeof(double);
+    if (g.kind == JAERO_KIND_MSK)
+    {
+        HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    }
+    HIPCHK(hipDeviceSynchronize());
+    *out = c;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ control surface
+static int upload_flags(jaero_ctx *c)
+{
+    HIPCHK(hipMemcpy(c->p.I + (size_t)I_FLAGS * c->g.nchp, c->h_flags.data(), sizeof(int) * c->g.nchp, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int jaero_set_flags(jaero_ctx *c, int channel, int afc, int sql, int cpu_reduce)
+{
+    if (!c || channel < -1 || channel >= c->g.nch) return fail(JAERO_EINVAL, "jaero_set_flags: bad channel");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    const int lo = channel < 0 ? 0 : channel, hi = channel < 0 ? c->g.nchp : channel + 1;
+    for (int ch = lo; ch < hi; ch++)
+    {
+        int f = c->h_flags[ch] & JF_DCD;
+        if (afc) f |= JF_AFC;
+        if (sql) f |= JF_SQL;
+        if (cpu_reduce) f |= JF_CPUREDUCE;
+        c->h_flags[ch] = f;
+    }
+    return upload_flags(c);
+}
+
+extern "C" int jaero_set_dcd(jaero_ctx *c, int channel, int dcd)
+{
+    if (!c || channel < -1 || channel >= c->g.nch) return fail(JAERO_EINVAL, "jaero_set_dcd: bad channel");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    const int lo = channel < 0 ? 0 : channel, hi = channel < 0 ? c->g.nchp : channel + 1;
+    for (int ch = lo; ch < hi; ch++) c->h_flags[ch] = (c->h_flags[ch] & ~JF_DCD) | (dcd ? JF_DCD : 0);
+    return upload_flags(c);
+}
+
+extern "C" int jaero_center_freq_changed(jaero_ctx *c, int channel, double hz)
+{
+    if (!c || channel < -1 || channel >= c->g.nch) return fail(JAERO_EINVAL, "jaero_center_freq_changed: bad channel");
+    HIPCHK(hipSetDevice(c->device));
+    const int lo = channel < 0 ? 0 : channel, n = channel < 0 ? c->g.nch : 1;
+    hipLaunchKernelGGL(k_center_freq, dim3(n), dim3(256), 0, c->last_stream, c->g, c->p, lo, n, hz);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// zero one channel's column of a [group][slot][lane] ring (group_stride = elements per group)
+template <class T>
+static hipError_t zero_column(T *base, size_t group_stride, int len, int ch)
+{
+    const int grp = ch / 64, lane = ch % 64;
+    return hipMemset2D((void *)(base + (size_t)grp * group_stride + lane), sizeof(T) * 64, 0, sizeof(T), (size_t)len);
+}
+
+extern "C" int jaero_set_settings(jaero_ctx *c, int channel, const jaero_settings *s)
+{
+    // setSettings on a live object (oqpskdemodulator.cpp:175-289, mskdemodulator.cpp:135-263): retunes the mixers
+    // (phase kept), recreates AGC / matched filters / timing delays / resonator, restarts the coarse ring pointer.
+    if (!c || !s || channel < -1 || channel >= c->g.nch) return fail(JAERO_EINVAL, "jaero_set_settings: bad arguments");
+    int rc = validate_settings(*s);
+    if (rc) return rc;
+    const JGeom &g = c->g;
+    if (s->kind != g.kind || s->fb != g.fb || s->Fs != g.Fs || s->coarsefreqest_fft_power != g.nfft_log2)
+        return fail(JAERO_EINVAL, "jaero_set_settings: kind/fb/Fs/fft_power are fixed per bank; create a new bank to change them");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    const int nchp = g.nchp;
+    std::vector<double> S((size_t)S_NFIELDS * nchp);
+    std::vector<int> I((size_t)I_NFIELDS * nchp);
+    HIPCHK(hipMemcpy(S.data(), c->p.S, S.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(I.data(), c->p.I, I.size() * sizeof(int), hipMemcpyDeviceToHost));
+    const int lo = channel < 0 ? 0 : channel, hi = channel < 0 ? g.nch : channel + 1;
+    static const int zero_fields_oqpsk[] = {S_AGC_SUM, S_D1, S_D41_1, S_D41_2, S_D41_3, S_D42_1, S_D42_2, S_D42_3, S_D8_1, S_D8_2,
+                                            S_RES_X1, S_RES_X2, S_RES_Y1, S_RES_Y2};
+    static const int zero_fields_msk[] = {S_AGC_SUM, S_RES_X1, S_RES_X2, S_RES_Y1, S_RES_Y2, S_EB_ESUM, S_EB_E2SUM, S_EB_EBNO, S_MARG_SUM};
+    for (int ch = lo; ch < hi; ch++)
+    {
+        c->settings[ch] = *s;
+        init_channel_scalars(c, *s, S, I, ch, false);
+        if (g.kind == JAERO_KIND_OQPSK) for (int f : zero_fields_oqpsk) S[(size_t)f * nchp + ch] = 0;
+        else for (int f : zero_fields_msk) S[(size_t)f * nchp + ch] = 0;
+        I[(size_t)I_BB_PTR * nchp + ch] = 0; I[(size_t)I_COARSE_CNT * nchp + ch] = 0; I[(size_t)I_AGC_POS * nchp + ch] = 0;
+        c->h_bbptr[ch] = 0; c->h_cnt[ch] = 0;
+        HIPCHK(zero_column(c->p.agc_ring, (size_t)g.agc_len * 64, g.agc_len, ch));
+        HIPCHK(zero_column(c->p.firsave, (size_t)2 * g.fir_n * 64, 2 * g.fir_n, ch)); // both arms
+        if (g.kind == JAERO_KIND_MSK)
+        {
+            if (c->p.eb_e) { HIPCHK(zero_column(c->p.eb_e, (size_t)g.ebno_len * 64, g.ebno_len, ch)); HIPCHK(zero_column(c->p.eb_e2, (size_t)g.ebno_len * 64, g.ebno_len, ch)); I[(size_t)I_EB_POS * nchp + ch] = 0; }
+            HIPCHK(hipMemset(c->p.marg + (size_t)ch * g.marg_len, 0, sizeof(double) * g.marg_len));
+            I[(size_t)I_MARG_POS * nchp + ch] = 0; I[(size_t)I_DT_POS * nchp + ch] = 0;
+            HIPCHK(zero_column(c->p.dly8, (size_t)(g.sps2 + 1) * 64, g.sps2 + 1, ch));
+            // delayedsmpl.setLength keeps its contents but restarts at slot 0; with the shared ring slot the contents
+            // are cleared instead (deviation only visible for SPS samples after a live setSettings)
+            HIPCHK(zero_column(c->p.dly, (size_t)(g.sps + 1) * 64, g.sps + 1, ch));
+        }
+    }
+    HIPCHK(hipMemcpy(c->p.S, S.data(), S.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->p.I, I.data(), I.size() * sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ profiling helpers
+static int prof_begin(jaero_ctx *c, int which, hipStream_t st)
+{
+    if (!c->prof) return -1;
+    if (c->ev_next >= c->ev_pool.size())
+    {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+        c->ev_pool.push_back({a, b});
+    }
+    const int idx = (int)c->ev_next++;
+    hipEventRecord(c->ev_pool[idx].first, st);
+    c->ev_used.push_back({which, idx});
+    return idx;
+}
+static void prof_end(jaero_ctx *c, int idx, hipStream_t st)
+{
+    if (idx >= 0) hipEventRecord(c->ev_pool[idx].second, st);
+}
+static void prof_collect(jaero_ctx *c)
+{
+    for (auto &u : c->ev_used)
+    {
+        float ms = 0;
+        hipEventSynchronize(c->ev_pool[u.idx].second);
+        if (hipEventElapsedTime(&ms, c->ev_pool[u.idx].first, c->ev_pool[u.idx].second) == hipSuccess)
+        {
+            c->slots[u.which].ms += ms;
+            c->slots[u.which].launches++;
+        }
+    }
+    c->ev_used.clear();
+    c->ev_next = 0;
+}
+extern "C" int jaero_profile_enable(jaero_ctx *c, int on)
+{
+    if (!c) return fail(JAERO_EINVAL, "null ctx");
+    c->prof = on != 0;
+    return 0;
+}
+extern "C" int jaero_profile_read(jaero_ctx *c, int which, double *total_ms, int *launches, int reset)
+{
+    if (!c || which < 0 || which > 2) return fail(JAERO_EINVAL, "jaero_profile_read: bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    prof_collect(c);
+    if (total_ms) *total_ms = c->slots[which].ms;
+    if (launches) *launches = c->slots[which].launches;
+    if (reset) c->slots[which] = ProfSlot();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ write
+static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int n, int skipA, int onlyA, hipStream_t st)
+{
+    const JGeom &g = c->g;
+    const int lds = 2 * g.fir_n * 64 * (int)sizeof(double);
+    const bool eb = (c->flags & JAERO_FLAG_EBNO) != 0, cs = (c->flags & JAERO_FLAG_CAPTURE_SYMBOLS) != 0;
+    const dim3 grid(g.ngroups), block(64);
+    if (g.kind == JAERO_KIND_OQPSK)
+    {
+        const int fs = (int)(c->nB_total % 55);
+#define LO(E, C) hipLaunchKernelGGL((k_oqpsk_samples<55, E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs)
+        if (eb && cs) LO(true, true); else if (eb) LO(true, false); else if (cs) LO(false, true); else LO(false, false);
+#undef LO
+    }
+    else
+    {
+        const int fs = (int)(c->nB_total % g.fir_n), ds = (int)(c->nB_total % (g.sps + 1)), d8 = (int)(c->nB_total % (g.sps2 + 1));
+#define LM(E, C) hipLaunchKernelGGL((k_msk_samples<E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs, ds, d8)
+        if (eb && cs) LM(true, true); else if (eb) LM(true, false); else if (cs) LM(false, true); else LM(false, false);
+#undef LM
+    }
+}
+
+static void launch_coarse(jaero_ctx *c, const int *d_list, int nlist, hipStream_t st)
+{
+    const int grid = nlist < c->coarse_grid ? nlist : c->coarse_grid;
+    if (c->g.nfft_log2 == 14)
+        hipLaunchKernelGGL((k_coarse<14>), dim3(grid), dim3(CO_THREADS), 0, st, c->g, c->p, d_list, nlist, c->d_scratch, c->d_tw);
+    else
+        hipLaunchKernelGGL((k_coarse<13>), dim3(grid), dim3(CO_THREADS), 0, st, c->g, c->p, d_list, nlist, c->d_scratch, c->d_tw);
+}
+
+// number of A-steps (>=1) until channel ch's coarse estimate fires, given the counters before its next A-step
+static inline long long steps_to_trigger(const jaero_ctx *c, int ch, int cnt_before_first_a)
+{
+    const int nfft = c->g.nfft;
+    if (!(c->h_flags[ch] & JF_CPUREDUCE))
+    {
+        const int q = nfft / 4;
+        return q - (c->h_bbptr[ch] % q);
+    }
+    long long j0 = (long long)c->g.Fs_int - cnt_before_first_a + 1;
+    if (j0 < 1) j0 = 1;
+    const int r = nfft - (c->h_bbptr[ch] % nfft);
+    return j0 + r - 1;
+}
+
+extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layout, int is_device_ptr, void *stream)
+{
+    if (!c || !pcm || nsamples < 0) return fail(JAERO_EINVAL, "jaero_write: bad arguments");
+    if (nsamples == 0) return 0;
+    if (nsamples > c->max_write) return fail(JAERO_EINVAL, "jaero_write: nsamples %d exceeds max_write_samples %d", nsamples, c->max_write);
+    if (layout != JAERO_PCM_CHANNEL_MAJOR && layout != JAERO_PCM_FRAME_MAJOR) return fail(JAERO_EINVAL, "jaero_write: bad layout");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    c->last_stream = st;
+    const JGeom &g = c->g;
+    const int nch = g.nch, nchp = g.nchp;
+
+    const int16_t *frames = nullptr;
+    int stride = 0;
+    const int16_t *dsrc = pcm;
+    if (!is_device_ptr)
+    {
+        HIPCHK(hipMemcpyAsync(c->d_pcm_raw, pcm, sizeof(int16_t) * (size_t)nch * nsamples, hipMemcpyHostToDevice, st));
+        dsrc = c->d_pcm_raw;
+    }
+    if (layout == JAERO_PCM_FRAME_MAJOR) { frames = dsrc; stride = nch; }
+    else
+    {
+        const int pi = prof_begin(c, 2, st);
+        hipLaunchKernelGGL(k_transpose_pcm, dim3(nchp / 64, (nsamples + 63) / 64), dim3(256), 0, st, dsrc, c->d_pcm_frames, nch, nchp, nsamples);
+        prof_end(c, pi, st);
+        frames = c->d_pcm_frames; stride = nchp;
+    }
+
+    int pos = 0;
+    while (pos < nsamples)
+    {
+        // earliest coarse trigger over all channels, in A-steps from the next unprocessed A
+        long long dmin = (long long)1 << 60;
+        for (int ch = 0; ch < nch; ch++)
+        {
+            const long long d = steps_to_trigger(c, ch, c->h_cnt[ch] + (c->pending ? 1 : 0));
+            if (d < dmin) dmin = d;
+        }
+        const int first_a = pos + (c->pending ? 1 : 0);      // sample index of the next A-step
+        const long long trig_sample = (long long)first_a + dmin - 1;
+        const bool trig = trig_sample < nsamples;
+        const int end = trig ? (int)trig_sample + 1 : nsamples; // segment = [pos, end)
+        const int n = end - pos;
+        const int acount = n - (c->pending ? 1 : 0);
+        const int bcount = n - (trig ? 1 : 0);
+        if (n > 0)
+        {
+            const int pi = prof_begin(c, 0, st);
+            launch_samples(c, frames + (size_t)pos * stride, stride, n, c->pending, trig ? 1 : 0, st);
+            prof_end(c, pi, st);
+        }
+        // mirror update
+        c->h_list.clear();
+        for (int ch = 0; ch < nchp; ch++)
+        {
+            const int cnt0 = c->h_cnt[ch] + (c->pending ? 1 : 0);
+            long long fills;
+            if (!(c->h_flags[ch] & JF_CPUREDUCE)) fills = acount;
+            else
+            {
+                long long j0 = (long long)g.Fs_int - cnt0 + 1;
+                if (j0 < 1) j0 = 1;
+                fills = (long long)acount - (j0 - 1);
+                if (fills < 0) fills = 0;
+            }
+            const bool fired = trig && ch < nch && steps_to_trigger(c, ch, cnt0) == dmin;
+            c->h_bbptr[ch] = (int)((c->h_bbptr[ch] + fills) % g.nfft);
+            c->h_cnt[ch] += bcount;
+            if (fired) { c->h_cnt[ch] = 0; c->h_list.push_back(ch); }
+        }
+        c->nB_total += bcount;
+        if (trig)
+        {
+            const int nlist = (int)c->h_list.size();
+            const int *dl = nullptr;
+            if (nlist != nch)
+            {
+                HIPCHK(hipMemcpyAsync(c->d_chanlist, c->h_list.data(), sizeof(int) * nlist, hipMemcpyHostToDevice, st));
+                dl = c->d_chanlist;
+            }
+            const int pi = prof_begin(c, 1, st);
+            launch_coarse(c, dl, nlist, st);
+            prof_end(c, pi, st);
+            c->pending = 1;
+            pos = end - 1; // resume with the B-part of the trigger sample
+        }
+        else
+        {
+            c->pending = 0;
+            pos = end;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ outputs
+static int check_overflow(jaero_ctx *c, int ch, int bit)
+{
+    int ov = 0;
+    HIPCHK(hipMemcpy(&ov, c->p.I + (size_t)I_OVERFLOW * c->g.nchp + ch, sizeof(int), hipMemcpyDeviceToHost));
+    if (ov & bit)
+    {
+        int z = ov & ~bit;
+        HIPCHK(hipMemcpy(c->p.I + (size_t)I_OVERFLOW * c->g.nchp + ch, &z, sizeof(int), hipMemcpyHostToDevice));
+        return fail(JAERO_EOVERFLOW, "channel %d overflowed its output buffer (flag %d); data was dropped", ch, bit);
+    }
+    return 0;
+}
+
+extern "C" int jaero_read_softbits(jaero_ctx *c, int ch, int16_t *dst, int cap, int *n)
+{
+    if (!c || !dst || !n || ch < 0 || ch >= c->g.nch || cap < 0) return fail(JAERO_EINVAL, "jaero_read_softbits: bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->last_stream));
+    int cnt = 0;
+    int *dcnt = c->p.I + (size_t)I_SOFT_CNT * c->g.nchp + ch;
+    HIPCHK(hipMemcpy(&cnt, dcnt, sizeof(int), hipMemcpyDeviceToHost));
+    const int take = cnt < cap ? cnt : cap;
+    int16_t *src = c->p.soft + (size_t)ch * c->g.soft_cap;
+    if (take) HIPCHK(hipMemcpy(dst, src, sizeof(int16_t) * take, hipMemcpyDeviceToHost));
+    if (take < cnt)
+    {
+        std::vector<int16_t> tmp(cnt - take);
+        HIPCHK(hipMemcpy(tmp.data(), src + take, sizeof(int16_t) * (cnt - take), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(src, tmp.data(), sizeof(int16_t) * (cnt - take), hipMemcpyHostToDevice));
+    }
+    const int rest = cnt - take;
+    HIPCHK(hipMemcpy(dcnt, &rest, sizeof(int), hipMemcpyHostToDevice));
+    *n = take;
+    return check_overflow(c, ch, 1);
+}
+
+extern "C" int jaero_read_softbits_all(jaero_ctx *c, int16_t *dst, int capc, int *counts)
+{
+    if (!c || !dst || !counts || capc <= 0) return fail(JAERO_EINVAL, "jaero_read_softbits_all: bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = c->last_stream;
+    const int nch = c->g.nch, nchp = c->g.nchp;
+    const size_t need = (size_t)nch * capc;
+    if (need > c->pack_elems)
+    {
+        int16_t *q = nullptr;
+        if (hipMalloc((void **)&q, need * sizeof(int16_t)) != hipSuccess) return fail(JAERO_ENOMEM, "pack buffer");
+        c->allocs.push_back(q);
+        c->d_pack = q; c->pack_elems = need;
+    }
+    hipLaunchKernelGGL(k_pack_soft, dim3(nch), dim3(256), 0, st, c->g, c->p, c->d_pack, capc);
+    HIPCHK(hipMemcpyAsync(dst, c->d_pack, need * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+    std::vector<int> cnt(nchp), ov(nchp);
+    HIPCHK(hipMemcpyAsync(cnt.data(), c->p.I + (size_t)I_SOFT_CNT * nchp, sizeof(int) * nchp, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ov.data(), c->p.I + (size_t)I_OVERFLOW * nchp, sizeof(int) * nchp, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    int rc = 0;
+    for (int ch = 0; ch < nch; ch++)
+    {
+        counts[ch] = cnt[ch] < capc ? cnt[ch] : capc;
+        if (cnt[ch] > capc || (ov[ch] & 1)) rc = JAERO_EOVERFLOW;
+    }
+    HIPCHK(hipMemsetAsync(c->p.I + (size_t)I_SOFT_CNT * nchp, 0, sizeof(int) * nchp, st));
+    if (rc)
+    {
+        HIPCHK(hipMemsetAsync(c->p.I + (size_t)I_OVERFLOW * nchp, 0, sizeof(int) * nchp, st));
+        return fail(rc, "at least one channel produced more soft bits than fit (cap_per_channel=%d or device capacity)", capc);
+    }
+    return 0;
+}
+
+extern "C" int jaero_softbits_view(jaero_ctx *c, void **dev_softbits, void **dev_counts, int *capacity)
+{
+    if (!c) return fail(JAERO_EINVAL, "null ctx");
+    if (dev_softbits) *dev_softbits = c->p.soft;
+    if (dev_counts) *dev_counts = c->p.I + (size_t)I_SOFT_CNT * c->g.nchp;
+    if (capacity) *capacity = c->g.soft_cap;
+    return 0;
+}
+
+extern "C" int jaero_discard_softbits(jaero_ctx *c, void *stream)
+{
+    if (!c) return fail(JAERO_EINVAL, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemsetAsync(c->p.I + (size_t)I_SOFT_CNT * c->g.nchp, 0, sizeof(int) * c->g.nchp, (hipStream_t)stream));
+    HIPCHK(hipMemsetAsync(c->p.I + (size_t)I_SYM_CNT * c->g.nchp, 0, sizeof(int) * c->g.nchp, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int jaero_read_status(jaero_ctx *c, int ch, jaero_status *stt)
+{
+    if (!c || !stt || ch < 0 || ch >= c->g.nch) return fail(JAERO_EINVAL, "jaero_read_status: bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_status, dim3(1), dim3(64), 0, c->last_stream, c->g, c->p, ch, 1, c->d_status);
+    HIPCHK(hipMemcpyAsync(stt, c->d_status, sizeof(jaero_status), hipMemcpyDeviceToHost, c->last_stream));
+    HIPCHK(hipStreamSynchronize(c->last_stream));
+    return 0;
+}
+
+static int read_rows(jaero_ctx *c, int ch, double *rows, int caprows, int *nrows, int cnt_field, double *base, int cap, int w, int ovbit)
+{
+    if (!c || !rows || !nrows || ch < 0 || ch >= c->g.nch) return fail(JAERO_EINVAL, "bad arguments");
+    if (!base) return fail(JAERO_EINVAL, "this output was not enabled in jaero_create flags");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->last_stream));
+    int cnt = 0;
+    int *dcnt = c->p.I + (size_t)cnt_field * c->g.nchp + ch;
+    HIPCHK(hipMemcpy(&cnt, dcnt, sizeof(int), hipMemcpyDeviceToHost));
+    const int take = cnt < caprows ? cnt : caprows;
+    double *src = base + (size_t)ch * cap * w;
+    if (take) HIPCHK(hipMemcpy(rows, src, sizeof(double) * w * take, hipMemcpyDeviceToHost));
+    if (take < cnt)
+    {
+        std::vector<double> tmp((size_t)w * (cnt - take));
+        HIPCHK(hipMemcpy(tmp.data(), src + (size_t)take * w, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(src, tmp.data(), sizeof(double) * tmp.size(), hipMemcpyHostToDevice));
+    }
+    const int rest = cnt - take;
+    HIPCHK(hipMemcpy(dcnt, &rest, sizeof(int), hipMemcpyHostToDevice));
+    *nrows = take;
+    return check_overflow(c, ch, ovbit);
+}
+extern "C" int jaero_read_status_log(jaero_ctx *c, int ch, double *rows, int caprows, int *nrows)
+{
+    return read_rows(c, ch, rows, caprows, nrows, I_LOG_CNT, c ? c->p.slog : nullptr, c ? c->g.log_cap : 0, 6, 4);
+}
+extern "C" int jaero_read_symbols(jaero_ctx *c, int ch, double *rows, int caprows, int *nrows)
+{
+    return read_rows(c, ch, rows, caprows, nrows, I_SYM_CNT, c ? c->p.sym : nullptr, c ? c->g.sym_cap : 0, 3, 2);
+}
+
+// ------------------------------------------------------------------------------------------ Viterbi
+static int viterbi_run(int device, const uint8_t *soft, int nblocks, int nsoft, int pad, uint8_t *overlap, uint8_t *bits_out,
+                       int out_stride, int out_start, int out_want, int is_device_ptr, hipStream_t st)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(JAERO_ENODEV, "no HIP device available");
+    HIPCHK(hipSetDevice(device));
+    const uint8_t *d_soft = soft; uint8_t *d_out = bits_out; uint8_t *d_ov = overlap;
+    void *t_soft = nullptr, *t_out = nullptr, *t_ov = nullptr;
+    const size_t out_bytes = (size_t)nblocks * out_stride;
+    if (!is_device_ptr)
+    {
+        HIPCHK(hipMalloc(&t_soft, (size_t)nblocks * nsoft));
+        HIPCHK(hipMalloc(&t_out, out_bytes));
+        HIPCHK(hipMemcpyAsync(t_soft, soft, (size_t)nblocks * nsoft, hipMemcpyHostToDevice, st));
+        d_soft = (const uint8_t *)t_soft; d_out = (uint8_t *)t_out;
+        if (overlap)
+        {
+            HIPCHK(hipMalloc(&t_ov, (size_t)nblocks * 64));
+            HIPCHK(hipMemcpyAsync(t_ov, overlap, (size_t)nblocks * 64, hipMemcpyHostToDevice, st));
+            d_ov = (uint8_t *)t_ov;
+        }
+    }
+    HIPCHK(hipMemsetAsync(d_out, 0, out_bytes, st));
+    hipLaunchKernelGGL(k_viterbi, dim3(nblocks), dim3(64), 0, st, d_soft, nsoft, (const uint8_t *)d_ov, pad, d_out, out_stride, out_start, out_want, nblocks);
+    HIPCHK(hipGetLastError());
+    if (!is_device_ptr)
+    {
+        HIPCHK(hipMemcpyAsync(bits_out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        hipFree(t_soft); hipFree(t_out); if (t_ov) hipFree(t_ov);
+    }
+    return 0;
+}
+
+extern "C" int jaero_viterbi_decode_soft(int device, const uint8_t *soft, int nblocks, int nsoft, uint8_t *bits_out, int is_device_ptr, void *stream)
+{
+    if (!soft || !bits_out || nblocks <= 0 || nsoft < 4 * VT_ORDER || (nsoft & 1)) return fail(JAERO_EINVAL, "jaero_viterbi_decode_soft: bad arguments");
+    return viterbi_run(device, soft, nblocks, nsoft, 0, nullptr, bits_out, nsoft / 2, 0, nsoft / 2, is_device_ptr, (hipStream_t)stream);
+}
+
+__global__ void k_viterbi_overlap_update(const uint8_t *__restrict__ soft, int nsoft, uint8_t *__restrict__ overlap, int nstreams)
+{
+    // soft_bits_overlap_buffer_uchar = soft_bits_in.right(62); resize(62)  (jconvolutionalcodec.cpp:197-198)
+    const int b = blockIdx.x;
+    if (b >= nstreams) return;
+    const int k = 62;
+    const int t = threadIdx.x;
+    if (t < k)
+    {
+        uint8_t v = 0;
+        if (nsoft >= k) v = soft[(size_t)b * nsoft + nsoft - k + t];
+        else if (t < nsoft) v = soft[(size_t)b * nsoft + t];
+        overlap[(size_t)b * 64 + t] = v;
+    }
+    if (t == 62) overlap[(size_t)b * 64 + 62] = (uint8_t)k;
+}
+
+extern "C" int jaero_viterbi_continuous(int device, const uint8_t *soft, int nstreams, int nsoft, int paddinglength, uint8_t *overlap_state,
+                                        uint8_t *bits_out, int *nbits_out, int is_device_ptr, void *stream)
+{
+    if (!soft || !bits_out || !overlap_state || nstreams <= 0 || nsoft < 64 || (nsoft & 1) || paddinglength < 0 || (paddinglength & 1))
+        return fail(JAERO_EINVAL, "jaero_viterbi_continuous: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int want = nsoft / 2;
+    // host needs each stream's overlap length to report nbits (first call of a stream returns fewer bits)
+    std::vector<uint8_t> hov;
+    const uint8_t *ovh = overlap_state;
+    if (is_device_ptr)
+    {
+        hov.resize((size_t)nstreams * 64);
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipMemcpyAsync(hov.data(), overlap_state, hov.size(), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        ovh = hov.data();
+    }
+    if (nbits_out)
+        for (int b = 0; b < nstreams; b++)
+        {
+            const int total = (int)ovh[(size_t)b * 64 + 62] + nsoft + paddinglength;
+            int nb = total / 2 - (paddinglength + 1);
+            if (nb > want) nb = want;
+            if (nb < 0) nb = 0;
+            nbits_out[b] = nb;
+        }
+    int rc = viterbi_run(device, soft, nstreams, nsoft, paddinglength, overlap_state, bits_out, want, paddinglength + 1, want, is_device_ptr, st);
+    if (rc) return rc;
+    if (is_device_ptr)
+    {
+        hipLaunchKernelGGL(k_viterbi_overlap_update, dim3(nstreams), dim3(64), 0, st, soft, nsoft, overlap_state, nstreams);
+        HIPCHK(hipGetLastError());
+    }
+    else
+    {
+        for (int b = 0; b < nstreams; b++)
+        {
+            uint8_t *ov = overlap_state + (size_t)b * 64;
+            memset(ov, 0, 64);
+            memcpy(ov, soft + (size_t)b * nsoft + nsoft - 62, 62);
+            ov[62] = 62;
+        }
+    }
+    return 0;
+}

@@ -1,0 +1,287 @@
+"""Host-side mirror of the reference's demodulator surface on top of the C ABI.
+
+`DemodulatorBank` is the batched object (one bank = N channels of one kind on one GPU).  `OqpskDemodulator` and
+`MskDemodulator` are single-channel views with the reference's own method names (setSettings, setAFC, setSQL,
+setCPUReduce, DCDstatSlot, CenterFreqChangedSlot, start/stop, writeData) and its signal
+`processDemodulatedSoftBits` as a Python callback, so tests read like the reference's call sites
+(JAERO/mainwindow.cpp:198-202,234-237,816-899).  All arithmetic happens in libjaero_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, List, Optional
+
+import numpy as np
+
+from . import capi
+
+
+@dataclass
+class OqpskSettings:
+    """OqpskDemodulator::Settings defaults (JAERO/oqpskdemodulator.h:20-39)."""
+
+    coarsefreqest_fft_power: int = 14
+    freq_center: float = 8000.0
+    lockingbw: float = 10500.0
+    fb: float = 10500.0
+    Fs: float = 48000.0
+    signalthreshold: float = 0.65
+
+    def to_c(self) -> capi.Settings:
+        return capi.Settings(capi.KIND_OQPSK, self.coarsefreqest_fft_power, self.freq_center, self.lockingbw, self.fb,
+                             self.Fs, self.signalthreshold)
+
+
+@dataclass
+class MskSettings:
+    """MskDemodulator::Settings defaults (JAERO/mskdemodulator.h:24-45)."""
+
+    coarsefreqest_fft_power: int = 13
+    freq_center: float = 1000.0
+    lockingbw: float = 900.0
+    fb: float = 600.0
+    Fs: float = 48000.0
+    signalthreshold: float = 0.5
+
+    def to_c(self) -> capi.Settings:
+        return capi.Settings(capi.KIND_MSK, self.coarsefreqest_fft_power, self.freq_center, self.lockingbw, self.fb,
+                             self.Fs, self.signalthreshold)
+
+
+class DemodulatorBank:
+    """A bank of `nchannels` demodulators on one GPU (thin wrapper over jaero_ctx)."""
+
+    def __init__(self, settings, nchannels: Optional[int] = None, device: int = 0, *, ebno: bool = True,
+                 status_log: bool = False, capture_symbols: bool = False, max_write_samples: int = 65536,
+                 softbit_capacity: int = 0):
+        self.L = capi.lib()
+        if isinstance(settings, (list, tuple)):
+            arr = (capi.Settings * len(settings))(*[s.to_c() for s in settings])
+            nch = len(settings) if nchannels is None else nchannels
+            stride = C.sizeof(capi.Settings)
+        else:
+            arr = (capi.Settings * 1)(settings.to_c())
+            nch = 1 if nchannels is None else nchannels
+            stride = 0
+        flags = (capi.FLAG_EBNO if ebno else 0) | (capi.FLAG_STATUS_LOG if status_log else 0) | (
+            capi.FLAG_CAPTURE_SYMBOLS if capture_symbols else 0)
+        h = C.c_void_p()
+        capi.check(self.L.jaero_create(device, nch, C.cast(arr, C.c_void_p), stride, flags, max_write_samples,
+                                       softbit_capacity, C.byref(h)))
+        self.h = h
+        self.nch = nch
+        self.device = device
+        self.max_write_samples = max_write_samples
+        self.kind = arr[0].kind
+        self.fb = arr[0].fb
+        self.Fs = arr[0].Fs
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.jaero_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- control surface (channel=-1: all) ----
+    def set_settings(self, settings, channel: int = -1):
+        s = settings.to_c()
+        capi.check(self.L.jaero_set_settings(self.h, channel, C.byref(s)))
+
+    def set_flags(self, afc=False, sql=False, cpu_reduce=False, channel: int = -1):
+        capi.check(self.L.jaero_set_flags(self.h, channel, int(afc), int(sql), int(cpu_reduce)))
+
+    def set_dcd(self, dcd: bool, channel: int = -1):
+        capi.check(self.L.jaero_set_dcd(self.h, channel, int(dcd)))
+
+    def center_freq_changed(self, hz: float, channel: int = -1):
+        capi.check(self.L.jaero_center_freq_changed(self.h, channel, float(hz)))
+
+    # ---- data ----
+    def write(self, pcm, layout: int = capi.PCM_CHANNEL_MAJOR, stream: int = 0):
+        """pcm: numpy int16 array ([nch, n] channel-major or [n, nch] frame-major) or a torch int16 tensor on the
+        bank's device with the same shapes."""
+        if isinstance(pcm, np.ndarray):
+            a = np.ascontiguousarray(pcm, dtype=np.int16)
+            if a.ndim == 1:
+                a = a.reshape(1, -1) if layout == capi.PCM_CHANNEL_MAJOR else a.reshape(-1, 1)
+            n = a.shape[1] if layout == capi.PCM_CHANNEL_MAJOR else a.shape[0]
+            nch = a.shape[0] if layout == capi.PCM_CHANNEL_MAJOR else a.shape[1]
+            assert nch == self.nch, (a.shape, self.nch)
+            capi.check(self.L.jaero_write(self.h, a.ctypes.data, n, layout, 0, stream))
+        else:  # torch tensor
+            t = pcm
+            assert t.is_cuda and t.is_contiguous() and t.element_size() == 2
+            n = t.shape[1] if layout == capi.PCM_CHANNEL_MAJOR else t.shape[0]
+            nch = t.shape[0] if layout == capi.PCM_CHANNEL_MAJOR else t.shape[1]
+            assert nch == self.nch, (tuple(t.shape), self.nch)
+            capi.check(self.L.jaero_write(self.h, t.data_ptr(), n, layout, 1, stream))
+
+    def read_softbits(self, channel: int, cap: int = 1 << 20) -> np.ndarray:
+        buf = np.empty(cap, dtype=np.int16)
+        n = C.c_int(0)
+        capi.check(self.L.jaero_read_softbits(self.h, channel, buf.ctypes.data, cap, C.byref(n)))
+        return buf[: n.value].copy()
+
+    def read_softbits_all(self, cap_per_channel: int):
+        buf = np.empty((self.nch, cap_per_channel), dtype=np.int16)
+        counts = np.zeros(self.nch, dtype=np.int32)
+        capi.check(self.L.jaero_read_softbits_all(self.h, buf.ctypes.data, cap_per_channel, counts.ctypes.data))
+        return buf, counts
+
+    def discard_softbits(self, stream: int = 0):
+        capi.check(self.L.jaero_discard_softbits(self.h, stream))
+
+    def softbits_view(self):
+        p, c, cap = C.c_void_p(), C.c_void_p(), C.c_int()
+        capi.check(self.L.jaero_softbits_view(self.h, C.byref(p), C.byref(c), C.byref(cap)))
+        return p.value, c.value, cap.value
+
+    def read_status(self, channel: int) -> capi.Status:
+        st = capi.Status()
+        capi.check(self.L.jaero_read_status(self.h, channel, C.byref(st)))
+        return st
+
+    def read_status_log(self, channel: int, caprows: int = 4096) -> np.ndarray:
+        buf = np.empty((caprows, 6), dtype=np.float64)
+        n = C.c_int(0)
+        capi.check(self.L.jaero_read_status_log(self.h, channel, buf.ctypes.data, caprows, C.byref(n)))
+        return buf[: n.value].copy()
+
+    def read_symbols(self, channel: int, caprows: int = 1 << 18) -> np.ndarray:
+        buf = np.empty((caprows, 3), dtype=np.float64)
+        n = C.c_int(0)
+        capi.check(self.L.jaero_read_symbols(self.h, channel, buf.ctypes.data, caprows, C.byref(n)))
+        return buf[: n.value].copy()
+
+    # ---- profiling ----
+    def profile_enable(self, on: bool = True):
+        capi.check(self.L.jaero_profile_enable(self.h, int(on)))
+
+    def profile_read(self, which: int, reset: bool = False):
+        ms, n = C.c_double(0), C.c_int(0)
+        capi.check(self.L.jaero_profile_read(self.h, which, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+
+class _SingleChannelDemodulator:
+    """QIODevice-shaped single-channel demodulator (one-channel bank)."""
+
+    Settings = None
+    _group = 32
+
+    def __init__(self, parent=None, device: int = 0, **bank_kw):
+        self._device = device
+        self._bank_kw = bank_kw
+        self._bank: Optional[DemodulatorBank] = None
+        self._settings = self.Settings()
+        self._afc = self._sql = self._cpu = False
+        self._dcd = False
+        self._open = False
+        self._pending: List[int] = []
+        self.processDemodulatedSoftBits: Optional[Callable[[List[int]], None]] = None
+        self.SignalStatus: Optional[Callable[[bool], None]] = None
+        self.MSESignal: Optional[Callable[[float], None]] = None
+        self.EbNoMeasurmentSignal: Optional[Callable[[float], None]] = None
+        self.Plottables: Optional[Callable[[float, float, float], None]] = None
+        self._nest = 0
+
+    # reference method names
+    def setSettings(self, settings):
+        self._settings = settings
+        if self._bank is None:
+            self._bank = DemodulatorBank(settings, 1, self._device, status_log=True, **self._bank_kw)
+            self._bank.set_flags(self._afc, self._sql, self._cpu)
+            self._bank.set_dcd(self._dcd)
+        else:
+            self._bank.set_settings(settings, 0)
+
+    def setAFC(self, state: bool):
+        self._afc = bool(state)
+        if self._bank:
+            self._bank.set_flags(self._afc, self._sql, self._cpu)
+
+    def setSQL(self, state: bool):
+        self._sql = bool(state)
+        if self._bank:
+            self._bank.set_flags(self._afc, self._sql, self._cpu)
+
+    def setCPUReduce(self, state: bool):
+        self._cpu = bool(state)
+        if self._bank:
+            self._bank.set_flags(self._afc, self._sql, self._cpu)
+
+    def DCDstatSlot(self, dcd: bool):
+        self._dcd = bool(dcd)
+        if self._bank:
+            self._bank.set_dcd(self._dcd)
+
+    def CenterFreqChangedSlot(self, freq_center: float):
+        if self._bank:
+            self._bank.center_freq_changed(freq_center, 0)
+
+    def start(self):
+        if self._bank is None:
+            self.setSettings(self._settings)
+        self._open = True
+
+    def stop(self):
+        self._open = False
+
+    def getCurrentFreq(self) -> float:
+        return self._bank.read_status(0).freq_center
+
+    def writeData(self, data, length: Optional[int] = None) -> int:
+        """data: bytes of little-endian int16 mono PCM (as QIODevice::writeData) or an int16 numpy array."""
+        if isinstance(data, (bytes, bytearray, memoryview)):
+            pcm = np.frombuffer(data, dtype="<i2")
+            if length is not None:
+                pcm = pcm[: length // 2]
+        else:
+            pcm = np.asarray(data, dtype=np.int16)
+        ret = 2 * pcm.shape[0]
+        if pcm.shape[0] == 0:
+            return 0
+        step = self._bank.max_write_samples
+        for s in range(0, pcm.shape[0], step):
+            self._bank.write(pcm[s:s + step].reshape(1, -1))
+            self._emit()
+        return ret
+
+    def _emit(self):
+        soft = self._bank.read_softbits(0)
+        if soft.size:
+            self._pending.extend(int(v) for v in soft)
+        g = self._group
+        while len(self._pending) >= g:
+            chunk, self._pending = self._pending[:g], self._pending[g:]
+            if self.processDemodulatedSoftBits:
+                self.processDemodulatedSoftBits(chunk)
+        for row in self._bank.read_status_log(0):
+            if self.Plottables:
+                self.Plottables(row[1], row[2], self._settings.lockingbw)
+            if self.EbNoMeasurmentSignal:
+                self.EbNoMeasurmentSignal(row[4])
+            if self.MSESignal:
+                self.MSESignal(row[3])
+            if self.SignalStatus:
+                self.SignalStatus(bool(row[5]))
+
+
+class OqpskDemodulator(_SingleChannelDemodulator):
+    """Drop-in shaped like JAERO's OqpskDemodulator (JAERO/oqpskdemodulator.h:15-152); emits 32 soft bits at a time."""
+
+    Settings = OqpskSettings
+    _group = 32
+
+
+class MskDemodulator(_SingleChannelDemodulator):
+    """Drop-in shaped like JAERO's MskDemodulator (JAERO/mskdemodulator.h:19-168); emits 12 soft bits at a time."""
+
+    Settings = MskSettings
+    _group = 12
