@@ -135,12 +135,20 @@ int jaero_read_symbols(jaero_ctx *ctx, int channel, double *rows, int caprows, i
  *   (the first nsoft/2 - 6 are decoded data, the rest 0).
  * jaero_viterbi_continuous: = JConvolutionalCodec::Decode_Continuous for nstreams independent streams, one
  *   block of nsoft soft bytes each per call; the 62-byte overlap of each stream is kept in the ctx-less state
- *   buffer `overlap` (nstreams*64 bytes, zero it for a fresh stream, first byte pair = length).
+ *   buffer `overlap_state` (nstreams*64 bytes: bytes 0..61 = the kept soft bytes, byte 62 = how many are valid, 0 or
+ *   62; zero it for a fresh stream).  nbits_out[s] receives the number of bits returned for stream s (nsoft/2, fewer
+ *   on the first block of a stream, exactly as the reference).
  * Both take host pointers (is_device_ptr=0) or device pointers (1). */
 int jaero_viterbi_decode_soft(int device, const uint8_t *soft, int nblocks, int nsoft, uint8_t *bits_out,
                               int is_device_ptr, void *stream);
 int jaero_viterbi_continuous(int device, const uint8_t *soft, int nstreams, int nsoft, int paddinglength,
                              uint8_t *overlap_state, uint8_t *bits_out, int *nbits_out, int is_device_ptr, void *stream);
+
+/* Host-only debugging aid (no device needed): the sample indices at which jaero_write would run the coarse-frequency
+ * estimate for a fresh channel fed `nwrites` writes of write_sizes[i] samples.  Returns the number of triggers
+ * (>= 0; up to `cap` are stored) or a negative error. */
+int jaero_debug_schedule(int fft_power, int Fs, int cpu_reduce, const int *write_sizes, int nwrites,
+                         long long *trigger_samples, int cap, int *segments_out);
 
 /* introspection */
 int jaero_abi_version(void);

@@ -23,6 +23,7 @@ EXPORTS = [
     "jaero_softbits_view", "jaero_discard_softbits", "jaero_read_status", "jaero_read_status_log",
     "jaero_read_symbols", "jaero_viterbi_decode_soft", "jaero_viterbi_continuous", "jaero_abi_version",
     "jaero_num_channels", "jaero_strerror", "jaero_last_error", "jaero_profile_enable", "jaero_profile_read",
+    "jaero_debug_schedule",
 ]
 
 
@@ -70,6 +71,13 @@ def lib():
             f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
             "or make -C jaero_amd/csrc).  jaero_amd has no CPU fallback."
         )
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.7.  Importing torch first makes the
+    # dynamic linker resolve libjaero_hip.so's libamdhip64.so.7 dependency to that already-loaded copy, so tensors,
+    # streams and this library share one runtime (loading /opt/rocm's copy first leaves torch without a device).
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover - torch is part of the image
+        pass
     L = C.CDLL(LIB_PATH)
     vp, ip, dp = C.c_void_p, C.c_int, C.c_double
     L.jaero_create.argtypes = [ip, ip, vp, ip, C.c_uint, ip, ip, C.POINTER(vp)]
@@ -96,6 +104,7 @@ def lib():
     L.jaero_last_error.restype = C.c_char_p
     L.jaero_profile_enable.argtypes = [vp, ip]
     L.jaero_profile_read.argtypes = [vp, ip, C.POINTER(dp), C.POINTER(ip), ip]
+    L.jaero_debug_schedule.argtypes = [ip, ip, ip, vp, ip, vp, ip, C.POINTER(ip)]
     for name in EXPORTS:
         getattr(L, name)  # raises AttributeError if a declared symbol is not exported
     _lib = L

@@ -42,6 +42,75 @@ static int fail(int code, const char *fmt, ...)
 
 struct ProfSlot { double ms = 0; int launches = 0; };
 
+// Host mirror of the two integer counters that decide WHEN the reference runs its coarse-frequency estimate
+// (bbcycbuff_ptr and coarseCounter, JAERO/oqpskdemodulator.cpp:410-431 == JAERO/mskdemodulator.cpp:350-368).
+// A "segment" is a run of samples handed to one sample-kernel launch; it ends at the first sample (over all channels)
+// whose ring write makes bbcycbuff_ptr % (cpuReduce ? nfft : nfft/4) == 0.  For that sample only the ring write
+// ("A-part") is done; the rest of the sample ("B-part") runs in the next segment, after the coarse kernel.
+struct Mirror
+{
+    int nch = 0, nchp = 0, nfft = 0, Fs_int = 0;
+    std::vector<int> flags, bbptr, cnt;
+    int pending = 0;        // A-part of the next sample already done
+    long long nB_total = 0; // B-parts executed so far (uniform ring slots derive from it)
+    std::vector<int> fired; // channels whose estimate fires at the end of the last planned segment
+
+    // number of A-steps (>=1) until channel ch fires, given its coarseCounter before its next A-step
+    long long steps_to_trigger(int ch, int cnt_before_first_a) const
+    {
+        if (!(flags[ch] & JF_CPUREDUCE))
+        {
+            const int q = nfft / 4;
+            return q - (bbptr[ch] % q);
+        }
+        long long j0 = (long long)Fs_int - cnt_before_first_a + 1;
+        if (j0 < 1) j0 = 1;
+        const int r = nfft - (bbptr[ch] % nfft);
+        return j0 + r - 1;
+    }
+    // Plans the segment starting at sample `pos` of a write of `nsamples`; returns its length n (samples pos..pos+n-1),
+    // sets skip_a/only_a, fills `fired`, updates the counters, and returns the position the next segment starts at.
+    int next_segment(int pos, int nsamples, int &n, int &skip_a, int &only_a)
+    {
+        long long dmin = (long long)1 << 60;
+        for (int ch = 0; ch < nch; ch++)
+        {
+            const long long d = steps_to_trigger(ch, cnt[ch] + (pending ? 1 : 0));
+            if (d < dmin) dmin = d;
+        }
+        const int first_a = pos + (pending ? 1 : 0);
+        const long long trig_sample = (long long)first_a + dmin - 1;
+        const bool trig = trig_sample < nsamples;
+        const int end = trig ? (int)trig_sample + 1 : nsamples;
+        n = end - pos;
+        skip_a = pending;
+        only_a = trig ? 1 : 0;
+        const int acount = n - (pending ? 1 : 0);
+        const int bcount = n - (trig ? 1 : 0);
+        fired.clear();
+        for (int ch = 0; ch < nchp; ch++)
+        {
+            const int cnt0 = cnt[ch] + (pending ? 1 : 0);
+            long long fills;
+            if (!(flags[ch] & JF_CPUREDUCE)) fills = acount;
+            else
+            {
+                long long j0 = (long long)Fs_int - cnt0 + 1;
+                if (j0 < 1) j0 = 1;
+                fills = (long long)acount - (j0 - 1);
+                if (fills < 0) fills = 0;
+            }
+            const bool f = trig && ch < nch && steps_to_trigger(ch, cnt0) == dmin;
+            bbptr[ch] = (int)((bbptr[ch] + fills) % nfft);
+            cnt[ch] += bcount;
+            if (f) { cnt[ch] = 0; fired.push_back(ch); }
+        }
+        nB_total += bcount;
+        pending = trig ? 1 : 0;
+        return trig ? end - 1 : end;
+    }
+};
+
 struct jaero_ctx
 {
     int device = 0;
@@ -61,10 +130,7 @@ struct jaero_ctx
     int16_t *d_pack = nullptr; size_t pack_elems = 0;
     // host mirrors
     std::vector<jaero_settings> settings;
-    std::vector<int> h_flags, h_bbptr, h_cnt;
-    long long nB_total = 0; // B-parts executed so far (uniform ring slots derive from it)
-    int pending = 0;        // A-part of the next sample already done
-    std::vector<int> h_list;
+    Mirror m;
     // profiling
     bool prof = false;
     ProfSlot slots[3];
@@ -431,7 +497,8 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         HIPCHK(hipMemcpy(c->p.S, S.data(), S.size() * sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->p.I, I.data(), I.size() * sizeof(int), hipMemcpyHostToDevice));
     }
-    c->h_flags.assign(nchp, 0); c->h_bbptr.assign(nchp, 0); c->h_cnt.assign(nchp, 0);
+    c->m.nch = nchannels; c->m.nchp = nchp; c->m.nfft = g.nfft; c->m.Fs_int = g.Fs_int;
+    c->m.flags.assign(nchp, 0); c->m.bbptr.assign(nchp, 0); c->m.cnt.assign(nchp, 0);
     // dynamic LDS for the matched-filter rings
     const int lds_bytes = 2 * g.fir_n * 64 * (int)sizeof(double);
     if (g.kind == JAERO_KIND_MSK)
@@ -449,7 +516,7 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
 // ------------------------------------------------------------------------------------------ control surface
 static int upload_flags(jaero_ctx *c)
 {
-    HIPCHK(hipMemcpy(c->p.I + (size_t)I_FLAGS * c->g.nchp, c->h_flags.data(), sizeof(int) * c->g.nchp, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->p.I + (size_t)I_FLAGS * c->g.nchp, c->m.flags.data(), sizeof(int) * c->g.nchp, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -461,11 +528,11 @@ extern "C" int jaero_set_flags(jaero_ctx *c, int channel, int afc, int sql, int 
     const int lo = channel < 0 ? 0 : channel, hi = channel < 0 ? c->g.nchp : channel + 1;
     for (int ch = lo; ch < hi; ch++)
     {
-        int f = c->h_flags[ch] & JF_DCD;
+        int f = c->m.flags[ch] & JF_DCD;
         if (afc) f |= JF_AFC;
         if (sql) f |= JF_SQL;
         if (cpu_reduce) f |= JF_CPUREDUCE;
-        c->h_flags[ch] = f;
+        c->m.flags[ch] = f;
     }
     return upload_flags(c);
 }
@@ -476,7 +543,7 @@ extern "C" int jaero_set_dcd(jaero_ctx *c, int channel, int dcd)
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
     const int lo = channel < 0 ? 0 : channel, hi = channel < 0 ? c->g.nchp : channel + 1;
-    for (int ch = lo; ch < hi; ch++) c->h_flags[ch] = (c->h_flags[ch] & ~JF_DCD) | (dcd ? JF_DCD : 0);
+    for (int ch = lo; ch < hi; ch++) c->m.flags[ch] = (c->m.flags[ch] & ~JF_DCD) | (dcd ? JF_DCD : 0);
     return upload_flags(c);
 }
 
@@ -526,7 +593,7 @@ extern "C" int jaero_set_settings(jaero_ctx *c, int channel, const jaero_setting
         if (g.kind == JAERO_KIND_OQPSK) for (int f : zero_fields_oqpsk) S[(size_t)f * nchp + ch] = 0;
         else for (int f : zero_fields_msk) S[(size_t)f * nchp + ch] = 0;
         I[(size_t)I_BB_PTR * nchp + ch] = 0; I[(size_t)I_COARSE_CNT * nchp + ch] = 0; I[(size_t)I_AGC_POS * nchp + ch] = 0;
-        c->h_bbptr[ch] = 0; c->h_cnt[ch] = 0;
+        c->m.bbptr[ch] = 0; c->m.cnt[ch] = 0;
         HIPCHK(zero_column(c->p.agc_ring, (size_t)g.agc_len * 64, g.agc_len, ch));
         HIPCHK(zero_column(c->p.firsave, (size_t)2 * g.fir_n * 64, 2 * g.fir_n, ch)); // both arms
         if (g.kind == JAERO_KIND_MSK)
@@ -605,14 +672,14 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
     const dim3 grid(g.ngroups), block(64);
     if (g.kind == JAERO_KIND_OQPSK)
     {
-        const int fs = (int)(c->nB_total % 55);
+        const int fs = (int)(c->m.nB_total % 55);
 #define LO(E, C) hipLaunchKernelGGL((k_oqpsk_samples<55, E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs)
         if (eb && cs) LO(true, true); else if (eb) LO(true, false); else if (cs) LO(false, true); else LO(false, false);
 #undef LO
     }
     else
     {
-        const int fs = (int)(c->nB_total % g.fir_n), ds = (int)(c->nB_total % (g.sps + 1)), d8 = (int)(c->nB_total % (g.sps2 + 1));
+        const int fs = (int)(c->m.nB_total % g.fir_n), ds = (int)(c->m.nB_total % (g.sps + 1)), d8 = (int)(c->m.nB_total % (g.sps2 + 1));
 #define LM(E, C) hipLaunchKernelGGL((k_msk_samples<E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs, ds, d8)
         if (eb && cs) LM(true, true); else if (eb) LM(true, false); else if (cs) LM(false, true); else LM(false, false);
 #undef LM
@@ -626,21 +693,6 @@ static void launch_coarse(jaero_ctx *c, const int *d_list, int nlist, hipStream_
         hipLaunchKernelGGL((k_coarse<14>), dim3(grid), dim3(CO_THREADS), 0, st, c->g, c->p, d_list, nlist, c->d_scratch, c->d_tw);
     else
         hipLaunchKernelGGL((k_coarse<13>), dim3(grid), dim3(CO_THREADS), 0, st, c->g, c->p, d_list, nlist, c->d_scratch, c->d_tw);
-}
-
-// number of A-steps (>=1) until channel ch's coarse estimate fires, given the counters before its next A-step
-static inline long long steps_to_trigger(const jaero_ctx *c, int ch, int cnt_before_first_a)
-{
-    const int nfft = c->g.nfft;
-    if (!(c->h_flags[ch] & JF_CPUREDUCE))
-    {
-        const int q = nfft / 4;
-        return q - (c->h_bbptr[ch] % q);
-    }
-    long long j0 = (long long)c->g.Fs_int - cnt_before_first_a + 1;
-    if (j0 < 1) j0 = 1;
-    const int r = nfft - (c->h_bbptr[ch] % nfft);
-    return j0 + r - 1;
 }
 
 extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layout, int is_device_ptr, void *stream)
@@ -675,69 +727,64 @@ extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int l
     int pos = 0;
     while (pos < nsamples)
     {
-        // earliest coarse trigger over all channels, in A-steps from the next unprocessed A
-        long long dmin = (long long)1 << 60;
-        for (int ch = 0; ch < nch; ch++)
-        {
-            const long long d = steps_to_trigger(c, ch, c->h_cnt[ch] + (c->pending ? 1 : 0));
-            if (d < dmin) dmin = d;
-        }
-        const int first_a = pos + (c->pending ? 1 : 0);      // sample index of the next A-step
-        const long long trig_sample = (long long)first_a + dmin - 1;
-        const bool trig = trig_sample < nsamples;
-        const int end = trig ? (int)trig_sample + 1 : nsamples; // segment = [pos, end)
-        const int n = end - pos;
-        const int acount = n - (c->pending ? 1 : 0);
-        const int bcount = n - (trig ? 1 : 0);
+        int n = 0, skip_a = 0, only_a = 0;
+        const long long nb_before = c->m.nB_total;
+        const int next = c->m.next_segment(pos, nsamples, n, skip_a, only_a);
         if (n > 0)
         {
+            const long long nb_after = c->m.nB_total;
+            c->m.nB_total = nb_before; // ring slots are those at the START of the segment
             const int pi = prof_begin(c, 0, st);
-            launch_samples(c, frames + (size_t)pos * stride, stride, n, c->pending, trig ? 1 : 0, st);
+            launch_samples(c, frames + (size_t)pos * stride, stride, n, skip_a, only_a, st);
             prof_end(c, pi, st);
+            c->m.nB_total = nb_after;
         }
-        // mirror update
-        c->h_list.clear();
-        for (int ch = 0; ch < nchp; ch++)
+        if (only_a)
         {
-            const int cnt0 = c->h_cnt[ch] + (c->pending ? 1 : 0);
-            long long fills;
-            if (!(c->h_flags[ch] & JF_CPUREDUCE)) fills = acount;
-            else
-            {
-                long long j0 = (long long)g.Fs_int - cnt0 + 1;
-                if (j0 < 1) j0 = 1;
-                fills = (long long)acount - (j0 - 1);
-                if (fills < 0) fills = 0;
-            }
-            const bool fired = trig && ch < nch && steps_to_trigger(c, ch, cnt0) == dmin;
-            c->h_bbptr[ch] = (int)((c->h_bbptr[ch] + fills) % g.nfft);
-            c->h_cnt[ch] += bcount;
-            if (fired) { c->h_cnt[ch] = 0; c->h_list.push_back(ch); }
-        }
-        c->nB_total += bcount;
-        if (trig)
-        {
-            const int nlist = (int)c->h_list.size();
+            const int nlist = (int)c->m.fired.size();
             const int *dl = nullptr;
             if (nlist != nch)
             {
-                HIPCHK(hipMemcpyAsync(c->d_chanlist, c->h_list.data(), sizeof(int) * nlist, hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemcpyAsync(c->d_chanlist, c->m.fired.data(), sizeof(int) * nlist, hipMemcpyHostToDevice, st));
                 dl = c->d_chanlist;
             }
             const int pi = prof_begin(c, 1, st);
             launch_coarse(c, dl, nlist, st);
             prof_end(c, pi, st);
-            c->pending = 1;
-            pos = end - 1; // resume with the B-part of the trigger sample
         }
-        else
-        {
-            c->pending = 0;
-            pos = end;
-        }
+        pos = next;
     }
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+// Host-only: the segmentation jaero_write would perform for one channel with the given flags over a sequence of
+// writes; returns the global sample indices at which the coarse estimate fires (used by CPU tests; no device needed).
+extern "C" int jaero_debug_schedule(int fft_power, int Fs, int cpu_reduce, const int *write_sizes, int nwrites,
+                                    long long *trigger_samples, int cap, int *segments_out)
+{
+    if (!write_sizes || !trigger_samples || fft_power < 4 || fft_power > 20) return fail(JAERO_EINVAL, "jaero_debug_schedule: bad arguments");
+    Mirror m;
+    m.nch = 1; m.nchp = 64; m.nfft = 1 << fft_power; m.Fs_int = Fs;
+    m.flags.assign(64, cpu_reduce ? JF_CPUREDUCE : 0); m.bbptr.assign(64, 0); m.cnt.assign(64, 0);
+    long long base = 0;
+    int ntrig = 0, nseg = 0;
+    for (int w = 0; w < nwrites; w++)
+    {
+        int pos = 0;
+        const int ns = write_sizes[w];
+        while (pos < ns)
+        {
+            int n, sa, oa;
+            const int next = m.next_segment(pos, ns, n, sa, oa);
+            nseg++;
+            if (oa) { if (ntrig < cap) trigger_samples[ntrig] = base + pos + n - 1; ntrig++; }
+            pos = next;
+        }
+        base += ns;
+    }
+    if (segments_out) *segments_out = nseg;
+    return ntrig;
 }
 
 // ------------------------------------------------------------------------------------------ outputs

@@ -1,0 +1,90 @@
+"""Regenerates the committed golden fixtures from the UNMODIFIED reference (oracle/_ref/jaero_ref).
+
+Run in the build container only (needs /root/reference + /opt/conda Qt):  python tests/golden/make_golden.py
+Each .npz holds the exact int16 PCM fed in, the driver options, and what the reference emitted
+(soft bits passed to processDemodulatedSoftBits; one status row per FreqOffsetEstimateSlot).
+fft_golden.npz holds the 16-point vectors of JAERO/tests/fftwrapper_tests.cpp:27-29 and
+JAERO/tests/fftrwrapper_tests.cpp:28-30, parsed from those files (numbers only).
+"""
+import os
+import re
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from jaero_amd import signalgen as G  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def save(name, pcm, kind, opts, ref):
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), pcm=pcm, kind=kind, opts=np.array(repr(opts)),
+                        soft=ref["soft"], status=ref["status"])
+    print(name, "pcm", pcm.shape, "soft", ref["soft"].shape, "status", ref["status"].shape)
+
+
+def main():
+    assert O.have_ref(), "build oracle/_ref first (make -C oracle ref)"
+    n = 72000  # 1.5 s
+    pcm, _ = G.oqpsk(n, fc=8037.5, ebno_db=12.0, seed=G.SEED_BASE + 1)
+    save("oqpsk_10k5_default", pcm, "oqpsk", {}, O.run_ref("oqpsk", pcm))
+    opts = dict(afc=1, chunk=1000, dcd_at=40000)
+    pcm, _ = G.oqpsk(n, fc=7961.0, ebno_db=9.0, seed=G.SEED_BASE + 2)
+    save("oqpsk_10k5_afc_chunk1000_dcd", pcm, "oqpsk", opts, O.run_ref("oqpsk", pcm, **opts))
+    pcm, _ = G.msk(n, fb=1200, fc=1012.0, ebno_db=14.0, seed=G.SEED_BASE + 3)
+    save("msk_1200_default", pcm, "msk", dict(fb=1200, lockingbw=1800), O.run_ref("msk", pcm, fb=1200, lockingbw=1800))
+    pcm, _ = G.msk(n, fb=600, fc=995.0, ebno_db=12.0, seed=G.SEED_BASE + 4)
+    opts = dict(fb=600, lockingbw=900, chunk=777, dcd_at=30000)
+    save("msk_600_chunk777_dcd", pcm, "msk", opts, O.run_ref("msk", pcm, **opts))
+    opts = dict(cpureduce=1)
+    pcm, _ = G.oqpsk(120000, fc=8020.0, ebno_db=12.0, seed=G.SEED_BASE + 5)
+    save("oqpsk_10k5_cpureduce", pcm, "oqpsk", opts, O.run_ref("oqpsk", pcm, **opts))
+
+    # the reference's bundled recordings through the continuous MSK demodulator: outputs only (inputs stay in
+    # /root/reference/samples; the test that uses them skips when that tree is absent)
+    import wave
+    for f in ("1200bps_burst_sample1.wav", "1200bps_burst_sample2.wav"):
+        w = wave.open("/root/reference/samples/" + f)
+        x = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+        r = O.run_ref("msk", x, fb=1200, lockingbw=1800)
+        np.savez_compressed(os.path.join(HERE, f.replace(".wav", "") + "_contmsk.npz"), nsamples=len(x),
+                            crc=np.uint32(np.bitwise_xor.reduce(x.astype(np.uint16).astype(np.uint32) * np.arange(1, len(x) + 1, dtype=np.uint32))),
+                            soft=r["soft"], status=r["status"])
+        print(f, len(x), r["soft"].shape)
+
+    # Viterbi through the reference's JConvolutionalCodec wrapper (libcorrect = oracle restatement: parity unpinned)
+    rng = np.random.default_rng(99)
+    msg = rng.integers(0, 256, size=3 * 317, dtype=np.uint8)
+    coded = O.encode_bits(msg)
+    nblk, blen = 3, 5078
+    coded = coded[: nblk * blen]
+    x = (coded.astype(float) * 2 - 1) + rng.normal(0, 0.6, coded.shape)
+    soft = np.clip(np.round(x * 50 + 128), 0, 255).astype(np.uint8)
+    out = O.ref_tool("viterbi_cont", soft, np.uint8, blocklen=blen, padding=24)
+    blen2 = 5072  # Decode_soft writes whole bytes: keep size/2 a multiple of 8 (jconvolutionalcodec.cpp:107-117)
+    out2 = O.ref_tool("viterbi_soft", soft[: 3 * blen2], np.uint8, blocklen=blen2)
+    np.savez_compressed(os.path.join(HERE, "viterbi_cont.npz"), soft=soft, blocklen=blen, padding=24, out_cont=out,
+                        blocklen_soft=blen2, out_soft=out2, msg=msg)
+    print("viterbi", soft.shape, out.shape, out2.shape)
+
+    # FFT golden vectors from the reference's own unit tests
+    def parse(path, name):
+        txt = open(path).read()
+        m = re.search(name + r"\s*=\s*\{(.*?)\};", txt, re.S)
+        body = m.group(1)
+        if "cpx_type" in body:
+            nums = re.findall(r"cpx_type\(([-0-9.e]+),([-0-9.e]+)\)", body)
+            return np.array([complex(float(a), float(b)) for a, b in nums])
+        return np.array([float(v) for v in body.split(",")])
+    t1 = "/root/reference/JAERO/tests/fftwrapper_tests.cpp"
+    t2 = "/root/reference/JAERO/tests/fftrwrapper_tests.cpp"
+    np.savez(os.path.join(HERE, "fft_golden.npz"),
+             c_input=parse(t1, "input"), c_forward=parse(t1, "expected_forward"), c_fb=parse(t1, "expected_forward_backwards"),
+             r_input=parse(t2, "input"), r_forward=parse(t2, "expected_forward"), r_fb=parse(t2, "expected_forward_backwards"))
+    print("fft golden ok")
+
+
+if __name__ == "__main__":
+    main()
