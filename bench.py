@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the demodulator hot path on N MI355X GPUs of one node (driver contract in the task).
+
+A "step" = one jaero_write of `--chunk` (4096) samples for every channel of the bank: one sample-loop kernel launch
+plus one coarse-frequency kernel launch (the reference runs its 2^14-point estimate every 4096 samples), on synthetic
+10.5 kbps OQPSK PCM that is already resident in HBM as interleaved frames.  Channels are sharded across ranks with
+no collective on the data path (weak scaling: `--channels` per GPU); the aggregate is all ranks' samples divided by
+the slowest rank's time.
+
+Printed JSON (one line, rank 0): metric Msamples/s (real 48 kHz PCM samples consumed per second, all channels),
+plus `roofline` for the dominant kernel (HIP-event timed inside libjaero_hip on the launch stream) and
+`cpu_baseline` (the unmodified reference, or the C port when the reference binary cannot run, on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes per input sample, continuous OQPSK 10.5k (fp64 state as in the reference)
+ALG_BYTES_SAMPLE_KERNEL = 2.0 + 16.0 + 16.0 + 0.44 + 0.5      # PCM + AGC ring r/w + coarse ring write + soft out + state
+ALG_BYTES_SAMPLE_KERNEL_EBNO = 32.0                           # optional EbNo rings (2 x read+write)
+ALG_BYTES_COARSE_KERNEL = 128.0                               # (ring read 256 KiB + y r/w 256 KiB) / 4096 samples
+ALG_BYTES_WHOLE_PATH = 163.0                                  # SURVEY.md 8(d) headline
+HBM_PEAK_GBS = 8000.0                                         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--channels", type=int, default=int(os.environ.get("JAERO_BENCH_CHANNELS", "16384")), help="channels per GPU")
+    ap.add_argument("--chunk", type=int, default=4096)
+    ap.add_argument("--ebno", type=int, default=1, help="run the EbNo meters (the reference always does)")
+    ap.add_argument("--ebno-db", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-samples", type=int, default=1_000_000, help="samples per core for the CPU baseline leg")
+    return ap.parse_args()
+
+
+def cpu_baseline(chunk: int):
+    """The reference's own CPU path timed on this box's host cores: one process per core (function-local statics
+    make instances unshareable), each demodulating `n` samples of the same kind of synthetic signal."""
+    from jaero_amd import signalgen as G
+    from oracle import oracle as O  # cpu_baseline leg only
+
+    ncores = os.cpu_count() or 1
+    n = ARGS.cpu_samples
+    pcm, _ = G.oqpsk(n, fc=8037.5, ebno_db=ARGS.ebno_db, seed=G.SEED_BASE + 77)
+    kind = "port"
+    use_ref = O.have_ref()
+    if use_ref:
+        try:
+            subprocess.check_output([O.REF_BIN, "fft", "/dev/null", "/dev/null", "n=1"], stderr=subprocess.STDOUT)
+        except Exception:
+            use_ref = False
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "in.s16")
+        pcm.tofile(path)
+        t0 = time.time()
+        if use_ref:
+            kind = "reference"
+            procs = [subprocess.Popen([O.REF_BIN, "time", "oqpsk", path, f"chunk={chunk}"], stdout=subprocess.PIPE) for _ in range(ncores)]
+            outs = [p.communicate()[0] for p in procs]
+            inner = [float(o.split()[0]) for o in outs]
+        else:
+            code = ("import sys,time,numpy as np; sys.path.insert(0,%r); from oracle import oracle as O; "
+                    "x=np.fromfile(%r,dtype=np.int16); d=O.Demod(O.oqpsk_settings()); t=time.time(); "
+                    "[d.write(x[s:s+%d]) for s in range(0,len(x),%d)]; print(time.time()-t)") % (ROOT, path, chunk, chunk)
+            procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE) for _ in range(ncores)]
+            outs = [p.communicate()[0] for p in procs]
+            inner = [float(o.split()[0]) for o in outs]
+        wall = time.time() - t0
+    # aggregate over cores: every core did n samples in `inner[i]` seconds of writeData time, concurrently
+    value = sum(n / t for t in inner) / 1e6
+    return {"value": round(value, 3), "unit": "Msamples/s", "cores": ncores, "kind": kind,
+            "sample": f"{n} samples of 48 kHz 10.5k OQPSK per core, {chunk}-sample writes, cpuReduce=false, "
+                      f"one process per core ({wall:.1f} s wall)",
+            "per_core_msps": round(value / ncores, 3),
+            "note": "FFT inside the reference build is the JFFT stand-in (oracle/ref/shim/jfft.h), not JFFT"}
+
+
+def ber_check(bank, bits, nch_check: int, tail: int = 3000):
+    """Hard decisions of the last `tail` symbols of a few channels against the transmitted bits (4 ambiguity states)."""
+    worst, locked = 0.0, 0
+    for c in range(nch_check):
+        soft = bank.read_softbits(c, cap=1 << 22)
+        st = bank.read_status(c)
+        locked += int(st.signal)
+        if len(soft) < 2 * tail + 64:
+            worst = 1.0
+            continue
+        hard = (soft >= 128).astype(np.uint8)
+        im, re = hard[0::2][-tail:], hard[1::2][-tail:]
+        b = bits[c].cpu().numpy()
+        arms = (b[0::2], b[1::2])
+        # both output streams must decode an arm: score the worse of (im best, re best)
+        def arm_ber(stream):
+            bb = 1.0
+            for arm in arms:
+                for lag in range(max(0, len(arm) - tail - 600), len(arm) - tail):
+                    e = float(np.mean(arm[lag:lag + tail] != stream))
+                    bb = min(bb, e, 1.0 - e)
+            return bb
+        worst = max(worst, arm_ber(im), arm_ber(re))
+    return worst, locked
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+
+    from jaero_amd import capi, signalgen
+    from jaero_amd import dist as jd
+    from jaero_amd.demodulator import DemodulatorBank, OqpskSettings
+
+    capi.lib()  # fail loudly if the HIP extension is missing
+    rank, world, local = jd.init_from_env()
+    assert world == ARGS.gpus or world == 1, (world, ARGS.gpus)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    nch, chunk, K, W = ARGS.channels, ARGS.chunk, ARGS.steps, ARGS.warmup
+    nsamp = (K + W) * chunk
+
+    # synthetic input, resident in HBM before anything is timed: interleaved frames [nsamp, nch]
+    lo, _ = jd.shard_range(nch * world, rank, world)
+    pcm, bits, _ = signalgen.oqpsk_torch(nch, nsamp, dev, ebno_db=ARGS.ebno_db, seed=signalgen.SEED_BASE + lo)
+    soft_cap = int(nsamp * 10500 / 48000) + 64
+    bank = DemodulatorBank(OqpskSettings(), nch, device=local, ebno=bool(ARGS.ebno), max_write_samples=chunk, softbit_capacity=soft_cap)
+    bank.set_flags(afc=False, sql=False, cpu_reduce=False)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        bank.write(pcm[i * chunk:(i + 1) * chunk], layout=capi.PCM_FRAME_MAJOR, stream=stream)
+
+    for i in range(W):
+        step(i)
+    torch.cuda.synchronize()
+    bank.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    samp_ms, samp_n = bank.profile_read(0)
+    coarse_ms, coarse_n = bank.profile_read(1)
+    total_samples = float(K) * chunk * nch * world
+    value = total_samples / dt / 1e6
+
+    ber, locked = ber_check(bank, bits, min(8, nch))
+    if world > 1:
+        # gather per-rank soft-bit counts on rank 0 (not timed): the only exchange step this path has
+        _, cnt_ptr, _ = bank.softbits_view()
+        st = bank.read_status(0)
+        flag = torch.tensor([st.n_estimates], dtype=torch.int32, device=dev)
+        gathered = [torch.zeros_like(flag) for _ in range(world)] if rank == 0 else None
+        dist.gather(flag, gathered, dst=0)
+
+    if rank == 0:
+        dom = "sample_loop" if samp_ms >= coarse_ms else "coarse_freq"
+        per_sample = (ALG_BYTES_SAMPLE_KERNEL + (ALG_BYTES_SAMPLE_KERNEL_EBNO if ARGS.ebno else 0.0)) if dom == "sample_loop" else ALG_BYTES_COARSE_KERNEL
+        launches = samp_n if dom == "sample_loop" else coarse_n
+        dom_ms = samp_ms if dom == "sample_loop" else coarse_ms
+        avg_ms = dom_ms / max(launches, 1)
+        units_per_launch = K * chunk * nch / max(launches, 1)   # samples one launch processes (this rank)
+        achieved = per_sample * units_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Msamples/s of real 48 kHz PCM through the 10.5 kbps OQPSK demodulator hot path",
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{nch}-channel-per-GPU synthetic 48 kHz 10.5 kbps OQPSK continuous (BASELINE configs[2] shape, "
+                                   f"scaled to {nch} channels so every SIMD of the 256 CUs holds a wavefront of 64 channels), "
+                                   f"{chunk}-sample writes, coarse 2^14 FFT every 4096 samples, AFC off, EbNo meters {'on' if ARGS.ebno else 'off'}, "
+                                   f"Eb/N0 {ARGS.ebno_db} dB",
+                       "channels_per_gpu": nch, "total_channels": nch * world, "chunk": chunk, "ebno_meters": bool(ARGS.ebno),
+                       "realtime_channel_equivalents": int(value / 0.048),
+                       "ber_tail_worst_of_checked": ber, "channels_checked": min(8, nch), "locked_of_checked": locked,
+                       "whole_path_hbm_frac_at_163B_per_sample": round(value * 1e6 * ALG_BYTES_WHOLE_PATH / 1e9 / (HBM_PEAK_GBS * world), 5),
+                       "kernel_ms_total": {"sample_loop": round(samp_ms, 3), "coarse_freq": round(coarse_ms, 3)},
+                       "kernel_launches": {"sample_loop": samp_n, "coarse_freq": coarse_n}},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "alg_bytes_per_sample": per_sample, "samples_per_launch": units_per_launch, "avg_launch_ms": round(avg_ms, 4)},
+        }
+        if world == 1 and not ARGS.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(chunk)
+            except Exception as e:  # never lose the GPU line because the CPU leg failed
+                line["cpu_baseline"] = {"value": None, "error": str(e)}
+        print(json.dumps(line), flush=True)
+    bank.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    ARGS = parse()
+    main()

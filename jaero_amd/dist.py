@@ -1,0 +1,98 @@
+"""Multi-GPU sharding: one process per GPU, channels partitioned contiguously, no collective on the data path.
+
+The demodulator path shards embarrassingly by channel (the reference even runs its two stereo burst
+channels as two unrelated objects, JAERO/audioburstoqpskdemodulator.cpp:8-10), so the steady state has NO exchange
+step.  torch.distributed (backend "nccl" = RCCL over xGMI on GPUs, "gloo" on CPU for tests) is used only for the two
+edge operations the north star names:
+  * fan_out_pcm : rank `src` holds one block of interleaved frames [nsamples, nch_total] and scatters each rank's
+                  contiguous channel slice to it;
+  * gather_softbits : fixed-size per-channel soft-bit slots (+counts) are gathered on rank `dst`.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+
+def shard_range(nch_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous channel range [lo, hi) of `rank`: ch in [rank*N/W, (rank+1)*N/W)."""
+    lo = (rank * nch_total) // world
+    hi = ((rank + 1) * nch_total) // world
+    return lo, hi
+
+
+def init_from_env(backend: Optional[str] = None):
+    """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* (as torchrun sets them); returns
+    (rank, world, local_rank).  With WORLD_SIZE unset or 1 nothing is initialised."""
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def fan_out_pcm(frames, nch_total: int, nsamples: int, src: int = 0, device=None):
+    """frames: int16 tensor [nsamples, nch_total] on rank `src` (ignored elsewhere).  Returns this rank's
+    [nsamples, hi-lo] slice (contiguous, on `device`)."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return frames
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lo, hi = shard_range(nch_total, rank, world)
+    if device is None:
+        device = frames.device if frames is not None else torch.device("cpu")
+    mine = torch.empty((nsamples, hi - lo), dtype=torch.int16, device=device)
+    # point-to-point (xGMI is point-to-point; the volumes are tiny next to one link): src sends each peer its slice
+    if rank == src:
+        reqs = []
+        for r in range(world):
+            l, h = shard_range(nch_total, r, world)
+            part = frames[:, l:h].contiguous()
+            if r == src:
+                mine.copy_(part)
+            else:
+                reqs.append(dist.isend(part, dst=r))
+        for q in reqs:
+            q.wait()
+    else:
+        dist.recv(mine, src=src)
+    return mine
+
+
+def gather_softbits(soft, counts, nch_total: int, dst: int = 0):
+    """soft: int16 [nch_local, cap], counts: int32 [nch_local] (same cap on every rank).  Returns on `dst`
+    (soft_all [nch_total, cap], counts_all [nch_total]); (None, None) elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return soft, counts
+    rank, world = dist.get_rank(), dist.get_world_size()
+    cap = soft.shape[1]
+    if rank == dst:
+        soft_all = torch.empty((nch_total, cap), dtype=soft.dtype, device=soft.device)
+        counts_all = torch.empty((nch_total,), dtype=counts.dtype, device=counts.device)
+        for r in range(world):
+            l, h = shard_range(nch_total, r, world)
+            if r == dst:
+                soft_all[l:h].copy_(soft)
+                counts_all[l:h].copy_(counts)
+            else:
+                dist.recv(soft_all[l:h], src=r)
+                dist.recv(counts_all[l:h], src=r)
+        return soft_all, counts_all
+    dist.send(soft.contiguous(), dst=dst)
+    dist.send(counts.contiguous(), dst=dst)
+    return None, None

@@ -127,3 +127,65 @@ def channel_bank(kind: str, nch: int, nsamples: int, *, ebno_db: float | None = 
         carriers[c] = fc
         bits_list.append(b)
     return pcm, carriers, bits_list
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# torch (device-resident) generator for large banks: same waveform family as `oqpsk` above
+# ----------------------------------------------------------------------------------------------------------------------
+def oqpsk_torch(nch: int, nsamples: int, device, *, fb: float = 10500.0, Fs: float = 48000.0, fc_center: float = 8000.0,
+                fc_spread: float = 100.0, ebno_db: float | None = 10.0, peak: float = 0.3, seed: int = SEED_BASE,
+                block: int = 2048):
+    """Returns (pcm int16 [nsamples, nch] frame-major on `device`, bits uint8 [nch, 2*nsym], carriers float64 [nch]).
+
+    Channel c: carrier fc_center + U(-fc_spread, fc_spread), random bits, AWGN at Eb/N0, as SURVEY.md 8(d) config 3.
+    """
+    import torch
+
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    T = Fs / (fb / 2.0)
+    nsym = int(np.ceil(nsamples / T)) + 16
+    bits = torch.randint(0, 2, (nch, 2 * nsym), generator=gen, device=device, dtype=torch.uint8)
+    a_i = bits[:, 0::2].to(torch.float32) * 2 - 1
+    a_q = bits[:, 1::2].to(torch.float32) * 2 - 1
+    carriers = fc_center + (torch.rand(nch, generator=gen, device=device, dtype=torch.float64) * 2 - 1) * fc_spread
+    out = torch.empty((nsamples, nch), dtype=torch.int16, device=device)
+    P = 1.0 / T  # signal power of unit-symbol OQPSK with a unit-energy RRC pulse
+    sigma = float(np.sqrt(P * Fs / (2.0 * fb * 10.0 ** (ebno_db / 10.0)))) if ebno_db is not None else 0.0
+    scale = peak / (3.0 * np.sqrt(P)) * 32768.0
+
+    def pulse(t):  # alpha = 1
+        x = 4.0 * t / T
+        den = 1.0 - x * x
+        safe_t = torch.where(t.abs() < 1e-9, torch.ones_like(t), t)
+        safe_den = torch.where(den.abs() < 1e-9, torch.ones_like(den), den)
+        reg = 4.0 / (np.pi * np.sqrt(T)) * (torch.cos(2.0 * np.pi * safe_t / T)) / safe_den  # sin((1-alpha)..)=0 for alpha=1
+        centre = (4.0 + np.pi - np.pi) / (np.pi * np.sqrt(T))
+        sing = ((np.pi - 2.0) * np.cos(np.pi / 4.0) + (np.pi + 2.0) * np.sin(np.pi / 4.0)) / (np.pi * np.sqrt(2.0 * T))
+        r = torch.where(den.abs() < 1e-9, torch.full_like(t, sing), reg)
+        return torch.where(t.abs() < 1e-9, torch.full_like(t, centre), r)
+
+    def shape(a, n, delay):
+        t = n - delay
+        k0 = torch.floor(t / T).to(torch.int64)
+        acc = torch.zeros((nch, n.shape[0]), dtype=torch.float32, device=device)
+        for j in range(-6, 8):
+            k = k0 + j
+            ok = (k >= 0) & (k < nsym)
+            kk = k.clamp(0, nsym - 1)
+            h = pulse((t - k.to(torch.float64) * T)).to(torch.float32) * ok.to(torch.float32)
+            acc += a[:, kk] * h[None, :]
+        return acc
+
+    for s in range(0, nsamples, block):
+        e = min(nsamples, s + block)
+        n = torch.arange(s, e, device=device, dtype=torch.float64)
+        i_t = shape(a_i, n, 0.0)
+        q_t = shape(a_q, n, T / 2.0)
+        ph = (2.0 * np.pi / Fs) * carriers[:, None] * n[None, :]
+        ph = torch.remainder(ph, 2.0 * np.pi).to(torch.float32)
+        x = i_t * torch.cos(ph) - q_t * torch.sin(ph)
+        if sigma > 0:
+            x = x + torch.randn(x.shape, generator=gen, device=device, dtype=torch.float32) * sigma
+        out[s:e] = torch.clamp(torch.round(x * scale), -32768, 32767).to(torch.int16).t()
+    return out, bits, carriers
