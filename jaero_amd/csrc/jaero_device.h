@@ -9,8 +9,9 @@
 //     once per sample for all lanes.
 //   * symbol-rate rings (marg, dt, pointmean, msema): [channel][slot]       -> per-lane positions (symbol instants
 //     are not aligned between channels).
-//   * coarse-frequency ring: [channel][nfft] packed {int16 pcm, uint16 NCO table index}; the coarse kernel rebuilds
-//     the reference's complex double bbcycbuff entry exactly as CIS[index] * (pcm/32768.0).
+//   * coarse-frequency ring: [channel][nfft] complex double = mixer_center.WTCISValue()*dval, as the reference's
+//     bbcycbuff (a packed {pcm, table index} form was tried first: its 4x-overlapped table gathers in the coarse kernel
+//     cost more than the 12 extra bytes per sample).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -80,7 +81,7 @@ struct JPtrs
     int *I;
     double *agc_ring;    // [ng][agc_len][64]
     double *eb_e, *eb_e2;// [ng][ebno_len][64]
-    uint32_t *bbring;    // [nchp][nfft]
+    double2 *bbring;     // [nchp][nfft] complex double, exactly the reference's bbcycbuff entries
     double *y;           // [nchp][nfft]
     double *marg;        // [nchp][marg_len]
     double2 *dt;         // [nchp][dt_len]

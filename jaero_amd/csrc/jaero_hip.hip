@@ -21,6 +21,7 @@
 #include "k_oqpsk.h"
 #include "k_msk.h"
 #include "k_coarse.h"
+#include "k_coarse2.h"
 #include "k_viterbi.h"
 
 static thread_local std::string g_last_error;
@@ -126,6 +127,8 @@ struct jaero_ctx
     double2 *d_tw = nullptr;
     int *d_chanlist = nullptr;
     int coarse_grid = 0;
+    bool coarse_v1 = false;  // JAERO_COARSE_V1=1 selects the four-step LDS/scratch FFT (kept for A/B validation)
+    int coarse2_grid = 0, coarse2_lds = 0;
     jaero_status *d_status = nullptr;
     int16_t *d_pack = nullptr; size_t pack_elems = 0;
     // host mirrors
@@ -197,8 +200,8 @@ __global__ void k_center_freq(const JGeom g, const JPtrs p, int ch_first, int nc
         S[(size_t)S_MC_FREQ * nchp] = mc_freq; S[(size_t)S_MC_STEP * nchp] = mc_step; S[(size_t)S_MC_PTR * nchp] = mc_ptr;
         S[(size_t)S_M2_FREQ * nchp] = m2_freq; S[(size_t)S_M2_STEP * nchp] = m2_step;
     }
-    uint32_t *ring = p.bbring + (size_t)ch * g.nfft;
-    for (int i = threadIdx.x; i < g.nfft; i += blockDim.x) ring[i] = 0; // bbcycbuff[j]=0
+    double2 *ring = p.bbring + (size_t)ch * g.nfft;
+    for (int i = threadIdx.x; i < g.nfft; i += blockDim.x) ring[i] = make_double2(0.0, 0.0); // bbcycbuff[j]=0
 }
 
 __global__ void k_status(const JGeom g, const JPtrs p, int ch_first, int n, jaero_status *out)
@@ -449,8 +452,15 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
     DA(c->d_pcm_raw, (size_t)max_write_samples * nchannels);
     DA(c->d_chanlist, nchp);
     DA(c->d_status, nchp);
+    c->coarse_v1 = getenv("JAERO_COARSE_V1") && atoi(getenv("JAERO_COARSE_V1")) != 0;
     c->coarse_grid = nchannels < 512 ? nchannels : 512;
-    DA(c->d_scratch, (size_t)c->coarse_grid * 2 * g.nfft);
+    if (c->coarse_v1) DA(c->d_scratch, (size_t)c->coarse_grid * 2 * g.nfft);
+    {
+        const int E = g.nfft / C2_THREADS;
+        const int a = E * 528, b = C2_THREADS * (E + 1);
+        c->coarse2_lds = (a > b ? a : b) * (int)sizeof(double);
+        c->coarse2_grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     DA(c->d_tw, g.nfft);
     double2 *d_cis = nullptr;
     double *d_taps = nullptr;
@@ -508,6 +518,8 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     }
+    if (g.nfft_log2 == 14) HIPCHK(hipFuncSetAttribute((const void *)k_coarse2<14>, hipFuncAttributeMaxDynamicSharedMemorySize, c->coarse2_lds));
+    else HIPCHK(hipFuncSetAttribute((const void *)k_coarse2<13>, hipFuncAttributeMaxDynamicSharedMemorySize, c->coarse2_lds));
     HIPCHK(hipDeviceSynchronize());
     *out = c;
     return 0;
@@ -688,6 +700,16 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
 
 static void launch_coarse(jaero_ctx *c, const int *d_list, int nlist, hipStream_t st)
 {
+    if (!c->coarse_v1)
+    {
+        // register-resident FFT: one workgroup per CU (512-VGPR budget, ~140 KB LDS), persistent over the list
+        const int grid2 = nlist < c->coarse2_grid ? nlist : c->coarse2_grid;
+        if (c->g.nfft_log2 == 14)
+            hipLaunchKernelGGL((k_coarse2<14>), dim3(grid2), dim3(C2_THREADS), c->coarse2_lds, st, c->g, c->p, d_list, nlist, c->d_tw);
+        else
+            hipLaunchKernelGGL((k_coarse2<13>), dim3(grid2), dim3(C2_THREADS), c->coarse2_lds, st, c->g, c->p, d_list, nlist, c->d_tw);
+        return;
+    }
     const int grid = nlist < c->coarse_grid ? nlist : c->coarse_grid;
     if (c->g.nfft_log2 == 14)
         hipLaunchKernelGGL((k_coarse<14>), dim3(grid), dim3(CO_THREADS), 0, st, c->g, c->p, d_list, nlist, c->d_scratch, c->d_tw);

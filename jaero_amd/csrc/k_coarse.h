@@ -102,6 +102,89 @@ __device__ void fft_four_step(Loader load, double2 *__restrict__ T, double2 *__r
     }
 }
 
+// Thread-0 epilogue of one estimate: emptyingcountdown (coarsefreqestimate.cpp:133-135), FreqOffsetEstimateSlot
+// (oqpskdemodulator.cpp:629-677 / mskdemodulator.cpp:490-519), coarseCounter reset, status row.  Returns 1 when the
+// AFC recentre fired (caller then performs bigchange(): y[i]=20 and zeroes the ring).
+__device__ __forceinline__ int coarse_slot(const JGeom &g, const JPtrs &p, int ch, int zmaxloc, int N, double hzperbin, double lockingbw)
+{
+    const int nchp = g.nchp;
+    int *I = p.I + ch;
+    double *S = p.S + ch;
+#define CI(f) I[(size_t)(f) * nchp]
+#define CS(f) S[(size_t)(f) * nchp]
+    double freq_offset_est = -((double)(zmaxloc - N / 2)) * hzperbin * 0.5;
+    int emptying = CI(I_EMPTYING);
+    if (emptying > 0) { emptying--; freq_offset_est = 0; }
+    CI(I_EMPTYING) = emptying;
+
+    const int flags = CI(I_FLAGS);
+    const bool afc = flags & JF_AFC, dcd = flags & JF_DCD;
+    const double mse = CS(S_MSE), thr = CS(S_THRESH);
+    double m2_freq = CS(S_M2_FREQ), m2_step = CS(S_M2_STEP);
+    double mc_freq = CS(S_MC_FREQ), mc_step = CS(S_MC_STEP);
+    int countdown = CI(I_COUNTDOWN);
+    bool big = false;
+    if (g.kind == 1) // OQPSK
+    {
+        int countdown2 = CI(I_COUNTDOWN2);
+        if ((mse < thr) && (!dcd))
+        {
+            if (countdown2 > 0) countdown2--;
+            else jd_wt_setfreq(m2_freq, m2_step, mc_freq + freq_offset_est, g.Fs);
+        }
+        else countdown2 = 5;
+        CI(I_COUNTDOWN2) = countdown2;
+        if ((mse > thr) && (fabs(m2_freq - (mc_freq + freq_offset_est)) > 3.0))
+            jd_wt_setfreq(m2_freq, m2_step, mc_freq + freq_offset_est, g.Fs);
+        if ((afc) && (mse < thr) && (fabs(m2_freq - mc_freq) > 3.0))
+        {
+            if (countdown > 0) countdown--;
+            else big = true;
+        }
+        else countdown = 4;
+    }
+    else // MSK
+    {
+        if ((mse > thr) && (fabs(m2_freq - (mc_freq + freq_offset_est)) > 0.0))
+            jd_wt_setfreq(m2_freq, m2_step, mc_freq + freq_offset_est, g.Fs);
+        if ((afc) && (dcd) && (fabs(m2_freq - mc_freq) > 2.0))
+        {
+            if (countdown > 0) countdown--;
+            else big = true;
+        }
+        else countdown = 4;
+    }
+    if (big)
+    {
+        const double lbw = lockingbw; // demodulator's lockingbw == estimator's (oqpsk passes 2*bw/2)
+        jd_wt_setfreq(mc_freq, mc_step, m2_freq, g.Fs);
+        if (mc_freq < lbw / 2.0) jd_wt_setfreq(mc_freq, mc_step, lbw / 2.0, g.Fs);
+        if (mc_freq > (g.Fs / 2.0 - lbw / 2.0)) jd_wt_setfreq(mc_freq, mc_step, g.Fs / 2.0 - lbw / 2.0, g.Fs);
+        CI(I_EMPTYING) = 4; // coarsefreqestimate->bigchange()
+    }
+    CI(I_COUNTDOWN) = countdown;
+    CS(S_M2_FREQ) = m2_freq; CS(S_M2_STEP) = m2_step;
+    CS(S_MC_FREQ) = mc_freq; CS(S_MC_STEP) = mc_step;
+    CI(I_COARSE_CNT) = 0; // :426 coarseCounter = 0
+    const int nest = CI(I_NEST);
+    if (g.flags & 2u)
+    {
+        const int lc = CI(I_LOG_CNT);
+        if (lc < g.log_cap)
+        {
+            double *row = p.slog + ((size_t)ch * g.log_cap + lc) * 6;
+            row[0] = (double)nest; row[1] = m2_freq; row[2] = mc_freq; row[3] = mse; row[4] = CS(S_EB_EBNO);
+            row[5] = (mse > thr) ? 0.0 : 1.0;
+            CI(I_LOG_CNT) = lc + 1;
+        }
+        else CI(I_OVERFLOW) = CI(I_OVERFLOW) | 4;
+    }
+    CI(I_NEST) = nest + 1;
+#undef CI
+#undef CS
+    return big ? 1 : 0;
+}
+
 template <int LOG2N>
 __global__ __launch_bounds__(CO_THREADS) void k_coarse(const JGeom g, const JPtrs p, const int *__restrict__ chan_list,
                                                        int nlist, double2 *__restrict__ scratch,
@@ -116,12 +199,11 @@ __global__ __launch_bounds__(CO_THREADS) void k_coarse(const JGeom g, const JPtr
     const int nchp = g.nchp;
     double2 *B = scratch + (size_t)blockIdx.x * 2 * N;
     double2 *T = B + N;
-    const double2 *__restrict__ cis = p.cis;
 
     for (int li = blockIdx.x; li < nlist; li += gridDim.x)
     {
         const int ch = chan_list ? chan_list[li] : li;
-        const uint32_t *__restrict__ ring = p.bbring + (size_t)ch * N;
+        const double2 *__restrict__ ring = p.bbring + (size_t)ch * N;
         const int bb_ptr = p.I[(size_t)I_BB_PTR * nchp + ch];
         const double lockingbw = p.S[(size_t)S_LOCKINGBW * nchp + ch];
         const double hzperbin = g.Fs / ((double)N);
@@ -131,12 +213,7 @@ __global__ __launch_bounds__(CO_THREADS) void k_coarse(const JGeom g, const JPtr
         double *__restrict__ y = p.y + (size_t)ch * N;
 
         // FFT 1: bbtmpbuff[j] = bbcycbuff[(ptr+j)%N] = CIS[idx] * dval
-        auto load_ring = [&](int j) -> double2 {
-            const uint32_t v = ring[(bb_ptr + j) & (N - 1)];
-            const double dval = ((double)(int16_t)(v & 0xffffu)) / 32768.0;
-            const double2 c = cis[v >> 16];
-            return make_double2(c.x * dval, c.y * dval);
-        };
+        auto load_ring = [&](int j) -> double2 { return ring[(bb_ptr + j) & (N - 1)]; };
         fft_four_step<LOG2N>(load_ring, T, B, tile, tw, false, tid);
         // IFFT of the band-limited spectrum (fb != 8400 boxcar branch, coarsefreqestimate.cpp:99)
         auto load_masked = [&](int i) -> double2 {
@@ -192,93 +269,13 @@ __global__ __launch_bounds__(CO_THREADS) void k_coarse(const JGeom g, const JPtr
             __syncthreads();
         }
 
-        if (tid == 0)
-        {
-            int *I = p.I + ch;
-            double *S = p.S + ch;
-#define CI(f) I[(size_t)(f) * nchp]
-#define CS(f) S[(size_t)(f) * nchp]
-            const int zmaxloc = (red_idx[0] >= 0) ? red_idx[0] : (N / 2);
-            double freq_offset_est = -((double)(zmaxloc - N / 2)) * hzperbin * 0.5;
-            int emptying = CI(I_EMPTYING);
-            if (emptying > 0) { emptying--; freq_offset_est = 0; }
-            CI(I_EMPTYING) = emptying;
-
-            // ---- FreqOffsetEstimateSlot ----
-            const int flags = CI(I_FLAGS);
-            const bool afc = flags & JF_AFC, dcd = flags & JF_DCD;
-            const double mse = CS(S_MSE), thr = CS(S_THRESH);
-            double m2_freq = CS(S_M2_FREQ), m2_step = CS(S_M2_STEP);
-            double mc_freq = CS(S_MC_FREQ), mc_step = CS(S_MC_STEP);
-            int countdown = CI(I_COUNTDOWN);
-            bool big = false;
-            if (g.kind == 1) // OQPSK (oqpskdemodulator.cpp:629-677)
-            {
-                int countdown2 = CI(I_COUNTDOWN2);
-                if ((mse < thr) && (!dcd))
-                {
-                    if (countdown2 > 0) countdown2--;
-                    else jd_wt_setfreq(m2_freq, m2_step, mc_freq + freq_offset_est, g.Fs);
-                }
-                else countdown2 = 5;
-                CI(I_COUNTDOWN2) = countdown2;
-                if ((mse > thr) && (fabs(m2_freq - (mc_freq + freq_offset_est)) > 3.0))
-                    jd_wt_setfreq(m2_freq, m2_step, mc_freq + freq_offset_est, g.Fs);
-                if ((afc) && (mse < thr) && (fabs(m2_freq - mc_freq) > 3.0))
-                {
-                    if (countdown > 0) countdown--;
-                    else big = true;
-                }
-                else countdown = 4;
-            }
-            else // MSK (mskdemodulator.cpp:490-519)
-            {
-                if ((mse > thr) && (fabs(m2_freq - (mc_freq + freq_offset_est)) > 0.0))
-                    jd_wt_setfreq(m2_freq, m2_step, mc_freq + freq_offset_est, g.Fs);
-                if ((afc) && (dcd) && (fabs(m2_freq - mc_freq) > 2.0))
-                {
-                    if (countdown > 0) countdown--;
-                    else big = true;
-                }
-                else countdown = 4;
-            }
-            if (big)
-            {
-                const double lbw = lockingbw; // demodulator's lockingbw == estimator's (oqpsk passes 2*bw/2)
-                jd_wt_setfreq(mc_freq, mc_step, m2_freq, g.Fs);
-                if (mc_freq < lbw / 2.0) jd_wt_setfreq(mc_freq, mc_step, lbw / 2.0, g.Fs);
-                if (mc_freq > (g.Fs / 2.0 - lbw / 2.0)) jd_wt_setfreq(mc_freq, mc_step, g.Fs / 2.0 - lbw / 2.0, g.Fs);
-                CI(I_EMPTYING) = 4; // coarsefreqestimate->bigchange()
-            }
-            CI(I_COUNTDOWN) = countdown;
-            CS(S_M2_FREQ) = m2_freq; CS(S_M2_STEP) = m2_step;
-            CS(S_MC_FREQ) = mc_freq; CS(S_MC_STEP) = mc_step;
-            CI(I_COARSE_CNT) = 0; // :426 coarseCounter = 0
-            // status (emitted at the end of the slot)
-            const int nest = CI(I_NEST);
-            if (g.flags & 2u)
-            {
-                const int lc = CI(I_LOG_CNT);
-                if (lc < g.log_cap)
-                {
-                    double *row = p.slog + ((size_t)ch * g.log_cap + lc) * 6;
-                    row[0] = (double)nest; row[1] = m2_freq; row[2] = mc_freq; row[3] = mse; row[4] = CS(S_EB_EBNO);
-                    row[5] = (mse > thr) ? 0.0 : 1.0;
-                    CI(I_LOG_CNT) = lc + 1;
-                }
-                else CI(I_OVERFLOW) = CI(I_OVERFLOW) | 4;
-            }
-            CI(I_NEST) = nest + 1;
-            sh_bigchange = big ? 1 : 0;
-#undef CI
-#undef CS
-        }
+        if (tid == 0) sh_bigchange = coarse_slot(g, p, ch, (red_idx[0] >= 0) ? red_idx[0] : (N / 2), N, hzperbin, lockingbw);
         __syncthreads();
         if (sh_bigchange)
         {
             // bigchange(): y[i]=20 ; bbcycbuff[j]=0
-            uint32_t *ringw = p.bbring + (size_t)ch * N;
-            for (int i = tid; i < N; i += CO_THREADS) { y[i] = 20; ringw[i] = 0; }
+            double2 *ringw = p.bbring + (size_t)ch * N;
+            for (int i = tid; i < N; i += CO_THREADS) { y[i] = 20; ringw[i] = make_double2(0.0, 0.0); }
         }
         __syncthreads();
     }

@@ -1,0 +1,311 @@
+// k_coarse2.h -- register-resident coarse frequency estimator (replaces the four-step LDS/scratch version).
+//
+// Same function as k_coarse.h (CoarseFreqEstimate::ProcessBasebandData + FreqOffsetEstimateSlot,
+// JAERO/coarsefreqestimate.cpp:90-137, JAERO/oqpskdemodulator.cpp:629-677, JAERO/mskdemodulator.cpp:490-519), but the
+// three N-point fp64 FFTs never leave the chip:
+//   * one 512-thread workgroup per channel-estimate (2 waves per SIMD, <=256 VGPRs each), each thread holds
+//     E = N/512 complex points (E = 32 for N = 2^14, 16 for 2^13) in VGPRs;
+//   * N = E x 32 x 16: an E-point FFT per thread in registers, exchange through LDS, 32-point FFTs in registers,
+//     exchange, 16-point FFTs -- real and imaginary planes are exchanged one after the other so the exchange buffer is
+//     N doubles (padded: 135 KB for N = 2^14), LDS strides chosen bank-conflict free for ds_write_b64 / ds_read_b64;
+//   * the output distribution of one transform (thread v holds bins k = v mod 512) is exactly the input distribution of
+//     the next, so FFT -> band-limit mask -> IFFT -> square -> FFT -> |.| -> dB smoothing runs register to register;
+//     the inverse transform is the forward one with real/imag planes swapped (unnormalised, as FFTWrapper's x N / N).
+// HBM traffic per estimate: the packed ring (4 B/sample) + y[] read/write; algorithmic bytes: 524 288 B.
+#pragma once
+#include "jaero_device.h"
+#include "fft_consts.h"
+#include "k_coarse.h"
+
+#define C2_THREADS 512
+
+template <int L>
+struct CV
+{
+    double r[L], i[L];
+};
+
+// y = x * W_64^IDX  (IDX is a compile-time constant after unrolling)
+__device__ __forceinline__ void cmul_w64(double &re, double &im, int idx)
+{
+#pragma clang fp contract(fast)
+    idx &= 63;
+    if (idx == 0) return;
+    if (idx == 16) { const double t = re; re = im; im = -t; return; }   // * (-i)
+    if (idx == 32) { re = -re; im = -im; return; }
+    if (idx == 48) { const double t = re; re = -im; im = t; return; }   // * (+i)
+    const double wr = JD_W64R[idx], wi = JD_W64I[idx];
+    const double nr = re * wr - im * wi;
+    const double ni = re * wi + im * wr;
+    re = nr; im = ni;
+}
+
+// forward DFT of length L held in registers (radix-4 decimation in frequency, radix-2 tail), natural order in & out
+template <int L>
+__device__ __forceinline__ void regfft(const CV<L> &x, CV<L> &y)
+{
+#pragma clang fp contract(fast)
+    if constexpr (L == 1) { y.r[0] = x.r[0]; y.i[0] = x.i[0]; }
+    else if constexpr (L == 2)
+    {
+        y.r[0] = x.r[0] + x.r[1]; y.i[0] = x.i[0] + x.i[1];
+        y.r[1] = x.r[0] - x.r[1]; y.i[1] = x.i[0] - x.i[1];
+    }
+    else
+    {
+        constexpr int Q = L / 4;
+        CV<Q> u0, u1, u2, u3, z0, z1, z2, z3;
+#pragma unroll
+        for (int j = 0; j < Q; j++)
+        {
+            const double ar = x.r[j], ai = x.i[j], br = x.r[j + Q], bi = x.i[j + Q];
+            const double cr = x.r[j + 2 * Q], ci = x.i[j + 2 * Q], dr = x.r[j + 3 * Q], di = x.i[j + 3 * Q];
+            const double t0r = ar + cr, t0i = ai + ci, t1r = ar - cr, t1i = ai - ci;
+            const double t2r = br + dr, t2i = bi + di;
+            const double t3r = (bi - di), t3i = -(br - dr); // -i (b - d)
+            u0.r[j] = t0r + t2r; u0.i[j] = t0i + t2i;
+            double v1r = t1r + t3r, v1i = t1i + t3i, v2r = t0r - t2r, v2i = t0i - t2i, v3r = t1r - t3r, v3i = t1i - t3i;
+            cmul_w64(v1r, v1i, j * (64 / L));
+            cmul_w64(v2r, v2i, 2 * j * (64 / L));
+            cmul_w64(v3r, v3i, 3 * j * (64 / L));
+            u1.r[j] = v1r; u1.i[j] = v1i; u2.r[j] = v2r; u2.i[j] = v2i; u3.r[j] = v3r; u3.i[j] = v3i;
+        }
+        regfft<Q>(u0, z0); regfft<Q>(u1, z1); regfft<Q>(u2, z2); regfft<Q>(u3, z3);
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+        {
+            y.r[4 * q + 0] = z0.r[q]; y.i[4 * q + 0] = z0.i[q];
+            y.r[4 * q + 1] = z1.r[q]; y.i[4 * q + 1] = z1.i[q];
+            y.r[4 * q + 2] = z2.r[q]; y.i[4 * q + 2] = z2.i[q];
+            y.r[4 * q + 3] = z3.r[q]; y.i[4 * q + 3] = z3.i[q];
+        }
+    }
+}
+
+__device__ __forceinline__ double2 cmul2(const double2 a, const double2 b)
+{
+#pragma clang fp contract(fast)
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// tws[k] = base * step^k for k < 32, from two table values, by products of depth <= 6 (no per-element table gathers:
+// 64 distinct 16-byte addresses per wave instruction were what bounded the first version of this kernel).
+template <int E>
+__device__ __forceinline__ void twiddle_powers(const double2 base, const double2 step, double2 (&B)[4], double2 (&A)[8])
+{
+    const double2 s2 = cmul2(step, step), s3 = cmul2(s2, step), s4 = cmul2(s2, s2);
+    B[0] = base; B[1] = cmul2(base, step); B[2] = cmul2(base, s2); B[3] = cmul2(base, s3);
+    A[0] = make_double2(1.0, 0.0);
+    A[1] = s4; A[2] = cmul2(s4, s4); A[3] = cmul2(A[2], s4); A[4] = cmul2(A[2], A[2]);
+    A[5] = cmul2(A[4], s4); A[6] = cmul2(A[3], A[3]); A[7] = cmul2(A[4], A[3]);
+}
+
+// In-place forward N-point DFT of the workgroup's data, 512 threads, N = E x 32 x 16 (E = N/512 = 32 or 16).
+// On entry thread t holds x[s*512 + t] in slot s (s < E); on exit thread t holds X[s*512 + t] in slot s.
+// xch: LDS exchange buffer of max(E*528, 512*(E+1)) doubles.
+template <int LOG2N>
+__device__ __forceinline__ void wg_fft(CV<(1 << LOG2N) / C2_THREADS> &d, double *xch, const double2 *__restrict__ tw, int t)
+{
+#pragma clang fp contract(fast)
+    constexpr int N = 1 << LOG2N;
+    constexpr int E = N / C2_THREADS;          // 32 or 16
+    constexpr int LOGE = (E == 32) ? 5 : 4;
+    constexpr int G3 = E / 16;                 // 16-point FFTs per thread in pass 3
+    constexpr int S1 = 528, S2 = E + 1;
+    const int n3 = t & 15, n2 = t >> 4;        // pass-1 identity of this thread: (n2, n3) = n mod 512
+
+    // ---- pass 1: E-point FFT over n1, twiddle W_N^(16*n2*k1) ----
+    {
+        CV<E> a;
+        regfft<E>(d, a);
+        double2 B[4], A[8];
+        twiddle_powers<E>(make_double2(1.0, 0.0), tw[(16 * n2) & (N - 1)], B, A);
+#pragma unroll
+        for (int k1 = 0; k1 < E; k1++)
+        {
+            const double2 w = (k1 < 4) ? B[k1 & 3] : cmul2(A[k1 >> 2], B[k1 & 3]);
+            d.r[k1] = a.r[k1] * w.x - a.i[k1] * w.y;
+            d.i[k1] = a.r[k1] * w.y + a.i[k1] * w.x;
+        }
+    }
+    // ---- exchange 1: L1[k1][n2][n3] (k1 stride 528); pass-2 thread u: n3 = u&15, k1 = u>>4 (active if k1 < E) ----
+    CV<32> b;
+    const int k1u = t >> 4;
+    const bool act2 = k1u < E;
+    {
+        __syncthreads();
+#pragma unroll
+        for (int k1 = 0; k1 < E; k1++) xch[k1 * S1 + t] = d.r[k1];
+        __syncthreads();
+        if (act2)
+        {
+#pragma unroll
+            for (int m = 0; m < 32; m++) b.r[m] = xch[k1u * S1 + m * 16 + n3];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k1 = 0; k1 < E; k1++) xch[k1 * S1 + t] = d.i[k1];
+        __syncthreads();
+        if (act2)
+        {
+#pragma unroll
+            for (int m = 0; m < 32; m++) b.i[m] = xch[k1u * S1 + m * 16 + n3];
+        }
+    }
+    // ---- pass 2: 32-point FFT over n2, twiddle W_N^(n3*(k1 + E*k2)) ----
+    if (act2)
+    {
+        CV<32> c;
+        regfft<32>(b, c);
+        double2 B[4], A[8];
+        twiddle_powers<E>(tw[(n3 * k1u) & (N - 1)], tw[(n3 * E) & (N - 1)], B, A);
+#pragma unroll
+        for (int k2 = 0; k2 < 32; k2++)
+        {
+            const double2 w = (k2 < 4) ? B[k2 & 3] : cmul2(A[k2 >> 2], B[k2 & 3]);
+            b.r[k2] = c.r[k2] * w.x - c.i[k2] * w.y;
+            b.i[k2] = c.r[k2] * w.y + c.i[k2] * w.x;
+        }
+    }
+    // ---- exchange 2: M[(k2*16 + n3)][k1] (row stride E+1); pass-3 thread v: k1 = v & (E-1), k2 = (v >> LOGE) + (512/E) r ----
+    {
+        const int k1v = t & (E - 1), k2b = t >> LOGE;
+        CV<16> c[G3];
+        __syncthreads();
+        if (act2)
+        {
+#pragma unroll
+            for (int k2 = 0; k2 < 32; k2++) xch[(k2 * 16 + n3) * S2 + k1u] = b.r[k2];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < G3; r++)
+#pragma unroll
+            for (int m = 0; m < 16; m++) c[r].r[m] = xch[((k2b + (C2_THREADS / E) * r) * 16 + m) * S2 + k1v];
+        __syncthreads();
+        if (act2)
+        {
+#pragma unroll
+            for (int k2 = 0; k2 < 32; k2++) xch[(k2 * 16 + n3) * S2 + k1u] = b.i[k2];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < G3; r++)
+#pragma unroll
+            for (int m = 0; m < 16; m++) c[r].i[m] = xch[((k2b + (C2_THREADS / E) * r) * 16 + m) * S2 + k1v];
+        // ---- pass 3: 16-point FFT over n3; X[k1 + E*k2 + 32E*k3] -> slot r + G3*k3 ----
+#pragma unroll
+        for (int r = 0; r < G3; r++)
+        {
+            CV<16> o;
+            regfft<16>(c[r], o);
+#pragma unroll
+            for (int k3 = 0; k3 < 16; k3++) { d.r[r + G3 * k3] = o.r[k3]; d.i[r + G3 * k3] = o.i[k3]; }
+        }
+    }
+}
+
+template <int LOG2N>
+__global__ __launch_bounds__(C2_THREADS) void k_coarse2(const JGeom g, const JPtrs p, const int *__restrict__ chan_list,
+                                                           int nlist, const double2 *__restrict__ tw)
+{
+    constexpr int N = 1 << LOG2N;
+    constexpr int E = N / C2_THREADS;
+    extern __shared__ __attribute__((aligned(16))) double xch[];
+    __shared__ double red_val[C2_THREADS];
+    __shared__ int red_idx[C2_THREADS];
+    __shared__ int sh_bigchange;
+    const int t = threadIdx.x;
+    const int nchp = g.nchp;
+
+    for (int li = blockIdx.x; li < nlist; li += gridDim.x)
+    {
+        const int ch = chan_list ? chan_list[li] : li;
+        const double2 *__restrict__ ring = p.bbring + (size_t)ch * N;
+        const int bb_ptr = p.I[(size_t)I_BB_PTR * nchp + ch];
+        const double lockingbw = p.S[(size_t)S_LOCKINGBW * nchp + ch];
+        const double hzperbin = g.Fs / ((double)N);
+        const int startbin = (int)fmax(round(lockingbw / hzperbin), 1.0);
+        const int stopbin = N - startbin;
+        const int expectedpeakbin = (int)round(g.fb / (2.0 * hzperbin));
+        double *__restrict__ y = p.y + (size_t)ch * N;
+
+        CV<E> d;
+        // bbtmpbuff[j] = bbcycbuff[(ptr+j)%N] = CIS[idx] * dval   (time order)
+#pragma unroll
+        for (int s = 0; s < E; s++)
+        {
+            const double2 v = ring[(bb_ptr + s * C2_THREADS + t) & (N - 1)];
+            d.r[s] = v.x; d.i[s] = v.y;
+        }
+        wg_fft<LOG2N>(d, xch, tw, t);
+        // band limit (fb != 8400 boxcar, coarsefreqestimate.cpp:99) then inverse transform = forward on swapped planes
+#pragma unroll
+        for (int s = 0; s < E; s++)
+        {
+            const int k = s * C2_THREADS + t;
+            const bool z = (k >= startbin) && (k <= stopbin);
+            const double re = z ? 0.0 : d.r[s], im = z ? 0.0 : d.i[s];
+            d.r[s] = im; d.i[s] = re;
+        }
+        wg_fft<LOG2N>(d, xch, tw, t);
+        // swap back (x N / N = 1), square
+#pragma unroll
+        for (int s = 0; s < E; s++)
+        {
+            const double re = d.i[s], im = d.r[s];
+            d.r[s] = re * re - im * im;
+            d.i[s] = re * im + im * re;
+        }
+        wg_fft<LOG2N>(d, xch, tw, t);
+        // smooth with fftshift: y[i] = y[i]*0.9 + 0.1*10*log10(fmax(abs(out[i]),1)), out[i] = X[i ^ N/2]
+#pragma unroll
+        for (int s = 0; s < E; s++)
+        {
+            const int k = s * C2_THREADS + t;
+            const int i = k ^ (N / 2);
+            y[i] = y[i] * 0.9 + (0.1 * 10) * log10(fmax(hypot(d.r[s], d.i[s]), 1.0));
+        }
+        __syncthreads();
+
+        // fold + peak search (:116-131)
+        const int i0 = (int)round((-lockingbw / hzperbin) + ((double)(N / 2)));
+        const int i1 = (int)round((lockingbw / hzperbin) + ((double)(N / 2)));
+        double best = 0;
+        int besti = -1;
+        for (int i = i0 + t; i < i1; i += C2_THREADS)
+        {
+            if ((i < 0) || (i >= N)) continue;
+            double val = 0;
+            for (int j = -1; j <= 1; j++)
+            {
+                if (((i - expectedpeakbin - j) < 0) || ((i + expectedpeakbin + j) >= N)) continue;
+                val += (y[i - expectedpeakbin - j] + y[i + expectedpeakbin + j]);
+            }
+            if (val > best) { best = val; besti = i; }
+        }
+        red_val[t] = best;
+        red_idx[t] = besti;
+        __syncthreads();
+        for (int s = C2_THREADS / 2; s > 0; s >>= 1)
+        {
+            if (t < s)
+            {
+                const double ov = red_val[t + s];
+                const int oi = red_idx[t + s];
+                const double mv = red_val[t];
+                const int mi = red_idx[t];
+                if (oi >= 0 && (mi < 0 || ov > mv || (ov == mv && oi < mi))) { red_val[t] = ov; red_idx[t] = oi; }
+            }
+            __syncthreads();
+        }
+        if (t == 0) sh_bigchange = coarse_slot(g, p, ch, (red_idx[0] >= 0) ? red_idx[0] : (N / 2), N, hzperbin, lockingbw);
+        __syncthreads();
+        if (sh_bigchange)
+        {
+            double2 *ringw = p.bbring + (size_t)ch * N;
+            for (int i = t; i < N; i += C2_THREADS) { y[i] = 20; ringw[i] = make_double2(0.0, 0.0); }
+        }
+        __syncthreads();
+    }
+}

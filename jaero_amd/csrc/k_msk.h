@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
 
     const double samplerate = g.Fs;
     const int nfft_mask = g.nfft - 1;
-    uint32_t *__restrict__ bbring = p.bbring + (size_t)ch * g.nfft;
+    double2 *__restrict__ bbring = p.bbring + (size_t)ch * g.nfft;
     double *__restrict__ agc_ring = p.agc_ring + (size_t)grp * g.agc_len * 64 + lane;
     double *__restrict__ ebe_ring = p.eb_e + (size_t)grp * g.ebno_len * 64 + lane;
     double *__restrict__ ebe2_ring = p.eb_e2 + (size_t)grp * g.ebno_len * 64 + lane;
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
             const bool fill = (coarse_cnt >= g.Fs_int) || !(flags & JF_CPUREDUCE);
             if (fill)
             {
-                const uint32_t idx = (uint32_t)jd_cisidx(mc_ptr);
-                bbring[bb_ptr] = ((uint32_t)(uint16_t)s) | (idx << 16);
+                const double2 cc = cis[jd_cisidx(mc_ptr)];
+                bbring[bb_ptr] = make_double2(cc.x * dval, cc.y * dval);
                 bb_ptr = (bb_ptr + 1) & nfft_mask;
             }
         }
