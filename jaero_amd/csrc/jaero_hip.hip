@@ -41,6 +41,8 @@ static int fail(int code, const char *fmt, ...)
         if (_e != hipSuccess) return fail(JAERO_EHIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
+#define OQ_LDSN 40 // matched-filter history slots kept in LDS (rest in VGPRs): 40 KiB per wavefront -> 4 wavefronts per CU
+
 struct ProfSlot { double ms = 0; int launches = 0; };
 
 // Host mirror of the two integer counters that decide WHEN the reference runs its coarse-frequency estimate
@@ -679,13 +681,13 @@ extern "C" int jaero_profile_read(jaero_ctx *c, int which, double *total_ms, int
 static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int n, int skipA, int onlyA, hipStream_t st)
 {
     const JGeom &g = c->g;
-    const int lds = 2 * g.fir_n * 64 * (int)sizeof(double);
+    const int lds = 2 * (g.kind == JAERO_KIND_OQPSK ? OQ_LDSN : g.fir_n) * 64 * (int)sizeof(double);
     const bool eb = (c->flags & JAERO_FLAG_EBNO) != 0, cs = (c->flags & JAERO_FLAG_CAPTURE_SYMBOLS) != 0;
     const dim3 grid(g.ngroups), block(64);
     if (g.kind == JAERO_KIND_OQPSK)
     {
-        const int fs = (int)(c->m.nB_total % 55);
-#define LO(E, C) hipLaunchKernelGGL((k_oqpsk_samples<55, E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs)
+        const int fs = (int)(c->m.nB_total % OQ_LDSN);
+#define LO(E, C) hipLaunchKernelGGL((k_oqpsk_samples<55, OQ_LDSN, E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs)
         if (eb && cs) LO(true, true); else if (eb) LO(true, false); else if (cs) LO(false, true); else LO(false, false);
 #undef LO
     }

@@ -2,7 +2,7 @@
 //
 // Re-implements OqpskDemodulator::writeData's per-sample loop (JAERO/oqpskdemodulator.cpp:388-605, fb>8400 branch)
 // for 64 channels per wavefront, one channel per lane.  Per-sample stages (SURVEY.md 2.1 numbering):
-//   K1 PCM->double, K3 coarse ring fill, K2 NCO mix, K6 RRC matched filter (ring in LDS, taps via scalar loads),
+//   K1 PCM->double, K3 coarse ring fill, K2 NCO mix, K6 RRC matched filter (history in LDS + VGPR tail, taps via scalar loads),
 //   K7 EbNo meter (optional), K8 AGC + clip, K9 symbol-timing detector + PLL, K10 sample instant + interpolation,
 //   K11 carrier loop, K12 residual rotation, K13 MSE lock detector, K14 soft-bit demap.
 // The coarse-frequency estimate (K4/K5) runs in k_coarse.h between two launches of this kernel, at exactly the
@@ -13,13 +13,20 @@
 #define LDF(f) (p.S[(size_t)(f) * nchp + ch])
 #define LDI(f) (p.I[(size_t)(f) * nchp + ch])
 
-template <int FIRN, bool EBNO, bool CAPSYM>
+// Matched-filter history: the LDSN most recent mixed samples of each arm live in LDS ([slot][lane], wave-uniform slot),
+// the FIRN-LDSN oldest ones in a VGPR shift register.  LDSN = 40 makes the ring 40 KiB per wavefront, so four
+// wavefronts (one per SIMD) fit a CU's 160 KiB.  The filter output for sample n+1 depends only on inputs up to sample n
+// (FIR::FIRUpdateAndProcess excludes the newest sample, DSP.cpp:292-304), so it is evaluated one iteration ahead of the
+// serial AGC/timing/carrier chain and overlaps with it.
+template <int FIRN, int LDSN, bool EBNO, bool CAPSYM>
 __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs p, const int16_t *__restrict__ pcm,
                                                       int pcm_stride, int n, int skip_a_first, int only_a_last, int fir_slot0)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *lre = lds;              // [FIRN][64]
-    double *lim = lds + FIRN * 64;  // [FIRN][64]
+    double *lre = lds;              // [LDSN][64]
+    double *lim = lds + LDSN * 64;  // [LDSN][64]
+    constexpr int TAILN = FIRN - LDSN;
+    double tre[TAILN], tim[TAILN];  // tre[j] = x_re[n-LDSN-j] once x[n] has been pushed
 
     const int lane = threadIdx.x;
     const int grp = blockIdx.x;
@@ -63,16 +70,47 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
     double *__restrict__ msema_ring = p.msema + (size_t)ch * g.msema_len;
     int16_t *__restrict__ soft = p.soft + (size_t)ch * g.soft_cap;
 
-    // ---- matched-filter rings -> LDS (each lane owns one column: no barrier needed) ----
+    // ---- matched-filter history -> LDS + registers (each lane owns one LDS column: no barrier needed) ----
     {
         const double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
-        for (int k = 0; k < FIRN; k++)
+        for (int k = 0; k < LDSN; k++)
         {
             lre[k * 64 + lane] = fs[(size_t)k * 64];
             lim[k * 64 + lane] = fs[(size_t)(FIRN + k) * 64];
         }
+#pragma unroll
+        for (int j = 0; j < TAILN; j++)
+        {
+            tre[j] = fs[(size_t)(LDSN + j) * 64];
+            tim[j] = fs[(size_t)(FIRN + LDSN + j) * 64];
+        }
     }
-    int fir_slot = fir_slot0; // wave-uniform: slot holding x[n-FIRN], overwritten by x[n]
+    int fir_slot = fir_slot0; // wave-uniform: LDS slot holding the oldest LDS entry, overwritten by the next input
+
+    // filter output for the current sample from the history x[n-FIRN .. n-1]: taps[i] <-> x[n-FIRN+i]
+    auto fir_eval = [&](double &ore, double &oim) {
+        double are = 0, aim = 0;
+#pragma unroll
+        for (int j = TAILN - 1; j >= 0; j--)
+        {
+            const double tp = taps[TAILN - 1 - j];
+            are = fma(tp, tre[j], are);
+            aim = fma(tp, tim[j], aim);
+        }
+        int slot = fir_slot;
+#pragma unroll 8
+        for (int k = 0; k < LDSN; k++)
+        {
+            const double tp = taps[TAILN + k];
+            are = fma(tp, lre[slot * 64 + lane], are);
+            aim = fma(tp, lim[slot * 64 + lane], aim);
+            slot++;
+            if (slot >= LDSN) slot = 0;
+        }
+        ore = are; oim = aim;
+    };
+    double ycur_re, ycur_im;
+    fir_eval(ycur_re, ycur_im);
 
     const double w4 = g.w4, w4c = 1.0 - g.w4, w8 = g.w8, w8c = 1.0 - g.w8;
     const double agc_len_d = (double)g.agc_len, eb_len_d = (double)g.ebno_len;
@@ -97,24 +135,20 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
         coarse_cnt++;                          // :431
 
         // ---- K2 mix + K6 matched filter (:453-456, DSP.cpp:292-304) ----
-        const double2 c2 = cis[jd_cisidx(m2_ptr)];
-        const double cre = c2.x * dval, cim = c2.y * dval;
-        double sre = 0, sim = 0;
+        // this sample's filter output was evaluated one iteration ago; push x[n] and evaluate the next one now
+        double sre = ycur_re, sim = ycur_im;
         {
-            int slot = fir_slot;
+            const double2 c2 = cis[jd_cisidx(m2_ptr)];
+            const double cre = c2.x * dval, cim = c2.y * dval;
 #pragma unroll
-            for (int t = 0; t < FIRN; t++)
-            {
-                const double tp = taps[t];
-                sre = fma(tp, lre[slot * 64 + lane], sre);
-                sim = fma(tp, lim[slot * 64 + lane], sim);
-                slot++;
-                if (slot >= FIRN) slot = 0;
-            }
+            for (int j = TAILN - 1; j > 0; j--) { tre[j] = tre[j - 1]; tim[j] = tim[j - 1]; }
+            tre[0] = lre[fir_slot * 64 + lane];
+            tim[0] = lim[fir_slot * 64 + lane];
             lre[fir_slot * 64 + lane] = cre;
             lim[fir_slot * 64 + lane] = cim;
             fir_slot++;
-            if (fir_slot >= FIRN) fir_slot = 0;
+            if (fir_slot >= LDSN) fir_slot = 0;
+            fir_eval(ycur_re, ycur_im);
         }
 
         // ---- K7 EbNo (DSP.cpp:729-744) ----
@@ -302,10 +336,16 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
     LDI(I_SOFT_CNT) = soft_cnt; LDI(I_SYM_CNT) = sym_cnt; LDI(I_OVERFLOW) = overflow;
     {
         double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
-        for (int k = 0; k < FIRN; k++)
+        for (int k = 0; k < LDSN; k++)
         {
             fs[(size_t)k * 64] = lre[k * 64 + lane];
             fs[(size_t)(FIRN + k) * 64] = lim[k * 64 + lane];
+        }
+#pragma unroll
+        for (int j = 0; j < TAILN; j++)
+        {
+            fs[(size_t)(LDSN + j) * 64] = tre[j];
+            fs[(size_t)(FIRN + LDSN + j) * 64] = tim[j];
         }
     }
 }
