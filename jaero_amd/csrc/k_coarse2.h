@@ -118,6 +118,7 @@ __device__ __forceinline__ void wg_fft(CV<(1 << LOG2N) / C2_THREADS> &d, double 
     {
         CV<E> a;
         regfft<E>(d, a);
+        __builtin_amdgcn_sched_barrier(0);
         double2 B[4], A[8];
         twiddle_powers<E>(make_double2(1.0, 0.0), tw[(16 * n2) & (N - 1)], B, A);
 #pragma unroll
@@ -128,6 +129,7 @@ __device__ __forceinline__ void wg_fft(CV<(1 << LOG2N) / C2_THREADS> &d, double 
             d.i[k1] = a.r[k1] * w.y + a.i[k1] * w.x;
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
     // ---- exchange 1: L1[k1][n2][n3] (k1 stride 528); pass-2 thread u: n3 = u&15, k1 = u>>4 (active if k1 < E) ----
     CV<32> b;
     const int k1u = t >> 4;
@@ -156,7 +158,9 @@ __device__ __forceinline__ void wg_fft(CV<(1 << LOG2N) / C2_THREADS> &d, double 
     if (act2)
     {
         CV<32> c;
+        __builtin_amdgcn_sched_barrier(0);
         regfft<32>(b, c);
+        __builtin_amdgcn_sched_barrier(0);
         double2 B[4], A[8];
         twiddle_powers<E>(tw[(n3 * k1u) & (N - 1)], tw[(n3 * E) & (N - 1)], B, A);
 #pragma unroll
@@ -167,6 +171,7 @@ __device__ __forceinline__ void wg_fft(CV<(1 << LOG2N) / C2_THREADS> &d, double 
             b.i[k2] = c.r[k2] * w.y + c.i[k2] * w.x;
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
     // ---- exchange 2: M[(k2*16 + n3)][k1] (row stride E+1); pass-3 thread v: k1 = v & (E-1), k2 = (v >> LOGE) + (512/E) r ----
     {
         const int k1v = t & (E - 1), k2b = t >> LOGE;
@@ -218,6 +223,7 @@ __global__ __launch_bounds__(C2_THREADS) void k_coarse2(const JGeom g, const JPt
     const int t = threadIdx.x;
     const int nchp = g.nchp;
 
+    CV<E> d;
     for (int li = blockIdx.x; li < nlist; li += gridDim.x)
     {
         const int ch = chan_list ? chan_list[li] : li;
@@ -230,13 +236,16 @@ __global__ __launch_bounds__(C2_THREADS) void k_coarse2(const JGeom g, const JPt
         const int expectedpeakbin = (int)round(g.fb / (2.0 * hzperbin));
         double *__restrict__ y = p.y + (size_t)ch * N;
 
-        CV<E> d;
-        // bbtmpbuff[j] = bbcycbuff[(ptr+j)%N] = CIS[idx] * dval   (time order)
-#pragma unroll
-        for (int s = 0; s < E; s++)
+        // bbtmpbuff[j] = bbcycbuff[(ptr+j)%N] (time order); for every list entry but the first, these loads were issued
+        // while the previous estimate was in its peak search / state machine (d is free there), hiding the HBM latency
+        if (li == (int)blockIdx.x)
         {
-            const double2 v = ring[(bb_ptr + s * C2_THREADS + t) & (N - 1)];
-            d.r[s] = v.x; d.i[s] = v.y;
+#pragma unroll
+            for (int s = 0; s < E; s++)
+            {
+                const double2 v = ring[(bb_ptr + s * C2_THREADS + t) & (N - 1)];
+                d.r[s] = v.x; d.i[s] = v.y;
+            }
         }
         wg_fft<LOG2N>(d, xch, tw, t);
         // band limit (fb != 8400 boxcar, coarsefreqestimate.cpp:99) then inverse transform = forward on swapped planes
@@ -264,9 +273,25 @@ __global__ __launch_bounds__(C2_THREADS) void k_coarse2(const JGeom g, const JPt
         {
             const int k = s * C2_THREADS + t;
             const int i = k ^ (N / 2);
-            y[i] = y[i] * 0.9 + (0.1 * 10) * log10(fmax(hypot(d.r[s], d.i[s]), 1.0));
+            // 10*log10(max(|X|,1)) == 5*log10(max(|X|^2,1)): no hypot; differs from the reference expression by <= 1 ulp
+            y[i] = y[i] * 0.9 + 5.0 * log10(fmax(d.r[s] * d.r[s] + d.i[s] * d.i[s], 1.0));
         }
         __syncthreads();
+        {
+            const int ln = li + (int)gridDim.x;
+            if (ln < nlist)
+            {
+                const int chn = chan_list ? chan_list[ln] : ln;
+                const double2 *__restrict__ ringn = p.bbring + (size_t)chn * N;
+                const int bpn = p.I[(size_t)I_BB_PTR * nchp + chn];
+#pragma unroll
+                for (int s = 0; s < E; s++)
+                {
+                    const double2 v = ringn[(bpn + s * C2_THREADS + t) & (N - 1)];
+                    d.r[s] = v.x; d.i[s] = v.y;
+                }
+            }
+        }
 
         // fold + peak search (:116-131)
         const int i0 = (int)round((-lockingbw / hzperbin) + ((double)(N / 2)));
