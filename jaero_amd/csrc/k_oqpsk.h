@@ -115,10 +115,33 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
     const double w4 = g.w4, w4c = 1.0 - g.w4, w8 = g.w8, w8c = 1.0 - g.w8;
     const double agc_len_d = (double)g.agc_len, eb_len_d = (double)g.ebno_len;
 
+    // Inputs of sample i+1 (PCM and the ring rows that leave the AGC / EbNo windows) are requested at the top of
+    // iteration i and consumed one iteration later, so their HBM latency overlaps a whole sample of arithmetic.
+    short nx_pcm = (live && n > 0) ? pcm[ch] : (short)0;
+    double nx_agc = agc_ring[(size_t)agc_pos * 64];
+    double nx_e = 0, nx_e2 = 0;
+    if (EBNO) { nx_e = ebe_ring[(size_t)eb_pos * 64]; nx_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
+
     for (int i = 0; i < n; i++)
     {
-        const short s = live ? pcm[(size_t)i * pcm_stride + ch] : (short)0;
+        const short s = nx_pcm;
         const double dval = ((double)s) / 32768.0;
+        const double agc_old = nx_agc, e_old = nx_e, e2_old = nx_e2;
+        // requests for this iteration's table look-ups and next iteration's streams, all independent of the chain below
+        const double2 c_m2 = cis[jd_cisidx(m2_ptr)];
+        const double2 c_st = cis[jd_cisidx(st_ptr)];
+        if (i + 1 < n)
+        {
+            nx_pcm = live ? pcm[(size_t)(i + 1) * pcm_stride + ch] : (short)0;
+            int ap = agc_pos + 1; if (ap >= g.agc_len) ap = 0;
+            nx_agc = agc_ring[(size_t)ap * 64];
+            if (EBNO)
+            {
+                int ep = eb_pos + 1; if (ep >= g.ebno_len) ep = 0;
+                nx_e = ebe_ring[(size_t)ep * 64];
+                nx_e2 = ebe2_ring[(size_t)ep * 64];
+            }
+        }
 
         // ---- K3: coarse-frequency ring fill (oqpskdemodulator.cpp:410-415) ----
         if (!(i == 0 && skip_a_first))
@@ -137,19 +160,6 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
         // ---- K2 mix + K6 matched filter (:453-456, DSP.cpp:292-304) ----
         // this sample's filter output was evaluated one iteration ago; push x[n] and evaluate the next one now
         double sre = ycur_re, sim = ycur_im;
-        {
-            const double2 c2 = cis[jd_cisidx(m2_ptr)];
-            const double cre = c2.x * dval, cim = c2.y * dval;
-#pragma unroll
-            for (int j = TAILN - 1; j > 0; j--) { tre[j] = tre[j - 1]; tim[j] = tim[j - 1]; }
-            tre[0] = lre[fir_slot * 64 + lane];
-            tim[0] = lim[fir_slot * 64 + lane];
-            lre[fir_slot * 64 + lane] = cre;
-            lim[fir_slot * 64 + lane] = cim;
-            fir_slot++;
-            if (fir_slot >= LDSN) fir_slot = 0;
-            fir_eval(ycur_re, ycur_im);
-        }
 
         // ---- K7 EbNo (DSP.cpp:729-744) ----
         const double dabval = sqrt(sre * sre + sim * sim);
@@ -158,8 +168,8 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
             const double sq = dabval * dabval;
             double *e2p = ebe2_ring + (size_t)eb_pos * 64;
             double *ep = ebe_ring + (size_t)eb_pos * 64;
-            eb_e2sum = eb_e2sum - *e2p; eb_e2sum = eb_e2sum + fabs(sq); *e2p = fabs(sq);
-            eb_esum = eb_esum - *ep; eb_esum = eb_esum + fabs(dabval); *ep = fabs(dabval);
+            eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq); *e2p = fabs(sq);
+            eb_esum = eb_esum - e_old; eb_esum = eb_esum + fabs(dabval); *ep = fabs(dabval);
             eb_pos++; if (eb_pos >= g.ebno_len) eb_pos = 0;
             const double e2val = eb_e2sum / eb_len_d, mean = eb_esum / eb_len_d;
             const double meansq = mean * mean;
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
         // ---- K8 AGC + clip (DSP.cpp:370-379, :466-470) ----
         {
             double *ap = agc_ring + (size_t)agc_pos * 64;
-            agc_sum = agc_sum - *ap;
+            agc_sum = agc_sum - agc_old;
             agc_sum = agc_sum + fabs(dabval);
             *ap = fabs(dabval);
             agc_pos++; if (agc_pos >= g.agc_len) agc_pos = 0;
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
         }
         const double d8out = w8 * d8_1 + w8c * d8_2; d8_2 = d8_1; d8_1 = st_eta;
         {
-            const double2 so = cis[jd_cisidx(st_ptr)];
+            const double2 so = c_st;
             const double m_re = st_eta, m_im = -d8out;
             const double o_re = so.x * m_re - so.y * m_im;
             const double o_im = so.x * m_im + so.y * m_re;
@@ -306,6 +316,20 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
             }
         }
         sig2l_re = sre; sig2l_im = sim;
+
+        // ---- push x[n] (mixed with the carrier phase this sample started with) and evaluate the filter for n+1 ----
+        {
+            const double cre = c_m2.x * dval, cim = c_m2.y * dval;
+#pragma unroll
+            for (int j = TAILN - 1; j > 0; j--) { tre[j] = tre[j - 1]; tim[j] = tim[j - 1]; }
+            tre[0] = lre[fir_slot * 64 + lane];
+            tim[0] = lim[fir_slot * 64 + lane];
+            lre[fir_slot * 64 + lane] = cre;
+            lim[fir_slot * 64 + lane] = cim;
+            fir_slot++;
+            if (fir_slot >= LDSN) fir_slot = 0;
+            fir_eval(ycur_re, ycur_im);
+        }
 
         // ---- advance the NCOs (:600-603) ----
         jd_wt_next(m2_ptr, m2_step);
