@@ -105,6 +105,45 @@ def msk(nsamples: int, *, fb: float = 1200.0, Fs: float = 48000.0, fc: float = 1
     return pcm, bits
 
 
+def burst_oqpsk(nsamples: int, *, burst_starts, ndata_sym: int = 1500, fb: float = 10500.0, Fs: float = 48000.0, fc: float = 8000.0,
+                ebno_db: float | None = 15.0, peak: float = 0.3, seed: int = SEED_BASE, noise_in_gaps: bool = True):
+    """10.5 kbps burst OQPSK: per burst 128 symbols of constant (+1,+1) [carrier burst],
+    128 symbols alternating +1,-1 on both arms [tones at fc +- fb/4: the "trident"], then `ndata_sym` random symbols
+    per arm; same RRC alpha=1 pulse / half-symbol Q offset / passband law as `oqpsk`.  `burst_starts` are sample
+    indices (rounded to the symbol grid).  Returns (pcm int16[nsamples], list of (start_sample, bits uint8[2*ndata_sym]))."""
+    rng = np.random.default_rng(seed)
+    T = Fs / (fb / 2.0)
+    nsym = int(np.ceil(nsamples / T)) + 16
+    a_i = np.zeros(nsym)
+    a_q = np.zeros(nsym)
+    bursts = []
+    for st in burst_starts:
+        k0 = int(round(st / T))
+        nb = 256 + ndata_sym
+        if k0 + nb > nsym:
+            break
+        bits = rng.integers(0, 2, size=2 * ndata_sym, dtype=np.uint8)
+        pre = np.concatenate([np.ones(128), np.where(np.arange(128) % 2 == 0, 1.0, -1.0)])
+        a_i[k0:k0 + nb] = np.concatenate([pre, 2.0 * bits[0::2] - 1.0])
+        a_q[k0:k0 + nb] = np.concatenate([pre, 2.0 * bits[1::2] - 1.0])
+        bursts.append((int(round(k0 * T)), bits))
+    n = np.arange(nsamples, dtype=np.float64)
+    i_t = _shape(a_i, n, T, 0.0)
+    q_t = _shape(a_q, n, T, T / 2.0)
+    ph = 2.0 * np.pi * fc * n / Fs
+    x = i_t * np.cos(ph) - q_t * np.sin(ph)
+    p = 1.0 / T  # in-burst power of unit-symbol OQPSK with a unit-energy RRC pulse
+    if ebno_db is not None:
+        sigma2 = p * Fs / (2.0 * fb * 10.0 ** (ebno_db / 10.0))
+        noise = rng.normal(0.0, np.sqrt(sigma2), size=nsamples)
+        if not noise_in_gaps:
+            noise = noise * ((np.abs(i_t) + np.abs(q_t)) > 0)
+        x = x + noise
+    scale = peak / (3.0 * np.sqrt(p))
+    pcm = np.clip(np.round(x * scale * 32768.0), -32768, 32767).astype(np.int16)
+    return pcm, bursts
+
+
 def channel_bank(kind: str, nch: int, nsamples: int, *, ebno_db: float | None = 10.0, seed0: int = SEED_BASE, **kw):
     """[nch, nsamples] int16 bank with per-channel carrier offsets as in SURVEY.md 8(d) configs 2/3.
 

@@ -1035,3 +1035,6 @@ int jo_demod_pending_soft(jo_demod *d) { return d->nrx; }
 double jo_demod_get_mse(jo_demod *d) { return d->mse; }
 double jo_demod_get_freq_est(jo_demod *d) { return d->mixer2.freq; }
 double jo_demod_get_freq_center(jo_demod *d) { return d->mixer_center.freq; }
+
+/* burst demodulators: same translation unit (shares the static primitives above) */
+#include "jaero_oracle_burst.c"

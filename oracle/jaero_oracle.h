@@ -8,7 +8,7 @@
 extern "C" {
 #endif
 
-enum { JO_KIND_MSK = 0, JO_KIND_OQPSK = 1 };
+enum { JO_KIND_MSK = 0, JO_KIND_OQPSK = 1, JO_KIND_BURST_MSK = 2, JO_KIND_BURST_OQPSK = 3 };
 
 typedef struct
 {
@@ -67,6 +67,36 @@ void jo_coarse_destroy(jo_coarse *c);
 void jo_coarse_bigchange(jo_coarse *c);
 double jo_coarse_process(jo_coarse *c, const double *re_im);
 void jo_coarse_get_y(jo_coarse *c, double *y);
+
+/* ---- burst demodulators (jaero_oracle_burst.c): BurstOqpskDemodulator / BurstMskDemodulator ---- */
+typedef struct jo_burst jo_burst;
+/* = constructor + setAFC/SQL/CPUReduce defaults + setSettings + start(); kind = JO_KIND_BURST_* */
+jo_burst *jo_burst_create(const jo_settings *s);
+void jo_burst_destroy(jo_burst *d);
+void jo_burst_set_flags(jo_burst *d, int afc, int sql, int cpu_reduce);
+void jo_burst_set_dcd(jo_burst *d, int dcd); /* BurstMskDemodulator::DCDstatSlot */
+/* = writeData (mono) */
+long jo_burst_write(jo_burst *d, const int16_t *pcm, long nsamples);
+/* soft bits as passed to processDemodulatedSoftBits, concatenated; -1 = start-of-burst marker */
+long jo_burst_take_soft(jo_burst *d, int16_t *dst, long cap);
+/* rows of 3 doubles [absolute sample index, kind, value]; kind 0 SignalStatus(value), 1 EbNoMeasurmentSignal(value),
+ * 2 Plottables(freq_est=value); with jo_burst_trace(d,1) also 3 = peak detector fired, 4 = trident check ran
+ * (value = +metric accepted / -metric rejected) */
+long jo_burst_take_events(jo_burst *d, double *dst, long caprows);
+void jo_burst_trace(jo_burst *d, int on);
+/* rows [re, im, mse] of pt_qpsk (burst OQPSK, while startstop>0) / pt_msk (burst MSK, every symbol instant) */
+void jo_burst_capture_symbols(jo_burst *d, int on);
+long jo_burst_take_symbols(jo_burst *d, double *dst, long caprows);
+int jo_burst_pending_soft(jo_burst *d);
+double jo_burst_get_mse(jo_burst *d);
+double jo_burst_get_freq_est(jo_burst *d);
+/* QJHilbertFilter pieces (JAERO/DSP.cpp:754-794) */
+int jo_hilbert_kernel(int N, double *re_im);
+typedef struct jo_hilbert jo_hilbert;
+jo_hilbert *jo_hilbert_create(int N);
+void jo_hilbert_destroy(jo_hilbert *h);
+int jo_hilbert_latency(jo_hilbert *h);
+void jo_hilbert_update(jo_hilbert *h, const int16_t *pcm, long n, double *out_re_im);
 
 #ifdef __cplusplus
 }

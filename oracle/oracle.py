@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liboracle.so")
 REF_BIN = os.path.join(HERE, "_ref", "jaero_ref")
 
-KIND_MSK, KIND_OQPSK = 0, 1
+KIND_MSK, KIND_OQPSK, KIND_BURST_MSK, KIND_BURST_OQPSK = 0, 1, 2, 3
 
 
 class Settings(C.Structure):
@@ -41,10 +41,18 @@ def msk_settings(freq_center=1000.0, lockingbw=1800.0, fb=1200.0, Fs=48000.0, po
     return Settings(KIND_MSK, power, freq_center, lockingbw, fb, Fs, threshold)
 
 
+def burst_oqpsk_settings(freq_center=8000.0, lockingbw=10500.0, fb=10500.0, Fs=48000.0, power=13, threshold=0.6):
+    return Settings(KIND_BURST_OQPSK, power, freq_center, lockingbw, fb, Fs, threshold)
+
+
+def burst_msk_settings(freq_center=1000.0, lockingbw=1800.0, fb=1200.0, Fs=48000.0, power=13, threshold=0.6):
+    return Settings(KIND_BURST_MSK, power, freq_center, lockingbw, fb, Fs, threshold)
+
+
 def build(force: bool = False) -> None:
     """Compile liboracle.so (and _ref when the reference tree is present)."""
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(
-        os.path.getmtime(os.path.join(HERE, f)) for f in ("jaero_oracle.c", "viterbi_oracle.c", "jaero_oracle.h")
+        os.path.getmtime(os.path.join(HERE, f)) for f in ("jaero_oracle.c", "jaero_oracle_burst.c", "viterbi_oracle.c", "jaero_oracle.h")
     ):
         subprocess.check_call(["make", "-C", HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/JAERO") and os.path.exists("/opt/conda/bin/moc"):
@@ -97,6 +105,30 @@ def lib():
         L.jo_decode_continuous.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.jo_decode_soft.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.jo_encode_bits.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.jo_burst_create.restype = C.c_void_p
+        L.jo_burst_create.argtypes = [C.POINTER(Settings)]
+        L.jo_burst_destroy.argtypes = [C.c_void_p]
+        L.jo_burst_set_flags.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.jo_burst_set_dcd.argtypes = [C.c_void_p, C.c_int]
+        L.jo_burst_trace.argtypes = [C.c_void_p, C.c_int]
+        L.jo_burst_capture_symbols.argtypes = [C.c_void_p, C.c_int]
+        L.jo_burst_write.restype = C.c_long
+        L.jo_burst_write.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        for name in ("jo_burst_take_soft", "jo_burst_take_events", "jo_burst_take_symbols"):
+            f = getattr(L, name)
+            f.restype = C.c_long
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        L.jo_burst_pending_soft.argtypes = [C.c_void_p]
+        for name in ("jo_burst_get_mse", "jo_burst_get_freq_est"):
+            f = getattr(L, name)
+            f.restype = C.c_double
+            f.argtypes = [C.c_void_p]
+        L.jo_hilbert_kernel.argtypes = [C.c_int, C.c_void_p]
+        L.jo_hilbert_create.restype = C.c_void_p
+        L.jo_hilbert_create.argtypes = [C.c_int]
+        L.jo_hilbert_destroy.argtypes = [C.c_void_p]
+        L.jo_hilbert_latency.argtypes = [C.c_void_p]
+        L.jo_hilbert_update.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
         _lib = L
     return _lib
 
@@ -202,6 +234,92 @@ def run_demod(settings: Settings, pcm: np.ndarray, chunk: int = 4096, afc=False,
     return out
 
 
+def _drain(fn, h, width, dtype, rows=1 << 14):
+    out = []
+    buf = np.empty((rows, width) if width > 1 else (rows,), dtype=dtype)
+    while True:
+        n = fn(h, buf.ctypes.data, rows)
+        out.append(buf[:n].copy())
+        if n < rows:
+            break
+    return np.concatenate(out)
+
+
+class BurstDemod:
+    """One reference-semantics burst demodulator object (BurstOqpskDemodulator or BurstMskDemodulator)."""
+
+    def __init__(self, settings: Settings, afc=False, sql=False, cpu_reduce=False, capture_symbols=False, trace=False):
+        self.L = lib()
+        self.h = self.L.jo_burst_create(C.byref(settings))
+        self.L.jo_burst_set_flags(self.h, int(afc), int(sql), int(cpu_reduce))
+        self.L.jo_burst_capture_symbols(self.h, int(capture_symbols))
+        self.L.jo_burst_trace(self.h, int(trace))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.jo_burst_destroy(self.h)
+            self.h = None
+
+    def set_dcd(self, dcd):
+        self.L.jo_burst_set_dcd(self.h, int(dcd))
+
+    def write(self, pcm: np.ndarray):
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        self.L.jo_burst_write(self.h, pcm.ctypes.data, pcm.shape[0])
+
+    def take_soft(self):
+        return _drain(self.L.jo_burst_take_soft, self.h, 1, np.int16, 1 << 16)
+
+    def take_events(self):
+        return _drain(self.L.jo_burst_take_events, self.h, 3, np.float64)
+
+    def take_symbols(self):
+        return _drain(self.L.jo_burst_take_symbols, self.h, 3, np.float64)
+
+    @property
+    def pending(self):
+        return self.L.jo_burst_pending_soft(self.h)
+
+    @property
+    def mse(self):
+        return self.L.jo_burst_get_mse(self.h)
+
+    @property
+    def freq_est(self):
+        return self.L.jo_burst_get_freq_est(self.h)
+
+
+def run_burst(settings: Settings, pcm: np.ndarray, chunk: int = 4096, afc=False, sql=False, capture_symbols=False, trace=False):
+    """Feed pcm in `chunk`-sample writes; returns dict(soft, events[, symbols], pending, mse, freq_est)."""
+    d = BurstDemod(settings, afc=afc, sql=sql, capture_symbols=capture_symbols, trace=trace)
+    for s in range(0, pcm.shape[0], chunk):
+        d.write(pcm[s:s + chunk])
+    out = {"soft": d.take_soft(), "events": d.take_events(), "pending": d.pending, "mse": d.mse, "freq_est": d.freq_est}
+    if capture_symbols:
+        out["symbols"] = d.take_symbols()
+    return out
+
+
+def hilbert_kernel(N=2048) -> np.ndarray:
+    out = np.zeros(N, dtype=np.complex128)
+    lib().jo_hilbert_kernel(N, out.ctypes.data)
+    return out
+
+
+def hilbert_stream(pcm: np.ndarray, chunk: int = 4096, N=2048):
+    """QJHilbertFilter::update over a real int16 stream; returns (analytic complex128 [n], latency L)."""
+    L = lib()
+    h = L.jo_hilbert_create(N)
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    out = np.zeros(pcm.shape[0], dtype=np.complex128)
+    for s in range(0, pcm.shape[0], chunk):
+        m = min(chunk, pcm.shape[0] - s)
+        L.jo_hilbert_update(h, pcm[s:].ctypes.data, m, out[s:].ctypes.data)
+    lat = L.jo_hilbert_latency(h)
+    L.jo_hilbert_destroy(h)
+    return out, lat
+
+
 # ----------------------------------------------------------------------------------------------- _ref runner
 def have_ref() -> bool:
     return os.path.exists(REF_BIN) and os.access(REF_BIN, os.X_OK)
@@ -217,6 +335,9 @@ def run_ref(kind: str, pcm: np.ndarray, **kv):
         args = [REF_BIN, kind, inp, outp] + [f"{k}={v}" for k, v in kv.items()]
         subprocess.check_call(args)
         soft = np.fromfile(outp + ".soft", dtype=np.int16)
+        if kind.startswith("burst"):
+            events = np.fromfile(outp + ".events", dtype=np.float64).reshape(-1, 3)
+            return {"soft": soft, "events": events}
         status = np.fromfile(outp + ".status", dtype=np.float64).reshape(-1, 6)
     return {"soft": soft, "status": status}
 

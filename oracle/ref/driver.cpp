@@ -7,6 +7,10 @@
 //       writes <outprefix>.soft   int16 soft bits exactly as passed to processDemodulatedSoftBits
 //              <outprefix>.status float64 rows [n_estimate, freq_est, freq_center, mse, ebno, signal]
 //                                 one row per FreqOffsetEstimateSlot call
+//   jaero_ref burstoqpsk|burstmsk <in.s16> <outprefix> [key=value ...]
+//       same outputs; the soft stream keeps the -1 start-of-burst markers; one status row per SignalStatus emission,
+//       plus <outprefix>.events float64 rows [sample index of the write that carried it, kind, value]:
+//       kind 0 = SignalStatus(value), 1 = EbNoMeasurmentSignal(value), 2 = Plottables freq_est
 //   jaero_ref viterbi_cont <in.u8> <out.u8> blocklen=N [padding=24]
 //       JConvolutionalCodec::Decode_Continuous per block of N soft bytes (code 2,7,{109,79} as AeroL, aerol.cpp:936-940)
 //   jaero_ref viterbi_soft <in.u8> <out.u8> blocklen=N
@@ -28,6 +32,8 @@
 #include <vector>
 #include "oqpskdemodulator.h"
 #include "mskdemodulator.h"
+#include "burstoqpskdemodulator.h"
+#include "burstmskdemodulator.h"
 #include "fftwrapper.h"
 #include "fftrwrapper.h"
 #include "jconvolutionalcodec.h"
@@ -71,6 +77,22 @@ static void hook(DEMOD &d, Capture &c)
     });
 }
 
+// burst demodulators: no MSESignal; SignalStatus(true/false) at burst start/timeout, EbNo once per burst
+static long g_write_start = 0;
+template <class DEMOD>
+static void hook_burst(DEMOD &d, Capture &c)
+{
+    QObject::connect(&d, &DEMOD::processDemodulatedSoftBits, [&c](const QVector<short> &v) { for (int i = 0; i < v.size(); i++) c.soft.push_back(v[i]); });
+    QObject::connect(&d, &DEMOD::Plottables, [&c](double fe, double fc, double) {
+        c.freq_est = fe; c.freq_center = fc;
+        c.status.push_back((double)g_write_start); c.status.push_back(2.0); c.status.push_back(fe); });
+    QObject::connect(&d, &DEMOD::EbNoMeasurmentSignal, [&c](double e) {
+        c.ebno = e;
+        c.status.push_back((double)g_write_start); c.status.push_back(1.0); c.status.push_back(e); });
+    QObject::connect(&d, &DEMOD::SignalStatus, [&c](bool s) {
+        c.status.push_back((double)g_write_start); c.status.push_back(0.0); c.status.push_back(s ? 1.0 : 0.0); });
+}
+
 template <class DEMOD>
 static double feed(DEMOD &d, const QByteArray &pcm)
 {
@@ -89,6 +111,7 @@ static double feed(DEMOD &d, const QByteArray &pcm)
         if (cf_at >= 0 && s >= cf_at) { d.CenterFreqChangedSlot(cf_hz); cf_at = -1; }
         long n = chunk;
         if (s + n > nsamp) n = nsamp - s;
+        g_write_start = s;
         auto t0 = std::chrono::steady_clock::now();
         d.writeData(p + 2 * s, 2 * n);
         secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -127,6 +150,56 @@ static double run_msk(const QByteArray &pcm, Capture &c)
     return feed(d, pcm);
 }
 
+// The burst classes leave members uninitialised (BurstOqpskDemodulator::rotator_freq is read on the first sample,
+// JAERO/burstoqpskdemodulator.h:186, burstoqpskdemodulator.cpp:572): construct them in zeroed storage so that a run
+// is deterministic.
+struct BurstOqpskFeed : public BurstOqpskDemodulator
+{
+    BurstOqpskFeed() : BurstOqpskDemodulator(0) {}
+    void DCDstatSlot(bool) {} // the burst OQPSK demodulator has no DCD input
+    static void *operator new(size_t n) { return calloc(1, n); }
+    static void operator delete(void *p) { free(p); }
+};
+struct BurstMskFeed : public BurstMskDemodulator
+{
+    BurstMskFeed() : BurstMskDemodulator(0) {}
+    static void *operator new(size_t n) { return calloc(1, n); }
+    static void operator delete(void *p) { free(p); }
+};
+
+static double run_burstoqpsk(const QByteArray &pcm, Capture &c)
+{
+    BurstOqpskFeed *dp = new BurstOqpskFeed();
+    BurstOqpskFeed &d = *dp;
+    hook_burst<BurstOqpskDemodulator>(d, c);
+    BurstOqpskDemodulator::Settings s;
+    s.fb = getd("fb", 10500); s.Fs = getd("Fs", 48000); s.freq_center = getd("freq_center", 8000);
+    s.lockingbw = getd("lockingbw", 10500); s.coarsefreqest_fft_power = geti("power", 13);
+    s.signalthreshold = getd("threshold", 0.6);
+    d.setAFC(geti("afc", 0)); d.setSQL(geti("sql", 0)); d.setCPUReduce(geti("cpureduce", 0));
+    d.setScatterPointType(BurstOqpskDemodulator::SPT_None);
+    d.setSettings(s);
+    d.start();
+    return feed(d, pcm);
+}
+
+static double run_burstmsk(const QByteArray &pcm, Capture &c)
+{
+    BurstMskFeed *dp = new BurstMskFeed();
+    BurstMskFeed &d = *dp;
+    hook_burst<BurstMskDemodulator>(d, c);
+    BurstMskDemodulator::Settings s;
+    s.fb = getd("fb", 1200); s.Fs = getd("Fs", 48000); s.freq_center = getd("freq_center", 1000);
+    s.lockingbw = getd("lockingbw", 1800); s.coarsefreqest_fft_power = geti("power", 13);
+    s.signalthreshold = getd("threshold", 0.6); s.symbolspercycle = geti("symbolspercycle", 16);
+    d.setAFC(geti("afc", 0)); d.setSQL(geti("sql", 0)); d.setCPUReduce(geti("cpureduce", 0));
+    d.setScatterPointType(BurstMskDemodulator::SPT_None);
+    d.DCDstatSlot(false);
+    d.setSettings(s);
+    d.start();
+    return feed(d, pcm);
+}
+
 int main(int argc, char **argv)
 {
     QCoreApplication app(argc, argv);
@@ -149,12 +222,22 @@ int main(int argc, char **argv)
         writeall(QString(argv[3]) + ".status", c.status.data(), c.status.size() * sizeof(double));
         return 0;
     }
+    if (mode == "burstoqpsk" || mode == "burstmsk")
+    {
+        QByteArray pcm = readall(argv[2]);
+        Capture c;
+        if (mode == "burstoqpsk") run_burstoqpsk(pcm, c); else run_burstmsk(pcm, c);
+        writeall(QString(argv[3]) + ".soft", c.soft.data(), c.soft.size() * sizeof(short));
+        writeall(QString(argv[3]) + ".events", c.status.data(), c.status.size() * sizeof(double));
+        return 0;
+    }
     if (mode == "time")
     {
         QString which = argv[2];
         QByteArray pcm = readall(argv[3]);
         Capture c;
-        double secs = (which == "oqpsk") ? run_oqpsk(pcm, c) : run_msk(pcm, c);
+        double secs = (which == "oqpsk") ? run_oqpsk(pcm, c) : (which == "msk") ? run_msk(pcm, c)
+                    : (which == "burstoqpsk") ? run_burstoqpsk(pcm, c) : run_burstmsk(pcm, c);
         printf("%.6f %ld %zu\n", secs, (long)(pcm.size() / 2), c.soft.size());
         return 0;
     }

@@ -1,0 +1,24 @@
+#!/bin/bash
+# One GPU-box pass: parity tests, default bench, rocprofv3 kernel stats, then two PMC passes (FETCH_SIZE / WRITE_SIZE
+# separately, kernel-trace only -- MI355X_MICROARCH.md "HBM", "rocprofv3 PMC slots").  Everything lands in gpurun_out/<tag>/.
+# usage: scripts/gpu_round.sh <tag> [bench flags...]
+set -u
+TAG=${1:-run}; shift || true
+BFLAGS="$*"
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+( timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 ) > "$OUT/pytest_gpu.log"
+tail -3 "$OUT/pytest_gpu.log"
+( timeout 600 python bench.py $BFLAGS 2> "$OUT/bench.err" | tail -1 ) > "$OUT/bench_line.json"
+cat "$OUT/bench_line.json"
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o stats -- python "$GRAFT_REPO_ROOT/bench.py" $BFLAGS --no-cpu-baseline > "$OUT/bench_prof_line.json" 2> "$OUT/prof.err"
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" $BFLAGS --no-cpu-baseline --steps 4 --warmup 2 > "$OUT/pmc_fetch.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" $BFLAGS --no-cpu-baseline --steps 4 --warmup 2 > "$OUT/pmc_write.log" 2>&1
+cd "$GRAFT_REPO_ROOT"
+python scripts/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+cat "$OUT/summary.txt" | tail -30
+find "$OUT" -name "*.csv" -size +8M -delete
+du -sh "$OUT"
