@@ -27,6 +27,14 @@
  *     JAERO/oqpskdemodulator.cpp:414-428,629-677; coarsefreqestimate.cpp:90-137   same sample the reference does)
  *   JConvolutionalCodec::Decode_Continuous / Decode_soft              jaero_viterbi_* (batched, stateless blocks)
  *     JAERO/jconvolutionalcodec.cpp:151-201,90-119
+ *   BurstOqpskDemodulator / BurstMskDemodulator: ctor+setSettings+start   jaero_create (kind = JAERO_KIND_BURST_*)
+ *     JAERO/burstoqpskdemodulator.cpp:4-131,202-277  JAERO/burstmskdemodulator.cpp:9-84,150-325
+ *   their writeData / writeDataSlot                                    jaero_write (same call)
+ *     JAERO/burstoqpskdemodulator.cpp:300-737  JAERO/burstmskdemodulator.cpp:371-754
+ *   their processDemodulatedSoftBits (with the -1 start-of-burst marker)  jaero_read_softbits (marker kept as -1)
+ *   their SignalStatus / EbNoMeasurmentSignal / Plottables emissions   jaero_read_events
+ *   channel_stereo / channel_select_other (two objects fed the L and R     two channels of one bank fed with
+ *     samples of one interleaved stream, audioburstoqpskdemodulator.cpp:8-10)  JAERO_PCM_FRAME_MAJOR input
  *   stop() / destructor                                               jaero_destroy
  *
  * Conventions: every function returns 0 on success or a negative JAERO_E* code (the reference has no error
@@ -46,9 +54,11 @@ extern "C" {
 
 #define JAERO_ABI_VERSION 1
 
-/* demodulator kinds (burst kinds are reserved for the next round: SURVEY.md 8 row a3) */
-#define JAERO_KIND_MSK 0
-#define JAERO_KIND_OQPSK 1
+/* demodulator kinds */
+#define JAERO_KIND_MSK 0         /* MskDemodulator          JAERO/mskdemodulator.h:17                      */
+#define JAERO_KIND_OQPSK 1       /* OqpskDemodulator        JAERO/oqpskdemodulator.h:15                    */
+#define JAERO_KIND_BURST_MSK 2   /* BurstMskDemodulator     JAERO/burstmskdemodulator.h:22   (600 / 1200)  */
+#define JAERO_KIND_BURST_OQPSK 3 /* BurstOqpskDemodulator   JAERO/burstoqpskdemodulator.h:19 (10500)       */
 
 /* error codes */
 #define JAERO_OK 0
@@ -63,6 +73,14 @@ extern "C" {
 #define JAERO_FLAG_EBNO 1u            /* run the EbNo meters (OQPSKEbNoMeasure/MSKEbNoMeasure, diagnostic only)   */
 #define JAERO_FLAG_STATUS_LOG 2u      /* keep one status row per FreqOffsetEstimateSlot call (tests)              */
 #define JAERO_FLAG_CAPTURE_SYMBOLS 4u /* keep the soft symbol (pt_qpsk / pt_msk) + mse of every symbol (tests)     */
+#define JAERO_FLAG_TRACE 8u           /* burst kinds: also log peak-detector firings and every trident check (tests)   */
+
+/* burst event kinds (jaero_read_events): what the burst classes emit as Qt signals while demodulating */
+#define JAERO_EV_SIGNAL 0  /* SignalStatus(value != 0)        burstoqpskdemodulator.cpp:511,542  burstmskdemodulator.cpp:545,593 */
+#define JAERO_EV_EBNO 1    /* EbNoMeasurmentSignal(value)     burstoqpskdemodulator.cpp:581      burstmskdemodulator.cpp:637     */
+#define JAERO_EV_FREQ 2    /* Plottables(freq_est = value)    burstoqpskdemodulator.cpp:275,484  burstmskdemodulator.cpp:196,342,538 */
+#define JAERO_EV_PEAK 3    /* (JAERO_FLAG_TRACE) pdet.update() returned true                                                      */
+#define JAERO_EV_TRIDENT 4 /* (JAERO_FLAG_TRACE) trident check ran: value = +metric accepted / -metric rejected                   */
 
 /* PCM layouts accepted by jaero_write */
 #define JAERO_PCM_CHANNEL_MAJOR 0 /* pcm[ch * nsamples + i]  : one contiguous mono stream per channel            */
@@ -129,6 +147,10 @@ int jaero_read_status_log(jaero_ctx *ctx, int channel, double *rows, int caprows
 /* soft symbols rows of 3 doubles [re, im, mse] (JAERO_FLAG_CAPTURE_SYMBOLS) */
 int jaero_read_symbols(jaero_ctx *ctx, int channel, double *rows, int caprows, int *nrows);
 
+/* Burst kinds: rows of 3 doubles [absolute sample index (count of samples written before it), JAERO_EV_* kind, value],
+ * oldest first, drained by the call.  The first row of every channel is the Plottables emission of setSettings. */
+int jaero_read_events(jaero_ctx *ctx, int channel, double *rows, int caprows, int *nrows);
+
 /* Batched K=7 r=1/2 {109,79} soft Viterbi (libcorrect semantics as used by JConvolutionalCodec).
  * jaero_viterbi_decode_soft: nblocks independent blocks of nsoft soft bytes each (0..255, 128 = erasure);
  *   = correct_convolutional_decode_soft per block; bits_out[b * (nsoft/2) + k] one byte per decoded bit
@@ -157,7 +179,8 @@ const char *jaero_strerror(int code);
 const char *jaero_last_error(void);
 /* Time (ms) the GPU spent in each kernel class over the jaero_write calls since the last reset, measured with HIP
  * events on the launch stream; enabled by jaero_profile_enable(ctx,1).  which: 0 = sample-loop kernel,
- * 1 = coarse-frequency kernel, 2 = PCM transpose.  *launches receives the launch count. */
+ * 1 = coarse-frequency kernel (burst kinds: trident check), 2 = PCM transpose / history push, 3 = Hilbert FIR (burst),
+ * 4 = burst front end (burst).  *launches receives the launch count. */
 int jaero_profile_enable(jaero_ctx *ctx, int on);
 int jaero_profile_read(jaero_ctx *ctx, int which, double *total_ms, int *launches, int reset);
 

@@ -12,8 +12,9 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libjaero_hip.so")
 
-KIND_MSK, KIND_OQPSK = 0, 1
-FLAG_EBNO, FLAG_STATUS_LOG, FLAG_CAPTURE_SYMBOLS = 1, 2, 4
+KIND_MSK, KIND_OQPSK, KIND_BURST_MSK, KIND_BURST_OQPSK = 0, 1, 2, 3
+FLAG_EBNO, FLAG_STATUS_LOG, FLAG_CAPTURE_SYMBOLS, FLAG_TRACE = 1, 2, 4, 8
+EV_SIGNAL, EV_EBNO, EV_FREQ, EV_PEAK, EV_TRIDENT = 0, 1, 2, 3, 4
 PCM_CHANNEL_MAJOR, PCM_FRAME_MAJOR = 0, 1
 E_OK, E_INVAL, E_NODEV, E_NOMEM, E_HIP, E_OVERFLOW, E_NOTSUP = 0, -1, -2, -3, -4, -5, -6
 
@@ -23,7 +24,7 @@ EXPORTS = [
     "jaero_softbits_view", "jaero_discard_softbits", "jaero_read_status", "jaero_read_status_log",
     "jaero_read_symbols", "jaero_viterbi_decode_soft", "jaero_viterbi_continuous", "jaero_abi_version",
     "jaero_num_channels", "jaero_strerror", "jaero_last_error", "jaero_profile_enable", "jaero_profile_read",
-    "jaero_debug_schedule",
+    "jaero_debug_schedule", "jaero_read_events",
 ]
 
 
@@ -95,6 +96,7 @@ def lib():
     L.jaero_read_status.argtypes = [vp, ip, C.POINTER(Status)]
     L.jaero_read_status_log.argtypes = [vp, ip, vp, ip, C.POINTER(ip)]
     L.jaero_read_symbols.argtypes = [vp, ip, vp, ip, C.POINTER(ip)]
+    L.jaero_read_events.argtypes = [vp, ip, vp, ip, C.POINTER(ip)]
     L.jaero_viterbi_decode_soft.argtypes = [ip, vp, ip, ip, vp, ip, vp]
     L.jaero_viterbi_continuous.argtypes = [ip, vp, ip, ip, ip, vp, vp, vp, ip, vp]
     L.jaero_abi_version.restype = ip

@@ -1,0 +1,293 @@
+// burst_host.h -- host side of the burst banks (included by jaero_hip.hip after jaero_ctx / dalloc / fail are defined).
+// Geometry = what BurstOqpskDemodulator::setSettings / BurstMskDemodulator::setSettings compute
+// (JAERO/burstoqpskdemodulator.cpp:202-277, JAERO/burstmskdemodulator.cpp:150-325); initial scalar state = their constructors.
+#pragma once
+
+static int prof_begin(jaero_ctx *c, int which, hipStream_t st);
+static void prof_end(jaero_ctx *c, int idx, hipStream_t st);
+
+static int host_qround(double d) { return d >= 0.0 ? (int)(d + 0.5) : (int)(d - (double)((int)(d - 1)) + 0.5) + (int)(d - 1); }
+
+static void burst_fill_geometry(BGeom &g, const jaero_settings &s, int nch, unsigned flags, int max_write)
+{
+    memset(&g, 0, sizeof g);
+    g.kind = s.kind; g.nch = nch; g.nchp = (nch + 63) / 64 * 64; g.ngroups = g.nchp / 64;
+    g.Fs = s.Fs; g.fb = s.fb; g.flags = flags;
+    g.hil_ntaps = 2048;
+    g.hil_lat = 4 * 2048 - 2048 + 1; // JFastFir: nfft - K + 1 with the inferred default nfft = 4 * 2^ceil(log2 K)
+    g.agc_len = (int)round(1 * s.Fs);
+    if (s.kind == JAERO_KIND_BURST_OQPSK)
+    {
+        const double SPS = 2.0 * s.Fs / s.fb;
+        g.SPS = SPS;
+        g.agc2_len = (int)round((SPS * 64.0 / s.Fs) * s.Fs);
+        g.bt_lag = (int)ceil(1.0 * SPS); g.bt_w = delay_weight(1.0 * SPS);
+        g.ma1_len = (int)round((double)host_qround(128.0 * SPS));
+        g.mav1_len = (int)(SPS * 128);
+        g.fa_lag = (int)ceil(SPS * 128); g.fa_w = delay_weight(SPS * 128); g.fa_len = g.fa_lag + 1;
+        g.D1 = (int)(SPS * 128.0 * 2.5 - 190);
+        g.tri_sz = host_qround((256.0 + 16.0 + 16.0) * SPS);
+        g.D2 = g.tri_sz;
+        g.PL = (int)(SPS * 128.0 / 2.0); g.pd_thr = 0.2;
+        g.nb = host_qround(128.0 * SPS); g.nt = g.nb;
+        g.a1_lag = (int)ceil(SPS / 2.0); g.a1_w = delay_weight(SPS / 2.0);
+        g.ee = 0.4;
+        g.eb_len = (int)(SPS * (256.0));
+        g.msema_len = 128;
+        g.startstopstart = (int)(SPS * (1050));
+        g.w4 = delay_weight(SPS / 4.0); g.w8 = delay_weight(SPS / 8.0);
+        g.res_b0 = 0.0048847995518126464; g.res_b1 = 0; g.res_b2 = -0.0048847995518126464;
+        g.res_a1 = -0.3882746897971619; g.res_a2 = 0.99023040089637471;
+        g.stref_freq = s.fb;
+        g.stq_step = (s.fb / 4.0) * ((double)JD_WTSIZE) / ((float)(double)(int)s.Fs);
+        g.fir_n = 55;
+        g.maxseg = 2048; // <= tri_sz: at most one trident event per channel per segment
+    }
+    else
+    {
+        const double SPS = (int)(s.Fs / s.fb);
+        g.SPS = SPS;
+        g.agc2_len = (int)round((SPS * 128.0 / s.Fs) * s.Fs);
+        g.eb_len = (int)(0.15 * s.Fs);
+        g.msema_len = 75;
+        g.bt_lag = (int)ceil(1.0 * SPS); g.bt_w = delay_weight(1.0 * SPS);
+        if (s.fb >= 1200)
+        {
+            g.ma1_len = (int)round((double)host_qround(126.0 * SPS));
+            g.mav1_len = (int)(SPS * 126);
+            g.fa_lag = (int)ceil(SPS * 126); g.fa_w = delay_weight(SPS * 126);
+            g.PL = (int)(SPS * 126.0 / 2.0); g.pd_thr = 0.1;
+            g.tri_sz = host_qround((200.0) * SPS);
+            g.D1 = (int)(((int)289 * SPS) + 20);
+            g.D2 = (int)(host_qround(72 + 120.0) * SPS);
+            g.startstopstart = (int)(SPS * (500));
+            g.endRotation = (int)((120 + 37) * SPS);
+            g.res_a1 = -1.993312819378528; g.res_a2 = 0.999476538254407;
+            g.res_b0 = 2.617308727964618e-04; g.res_b1 = 0; g.res_b2 = -2.617308727964618e-04;
+            g.ee = 0.025;
+            g.startProcessing = 120;
+            g.nb = host_qround(126 * SPS); g.nt = host_qround(74 * SPS);
+        }
+        else
+        {
+            g.mav1_len = (int)(SPS * 150);
+            g.fa_lag = (int)ceil(SPS * 150); g.fa_w = delay_weight(SPS * 150);
+            g.ma1_len = (int)round((double)host_qround(150.0 * SPS));
+            g.PL = (int)(SPS * 150.0 / 2.0); g.pd_thr = 0.2;
+            g.tri_sz = host_qround((224) * SPS);
+            g.D1 = (int)(((int)397 * SPS) + 20);
+            g.D2 = host_qround((72 + 150.0) * SPS);
+            g.startstopstart = (int)(SPS * (500));
+            g.res_a1 = -1.991228154418550; g.res_a2 = 0.997385427096603;
+            g.res_b0 = 0.001307286451699; g.res_b1 = 0; g.res_b2 = -0.001307286451699;
+            g.ee = 0.015;
+            g.startProcessing = 150;
+            g.endRotation = (int)((g.startProcessing + 56) * SPS);
+            g.nb = host_qround(150 * SPS); g.nt = host_qround(74 * SPS);
+        }
+        g.fa_len = g.fa_lag + 1;
+        g.a1_lag = (int)(SPS / 2); g.a1_w = 0.0;
+        g.d8_len = (int)(SPS / 2) + 1; g.dly_len = (int)SPS + 1;
+        g.stref_freq = s.fb / 2.0;
+        g.stq_step = (s.fb / 2.0) * ((double)JD_WTSIZE) / ((float)(double)(int)s.Fs);
+        g.fir_n = 2 * (int)SPS;
+        g.maxseg = 4096; // <= tri_sz (8000 / 17920)
+    }
+    if (g.maxseg > max_write) g.maxseg = (max_write + 15) / 16 * 16;
+    g.bt_len = 2 * g.PL + 1;
+    g.cv_len = g.D1 + (g.D2 > g.tri_sz ? g.D2 : g.tri_sz) + g.maxseg + 64;
+    g.hist_len = g.hil_lat + g.hil_ntaps + max_write + 64;
+}
+
+static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, const hipDeviceProp_t &prop, int softbit_capacity)
+{
+    const jaero_settings &s0 = sets[0];
+    const int nch = (int)sets.size();
+    int rc = 0;
+    c->burst = true;
+    burst_fill_geometry(c->bg, s0, nch, c->flags, c->max_write);
+    BGeom &g = c->bg;
+    BPtrs &p = c->bp;
+    if (softbit_capacity <= 0) softbit_capacity = (int)ceil(2.0 * c->max_write * g.fb / g.Fs) + 128;
+    g.soft_cap = (softbit_capacity + 1) & ~1;
+    g.sym_cap = (c->flags & JAERO_FLAG_CAPTURE_SYMBOLS) ? g.soft_cap / 2 + 8 : 0;
+    g.ev_cap = (c->flags & JAERO_FLAG_TRACE) ? 4096 : 256;
+    const int nchp = g.nchp, ng = g.ngroups;
+    const bool oq = g.kind == JAERO_KIND_BURST_OQPSK;
+#define DA(ptr, count) do { if ((rc = dalloc(c, &(ptr), (size_t)(count)))) return rc; } while (0)
+    DA(p.S, (size_t)BS_NFIELDS * nchp);
+    DA(p.I, (size_t)BI_NFIELDS * nchp);
+    DA(p.pcmhist, (size_t)g.hist_len * nchp);
+    DA(p.hre, (size_t)ng * g.maxseg * 64); DA(p.him, (size_t)ng * g.maxseg * 64);
+    DA(p.agc_ring, (size_t)ng * g.agc_len * 64);
+    DA(p.cvre, (size_t)ng * g.cv_len * 64); DA(p.cvim, (size_t)ng * g.cv_len * 64);
+    DA(p.ma1re, (size_t)ng * g.ma1_len * 64); DA(p.ma1im, (size_t)ng * g.ma1_len * 64);
+    DA(p.mav1, (size_t)ng * g.mav1_len * 64);
+    DA(p.fa, (size_t)ng * g.fa_len * 64);
+    DA(p.bt, (size_t)ng * g.bt_len * 64);
+    DA(p.ev_list, nchp); DA(p.ev_count, 4);
+    DA(p.tri, nchp);
+    DA(p.agc2_ring, (size_t)nchp * g.agc2_len);
+    DA(p.eb_e, (size_t)nchp * g.eb_len); DA(p.eb_e2, (size_t)nchp * g.eb_len);
+    DA(p.firsave, (size_t)nchp * 2 * g.fir_n);
+    if (!oq) { DA(p.dly, (size_t)nchp * g.dly_len); DA(p.dly8, (size_t)nchp * g.d8_len); DA(p.a1, (size_t)nchp * g.d8_len); }
+    DA(p.msema, (size_t)nchp * g.msema_len);
+    DA(p.soft, (size_t)nchp * g.soft_cap);
+    if (g.sym_cap) DA(p.sym, (size_t)nchp * g.sym_cap * 3);
+    DA(p.evlog, (size_t)nchp * g.ev_cap * 3);
+    DA(c->d_pcm_raw, (size_t)c->max_write * nch);
+    DA(c->d_status, nchp);
+    c->tri_grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (c->tri_grid > nchp) c->tri_grid = nchp;
+    DA(c->d_tri_scratch, c->tri_grid);
+    {
+        const int E = TRI_H / C2_THREADS;
+        const int a = E * 528, b = C2_THREADS * (E + 1);
+        c->tri_lds = (a > b ? a : b) * (int)sizeof(double);
+    }
+    double2 *d_cis = nullptr, *d_tw = nullptr;
+    double *d_taps = nullptr, *d_hil = nullptr;
+    DA(d_cis, JD_WTSIZE); DA(d_tw, TRI_H); DA(d_taps, 2 * g.fir_n); DA(d_hil, g.hil_ntaps / 4);
+#undef DA
+    p.cis = d_cis; p.tw14 = d_tw; p.taps2 = d_taps; p.hil_taps = d_hil;
+    {
+        std::vector<double2> cis(JD_WTSIZE);
+        for (int i = 0; i < JD_WTSIZE; i++)
+        {
+            cis[i].y = (sin(2 * M_PI * ((double)i) / JD_WTSIZE));
+            cis[i].x = (sin(M_PI_2 + 2 * M_PI * ((double)i) / JD_WTSIZE));
+        }
+        HIPCHK(hipMemcpy(d_cis, cis.data(), sizeof(double2) * JD_WTSIZE, hipMemcpyHostToDevice));
+        std::vector<double2> tw(TRI_H);
+        for (int i = 0; i < TRI_H; i++) { double a = -2.0 * M_PI * ((double)i) / ((double)TRI_H); tw[i].x = cos(a); tw[i].y = sin(a); }
+        HIPCHK(hipMemcpy(d_tw, tw.data(), sizeof(double2) * TRI_H, hipMemcpyHostToDevice));
+        std::vector<double> taps;
+        if (oq) taps = rrc_design(1.0, 55, g.Fs, g.fb / 2.0);
+        else
+        {
+            taps.resize(g.fir_n);
+            for (int i = 0; i < g.fir_n; i++) taps[i] = sin(M_PI * i / (2.0 * g.SPS)) / (2.0 * g.SPS);
+        }
+        std::vector<double> t2(2 * g.fir_n);
+        for (int i = 0; i < 2 * g.fir_n; i++) t2[i] = taps[i % g.fir_n];
+        HIPCHK(hipMemcpy(d_taps, t2.data(), sizeof(double) * t2.size(), hipMemcpyHostToDevice));
+        // QJHilbertFilter::setSize (JAERO/DSP.cpp:760-787): imaginary part of the odd taps
+        const int N = g.hil_ntaps;
+        std::vector<double> hil(N / 4);
+        for (int j = 0; j < N / 4; j++)
+        {
+            const int i = 2 * j + 1;
+            hil[j] = (2.0 / ((double)N)) / (tan(M_PI * (((double)i) / ((double)N) - 0.5)));
+        }
+        HIPCHK(hipMemcpy(d_hil, hil.data(), sizeof(double) * hil.size(), hipMemcpyHostToDevice));
+    }
+    // scalar state
+    {
+        std::vector<double> S((size_t)BS_NFIELDS * nchp, 0.0);
+        std::vector<int> I((size_t)BI_NFIELDS * nchp, 0);
+        std::vector<double> ev((size_t)nchp * g.ev_cap * 3, 0.0);
+        c->settings.resize(nchp);
+        for (int ch = 0; ch < nchp; ch++)
+        {
+            const jaero_settings &s = sets[ch < nch ? ch : 0];
+            c->settings[ch] = s;
+            auto SS = [&](int f) -> double & { return S[(size_t)f * nchp + ch]; };
+            auto II = [&](int f) -> int & { return I[(size_t)f * nchp + ch]; };
+            double fc = s.freq_center;
+            if (fc > ((s.Fs / 2.0) - (s.lockingbw / 2.0))) fc = ((s.Fs / 2.0) - (s.lockingbw / 2.0));
+            if (fc < 0) fc = 0;
+            SS(BS_M2_FREQ) = fc; SS(BS_M2_STEP) = fc * ((double)JD_WTSIZE) / ((float)(double)(int)s.Fs); SS(BS_MC_FREQ) = fc;
+            SS(BS_ST_FREQ) = g.stref_freq; SS(BS_ST_STEP) = g.stref_freq * ((double)JD_WTSIZE) / ((float)(double)(int)s.Fs);
+            SS(BS_VOL_GAIN) = 1; SS(BS_STR_RE) = 1; SS(BS_SAV_RE) = 1; SS(BS_ROT_RE) = 1;
+            SS(BS_MSE) = oq ? 100.0 : 10.0; SS(BS_LASTMSE) = SS(BS_MSE);
+            SS(BS_THRESH) = s.signalthreshold; SS(BS_LOCKINGBW) = s.lockingbw; SS(BS_DIFF_LAST) = -1.0;
+            II(BI_CNTDOWN) = 2 * g.PL; II(BI_MAXPOSCD) = -1; II(BI_TRI_PTR) = 0; II(BI_EV_POS) = -1;
+            II(BI_STARTSTOP) = -1;
+            // emit Plottables(...) at the end of setSettings
+            ev[((size_t)ch * g.ev_cap) * 3 + 0] = 0; ev[((size_t)ch * g.ev_cap) * 3 + 1] = BEV_FREQ; ev[((size_t)ch * g.ev_cap) * 3 + 2] = fc;
+            II(BI_EV_CNT) = 1;
+        }
+        HIPCHK(hipMemcpy(p.S, S.data(), S.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(p.I, I.data(), I.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(p.evlog, ev.data(), ev.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    c->o_nch = nch; c->o_nchp = nchp; c->o_soft_cap = g.soft_cap; c->o_sym_cap = g.sym_cap;
+    c->o_soft = p.soft; c->o_sym = p.sym;
+    c->o_soft_cnt = p.I + (size_t)BI_SOFT_CNT * nchp; c->o_sym_cnt = p.I + (size_t)BI_SYM_CNT * nchp;
+    c->o_overflow = p.I + (size_t)BI_OVERFLOW * nchp; c->o_flags = p.I + (size_t)BI_FLAGS * nchp;
+    c->o_nrx = p.I + (size_t)BI_NRX * nchp;
+    c->m.nch = nch; c->m.nchp = nchp;
+    c->m.flags.assign(nchp, 0);
+    const int lds = 2 * g.fir_n * 64 * (int)sizeof(double);
+    if (oq)
+    {
+        HIPCHK(hipFuncSetAttribute((const void *)k_burst_oqpsk_demod<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_burst_oqpsk_demod<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+    else
+    {
+        HIPCHK(hipFuncSetAttribute((const void *)k_burst_msk_demod<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_burst_msk_demod<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+    HIPCHK(hipFuncSetAttribute((const void *)k_trident, hipFuncAttributeMaxDynamicSharedMemorySize, c->tri_lds));
+    HIPCHK(hipDeviceSynchronize());
+    return 0;
+}
+
+static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layout, int is_device_ptr, hipStream_t st)
+{
+    const BGeom &g = c->bg;
+    const BPtrs &p = c->bp;
+    const int nch = g.nch, nchp = g.nchp;
+    const int16_t *dsrc = pcm;
+    if (!is_device_ptr)
+    {
+        HIPCHK(hipMemcpyAsync(c->d_pcm_raw, pcm, sizeof(int16_t) * (size_t)nch * nsamples, hipMemcpyHostToDevice, st));
+        dsrc = c->d_pcm_raw;
+    }
+    // new samples -> PCM history ring (the Hilbert FIR only ever reads the ring)
+    {
+        const int pi = prof_begin(c, 2, st);
+        const int slot0 = (int)(c->nsamples_total % g.hist_len);
+        if (layout == JAERO_PCM_FRAME_MAJOR)
+            hipLaunchKernelGGL(k_hist_push_frames, dim3((nchp + 255) / 256, nsamples), dim3(256), 0, st, dsrc, nch, nch, p.pcmhist, nchp, g.hist_len, slot0, nsamples);
+        else
+            hipLaunchKernelGGL(k_hist_push_chmajor, dim3(nchp / 64, (nsamples + 63) / 64), dim3(256), 0, st, dsrc, nch, nsamples, p.pcmhist, nchp, g.hist_len, slot0);
+        prof_end(c, pi, st);
+    }
+    const bool cs = (c->flags & JAERO_FLAG_CAPTURE_SYMBOLS) != 0;
+    const int lds = 2 * g.fir_n * 64 * (int)sizeof(double);
+    int first = 1;
+    for (int pos = 0; pos < nsamples;)
+    {
+        const int n = (nsamples - pos) < g.maxseg ? (nsamples - pos) : g.maxseg;
+        const long long n0 = c->nsamples_total;
+        HIPCHK(hipMemsetAsync(p.ev_count, 0, sizeof(int), st));
+        int pi = prof_begin(c, 3, st);
+        hipLaunchKernelGGL(k_hilbert, dim3(g.ngroups, (n + 4 * HB_R - 1) / (4 * HB_R)), dim3(256), 0, st, g, p, n, n0);
+        prof_end(c, pi, st);
+        pi = prof_begin(c, 4, st);
+        hipLaunchKernelGGL(k_burst_front, dim3(g.ngroups), dim3(64), 0, st, g, p, n, n0);
+        prof_end(c, pi, st);
+        pi = prof_begin(c, 1, st);
+        hipLaunchKernelGGL(k_trident, dim3(c->tri_grid), dim3(C2_THREADS), c->tri_lds, st, g, p, c->d_tri_scratch, n0);
+        prof_end(c, pi, st);
+        pi = prof_begin(c, 0, st);
+        if (g.kind == JAERO_KIND_BURST_OQPSK)
+        {
+            if (cs) hipLaunchKernelGGL((k_burst_oqpsk_demod<true>), dim3(g.ngroups), dim3(64), lds, st, g, p, n, n0, first);
+            else hipLaunchKernelGGL((k_burst_oqpsk_demod<false>), dim3(g.ngroups), dim3(64), lds, st, g, p, n, n0, first);
+        }
+        else
+        {
+            if (cs) hipLaunchKernelGGL((k_burst_msk_demod<true>), dim3(g.ngroups), dim3(64), lds, st, g, p, n, n0, first);
+            else hipLaunchKernelGGL((k_burst_msk_demod<false>), dim3(g.ngroups), dim3(64), lds, st, g, p, n, n0, first);
+        }
+        prof_end(c, pi, st);
+        first = 0;
+        c->nsamples_total += n;
+        pos += n;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}

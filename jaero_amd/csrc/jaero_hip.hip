@@ -23,6 +23,9 @@
 #include "k_coarse.h"
 #include "k_coarse2.h"
 #include "k_viterbi.h"
+#include "burst_device.h"
+#include "k_burst_front.h"
+#include "k_burst_demod.h"
 
 static thread_local std::string g_last_error;
 static int fail(int code, const char *fmt, ...)
@@ -136,9 +139,21 @@ struct jaero_ctx
     // host mirrors
     std::vector<jaero_settings> settings;
     Mirror m;
+    // burst kinds (JAERO_KIND_BURST_*): their own geometry / state (burst_device.h); g/p above stay unused
+    bool burst = false;
+    BGeom bg{};
+    BPtrs bp{};
+    TriScratch *d_tri_scratch = nullptr;
+    int tri_grid = 0, tri_lds = 0;
+    long long nsamples_total = 0; // samples written so far (uniform ring slots and event time stamps derive from it)
+    // generic views of the per-channel output buffers (either kind)
+    int o_nchp = 0, o_nch = 0, o_soft_cap = 0, o_sym_cap = 0;
+    int16_t *o_soft = nullptr; double *o_sym = nullptr;
+    int *o_soft_cnt = nullptr, *o_sym_cnt = nullptr, *o_overflow = nullptr, *o_flags = nullptr;
+    int *o_nrx = nullptr; // burst: soft bits pushed but not yet emitted (RxDataBits.size()), kept at the tail of the buffer
     // profiling
     bool prof = false;
-    ProfSlot slots[3];
+    ProfSlot slots[5];
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     struct EvUse { int which; int idx; };
     std::vector<EvUse> ev_used;
@@ -221,12 +236,27 @@ __global__ void k_status(const JGeom g, const JPtrs p, int ch_first, int n, jaer
     out[k] = st;
 }
 
-__global__ void k_pack_soft(const JGeom g, const JPtrs p, int16_t *dst, int capc)
+__global__ void k_pack_soft(const int *__restrict__ soft_cnt, const int16_t *__restrict__ soft, int soft_cap, int16_t *dst, int capc)
 {
     const int ch = blockIdx.x;
-    const int cnt = min(p.I[(size_t)I_SOFT_CNT * g.nchp + ch], capc);
-    const int16_t *src = p.soft + (size_t)ch * g.soft_cap;
+    const int cnt = min(soft_cnt[ch], capc);
+    const int16_t *src = soft + (size_t)ch * soft_cap;
     for (int k = threadIdx.x; k < cnt; k += blockDim.x) dst[(size_t)ch * capc + k] = src[k];
+}
+
+__global__ void k_status_burst(const BGeom g, const BPtrs p, int ch_first, int n, jaero_status *out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int ch = ch_first + k, nchp = g.nchp;
+    jaero_status st;
+    st.mse = p.S[(size_t)BS_MSE * nchp + ch];
+    st.ebno = p.S[(size_t)BS_EB_EBNO * nchp + ch];
+    st.freq_est = p.S[(size_t)BS_M2_FREQ * nchp + ch];
+    st.freq_center = (g.kind == JAERO_KIND_BURST_MSK_D) ? p.S[(size_t)BS_MC_FREQ * nchp + ch] : st.freq_est;
+    st.signal = p.I[(size_t)BI_STARTSTOP * nchp + ch] > 0 ? 1 : 0; // between SignalStatus(true) and SignalStatus(false)
+    st.n_estimates = p.I[(size_t)BI_EV_CNT * nchp + ch];
+    out[k] = st;
 }
 
 __global__ void k_fill_int(int *p, int n, int v)
@@ -283,11 +313,13 @@ static double delay_weight(double fractdelay)
 
 static int validate_settings(const jaero_settings &s)
 {
-    if (s.kind != JAERO_KIND_MSK && s.kind != JAERO_KIND_OQPSK) return fail(JAERO_ENOTSUP, "kind %d not implemented (burst kinds: next round)", s.kind);
+    if (s.kind < JAERO_KIND_MSK || s.kind > JAERO_KIND_BURST_OQPSK) return fail(JAERO_ENOTSUP, "kind %d not implemented", s.kind);
     if (s.Fs != 48000) return fail(JAERO_ENOTSUP, "only Fs=48000 is implemented (got %g)", s.Fs);
-    if (s.kind == JAERO_KIND_OQPSK && s.fb != 10500) return fail(JAERO_ENOTSUP, "OQPSK: only fb=10500 is implemented (8400 C-channel: SURVEY 8f4)");
-    if (s.kind == JAERO_KIND_MSK && s.fb != 600 && s.fb != 1200) return fail(JAERO_ENOTSUP, "MSK: fb must be 600 or 1200");
-    if (s.coarsefreqest_fft_power != 13 && s.coarsefreqest_fft_power != 14) return fail(JAERO_ENOTSUP, "coarsefreqest_fft_power must be 13 or 14");
+    const bool oq = s.kind == JAERO_KIND_OQPSK || s.kind == JAERO_KIND_BURST_OQPSK;
+    if (oq && s.fb != 10500) return fail(JAERO_ENOTSUP, "OQPSK: only fb=10500 is implemented (8400 C-channel: SURVEY 8f4)");
+    if (!oq && s.fb != 600 && s.fb != 1200) return fail(JAERO_ENOTSUP, "MSK: fb must be 600 or 1200");
+    const bool burst = s.kind >= JAERO_KIND_BURST_MSK;
+    if (!burst && s.coarsefreqest_fft_power != 13 && s.coarsefreqest_fft_power != 14) return fail(JAERO_ENOTSUP, "coarsefreqest_fft_power must be 13 or 14");
     if (!(s.lockingbw > 0) || !(s.freq_center >= 0)) return fail(JAERO_EINVAL, "bad lockingbw/freq_center");
     return 0;
 }
@@ -363,6 +395,8 @@ static void fill_geometry(JGeom &g, const jaero_settings &s, int nch, unsigned f
     }
 }
 
+#include "burst_host.h"
+
 // ------------------------------------------------------------------------------------------ create / destroy
 extern "C" int jaero_abi_version(void) { return JAERO_ABI_VERSION; }
 extern "C" const char *jaero_last_error(void) { return g_last_error.c_str(); }
@@ -380,7 +414,7 @@ extern "C" const char *jaero_strerror(int code)
     default: return "unknown error";
     }
 }
-extern "C" int jaero_num_channels(const jaero_ctx *ctx) { return ctx ? ctx->g.nch : 0; }
+extern "C" int jaero_num_channels(const jaero_ctx *ctx) { return ctx ? ctx->o_nch : 0; }
 
 extern "C" void jaero_destroy(jaero_ctx *c)
 {
@@ -424,6 +458,15 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
     c->device = device;
     c->flags = flags;
     c->max_write = max_write_samples;
+    if (s0.kind >= JAERO_KIND_BURST_MSK)
+    {
+        std::vector<jaero_settings> all(nchannels);
+        for (int ch = 0; ch < nchannels; ch++) all[ch] = sat(ch);
+        rc = burst_create(c, all, prop, softbit_capacity);
+        if (rc) { jaero_destroy(c); return rc; }
+        *out = c;
+        return 0;
+    }
     fill_geometry(c->g, s0, nchannels, flags);
     JGeom &g = c->g;
     if (softbit_capacity <= 0)
@@ -509,6 +552,10 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         HIPCHK(hipMemcpy(c->p.S, S.data(), S.size() * sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->p.I, I.data(), I.size() * sizeof(int), hipMemcpyHostToDevice));
     }
+    c->o_nch = nchannels; c->o_nchp = nchp; c->o_soft_cap = g.soft_cap; c->o_sym_cap = g.sym_cap;
+    c->o_soft = c->p.soft; c->o_sym = c->p.sym;
+    c->o_soft_cnt = c->p.I + (size_t)I_SOFT_CNT * nchp; c->o_sym_cnt = c->p.I + (size_t)I_SYM_CNT * nchp;
+    c->o_overflow = c->p.I + (size_t)I_OVERFLOW * nchp; c->o_flags = c->p.I + (size_t)I_FLAGS * nchp;
     c->m.nch = nchannels; c->m.nchp = nchp; c->m.nfft = g.nfft; c->m.Fs_int = g.Fs_int;
     c->m.flags.assign(nchp, 0); c->m.bbptr.assign(nchp, 0); c->m.cnt.assign(nchp, 0);
     // dynamic LDS for the matched-filter rings
@@ -530,16 +577,16 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
 // ------------------------------------------------------------------------------------------ control surface
 static int upload_flags(jaero_ctx *c)
 {
-    HIPCHK(hipMemcpy(c->p.I + (size_t)I_FLAGS * c->g.nchp, c->m.flags.data(), sizeof(int) * c->g.nchp, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->o_flags, c->m.flags.data(), sizeof(int) * c->o_nchp, hipMemcpyHostToDevice));
     return 0;
 }
 
 extern "C" int jaero_set_flags(jaero_ctx *c, int channel, int afc, int sql, int cpu_reduce)
 {
-    if (!c || channel < -1 || channel >= c->g.nch) return fail(JAERO_EINVAL, "jaero_set_flags: bad channel");
+    if (!c || channel < -1 || channel >= c->o_nch) return fail(JAERO_EINVAL, "jaero_set_flags: bad channel");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
-    const int lo = channel < 0 ? 0 : channel, hi = channel < 0 ? c->g.nchp : channel + 1;
+    const int lo = channel < 0 ? 0 : channel, hi = channel < 0 ? c->o_nchp : channel + 1;
     for (int ch = lo; ch < hi; ch++)
     {
         int f = c->m.flags[ch] & JF_DCD;
@@ -553,18 +600,24 @@ extern "C" int jaero_set_flags(jaero_ctx *c, int channel, int afc, int sql, int 
 
 extern "C" int jaero_set_dcd(jaero_ctx *c, int channel, int dcd)
 {
-    if (!c || channel < -1 || channel >= c->g.nch) return fail(JAERO_EINVAL, "jaero_set_dcd: bad channel");
+    if (!c || channel < -1 || channel >= c->o_nch) return fail(JAERO_EINVAL, "jaero_set_dcd: bad channel");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
-    const int lo = channel < 0 ? 0 : channel, hi = channel < 0 ? c->g.nchp : channel + 1;
+    const int lo = channel < 0 ? 0 : channel, hi = channel < 0 ? c->o_nchp : channel + 1;
     for (int ch = lo; ch < hi; ch++) c->m.flags[ch] = (c->m.flags[ch] & ~JF_DCD) | (dcd ? JF_DCD : 0);
     return upload_flags(c);
 }
 
 extern "C" int jaero_center_freq_changed(jaero_ctx *c, int channel, double hz)
 {
-    if (!c || channel < -1 || channel >= c->g.nch) return fail(JAERO_EINVAL, "jaero_center_freq_changed: bad channel");
+    if (!c || channel < -1 || channel >= c->o_nch) return fail(JAERO_EINVAL, "jaero_center_freq_changed: bad channel");
     HIPCHK(hipSetDevice(c->device));
+    if (c->burst)
+    {
+        // BurstOqpskDemodulator::CenterFreqChangedSlot does nothing (burstoqpskdemodulator.cpp:284-289)
+        if (c->bg.kind == JAERO_KIND_BURST_OQPSK) return 0;
+        return fail(JAERO_ENOTSUP, "jaero_center_freq_changed: not implemented for burst MSK banks (the trident check retunes them)");
+    }
     const int lo = channel < 0 ? 0 : channel, n = channel < 0 ? c->g.nch : 1;
     hipLaunchKernelGGL(k_center_freq, dim3(n), dim3(256), 0, c->last_stream, c->g, c->p, lo, n, hz);
     HIPCHK(hipGetLastError());
@@ -583,7 +636,8 @@ extern "C" int jaero_set_settings(jaero_ctx *c, int channel, const jaero_setting
 {
     // setSettings on a live object (oqpskdemodulator.cpp:175-289, mskdemodulator.cpp:135-263): retunes the mixers
     // (phase kept), recreates AGC / matched filters / timing delays / resonator, restarts the coarse ring pointer.
-    if (!c || !s || channel < -1 || channel >= c->g.nch) return fail(JAERO_EINVAL, "jaero_set_settings: bad arguments");
+    if (!c || !s || channel < -1 || channel >= c->o_nch) return fail(JAERO_EINVAL, "jaero_set_settings: bad arguments");
+    if (c->burst) return fail(JAERO_ENOTSUP, "jaero_set_settings on a live burst bank is not implemented; create a new bank");
     int rc = validate_settings(*s);
     if (rc) return rc;
     const JGeom &g = c->g;
@@ -668,7 +722,7 @@ extern "C" int jaero_profile_enable(jaero_ctx *c, int on)
 }
 extern "C" int jaero_profile_read(jaero_ctx *c, int which, double *total_ms, int *launches, int reset)
 {
-    if (!c || which < 0 || which > 2) return fail(JAERO_EINVAL, "jaero_profile_read: bad arguments");
+    if (!c || which < 0 || which > 4) return fail(JAERO_EINVAL, "jaero_profile_read: bad arguments");
     HIPCHK(hipSetDevice(c->device));
     prof_collect(c);
     if (total_ms) *total_ms = c->slots[which].ms;
@@ -728,6 +782,7 @@ extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int l
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     c->last_stream = st;
+    if (c->burst) return burst_write(c, pcm, nsamples, layout, is_device_ptr, st);
     const JGeom &g = c->g;
     const int nch = g.nch, nchp = g.nchp;
 
@@ -815,11 +870,11 @@ extern "C" int jaero_debug_schedule(int fft_power, int Fs, int cpu_reduce, const
 static int check_overflow(jaero_ctx *c, int ch, int bit)
 {
     int ov = 0;
-    HIPCHK(hipMemcpy(&ov, c->p.I + (size_t)I_OVERFLOW * c->g.nchp + ch, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&ov, c->o_overflow + ch, sizeof(int), hipMemcpyDeviceToHost));
     if (ov & bit)
     {
         int z = ov & ~bit;
-        HIPCHK(hipMemcpy(c->p.I + (size_t)I_OVERFLOW * c->g.nchp + ch, &z, sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->o_overflow + ch, &z, sizeof(int), hipMemcpyHostToDevice));
         return fail(JAERO_EOVERFLOW, "channel %d overflowed its output buffer (flag %d); data was dropped", ch, bit);
     }
     return 0;
@@ -827,14 +882,17 @@ static int check_overflow(jaero_ctx *c, int ch, int bit)
 
 extern "C" int jaero_read_softbits(jaero_ctx *c, int ch, int16_t *dst, int cap, int *n)
 {
-    if (!c || !dst || !n || ch < 0 || ch >= c->g.nch || cap < 0) return fail(JAERO_EINVAL, "jaero_read_softbits: bad arguments");
+    if (!c || !dst || !n || ch < 0 || ch >= c->o_nch || cap < 0) return fail(JAERO_EINVAL, "jaero_read_softbits: bad arguments");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->last_stream));
     int cnt = 0;
-    int *dcnt = c->p.I + (size_t)I_SOFT_CNT * c->g.nchp + ch;
+    int *dcnt = c->o_soft_cnt + ch;
     HIPCHK(hipMemcpy(&cnt, dcnt, sizeof(int), hipMemcpyDeviceToHost));
-    const int take = cnt < cap ? cnt : cap;
-    int16_t *src = c->p.soft + (size_t)ch * c->g.soft_cap;
+    int pend = 0;
+    if (c->o_nrx) HIPCHK(hipMemcpy(&pend, c->o_nrx + ch, sizeof(int), hipMemcpyDeviceToHost));
+    const int emitted = cnt - pend;
+    const int take = emitted < cap ? emitted : cap;
+    int16_t *src = c->o_soft + (size_t)ch * c->o_soft_cap;
     if (take) HIPCHK(hipMemcpy(dst, src, sizeof(int16_t) * take, hipMemcpyDeviceToHost));
     if (take < cnt)
     {
@@ -853,7 +911,7 @@ extern "C" int jaero_read_softbits_all(jaero_ctx *c, int16_t *dst, int capc, int
     if (!c || !dst || !counts || capc <= 0) return fail(JAERO_EINVAL, "jaero_read_softbits_all: bad arguments");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = c->last_stream;
-    const int nch = c->g.nch, nchp = c->g.nchp;
+    const int nch = c->o_nch, nchp = c->o_nchp;
     const size_t need = (size_t)nch * capc;
     if (need > c->pack_elems)
     {
@@ -862,11 +920,11 @@ extern "C" int jaero_read_softbits_all(jaero_ctx *c, int16_t *dst, int capc, int
         c->allocs.push_back(q);
         c->d_pack = q; c->pack_elems = need;
     }
-    hipLaunchKernelGGL(k_pack_soft, dim3(nch), dim3(256), 0, st, c->g, c->p, c->d_pack, capc);
+    hipLaunchKernelGGL(k_pack_soft, dim3(nch), dim3(256), 0, st, c->o_soft_cnt, c->o_soft, c->o_soft_cap, c->d_pack, capc);
     HIPCHK(hipMemcpyAsync(dst, c->d_pack, need * sizeof(int16_t), hipMemcpyDeviceToHost, st));
     std::vector<int> cnt(nchp), ov(nchp);
-    HIPCHK(hipMemcpyAsync(cnt.data(), c->p.I + (size_t)I_SOFT_CNT * nchp, sizeof(int) * nchp, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(ov.data(), c->p.I + (size_t)I_OVERFLOW * nchp, sizeof(int) * nchp, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(cnt.data(), c->o_soft_cnt, sizeof(int) * nchp, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ov.data(), c->o_overflow, sizeof(int) * nchp, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     int rc = 0;
     for (int ch = 0; ch < nch; ch++)
@@ -874,10 +932,12 @@ extern "C" int jaero_read_softbits_all(jaero_ctx *c, int16_t *dst, int capc, int
         counts[ch] = cnt[ch] < capc ? cnt[ch] : capc;
         if (cnt[ch] > capc || (ov[ch] & 1)) rc = JAERO_EOVERFLOW;
     }
-    HIPCHK(hipMemsetAsync(c->p.I + (size_t)I_SOFT_CNT * nchp, 0, sizeof(int) * nchp, st));
+    if (c->burst)
+        return fail(JAERO_ENOTSUP, "jaero_read_softbits_all: burst banks keep a pending (not yet emitted) tail per channel; use jaero_read_softbits");
+    HIPCHK(hipMemsetAsync(c->o_soft_cnt, 0, sizeof(int) * nchp, st));
     if (rc)
     {
-        HIPCHK(hipMemsetAsync(c->p.I + (size_t)I_OVERFLOW * nchp, 0, sizeof(int) * nchp, st));
+        HIPCHK(hipMemsetAsync(c->o_overflow, 0, sizeof(int) * nchp, st));
         return fail(rc, "at least one channel produced more soft bits than fit (cap_per_channel=%d or device capacity)", capc);
     }
     return 0;
@@ -886,9 +946,9 @@ extern "C" int jaero_read_softbits_all(jaero_ctx *c, int16_t *dst, int capc, int
 extern "C" int jaero_softbits_view(jaero_ctx *c, void **dev_softbits, void **dev_counts, int *capacity)
 {
     if (!c) return fail(JAERO_EINVAL, "null ctx");
-    if (dev_softbits) *dev_softbits = c->p.soft;
-    if (dev_counts) *dev_counts = c->p.I + (size_t)I_SOFT_CNT * c->g.nchp;
-    if (capacity) *capacity = c->g.soft_cap;
+    if (dev_softbits) *dev_softbits = c->o_soft;
+    if (dev_counts) *dev_counts = c->o_soft_cnt;
+    if (capacity) *capacity = c->o_soft_cap;
     return 0;
 }
 
@@ -896,29 +956,31 @@ extern "C" int jaero_discard_softbits(jaero_ctx *c, void *stream)
 {
     if (!c) return fail(JAERO_EINVAL, "null ctx");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemsetAsync(c->p.I + (size_t)I_SOFT_CNT * c->g.nchp, 0, sizeof(int) * c->g.nchp, (hipStream_t)stream));
-    HIPCHK(hipMemsetAsync(c->p.I + (size_t)I_SYM_CNT * c->g.nchp, 0, sizeof(int) * c->g.nchp, (hipStream_t)stream));
+    if (c->burst) return fail(JAERO_ENOTSUP, "jaero_discard_softbits: not for burst banks (pending tail); use jaero_read_softbits");
+    HIPCHK(hipMemsetAsync(c->o_soft_cnt, 0, sizeof(int) * c->o_nchp, (hipStream_t)stream));
+    HIPCHK(hipMemsetAsync(c->o_sym_cnt, 0, sizeof(int) * c->o_nchp, (hipStream_t)stream));
     return 0;
 }
 
 extern "C" int jaero_read_status(jaero_ctx *c, int ch, jaero_status *stt)
 {
-    if (!c || !stt || ch < 0 || ch >= c->g.nch) return fail(JAERO_EINVAL, "jaero_read_status: bad arguments");
+    if (!c || !stt || ch < 0 || ch >= c->o_nch) return fail(JAERO_EINVAL, "jaero_read_status: bad arguments");
     HIPCHK(hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_status, dim3(1), dim3(64), 0, c->last_stream, c->g, c->p, ch, 1, c->d_status);
+    if (c->burst) hipLaunchKernelGGL(k_status_burst, dim3(1), dim3(64), 0, c->last_stream, c->bg, c->bp, ch, 1, c->d_status);
+    else hipLaunchKernelGGL(k_status, dim3(1), dim3(64), 0, c->last_stream, c->g, c->p, ch, 1, c->d_status);
     HIPCHK(hipMemcpyAsync(stt, c->d_status, sizeof(jaero_status), hipMemcpyDeviceToHost, c->last_stream));
     HIPCHK(hipStreamSynchronize(c->last_stream));
     return 0;
 }
 
-static int read_rows(jaero_ctx *c, int ch, double *rows, int caprows, int *nrows, int cnt_field, double *base, int cap, int w, int ovbit)
+static int read_rows(jaero_ctx *c, int ch, double *rows, int caprows, int *nrows, int *cnt_base, double *base, int cap, int w, int ovbit)
 {
-    if (!c || !rows || !nrows || ch < 0 || ch >= c->g.nch) return fail(JAERO_EINVAL, "bad arguments");
-    if (!base) return fail(JAERO_EINVAL, "this output was not enabled in jaero_create flags");
+    if (!c || !rows || !nrows || ch < 0 || ch >= c->o_nch) return fail(JAERO_EINVAL, "bad arguments");
+    if (!base || !cnt_base) return fail(JAERO_EINVAL, "this output was not enabled in jaero_create flags (or does not exist for this kind)");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->last_stream));
     int cnt = 0;
-    int *dcnt = c->p.I + (size_t)cnt_field * c->g.nchp + ch;
+    int *dcnt = cnt_base + ch;
     HIPCHK(hipMemcpy(&cnt, dcnt, sizeof(int), hipMemcpyDeviceToHost));
     const int take = cnt < caprows ? cnt : caprows;
     double *src = base + (size_t)ch * cap * w;
@@ -936,11 +998,17 @@ static int read_rows(jaero_ctx *c, int ch, double *rows, int caprows, int *nrows
 }
 extern "C" int jaero_read_status_log(jaero_ctx *c, int ch, double *rows, int caprows, int *nrows)
 {
-    return read_rows(c, ch, rows, caprows, nrows, I_LOG_CNT, c ? c->p.slog : nullptr, c ? c->g.log_cap : 0, 6, 4);
+    if (c && c->burst) return fail(JAERO_ENOTSUP, "burst banks have an event log (jaero_read_events), not a status log");
+    return read_rows(c, ch, rows, caprows, nrows, c ? c->p.I + (size_t)I_LOG_CNT * c->g.nchp : nullptr, c ? c->p.slog : nullptr, c ? c->g.log_cap : 0, 6, 4);
 }
 extern "C" int jaero_read_symbols(jaero_ctx *c, int ch, double *rows, int caprows, int *nrows)
 {
-    return read_rows(c, ch, rows, caprows, nrows, I_SYM_CNT, c ? c->p.sym : nullptr, c ? c->g.sym_cap : 0, 3, 2);
+    return read_rows(c, ch, rows, caprows, nrows, c ? c->o_sym_cnt : nullptr, c ? c->o_sym : nullptr, c ? c->o_sym_cap : 0, 3, 2);
+}
+extern "C" int jaero_read_events(jaero_ctx *c, int ch, double *rows, int caprows, int *nrows)
+{
+    if (c && !c->burst) return fail(JAERO_ENOTSUP, "continuous banks have a status log (jaero_read_status_log), not an event log");
+    return read_rows(c, ch, rows, caprows, nrows, c ? c->bp.I + (size_t)BI_EV_CNT * c->bg.nchp : nullptr, c ? c->bp.evlog : nullptr, c ? c->bg.ev_cap : 0, 3, 4);
 }
 
 // ------------------------------------------------------------------------------------------ Viterbi

@@ -1,0 +1,600 @@
+// k_burst_demod.h -- consumer side of the burst demodulators: the tracking chains, one channel per lane.
+//   k_burst_oqpsk_demod : JAERO/burstoqpskdemodulator.cpp:488-515 (trident result applied), :517-733
+//   k_burst_msk_demod   : JAERO/burstmskdemodulator.cpp:524-568 (trident result applied), :571-745
+// Input is val_to_demod = real(cv[n - D1 - D2]) from the ring k_burst_front filled; the trident verdict for the event sample of
+// this segment (if any) was computed by k_trident between the two launches.
+#pragma once
+#include "burst_device.h"
+#include "jaero_device.h"
+#include "k_burst_front.h"
+
+__device__ __forceinline__ void bd_set_phase_deg(double &ptr, double phase_deg) // WaveTable::SetPhaseDeg (DSP.cpp:175-180)
+{
+    phase_deg = fmod(phase_deg, 360.0);
+    while (phase_deg < 0) phase_deg += 360.0;
+    ptr = (phase_deg / 360.0) * ((double)JD_WTSIZE);
+}
+__device__ __forceinline__ void bd_event(const BGeom &g, const BPtrs &p, int ch, int &ev_cnt, int &overflow, long long sample, int kind, double value)
+{
+    if (ev_cnt < g.ev_cap)
+    {
+        double *e = p.evlog + ((size_t)ch * g.ev_cap + ev_cnt) * 3;
+        e[0] = (double)sample; e[1] = (double)kind; e[2] = value;
+        ev_cnt++;
+    }
+    else overflow |= 4;
+}
+__device__ __forceinline__ void bd_cmul(double &ar, double &ai, double br, double bi)
+{
+    const double r = ar * br - ai * bi, i = ar * bi + ai * br;
+    ar = r; ai = i;
+}
+
+template <bool CAPSYM>
+__global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const BPtrs p, int n, long long n0, int first_of_write)
+{
+    constexpr int FIRN = 55;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *lre = lds, *lim = lds + FIRN * 64;
+    const int lane = threadIdx.x, grp = blockIdx.x, ch = grp * 64 + lane, nchp = g.nchp;
+    const double2 *__restrict__ cis = p.cis;
+    const double *__restrict__ taps = p.taps2;
+    const double SPS = g.SPS, samplerate = g.Fs;
+
+    double m2_ptr = BLDF(BS_M2_PTR), m2_step = BLDF(BS_M2_STEP), m2_freq = BLDF(BS_M2_FREQ);
+    double st_ptr = BLDF(BS_ST_PTR), st_step = BLDF(BS_ST_STEP), st_freq = BLDF(BS_ST_FREQ), st_last = BLDF(BS_ST_LAST);
+    double stq_ptr = BLDF(BS_STQ_PTR), vol_gain = BLDF(BS_VOL_GAIN);
+    double str_re = BLDF(BS_STR_RE), str_im = BLDF(BS_STR_IM), sav_re = BLDF(BS_SAV_RE), sav_im = BLDF(BS_SAV_IM);
+    double rot_re = BLDF(BS_ROT_RE), rot_im = BLDF(BS_ROT_IM), rot_freq = BLDF(BS_ROT_FREQ);
+    double a1_1 = BLDF(BS_A1_1), a1_2 = BLDF(BS_A1_2), a1_3 = BLDF(BS_A1_3), a1_4 = BLDF(BS_A1_4), a1_5 = BLDF(BS_A1_5);
+    double agc2_sum = BLDF(BS_AGC2_SUM), eb_esum = BLDF(BS_EB_ESUM), eb_e2sum = BLDF(BS_EB_E2SUM), eb_ebno = BLDF(BS_EB_EBNO);
+    double d1 = BLDF(BS_D1), d41_1 = BLDF(BS_D41_1), d41_2 = BLDF(BS_D41_2), d41_3 = BLDF(BS_D41_3);
+    double d42_1 = BLDF(BS_D42_1), d42_2 = BLDF(BS_D42_2), d42_3 = BLDF(BS_D42_3), d8_1 = BLDF(BS_D8_1), d8_2 = BLDF(BS_D8_2);
+    double res_x1 = BLDF(BS_RES_X1), res_x2 = BLDF(BS_RES_X2), res_y1 = BLDF(BS_RES_Y1), res_y2 = BLDF(BS_RES_Y2);
+    double sig2l_re = BLDF(BS_SIG2L_RE), sig2l_im = BLDF(BS_SIG2L_IM), ptd_re = BLDF(BS_PTD_RE), ptd_im = BLDF(BS_PTD_IM);
+    double msema_sum = BLDF(BS_MSEMA_SUM), mse = BLDF(BS_MSE), lastmse = BLDF(BS_LASTMSE);
+    const double thresh = BLDF(BS_THRESH);
+    if (first_of_write) lastmse = mse; // double lastmse=mse at the top of writeDataSlot (:318)
+
+    int startstop = BLDI(BI_STARTSTOP), cntr = BLDI(BI_CNTR), yui = BLDI(BI_YUI), insertpre = BLDI(BI_INSERTPRE);
+    int msema_pos = BLDI(BI_MSEMA_POS), nrx = BLDI(BI_NRX);
+    int soft_cnt = BLDI(BI_SOFT_CNT), sym_cnt = BLDI(BI_SYM_CNT), ev_cnt = BLDI(BI_EV_CNT), overflow = BLDI(BI_OVERFLOW);
+    const int flags = BLDI(BI_FLAGS);
+    const int ev_pos = BLDI(BI_EV_POS);
+    const bool trace = (g.flags & 8u) != 0;
+
+    const double *__restrict__ cvre = p.cvre + (size_t)grp * g.cv_len * 64 + lane;
+    double *agc2_ring = p.agc2_ring + (size_t)grp * g.agc2_len * 64 + lane;
+    double *ebe_ring = p.eb_e + (size_t)grp * g.eb_len * 64 + lane;
+    double *ebe2_ring = p.eb_e2 + (size_t)grp * g.eb_len * 64 + lane;
+    double *msema_ring = p.msema + (size_t)ch * g.msema_len;
+    int16_t *__restrict__ soft = p.soft + (size_t)ch * g.soft_cap;
+
+    {
+        const double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
+        for (int k = 0; k < FIRN; k++) { lre[k * 64 + lane] = fs[(size_t)k * 64]; lim[k * 64 + lane] = fs[(size_t)(FIRN + k) * 64]; }
+    }
+    int fir_slot = (int)(n0 % FIRN), s_agc2 = (int)(n0 % g.agc2_len), s_eb = (int)(n0 % g.eb_len);
+    int s_val = (int)((n0 - g.D1 - g.D2 + 8LL * g.cv_len) % g.cv_len);
+    const double w4 = g.w4, w4c = 1.0 - g.w4, w8 = g.w8, w8c = 1.0 - g.w8, a1w = g.a1_w, a1wc = 1.0 - g.a1_w;
+    const double agc2_len_d = (double)g.agc2_len, eb_len_d = (double)g.eb_len;
+
+    for (int i = 0; i < n; i++)
+    {
+        const long long sample = n0 + i;
+        // ---- trident verdict for this sample (:488-515) ----
+        if (i == ev_pos)
+        {
+            const TriResult tr = p.tri[ch];
+            if (trace) bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_TRIDENT, tr.ok ? tr.metric : -tr.metric);
+            if (tr.ok)
+            {
+                jd_wt_setfreq(m2_freq, m2_step, tr.freq, samplerate);
+                bd_set_phase_deg(m2_ptr, tr.phase_deg);
+                bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_FREQ, m2_freq);
+                vol_gain = tr.vol_gain;
+                jd_wt_setfreq(st_freq, st_step, g.stref_freq, samplerate);
+                bd_set_phase_deg(st_ptr, 0);
+                res_x1 = res_x2 = res_y1 = res_y2 = 0;
+                startstop = g.startstopstart;
+                cntr = 0;
+                rot_re = 1; rot_im = 0;
+                insertpre = 1;
+                rot_freq = 0;
+                sav_re = 1; sav_im = 0;
+                bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_SIGNAL, 1.0);
+                mse = 0;
+                for (int k = 0; k < g.msema_len; k++) msema_ring[k] = 0;
+                msema_pos = 0; msema_sum = 0;
+            }
+        }
+        // ---- mix + rrc (:517-521) ----
+        const double val = cvre[(size_t)s_val * 64];
+        const double2 c2 = cis[jd_cisidx(m2_ptr)];
+        const double xin = (vol_gain * val);
+        const double cre = c2.x * xin, cim = c2.y * xin;
+        double sre = 0, sim = 0;
+        {
+            int slot = fir_slot;
+#pragma unroll 5
+            for (int t = 0; t < FIRN; t++)
+            {
+                const double tp = taps[t];
+                sre = fma(tp, lre[slot * 64 + lane], sre);
+                sim = fma(tp, lim[slot * 64 + lane], sim);
+                slot++; if (slot >= FIRN) slot = 0;
+            }
+            lre[fir_slot * 64 + lane] = cre; lim[fir_slot * 64 + lane] = cim;
+            fir_slot++; if (fir_slot >= FIRN) fir_slot = 0;
+        }
+        // ---- sample counting and signal time-out (:523-544) ----
+        if (startstop > 0)
+        {
+            startstop--;
+            if (cntr < 1000000) cntr++;
+            if (mse < 0.75) startstop = g.startstopstart;
+        }
+        if (startstop == 0) { startstop--; bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_SIGNAL, 0.0); }
+        if ((cntr > ((256 - 10) * SPS)) && insertpre)
+        {
+            if (soft_cnt < g.soft_cap) { soft[soft_cnt++] = (int16_t)-1; nrx++; } else overflow |= 1;
+            insertpre = 0;
+        }
+        // ---- symbol tone in the preamble (:547-566) ----
+        if ((cntr > SPS * (128 + 10)) && (cntr < ((256 - 10) * SPS)))
+        {
+            const double progress = (((double)cntr) - (SPS * (128 + 10))) / (((256 - 10) * SPS) - (SPS * (128 + 10)));
+            double t_re = sre, t_im = sim;
+            bd_cmul(t_re, t_im, str_re, str_im);
+            bd_cmul(t_re, t_im, 0.0, 1.0);
+            const double er = tanh(t_im) * (t_re);
+            double sn, cs;
+            sincos(er * 0.01, &sn, &cs);
+            bd_cmul(str_re, str_im, cs, sn);
+            sav_re = sav_re * 0.95 + 0.05 * str_re; sav_im = sav_im * 0.95 + 0.05 * str_im;
+            // a1.update(symboltone_pt.real()): Delay<double>(SPS/2): older = x[k-5], newer = x[k-4]
+            const double a1out = a1w * a1_4 + a1wc * a1_5;
+            a1_5 = a1_4; a1_4 = a1_3; a1_3 = a1_2; a1_2 = a1_1; a1_1 = t_re;
+            t_im = a1out;
+            const double2 cq = cis[jd_cisidx(stq_ptr)];
+            const double e_re = cq.x * t_re - cq.y * (-t_im), e_im = cq.x * (-t_im) + cq.y * t_re;
+            double st_err = atan2(e_im, e_re);
+            st_err *= 1.5 * (1.0 - progress * progress);
+            jd_wt_advance_fraction(stq_ptr, -(1.0 / (2.0 * M_PI)) * st_err * 0.1);
+            bd_set_phase_deg(st_ptr, (360.0 * stq_ptr / ((double)JD_WTSIZE)) * 4.0 + (360.0 * g.ee));
+        }
+        // ---- carrier phase correction, EbNo, AGC, clip (:570-590) ----
+        bd_cmul(sre, sim, sav_re, sav_im);
+        {
+            double sn, cs;
+            sincos(rot_freq, &sn, &cs);
+            bd_cmul(rot_re, rot_im, cs, sn);
+        }
+        bd_cmul(sre, sim, rot_re, rot_im);
+        const double sig2abs = hypot(sre, sim);
+        {
+            const double sq = sig2abs * sig2abs;
+            double *e2p = ebe2_ring + (size_t)s_eb * 64, *ep = ebe_ring + (size_t)s_eb * 64;
+            eb_e2sum = eb_e2sum - *e2p; eb_e2sum = eb_e2sum + fabs(sq); *e2p = fabs(sq);
+            eb_esum = eb_esum - *ep; eb_esum = eb_esum + fabs(sig2abs); *ep = fabs(sig2abs);
+            s_eb++; if (s_eb >= g.eb_len) s_eb = 0;
+            const double e2val = eb_e2sum / eb_len_d, mean = eb_esum / eb_len_d;
+            const double meansq = mean * mean;
+            double var = e2val - (mean * mean);
+            var -= (0.024709 * meansq);
+            double mvr = (((g.Fs * meansq / (2.0 * g.fb * var))) * 0.13743);
+            if (mvr < 0.000000001) mvr = 0.000000001;
+            double tebno = 10.0 * log10(mvr);
+            if (isnan(tebno)) tebno = 50;
+            if (tebno > 50.0) tebno = 50;
+            if (tebno < 0.0) tebno = 0;
+            eb_ebno = eb_ebno * 0.8 + 0.2 * tebno;
+        }
+        if (fabs(cntr - ((128.0 + 128.0 + 128.0) * SPS)) < 0.5) bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_EBNO, eb_ebno);
+        {
+            double *ap = agc2_ring + (size_t)s_agc2 * 64;
+            agc2_sum = agc2_sum - *ap; agc2_sum = agc2_sum + fabs(sig2abs); *ap = fabs(sig2abs);
+            s_agc2++; if (s_agc2 >= g.agc2_len) s_agc2 = 0;
+            double gain = 1.414213562 / fmax(agc2_sum / agc2_len_d, 0.000001);
+            gain = fmax(gain, 0.000001);
+            sre *= gain; sim *= gain;
+        }
+        const double abval = hypot(sre, sim);
+        if (abval > 2.84) { const double k = (2.84 / abval); sre = k * sre; sim = k * sim; }
+
+        // ---- symbol timer (:592-612) ----
+        const double ab2 = abval * abval;
+        const double st_diff = d1 - ab2; d1 = ab2;
+        const double st_d1out = w4 * d41_2 + w4c * d41_3; d41_3 = d41_2; d41_2 = d41_1; d41_1 = st_diff;
+        const double st_d2out = w4 * d42_2 + w4c * d42_3; d42_3 = d42_2; d42_2 = d42_1; d42_1 = st_d1out;
+        double st_eta = (st_d2out - st_diff) * st_d1out;
+        {
+            double y = 0;
+            y += res_x2 * g.res_b2; y += res_x1 * g.res_b1; y += st_eta * g.res_b0;
+            y -= res_y2 * g.res_a2; y -= res_y1 * g.res_a1;
+            res_x2 = res_x1; res_x1 = st_eta; res_y2 = res_y1; res_y1 = y;
+            if (cntr > SPS * (128 + 128)) st_eta = y;
+        }
+        const double d8out = w8 * d8_1 + w8c * d8_2; d8_2 = d8_1; d8_1 = st_eta;
+        {
+            const double2 so = cis[jd_cisidx(st_ptr)];
+            const double m_re = st_eta, m_im = -d8out;
+            const double o_re = so.x * m_re - so.y * m_im, o_im = so.x * m_im + so.y * m_re;
+            const double st_angle_error = atan2(o_im, o_re);
+            if (cntr > SPS * (128 + 64))
+            {
+                jd_wt_setfreq(st_freq, st_step, (-st_angle_error * 0.00000001) + st_freq, samplerate);
+                jd_wt_advance_fraction(st_ptr, -st_angle_error * 0.01 / 360.0);
+            }
+            if (st_freq < (g.stref_freq - 0.1)) jd_wt_setfreq(st_freq, st_step, (g.stref_freq - 0.1), samplerate);
+            if (st_freq > (g.stref_freq + 0.1)) jd_wt_setfreq(st_freq, st_step, (g.stref_freq + 0.1), samplerate);
+        }
+        // ---- sample times (:615-724) ----
+        double frac;
+        if (jd_wt_passed(st_last, st_ptr, st_step, g.ee, frac))
+        {
+            const double pt_last = frac, pt_this = 1.0 - pt_last;
+            const double pt_re = pt_this * sre + pt_last * sig2l_re, pt_im = pt_this * sim + pt_last * sig2l_im;
+            const double twospeed = -4.0 * ((fmod((360.0 * stq_ptr / ((double)JD_WTSIZE)) * 2.0 + (360.0 * g.ee * 0.5), 360.0) / 360.0) - (0.34046 + 0.4111 * g.ee));
+            const bool even = !(twospeed < 0);
+            yui++; yui %= 2;
+            if (cntr < ((128 + 128) * SPS))
+            {
+                if ((even && yui == 1) || (!even && yui == 0)) { yui++; yui %= 2; }
+            }
+            if (!yui) { ptd_re = pt_re; ptd_im = pt_im; }
+            else
+            {
+                const double q_re = pt_re, q_im = ptd_im;
+                const double ct_xt = tanh(pt_im) * pt_re;
+                const double ct_xt_d = tanh(ptd_re) * ptd_im;
+                double ct_ec = ct_xt_d - ct_xt;
+                if (ct_ec > M_PI) ct_ec = M_PI;
+                if (ct_ec < -M_PI) ct_ec = -M_PI;
+                if (ct_ec > M_PI_2) ct_ec = M_PI_2;
+                if (ct_ec < -M_PI_2) ct_ec = -M_PI_2;
+                if (cntr > ((128 + 10) * SPS))
+                {
+                    double sn, cs;
+                    sincos(ct_ec * 0.1, &sn, &cs);
+                    bd_cmul(rot_re, rot_im, cs, sn);
+                    rot_freq = rot_freq + ct_ec * 0.0001;
+                    const double tda = (fabs(q_re) - 1.0), tdb = (fabs(q_im) - 1.0);
+                    const double e = (tda * tda) + (tdb * tdb);
+                    double *mp = msema_ring + msema_pos;
+                    msema_sum = msema_sum - *mp; msema_sum = msema_sum + fabs(e); *mp = fabs(e);
+                    msema_pos++; if (msema_pos >= g.msema_len) msema_pos = 0;
+                    mse = msema_sum / ((double)g.msema_len);
+                }
+                if (startstop > 0)
+                {
+                    if (CAPSYM)
+                    {
+                        if (sym_cnt < g.sym_cap) { double *sp = p.sym + ((size_t)ch * g.sym_cap + sym_cnt) * 3; sp[0] = q_re; sp[1] = q_im; sp[2] = mse; sym_cnt++; }
+                        else overflow |= 2;
+                    }
+                    const int b0 = jd_softbit(0.75 * q_im * 127.0 + 128.0);
+                    const int b1 = jd_softbit(0.75 * q_re * 127.0 + 128.0);
+                    if (soft_cnt + 2 <= g.soft_cap) { soft[soft_cnt] = (int16_t)b0; soft[soft_cnt + 1] = (int16_t)b1; soft_cnt += 2; nrx += 2; }
+                    else overflow |= 1;
+                    if (nrx >= 32)
+                    {
+                        // emit unless squelched (:708-715); a squelched group is dropped
+                        if (!(!(flags & JF_SQL) || mse < thresh || lastmse < thresh)) soft_cnt -= nrx;
+                        nrx = 0;
+                    }
+                }
+            }
+        }
+        sig2l_re = sre; sig2l_im = sim;
+        // ---- advance the oscillators (:727-730) ----
+        jd_wt_next(m2_ptr, m2_step);
+        if (st_step < 0) st_step = 0;
+        st_last = st_ptr;
+        st_ptr += st_step;
+        while (((int)st_ptr) >= JD_WTSIZE) st_ptr -= JD_WTSIZE;
+        stq_ptr += g.stq_step;
+        while (((int)stq_ptr) >= JD_WTSIZE) stq_ptr -= JD_WTSIZE;
+        s_val++; if (s_val >= g.cv_len) s_val = 0;
+    }
+
+    BLDF(BS_M2_PTR) = m2_ptr; BLDF(BS_M2_STEP) = m2_step; BLDF(BS_M2_FREQ) = m2_freq;
+    BLDF(BS_ST_PTR) = st_ptr; BLDF(BS_ST_STEP) = st_step; BLDF(BS_ST_FREQ) = st_freq; BLDF(BS_ST_LAST) = st_last;
+    BLDF(BS_STQ_PTR) = stq_ptr; BLDF(BS_VOL_GAIN) = vol_gain;
+    BLDF(BS_STR_RE) = str_re; BLDF(BS_STR_IM) = str_im; BLDF(BS_SAV_RE) = sav_re; BLDF(BS_SAV_IM) = sav_im;
+    BLDF(BS_ROT_RE) = rot_re; BLDF(BS_ROT_IM) = rot_im; BLDF(BS_ROT_FREQ) = rot_freq;
+    BLDF(BS_A1_1) = a1_1; BLDF(BS_A1_2) = a1_2; BLDF(BS_A1_3) = a1_3; BLDF(BS_A1_4) = a1_4; BLDF(BS_A1_5) = a1_5;
+    BLDF(BS_AGC2_SUM) = agc2_sum; BLDF(BS_EB_ESUM) = eb_esum; BLDF(BS_EB_E2SUM) = eb_e2sum; BLDF(BS_EB_EBNO) = eb_ebno;
+    BLDF(BS_D1) = d1; BLDF(BS_D41_1) = d41_1; BLDF(BS_D41_2) = d41_2; BLDF(BS_D41_3) = d41_3;
+    BLDF(BS_D42_1) = d42_1; BLDF(BS_D42_2) = d42_2; BLDF(BS_D42_3) = d42_3; BLDF(BS_D8_1) = d8_1; BLDF(BS_D8_2) = d8_2;
+    BLDF(BS_RES_X1) = res_x1; BLDF(BS_RES_X2) = res_x2; BLDF(BS_RES_Y1) = res_y1; BLDF(BS_RES_Y2) = res_y2;
+    BLDF(BS_SIG2L_RE) = sig2l_re; BLDF(BS_SIG2L_IM) = sig2l_im; BLDF(BS_PTD_RE) = ptd_re; BLDF(BS_PTD_IM) = ptd_im;
+    BLDF(BS_MSEMA_SUM) = msema_sum; BLDF(BS_MSE) = mse; BLDF(BS_LASTMSE) = lastmse;
+    BLDI(BI_STARTSTOP) = startstop; BLDI(BI_CNTR) = cntr; BLDI(BI_YUI) = yui; BLDI(BI_INSERTPRE) = insertpre;
+    BLDI(BI_MSEMA_POS) = msema_pos; BLDI(BI_NRX) = nrx;
+    BLDI(BI_SOFT_CNT) = soft_cnt; BLDI(BI_SYM_CNT) = sym_cnt; BLDI(BI_EV_CNT) = ev_cnt; BLDI(BI_OVERFLOW) = overflow;
+    {
+        double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
+        for (int k = 0; k < FIRN; k++) { fs[(size_t)k * 64] = lre[k * 64 + lane]; fs[(size_t)(FIRN + k) * 64] = lim[k * 64 + lane]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ burst MSK
+// Everything after the sample counters runs only while (startstop > 0 || mse < signalthreshold) (:601), so the matched
+// filter, agc2, EbNo, delayedsmpl and delayt8 rings advance per channel: their positions are per-lane state and the rings are
+// per-channel arrays; the matched-filter ring lives in LDS for the launch ([slot][lane], per-lane slot, conflict-free).
+template <bool CAPSYM>
+__global__ __launch_bounds__(64) void k_burst_msk_demod(const BGeom g, const BPtrs p, int n, long long n0, int first_of_write)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int FIRN = g.fir_n;
+    double *lre = lds, *lim = lds + FIRN * 64;
+    const int lane = threadIdx.x, grp = blockIdx.x, ch = grp * 64 + lane, nchp = g.nchp;
+    const double2 *__restrict__ cis = p.cis;
+    const double *__restrict__ taps = p.taps2;
+    const double SPS = g.SPS, samplerate = g.Fs;
+
+    double m2_ptr = BLDF(BS_M2_PTR), m2_step = BLDF(BS_M2_STEP), m2_freq = BLDF(BS_M2_FREQ), mc_freq = BLDF(BS_MC_FREQ);
+    double st_ptr = BLDF(BS_ST_PTR), st_last = BLDF(BS_ST_LAST), sth_ptr = BLDF(BS_STQ_PTR), vol_gain = BLDF(BS_VOL_GAIN);
+    const double st_step = BLDF(BS_ST_STEP);
+    double str_re = BLDF(BS_STR_RE), str_im = BLDF(BS_STR_IM), sav_re = BLDF(BS_SAV_RE), sav_im = BLDF(BS_SAV_IM);
+    double rot_re = BLDF(BS_ROT_RE), rot_im = BLDF(BS_ROT_IM), rot_freq = BLDF(BS_ROT_FREQ);
+    double agc2_sum = BLDF(BS_AGC2_SUM), eb_esum = BLDF(BS_EB_ESUM), eb_e2sum = BLDF(BS_EB_E2SUM), eb_ebno = BLDF(BS_EB_EBNO);
+    double res_x1 = BLDF(BS_RES_X1), res_x2 = BLDF(BS_RES_X2), res_y1 = BLDF(BS_RES_Y1), res_y2 = BLDF(BS_RES_Y2);
+    double msema_sum = BLDF(BS_MSEMA_SUM), mse = BLDF(BS_MSE), diff_last = BLDF(BS_DIFF_LAST);
+    const double thresh = BLDF(BS_THRESH), lockingbw = BLDF(BS_LOCKINGBW);
+
+    int startstop = BLDI(BI_STARTSTOP), cntr = BLDI(BI_CNTR), msema_pos = BLDI(BI_MSEMA_POS), nrx = BLDI(BI_NRX);
+    int fir_pos = BLDI(BI_FIR_POS), agc2_pos = BLDI(BI_AGC2_POS), eb_pos = BLDI(BI_EB_POS), dly_pos = BLDI(BI_DLY_POS), d8_pos = BLDI(BI_D8_POS), a1_pos = BLDI(BI_A1_POS);
+    int soft_cnt = BLDI(BI_SOFT_CNT), sym_cnt = BLDI(BI_SYM_CNT), ev_cnt = BLDI(BI_EV_CNT), overflow = BLDI(BI_OVERFLOW);
+    const int flags = BLDI(BI_FLAGS);
+    const int ev_pos = BLDI(BI_EV_POS);
+    const bool dcd = flags & JF_DCD, afc = flags & JF_AFC;
+    const bool trace = (g.flags & 8u) != 0;
+    (void)first_of_write;
+
+    const double *__restrict__ cvre = p.cvre + (size_t)grp * g.cv_len * 64 + lane;
+    double *agc2_ring = p.agc2_ring + (size_t)ch * g.agc2_len;
+    double *ebe_ring = p.eb_e + (size_t)ch * g.eb_len, *ebe2_ring = p.eb_e2 + (size_t)ch * g.eb_len;
+    double2 *dly_ring = p.dly + (size_t)ch * g.dly_len;
+    double *d8_ring = p.dly8 + (size_t)ch * g.d8_len;
+    double *a1_ring = p.a1 + (size_t)ch * g.d8_len;
+    double *msema_ring = p.msema + (size_t)ch * g.msema_len;
+    int16_t *__restrict__ soft = p.soft + (size_t)ch * g.soft_cap;
+    {
+        const double *fs = p.firsave + (size_t)ch * 2 * FIRN;
+        for (int k = 0; k < FIRN; k++) { lre[k * 64 + lane] = fs[k]; lim[k * 64 + lane] = fs[FIRN + k]; }
+    }
+    int s_val = (int)((n0 - g.D1 - g.D2 + 8LL * g.cv_len) % g.cv_len);
+    const double agc2_len_d = (double)g.agc2_len, eb_len_d = (double)g.eb_len;
+
+    for (int i = 0; i < n; i++)
+    {
+        const long long sample = n0 + i;
+        // ---- trident verdict (:524-568) ----
+        if (i == ev_pos)
+        {
+            const TriResult tr = p.tri[ch];
+            const bool ok = tr.ok && !(dcd) && !(cntr > 0 && cntr < (500 * SPS));
+            if (trace) bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_TRIDENT, ok ? tr.metric : -tr.metric);
+            if (ok)
+            {
+                vol_gain = tr.vol_gain;
+                bd_set_phase_deg(m2_ptr, tr.phase_deg);
+                jd_wt_setfreq(m2_freq, m2_step, tr.freq, samplerate);
+                // CenterFreqChangedSlot(freq) (:327-343)
+                {
+                    double fc = tr.freq;
+                    if (fc < (0.75 * g.fb)) fc = 0.75 * g.fb;
+                    if (fc > (g.Fs / 2.0 - 0.75 * g.fb)) fc = g.Fs / 2.0 - 0.75 * g.fb;
+                    mc_freq = fc; if (mc_freq < 0) mc_freq = 0;
+                    if (afc) jd_wt_setfreq(m2_freq, m2_step, mc_freq, samplerate);
+                    if ((m2_freq - mc_freq) > (lockingbw / 2.0)) jd_wt_setfreq(m2_freq, m2_step, mc_freq + (lockingbw / 2.0), samplerate);
+                    if ((m2_freq - mc_freq) < (-lockingbw / 2.0)) jd_wt_setfreq(m2_freq, m2_step, mc_freq - (lockingbw / 2.0), samplerate);
+                    bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_FREQ, m2_freq);
+                }
+                bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_FREQ, m2_freq);
+                startstop = g.startstopstart;
+                cntr = 0;
+                bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_SIGNAL, 1.0);
+                soft_cnt -= nrx; nrx = 0; // RxDataBits.clear()
+                if (soft_cnt < g.soft_cap) { soft[soft_cnt++] = (int16_t)-1; nrx = 1; } else overflow |= 1;
+                mse = 0;
+                for (int k = 0; k < g.msema_len; k++) msema_ring[k] = 0;
+                msema_pos = 0; msema_sum = 0;
+                sav_re = 1; sav_im = 0; str_re = 1; str_im = 0;
+                rot_re = 1; rot_im = 0; rot_freq = 0;
+                res_x1 = res_x2 = res_y1 = res_y2 = 0;
+                bd_set_phase_deg(st_ptr, 0);
+                bd_set_phase_deg(sth_ptr, 0);
+            }
+        }
+        const double val = cvre[(size_t)s_val * 64];
+        s_val++; if (s_val >= g.cv_len) s_val = 0;
+        // ---- sample counting (:571-598) ----
+        if (startstop > 0)
+        {
+            if (cntr >= (g.startProcessing * SPS)) startstop--;
+            if (cntr < 1000000) cntr++;
+            if (mse < thresh) startstop = g.startstopstart;
+        }
+        if (startstop == 0)
+        {
+            startstop--;
+            bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_SIGNAL, 0.0);
+            cntr = 0;
+            mse = 1;
+        }
+        if (startstop > 0 || mse < thresh)
+        {
+            const double2 c2 = cis[jd_cisidx(m2_ptr)];
+            const double cre = (c2.x * val) * vol_gain, cim = (c2.y * val) * vol_gain;
+            double sre = 0, sim = 0;
+            {
+                int slot = fir_pos;
+                for (int t = 0; t < FIRN; t++)
+                {
+                    const double tp = taps[t];
+                    sre = fma(tp, lre[slot * 64 + lane], sre);
+                    sim = fma(tp, lim[slot * 64 + lane], sim);
+                    slot++; if (slot >= FIRN) slot = 0;
+                }
+                lre[fir_pos * 64 + lane] = cre; lim[fir_pos * 64 + lane] = cim;
+                fir_pos++; if (fir_pos >= FIRN) fir_pos = 0;
+            }
+            if (cntr > (g.startProcessing * SPS) && cntr < g.endRotation)
+            {
+                double t_re = sre, t_im = sim;
+                bd_cmul(t_re, t_im, str_re, str_im);
+                bd_cmul(t_re, t_im, 0.0, 1.0);
+                const double er = tanh(t_im) * (t_re);
+                double sn, cs;
+                sincos(er * 0.5, &sn, &cs);
+                bd_cmul(str_re, str_im, cs, sn);
+                sav_re = sav_re * 0.999 + 0.001 * str_re; sav_im = sav_im * 0.999 + 0.001 * str_im;
+                // a1.update(): integer delay SPS/2 -> weighting 0: the value written d8_len-1 updates ago
+                a1_ring[a1_pos] = t_re;
+                a1_pos++; if (a1_pos >= g.d8_len) a1_pos = 0;
+                t_im = 0.0 * a1_ring[(a1_pos + 1 >= g.d8_len) ? 0 : a1_pos + 1] + 1.0 * a1_ring[a1_pos];
+                double progress = (double)cntr - (SPS * (g.startProcessing));
+                const double goal = g.endRotation - (SPS * g.startProcessing);
+                progress = progress / goal;
+                const double2 cq = cis[jd_cisidx(sth_ptr)];
+                const double e_re = cq.x * t_re - cq.y * (-t_im), e_im = cq.x * (-t_im) + cq.y * t_re;
+                double st_err = atan2(e_im, e_re);
+                st_err *= 0.5 * (1.0 - progress * progress);
+                jd_wt_advance_fraction(sth_ptr, -(1.0 / (2.0 * M_PI)) * st_err * 0.05);
+                bd_set_phase_deg(st_ptr, (360.0 * sth_ptr / ((double)JD_WTSIZE)) + (360.0 * (1.0 - g.ee)));
+            }
+            bd_cmul(sre, sim, sav_re, sav_im);
+            {
+                double sn, cs;
+                sincos(rot_freq, &sn, &cs);
+                bd_cmul(rot_re, rot_im, cs, sn);
+            }
+            bd_cmul(sre, sim, rot_re, rot_im);
+            const double sabs = hypot(sre, sim);
+            {
+                const double sq = sabs * sabs;
+                double *e2p = ebe2_ring + eb_pos, *ep = ebe_ring + eb_pos;
+                eb_e2sum = eb_e2sum - *e2p; eb_e2sum = eb_e2sum + fabs(sq); *e2p = fabs(sq);
+                eb_esum = eb_esum - *ep; eb_esum = eb_esum + fabs(sabs); *ep = fabs(sabs);
+                eb_pos++; if (eb_pos >= g.eb_len) eb_pos = 0;
+                const double e2val = eb_e2sum / eb_len_d, mean = eb_esum / eb_len_d;
+                const double var = e2val - (mean * mean);
+                const double alpha = sqrt(2.0) / mean;
+                double tebno = 10.0 * (log10(2.0) - log10(((var * alpha * alpha) - 0.0085))) - 5.0;
+                if (isnan(tebno)) tebno = 50;
+                if (tebno > 50.0) tebno = 50;
+                eb_ebno = eb_ebno * 0.8 + 0.2 * tebno;
+            }
+            if (cntr == g.endRotation + (200 * SPS)) bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_EBNO, eb_ebno);
+            {
+                double *ap = agc2_ring + agc2_pos;
+                agc2_sum = agc2_sum - *ap; agc2_sum = agc2_sum + fabs(sabs); *ap = fabs(sabs);
+                agc2_pos++; if (agc2_pos >= g.agc2_len) agc2_pos = 0;
+                double gain = 1.414213562 / fmax(agc2_sum / agc2_len_d, 0.000001);
+                gain = fmax(gain, 0.000001);
+                sre *= gain; sim *= gain;
+            }
+            const double abval = hypot(sre, sim);
+            if (abval > 2.84) { const double k = (2.84 / abval); sre = k * sre; sim = k * sim; }
+            // delayedsmpl.update_dont_touch(sig2)
+            dly_ring[dly_pos] = make_double2(sre, sim);
+            dly_pos++; if (dly_pos >= g.dly_len) dly_pos = 0;
+            const double2 ptd = dly_ring[dly_pos];
+            const double pm_re = sre, pm_im = ptd.y;
+            double st_eta = hypot(pm_re, pm_im);
+            {
+                double y = 0;
+                y += res_x2 * g.res_b2; y += res_x1 * g.res_b1; y += st_eta * g.res_b0;
+                y -= res_y2 * g.res_a2; y -= res_y1 * g.res_a1;
+                res_x2 = res_x1; res_x1 = st_eta; res_y2 = res_y1; res_y1 = y;
+                st_eta = y;
+            }
+            // delayt8.update(st_eta): integer delay SPS/2
+            d8_ring[d8_pos] = st_eta;
+            d8_pos++; if (d8_pos >= g.d8_len) d8_pos = 0;
+            const double d8out = 0.0 * d8_ring[(d8_pos + 1 >= g.d8_len) ? 0 : d8_pos + 1] + 1.0 * d8_ring[d8_pos];
+            {
+                const double2 so = cis[jd_cisidx(st_ptr)];
+                const double m_re = st_eta, m_im = -d8out;
+                const double o_re = so.x * m_re - so.y * m_im, o_im = so.x * m_im + so.y * m_re;
+                const double st_angle_error = atan2(o_im, o_re);
+                if (cntr > g.endRotation) jd_wt_advance_fraction(st_ptr, -st_angle_error * 0.002 / 360.0);
+            }
+            double frac;
+            if (jd_wt_passed(st_last, st_ptr, st_step, g.ee, frac))
+            {
+                const double ct_xt = tanh(sim) * sre;
+                const double ct_xt_d = tanh(ptd.x) * ptd.y;
+                double ct_ec = ct_xt_d - ct_xt;
+                if (ct_ec > M_PI) ct_ec = M_PI;
+                if (ct_ec < -M_PI) ct_ec = -M_PI;
+                if (ct_ec > M_PI_2) ct_ec = M_PI_2;
+                if (ct_ec < -M_PI_2) ct_ec = -M_PI_2;
+                if (cntr > (g.startProcessing * SPS))
+                {
+                    double sn, cs;
+                    sincos(ct_ec * 0.25, &sn, &cs);
+                    bd_cmul(rot_re, rot_im, cs, sn);
+                    if (cntr > g.endRotation) rot_freq = rot_freq + ct_ec * 0.0001;
+                    const double tda = (fabs((pm_re * 0.75)) - 1.0), tdb = (fabs((pm_im * 0.75)) - 1.0);
+                    const double e = (tda * tda) + (tdb * tdb);
+                    double *mp = msema_ring + msema_pos;
+                    msema_sum = msema_sum - *mp; msema_sum = msema_sum + fabs(e); *mp = fabs(e);
+                    msema_pos++; if (msema_pos >= g.msema_len) msema_pos = 0;
+                    mse = msema_sum / ((double)g.msema_len);
+                }
+                if (CAPSYM)
+                {
+                    if (sym_cnt < g.sym_cap) { double *sp = p.sym + ((size_t)ch * g.sym_cap + sym_cnt) * 3; sp[0] = pm_re; sp[1] = pm_im; sp[2] = mse; sym_cnt++; }
+                    else overflow |= 2;
+                }
+                // DiffDecode::UpdateSoft x2 (DSP.cpp:531-563)
+                double imagin, realv;
+                {
+                    const double sf = pm_im;
+                    if (sf < 0 && diff_last < 0) imagin = diff_last;
+                    else if (sf > 0 && diff_last > 0) imagin = -diff_last;
+                    else imagin = fabs(diff_last);
+                    diff_last = sf;
+                }
+                {
+                    const double sf = pm_re;
+                    if (sf < 0 && diff_last < 0) realv = diff_last;
+                    else if (sf > 0 && diff_last > 0) realv = -diff_last;
+                    else realv = fabs(diff_last);
+                    diff_last = sf;
+                }
+                realv = -realv;
+                const int b0 = jd_softbit((imagin) * 127.0 + 128.0);
+                const int b1 = jd_softbit((realv) * 127.0 + 128.0);
+                if (soft_cnt + 2 <= g.soft_cap) { soft[soft_cnt] = (int16_t)b0; soft[soft_cnt + 1] = (int16_t)b1; soft_cnt += 2; nrx += 2; }
+                else overflow |= 1;
+                if (nrx >= 12) nrx = 0;
+            }
+            // st_osc / st_osc_half / mixer2 WTnextFrame (:736-740)
+            st_last = st_ptr;
+            st_ptr += st_step;
+            while (((int)st_ptr) >= JD_WTSIZE) st_ptr -= JD_WTSIZE;
+            sth_ptr += st_step;
+            while (((int)sth_ptr) >= JD_WTSIZE) sth_ptr -= JD_WTSIZE;
+            jd_wt_next(m2_ptr, m2_step);
+        }
+    }
+    BLDF(BS_M2_PTR) = m2_ptr; BLDF(BS_M2_STEP) = m2_step; BLDF(BS_M2_FREQ) = m2_freq; BLDF(BS_MC_FREQ) = mc_freq;
+    BLDF(BS_ST_PTR) = st_ptr; BLDF(BS_ST_LAST) = st_last; BLDF(BS_STQ_PTR) = sth_ptr; BLDF(BS_VOL_GAIN) = vol_gain;
+    BLDF(BS_STR_RE) = str_re; BLDF(BS_STR_IM) = str_im; BLDF(BS_SAV_RE) = sav_re; BLDF(BS_SAV_IM) = sav_im;
+    BLDF(BS_ROT_RE) = rot_re; BLDF(BS_ROT_IM) = rot_im; BLDF(BS_ROT_FREQ) = rot_freq;
+    BLDF(BS_AGC2_SUM) = agc2_sum; BLDF(BS_EB_ESUM) = eb_esum; BLDF(BS_EB_E2SUM) = eb_e2sum; BLDF(BS_EB_EBNO) = eb_ebno;
+    BLDF(BS_RES_X1) = res_x1; BLDF(BS_RES_X2) = res_x2; BLDF(BS_RES_Y1) = res_y1; BLDF(BS_RES_Y2) = res_y2;
+    BLDF(BS_MSEMA_SUM) = msema_sum; BLDF(BS_MSE) = mse; BLDF(BS_DIFF_LAST) = diff_last;
+    BLDI(BI_STARTSTOP) = startstop; BLDI(BI_CNTR) = cntr; BLDI(BI_MSEMA_POS) = msema_pos; BLDI(BI_NRX) = nrx;
+    BLDI(BI_FIR_POS) = fir_pos; BLDI(BI_AGC2_POS) = agc2_pos; BLDI(BI_EB_POS) = eb_pos; BLDI(BI_DLY_POS) = dly_pos; BLDI(BI_D8_POS) = d8_pos; BLDI(BI_A1_POS) = a1_pos;
+    BLDI(BI_SOFT_CNT) = soft_cnt; BLDI(BI_SYM_CNT) = sym_cnt; BLDI(BI_EV_CNT) = ev_cnt; BLDI(BI_OVERFLOW) = overflow;
+    {
+        double *fs = p.firsave + (size_t)ch * 2 * FIRN;
+        for (int k = 0; k < FIRN; k++) { fs[k] = lre[k * 64 + lane]; fs[FIRN + k] = lim[k * 64 + lane]; }
+    }
+}

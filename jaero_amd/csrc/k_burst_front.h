@@ -1,0 +1,398 @@
+// k_burst_front.h -- producer side of the burst demodulators: Hilbert FIR, burst-timing detector, trident check.
+// Reference: JAERO/burstoqpskdemodulator.cpp:323-515, JAERO/burstmskdemodulator.cpp:376-569, JAERO/DSP.cpp:754-794 (QJHilbertFilter),
+// JAERO/DSP.h:491-576 (PeakDetector), JAERO/fftrwrapper.cpp:19-27.
+#pragma once
+#include "burst_device.h"
+#include "jaero_device.h"
+#include "k_coarse2.h"
+
+#define BLDF(f) (p.S[(size_t)(f) * nchp + ch])
+#define BLDI(f) (p.I[(size_t)(f) * nchp + ch])
+
+// ------------------------------------------------------------------------------------------------ Hilbert
+// hfir.update(hfirbuff) (JAERO/burstoqpskdemodulator.cpp:344, JAERO/DSP.cpp:754-794): the 2048-tap kernel is
+//   kernel[1024] = -1, kernel[odd k] = j (2/N)/tan(pi (k/N - 1/2)), everything else 0, and JFastFir delays by L = nfft-K+1.
+// So   re y[n] = -x[n-L-1024],   im y[n] = sum_{j<512} h[2j+1] (x[n-L-(2j+1)] - x[n-L-(2047-2j)])   (h[N-k] = -h[k]).
+// One wavefront = 64 channels (lane = channel) x HB_R consecutive outputs; taps are wave-uniform (scalar loads); the two input
+// windows of a block of HB_U tap pairs are loaded once into registers (static indices after unrolling, no shifting).
+#define HB_R 16
+#define HB_U 8
+__global__ __launch_bounds__(256) void k_hilbert(const BGeom g, const BPtrs p, int ns, long long n0)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int grp = blockIdx.x, ch = grp * 64 + lane;
+    const int i0 = (blockIdx.y * 4 + wv) * HB_R;
+    if (i0 >= ns) return;
+    const int H = g.hist_len, nchp = g.nchp;
+    const int16_t *__restrict__ hist = p.pcmhist + ch;
+    const double *__restrict__ taps = p.hil_taps;
+    // index of x feeding tap k = 0 of output r = 0, made non-negative by a multiple of the ring length
+    const long long nb0 = n0 + i0 - g.hil_lat + 4LL * H;
+    double acc[HB_R];
+#pragma unroll
+    for (int r = 0; r < HB_R; r++) acc[r] = 0.0;
+    constexpr int WN = HB_R + 2 * (HB_U - 1);
+    for (int j0 = 0; j0 < 512; j0 += HB_U)
+    {
+        double ea[WN], eb[WN];
+        int sa = (int)((nb0 - 2 * j0 - 1 - 2 * (HB_U - 1)) % H);
+        int sb = (int)((nb0 - 2047 + 2 * j0) % H);
+#pragma unroll
+        for (int m = 0; m < WN; m++)
+        {
+            ea[m] = (double)hist[(size_t)sa * nchp];
+            eb[m] = (double)hist[(size_t)sb * nchp];
+            sa++; if (sa >= H) sa = 0;
+            sb++; if (sb >= H) sb = 0;
+        }
+#pragma unroll
+        for (int u = 0; u < HB_U; u++)
+        {
+            const double tp = taps[j0 + u];
+#pragma unroll
+            for (int r = 0; r < HB_R; r++) acc[r] = fma(tp, ea[r - 2 * u + 2 * (HB_U - 1)] - eb[r + 2 * u], acc[r]);
+        }
+    }
+    int sr = (int)((nb0 - 1024) % H);
+    double *__restrict__ ore = p.hre + ((size_t)grp * g.maxseg + i0) * 64 + lane;
+    double *__restrict__ oim = p.him + ((size_t)grp * g.maxseg + i0) * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < HB_R; r++)
+    {
+        if (i0 + r < ns)
+        {
+            // PCM -> double as the reference does (x/32768.0); the taps carry no scaling, so scale the sums here
+            ore[(size_t)r * 64] = -(((double)hist[(size_t)sr * nchp]) / 32768.0);
+            oim[(size_t)r * 64] = acc[r] / 32768.0;
+        }
+        sr++; if (sr >= H) sr = 0;
+    }
+}
+
+// PCM frames -> history ring rows (frame-major [n][stride] -> ring [slot][nchp])
+__global__ void k_hist_push_frames(const int16_t *__restrict__ src, int stride, int nch, int16_t *__restrict__ hist, int nchp, int H,
+                                   int slot0, int n)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (c >= nchp || i >= n) return;
+    int slot = slot0 + i; if (slot >= H) slot -= H;
+    hist[(size_t)slot * nchp + c] = (c < nch) ? src[(size_t)i * stride + c] : (int16_t)0;
+}
+// channel-major [nch][n] -> ring rows, through a 64x64 LDS tile
+__global__ void k_hist_push_chmajor(const int16_t *__restrict__ src, int nch, int n, int16_t *__restrict__ hist, int nchp, int H, int slot0)
+{
+    __shared__ int16_t tile[64][65];
+    const int c0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4)
+    {
+        const int c = c0 + r, i = i0 + tx;
+        tile[r][tx] = (c < nch && i < n) ? src[(size_t)c * n + i] : (int16_t)0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4)
+    {
+        const int i = i0 + r, c = c0 + tx;
+        if (i < n && c < nchp)
+        {
+            int slot = (slot0 + i) % H;
+            hist[(size_t)slot * nchp + c] = tile[tx][r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ front end
+// Per sample (burstoqpskdemodulator.cpp:372-410 == burstmskdemodulator.cpp:413-441): AGC, the delay lines, the burst-timing
+// signal, the peak detector and the trident-buffer fill counter.  d1, d2, bt_d1 and tridentbuffer are all read out of ONE ring
+// of AGC'd analytic samples (cvre/cvim).  All ring addresses are data independent, so a block of FB samples' worth of loads is
+// issued before the block's serial arithmetic (every lag is >= 9 > FB, so nothing a block needs is written inside it).
+#define FB 8
+__device__ __forceinline__ int bwrap(int s, int len) { return s >= len ? s - len : s; }
+__device__ __forceinline__ int bback(int s, int lag, int len) { s -= lag; return s < 0 ? s + len : s; }
+
+__global__ __launch_bounds__(64) void k_burst_front(const BGeom g, const BPtrs p, int n, long long n0)
+{
+    const int lane = threadIdx.x, grp = blockIdx.x, ch = grp * 64 + lane, nchp = g.nchp;
+    double agc_sum = BLDF(BS_AGC_SUM), ma1_re = BLDF(BS_MA1_RE), ma1_im = BLDF(BS_MA1_IM), mav1_sum = BLDF(BS_MAV1_SUM), lastdy = BLDF(BS_LASTDY);
+    int cntdown = BLDI(BI_CNTDOWN), maxposcd = BLDI(BI_MAXPOSCD), tri_ptr = BLDI(BI_TRI_PTR);
+    const int flags = BLDI(BI_FLAGS);
+    int ev_pos = -1, ev_cnt = BLDI(BI_EV_CNT);
+    const bool trace = (g.flags & 8u) != 0; // JAERO_FLAG_TRACE
+
+    const double *__restrict__ hre = p.hre + (size_t)grp * g.maxseg * 64 + lane;
+    const double *__restrict__ him = p.him + (size_t)grp * g.maxseg * 64 + lane;
+    double *agc_ring = p.agc_ring + (size_t)grp * g.agc_len * 64 + lane;
+    double *cvre = p.cvre + (size_t)grp * g.cv_len * 64 + lane;
+    double *cvim = p.cvim + (size_t)grp * g.cv_len * 64 + lane;
+    double *ma1r = p.ma1re + (size_t)grp * g.ma1_len * 64 + lane;
+    double *ma1i = p.ma1im + (size_t)grp * g.ma1_len * 64 + lane;
+    double *mav1 = p.mav1 + (size_t)grp * g.mav1_len * 64 + lane;
+    double *fa = p.fa + (size_t)grp * g.fa_len * 64 + lane;
+    double *bt = p.bt + (size_t)grp * g.bt_len * 64 + lane;
+
+    int s_agc = (int)(n0 % g.agc_len), s_cv = (int)(n0 % g.cv_len), s_ma1 = (int)(n0 % g.ma1_len), s_mav1 = (int)(n0 % g.mav1_len);
+    int s_fa = (int)(n0 % g.fa_len), s_bt = (int)(n0 % g.bt_len);
+    const double agc_len_d = (double)g.agc_len, ma1_len_d = (double)g.ma1_len, mav1_len_d = (double)g.mav1_len;
+    const double btw = g.bt_w, btwc = 1.0 - g.bt_w, faw = g.fa_w, fawc = 1.0 - g.fa_w;
+    const int twoPL = 2 * g.PL;
+
+    for (int i0 = 0; i0 < n; i0 += FB)
+    {
+        double x_re[FB], x_im[FB], o_agc[FB], o_m1r[FB], o_m1i[FB], o_mav[FB], fa_old[FB], fa_new[FB], bt_2[FB], bt_1[FB];
+        double co_r[FB], co_i[FB], cn_r[FB], cn_i[FB];
+#pragma unroll
+        for (int k = 0; k < FB; k++)
+        {
+            const int ii = (i0 + k < n) ? i0 + k : n - 1;
+            const int d = ii - i0; // == k except past the end (results unused there)
+            x_re[k] = hre[(size_t)ii * 64]; x_im[k] = him[(size_t)ii * 64];
+            o_agc[k] = agc_ring[(size_t)bwrap(s_agc + d, g.agc_len) * 64];
+            o_m1r[k] = ma1r[(size_t)bwrap(s_ma1 + d, g.ma1_len) * 64];
+            o_m1i[k] = ma1i[(size_t)bwrap(s_ma1 + d, g.ma1_len) * 64];
+            o_mav[k] = mav1[(size_t)bwrap(s_mav1 + d, g.mav1_len) * 64];
+            const int cs = bwrap(s_cv + d, g.cv_len);
+            const int c_old = bback(cs, g.bt_lag, g.cv_len), c_new = bwrap(c_old + 1, g.cv_len);
+            co_r[k] = cvre[(size_t)c_old * 64]; co_i[k] = cvim[(size_t)c_old * 64];
+            cn_r[k] = cvre[(size_t)c_new * 64]; cn_i[k] = cvim[(size_t)c_new * 64];
+            const int fs = bwrap(s_fa + d, g.fa_len);
+            const int f_old = bback(fs, g.fa_lag, g.fa_len), f_new = bwrap(f_old + 1, g.fa_len);
+            fa_old[k] = fa[(size_t)f_old * 64]; fa_new[k] = fa[(size_t)f_new * 64];
+            const int bs = bwrap(s_bt + d, g.bt_len);
+            bt_2[k] = bt[(size_t)bback(bs, twoPL, g.bt_len) * 64];
+            bt_1[k] = bt[(size_t)bback(bs, g.PL, g.bt_len) * 64];
+        }
+#pragma unroll
+        for (int k = 0; k < FB; k++)
+        {
+            const int i = i0 + k;
+            if (i >= n) break;
+            // agc->Update(std::abs(cval)); cval*=agc->AGCVal  (DSP.cpp:370-379)
+            const double a = hypot(x_re[k], x_im[k]);
+            agc_sum = agc_sum - o_agc[k];
+            agc_sum = agc_sum + fabs(a);
+            agc_ring[(size_t)s_agc * 64] = fabs(a);
+            double gain = 1.414213562 / fmax(agc_sum / agc_len_d, 0.000001);
+            gain = fmax(gain, 0.000001);
+            const double c_re = x_re[k] * gain, c_im = x_im[k] * gain;
+            cvre[(size_t)s_cv * 64] = c_re; cvim[(size_t)s_cv * 64] = c_im;
+            // bt_d1.update(cval) (Delay<cpx>, DSP.h:341-379): weighting*newer + (1-weighting)*older; with an integer delay
+            // (burst MSK) the "newer" entry is the one just written
+            double nr = cn_r[k], ni = cn_i[k];
+            if (g.bt_lag == 1) { nr = c_re; ni = c_im; }
+            const double dl_re = btw * nr + btwc * co_r[k], dl_im = btw * ni + btwc * co_i[k];
+            // cval*std::conj(dl)
+            const double pr = c_re * dl_re - c_im * (-dl_im), pi = c_re * (-dl_im) + c_im * dl_re;
+            // bt_ma1.UpdateSigned (TMovingAverage<complex>, DSP.h:184-192)
+            ma1_re = ma1_re - o_m1r[k]; ma1_im = ma1_im - o_m1i[k];
+            ma1_re = ma1_re + pr; ma1_im = ma1_im + pi;
+            ma1r[(size_t)s_ma1 * 64] = pr; ma1i[(size_t)s_ma1 * 64] = pi;
+            double fastarm = hypot(ma1_re / ma1_len_d, ma1_im / ma1_len_d);
+            // mav1->UpdateSigned
+            mav1_sum = mav1_sum - o_mav[k];
+            mav1_sum = mav1_sum + fastarm;
+            mav1[(size_t)s_mav1 * 64] = fastarm;
+            fastarm = mav1_sum / mav1_len_d;
+            // fastarm -= bt_ma_diff.update(fastarm)
+            fa[(size_t)s_fa * 64] = fastarm;
+            fastarm -= (faw * fa_new[k] + fawc * fa_old[k]);
+            if (fastarm < 0) fastarm = 0;
+            double bt_sig = fastarm * fastarm;
+            if (bt_sig > 500) bt_sig = 500;
+            // PeakDetector::update (DSP.h:528-560)
+            bt[(size_t)s_bt * 64] = bt_sig;
+            const double dy = bt_sig - bt_2[k];
+            const double vald = bt_1[k];
+            if ((!cntdown) && (vald > g.pd_thr) && (lastdy >= 0 && dy < 0))
+            {
+                cntdown = twoPL;
+                // d3.findmaxpos: first strict maximum scanning oldest -> newest over 2*PL+1 entries
+                int pos = bback(s_bt, twoPL, g.bt_len);
+                double mv = bt[(size_t)pos * 64];
+                int mp = 0;
+                for (int q = 0; q <= twoPL; q++)
+                {
+                    const double v = bt[(size_t)pos * 64];
+                    if (v > mv) { mv = v; mp = q; }
+                    pos = bwrap(pos + 1, g.bt_len);
+                }
+                maxposcd = mp;
+            }
+            if (cntdown > 0) cntdown--;
+            lastdy = dy;
+            bool fire = false;
+            if (!maxposcd) { maxposcd--; fire = true; }
+            else if (maxposcd > 0) maxposcd--;
+            if (fire)
+            {
+                tri_ptr = 0;
+                if (trace && ev_cnt < g.ev_cap)
+                {
+                    double *e = p.evlog + ((size_t)ch * g.ev_cap + ev_cnt) * 3;
+                    e[0] = (double)(n0 + i); e[1] = BEV_PEAK; e[2] = 0; ev_cnt++;
+                }
+            }
+            if (tri_ptr < g.tri_sz) tri_ptr++;
+            else if (tri_ptr == g.tri_sz) { tri_ptr++; ev_pos = i; }
+            s_agc = bwrap(s_agc + 1, g.agc_len); s_cv = bwrap(s_cv + 1, g.cv_len); s_ma1 = bwrap(s_ma1 + 1, g.ma1_len);
+            s_mav1 = bwrap(s_mav1 + 1, g.mav1_len); s_fa = bwrap(s_fa + 1, g.fa_len); s_bt = bwrap(s_bt + 1, g.bt_len);
+        }
+    }
+    BLDF(BS_AGC_SUM) = agc_sum; BLDF(BS_MA1_RE) = ma1_re; BLDF(BS_MA1_IM) = ma1_im; BLDF(BS_MAV1_SUM) = mav1_sum; BLDF(BS_LASTDY) = lastdy;
+    BLDI(BI_CNTDOWN) = cntdown; BLDI(BI_MAXPOSCD) = maxposcd; BLDI(BI_TRI_PTR) = tri_ptr; BLDI(BI_EV_POS) = ev_pos; BLDI(BI_EV_CNT) = ev_cnt;
+    (void)flags;
+    if (ev_pos >= 0 && ch < g.nch)
+    {
+        const int k = atomicAdd(p.ev_count, 1);
+        p.ev_list[k] = ch;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ trident check
+// The two fftr->transform calls (burstoqpskdemodulator.cpp:416-426, burstmskdemodulator.cpp:458-473) are 2^15-point FFTs of
+// <= 2^14 real samples followed by zeros.  X[2q + r] = sum_n (x[n] W_32768^(n r)) W_16384^(n q): two 2^14-point transforms per
+// window, run register-resident with wg_fft<14> (k_coarse2.h).  Only bins below N/2 are ever read by the reference.
+#define TRI_N 32768
+#define TRI_H 16384
+struct TriScratch { double2 base[TRI_H]; double d[TRI_H]; };
+
+__device__ __forceinline__ void tri_argmax_first(double v, int idx, double *red_val, int *red_idx, int t)
+{
+    red_val[t] = v; red_idx[t] = idx;
+    __syncthreads();
+    for (int s = C2_THREADS / 2; s > 0; s >>= 1)
+    {
+        if (t < s)
+        {
+            const double ov = red_val[t + s]; const int oi = red_idx[t + s];
+            const double mv = red_val[t]; const int mi = red_idx[t];
+            if (oi >= 0 && (mi < 0 || ov > mv || (ov == mv && oi < mi))) { red_val[t] = ov; red_idx[t] = oi; }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(C2_THREADS) void k_trident(const BGeom g, const BPtrs p, TriScratch *scratch, long long n0)
+{
+    extern __shared__ __attribute__((aligned(16))) double xch[];
+    __shared__ double red_val[C2_THREADS];
+    __shared__ int red_idx[C2_THREADS];
+    const int t = threadIdx.x, nchp = g.nchp;
+    const int nev = *p.ev_count;
+    TriScratch *sc = scratch + blockIdx.x;
+    const bool oq = g.kind == JAERO_KIND_BURST_OQPSK_D;
+    for (int li = blockIdx.x; li < nev; li += gridDim.x)
+    {
+        const int ch = p.ev_list[li];
+        const int grp = ch >> 6, lane = ch & 63;
+        const int evp = p.I[(size_t)BI_EV_POS * nchp + ch];
+        // window: cval_d[e - tri_sz + k] = cv[e - tri_sz - D1 + k], e = n0 + evp
+        const long long w0 = n0 + evp - g.tri_sz - g.D1 + 8LL * g.cv_len;
+        const double *__restrict__ cvre = p.cvre + (size_t)grp * g.cv_len * 64 + lane;
+        for (int pass = 0; pass < 4; pass++)
+        {
+            const int which = pass >> 1, r = pass & 1; // which: 0 base, 1 top
+            const int off = which ? g.nb : 0, len = which ? g.nt : g.nb;
+            CV<32> d;
+#pragma unroll
+            for (int s = 0; s < 32; s++)
+            {
+                const int n = s * C2_THREADS + t;
+                double x = 0.0;
+                if (n < len && off + n < g.tri_sz) x = cvre[(size_t)((w0 + off + n) % g.cv_len) * 64];
+                if (r == 0) { d.r[s] = x; d.i[s] = 0.0; }
+                else
+                {
+                    double sn, cs;
+                    sincospi(((double)n) / ((double)TRI_H), &sn, &cs); // W_32768^n = exp(-j pi n / 16384)
+                    d.r[s] = x * cs; d.i[s] = -x * sn;
+                }
+            }
+            wg_fft<14>(d, xch, p.tw14, t);
+            // thread t slot s holds X_r[q = s*512 + t] = X[2q + r]; bins below TRI_H <=> s < 16
+#pragma unroll
+            for (int s = 0; s < 16; s++)
+            {
+                const int k = 2 * (s * C2_THREADS + t) + r;
+                if (which == 0) sc->base[k] = make_double2(d.r[s], d.i[s]);
+                else
+                {
+                    const double2 b = sc->base[k];
+                    const double at = hypot(d.r[s], d.i[s]);
+                    sc->d[k] = oq ? (at - hypot(b.x, b.y)) : at;
+                }
+            }
+            __syncthreads();
+        }
+        __threadfence_block();
+        __syncthreads();
+        const double hzperbin = g.Fs / ((double)TRI_N);
+        // strongest base bin: first maximum over [0, N/2)
+        double bv = -1.0; int bi = -1;
+        for (int k = t; k < TRI_H; k += C2_THREADS)
+        {
+            const double2 b = sc->base[k];
+            const double a = hypot(b.x, b.y);
+            if (a > bv) { bv = a; bi = k; }
+        }
+        tri_argmax_first(bv, bi, red_val, red_idx, t);
+        const double minval = red_val[0];
+        const int minvalbin = (minval > 0.0) ? red_idx[0] : 0; // MSK starts from minval = 0 with a strict compare
+        __syncthreads();
+        TriResult res;
+        res.pad = 0;
+        if (oq)
+        {
+            const int b = jd_qround((0.25 * g.fb) / hzperbin);
+            const int firstbin = b, lstbin = TRI_H - b;
+            double mv = 0.0; int mi = -1;
+            for (int k = firstbin + t; k < lstbin; k += C2_THREADS)
+            {
+                const double tv = sc->d[k - b] + sc->d[k + b] - sc->d[k];
+                if (mi < 0 || tv > mv) { mv = tv; mi = k; }
+            }
+            tri_argmax_first(mv, mi, red_val, red_idx, t);
+            const double maxval = red_val[0];
+            const int maxvalbin = red_idx[0];
+            __syncthreads();
+            res.ok = (maxval > 500.0) && (fabs((((double)(maxvalbin - minvalbin))) * hzperbin) < 20.0);
+            const double2 bb = sc->base[minvalbin];
+            const double carrierphase = atan2(bb.y, bb.x) - (M_PI / 4.0);
+            res.freq = hzperbin * (double)minvalbin;
+            res.phase_deg = (180.0 / M_PI) * carrierphase;
+            res.vol_gain = 1.4142 * 500.0 / minval;
+            res.metric = maxval;
+        }
+        else
+        {
+            const int psb = jd_qround((0.5 * g.fb) / hzperbin);
+            double lv = 0.0; int lidx = -1;
+            double hv = 0.0; int hidx = -1;
+            for (int k = t; k < TRI_H; k += C2_THREADS)
+            {
+                if (k > 50)
+                {
+                    const double a = sc->d[k];
+                    if ((k < minvalbin - (psb / 2)) && a > lv) { lv = a; lidx = k; }
+                    if ((k > minvalbin + (psb / 2)) && a > hv) { hv = a; hidx = k; }
+                }
+            }
+            tri_argmax_first(lv, lidx, red_val, red_idx, t);
+            const int maxtoppos = (red_idx[0] >= 0) ? red_idx[0] : 0;
+            __syncthreads();
+            tri_argmax_first(hv, hidx, red_val, red_idx, t);
+            const int maxtopposhigh = (red_idx[0] >= 0) ? red_idx[0] : 0;
+            __syncthreads();
+            const int distfrompeak = abs(maxtoppos - minvalbin);
+            res.ok = (minval > 500.0) && (abs(distfrompeak - psb) < abs(psb / 20));
+            const double2 bb = sc->base[minvalbin];
+            const double carrierphase = atan2(bb.y, bb.x) - (M_PI / 4.0);
+            res.freq = ((double)((maxtopposhigh + maxtoppos) / 2)) * hzperbin;
+            res.phase_deg = (180.0 / M_PI) * carrierphase;
+            res.vol_gain = 1.4142 * (500.0 / (minval / 3));
+            res.metric = minval;
+        }
+        if (t == 0) p.tri[ch] = res;
+        __syncthreads();
+    }
+}

@@ -49,12 +49,44 @@ class MskSettings:
                              self.Fs, self.signalthreshold)
 
 
+@dataclass
+class BurstOqpskSettings:
+    """BurstOqpskDemodulator::Settings defaults (JAERO/burstoqpskdemodulator.h:24-46)."""
+
+    coarsefreqest_fft_power: int = 13
+    freq_center: float = 8000.0
+    lockingbw: float = 10500.0
+    fb: float = 10500.0
+    Fs: float = 48000.0
+    signalthreshold: float = 0.6
+
+    def to_c(self) -> capi.Settings:
+        return capi.Settings(capi.KIND_BURST_OQPSK, self.coarsefreqest_fft_power, self.freq_center, self.lockingbw, self.fb,
+                             self.Fs, self.signalthreshold)
+
+
+@dataclass
+class BurstMskSettings:
+    """BurstMskDemodulator::Settings as the main window sets them for 600 / 1200 bps (JAERO/burstmskdemodulator.h:27-50)."""
+
+    coarsefreqest_fft_power: int = 13
+    freq_center: float = 1000.0
+    lockingbw: float = 1800.0
+    fb: float = 1200.0
+    Fs: float = 48000.0
+    signalthreshold: float = 0.6
+
+    def to_c(self) -> capi.Settings:
+        return capi.Settings(capi.KIND_BURST_MSK, self.coarsefreqest_fft_power, self.freq_center, self.lockingbw, self.fb,
+                             self.Fs, self.signalthreshold)
+
+
 class DemodulatorBank:
     """A bank of `nchannels` demodulators on one GPU (thin wrapper over jaero_ctx)."""
 
     def __init__(self, settings, nchannels: Optional[int] = None, device: int = 0, *, ebno: bool = True,
-                 status_log: bool = False, capture_symbols: bool = False, max_write_samples: int = 65536,
-                 softbit_capacity: int = 0):
+                 status_log: bool = False, capture_symbols: bool = False, trace: bool = False,
+                 max_write_samples: int = 65536, softbit_capacity: int = 0):
         self.L = capi.lib()
         if isinstance(settings, (list, tuple)):
             arr = (capi.Settings * len(settings))(*[s.to_c() for s in settings])
@@ -65,7 +97,7 @@ class DemodulatorBank:
             nch = 1 if nchannels is None else nchannels
             stride = 0
         flags = (capi.FLAG_EBNO if ebno else 0) | (capi.FLAG_STATUS_LOG if status_log else 0) | (
-            capi.FLAG_CAPTURE_SYMBOLS if capture_symbols else 0)
+            capi.FLAG_CAPTURE_SYMBOLS if capture_symbols else 0) | (capi.FLAG_TRACE if trace else 0)
         h = C.c_void_p()
         capi.check(self.L.jaero_create(device, nch, C.cast(arr, C.c_void_p), stride, flags, max_write_samples,
                                        softbit_capacity, C.byref(h)))
@@ -157,6 +189,13 @@ class DemodulatorBank:
         buf = np.empty((caprows, 3), dtype=np.float64)
         n = C.c_int(0)
         capi.check(self.L.jaero_read_symbols(self.h, channel, buf.ctypes.data, caprows, C.byref(n)))
+        return buf[: n.value].copy()
+
+    def read_events(self, channel: int, caprows: int = 8192) -> np.ndarray:
+        """Burst banks: rows [absolute sample index, capi.EV_* kind, value] (SignalStatus / EbNo / Plottables emissions)."""
+        buf = np.empty((caprows, 3), dtype=np.float64)
+        n = C.c_int(0)
+        capi.check(self.L.jaero_read_events(self.h, channel, buf.ctypes.data, caprows, C.byref(n)))
         return buf[: n.value].copy()
 
     # ---- profiling ----
@@ -284,4 +323,61 @@ class MskDemodulator(_SingleChannelDemodulator):
     """Drop-in shaped like JAERO's MskDemodulator (JAERO/mskdemodulator.h:19-168); emits 12 soft bits at a time."""
 
     Settings = MskSettings
+    _group = 12
+
+
+class _SingleChannelBurstDemodulator(_SingleChannelDemodulator):
+    """Burst classes: the soft-bit stream carries -1 start-of-burst markers and is re-emitted in the reference's groups
+    (first group of a burst = marker + 32 / 12 soft bits); SignalStatus / EbNoMeasurmentSignal / Plottables come from the
+    event log."""
+
+    def setSettings(self, settings):
+        self._settings = settings
+        if self._bank is not None:
+            self._bank.close()
+        self._bank = DemodulatorBank(settings, 1, self._device, **self._bank_kw)
+        self._bank.set_flags(self._afc, self._sql, self._cpu)
+        self._bank.set_dcd(self._dcd)
+
+    def getCurrentFreq(self) -> float:
+        return self._bank.read_status(0).freq_est
+
+    def _emit(self):
+        soft = self._bank.read_softbits(0)  # emitted groups only; the pending tail stays on the device
+        # the emitted stream is a concatenation of RxDataBits emissions: a group ends when, after a pair of soft bits
+        # was pushed, it holds >= 32 (12) entries; the -1 marker is pushed without that test
+        g, i, n = self._group, 0, int(soft.size)
+        while i < n:
+            j, size = i, 0
+            while j < n:
+                if soft[j] == -1:
+                    j, size = j + 1, size + 1
+                    continue
+                j, size = j + 2, size + 2
+                if size >= g:
+                    break
+            if self.processDemodulatedSoftBits:
+                self.processDemodulatedSoftBits([int(v) for v in soft[i:j]])
+            i = j
+        for row in self._bank.read_events(0):
+            kind = int(row[1])
+            if kind == capi.EV_SIGNAL and self.SignalStatus:
+                self.SignalStatus(bool(row[2]))
+            elif kind == capi.EV_EBNO and self.EbNoMeasurmentSignal:
+                self.EbNoMeasurmentSignal(row[2])
+            elif kind == capi.EV_FREQ and self.Plottables:
+                self.Plottables(row[2], row[2], self._settings.lockingbw)
+
+
+class BurstOqpskDemodulator(_SingleChannelBurstDemodulator):
+    """Drop-in shaped like JAERO's BurstOqpskDemodulator (JAERO/burstoqpskdemodulator.h:19-228)."""
+
+    Settings = BurstOqpskSettings
+    _group = 32
+
+
+class BurstMskDemodulator(_SingleChannelBurstDemodulator):
+    """Drop-in shaped like JAERO's BurstMskDemodulator (JAERO/burstmskdemodulator.h:22-219)."""
+
+    Settings = BurstMskSettings
     _group = 12

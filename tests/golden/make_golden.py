@@ -86,5 +86,39 @@ def main():
     print("fft golden ok")
 
 
+def burst():
+    """Burst demodulators: what the UNMODIFIED BurstOqpskDemodulator / BurstMskDemodulator emit.
+    events rows = [sample index of the write that carried the emission, kind (0 SignalStatus, 1 EbNo, 2 Plottables), value]."""
+    assert O.have_ref()
+    n = 150000
+    pcm, bursts = G.burst_oqpsk(n, burst_starts=[40000, 100000], ndata_sym=1000, fc=8037.5, ebno_db=15.0, seed=G.SEED_BASE + 40)
+    for name, opts in (("burst_oqpsk_10k5_default", dict(chunk=4096)), ("burst_oqpsk_10k5_chunk1500", dict(chunk=1500))):
+        r = O.run_ref("burstoqpsk", pcm, **opts)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), pcm=pcm, kind="burstoqpsk", opts=np.array(repr(opts)), soft=r["soft"],
+                            events=r["events"], tx_bits=np.concatenate([b for _, b in bursts]), tx_starts=np.array([s for s, _ in bursts]))
+        print(name, "soft", r["soft"].shape, "events", r["events"].shape)
+    # an excerpt (two bursts) of the reference's bundled 1200 bps R/T-channel recording: the real signal the burst MSK
+    # demodulator was written for; north_star: "bit-exact ... for the bundled sample files"
+    import wave
+    w = wave.open("/root/reference/samples/1200bps_burst_sample1.wav")
+    x = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)[140000:340000].copy()
+    opts = dict(fb=1200, freq_center=1000, chunk=4096)
+    r = O.run_ref("burstmsk", x, **opts)
+    np.savez_compressed(os.path.join(HERE, "burst_msk_1200_sample1_excerpt.npz"), pcm=x, kind="burstmsk", opts=np.array(repr(opts)),
+                        soft=r["soft"], events=r["events"], source=np.array("samples/1200bps_burst_sample1.wav[140000:340000]"))
+    print("burst_msk_1200_sample1_excerpt", x.shape, r["soft"].shape, r["events"].shape)
+    # whole files: outputs only (the inputs stay in /root/reference/samples)
+    for f in ("1200bps_burst_sample1.wav", "1200bps_burst_sample2.wav"):
+        w = wave.open("/root/reference/samples/" + f)
+        x = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+        r = O.run_ref("burstmsk", x, fb=1200, freq_center=1000, chunk=4096)
+        np.savez_compressed(os.path.join(HERE, f.replace(".wav", "") + "_burstmsk.npz"), nsamples=len(x), soft=r["soft"], events=r["events"])
+        print(f, len(x), r["soft"].shape, r["events"].shape)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "burst":
+        burst()
+    else:
+        main()
+        burst()

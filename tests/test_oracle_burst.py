@@ -1,0 +1,130 @@
+"""CPU: the burst-demodulator restatement (oracle/jaero_oracle_burst.c) pinned against what the UNMODIFIED reference emitted
+(tests/golden/burst_*.npz, made by oracle/_ref) and, where oracle/_ref can run, against the reference itself on fresh cases.
+Bit-exact: soft bits (incl. the -1 start-of-burst markers) and every SignalStatus / EbNo / Plottables emission."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from jaero_amd import signalgen as G
+
+
+def burst_settings(O, kind, opts):
+    if kind == "burstoqpsk":
+        return O.burst_oqpsk_settings(freq_center=opts.get("freq_center", 8000.0))
+    fb = float(opts.get("fb", 1200))
+    return O.burst_msk_settings(freq_center=opts.get("freq_center", 1000.0), fb=fb, lockingbw=opts.get("lockingbw", 1800.0))
+
+
+def as_write_stamps(events, chunk):
+    """The reference driver stamps an emission with the first sample of the write that carried it."""
+    ev = events[events[:, 1] < 3].copy()
+    ev[:, 0] = np.floor(ev[:, 0] / chunk) * chunk
+    return ev
+
+
+@pytest.mark.parametrize("name", ["burst_oqpsk_10k5_default", "burst_oqpsk_10k5_chunk1500", "burst_msk_1200_sample1_excerpt"])
+def test_oracle_matches_reference_golden(oracle_mod, name):
+    g = load_golden(name)
+    chunk = g["opts"].get("chunk", 4096)
+    o = oracle_mod.run_burst(burst_settings(oracle_mod, g["kind"], g["opts"]), g["pcm"], chunk=chunk)
+    assert np.array_equal(o["soft"], g["soft"])
+    assert (g["soft"] == -1).sum() >= 2  # the fixtures hold at least two accepted bursts
+    assert np.array_equal(as_write_stamps(o["events"], chunk), g["events"])
+
+
+def test_generator_bits_come_back(oracle_mod):
+    """The burst OQPSK fixture decodes: hard decisions of the two output streams equal the transmitted arm bits (up to the
+    per-burst 4-fold ambiguity) -- guards the generator and the marker position, not just self-consistency."""
+    g = load_golden("burst_oqpsk_10k5_default")
+    soft = g["soft"]
+    marks = np.nonzero(soft == -1)[0]
+    tx = g["tx_bits"].reshape(len(g["tx_starts"]), -1)
+    ok = 0
+    for b, m in enumerate(marks[-len(tx):]):
+        end = marks[marks > m][0] if (marks > m).any() else len(soft)
+        seg = soft[m + 1:end]
+        hard = (seg >= 128).astype(np.uint8)
+        s0, s1 = hard[0::2], hard[1::2]
+        best = 1.0
+        for arm in (tx[b][0::2], tx[b][1::2]):
+            for stream in (s0, s1):
+                for lag in range(0, 40):
+                    n = min(len(arm), len(stream) - lag, 600)
+                    if n < 300:
+                        continue
+                    e = np.mean(arm[:n] != stream[lag:lag + n])
+                    best = min(best, e, 1 - e)
+        ok += best < 0.02
+    assert ok >= 1
+
+
+def test_chunk_invariance(oracle_mod):
+    g = load_golden("burst_oqpsk_10k5_default")
+    a = oracle_mod.run_burst(oracle_mod.burst_oqpsk_settings(), g["pcm"], chunk=4096)
+    b = oracle_mod.run_burst(oracle_mod.burst_oqpsk_settings(), g["pcm"], chunk=777)
+    assert np.array_equal(a["soft"], b["soft"]) and np.array_equal(a["events"], b["events"])
+
+
+def test_hilbert_is_a_delayed_fir(oracle_mod):
+    """QJHilbertFilter through JFastFir == causal convolution with the 2048-tap kernel delayed by nfft-K+1 samples
+    (the property JAERO/tests/jfastfir_tests.cpp pins for JFastFir), independent of the write sizes."""
+    rng = np.random.default_rng(5)
+    x = rng.integers(-20000, 20000, size=30000).astype(np.int16)
+    y, lat = oracle_mod.hilbert_stream(x, chunk=1000)
+    y2, _ = oracle_mod.hilbert_stream(x, chunk=4096)
+    assert np.allclose(y, y2, atol=1e-12)
+    k = oracle_mod.hilbert_kernel(2048)
+    full = np.convolve(x.astype(np.float64) / 32768.0, k)[: len(x)]
+    ref = np.concatenate([np.zeros(lat, complex), full])[: len(x)]
+    assert lat == 8192 - 2048 + 1
+    assert np.max(np.abs(y - ref)) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------- against _ref itself
+@pytest.fixture(scope="module")
+def R(oracle_mod):
+    if not oracle_mod.have_ref():
+        pytest.skip("oracle/_ref/jaero_ref not available here")
+    try:
+        oracle_mod.run_ref("burstmsk", np.zeros(16, np.int16))
+    except Exception as e:
+        pytest.skip(f"_ref cannot run here: {e}")
+    return oracle_mod
+
+
+@pytest.mark.parametrize("fb,seed,chunk", [(1200, 31, 4096), (600, 32, 3000)])
+def test_burst_msk_synthetic_vs_ref(R, fb, seed, chunk):
+    n = int(48000 * 4 * (1200 / fb))
+    pcm, _ = G.burst_msk(n, burst_starts=[n // 5], fb=float(fb), fc=1900.0 + seed, ebno_db=18.0, seed=seed)
+    r = R.run_ref("burstmsk", pcm, fb=fb, lockingbw=1.5 * fb, chunk=chunk)
+    o = R.run_burst(R.burst_msk_settings(fb=float(fb), lockingbw=1.5 * fb), pcm, chunk=chunk)
+    assert (r["soft"] == -1).sum() >= 1
+    assert np.array_equal(r["soft"], o["soft"])
+    assert np.array_equal(r["events"], as_write_stamps(o["events"], chunk))
+
+
+def test_burst_oqpsk_random_vs_ref(R):
+    pcm, _ = G.burst_oqpsk(100000, burst_starts=[30000], ndata_sym=800, fc=7990.0, ebno_db=12.0, seed=77)
+    r = R.run_ref("burstoqpsk", pcm, chunk=2000)
+    o = R.run_burst(R.burst_oqpsk_settings(), pcm, chunk=2000)
+    assert np.array_equal(r["soft"], o["soft"])
+    assert np.array_equal(r["events"], as_write_stamps(o["events"], 2000))
+
+
+@pytest.mark.parametrize("f", ["1200bps_burst_sample1", "1200bps_burst_sample2"])
+def test_bundled_recordings(oracle_mod, f):
+    """The reference's bundled 1200 bps burst recordings through the burst MSK demodulator (inputs stay in /root/reference)."""
+    path = f"/root/reference/samples/{f}.wav"
+    if not os.path.exists(path):
+        pytest.skip("reference samples not present on this machine")
+    import wave
+
+    w = wave.open(path)
+    x = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+    g = load_golden(f + "_burstmsk")
+    assert int(g["nsamples"]) == len(x)
+    o = oracle_mod.run_burst(oracle_mod.burst_msk_settings(), x, chunk=4096)
+    assert np.array_equal(o["soft"], g["soft"])
+    assert np.array_equal(as_write_stamps(o["events"], 4096), g["events"])
