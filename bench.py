@@ -31,6 +31,10 @@ ALG_BYTES_SAMPLE_KERNEL = 2.0 + 16.0 + 16.0 + 0.44 + 0.5      # PCM + AGC ring r
 ALG_BYTES_SAMPLE_KERNEL_EBNO = 32.0                           # optional EbNo rings (2 x read+write)
 ALG_BYTES_COARSE_KERNEL = 128.0                               # (ring read 256 KiB + y r/w 256 KiB) / 4096 samples
 ALG_BYTES_WHOLE_PATH = 163.0                                  # SURVEY.md 8(d) headline
+# burst OQPSK (column "Burst OQPSK"): 187 B/sample = PCM 2 + AGC ring 16 + burst rings 168 + soft/state 0.94
+ALG_BURST = {"hilbert": 2.0, "front": 16.0 + 168.0, "demod": 0.44 + 0.5, "trident": 0.0}
+ALG_BURST_EBNO = 32.0                                         # optional EbNo rings, charged to the tracking kernel
+ALG_BYTES_WHOLE_PATH_BURST = 187.0
 HBM_PEAK_GBS = 8000.0                                         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 
 
@@ -39,10 +43,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=12)
-    ap.add_argument("--channels", type=int, default=int(os.environ.get("JAERO_BENCH_CHANNELS", "16384")), help="channels per GPU")
+    ap.add_argument("--channels", type=int, default=int(os.environ.get("JAERO_BENCH_CHANNELS", "65536")), help="channels per GPU")
     ap.add_argument("--chunk", type=int, default=4096)
     ap.add_argument("--ebno", type=int, default=1, help="run the EbNo meters (the reference always does)")
     ap.add_argument("--ebno-db", type=float, default=10.0)
+    ap.add_argument("--workload", default="oqpsk", choices=["oqpsk", "burst_oqpsk"],
+                    help="oqpsk = BASELINE configs[2] (continuous, the headline); burst_oqpsk = configs[3] (one burst per second per channel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=1_000_000, help="samples per core for the CPU baseline leg")
     return ap.parse_args()
@@ -56,7 +62,12 @@ def cpu_baseline(chunk: int):
 
     ncores = os.cpu_count() or 1
     n = ARGS.cpu_samples
-    pcm, _ = G.oqpsk(n, fc=8037.5, ebno_db=ARGS.ebno_db, seed=G.SEED_BASE + 77)
+    burst = ARGS.workload == "burst_oqpsk"
+    refkind = "burstoqpsk" if burst else "oqpsk"
+    if burst:
+        pcm, _ = G.burst_oqpsk(n, burst_starts=list(range(20000, n - 40000, 48000)), ndata_sym=3040, fc=8037.5, ebno_db=15.0, seed=G.SEED_BASE + 77)
+    else:
+        pcm, _ = G.oqpsk(n, fc=8037.5, ebno_db=ARGS.ebno_db, seed=G.SEED_BASE + 77)
     kind = "port"
     use_ref = O.have_ref()
     if use_ref:
@@ -70,13 +81,14 @@ def cpu_baseline(chunk: int):
         t0 = time.time()
         if use_ref:
             kind = "reference"
-            procs = [subprocess.Popen([O.REF_BIN, "time", "oqpsk", path, f"chunk={chunk}"], stdout=subprocess.PIPE) for _ in range(ncores)]
+            procs = [subprocess.Popen([O.REF_BIN, "time", refkind, path, f"chunk={chunk}"], stdout=subprocess.PIPE) for _ in range(ncores)]
             outs = [p.communicate()[0] for p in procs]
             inner = [float(o.split()[0]) for o in outs]
         else:
+            mk = "O.BurstDemod(O.burst_oqpsk_settings())" if burst else "O.Demod(O.oqpsk_settings())"
             code = ("import sys,time,numpy as np; sys.path.insert(0,%r); from oracle import oracle as O; "
-                    "x=np.fromfile(%r,dtype=np.int16); d=O.Demod(O.oqpsk_settings()); t=time.time(); "
-                    "[d.write(x[s:s+%d]) for s in range(0,len(x),%d)]; print(time.time()-t)") % (ROOT, path, chunk, chunk)
+                    "x=np.fromfile(%r,dtype=np.int16); d=%s; t=time.time(); "
+                    "[d.write(x[s:s+%d]) for s in range(0,len(x),%d)]; print(time.time()-t)") % (ROOT, path, mk, chunk, chunk)
             procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE) for _ in range(ncores)]
             outs = [p.communicate()[0] for p in procs]
             inner = [float(o.split()[0]) for o in outs]
@@ -84,7 +96,7 @@ def cpu_baseline(chunk: int):
     # aggregate over cores: every core did n samples in `inner[i]` seconds of writeData time, concurrently
     value = sum(n / t for t in inner) / 1e6
     return {"value": round(value, 3), "unit": "Msamples/s", "cores": ncores, "kind": kind,
-            "sample": f"{n} samples of 48 kHz 10.5k OQPSK per core, {chunk}-sample writes, cpuReduce=false, "
+            "sample": f"{n} samples of 48 kHz 10.5k {'burst ' if burst else ''}OQPSK per core, {chunk}-sample writes, cpuReduce=false, "
                       f"one process per core ({wall:.1f} s wall)",
             "per_core_msps": round(value / ncores, 3),
             "note": "FFT inside the reference build is the JFFT stand-in (oracle/ref/shim/jfft.h), not JFFT"}
@@ -116,13 +128,59 @@ def ber_check(bank, bits, nch_check: int, tail: int = 3000):
     return worst, locked
 
 
+def burst_line(bank, rank, world, nch, chunk, K, W, dt, value):
+    """JSON line for the burst OQPSK workload (BASELINE configs[3]); kernel classes: tracking chain, trident check, history
+    push, Hilbert FIR, front end (jaero_profile_read which = 0..4)."""
+    from jaero_amd import capi
+
+    names = ["demod", "trident", "hist_push", "hilbert", "front"]
+    ms, nl = {}, {}
+    for w, nm in enumerate(names):
+        ms[nm], nl[nm] = bank.profile_read(w)
+    acc = 0
+    for c in range(min(8, nch)):
+        ev = bank.read_events(c)
+        acc += int(np.sum((ev[:, 1] == capi.EV_SIGNAL) & (ev[:, 2] > 0)))
+    if rank != 0:
+        return
+    dom = max(("demod", "front", "hilbert", "trident"), key=lambda k: ms[k])
+    per_sample = ALG_BURST[dom] + (ALG_BURST_EBNO if dom == "demod" else 0.0)
+    launches = max(nl[dom], 1)
+    avg_ms = ms[dom] / launches
+    units = K * chunk * nch / launches
+    achieved = per_sample * units / (avg_ms * 1e-3) / 1e9
+    line = {
+        "metric": "Msamples/s of real 48 kHz PCM through the 10.5 kbps burst OQPSK demodulator hot path",
+        "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{nch}-channel-per-GPU synthetic 48 kHz 10.5 kbps burst OQPSK (BASELINE configs[3] shape): one burst per "
+                               f"second per channel (128 symbols carrier + 128 symbols preamble + 3040 symbols data) at a random offset, noise "
+                               f"between bursts, Eb/N0 15 dB, {chunk}-sample writes",
+                   "channels_per_gpu": nch, "total_channels": nch * world, "chunk": chunk,
+                   "realtime_channel_equivalents": int(value / 0.048),
+                   "bursts_accepted_in_first_channels": acc, "channels_checked": min(8, nch),
+                   "whole_path_hbm_frac_at_187B_per_sample": round(value * 1e6 * ALG_BYTES_WHOLE_PATH_BURST / 1e9 / (HBM_PEAK_GBS * world), 5),
+                   "kernel_ms_total": {k: round(v, 3) for k, v in ms.items()}, "kernel_launches": nl},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "alg_bytes_per_sample": per_sample,
+                     "samples_per_launch": units, "avg_launch_ms": round(avg_ms, 4)},
+    }
+    if world == 1 and not ARGS.no_cpu_baseline:
+        try:
+            line["cpu_baseline"] = cpu_baseline(chunk)
+        except Exception as e:
+            line["cpu_baseline"] = {"value": None, "error": str(e)}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     import torch
     import torch.distributed as dist
 
     from jaero_amd import capi, signalgen
     from jaero_amd import dist as jd
-    from jaero_amd.demodulator import DemodulatorBank, OqpskSettings
+    from jaero_amd.demodulator import BurstOqpskSettings, DemodulatorBank, OqpskSettings
 
     capi.lib()  # fail loudly if the HIP extension is missing
     rank, world, local = jd.init_from_env()
@@ -134,9 +192,15 @@ def main():
 
     # synthetic input, resident in HBM before anything is timed: interleaved frames [nsamp, nch]
     lo, _ = jd.shard_range(nch * world, rank, world)
-    pcm, bits, _ = signalgen.oqpsk_torch(nch, nsamp, dev, ebno_db=ARGS.ebno_db, seed=signalgen.SEED_BASE + lo)
+    burst = ARGS.workload == "burst_oqpsk"
     soft_cap = int(nsamp * 10500 / 48000) + 64
-    bank = DemodulatorBank(OqpskSettings(), nch, device=local, ebno=bool(ARGS.ebno), max_write_samples=chunk, softbit_capacity=soft_cap)
+    if burst:
+        pcm, _, _ = signalgen.burst_oqpsk_torch(nch, nsamp, dev, ebno_db=15.0, seed=signalgen.SEED_BASE + lo)
+        bits = None
+        bank = DemodulatorBank(BurstOqpskSettings(), nch, device=local, max_write_samples=chunk, softbit_capacity=soft_cap)
+    else:
+        pcm, bits, _ = signalgen.oqpsk_torch(nch, nsamp, dev, ebno_db=ARGS.ebno_db, seed=signalgen.SEED_BASE + lo)
+        bank = DemodulatorBank(OqpskSettings(), nch, device=local, ebno=bool(ARGS.ebno), max_write_samples=chunk, softbit_capacity=soft_cap)
     bank.set_flags(afc=False, sql=False, cpu_reduce=False)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -166,6 +230,13 @@ def main():
     coarse_ms, coarse_n = bank.profile_read(1)
     total_samples = float(K) * chunk * nch * world
     value = total_samples / dt / 1e6
+    if burst:
+        burst_line(bank, rank, world, nch, chunk, K, W, dt, value)
+        bank.close()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     ber, locked = ber_check(bank, bits, min(8, nch))
     if world > 1:

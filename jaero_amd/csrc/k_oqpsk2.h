@@ -1,0 +1,414 @@
+// k_oqpsk2.h -- sample-loop kernel for the continuous 10.5 kbps OQPSK demodulator, symbol-synchronised stepping.
+//
+// Re-implements OqpskDemodulator::writeData's per-sample loop (JAERO/oqpskdemodulator.cpp:388-605, fb>8400 branch)
+// for 64 channels per wavefront, one channel per lane.  Per-sample stages (SURVEY.md 2.1 numbering):
+//   K1 PCM->double, K3 coarse ring fill, K2 NCO mix, K6 RRC matched filter (history in LDS + VGPR tail, taps via scalar loads),
+//   K7 EbNo meter (optional), K8 AGC + clip, K9 symbol-timing detector + PLL, K10 sample instant + interpolation,
+//   K11 carrier loop, K12 residual rotation, K13 MSE lock detector, K14 soft-bit demap.
+// The coarse-frequency estimate (K4/K5) runs in k_coarse.h between two launches of this kernel, at exactly the
+// sample where the reference calls it (host splits jaero_write at those samples: `only_a_last`/`skip_a_first`).
+//
+// Difference to k_oqpsk.h (same arithmetic, same results): the ~800-instruction symbol-instant block (K10..K14) used to run in
+// almost every iteration because among 64 channels some lane is at a symbol instant nearly every sample (11 % of the lanes each
+// time).  Here every lane keeps its OWN sample index: lanes step sample by sample until they have reached their next symbol
+// instant (9 or 10 samples), wait for the rest of the wavefront, then all run the symbol block together -- once per symbol
+// instead of once per sample.  Lanes stay within ~10 samples of each other (all channels have the same nominal symbol rate), so
+// the [slot][lane] ring rows they touch are neighbours, and they all finish the launch at the same sample.
+// A sample is processed in two halves: "first half" = everything up to the symbol-instant test, "second half" = filter push,
+// next filter output, NCO advance.  One stepping iteration = second half of the previous sample + first half of the next.
+#pragma once
+#include "jaero_device.h"
+#include "k_oqpsk.h"
+
+
+// Matched-filter history: the LDSN most recent mixed samples of each arm live in LDS ([slot][lane], wave-uniform slot),
+// the FIRN-LDSN oldest ones in a VGPR shift register.  LDSN = 40 makes the ring 40 KiB per wavefront, so four
+// wavefronts (one per SIMD) fit a CU's 160 KiB.  The filter output for sample n+1 depends only on inputs up to sample n
+// (FIR::FIRUpdateAndProcess excludes the newest sample, DSP.cpp:292-304), so it is evaluated one iteration ahead of the
+// serial AGC/timing/carrier chain and overlaps with it.
+template <int FIRN, int LDSN, bool EBNO, bool CAPSYM>
+__global__ __launch_bounds__(64) void k_oqpsk_samples2(const JGeom g, const JPtrs p, const int16_t *__restrict__ pcm,
+                                                      int pcm_stride, int n, int skip_a_first, int only_a_last, int fir_slot0)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *lre = lds;              // [LDSN][64]
+    double *lim = lds + LDSN * 64;  // [LDSN][64]
+    constexpr int TAILN = FIRN - LDSN;
+    double tre[TAILN], tim[TAILN];  // tre[j] = x_re[n-LDSN-j] once x[n] has been pushed
+
+    const int lane = threadIdx.x;
+    const int grp = blockIdx.x;
+    const int ch = grp * 64 + lane;
+    const int nchp = g.nchp;
+    const bool live = ch < g.nch;
+    const double2 *__restrict__ cis = p.cis;
+    const double *__restrict__ taps = p.taps2;
+
+    // ---- load state ----
+    double m2_ptr = LDF(S_M2_PTR), m2_step = LDF(S_M2_STEP), m2_freq = LDF(S_M2_FREQ);
+    double mc_ptr = LDF(S_MC_PTR), mc_step = LDF(S_MC_STEP);
+    double st_ptr = LDF(S_ST_PTR), st_step = LDF(S_ST_STEP), st_freq = LDF(S_ST_FREQ), st_last = LDF(S_ST_LAST);
+    double agc_sum = LDF(S_AGC_SUM);
+    double eb_esum = LDF(S_EB_ESUM), eb_e2sum = LDF(S_EB_E2SUM), eb_ebno = LDF(S_EB_EBNO);
+    double d1 = LDF(S_D1);
+    double d41_1 = LDF(S_D41_1), d41_2 = LDF(S_D41_2), d41_3 = LDF(S_D41_3);
+    double d42_1 = LDF(S_D42_1), d42_2 = LDF(S_D42_2), d42_3 = LDF(S_D42_3);
+    double d8_1 = LDF(S_D8_1), d8_2 = LDF(S_D8_2);
+    double res_x1 = LDF(S_RES_X1), res_x2 = LDF(S_RES_X2), res_y1 = LDF(S_RES_Y1), res_y2 = LDF(S_RES_Y2);
+    double lf_x1 = LDF(S_LF_X1), lf_x2 = LDF(S_LF_X2), lf_y1 = LDF(S_LF_Y1), lf_y2 = LDF(S_LF_Y2);
+    double sig2l_re = LDF(S_SIG2L_RE), sig2l_im = LDF(S_SIG2L_IM), ptd_re = LDF(S_PTD_RE), ptd_im = LDF(S_PTD_IM);
+    double marg_sum = LDF(S_MARG_SUM), pm_sum = LDF(S_PM_SUM), msema_sum = LDF(S_MSEMA_SUM), mse = LDF(S_MSE);
+    const double thresh = LDF(S_THRESH);
+
+    int agc_pos = LDI(I_AGC_POS), eb_pos = LDI(I_EB_POS), bb_ptr = LDI(I_BB_PTR), coarse_cnt = LDI(I_COARSE_CNT);
+    int marg_pos = LDI(I_MARG_POS), dt_pos = LDI(I_DT_POS), pm_pos = LDI(I_PM_POS), msema_pos = LDI(I_MSEMA_POS);
+    int yui = LDI(I_YUI), sig2l_init = LDI(I_SIG2L_INIT);
+    const int flags = LDI(I_FLAGS);
+    int soft_cnt = LDI(I_SOFT_CNT), sym_cnt = LDI(I_SYM_CNT), overflow = LDI(I_OVERFLOW);
+
+    const double samplerate = g.Fs; // WaveTable::samplerate after SetFreq(freq,(int)Fs)
+    const int nfft_mask = g.nfft - 1;
+    double2 *__restrict__ bbring = p.bbring + (size_t)ch * g.nfft;
+    double *__restrict__ agc_ring = p.agc_ring + (size_t)grp * g.agc_len * 64 + lane;
+    double *__restrict__ ebe_ring = p.eb_e + (size_t)grp * g.ebno_len * 64 + lane;
+    double *__restrict__ ebe2_ring = p.eb_e2 + (size_t)grp * g.ebno_len * 64 + lane;
+    double *__restrict__ marg_ring = p.marg + (size_t)ch * g.marg_len;
+    double2 *__restrict__ dt_ring = p.dt + (size_t)ch * g.dt_len;
+    double *__restrict__ pm_ring = p.pm + (size_t)ch * g.pm_len;
+    double *__restrict__ msema_ring = p.msema + (size_t)ch * g.msema_len;
+    int16_t *__restrict__ soft = p.soft + (size_t)ch * g.soft_cap;
+
+    // ---- matched-filter history -> LDS + registers (each lane owns one LDS column: no barrier needed) ----
+    {
+        const double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
+        for (int k = 0; k < LDSN; k++)
+        {
+            lre[k * 64 + lane] = fs[(size_t)k * 64];
+            lim[k * 64 + lane] = fs[(size_t)(FIRN + k) * 64];
+        }
+#pragma unroll
+        for (int j = 0; j < TAILN; j++)
+        {
+            tre[j] = fs[(size_t)(LDSN + j) * 64];
+            tim[j] = fs[(size_t)(FIRN + LDSN + j) * 64];
+        }
+    }
+    int fir_slot = fir_slot0; // LDS slot holding the oldest LDS entry, overwritten by the next input (per lane inside the launch)
+
+    // filter output for the current sample from the history x[n-FIRN .. n-1]: taps[i] <-> x[n-FIRN+i]
+    auto fir_eval = [&](double &ore, double &oim) {
+        double are = 0, aim = 0;
+#pragma unroll
+        for (int j = TAILN - 1; j >= 0; j--)
+        {
+            const double tp = taps[TAILN - 1 - j];
+            are = fma(tp, tre[j], are);
+            aim = fma(tp, tim[j], aim);
+        }
+        int slot = fir_slot;
+#pragma unroll 8
+        for (int k = 0; k < LDSN; k++)
+        {
+            const double tp = taps[TAILN + k];
+            are = fma(tp, lre[slot * 64 + lane], are);
+            aim = fma(tp, lim[slot * 64 + lane], aim);
+            slot++;
+            if (slot >= LDSN) slot = 0;
+        }
+        ore = are; oim = aim;
+    };
+    double ycur_re, ycur_im;
+    fir_eval(ycur_re, ycur_im);
+
+    const double w4 = g.w4, w4c = 1.0 - g.w4, w8 = g.w8, w8c = 1.0 - g.w8;
+    const double agc_len_d = (double)g.agc_len, eb_len_d = (double)g.ebno_len;
+
+    // Inputs of sample i+1 (PCM and the ring rows that leave the AGC / EbNo windows) are requested at the top of
+    // iteration i and consumed one iteration later, so their HBM latency overlaps a whole sample of arithmetic.
+    short nx_pcm = (live && n > 0) ? pcm[ch] : (short)0;
+    double nx_agc = agc_ring[(size_t)agc_pos * 64];
+    double nx_e = 0, nx_e2 = 0;
+    if (EBNO) { nx_e = ebe_ring[(size_t)eb_pos * 64]; nx_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
+
+    int i = 0;                 // per-lane sample index inside this launch
+    bool done = (n <= 0), pend = false; // pend: the second half of sample i has not run yet
+    double dval = 0, sre = 0, sim = 0, frac = 0;
+    double2 c_m2 = make_double2(0.0, 0.0);
+    for (;;)
+    {
+        bool hit = false;
+        // ---- step every lane to its next symbol instant (or to the end of the launch) ----
+        while (__ballot(!hit && !done) != 0ull)
+        {
+            if (!hit && !done)
+            {
+                if (pend)
+                {
+                    sig2l_re = sre; sig2l_im = sim;
+
+                    // ---- push x[n] (mixed with the carrier phase this sample started with) and evaluate the filter for n+1 ----
+                    {
+                        const double cre = c_m2.x * dval, cim = c_m2.y * dval;
+#pragma unroll
+                        for (int j = TAILN - 1; j > 0; j--) { tre[j] = tre[j - 1]; tim[j] = tim[j - 1]; }
+                        tre[0] = lre[fir_slot * 64 + lane];
+                        tim[0] = lim[fir_slot * 64 + lane];
+                        lre[fir_slot * 64 + lane] = cre;
+                        lim[fir_slot * 64 + lane] = cim;
+                        fir_slot++;
+                        if (fir_slot >= LDSN) fir_slot = 0;
+                        fir_eval(ycur_re, ycur_im);
+                    }
+
+                    // ---- advance the NCOs (:600-603) ----
+                    jd_wt_next(m2_ptr, m2_step);
+                    jd_wt_next(mc_ptr, mc_step);
+                    if (st_step < 0) st_step = 0;
+                    st_last = st_ptr;
+                    st_ptr += st_step;
+                    while (((int)st_ptr) >= JD_WTSIZE) st_ptr -= JD_WTSIZE;
+
+                    i++;
+                    pend = false;
+                    done = (i >= n);
+                }
+                if (!done)
+                {
+                    const short s = nx_pcm;
+                    dval = ((double)s) / 32768.0;
+                    const double agc_old = nx_agc, e_old = nx_e, e2_old = nx_e2;
+                    // requests for this iteration's table look-ups and next iteration's streams, all independent of the chain below
+                    c_m2 = cis[jd_cisidx(m2_ptr)];
+                    const double2 c_st = cis[jd_cisidx(st_ptr)];
+                    if (i + 1 < n)
+                    {
+                        nx_pcm = live ? pcm[(size_t)(i + 1) * pcm_stride + ch] : (short)0;
+                        int ap = agc_pos + 1; if (ap >= g.agc_len) ap = 0;
+                        nx_agc = agc_ring[(size_t)ap * 64];
+                        if (EBNO)
+                        {
+                            int ep = eb_pos + 1; if (ep >= g.ebno_len) ep = 0;
+                            nx_e = ebe_ring[(size_t)ep * 64];
+                            nx_e2 = ebe2_ring[(size_t)ep * 64];
+                        }
+                    }
+
+                    // ---- K3: coarse-frequency ring fill (oqpskdemodulator.cpp:410-415) ----
+                    if (!(i == 0 && skip_a_first))
+                    {
+                        const bool fill = (coarse_cnt >= g.Fs_int) || !(flags & JF_CPUREDUCE);
+                        if (fill)
+                        {
+                            const double2 cc = cis[jd_cisidx(mc_ptr)];
+                            bbring[bb_ptr] = make_double2(cc.x * dval, cc.y * dval);
+                            bb_ptr = (bb_ptr + 1) & nfft_mask;
+                        }
+                    }
+
+                    if (i == n - 1 && only_a_last) done = true; // the coarse estimate runs now, then the next launch resumes here
+                    if (!done)
+                    {
+                        coarse_cnt++;                          // :431
+
+                        // ---- K2 mix + K6 matched filter (:453-456, DSP.cpp:292-304) ----
+                        // this sample's filter output was evaluated one iteration ago; push x[n] and evaluate the next one now
+                        sre = ycur_re; sim = ycur_im;
+
+                        // ---- K7 EbNo (DSP.cpp:729-744) ----
+                        const double dabval = sqrt(sre * sre + sim * sim);
+                        if (EBNO)
+                        {
+                            const double sq = dabval * dabval;
+                            double *e2p = ebe2_ring + (size_t)eb_pos * 64;
+                            double *ep = ebe_ring + (size_t)eb_pos * 64;
+                            eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq); *e2p = fabs(sq);
+                            eb_esum = eb_esum - e_old; eb_esum = eb_esum + fabs(dabval); *ep = fabs(dabval);
+                            eb_pos++; if (eb_pos >= g.ebno_len) eb_pos = 0;
+                            const double e2val = eb_e2sum / eb_len_d, mean = eb_esum / eb_len_d;
+                            const double meansq = mean * mean;
+                            double var = e2val - (mean * mean);
+                            var -= (0.024709 * meansq);
+                            double mvr = (((g.Fs * meansq / (2.0 * g.fb * var))) * 0.13743);
+                            if (mvr < 0.000000001) mvr = 0.000000001;
+                            double tebno = 10.0 * log10(mvr);
+                            if (isnan(tebno)) tebno = 50;
+                            if (tebno > 50.0) tebno = 50;
+                            if (tebno < 0.0) tebno = 0;
+                            eb_ebno = eb_ebno * 0.8 + 0.2 * tebno;
+                        }
+
+                        // ---- K8 AGC + clip (DSP.cpp:370-379, :466-470) ----
+                        {
+                            double *ap = agc_ring + (size_t)agc_pos * 64;
+                            agc_sum = agc_sum - agc_old;
+                            agc_sum = agc_sum + fabs(dabval);
+                            *ap = fabs(dabval);
+                            agc_pos++; if (agc_pos >= g.agc_len) agc_pos = 0;
+                        }
+                        double gain = 1.414213562 / fmax(agc_sum / agc_len_d, 0.000001);
+                        gain = fmax(gain, 0.000001);
+                        sre *= gain; sim *= gain;
+                        const double abval = hypot(sre, sim);
+                        if (abval > 2.84) { const double k = (2.84 / abval); sre = k * sre; sim = k * sim; }
+
+                        // ---- K9 symbol timing (:473-484) ----
+                        const double ab2 = abval * abval;
+                        const double st_diff = d1 - ab2; d1 = ab2;
+                        const double st_d1out = w4 * d41_2 + w4c * d41_3; d41_3 = d41_2; d41_2 = d41_1; d41_1 = st_diff;
+                        const double st_d2out = w4 * d42_2 + w4c * d42_3; d42_3 = d42_2; d42_2 = d42_1; d42_1 = st_d1out;
+                        double st_eta = (st_d2out - st_diff) * st_d1out;
+                        {
+                            double y = 0;
+                            y += res_x2 * g.res_b2; y += res_x1 * g.res_b1; y += st_eta * g.res_b0;
+                            y -= res_y2 * g.res_a2; y -= res_y1 * g.res_a1;
+                            res_x2 = res_x1; res_x1 = st_eta; res_y2 = res_y1; res_y1 = y;
+                            st_eta = y;
+                        }
+                        const double d8out = w8 * d8_1 + w8c * d8_2; d8_2 = d8_1; d8_1 = st_eta;
+                        {
+                            const double2 so = c_st;
+                            const double m_re = st_eta, m_im = -d8out;
+                            const double o_re = so.x * m_re - so.y * m_im;
+                            const double o_im = so.x * m_im + so.y * m_re;
+                            const double st_angle_error = atan2(o_im, o_re);
+                            jd_wt_setfreq(st_freq, st_step, (-st_angle_error * 0.00000001) + st_freq, samplerate);
+                            jd_wt_advance_fraction(st_ptr, -st_angle_error * 0.01 / 360.0);
+                            if (st_freq < (g.stref_freq - 0.1)) jd_wt_setfreq(st_freq, st_step, (g.stref_freq - 0.1), samplerate);
+                            if (st_freq > (g.stref_freq + 0.1)) jd_wt_setfreq(st_freq, st_step, (g.stref_freq + 0.1), samplerate);
+                        }
+
+                        // ---- K10..K14 at symbol instants (:487-595) ----
+                        if (!sig2l_init) { sig2l_re = sre; sig2l_im = sim; sig2l_init = 1; }
+
+                        hit = jd_wt_passed(st_last, st_ptr, st_step, g.ee, frac);
+                        pend = true;
+                    }
+                }
+            }
+        }
+        if (__ballot(hit) == 0ull) break; // every lane has consumed its n samples
+        // ---- K10..K14 for all lanes that reached an instant (:487-595) ----
+        if (hit)
+        {
+            const double pt_last = frac, pt_this = 1.0 - pt_last;
+            const double pt_re = pt_this * sre + pt_last * sig2l_re;
+            const double pt_im = pt_this * sim + pt_last * sig2l_im;
+            yui++; yui %= 2;
+            if (!yui) { ptd_re = pt_re; ptd_im = pt_im; }
+            else
+            {
+                double q_re = pt_re, q_im = ptd_im;
+                const double ct_xt = tanh(pt_im) * pt_re;
+                const double ct_xt_d = tanh(ptd_re) * ptd_im;
+                double ct_ec = ct_xt_d - ct_xt;
+                if (ct_ec > M_PI) ct_ec = M_PI;
+                if (ct_ec < -M_PI) ct_ec = -M_PI;
+                {
+                    double y = 0;
+                    y += lf_x2 * g.lf_b2; y += lf_x1 * g.lf_b1; y += ct_ec * g.lf_b0;
+                    y -= lf_y2 * g.lf_a2; y -= lf_y1 * g.lf_a1;
+                    lf_x2 = lf_x1; lf_x1 = ct_ec; lf_y2 = lf_y1; lf_y1 = y;
+                    ct_ec = y;
+                }
+                if (ct_ec > M_PI_2) ct_ec = M_PI_2;
+                if (ct_ec < -M_PI_2) ct_ec = -M_PI_2;
+                jd_wt_inc_phase_deg(m2_ptr, 1.0 * ct_ec);
+                jd_wt_setfreq(m2_freq, m2_step, (0.01 * ct_ec) + m2_freq, samplerate);
+
+                // marg->UpdateSigned(ct_ec)
+                {
+                    double *mp = marg_ring + marg_pos;
+                    marg_sum = marg_sum - *mp; marg_sum = marg_sum + ct_ec; *mp = ct_ec;
+                    marg_pos++; if (marg_pos >= g.marg_len) marg_pos = 0;
+                }
+                const double marg_val = marg_sum / ((double)g.marg_len);
+                // dt.update(pt_qpsk)
+                {
+                    dt_ring[dt_pos] = make_double2(q_re, q_im);
+                    dt_pos++; if (dt_pos >= g.dt_len) dt_pos = 0;
+                    const double2 o = dt_ring[dt_pos];
+                    q_re = o.x; q_im = o.y;
+                }
+                {
+                    const double cr = cos(marg_val), sr = sin(marg_val);
+                    const double nr = q_re * cr - q_im * sr;
+                    const double ni = q_re * sr + q_im * cr;
+                    q_re = nr; q_im = ni;
+                }
+                // MSEcalc::Update (DSP.cpp:451-463)
+                {
+                    const double av = hypot(q_re, q_im);
+                    double *pp = pm_ring + pm_pos;
+                    pm_sum = pm_sum - *pp; pm_sum = pm_sum + fabs(av); *pp = fabs(av);
+                    pm_pos++; if (pm_pos >= g.pm_len) pm_pos = 0;
+                    double mu = pm_sum / ((double)g.pm_len);
+                    if (mu < 0.000001) mu = 0.000001;
+                    const double s2 = sqrt(2.0);
+                    const double t_re = (s2 * q_re) / mu, t_im = (s2 * q_im) / mu;
+                    const double tda = (fabs(t_re) - 1.0), tdb = (fabs(t_im) - 1.0);
+                    const double e = (tda * tda) + (tdb * tdb);
+                    double *ep = msema_ring + msema_pos;
+                    msema_sum = msema_sum - *ep; msema_sum = msema_sum + fabs(e); *ep = fabs(e);
+                    msema_pos++; if (msema_pos >= g.msema_len) msema_pos = 0;
+                    mse = msema_sum / ((double)g.msema_len);
+                }
+                if (CAPSYM)
+                {
+                    if (sym_cnt < g.sym_cap)
+                    {
+                        double *sp = p.sym + ((size_t)ch * g.sym_cap + sym_cnt) * 3;
+                        sp[0] = q_re; sp[1] = q_im; sp[2] = mse;
+                        sym_cnt++;
+                    }
+                    else overflow |= 2;
+                }
+                if (mse < thresh)
+                {
+                    const int b0 = jd_softbit(0.75 * q_im * 127.0 + 128.0);
+                    const int b1 = jd_softbit(0.75 * q_re * 127.0 + 128.0);
+                    if (soft_cnt + 2 <= g.soft_cap)
+                    {
+                        soft[soft_cnt] = (int16_t)b0;
+                        soft[soft_cnt + 1] = (int16_t)b1;
+                        soft_cnt += 2;
+                    }
+                    else overflow |= 1;
+                }
+            }
+        }
+
+    }
+
+    // ---- store state ----
+    LDF(S_M2_PTR) = m2_ptr; LDF(S_M2_STEP) = m2_step; LDF(S_M2_FREQ) = m2_freq;
+    LDF(S_MC_PTR) = mc_ptr; LDF(S_MC_STEP) = mc_step;
+    LDF(S_ST_PTR) = st_ptr; LDF(S_ST_STEP) = st_step; LDF(S_ST_FREQ) = st_freq; LDF(S_ST_LAST) = st_last;
+    LDF(S_AGC_SUM) = agc_sum;
+    LDF(S_EB_ESUM) = eb_esum; LDF(S_EB_E2SUM) = eb_e2sum; LDF(S_EB_EBNO) = eb_ebno;
+    LDF(S_D1) = d1;
+    LDF(S_D41_1) = d41_1; LDF(S_D41_2) = d41_2; LDF(S_D41_3) = d41_3;
+    LDF(S_D42_1) = d42_1; LDF(S_D42_2) = d42_2; LDF(S_D42_3) = d42_3;
+    LDF(S_D8_1) = d8_1; LDF(S_D8_2) = d8_2;
+    LDF(S_RES_X1) = res_x1; LDF(S_RES_X2) = res_x2; LDF(S_RES_Y1) = res_y1; LDF(S_RES_Y2) = res_y2;
+    LDF(S_LF_X1) = lf_x1; LDF(S_LF_X2) = lf_x2; LDF(S_LF_Y1) = lf_y1; LDF(S_LF_Y2) = lf_y2;
+    LDF(S_SIG2L_RE) = sig2l_re; LDF(S_SIG2L_IM) = sig2l_im; LDF(S_PTD_RE) = ptd_re; LDF(S_PTD_IM) = ptd_im;
+    LDF(S_MARG_SUM) = marg_sum; LDF(S_PM_SUM) = pm_sum; LDF(S_MSEMA_SUM) = msema_sum; LDF(S_MSE) = mse;
+    LDI(I_AGC_POS) = agc_pos; LDI(I_EB_POS) = eb_pos; LDI(I_BB_PTR) = bb_ptr; LDI(I_COARSE_CNT) = coarse_cnt;
+    LDI(I_MARG_POS) = marg_pos; LDI(I_DT_POS) = dt_pos; LDI(I_PM_POS) = pm_pos; LDI(I_MSEMA_POS) = msema_pos;
+    LDI(I_YUI) = yui; LDI(I_SIG2L_INIT) = sig2l_init;
+    LDI(I_SOFT_CNT) = soft_cnt; LDI(I_SYM_CNT) = sym_cnt; LDI(I_OVERFLOW) = overflow;
+    {
+        double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
+        for (int k = 0; k < LDSN; k++)
+        {
+            fs[(size_t)k * 64] = lre[k * 64 + lane];
+            fs[(size_t)(FIRN + k) * 64] = lim[k * 64 + lane];
+        }
+#pragma unroll
+        for (int j = 0; j < TAILN; j++)
+        {
+            fs[(size_t)(LDSN + j) * 64] = tre[j];
+            fs[(size_t)(FIRN + LDSN + j) * 64] = tim[j];
+        }
+    }
+}

@@ -213,27 +213,14 @@ def channel_bank(kind: str, nch: int, nsamples: int, *, ebno_db: float | None = 
 # ----------------------------------------------------------------------------------------------------------------------
 # torch (device-resident) generator for large banks: same waveform family as `oqpsk` above
 # ----------------------------------------------------------------------------------------------------------------------
-def oqpsk_torch(nch: int, nsamples: int, device, *, fb: float = 10500.0, Fs: float = 48000.0, fc_center: float = 8000.0,
-                fc_spread: float = 100.0, ebno_db: float | None = 10.0, peak: float = 0.3, seed: int = SEED_BASE,
-                block: int = 2048):
-    """Returns (pcm int16 [nsamples, nch] frame-major on `device`, bits uint8 [nch, 2*nsym], carriers float64 [nch]).
-
-    Channel c: carrier fc_center + U(-fc_spread, fc_spread), random bits, AWGN at Eb/N0, as SURVEY.md 8(d) config 3.
-    """
+def _render_oqpsk_torch(a_i, a_q, carriers, nsamples: int, device, *, fb: float, Fs: float, sigma: float, scale: float, gen,
+                        block: int = 2048):
+    """Passband OQPSK (RRC alpha=1, Q arm delayed T/2) of the +-1/0 symbol arrays a_i, a_q [nch, nsym] -> int16 [nsamples, nch]."""
     import torch
 
-    gen = torch.Generator(device=device)
-    gen.manual_seed(seed)
+    nch, nsym = a_i.shape
     T = Fs / (fb / 2.0)
-    nsym = int(np.ceil(nsamples / T)) + 16
-    bits = torch.randint(0, 2, (nch, 2 * nsym), generator=gen, device=device, dtype=torch.uint8)
-    a_i = bits[:, 0::2].to(torch.float32) * 2 - 1
-    a_q = bits[:, 1::2].to(torch.float32) * 2 - 1
-    carriers = fc_center + (torch.rand(nch, generator=gen, device=device, dtype=torch.float64) * 2 - 1) * fc_spread
     out = torch.empty((nsamples, nch), dtype=torch.int16, device=device)
-    P = 1.0 / T  # signal power of unit-symbol OQPSK with a unit-energy RRC pulse
-    sigma = float(np.sqrt(P * Fs / (2.0 * fb * 10.0 ** (ebno_db / 10.0)))) if ebno_db is not None else 0.0
-    scale = peak / (3.0 * np.sqrt(P)) * 32768.0
 
     def pulse(t):  # alpha = 1
         x = 4.0 * t / T
@@ -255,7 +242,7 @@ def oqpsk_torch(nch: int, nsamples: int, device, *, fb: float = 10500.0, Fs: flo
             ok = (k >= 0) & (k < nsym)
             kk = k.clamp(0, nsym - 1)
             h = pulse((t - k.to(torch.float64) * T)).to(torch.float32) * ok.to(torch.float32)
-            acc += a[:, kk] * h[None, :]
+            acc += a[:, kk].to(torch.float32) * h[None, :]
         return acc
 
     for s in range(0, nsamples, block):
@@ -269,4 +256,60 @@ def oqpsk_torch(nch: int, nsamples: int, device, *, fb: float = 10500.0, Fs: flo
         if sigma > 0:
             x = x + torch.randn(x.shape, generator=gen, device=device, dtype=torch.float32) * sigma
         out[s:e] = torch.clamp(torch.round(x * scale), -32768, 32767).to(torch.int16).t()
+    return out
+
+
+def oqpsk_torch(nch: int, nsamples: int, device, *, fb: float = 10500.0, Fs: float = 48000.0, fc_center: float = 8000.0,
+                fc_spread: float = 100.0, ebno_db: float | None = 10.0, peak: float = 0.3, seed: int = SEED_BASE,
+                block: int = 2048):
+    """Returns (pcm int16 [nsamples, nch] frame-major on `device`, bits uint8 [nch, 2*nsym], carriers float64 [nch]).
+
+    Channel c: carrier fc_center + U(-fc_spread, fc_spread), random bits, AWGN at Eb/N0, as SURVEY.md 8(d) config 3.
+    """
+    import torch
+
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    T = Fs / (fb / 2.0)
+    nsym = int(np.ceil(nsamples / T)) + 16
+    bits = torch.randint(0, 2, (nch, 2 * nsym), generator=gen, device=device, dtype=torch.uint8)
+    a_i = bits[:, 0::2].to(torch.float32) * 2 - 1
+    a_q = bits[:, 1::2].to(torch.float32) * 2 - 1
+    carriers = fc_center + (torch.rand(nch, generator=gen, device=device, dtype=torch.float64) * 2 - 1) * fc_spread
+    P = 1.0 / T  # signal power of unit-symbol OQPSK with a unit-energy RRC pulse
+    sigma = float(np.sqrt(P * Fs / (2.0 * fb * 10.0 ** (ebno_db / 10.0)))) if ebno_db is not None else 0.0
+    scale = peak / (3.0 * np.sqrt(P)) * 32768.0
+    out = _render_oqpsk_torch(a_i, a_q, carriers, nsamples, device, fb=fb, Fs=Fs, sigma=sigma, scale=scale, gen=gen, block=block)
     return out, bits, carriers
+
+
+def burst_oqpsk_torch(nch: int, nsamples: int, device, *, period: int = 48000, ndata_sym: int = 3040, fb: float = 10500.0,
+                      Fs: float = 48000.0, fc_center: float = 8000.0, fc_spread: float = 100.0, ebno_db: float | None = 15.0,
+                      peak: float = 0.3, seed: int = SEED_BASE, block: int = 2048):
+    """SURVEY.md 8(d) config 4 on a torch device: every channel sends one burst per `period` samples (128 symbols of
+    carrier, 128 symbols of alternating preamble, `ndata_sym` random symbols per arm = <= 6080 bits), at a per-channel
+    random offset inside the period, noise in the gaps.  Returns (pcm int16 [nsamples, nch], carriers, offsets)."""
+    import torch
+
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    T = Fs / (fb / 2.0)
+    nsym = int(np.ceil(nsamples / T)) + 16
+    psym = int(round(period / T))
+    blen = 256 + ndata_sym
+    assert blen < psym
+    off = torch.randint(0, psym - blen, (nch,), generator=gen, device=device)
+    k = torch.arange(nsym, device=device)[None, :]
+    rel = torch.remainder(k - off[:, None], psym)  # symbol index inside the channel's period
+    inb = rel < blen
+    pre = torch.where(rel < 128, torch.ones_like(rel), torch.where(rel % 2 == 0, torch.ones_like(rel), -torch.ones_like(rel)))
+    di = torch.randint(0, 2, (nch, nsym), generator=gen, device=device, dtype=torch.int8) * 2 - 1
+    dq = torch.randint(0, 2, (nch, nsym), generator=gen, device=device, dtype=torch.int8) * 2 - 1
+    a_i = torch.where(inb, torch.where(rel < 256, pre.to(torch.int8), di), torch.zeros_like(di))
+    a_q = torch.where(inb, torch.where(rel < 256, pre.to(torch.int8), dq), torch.zeros_like(dq))
+    carriers = fc_center + (torch.rand(nch, generator=gen, device=device, dtype=torch.float64) * 2 - 1) * fc_spread
+    P = 1.0 / T
+    sigma = float(np.sqrt(P * Fs / (2.0 * fb * 10.0 ** (ebno_db / 10.0)))) if ebno_db is not None else 0.0
+    scale = peak / (3.0 * np.sqrt(P)) * 32768.0
+    out = _render_oqpsk_torch(a_i, a_q, carriers, nsamples, device, fb=fb, Fs=Fs, sigma=sigma, scale=scale, gen=gen, block=block)
+    return out, carriers, (off.to(torch.float64) * T)

@@ -15,7 +15,7 @@ from collections import defaultdict
 
 csv.field_size_limit(1 << 30)
 out = sys.argv[1]
-OURS = ("k_oqpsk", "k_msk", "k_coarse", "k_viterbi", "k_transpose", "k_center", "k_status", "k_pack", "k_burst", "k_aerol", "k_hilbert")
+OURS = ("k_oqpsk", "k_msk", "k_coarse", "k_viterbi", "k_transpose", "k_center", "k_status", "k_pack", "k_burst", "k_aerol", "k_hilbert", "k_trident", "k_hist")
 
 
 def short(name):
@@ -28,6 +28,9 @@ def role(name):
         return "sample_loop"
     if "k_coarse" in name:
         return "coarse_freq"
+    for k, r in (("k_burst_front", "front"), ("k_hilbert", "hilbert"), ("k_trident", "trident"), ("k_burst_oqpsk_demod", "demod"), ("k_burst_msk_demod", "demod")):
+        if k in name:
+            return r
     return None
 
 
@@ -50,7 +53,7 @@ if rows:
             print("  %-70s calls %6s avg %12.1f us  %5s%%" % (short(r["Name"])[:70], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
 
 pmc = {}
-for which in ("fetch", "write"):
+for which in ("fetch", "write", "rdreq"):
     acc = defaultdict(list)
     for f in glob.glob(os.path.join(out, "pmc_" + which, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -66,10 +69,15 @@ for which in ("fetch", "write"):
 summary = {}
 for n, d in pmc.items():
     f, w = d.get("FETCH_SIZE"), d.get("WRITE_SIZE")
-    e = {"kernel": n, "FETCH_SIZE_KiB_mean": f, "WRITE_SIZE_KiB_mean": w}
+    rd, rd32 = d.get("TCC_EA0_RDREQ_sum"), d.get("TCC_EA0_RDREQ_32B_sum")
+    e = {"kernel": n, "FETCH_SIZE_KiB_mean": f, "WRITE_SIZE_KiB_mean": w, "TCC_EA0_RDREQ_sum_mean": rd, "TCC_EA0_RDREQ_32B_sum_mean": rd32}
+    if f is None and rd is not None:
+        # FETCH_SIZE's own gfx950 expression without the TCC_BUBBLE term (counter_defs.yaml): 64 B per request, 32 B for the 32B ones
+        f = ((rd - (rd32 or 0.0)) * 64.0 + (rd32 or 0.0) * 32.0) / 1024.0
+        e["FETCH_SIZE_KiB_from_RDREQ"] = f
     if f is not None and w is not None:
         e["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0
-        e["correction"] = "gfx950: (2*FETCH_SIZE + WRITE_SIZE)*1024"
+        e["correction"] = "gfx950: (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE tallies 128-B read requests at 64 B; MI355X_MICROARCH.md HBM)"
     summary[n] = e
     r = role(n)
     if r and "hbm_bytes_per_launch" in e and (r not in summary or e["hbm_bytes_per_launch"] > summary[r].get("hbm_bytes_per_launch", 0)):
