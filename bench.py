@@ -259,7 +259,10 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
+                if traffic is not None:  # measured at pj["channels_per_gpu"] channels: scale to this run's bank
+                    traffic = traffic * nch / float(pj.get("channels_per_gpu", nch))
             except Exception:
                 traffic = None
         line = {

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libjaero_hip.so")
+LIB_PATH = os.environ.get("JAERO_HIP_LIB") or os.path.join(HERE, "libjaero_hip.so")  # override: A/B builds of the same ABI
 
 KIND_MSK, KIND_OQPSK, KIND_BURST_MSK, KIND_BURST_OQPSK = 0, 1, 2, 3
 FLAG_EBNO, FLAG_STATUS_LOG, FLAG_CAPTURE_SYMBOLS, FLAG_TRACE = 1, 2, 4, 8

@@ -160,3 +160,9 @@ __device__ __forceinline__ int jd_softbit(double v)
     if (ibit < 0) ibit = 0;
     return ibit;
 }
+
+// The EbNo meters (OQPSKEbNoMeasure / MSKEbNoMeasure, JAERO/DSP.cpp:729-744,493-505) never feed back into the signal path; their
+// output EbNo = 0.8 EbNo + 0.2 t[n] forgets a term after k samples as 0.8^k (0.8^192 = 2.5e-19).  The ring sums are kept up to
+// date on every sample, but the divide/log10 part is only evaluated over the last JD_EBNO_TAIL samples of a launch -- the value
+// anyone can read after the launch differs from the every-sample evaluation by < 1e-16.
+#define JD_EBNO_TAIL 192

@@ -19,7 +19,6 @@
 #include "../../include/jaero_hip.h"
 #include "jaero_device.h"
 #include "k_oqpsk.h"
-#include "k_oqpsk2.h"
 #include "k_msk.h"
 #include "k_coarse.h"
 #include "k_coarse2.h"
@@ -133,7 +132,6 @@ struct jaero_ctx
     double2 *d_tw = nullptr;
     int *d_chanlist = nullptr;
     int coarse_grid = 0;
-    bool oqpsk_v1 = false;   // JAERO_OQPSK_V1=1 selects the lock-step sample loop k_oqpsk.h (kept for A/B validation)
     bool coarse_v1 = false;  // JAERO_COARSE_V1=1 selects the four-step LDS/scratch FFT (kept for A/B validation)
     int coarse2_grid = 0, coarse2_lds = 0;
     jaero_status *d_status = nullptr;
@@ -500,7 +498,6 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
     DA(c->d_chanlist, nchp);
     DA(c->d_status, nchp);
     c->coarse_v1 = getenv("JAERO_COARSE_V1") && atoi(getenv("JAERO_COARSE_V1")) != 0;
-    c->oqpsk_v1 = getenv("JAERO_OQPSK_V1") && atoi(getenv("JAERO_OQPSK_V1")) != 0;
     c->coarse_grid = nchannels < 512 ? nchannels : 512;
     if (c->coarse_v1) DA(c->d_scratch, (size_t)c->coarse_grid * 2 * g.nfft);
     {
@@ -745,11 +742,8 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
     {
         const int fs = (int)(c->m.nB_total % OQ_LDSN);
 #define LO(E, C) hipLaunchKernelGGL((k_oqpsk_samples<55, OQ_LDSN, E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs)
-#define LO2(E, C) hipLaunchKernelGGL((k_oqpsk_samples2<55, OQ_LDSN, E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs)
-        if (c->oqpsk_v1) { if (eb && cs) LO(true, true); else if (eb) LO(true, false); else if (cs) LO(false, true); else LO(false, false); }
-        else { if (eb && cs) LO2(true, true); else if (eb) LO2(true, false); else if (cs) LO2(false, true); else LO2(false, false); }
+        if (eb && cs) LO(true, true); else if (eb) LO(true, false); else if (cs) LO(false, true); else LO(false, false);
 #undef LO
-#undef LO2
     }
     else
     {

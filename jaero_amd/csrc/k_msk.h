@@ -115,13 +115,16 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
             eb_e2sum = eb_e2sum - *e2p; eb_e2sum = eb_e2sum + fabs(sq); *e2p = fabs(sq);
             eb_esum = eb_esum - *ep; eb_esum = eb_esum + fabs(dabval); *ep = fabs(dabval);
             eb_pos++; if (eb_pos >= g.ebno_len) eb_pos = 0;
-            const double e2val = eb_e2sum / eb_len_d, mean = eb_esum / eb_len_d;
-            const double var = e2val - (mean * mean);
-            const double alpha = sqrt(2.0) / mean;
-            double tebno = 10.0 * (log10(2.0) - log10(((var * alpha * alpha) - 0.0085))) - 5.0;
-            if (isnan(tebno)) tebno = 50;
-            if (tebno > 50.0) tebno = 50;
-            eb_ebno = eb_ebno * 0.8 + 0.2 * tebno;
+            if (i >= n - JD_EBNO_TAIL) // wave-uniform; see JD_EBNO_TAIL
+            {
+                const double e2val = eb_e2sum / eb_len_d, mean = eb_esum / eb_len_d;
+                const double var = e2val - (mean * mean);
+                const double alpha = sqrt(2.0) / mean;
+                double tebno = 10.0 * (log10(2.0) - log10(((var * alpha * alpha) - 0.0085))) - 5.0;
+                if (isnan(tebno)) tebno = 50;
+                if (tebno > 50.0) tebno = 50;
+                eb_ebno = eb_ebno * 0.8 + 0.2 * tebno;
+            }
         }
 
         // AGC + clip (:378-382)

@@ -171,17 +171,20 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
             eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq); *e2p = fabs(sq);
             eb_esum = eb_esum - e_old; eb_esum = eb_esum + fabs(dabval); *ep = fabs(dabval);
             eb_pos++; if (eb_pos >= g.ebno_len) eb_pos = 0;
-            const double e2val = eb_e2sum / eb_len_d, mean = eb_esum / eb_len_d;
-            const double meansq = mean * mean;
-            double var = e2val - (mean * mean);
-            var -= (0.024709 * meansq);
-            double mvr = (((g.Fs * meansq / (2.0 * g.fb * var))) * 0.13743);
-            if (mvr < 0.000000001) mvr = 0.000000001;
-            double tebno = 10.0 * log10(mvr);
-            if (isnan(tebno)) tebno = 50;
-            if (tebno > 50.0) tebno = 50;
-            if (tebno < 0.0) tebno = 0;
-            eb_ebno = eb_ebno * 0.8 + 0.2 * tebno;
+            if (i >= n - JD_EBNO_TAIL) // wave-uniform; see JD_EBNO_TAIL
+            {
+                const double e2val = eb_e2sum / eb_len_d, mean = eb_esum / eb_len_d;
+                const double meansq = mean * mean;
+                double var = e2val - (mean * mean);
+                var -= (0.024709 * meansq);
+                double mvr = (((g.Fs * meansq / (2.0 * g.fb * var))) * 0.13743);
+                if (mvr < 0.000000001) mvr = 0.000000001;
+                double tebno = 10.0 * log10(mvr);
+                if (isnan(tebno)) tebno = 50;
+                if (tebno > 50.0) tebno = 50;
+                if (tebno < 0.0) tebno = 0;
+                eb_ebno = eb_ebno * 0.8 + 0.2 * tebno;
+            }
         }
 
         // ---- K8 AGC + clip (DSP.cpp:370-379, :466-470) ----
