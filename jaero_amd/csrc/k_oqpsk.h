@@ -121,6 +121,7 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
     double nx_agc = agc_ring[(size_t)agc_pos * 64];
     double nx_e = 0, nx_e2 = 0;
     if (EBNO) { nx_e = ebe_ring[(size_t)eb_pos * 64]; nx_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
+    double2 nx_cc = cis[jd_cisidx(mc_ptr)];
 
     for (int i = 0; i < n; i++)
     {
@@ -144,12 +145,17 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
         }
 
         // ---- K3: coarse-frequency ring fill (oqpskdemodulator.cpp:410-415) ----
+        const double2 cc = nx_cc; // table entry of mixer_center for this sample, requested one iteration ago
+        {
+            double mcn = mc_ptr, mcs = mc_step;
+            jd_wt_next(mcn, mcs); // where mixer_center will be for the next sample (nothing but WTnextFrame moves it in here)
+            nx_cc = cis[jd_cisidx(mcn)];
+        }
         if (!(i == 0 && skip_a_first))
         {
             const bool fill = (coarse_cnt >= g.Fs_int) || !(flags & JF_CPUREDUCE);
             if (fill)
             {
-                const double2 cc = cis[jd_cisidx(mc_ptr)];
                 bbring[bb_ptr] = make_double2(cc.x * dval, cc.y * dval);
                 bb_ptr = (bb_ptr + 1) & nfft_mask;
             }
@@ -236,6 +242,18 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
             const double pt_re = pt_this * sre + pt_last * sig2l_re;
             const double pt_im = pt_this * sim + pt_last * sig2l_im;
             yui++; yui %= 2;
+            // The four symbol-rate rings are per-channel arrays in HBM: request the entries that leave their windows now, all at
+            // once, so that one miss latency overlaps the tanh / loop-filter arithmetic instead of four serialised ones.
+            double marg_old = 0, pm_old = 0, ms_old = 0;
+            double2 dt_old = make_double2(0.0, 0.0);
+            if (yui)
+            {
+                marg_old = marg_ring[marg_pos];
+                int dn = dt_pos + 1; if (dn >= g.dt_len) dn = 0;
+                dt_old = dt_ring[dn];
+                pm_old = pm_ring[pm_pos];
+                ms_old = msema_ring[msema_pos];
+            }
             if (!yui) { ptd_re = pt_re; ptd_im = pt_im; }
             else
             {
@@ -260,7 +278,7 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
                 // marg->UpdateSigned(ct_ec)
                 {
                     double *mp = marg_ring + marg_pos;
-                    marg_sum = marg_sum - *mp; marg_sum = marg_sum + ct_ec; *mp = ct_ec;
+                    marg_sum = marg_sum - marg_old; marg_sum = marg_sum + ct_ec; *mp = ct_ec;
                     marg_pos++; if (marg_pos >= g.marg_len) marg_pos = 0;
                 }
                 const double marg_val = marg_sum / ((double)g.marg_len);
@@ -268,8 +286,7 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
                 {
                     dt_ring[dt_pos] = make_double2(q_re, q_im);
                     dt_pos++; if (dt_pos >= g.dt_len) dt_pos = 0;
-                    const double2 o = dt_ring[dt_pos];
-                    q_re = o.x; q_im = o.y;
+                    q_re = dt_old.x; q_im = dt_old.y; // = dt_ring[dt_pos]: dt_len > 1, so not the entry just written
                 }
                 {
                     const double cr = cos(marg_val), sr = sin(marg_val);
@@ -281,7 +298,7 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
                 {
                     const double av = hypot(q_re, q_im);
                     double *pp = pm_ring + pm_pos;
-                    pm_sum = pm_sum - *pp; pm_sum = pm_sum + fabs(av); *pp = fabs(av);
+                    pm_sum = pm_sum - pm_old; pm_sum = pm_sum + fabs(av); *pp = fabs(av);
                     pm_pos++; if (pm_pos >= g.pm_len) pm_pos = 0;
                     double mu = pm_sum / ((double)g.pm_len);
                     if (mu < 0.000001) mu = 0.000001;
@@ -290,7 +307,7 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
                     const double tda = (fabs(t_re) - 1.0), tdb = (fabs(t_im) - 1.0);
                     const double e = (tda * tda) + (tdb * tdb);
                     double *ep = msema_ring + msema_pos;
-                    msema_sum = msema_sum - *ep; msema_sum = msema_sum + fabs(e); *ep = fabs(e);
+                    msema_sum = msema_sum - ms_old; msema_sum = msema_sum + fabs(e); *ep = fabs(e);
                     msema_pos++; if (msema_pos >= g.msema_len) msema_pos = 0;
                     mse = msema_sum / ((double)g.msema_len);
                 }
