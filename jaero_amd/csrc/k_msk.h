@@ -181,6 +181,11 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
         double frac;
         if (jd_wt_passed(st_last, st_ptr, st_step, g.ee, frac))
         {
+            // entries leaving the three symbol-rate windows (per-channel arrays in HBM), requested together ahead of their use
+            const double marg_old = marg_ring[marg_pos];
+            int dn = dt_pos + 1; if (dn >= g.dt_len) dn = 0;
+            const double2 dt_old = dt_ring[dn]; // dt_len = SPS/2 + 1 > 1
+            const double ms_old = msema_ring[msema_pos];
             // carrier tracking (:411-426)
             const double ct_xt = tanh(sim) * sre;
             const double ct_xt_d = tanh(ptd.x) * ptd.y;
@@ -197,15 +202,14 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
             {
                 const double v = ct_ec / 2.0;
                 double *mp = marg_ring + marg_pos;
-                marg_sum = marg_sum - *mp; marg_sum = marg_sum + v; *mp = v;
+                marg_sum = marg_sum - marg_old; marg_sum = marg_sum + v; *mp = v;
                 marg_pos++; if (marg_pos >= g.marg_len) marg_pos = 0;
             }
             const double marg_val = marg_sum / ((double)g.marg_len);
             {
                 dt_ring[dt_pos] = make_double2(q_re, q_im);
                 dt_pos++; if (dt_pos >= g.dt_len) dt_pos = 0;
-                const double2 o = dt_ring[dt_pos];
-                q_re = o.x; q_im = o.y;
+                q_re = dt_old.x; q_im = dt_old.y;
             }
             {
                 const double cr = cos(marg_val), sr = sin(marg_val);
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
                 const double tda = (fabs(q_re * 0.75) - 1.0), tdb = (fabs(q_im * 0.75) - 1.0);
                 const double e = (tda * tda) + (tdb * tdb);
                 double *ep = msema_ring + msema_pos;
-                msema_sum = msema_sum - *ep; msema_sum = msema_sum + fabs(e); *ep = fabs(e);
+                msema_sum = msema_sum - ms_old; msema_sum = msema_sum + fabs(e); *ep = fabs(e);
                 msema_pos++; if (msema_pos >= g.msema_len) msema_pos = 0;
                 mse = msema_sum / ((double)g.msema_len);
             }
