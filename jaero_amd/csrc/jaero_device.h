@@ -166,3 +166,10 @@ __device__ __forceinline__ int jd_softbit(double v)
 // date on every sample, but the divide/log10 part is only evaluated over the last JD_EBNO_TAIL samples of a launch -- the value
 // anyone can read after the launch differs from the every-sample evaluation by < 1e-16.
 #define JD_EBNO_TAIL 192
+
+// Matched-filter taps in the constant address space: a uniform read of them compiles to scalar loads (s_load through the scalar
+// cache, SGPR operands of v_fma_f64).  Through the JPtrs pointer the compiler could not prove them invariant and fetched them with
+// per-lane vector loads inside the filter loop (exposed L2 latency five times per sample).  One table per kind/rate: the values are
+// functions of (kind, fb, Fs) only, so banks of one process never disagree about them.
+__constant__ double c_taps_oqpsk[64];     // RRC alpha=1, 55 taps @ 48 kHz / 5250 sym/s (continuous and burst OQPSK)
+__constant__ double c_taps_msk[2][160];   // half-sine, [0] = 1200 bps (80 taps), [1] = 600 bps (160 taps)

@@ -537,6 +537,8 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         std::vector<double> t2(2 * g.fir_n);
         for (int i = 0; i < 2 * g.fir_n; i++) t2[i] = taps[i % g.fir_n];
         HIPCHK(hipMemcpy(d_taps, t2.data(), sizeof(double) * t2.size(), hipMemcpyHostToDevice));
+        if (g.kind == JAERO_KIND_OQPSK) HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_taps_oqpsk), taps.data(), sizeof(double) * taps.size()));
+        else HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_taps_msk), taps.data(), sizeof(double) * taps.size(), (g.fb >= 1200 ? 0 : 1) * 160 * sizeof(double)));
     }
     // scalar state
     {

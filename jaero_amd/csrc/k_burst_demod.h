@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
     double *lre = lds, *lim = lds + FIRN * 64;
     const int lane = threadIdx.x, grp = blockIdx.x, ch = grp * 64 + lane, nchp = g.nchp;
     const double2 *__restrict__ cis = p.cis;
-    const double *__restrict__ taps = p.taps2;
+    const double *taps = c_taps_oqpsk;
     const double SPS = g.SPS, samplerate = g.Fs;
 
     double m2_ptr = BLDF(BS_M2_PTR), m2_step = BLDF(BS_M2_STEP), m2_freq = BLDF(BS_M2_FREQ);
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64) void k_burst_msk_demod(const BGeom g, const BPt
     double *lre = lds, *lim = lds + FIRN * 64;
     const int lane = threadIdx.x, grp = blockIdx.x, ch = grp * 64 + lane, nchp = g.nchp;
     const double2 *__restrict__ cis = p.cis;
-    const double *__restrict__ taps = p.taps2;
+    const double *taps = c_taps_msk[g.fb >= 1200 ? 0 : 1];
     const double SPS = g.SPS, samplerate = g.Fs;
 
     double m2_ptr = BLDF(BS_M2_PTR), m2_step = BLDF(BS_M2_STEP), m2_freq = BLDF(BS_M2_FREQ), mc_freq = BLDF(BS_MC_FREQ);

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
     const int nchp = g.nchp;
     const bool live = ch < g.nch;
     const double2 *__restrict__ cis = p.cis;
-    const double *__restrict__ taps = p.taps2;
+    const double *taps = c_taps_msk[g.fb >= 1200 ? 0 : 1];
 
     double m2_ptr = LDF(S_M2_PTR), m2_step = LDF(S_M2_STEP), m2_freq = LDF(S_M2_FREQ);
     double mc_ptr = LDF(S_MC_PTR), mc_step = LDF(S_MC_STEP);

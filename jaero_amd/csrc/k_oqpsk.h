@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
     const int nchp = g.nchp;
     const bool live = ch < g.nch;
     const double2 *__restrict__ cis = p.cis;
-    const double *__restrict__ taps = p.taps2;
+    const double *taps = c_taps_oqpsk;
 
     // ---- load state ----
     double m2_ptr = LDF(S_M2_PTR), m2_step = LDF(S_M2_STEP), m2_freq = LDF(S_M2_FREQ);
