@@ -105,5 +105,6 @@ struct BPtrs
     double *msema;               // [nchp][msema_len]
     int16_t *soft; double *sym; double *evlog;
     const double2 *cis; const double *taps2; const double *hil_taps; // hil_taps[j] = imag(kernel[2j+1]), j < ntaps/4
-    const double2 *tw14;         // W_16384^k
+    const double2 *tw14;         // W_8192^k (twiddle table of the 2^13-point transforms in k_trident)
+    const double2 *tw15;         // W_32768^n, n < 16384 (pre-twiddle of the odd-bin half transforms in k_trident)
 };

@@ -141,15 +141,15 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
     if (c->tri_grid > nchp) c->tri_grid = nchp;
     DA(c->d_tri_scratch, c->tri_grid);
     {
-        const int E = TRI_H / C2_THREADS;
+        const int E = 8192 / C2_THREADS; // wg_fft<13>
         const int a = E * 528, b = C2_THREADS * (E + 1);
         c->tri_lds = (a > b ? a : b) * (int)sizeof(double);
     }
-    double2 *d_cis = nullptr, *d_tw = nullptr;
+    double2 *d_cis = nullptr, *d_tw = nullptr, *d_tw15 = nullptr;
     double *d_taps = nullptr, *d_hil = nullptr;
-    DA(d_cis, JD_WTSIZE); DA(d_tw, TRI_H); DA(d_taps, 2 * g.fir_n); DA(d_hil, g.hil_ntaps / 4);
+    DA(d_cis, JD_WTSIZE); DA(d_tw, TRI_H); DA(d_tw15, TRI_H); DA(d_taps, 2 * g.fir_n); DA(d_hil, g.hil_ntaps / 4);
 #undef DA
-    p.cis = d_cis; p.tw14 = d_tw; p.taps2 = d_taps; p.hil_taps = d_hil;
+    p.cis = d_cis; p.tw14 = d_tw; p.tw15 = d_tw15; p.taps2 = d_taps; p.hil_taps = d_hil;
     {
         std::vector<double2> cis(JD_WTSIZE);
         for (int i = 0; i < JD_WTSIZE; i++)
@@ -159,8 +159,10 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
         }
         HIPCHK(hipMemcpy(d_cis, cis.data(), sizeof(double2) * JD_WTSIZE, hipMemcpyHostToDevice));
         std::vector<double2> tw(TRI_H);
-        for (int i = 0; i < TRI_H; i++) { double a = -2.0 * M_PI * ((double)i) / ((double)TRI_H); tw[i].x = cos(a); tw[i].y = sin(a); }
-        HIPCHK(hipMemcpy(d_tw, tw.data(), sizeof(double2) * TRI_H, hipMemcpyHostToDevice));
+        for (int i = 0; i < 8192; i++) { double a = -2.0 * M_PI * ((double)i) / 8192.0; tw[i].x = cos(a); tw[i].y = sin(a); }
+        HIPCHK(hipMemcpy(d_tw, tw.data(), sizeof(double2) * 8192, hipMemcpyHostToDevice));
+        for (int i = 0; i < TRI_H; i++) { double a = -2.0 * M_PI * ((double)i) / ((double)TRI_N); tw[i].x = cos(a); tw[i].y = sin(a); }
+        HIPCHK(hipMemcpy(d_tw15, tw.data(), sizeof(double2) * TRI_H, hipMemcpyHostToDevice));
         std::vector<double> taps;
         if (oq) taps = rrc_design(1.0, 55, g.Fs, g.fb / 2.0);
         else
@@ -220,7 +222,7 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
     c->o_nrx = p.I + (size_t)BI_NRX * nchp;
     c->m.nch = nch; c->m.nchp = nchp;
     c->m.flags.assign(nchp, 0);
-    const int lds = 2 * g.fir_n * 64 * (int)sizeof(double);
+    const int lds = 2 * (oq ? 40 : g.fir_n) * 64 * (int)sizeof(double); // burst OQPSK keeps 40 of its 55 history slots in LDS
     if (oq)
     {
         HIPCHK(hipFuncSetAttribute((const void *)k_burst_oqpsk_demod<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -258,7 +260,7 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
         prof_end(c, pi, st);
     }
     const bool cs = (c->flags & JAERO_FLAG_CAPTURE_SYMBOLS) != 0;
-    const int lds = 2 * g.fir_n * 64 * (int)sizeof(double);
+    const int lds = 2 * (g.kind == JAERO_KIND_BURST_OQPSK ? 40 : g.fir_n) * 64 * (int)sizeof(double);
     int first = 1;
     for (int pos = 0; pos < nsamples;)
     {

@@ -33,9 +33,12 @@ __device__ __forceinline__ void bd_cmul(double &ar, double &ai, double br, doubl
 template <bool CAPSYM>
 __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const BPtrs p, int n, long long n0, int first_of_write)
 {
-    constexpr int FIRN = 55;
+    // matched-filter history as in k_oqpsk.h: the LDSN newest entries of each arm in LDS ([slot][lane]), the FIRN-LDSN oldest in a
+    // VGPR shift register -> 40 KiB of LDS per wavefront, four wavefronts per CU
+    constexpr int FIRN = 55, LDSN = 40, TAILN = FIRN - LDSN;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *lre = lds, *lim = lds + FIRN * 64;
+    double *lre = lds, *lim = lds + LDSN * 64;
+    double tre[TAILN], tim[TAILN];
     const int lane = threadIdx.x, grp = blockIdx.x, ch = grp * 64 + lane, nchp = g.nchp;
     const double2 *__restrict__ cis = p.cis;
     const double *taps = c_taps_oqpsk;
@@ -72,16 +75,30 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
 
     {
         const double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
-        for (int k = 0; k < FIRN; k++) { lre[k * 64 + lane] = fs[(size_t)k * 64]; lim[k * 64 + lane] = fs[(size_t)(FIRN + k) * 64]; }
+        for (int k = 0; k < LDSN; k++) { lre[k * 64 + lane] = fs[(size_t)k * 64]; lim[k * 64 + lane] = fs[(size_t)(FIRN + k) * 64]; }
+#pragma unroll
+        for (int j = 0; j < TAILN; j++) { tre[j] = fs[(size_t)(LDSN + j) * 64]; tim[j] = fs[(size_t)(FIRN + LDSN + j) * 64]; }
     }
-    int fir_slot = (int)(n0 % FIRN), s_agc2 = (int)(n0 % g.agc2_len), s_eb = (int)(n0 % g.eb_len);
+    int fir_slot = (int)(n0 % LDSN), s_agc2 = (int)(n0 % g.agc2_len), s_eb = (int)(n0 % g.eb_len);
     int s_val = (int)((n0 - g.D1 - g.D2 + 8LL * g.cv_len) % g.cv_len);
     const double w4 = g.w4, w4c = 1.0 - g.w4, w8 = g.w8, w8c = 1.0 - g.w8, a1w = g.a1_w, a1wc = 1.0 - g.a1_w;
     const double agc2_len_d = (double)g.agc2_len, eb_len_d = (double)g.eb_len;
 
+    // ring entries of sample i+1 are requested at the top of iteration i (all slots are wave-uniform and data independent)
+    double nx_val = cvre[(size_t)s_val * 64], nx_agc2 = agc2_ring[(size_t)s_agc2 * 64];
+    double nx_e = ebe_ring[(size_t)s_eb * 64], nx_e2 = ebe2_ring[(size_t)s_eb * 64];
     for (int i = 0; i < n; i++)
     {
         const long long sample = n0 + i;
+        const double val = nx_val, agc2_old = nx_agc2, e_old = nx_e, e2_old = nx_e2;
+        if (i + 1 < n)
+        {
+            int sv = s_val + 1; if (sv >= g.cv_len) sv = 0;
+            int sa = s_agc2 + 1; if (sa >= g.agc2_len) sa = 0;
+            int se = s_eb + 1; if (se >= g.eb_len) se = 0;
+            nx_val = cvre[(size_t)sv * 64]; nx_agc2 = agc2_ring[(size_t)sa * 64];
+            nx_e = ebe_ring[(size_t)se * 64]; nx_e2 = ebe2_ring[(size_t)se * 64];
+        }
         // ---- trident verdict for this sample (:488-515) ----
         if (i == ev_pos)
         {
@@ -109,23 +126,34 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
             }
         }
         // ---- mix + rrc (:517-521) ----
-        const double val = cvre[(size_t)s_val * 64];
         const double2 c2 = cis[jd_cisidx(m2_ptr)];
         const double xin = (vol_gain * val);
         const double cre = c2.x * xin, cim = c2.y * xin;
         double sre = 0, sim = 0;
         {
-            int slot = fir_slot;
-#pragma unroll 5
-            for (int t = 0; t < FIRN; t++)
+            // output from x[n-FIRN .. n-1] (FIR::FIRUpdateAndProcess excludes the sample being pushed): taps[i] <-> x[n-FIRN+i]
+#pragma unroll
+            for (int j = TAILN - 1; j >= 0; j--)
             {
-                const double tp = taps[t];
+                const double tp = taps[TAILN - 1 - j];
+                sre = fma(tp, tre[j], sre);
+                sim = fma(tp, tim[j], sim);
+            }
+            int slot = fir_slot;
+#pragma unroll 8
+            for (int k = 0; k < LDSN; k++)
+            {
+                const double tp = taps[TAILN + k];
                 sre = fma(tp, lre[slot * 64 + lane], sre);
                 sim = fma(tp, lim[slot * 64 + lane], sim);
-                slot++; if (slot >= FIRN) slot = 0;
+                slot++; if (slot >= LDSN) slot = 0;
             }
+            // push x[n]: the oldest LDS entry moves into the register tail
+#pragma unroll
+            for (int j = TAILN - 1; j > 0; j--) { tre[j] = tre[j - 1]; tim[j] = tim[j - 1]; }
+            tre[0] = lre[fir_slot * 64 + lane]; tim[0] = lim[fir_slot * 64 + lane];
             lre[fir_slot * 64 + lane] = cre; lim[fir_slot * 64 + lane] = cim;
-            fir_slot++; if (fir_slot >= FIRN) fir_slot = 0;
+            fir_slot++; if (fir_slot >= LDSN) fir_slot = 0;
         }
         // ---- sample counting and signal time-out (:523-544) ----
         if (startstop > 0)
@@ -175,25 +203,31 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
         {
             const double sq = sig2abs * sig2abs;
             double *e2p = ebe2_ring + (size_t)s_eb * 64, *ep = ebe_ring + (size_t)s_eb * 64;
-            eb_e2sum = eb_e2sum - *e2p; eb_e2sum = eb_e2sum + fabs(sq); *e2p = fabs(sq);
-            eb_esum = eb_esum - *ep; eb_esum = eb_esum + fabs(sig2abs); *ep = fabs(sig2abs);
+            eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq); *e2p = fabs(sq);
+            eb_esum = eb_esum - e_old; eb_esum = eb_esum + fabs(sig2abs); *ep = fabs(sig2abs);
             s_eb++; if (s_eb >= g.eb_len) s_eb = 0;
-            const double e2val = eb_e2sum / eb_len_d, mean = eb_esum / eb_len_d;
-            const double meansq = mean * mean;
-            double var = e2val - (mean * mean);
-            var -= (0.024709 * meansq);
-            double mvr = (((g.Fs * meansq / (2.0 * g.fb * var))) * 0.13743);
-            if (mvr < 0.000000001) mvr = 0.000000001;
-            double tebno = 10.0 * log10(mvr);
-            if (isnan(tebno)) tebno = 50;
-            if (tebno > 50.0) tebno = 50;
-            if (tebno < 0.0) tebno = 0;
-            eb_ebno = eb_ebno * 0.8 + 0.2 * tebno;
+            // The meter's value is observable at the end of a launch (status) and once per burst, at cntr == 384 symbols (:581); its
+            // IIR forgets a term after k samples as 0.8^k, so the divide/log10 runs only in the JD_EBNO_TAIL samples before either.
+            const double to_emit = ((128.0 + 128.0 + 128.0) * SPS) - (double)cntr;
+            if (i >= n - JD_EBNO_TAIL || (to_emit > -1.0 && to_emit < (double)JD_EBNO_TAIL))
+            {
+                const double e2val = eb_e2sum / eb_len_d, mean = eb_esum / eb_len_d;
+                const double meansq = mean * mean;
+                double var = e2val - (mean * mean);
+                var -= (0.024709 * meansq);
+                double mvr = (((g.Fs * meansq / (2.0 * g.fb * var))) * 0.13743);
+                if (mvr < 0.000000001) mvr = 0.000000001;
+                double tebno = 10.0 * log10(mvr);
+                if (isnan(tebno)) tebno = 50;
+                if (tebno > 50.0) tebno = 50;
+                if (tebno < 0.0) tebno = 0;
+                eb_ebno = eb_ebno * 0.8 + 0.2 * tebno;
+            }
         }
         if (fabs(cntr - ((128.0 + 128.0 + 128.0) * SPS)) < 0.5) bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_EBNO, eb_ebno);
         {
             double *ap = agc2_ring + (size_t)s_agc2 * 64;
-            agc2_sum = agc2_sum - *ap; agc2_sum = agc2_sum + fabs(sig2abs); *ap = fabs(sig2abs);
+            agc2_sum = agc2_sum - agc2_old; agc2_sum = agc2_sum + fabs(sig2abs); *ap = fabs(sig2abs);
             s_agc2++; if (s_agc2 >= g.agc2_len) s_agc2 = 0;
             double gain = 1.414213562 / fmax(agc2_sum / agc2_len_d, 0.000001);
             gain = fmax(gain, 0.000001);
@@ -315,7 +349,9 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
     BLDI(BI_SOFT_CNT) = soft_cnt; BLDI(BI_SYM_CNT) = sym_cnt; BLDI(BI_EV_CNT) = ev_cnt; BLDI(BI_OVERFLOW) = overflow;
     {
         double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
-        for (int k = 0; k < FIRN; k++) { fs[(size_t)k * 64] = lre[k * 64 + lane]; fs[(size_t)(FIRN + k) * 64] = lim[k * 64 + lane]; }
+        for (int k = 0; k < LDSN; k++) { fs[(size_t)k * 64] = lre[k * 64 + lane]; fs[(size_t)(FIRN + k) * 64] = lim[k * 64 + lane]; }
+#pragma unroll
+        for (int j = 0; j < TAILN; j++) { fs[(size_t)(LDSN + j) * 64] = tre[j]; fs[(size_t)(FIRN + LDSN + j) * 64] = tim[j]; }
     }
 }
 

@@ -289,31 +289,48 @@ __global__ __launch_bounds__(C2_THREADS) void k_trident(const BGeom g, const BPt
         // window: cval_d[e - tri_sz + k] = cv[e - tri_sz - D1 + k], e = n0 + evp
         const long long w0 = n0 + evp - g.tri_sz - g.D1 + 8LL * g.cv_len;
         const double *__restrict__ cvre = p.cvre + (size_t)grp * g.cv_len * 64 + lane;
-        for (int pass = 0; pass < 4; pass++)
+        // X[4q + r] = sum_{n<8192} (x[n] + x[n+8192] (-j)^r) W_32768^(n r) W_8192^(n q): four 2^13-point transforms per window (the
+        // windows are <= 2^14 samples followed by zeros).  2^13 points over 512 threads = 16 per thread: wg_fft<13> runs without
+        // spilling, unlike the 32-points-per-thread 2^14 transform.  Only bins below N/2 are needed: q < 4096 (slots s < 8).
+        for (int pass = 0; pass < 8; pass++)
         {
-            const int which = pass >> 1, r = pass & 1; // which: 0 base, 1 top
+            const int which = pass >> 2, r = pass & 3; // which: 0 base, 1 top
             const int off = which ? g.nb : 0, len = which ? g.nt : g.nb;
-            CV<32> d;
-#pragma unroll
-            for (int s = 0; s < 32; s++)
-            {
-                const int n = s * C2_THREADS + t;
-                double x = 0.0;
-                if (n < len && off + n < g.tri_sz) x = cvre[(size_t)((w0 + off + n) % g.cv_len) * 64];
-                if (r == 0) { d.r[s] = x; d.i[s] = 0.0; }
-                else
-                {
-                    double sn, cs;
-                    sincospi(((double)n) / ((double)TRI_H), &sn, &cs); // W_32768^n = exp(-j pi n / 16384)
-                    d.r[s] = x * cs; d.i[s] = -x * sn;
-                }
-            }
-            wg_fft<14>(d, xch, p.tw14, t);
-            // thread t slot s holds X_r[q = s*512 + t] = X[2q + r]; bins below TRI_H <=> s < 16
+            CV<16> d;
+            const int slot0 = (int)((w0 + off) % g.cv_len); // wave-uniform; off + len <= tri_sz < cv_len: at most one wrap below
 #pragma unroll
             for (int s = 0; s < 16; s++)
             {
-                const int k = 2 * (s * C2_THREADS + t) + r;
+                const int n = s * C2_THREADS + t;
+                double x0 = 0.0, x1 = 0.0;
+                if (s * C2_THREADS < len && n < len)
+                {
+                    int sl = slot0 + n; if (sl >= g.cv_len) sl -= g.cv_len;
+                    x0 = cvre[(size_t)sl * 64];
+                }
+                if (len > 8192 && n + 8192 < len) // burst MSK 600: the 12000-sample base window folds once
+                {
+                    int sl = slot0 + n + 8192; while (sl >= g.cv_len) sl -= g.cv_len;
+                    x1 = cvre[(size_t)sl * 64];
+                }
+                // (x0 + x1 (-j)^r) W_32768^(n r)
+                double fr = x0, fi = 0.0;
+                if (r == 0) fr += x1; else if (r == 1) fi -= x1; else if (r == 2) fr -= x1; else fi += x1;
+                if (r == 0) { d.r[s] = fr; d.i[s] = fi; }
+                else
+                {
+                    const int m = n * r;                          // < 3 * 8192
+                    double2 w = p.tw15[m & (TRI_H - 1)];          // W_32768^m for m < 16384; W^(m+16384) = -W^m
+                    if (m & TRI_H) { w.x = -w.x; w.y = -w.y; }
+                    d.r[s] = fr * w.x - fi * w.y; d.i[s] = fr * w.y + fi * w.x;
+                }
+            }
+            wg_fft<13>(d, xch, p.tw14, t);
+            // thread t slot s holds X[4 (s*512 + t) + r]
+#pragma unroll
+            for (int s = 0; s < 8; s++)
+            {
+                const int k = 4 * (s * C2_THREADS + t) + r;
                 if (which == 0) sc->base[k] = make_double2(d.r[s], d.i[s]);
                 else
                 {
