@@ -200,7 +200,7 @@ def main():
         bank = DemodulatorBank(BurstOqpskSettings(), nch, device=local, max_write_samples=chunk, softbit_capacity=soft_cap)
     else:
         pcm, bits, _ = signalgen.oqpsk_torch(nch, nsamp, dev, ebno_db=ARGS.ebno_db, seed=signalgen.SEED_BASE + lo)
-        bank = DemodulatorBank(OqpskSettings(), nch, device=local, ebno=bool(ARGS.ebno), max_write_samples=chunk, softbit_capacity=soft_cap)
+        bank = DemodulatorBank(OqpskSettings(coarsefreqest_fft_power=int(os.environ.get('JAERO_BENCH_FFT_POWER', '14'))), nch, device=local, ebno=bool(ARGS.ebno), max_write_samples=chunk, softbit_capacity=soft_cap)
     bank.set_flags(afc=False, sql=False, cpu_reduce=False)
     stream = torch.cuda.current_stream().cuda_stream
 

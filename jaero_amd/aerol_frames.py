@@ -1,0 +1,137 @@
+"""Synthetic Aero-L P-channel frames (the inverse of the reference's AeroL::Decode continuous path), for tests and benches.
+
+The reference only decodes; this builds what it expects to see, from the decoder's own constants:
+  * signal units: 12 bytes = 10 payload + CRC-16 (AeroLcrc16::calcusingbytes, poly 0x8408 reflected, init 0xFFFF, inverted; low
+    byte first) -- JAERO/aerol.h:283-392, JAERO/aerol.cpp:1586-1589
+  * information field bits LSB first per byte (aerol.cpp:1566-1578), XOR the 15-bit LFSR sequence restarted every frame
+    (AeroLScrambler, aerol.h:394-440)
+  * K=7 rate-1/2 convolutional code {109, 79}, newest bit in the LSB of the shift register, polynomial 0 sent first
+    (libcorrect as JConvolutionalCodec uses it, aerol.cpp:936-940), run continuously over the frames
+  * 64 x N block interleaver with row permutation (i*27)%64, N = 6 / 9 / 78 for 600 / 1200 / 10500 bps
+    (AeroLInterleaver, aerol.cpp:523-625, 1013-1052)
+  * frame = unique word 0xE15AE893 (on each of the I and Q arms for 10500: 64 channel bits) + 16 header bits
+    (format id, super-frame marker, frame counter twice; aerol.cpp:1292-1296) + 178 dummy bits (10500 only) + coded bits:
+    1200 channel bits (600/1200 bps) or 5250 (10500 bps).
+The decoder's Viterbi (6 bits) + delay line make the signal units of frame f appear while frame f+1 (600/1200) or f+2 (10500) is
+being received (aerol.cpp:1557-1560).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+UW = 0xE15AE893
+POLYS = (109, 79)
+
+
+def crc16(data: bytes) -> int:
+    crc = 0xFFFF
+    for byte in data:
+        for k in range(8):
+            bit = (byte >> k) & 1
+            c = crc & 1
+            crc >>= 1
+            if c ^ bit:
+                crc ^= 0x8408
+    return (~crc) & 0xFFFF
+
+
+def make_su(payload10: bytes) -> bytes:
+    assert len(payload10) == 10
+    c = crc16(payload10)
+    return bytes(payload10) + bytes([c & 0xFF, c >> 8])
+
+
+def scrambler_sequence(n: int = 5000) -> np.ndarray:
+    state = [1, 1, 0, 1, 0, 0, 1, 0, 1, 0, 1, 1, 0, 0, 1]
+    out = np.zeros(n, dtype=np.uint8)
+    for a in range(n):
+        v = state[0] ^ state[14]
+        out[a] = v
+        state = [v] + state[:-1]
+    return out
+
+
+def conv_encode(bits: np.ndarray) -> np.ndarray:
+    """Continuous K=7 r=1/2 encode of a 0/1 array (no tail); returns 2*len coded bits."""
+    par = np.array([bin(i).count("1") & 1 for i in range(128)], dtype=np.uint8)
+    out = np.zeros(2 * len(bits), dtype=np.uint8)
+    sr = 0
+    for i, b in enumerate(bits):
+        sr = ((sr << 1) | int(b)) & 127
+        out[2 * i] = par[sr & POLYS[0]]
+        out[2 * i + 1] = par[sr & POLYS[1]]
+    return out
+
+
+def interleave(coded: np.ndarray, ncols: int) -> np.ndarray:
+    """One 64 x ncols block: the decoder reads deinterleaved[j*64+i] = received[((i*27)%64)*ncols + j]."""
+    assert len(coded) == 64 * ncols
+    rx = np.zeros_like(coded)
+    i = np.arange(64)
+    for j in range(ncols):
+        rx[((i * 27) % 64) * ncols + j] = coded[j * 64 + i]
+    return rx
+
+
+def geometry(fb: int):
+    if fb == 10500:
+        return dict(ncols=78, header=16, dummy=178, nbits=4992, uw=64, blocks=1, oqpsk=True, delay_frames=2)
+    if fb in (600, 1200):
+        n = 6 if fb == 600 else 9
+        return dict(ncols=n, header=16, dummy=0, nbits=1152, uw=32, blocks=1152 // (64 * n), oqpsk=False, delay_frames=1)
+    raise ValueError(fb)
+
+
+def p_channel_bits(frames_payload, fb: int = 10500, *, first_counter: int = 0, invert_i: bool = False, invert_q: bool = False):
+    """frames_payload: list (per frame) of lists of 10-byte payloads (26 signal units per frame at 10500, 6 at 600/1200;
+    missing ones are filled with all-zero units, which the decoder accepts).  Returns (channel bits uint8, frame length)."""
+    g = geometry(fb)
+    nsu = g["nbits"] // 2 // 8 // 12
+    scr = scrambler_sequence()
+    msg = []
+    for pay in frames_payload:
+        sus = [make_su(p) for p in pay] + [bytes(12)] * (nsu - len(pay))
+        info = b"".join(sus[:nsu])
+        b = np.unpackbits(np.frombuffer(info, dtype=np.uint8), bitorder="little")
+        msg.append(b ^ scr[: len(b)])
+    coded = conv_encode(np.concatenate(msg))
+    uwbits = np.array([(UW >> (31 - k)) & 1 for k in range(32)], dtype=np.uint8)
+    out = []
+    per_frame = g["nbits"]
+    blk = 64 * g["ncols"]
+    for f in range(len(frames_payload)):
+        fc = (first_counter + f) & 15
+        hdr_val = (1 << 12) | (0 << 8) | (fc << 4) | fc  # format id 1, super-frame marker 0, frame counter twice
+        hdr = np.array([(hdr_val >> (15 - k)) & 1 for k in range(16)], dtype=np.uint8)
+        body = coded[f * per_frame:(f + 1) * per_frame]
+        body = np.concatenate([interleave(body[k * blk:(k + 1) * blk], g["ncols"]) for k in range(per_frame // blk)])
+        if g["oqpsk"]:
+            uw = np.repeat(uwbits, 2)  # the same 32 bits on the imag (even positions) and real (odd positions) arms
+            fr = np.concatenate([uw, hdr, np.zeros(g["dummy"], np.uint8), body])
+        else:
+            fr = np.concatenate([uwbits, hdr, body])
+        out.append(fr)
+    bits = np.concatenate(out)
+    if g["oqpsk"] and (invert_i or invert_q):
+        bits = bits.copy()
+        if invert_i:
+            bits[0::2] ^= 1
+        if invert_q:
+            bits[1::2] ^= 1
+    return bits, len(out[0])
+
+
+def to_soft(bits: np.ndarray, *, sigma: float = 0.0, seed: int = 0) -> np.ndarray:
+    """Channel bits -> soft bits as the demodulators emit them (int16 0..255, 128 = erasure): 0 -> ~53, 1 -> ~203 plus noise."""
+    rng = np.random.default_rng(seed)
+    x = (bits.astype(np.float64) * 2 - 1) * 75.0 + 128.0
+    if sigma > 0:
+        x = x + rng.normal(0.0, sigma, size=x.shape)
+    return np.clip(np.round(x), 0, 255).astype(np.int16)
+
+
+def random_payloads(nframes: int, fb: int, seed: int = 0):
+    g = geometry(fb)
+    nsu = g["nbits"] // 2 // 8 // 12
+    rng = np.random.default_rng(seed)
+    return [[bytes(rng.integers(0, 256, size=10, dtype=np.uint8)) for _ in range(nsu)] for _ in range(nframes)]

@@ -11,6 +11,10 @@
 //       same outputs; the soft stream keeps the -1 start-of-burst markers; one status row per SignalStatus emission,
 //       plus <outprefix>.events float64 rows [sample index of the write that carried it, kind, value]:
 //       kind 0 = SignalStatus(value), 1 = EbNoMeasurmentSignal(value), 2 = Plottables freq_est
+//   jaero_ref aerol <in.s16 soft bits> <out.txt> fb=10500|1200|600 [group=32] [burst=0]
+//       the UNMODIFIED AeroL (JAERO/aerol.cpp): soft bits are handed to processDemodulatedSoftBits in groups, what it writes to its
+//       sink device (signal-unit dumps, "Bad CRC", ...) goes to <out.txt>; DataCarrierDetect emissions are interleaved as
+//       lines "#DCD <0|1> <index of the first soft bit of the group that carried it>"
 //   jaero_ref viterbi_cont <in.u8> <out.u8> blocklen=N [padding=24]
 //       JConvolutionalCodec::Decode_Continuous per block of N soft bytes (code 2,7,{109,79} as AeroL, aerol.cpp:936-940)
 //   jaero_ref viterbi_soft <in.u8> <out.u8> blocklen=N
@@ -37,6 +41,8 @@
 #include "fftwrapper.h"
 #include "fftrwrapper.h"
 #include "jconvolutionalcodec.h"
+#include "aerol.h"
+#include <QBuffer>
 
 static QMap<QString, QString> kv;
 static double getd(const char *k, double def) { return kv.contains(k) ? kv[k].toDouble() : def; }
@@ -229,6 +235,31 @@ int main(int argc, char **argv)
         if (mode == "burstoqpsk") run_burstoqpsk(pcm, c); else run_burstmsk(pcm, c);
         writeall(QString(argv[3]) + ".soft", c.soft.data(), c.soft.size() * sizeof(short));
         writeall(QString(argv[3]) + ".events", c.status.data(), c.status.size() * sizeof(double));
+        return 0;
+    }
+    if (mode == "aerol")
+    {
+        QByteArray in = readall(argv[2]);
+        const short *sp = (const short *)in.constData();
+        long n = in.size() / 2;
+        AeroL a(0);
+        QBuffer sink;
+        sink.open(QIODevice::ReadWrite);
+        a.ConnectSinkDevice(&sink);
+        long gstart = 0;
+        QByteArray dcdlog;
+        QObject::connect(&a, &AeroL::DataCarrierDetect, [&](bool d) { sink.write(QString("#DCD %1 %2\n").arg(d ? 1 : 0).arg(gstart).toLatin1()); });
+        a.setSettings(getd("fb", 10500), geti("burst", 0) != 0);
+        int group = geti("group", 32);
+        for (long s = 0; s < n; s += group)
+        {
+            long m = (s + group <= n) ? group : n - s;
+            QVector<short> v(m);
+            for (long i = 0; i < m; i++) v[i] = sp[s + i];
+            gstart = s;
+            a.processDemodulatedSoftBits(v);
+        }
+        writeall(argv[3], sink.data().constData(), sink.data().size());
         return 0;
     }
     if (mode == "time")
