@@ -166,6 +166,27 @@ int jaero_viterbi_decode_soft(int device, const uint8_t *soft, int nblocks, int 
 int jaero_viterbi_continuous(int device, const uint8_t *soft, int nstreams, int nsoft, int paddinglength,
                              uint8_t *overlap_state, uint8_t *bits_out, int *nbits_out, int is_device_ptr, void *stream);
 
+/* ---- Aero-L bit pipeline around the Viterbi (continuous P-channel path of AeroL::Decode, JAERO/aerol.cpp:1124-2039) ----
+ * A jaero_aerol_ctx is a bank of nchannels AeroL objects in non-burst mode at one bit rate (600 / 1200 / 10500):
+ *   AeroL(parent) + setSettings(fb,false)   JAERO/aerol.cpp:904-977,990-1072      jaero_aerol_create
+ *   processDemodulatedSoftBits(QVector<short>)  JAERO/aerol.cpp:2077-2099         jaero_aerol_write (all channels at once; the soft
+ *                                               bits can stay on the device: pass jaero_softbits_view's pointers, is_device_ptr = 1)
+ *   the signal units Decode() checks and prints  JAERO/aerol.cpp:1583-1600          jaero_aerol_read_sus: rows of 16 int32
+ *                                               [frame number, unit index k, 12 bytes (10 payload + CRC), crc_ok, frame-info word]
+ *   DataCarrierDetect(bool) and the "Error short frame" notice  :1593-1596,1995-2010   jaero_aerol_read_events: rows of 3 int64
+ *                                               [soft-bit index, kind (0 = DCD, 1 = short frame (value = its length), 2 = unique word), value]
+ *   updateDCD() from the 1 s QTimer            JAERO/aerol.cpp:1109-1122          jaero_aerol_tick_dcd (call once per second of signal)
+ * What follows a CRC-clean signal unit in the reference (message names, ISU / ACARS reassembly, plane database) is text and control
+ * plane and stays with the caller. */
+typedef struct jaero_aerol_ctx jaero_aerol_ctx;
+int jaero_aerol_create(int device, int nchannels, int fb, int max_softbits_per_write, int su_capacity, jaero_aerol_ctx **out);
+void jaero_aerol_destroy(jaero_aerol_ctx *ctx);
+/* soft[ch * stride + k], k < counts[ch] <= max_count <= stride; host pointers (copied) or device pointers */
+int jaero_aerol_write(jaero_aerol_ctx *ctx, const int16_t *soft, const int *counts, int stride, int max_count, int is_device_ptr, void *stream);
+int jaero_aerol_read_sus(jaero_aerol_ctx *ctx, int channel, int32_t *rows, int caprows, int *nrows);
+int jaero_aerol_read_events(jaero_aerol_ctx *ctx, int channel, long long *rows, int caprows, int *nrows);
+int jaero_aerol_tick_dcd(jaero_aerol_ctx *ctx, int *dcd_out /* optional [nchannels] */);
+
 /* Host-only debugging aid (no device needed): the sample indices at which jaero_write would run the coarse-frequency
  * estimate for a fresh channel fed `nwrites` writes of write_sizes[i] samples.  Returns the number of triggers
  * (>= 0; up to `cap` are stored) or a negative error. */

@@ -25,6 +25,8 @@ EXPORTS = [
     "jaero_read_symbols", "jaero_viterbi_decode_soft", "jaero_viterbi_continuous", "jaero_abi_version",
     "jaero_num_channels", "jaero_strerror", "jaero_last_error", "jaero_profile_enable", "jaero_profile_read",
     "jaero_debug_schedule", "jaero_read_events",
+    "jaero_aerol_create", "jaero_aerol_destroy", "jaero_aerol_write", "jaero_aerol_read_sus", "jaero_aerol_read_events",
+    "jaero_aerol_tick_dcd",
 ]
 
 
@@ -107,6 +109,13 @@ def lib():
     L.jaero_profile_enable.argtypes = [vp, ip]
     L.jaero_profile_read.argtypes = [vp, ip, C.POINTER(dp), C.POINTER(ip), ip]
     L.jaero_debug_schedule.argtypes = [ip, ip, ip, vp, ip, vp, ip, C.POINTER(ip)]
+    L.jaero_aerol_create.argtypes = [ip, ip, ip, ip, ip, C.POINTER(vp)]
+    L.jaero_aerol_destroy.argtypes = [vp]
+    L.jaero_aerol_destroy.restype = None
+    L.jaero_aerol_write.argtypes = [vp, vp, vp, ip, ip, ip, vp]
+    L.jaero_aerol_read_sus.argtypes = [vp, ip, vp, ip, C.POINTER(ip)]
+    L.jaero_aerol_read_events.argtypes = [vp, ip, vp, ip, C.POINTER(ip)]
+    L.jaero_aerol_tick_dcd.argtypes = [vp, vp]
     for name in EXPORTS:
         getattr(L, name)  # raises AttributeError if a declared symbol is not exported
     _lib = L

@@ -26,6 +26,7 @@
 #include "burst_device.h"
 #include "k_burst_front.h"
 #include "k_burst_demod.h"
+#include "k_aerol.h"
 
 static thread_local std::string g_last_error;
 static int fail(int code, const char *fmt, ...)
@@ -1054,11 +1055,13 @@ extern "C" int jaero_viterbi_decode_soft(int device, const uint8_t *soft, int nb
     return viterbi_run(device, soft, nblocks, nsoft, 0, nullptr, bits_out, nsoft / 2, 0, nsoft / 2, is_device_ptr, (hipStream_t)stream);
 }
 
-__global__ void k_viterbi_overlap_update(const uint8_t *__restrict__ soft, int nsoft, uint8_t *__restrict__ overlap, int nstreams)
+__global__ void k_viterbi_overlap_update(const uint8_t *__restrict__ soft, int nsoft, uint8_t *__restrict__ overlap, int nstreams,
+                                         const int *__restrict__ valid = nullptr)
 {
     // soft_bits_overlap_buffer_uchar = soft_bits_in.right(62); resize(62)  (jconvolutionalcodec.cpp:197-198)
     const int b = blockIdx.x;
     if (b >= nstreams) return;
+    if (valid && !valid[b]) return;
     const int k = 62;
     const int t = threadIdx.x;
     if (t < k)
@@ -1117,3 +1120,5 @@ extern "C" int jaero_viterbi_continuous(int device, const uint8_t *soft, int nst
     }
     return 0;
 }
+
+#include "aerol_host.h"

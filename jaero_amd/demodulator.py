@@ -381,3 +381,57 @@ class BurstMskDemodulator(_SingleChannelBurstDemodulator):
 
     Settings = BurstMskSettings
     _group = 12
+
+
+class AeroLBank:
+    """A bank of AeroL bit pipelines (continuous P-channel path of JAERO/aerol.cpp AeroL::Decode): soft bits in, CRC-checked
+    12-byte signal units out.  Thin wrapper over jaero_aerol_ctx."""
+
+    def __init__(self, nchannels: int, fb: int, device: int = 0, max_softbits_per_write: int = 1 << 16, su_capacity: int = 0):
+        self.L = capi.lib()
+        h = C.c_void_p()
+        capi.check(self.L.jaero_aerol_create(device, nchannels, int(fb), max_softbits_per_write, su_capacity, C.byref(h)))
+        self.h, self.nch, self.fb = h, nchannels, int(fb)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.jaero_aerol_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def write(self, soft: np.ndarray, counts=None, stream: int = 0):
+        """soft: int16 [nch, n] (host); counts: per-channel number of valid soft bits (default: all n)."""
+        a = np.ascontiguousarray(soft, dtype=np.int16)
+        if a.ndim == 1:
+            a = a.reshape(1, -1)
+        assert a.shape[0] == self.nch
+        cnt = np.full(self.nch, a.shape[1], dtype=np.int32) if counts is None else np.ascontiguousarray(counts, dtype=np.int32)
+        capi.check(self.L.jaero_aerol_write(self.h, a.ctypes.data, cnt.ctypes.data, a.shape[1], int(cnt.max(initial=0)), 0, stream))
+
+    def write_from_bank(self, bank: "DemodulatorBank", max_count: int, stream: int = 0):
+        """Zero-copy: consume what a continuous DemodulatorBank has produced since its last discard (device to device)."""
+        ptr, cnt, cap = bank.softbits_view()
+        capi.check(self.L.jaero_aerol_write(self.h, ptr, cnt, cap, min(max_count, cap), 1, stream))
+        bank.discard_softbits(stream)
+
+    def read_sus(self, channel: int, caprows: int = 4096) -> np.ndarray:
+        buf = np.empty((caprows, 16), dtype=np.int32)
+        n = C.c_int(0)
+        capi.check(self.L.jaero_aerol_read_sus(self.h, channel, buf.ctypes.data, caprows, C.byref(n)))
+        return buf[: n.value].copy()
+
+    def read_events(self, channel: int, caprows: int = 256) -> np.ndarray:
+        buf = np.empty((caprows, 3), dtype=np.int64)
+        n = C.c_int(0)
+        capi.check(self.L.jaero_aerol_read_events(self.h, channel, buf.ctypes.data, caprows, C.byref(n)))
+        return buf[: n.value].copy()
+
+    def tick_dcd(self) -> np.ndarray:
+        out = np.zeros(self.nch, dtype=np.int32)
+        capi.check(self.L.jaero_aerol_tick_dcd(self.h, out.ctypes.data))
+        return out

@@ -1,0 +1,278 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C restatement of the continuous (P-channel, non-burst) path of AeroL::Decode(bits, soft=true)
+ * (JAERO/aerol.cpp:1124-2039) for 600 / 1200 / 10500 bps, with the pieces it is made of:
+ *   PreambleDetector / PreambleDetectorPhaseInvariant   JAERO/aerol.cpp:717-809
+ *   AeroLInterleaver::deinterleave_ba                    JAERO/aerol.cpp:603-625
+ *   JConvolutionalCodec::Decode_Continuous               JAERO/jconvolutionalcodec.cpp:151-201 (viterbi_oracle.c)
+ *   DelayLine, AeroLScrambler, AeroLcrc16                JAERO/aerol.h:453-481,394-440,283-392
+ *   setSettings constants                                JAERO/aerol.cpp:990-1072
+ * Everything after the CRC check of a signal unit (message-type names, ISU/ACARS reassembly, plane database) is text
+ * formatting / control plane and is not restated; the data-carrier-detect bookkeeping that feeds back into the unique-word
+ * gating (datacd, datacdcountdown) is.  The reference also lowers datacdcountdown from a 1 s wall-clock QTimer
+ * (AeroL::updateDCD, aerol.cpp:1109-1122); a batch run has no event loop, so neither this file nor the _ref driver ticks it.
+ * Members the reference never initialises (realimag, muw, lastframeinfo: aerol.h:956,975,990) start at 0, as in the _ref
+ * driver's zeroed storage.  Pinned against the unmodified AeroL built into oracle/_ref (tests/test_aerol_oracle.py).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include "aerol_oracle.h"
+#include "viterbi_oracle.h"
+
+typedef struct { char *p; size_t len, cap; } gb;
+static void gb_push(gb *g, const void *src, size_t n)
+{
+    if (g->len + n > g->cap)
+    {
+        size_t nc = g->cap ? g->cap * 2 : 4096;
+        while (nc < g->len + n) nc *= 2;
+        g->p = (char *)realloc(g->p, nc); g->cap = nc;
+    }
+    memcpy(g->p + g->len, src, n); g->len += n;
+}
+static long gb_take(gb *g, void *dst, size_t elsz, long capels)
+{
+    long have = (long)(g->len / elsz), n = have < capels ? have : capels;
+    memcpy(dst, g->p, (size_t)n * elsz);
+    memmove(g->p, g->p + (size_t)n * elsz, g->len - (size_t)n * elsz);
+    g->len -= (size_t)n * elsz;
+    return n;
+}
+
+typedef struct { int preamble[64], buffer[64], len, tollerence, inverted; } pdet_t;
+static void pdet_set(pdet_t *d, uint64_t bits, int len) /* setPreamble(quint64,int) :730-743 */
+{
+    d->len = len;
+    for (int i = len - 1, k = 0; i >= 0; i--, k++) d->preamble[k] = (int)((bits >> i) & 1);
+    memset(d->buffer, 0, sizeof(d->buffer));
+}
+static int pdet_update_exact(pdet_t *d, int val) /* PreambleDetector::Update :744-750 */
+{
+    for (int i = 0; i < d->len - 1; i++) d->buffer[i] = d->buffer[i + 1];
+    d->buffer[d->len - 1] = val;
+    if (!memcmp(d->buffer, d->preamble, sizeof(int) * (size_t)d->len)) { memset(d->buffer, 0, sizeof(d->buffer)); return 1; }
+    return 0;
+}
+static int pdet_update_pi(pdet_t *d, int val) /* PreambleDetectorPhaseInvariant::Update :781-804 */
+{
+    int xorsum = 0;
+    for (int i = 0; i < d->len - 1; i++) { d->buffer[i] = d->buffer[i + 1]; xorsum += d->buffer[i] ^ d->preamble[i]; }
+    xorsum += val ^ d->preamble[d->len - 1];
+    d->buffer[d->len - 1] = val;
+    if (xorsum >= (d->len - d->tollerence)) { d->inverted = 1; return 1; }
+    if (xorsum <= d->tollerence) { d->inverted = 0; return 1; }
+    return 0;
+}
+
+static uint16_t crc16_bytes(const unsigned char *bytes, int n) /* AeroLcrc16::calcusingbytes aerol.h:333-360 */
+{
+    uint16_t crc = 0xFFFF;
+    for (int i = 0; i < n; i++)
+    {
+        int message_byte = (signed char)bytes[i]; /* message_byte=bytes[i] with char bytes: sign-extends, only the low 8 bits are used */
+        for (int k = 0; k < 8; k++)
+        {
+            int message_bit = message_byte & 1;
+            message_byte >>= 1;
+            int crc_bit = crc & 1;
+            crc >>= 1;
+            if (crc_bit ^ message_bit) crc = crc ^ 0x8408;
+        }
+    }
+    return (uint16_t)~crc;
+}
+
+struct jo_aerol
+{
+    int ifb, useingOQPSK, N, blocksz, dl2_len;
+    int NumberOfBits, BitsInHeader, TotalNumberOfBits;
+    int cntr, datacd, datacdcountdown, gotsync_last, realimag, blockcnt, muw;
+    uint16_t frameinfo, lastframeinfo;
+    int formatid, supfrmaker, framecounter1, framecounter2;
+    pdet_t pd_exact, pd_imag, pd_real;
+    int *block;
+    jo_codec *codec;
+    int *dl2; int dl2_ptr, dl2_sz;
+    unsigned char scr[5000]; int scr_pos;
+    unsigned char infofield[4096]; int ninfo;
+    int depermute[64];
+    long nbits_total, nframes;
+    gb sus, events;
+};
+
+static void ev(jo_aerol *a, long idx, int kind, long value)
+{
+    int64_t row[3] = {idx, kind, value};
+    gb_push(&a->events, row, sizeof(row));
+}
+
+jo_aerol *jo_aerol_create(int fb)
+{
+    jo_aerol *a = (jo_aerol *)calloc(1, sizeof(*a));
+    /* ctor :904-977 */
+    a->cntr = 1000000000; a->blockcnt = -1;
+    a->codec = jo_codec_create(24);
+    pdet_set(&a->pd_exact, 3780831379ULL, 32);
+    pdet_set(&a->pd_imag, 3780831379ULL, 32);
+    pdet_set(&a->pd_real, 3780831379ULL, 32);
+    for (int i = 0; i < 64; i++) a->depermute[i] = (i * 27) % 64; /* AeroLInterleaver ctor :523-537 */
+    { /* AeroLScrambler ctor aerol.h:397-420 */
+        int state[15] = {1, 1, 0, 1, 0, 0, 1, 0, 1, 0, 1, 1, 0, 0, 1};
+        for (int k = 0; k < 5000; k++)
+        {
+            int val0 = state[0] ^ state[14];
+            a->scr[k] = (unsigned char)val0;
+            for (int i = 14; i > 0; i--) state[i] = state[i - 1];
+            state[0] = val0;
+        }
+    }
+    /* setSettings(fb,false) :990-1072: non-burst tolerances 0 */
+    a->ifb = fb;
+    switch (fb)
+    {
+    case 600: a->N = 6; a->dl2_len = 576 - 6; a->NumberOfBits = 1152; a->BitsInHeader = 16; a->TotalNumberOfBits = 16 + 1152 + 32; a->useingOQPSK = 0; break;
+    case 1200: a->N = 9; a->dl2_len = 576 - 6; a->NumberOfBits = 1152; a->BitsInHeader = 16; a->TotalNumberOfBits = 16 + 1152 + 32; a->useingOQPSK = 0; break;
+    default: a->N = 78; a->dl2_len = 4992 - 6; a->NumberOfBits = 4992; a->BitsInHeader = 16 + 178; a->TotalNumberOfBits = 16 + 178 + 4992 + 64; a->useingOQPSK = 1; a->ifb = 10500; break;
+    }
+    a->blocksz = a->N * 64;
+    a->block = (int *)calloc((size_t)a->blocksz, sizeof(int));
+    a->dl2_sz = a->dl2_len + 1;
+    a->dl2 = (int *)calloc((size_t)a->dl2_sz, sizeof(int));
+    ev(a, 0, 0, 0); /* emit DataCarrierDetect(false) in the ctor */
+    return a;
+}
+void jo_aerol_destroy(jo_aerol *a)
+{
+    if (!a) return;
+    free(a->block); free(a->dl2); jo_codec_destroy(a->codec); free(a->sus.p); free(a->events.p); free(a);
+}
+int jo_aerol_dcd(jo_aerol *a) { return a->datacd; }
+long jo_aerol_take_sus(jo_aerol *a, int32_t *dst, long cap) { return gb_take(&a->sus, dst, 16 * sizeof(int32_t), cap); }
+long jo_aerol_take_events(jo_aerol *a, int64_t *dst, long cap) { return gb_take(&a->events, dst, 3 * sizeof(int64_t), cap); }
+
+static void block_done(jo_aerol *a, long bitidx) /* aerol.cpp:1553-1600 */
+{
+    a->blockcnt++;
+    /* leaver.deinterleave_ba(block, 0): matrix_ba[k] = block[depermute[i]*N + j], k = j*64 + i */
+    unsigned char *deleaved = (unsigned char *)malloc((size_t)a->blocksz);
+    int k = 0;
+    for (int j = 0; j < a->N; j++)
+        for (int i = 0; i < 64; i++) deleaved[k++] = (unsigned char)a->block[a->depermute[i] * a->N + j];
+    unsigned char *bits = (unsigned char *)malloc((size_t)a->blocksz);
+    int nb = jo_decode_continuous(a->codec, deleaved, a->blocksz, bits);
+    for (int h = 0; h < nb; h++)
+    {
+        /* dl2.update :1560 (DelayLine aerol.h:468-476) */
+        a->dl2[a->dl2_ptr] = bits[h];
+        a->dl2_ptr++; a->dl2_ptr %= a->dl2_sz;
+        int v = a->dl2[a->dl2_ptr];
+        /* scrambler.update :1563 */
+        v ^= a->scr[a->scr_pos < 5000 ? a->scr_pos : 4999];
+        a->scr_pos++;
+        bits[h] = (unsigned char)v;
+    }
+    /* pack :1566-1578 */
+    {
+        int charptr = 0; unsigned char ch = 0;
+        for (int h = 0; h < nb; h++)
+        {
+            ch |= bits[h] * 128;
+            charptr++; charptr %= 8;
+            if (charptr == 0) { if (a->ninfo < (int)sizeof(a->infofield)) a->infofield[a->ninfo++] = ch; ch = 0; }
+            else ch >>= 1;
+        }
+    }
+    free(deleaved); free(bits);
+    if ((a->cntr - a->BitsInHeader) == (a->NumberOfBits - 1)) /* frame is done :1580 */
+    {
+        for (int kk = 0; kk < a->ninfo / 12; kk++)
+        {
+            const unsigned char *su = a->infofield + kk * 12;
+            uint16_t crc_calc = crc16_bytes(su, 10);
+            uint16_t crc_rec = (uint16_t)((su[11] << 8) | su[10]);
+            if ((!crc_rec) && (crc_calc != crc_rec))
+            {
+                int tsum = 0;
+                for (int ii = 0; ii < 10; ii++) tsum += su[ii];
+                if (tsum == 0) crc_calc = 0;
+            }
+            if (crc_calc == crc_rec) { if (a->datacdcountdown < 12) a->datacdcountdown += 2; }
+            else { if (a->datacdcountdown > 0) a->datacdcountdown -= 3; }
+            if (!a->datacd && a->datacdcountdown > 2) { a->datacd = 1; ev(a, bitidx, 0, 1); }
+            int32_t row[16];
+            row[0] = (int32_t)a->nframes; row[1] = kk;
+            for (int j = 0; j < 12; j++) row[2 + j] = su[j];
+            row[14] = (crc_calc == crc_rec); row[15] = a->frameinfo;
+            gb_push(&a->sus, row, sizeof(row));
+        }
+        a->nframes++;
+    }
+}
+
+void jo_aerol_write(jo_aerol *a, const int16_t *sb, long n)
+{
+    /* Decode(): decodedbytes.clear() etc. are text; the loop :1131-2027 */
+    for (long i = 0; i < n; i++)
+    {
+        const long bitidx = a->nbits_total + i;
+        int bit = (((unsigned char)sb[i]) >= 128) ? 1 : 0;
+        unsigned short soft_bit = (unsigned short)sb[i];
+        if (sb[i] < 0) { a->muw = 0; continue; }
+        if (a->muw < 100000) a->muw++;
+        int gotsync;
+        if (a->useingOQPSK)
+        {
+            a->realimag++; a->realimag %= 2;
+            pdet_t *pd = a->realimag ? &a->pd_imag : &a->pd_real;
+            if (a->cntr > a->NumberOfBits - 68 || a->cntr <= 0 || !a->datacd)
+            {
+                gotsync = pdet_update_pi(pd, bit);
+                if (!a->gotsync_last) { a->gotsync_last = gotsync; gotsync = 0; }
+                else a->gotsync_last = 0;
+            }
+            else { gotsync = 0; a->gotsync_last = 0; }
+            if (pd->inverted)
+            {
+                bit = 1 - bit;
+                if (soft_bit > 128) soft_bit = 255 - soft_bit;
+                else if (soft_bit < 128) soft_bit = 255 - soft_bit;
+            }
+        }
+        else gotsync = pdet_update_exact(&a->pd_exact, bit);
+
+        if (a->cntr < 1000000000) a->cntr++;
+        if (a->cntr < 16)
+        {
+            if (a->cntr == 0) { a->frameinfo = (uint16_t)bit; a->ninfo = 0; }
+            else { a->frameinfo <<= 1; a->frameinfo |= (uint16_t)bit; }
+        }
+        if (a->cntr == 15)
+        {
+            uint16_t tval = a->frameinfo;
+            a->frameinfo = a->lastframeinfo;
+            a->lastframeinfo = tval;
+            a->formatid = (a->frameinfo >> 12) & 0xF; a->supfrmaker = (a->frameinfo >> 8) & 0xF;
+            a->framecounter1 = (a->frameinfo >> 4) & 0xF; a->framecounter2 = a->frameinfo & 0xF;
+        }
+        if (a->cntr >= 16)
+        {
+            if (a->cntr == 16) a->blockcnt = -1;
+            int idx = (a->cntr - a->BitsInHeader) % a->blocksz;
+            if (idx < 0) idx = 0;
+            a->block[idx] = soft_bit;
+            if (idx == (a->blocksz - 1)) block_done(a, bitidx);
+        }
+        if (gotsync)
+        {
+            if (a->cntr + 1 != a->TotalNumberOfBits) ev(a, bitidx, 1, a->cntr + 1); /* "Error short frame!!!" (isudata.reset()) */
+            a->cntr = -1;
+            a->datacd = 1; a->datacdcountdown = 12;
+            ev(a, bitidx, 0, 1);
+            ev(a, bitidx, 2, 0);
+            a->scr_pos = 0;
+        }
+        if (a->cntr + 1 == a->TotalNumberOfBits) { a->scr_pos = 0; a->cntr = -1; }
+    }
+    a->nbits_total += n;
+}

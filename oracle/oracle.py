@@ -52,7 +52,7 @@ def burst_msk_settings(freq_center=1000.0, lockingbw=1800.0, fb=1200.0, Fs=48000
 def build(force: bool = False) -> None:
     """Compile liboracle.so (and _ref when the reference tree is present)."""
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(
-        os.path.getmtime(os.path.join(HERE, f)) for f in ("jaero_oracle.c", "jaero_oracle_burst.c", "viterbi_oracle.c", "jaero_oracle.h")
+        os.path.getmtime(os.path.join(HERE, f)) for f in ("jaero_oracle.c", "jaero_oracle_burst.c", "viterbi_oracle.c", "jaero_oracle.h", "aerol_oracle.c", "aerol_oracle.h")
     ):
         subprocess.check_call(["make", "-C", HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/JAERO") and os.path.exists("/opt/conda/bin/moc"):
@@ -129,6 +129,15 @@ def lib():
         L.jo_hilbert_destroy.argtypes = [C.c_void_p]
         L.jo_hilbert_latency.argtypes = [C.c_void_p]
         L.jo_hilbert_update.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
+        L.jo_aerol_create.restype = C.c_void_p
+        L.jo_aerol_create.argtypes = [C.c_int]
+        L.jo_aerol_destroy.argtypes = [C.c_void_p]
+        L.jo_aerol_write.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        L.jo_aerol_take_sus.restype = C.c_long
+        L.jo_aerol_take_sus.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        L.jo_aerol_take_events.restype = C.c_long
+        L.jo_aerol_take_events.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        L.jo_aerol_dcd.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -318,6 +327,63 @@ def hilbert_stream(pcm: np.ndarray, chunk: int = 4096, N=2048):
     lat = L.jo_hilbert_latency(h)
     L.jo_hilbert_destroy(h)
     return out, lat
+
+
+class AeroL:
+    """Continuous (P-channel) path of the reference's AeroL bit pipeline: soft bits -> signal units."""
+
+    def __init__(self, fb: int):
+        self.L = lib()
+        self.h = self.L.jo_aerol_create(int(fb))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.jo_aerol_destroy(self.h)
+            self.h = None
+
+    def write(self, soft: np.ndarray):
+        soft = np.ascontiguousarray(soft, dtype=np.int16)
+        self.L.jo_aerol_write(self.h, soft.ctypes.data, soft.shape[0])
+
+    def take_sus(self) -> np.ndarray:
+        """rows [frame, k, 12 bytes, crc_ok, frameinfo]"""
+        return _drain(self.L.jo_aerol_take_sus, self.h, 16, np.int32)
+
+    def take_events(self) -> np.ndarray:
+        return _drain(self.L.jo_aerol_take_events, self.h, 3, np.int64)
+
+    @property
+    def dcd(self):
+        return self.L.jo_aerol_dcd(self.h)
+
+
+def run_aerol(fb: int, soft: np.ndarray, group: int = 32):
+    a = AeroL(fb)
+    for s in range(0, soft.shape[0], group):
+        a.write(soft[s:s + group])
+    return {"sus": a.take_sus(), "events": a.take_events(), "dcd": a.dcd}
+
+
+def run_ref_aerol(fb: int, soft: np.ndarray, group: int = 32):
+    """The unmodified AeroL (oracle/_ref): returns (list of (k, 10 bytes, crc_ok) in output order, raw text)."""
+    import re
+
+    assert have_ref()
+    with tempfile.TemporaryDirectory() as td:
+        inp, outp = os.path.join(td, "soft.s16"), os.path.join(td, "out.txt")
+        np.ascontiguousarray(soft, dtype=np.int16).tofile(inp)
+        env = dict(os.environ)
+        env["QT_QPA_PLATFORM"] = "offscreen"
+        subprocess.check_call([REF_BIN, "aerol", inp, outp, f"fb={fb}", f"group={group}"], env=env)
+        txt = open(outp, "rb").read().decode("latin1")
+    sus = []
+    for line in txt.split("\n"):
+        m = re.match(r"^(.)((?: 0x[0-9A-F]{2}){10})(.*)$", line)
+        if m:
+            k = ord(m.group(1)) - ord("0")
+            b = bytes(int(x, 16) for x in m.group(2).split())
+            sus.append((k, b, "Bad CRC" not in m.group(3)))
+    return sus, txt
 
 
 # ----------------------------------------------------------------------------------------------- _ref runner

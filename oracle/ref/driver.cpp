@@ -242,7 +242,16 @@ int main(int argc, char **argv)
         QByteArray in = readall(argv[2]);
         const short *sp = (const short *)in.constData();
         long n = in.size() / 2;
-        AeroL a(0);
+        // realimag, muw and lastframeinfo are never initialised by the reference (JAERO/aerol.h:956,975,990): zeroed storage makes a
+        // run deterministic
+        struct AeroLZ : public AeroL
+        {
+            AeroLZ() : AeroL(0) {}
+            static void *operator new(size_t n) { return calloc(1, n); }
+            static void operator delete(void *p) { free(p); }
+        };
+        AeroLZ *ap = new AeroLZ();
+        AeroL &a = *ap;
         QBuffer sink;
         sink.open(QIODevice::ReadWrite);
         a.ConnectSinkDevice(&sink);

@@ -116,9 +116,28 @@ def burst():
         print(f, len(x), r["soft"].shape, r["events"].shape)
 
 
+def aerol():
+    """Aero-L bit pipeline: what the UNMODIFIED AeroL (JAERO/aerol.cpp) makes of generated P-channel frames.
+    sus rows = [k, 10 payload bytes, crc_ok] in the order AeroL::Decode printed them."""
+    from jaero_amd import aerol_frames as AF
+    assert O.have_ref()
+    for fb, grp, inv in ((10500, 32, (True, False)), (1200, 12, (False, False)), (600, 12, (False, False))):
+        pay = AF.random_payloads(7, fb, seed=fb)
+        bits, _ = AF.p_channel_bits(pay, fb, invert_i=inv[0], invert_q=inv[1])
+        soft = AF.to_soft(bits, sigma=22.0, seed=fb + 1)
+        sus, _ = O.run_ref_aerol(fb, soft, grp)
+        rows = np.array([[k] + list(b) + [int(ok)] for k, b, ok in sus], dtype=np.int32)
+        np.savez_compressed(os.path.join(HERE, f"aerol_{fb}.npz"), soft=soft, fb=fb, group=grp, sus=rows,
+                            payloads=np.array([[list(p) for p in fr] for fr in pay], dtype=np.uint8))
+        print("aerol", fb, soft.shape, rows.shape, "crc ok", int(rows[:, 11].sum()))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "burst":
         burst()
+    elif len(sys.argv) > 1 and sys.argv[1] == "aerol":
+        aerol()
     else:
         main()
         burst()
+        aerol()

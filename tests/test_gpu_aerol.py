@@ -1,0 +1,110 @@
+"""GPU (-m gpu): the Aero-L bit pipeline (unique word / ambiguity -> deinterleave -> Viterbi -> delay line -> descramble -> CRC),
+called through the C ABI, against the unmodified AeroL's goldens and the oracle; and the whole chain PCM -> demodulator bank ->
+(device-resident soft bits) -> Aero-L bank -> CRC-clean signal units equal to the transmitted payloads.  Integer work: exact."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from jaero_amd import aerol_frames as AF
+from jaero_amd import signalgen as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def B():
+    from jaero_amd import capi
+    from jaero_amd import demodulator as D
+
+    capi.lib()
+    return D
+
+
+def rows12(sus):
+    return np.array([[int(r[1])] + [int(v) for v in r[2:12]] + [int(r[14])] for r in sus], dtype=np.int32).reshape(-1, 12)
+
+
+@pytest.mark.parametrize("fb", [10500, 1200, 600])
+def test_against_reference_golden(B, fb):
+    g = load_golden(f"aerol_{fb}")
+    soft, grp = g["soft"], int(g["group"])
+    bank = B.AeroLBank(1, fb, max_softbits_per_write=8192)
+    for s in range(0, len(soft), 4000):  # the unmodified AeroL was fed `grp` soft bits at a time; results are chunk invariant
+        bank.write(soft[None, s:s + 4000])
+    assert np.array_equal(rows12(bank.read_sus(0)), g["sus"])
+    bank.close()
+
+
+@pytest.mark.parametrize("fb", [10500, 1200])
+def test_bank_vs_oracle(B, oracle_mod, fb):
+    """70 channels (two wave groups), different frames / noise / arm inversions / garbage prefixes per channel, ragged per-channel
+    counts in every write."""
+    nch = 70
+    rng = np.random.default_rng(fb)
+    streams = []
+    for c in range(nch):
+        pay = AF.random_payloads(5, fb, seed=1000 + c)
+        bits, _ = AF.p_channel_bits(pay, fb, invert_i=bool(c & 1), invert_q=bool(c & 2))
+        pre = rng.integers(0, 2, size=int(rng.integers(0, 900)), dtype=np.uint8)
+        streams.append(AF.to_soft(np.concatenate([pre, bits]), sigma=float(rng.uniform(0, 45)), seed=c))
+    bank = B.AeroLBank(nch, fb, max_softbits_per_write=6000, su_capacity=400)
+    pos = np.zeros(nch, dtype=np.int64)
+    lens = np.array([len(s) for s in streams])
+    while (pos < lens).any():
+        cnt = np.minimum(rng.integers(1, 6000, size=nch), lens - pos).astype(np.int32)
+        buf = np.zeros((nch, 6000), np.int16)
+        for c in range(nch):
+            buf[c, :cnt[c]] = streams[c][pos[c]:pos[c] + cnt[c]]
+        bank.write(buf, cnt)
+        pos += cnt
+    nclean = 0
+    for c in range(nch):
+        o = oracle_mod.run_aerol(fb, streams[c], 1 << 20)
+        assert np.array_equal(bank.read_sus(c), o["sus"]), c
+        assert np.array_equal(bank.read_events(c), o["events"]), c
+        nclean += int(o["sus"][:, 14].sum())
+    assert nclean > nch * 10
+    bank.close()
+
+
+def test_tick_dcd(B):
+    g = load_golden("aerol_1200")
+    bank = B.AeroLBank(1, 1200, max_softbits_per_write=16384)
+    bank.write(g["soft"][None, :])
+    d = [int(bank.tick_dcd()[0]) for _ in range(6)]  # updateDCD: countdown 12 -> 0 in steps of 3, then DataCarrierDetect(false)
+    assert d[0] == 1 and d[-1] == 0
+    ev = bank.read_events(0)
+    assert ev[-1, 1] == 0 and ev[-1, 2] == 0
+    bank.close()
+
+
+def test_pcm_to_signal_units_on_device(B):
+    """10.5 kbps P-channel frames -> OQPSK passband PCM -> continuous demodulator bank -> soft bits stay in HBM -> Aero-L bank.
+    The recovered, CRC-clean signal units must be exactly the transmitted ones."""
+    fb, nch, nfr = 10500, 3, 14
+    pays, pcms = [], []
+    for c in range(nch):
+        pay = AF.random_payloads(nfr, fb, seed=50 + c)
+        bits, _ = AF.p_channel_bits(pay, fb)
+        n = int(len(bits) / 2 * 48000 / 5250) + 2000
+        pcm, _ = G.oqpsk(n, fc=8000.0 + 11.0 * c, ebno_db=13.0, seed=70 + c, bits=np.concatenate([bits, np.zeros(64, np.uint8)]))
+        pays.append(pay)
+        pcms.append(pcm)
+    n = min(len(p) for p in pcms)
+    pcm = np.stack([p[:n] for p in pcms])
+    chunk = 24000  # half a second = one frame
+    demod = B.DemodulatorBank(B.OqpskSettings(), nch, device=0, max_write_samples=chunk, softbit_capacity=8192)
+    aerol = B.AeroLBank(nch, fb, max_softbits_per_write=8192, su_capacity=26 * nfr + 8)
+    for s in range(0, n, chunk):
+        demod.write(pcm[:, s:s + chunk])
+        aerol.write_from_bank(demod, 8192)
+    for c in range(nch):
+        sus = aerol.read_sus(c)
+        good = [bytes(r[2:12].astype(np.uint8)) for r in sus if r[14]]
+        sent = [p for fr in pays[c] for p in fr]
+        assert len(good) >= 26 * 6, (c, len(good))
+        # in order, a contiguous run of the transmitted units
+        i0 = sent.index(good[0])
+        assert good == sent[i0:i0 + len(good)], c
+    demod.close()
+    aerol.close()
