@@ -47,8 +47,9 @@ def parse():
     ap.add_argument("--chunk", type=int, default=4096)
     ap.add_argument("--ebno", type=int, default=1, help="run the EbNo meters (the reference always does)")
     ap.add_argument("--ebno-db", type=float, default=10.0)
-    ap.add_argument("--workload", default="oqpsk", choices=["oqpsk", "burst_oqpsk"],
-                    help="oqpsk = BASELINE configs[2] (continuous, the headline); burst_oqpsk = configs[3] (one burst per second per channel)")
+    ap.add_argument("--workload", default="oqpsk", choices=["oqpsk", "burst_oqpsk", "aerol"],
+                    help="oqpsk = BASELINE configs[2] (continuous, the headline); burst_oqpsk = configs[3] (one burst per second per "
+                         "channel); aerol = the 10.5 kbps P-channel bit pipeline behind the demodulator (SURVEY 8 row f1), one frame per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=1_000_000, help="samples per core for the CPU baseline leg")
     return ap.parse_args()
@@ -172,6 +173,104 @@ def burst_line(bank, rank, world, nch, chunk, K, W, dt, value):
         except Exception as e:
             line["cpu_baseline"] = {"value": None, "error": str(e)}
     print(json.dumps(line), flush=True)
+
+
+def aerol_bench():
+    """Aero-L bit pipeline: a step = one 0.5 s P-channel frame (5250 soft bits) for every channel, soft bits resident in HBM.
+    Metric: soft bits per second (all channels).  Algorithmic bytes per soft bit: 2 (int16 in) + 1 (deinterleaved block write) + 1
+    (Viterbi read) + 0.5 + 0.5 (decoded bit write/read) + 1 (delay line r/w per decoded bit = 0.5 per soft bit x 2) = 6;
+    per kernel: k_aerol_bits 3, k_viterbi 1.5, k_aerol_post 1.5."""
+    import torch
+    import torch.distributed as dist
+
+    from jaero_amd import aerol_frames as AF
+    from jaero_amd import capi
+    from jaero_amd import dist as jd
+    from jaero_amd.demodulator import AeroLBank
+
+    capi.lib()
+    rank, world, local = jd.init_from_env()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    nch, K, W = ARGS.channels, ARGS.steps, ARGS.warmup
+    fb, flen = 10500, 5250
+    nuniq = 64
+    streams = []
+    for u in range(nuniq):
+        bits, _ = AF.p_channel_bits(AF.random_payloads(K + W, fb, seed=900 + u + 1000 * rank), fb, invert_i=bool(u & 1), invert_q=bool(u & 2))
+        streams.append(AF.to_soft(bits, sigma=25.0, seed=u))
+    host = np.stack(streams)  # [nuniq, (K+W)*5250]
+    soft = torch.from_numpy(host).to(dev)
+    idx = torch.arange(nch, device=dev) % nuniq
+    counts = torch.full((nch,), flen, dtype=torch.int32, device=dev)
+    bank = AeroLBank(nch, fb, device=local, max_softbits_per_write=flen, su_capacity=26 * (K + W) + 8)
+    stream = torch.cuda.current_stream().cuda_stream
+    frame = torch.empty((nch, flen), dtype=torch.int16, device=dev)
+
+    def step(i):
+        frame.copy_(soft[idx, i * flen:(i + 1) * flen])  # staging of the synthetic input (a demodulator bank writes it in place)
+        bank.write_device(frame.data_ptr(), counts.data_ptr(), flen, flen, stream)
+
+    for i in range(W):
+        step(i)
+    torch.cuda.synchronize()
+    bank.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    names = ["bits", "viterbi", "post"]
+    alg = {"bits": 3.0, "viterbi": 1.5, "post": 1.5}
+    ms, nl = {}, {}
+    for w, nm in enumerate(names):
+        ms[nm], nl[nm] = bank.profile_read(w)
+    good = sum(int(bank.read_sus(c, 26 * (K + W) + 8)[:, 14].sum()) for c in range(min(4, nch)))
+    if rank == 0:
+        value = float(K) * flen * nch * world / dt / 1e6
+        dom = max(names, key=lambda k: ms[k])
+        launches = max(nl[dom], 1)
+        avg_ms = ms[dom] / launches
+        units = K * flen * nch / launches
+        achieved = alg[dom] * units / (avg_ms * 1e-3) / 1e9
+        line = {
+            "metric": "Msoftbits/s through the Aero-L P-channel bit pipeline (unique word, deinterleave, Viterbi, descramble, CRC)",
+            "value": round(value, 2), "unit": "Msoftbits/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{nch}-channel-per-GPU 10.5 kbps P-channel frames (5250 soft bits = 0.5 s per step and channel), "
+                                   f"{nuniq} distinct noisy frame streams replicated over the channels, arm inversions mixed",
+                       "channels_per_gpu": nch, "total_channels": nch * world, "realtime_channel_equivalents": int(value * 1e6 / 10500),
+                       "crc_clean_units_in_first_channels": good, "channels_checked": min(4, nch),
+                       "kernel_ms_total": {k: round(v, 3) for k, v in ms.items()}, "kernel_launches": nl},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "alg_bytes_per_softbit": alg[dom],
+                         "softbits_per_launch": units, "avg_launch_ms": round(avg_ms, 4)},
+        }
+        if world == 1 and not ARGS.no_cpu_baseline:
+            from oracle import oracle as O  # cpu_baseline leg only
+            x = host[0][: 20 * flen] if host.shape[1] >= 20 * flen else host[0]
+            reps = max(1, int(2_000_000 / len(x)))
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                O.run_aerol(fb, x, 32)
+            ct = time.perf_counter() - t1
+            line["cpu_baseline"] = {"value": round(reps * len(x) / ct / 1e6, 3), "unit": "Msoftbits/s", "cores": 1, "kind": "port",
+                                    "sample": f"{reps} x {len(x)} soft bits through oracle/aerol_oracle.c (AeroL::Decode restated), 32-bit groups, one thread"}
+        print(json.dumps(line), flush=True)
+    bank.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -298,4 +397,7 @@ def main():
 
 if __name__ == "__main__":
     ARGS = parse()
-    main()
+    if ARGS.workload == "aerol":
+        aerol_bench()
+    else:
+        main()

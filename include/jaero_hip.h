@@ -186,6 +186,9 @@ int jaero_aerol_write(jaero_aerol_ctx *ctx, const int16_t *soft, const int *coun
 int jaero_aerol_read_sus(jaero_aerol_ctx *ctx, int channel, int32_t *rows, int caprows, int *nrows);
 int jaero_aerol_read_events(jaero_aerol_ctx *ctx, int channel, long long *rows, int caprows, int *nrows);
 int jaero_aerol_tick_dcd(jaero_aerol_ctx *ctx, int *dcd_out /* optional [nchannels] */);
+/* HIP-event time per kernel class since the last reset: which 0 = k_aerol_bits, 1 = Viterbi, 2 = k_aerol_post */
+int jaero_aerol_profile_enable(jaero_aerol_ctx *ctx, int on);
+int jaero_aerol_profile_read(jaero_aerol_ctx *ctx, int which, double *total_ms, int *launches, int reset);
 
 /* Host-only debugging aid (no device needed): the sample indices at which jaero_write would run the coarse-frequency
  * estimate for a fresh channel fed `nwrites` writes of write_sizes[i] samples.  Returns the number of triggers

@@ -26,7 +26,7 @@ EXPORTS = [
     "jaero_num_channels", "jaero_strerror", "jaero_last_error", "jaero_profile_enable", "jaero_profile_read",
     "jaero_debug_schedule", "jaero_read_events",
     "jaero_aerol_create", "jaero_aerol_destroy", "jaero_aerol_write", "jaero_aerol_read_sus", "jaero_aerol_read_events",
-    "jaero_aerol_tick_dcd",
+    "jaero_aerol_tick_dcd", "jaero_aerol_profile_enable", "jaero_aerol_profile_read",
 ]
 
 
@@ -116,6 +116,8 @@ def lib():
     L.jaero_aerol_read_sus.argtypes = [vp, ip, vp, ip, C.POINTER(ip)]
     L.jaero_aerol_read_events.argtypes = [vp, ip, vp, ip, C.POINTER(ip)]
     L.jaero_aerol_tick_dcd.argtypes = [vp, vp]
+    L.jaero_aerol_profile_enable.argtypes = [vp, ip]
+    L.jaero_aerol_profile_read.argtypes = [vp, ip, C.POINTER(dp), C.POINTER(ip), ip]
     for name in EXPORTS:
         getattr(L, name)  # raises AttributeError if a declared symbol is not exported
     _lib = L

@@ -9,7 +9,58 @@ struct jaero_aerol_ctx
     std::vector<void *> allocs;
     int16_t *d_soft = nullptr; int *d_counts = nullptr; int stage_stride = 0;
     hipStream_t last_stream = nullptr;
+    // HIP-event timing of the three kernel classes (0 = k_aerol_bits, 1 = k_viterbi + overlap update, 2 = k_aerol_post)
+    bool prof = false;
+    double prof_ms[3] = {0, 0, 0};
+    int prof_n[3] = {0, 0, 0};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<int> ev_which;
 };
+
+static void aprof_begin(jaero_aerol_ctx *c, int which, hipStream_t st)
+{
+    if (!c->prof) return;
+    hipEvent_t a, b;
+    if (c->ev_which.size() < c->ev_pool.size()) { a = c->ev_pool[c->ev_which.size()].first; }
+    else
+    {
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        c->ev_pool.push_back({a, b});
+    }
+    c->ev_which.push_back(which);
+    hipEventRecord(c->ev_pool[c->ev_which.size() - 1].first, st);
+}
+static void aprof_end(jaero_aerol_ctx *c, hipStream_t st)
+{
+    if (!c->prof || c->ev_which.empty()) return;
+    hipEventRecord(c->ev_pool[c->ev_which.size() - 1].second, st);
+}
+static void aprof_collect(jaero_aerol_ctx *c)
+{
+    for (size_t i = 0; i < c->ev_which.size(); i++)
+    {
+        float ms = 0;
+        hipEventSynchronize(c->ev_pool[i].second);
+        if (hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second) == hipSuccess) { c->prof_ms[c->ev_which[i]] += ms; c->prof_n[c->ev_which[i]]++; }
+    }
+    c->ev_which.clear();
+}
+extern "C" int jaero_aerol_profile_enable(jaero_aerol_ctx *c, int on)
+{
+    if (!c) return fail(JAERO_EINVAL, "null ctx");
+    c->prof = on != 0;
+    return 0;
+}
+extern "C" int jaero_aerol_profile_read(jaero_aerol_ctx *c, int which, double *total_ms, int *launches, int reset)
+{
+    if (!c || which < 0 || which > 2) return fail(JAERO_EINVAL, "jaero_aerol_profile_read: bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    aprof_collect(c);
+    if (total_ms) *total_ms = c->prof_ms[which];
+    if (launches) *launches = c->prof_n[which];
+    if (reset) { c->prof_ms[which] = 0; c->prof_n[which] = 0; }
+    return 0;
+}
 
 template <class T>
 static int aalloc(jaero_aerol_ctx *c, T **ptr, size_t count)
@@ -32,6 +83,7 @@ extern "C" void jaero_aerol_destroy(jaero_aerol_ctx *c)
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     for (void *q : c->allocs) hipFree(q);
+    for (auto &e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete c;
 }
 
@@ -130,11 +182,17 @@ extern "C" int jaero_aerol_write(jaero_aerol_ctx *c, const int16_t *soft, const 
     const dim3 grid(g.nchp / 64), block(64);
     for (int r = 0; r < rounds; r++)
     {
+        aprof_begin(c, 0, st);
         hipLaunchKernelGGL(k_aerol_bits, grid, block, 0, st, g, c->p, dsoft, dcounts, stride);
+        aprof_end(c, st);
+        aprof_begin(c, 1, st);
         hipLaunchKernelGGL(k_viterbi, dim3(g.nch), dim3(64), 0, st, (const uint8_t *)c->p.deint, g.blocksz, (const uint8_t *)c->p.overlap, 24,
                            c->p.vbits, g.blocksz / 2, 25, g.blocksz / 2, g.nch, valid);
         hipLaunchKernelGGL(k_viterbi_overlap_update, dim3(g.nch), dim3(64), 0, st, (const uint8_t *)c->p.deint, g.blocksz, c->p.overlap, g.nch, valid);
+        aprof_end(c, st);
+        aprof_begin(c, 2, st);
         hipLaunchKernelGGL(k_aerol_post, grid, block, 0, st, g, c->p);
+        aprof_end(c, st);
     }
     hipLaunchKernelGGL(k_aerol_end_write, grid, block, 0, st, g, c->p, dcounts);
     HIPCHK(hipGetLastError());

@@ -431,6 +431,18 @@ class AeroLBank:
         capi.check(self.L.jaero_aerol_read_events(self.h, channel, buf.ctypes.data, caprows, C.byref(n)))
         return buf[: n.value].copy()
 
+    def write_device(self, soft_ptr: int, counts_ptr: int, stride: int, max_count: int, stream: int = 0):
+        """soft int16 [nch][stride] and counts int32 [nch] already on the bank's device."""
+        capi.check(self.L.jaero_aerol_write(self.h, soft_ptr, counts_ptr, stride, max_count, 1, stream))
+
+    def profile_enable(self, on: bool = True):
+        capi.check(self.L.jaero_aerol_profile_enable(self.h, int(on)))
+
+    def profile_read(self, which: int, reset: bool = False):
+        ms, n = C.c_double(0), C.c_int(0)
+        capi.check(self.L.jaero_aerol_profile_read(self.h, which, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
     def tick_dcd(self) -> np.ndarray:
         out = np.zeros(self.nch, dtype=np.int32)
         capi.check(self.L.jaero_aerol_tick_dcd(self.h, out.ctypes.data))
