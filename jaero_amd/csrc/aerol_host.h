@@ -8,6 +8,7 @@ struct jaero_aerol_ctx
     APtrs p{};
     std::vector<void *> allocs;
     int16_t *d_soft = nullptr; int *d_counts = nullptr; int stage_stride = 0;
+    unsigned long long *d_vhist = nullptr; // k_viterbi_lanes history scratch (large banks only)
     hipStream_t last_stream = nullptr;
     // HIP-event timing of the three kernel classes (0 = k_aerol_bits, 1 = k_viterbi + overlap update, 2 = k_aerol_post)
     bool prof = false;
@@ -126,6 +127,7 @@ extern "C" int jaero_aerol_create(int device, int nchannels, int fb, int max_sof
     c->stage_stride = max_softbits_per_write;
     AA(c->d_soft, (size_t)g.nch * max_softbits_per_write);
     AA(c->d_counts, g.nchp);
+    if (viterbi_use_lanes(g.nch, g.blocksz, 24)) AA(c->d_vhist, viterbi_hist_bytes(g.nch) / sizeof(unsigned long long));
 #undef AA
     c->p.scr = d_scr;
     {
@@ -186,8 +188,8 @@ extern "C" int jaero_aerol_write(jaero_aerol_ctx *c, const int16_t *soft, const 
         hipLaunchKernelGGL(k_aerol_bits, grid, block, 0, st, g, c->p, dsoft, dcounts, stride);
         aprof_end(c, st);
         aprof_begin(c, 1, st);
-        hipLaunchKernelGGL(k_viterbi, dim3(g.nch), dim3(64), 0, st, (const uint8_t *)c->p.deint, g.blocksz, (const uint8_t *)c->p.overlap, 24,
-                           c->p.vbits, g.blocksz / 2, 25, g.blocksz / 2, g.nch, valid);
+        viterbi_launch(st, (const uint8_t *)c->p.deint, g.blocksz, (const uint8_t *)c->p.overlap, 24, c->p.vbits, g.blocksz / 2, 25, g.blocksz / 2,
+                       g.nch, valid, c->d_vhist);
         hipLaunchKernelGGL(k_viterbi_overlap_update, dim3(g.nch), dim3(64), 0, st, (const uint8_t *)c->p.deint, g.blocksz, c->p.overlap, g.nch, valid);
         aprof_end(c, st);
         aprof_begin(c, 2, st);

@@ -23,6 +23,7 @@
 #include "k_coarse.h"
 #include "k_coarse2.h"
 #include "k_viterbi.h"
+#include "k_viterbi_lanes.h"
 #include "burst_device.h"
 #include "k_burst_front.h"
 #include "k_burst_demod.h"
@@ -1015,6 +1016,28 @@ extern "C" int jaero_read_events(jaero_ctx *c, int ch, double *rows, int caprows
 }
 
 // ------------------------------------------------------------------------------------------ Viterbi
+// Two layouts of the same decoder: one block per wavefront (k_viterbi: ~57 SIMD cycles per step and block, fills the chip from a few
+// thousand blocks) and one block per lane (k_viterbi_lanes: ~12 cycles per step and block, but needs >= 64 blocks per SIMD-wave to
+// pay off).  The lane layout wins once the per-wavefront layout has more than ~14 waves queued per SIMD.
+#define VL_MIN_BLOCKS 16384
+static inline size_t viterbi_hist_bytes(int nblocks) { return (size_t)((nblocks + 63) / 64) * VT_CAP * 64 * sizeof(unsigned long long); }
+static inline bool viterbi_use_lanes(int nblocks, int nsoft, int pad)
+{
+    if ((nsoft + pad) / 2 < 4 * VT_ORDER) return false;
+    const char *e = getenv("JAERO_VITERBI_LAYOUT"); // "wave" / "lanes" force one layout (tests run both against the oracle); default: by size
+    if (e && !strcmp(e, "wave")) return false;
+    if (e && !strcmp(e, "lanes")) return true;
+    return nblocks >= VL_MIN_BLOCKS;
+}
+static void viterbi_launch(hipStream_t st, const uint8_t *d_soft, int nsoft, const uint8_t *d_ov, int pad, uint8_t *d_out, int out_stride,
+                           int out_start, int out_want, int nblocks, const int *valid, unsigned long long *hist)
+{
+    if (hist && viterbi_use_lanes(nblocks, nsoft, pad))
+        hipLaunchKernelGGL(k_viterbi_lanes, dim3((nblocks + 63) / 64), dim3(64), 0, st, d_soft, nsoft, d_ov, pad, d_out, out_stride, out_start, out_want,
+                           nblocks, valid, hist);
+    else
+        hipLaunchKernelGGL(k_viterbi, dim3(nblocks), dim3(64), 0, st, d_soft, nsoft, d_ov, pad, d_out, out_stride, out_start, out_want, nblocks, valid);
+}
 static int viterbi_run(int device, const uint8_t *soft, int nblocks, int nsoft, int pad, uint8_t *overlap, uint8_t *bits_out,
                        int out_stride, int out_start, int out_want, int is_device_ptr, hipStream_t st)
 {
@@ -1038,8 +1061,11 @@ static int viterbi_run(int device, const uint8_t *soft, int nblocks, int nsoft, 
         }
     }
     HIPCHK(hipMemsetAsync(d_out, 0, out_bytes, st));
-    hipLaunchKernelGGL(k_viterbi, dim3(nblocks), dim3(64), 0, st, d_soft, nsoft, (const uint8_t *)d_ov, pad, d_out, out_stride, out_start, out_want, nblocks);
+    void *t_hist = nullptr;
+    if (viterbi_use_lanes(nblocks, nsoft, pad)) HIPCHK(hipMallocAsync(&t_hist, viterbi_hist_bytes(nblocks), st));
+    viterbi_launch(st, d_soft, nsoft, (const uint8_t *)d_ov, pad, d_out, out_stride, out_start, out_want, nblocks, nullptr, (unsigned long long *)t_hist);
     HIPCHK(hipGetLastError());
+    if (t_hist) HIPCHK(hipFreeAsync(t_hist, st));
     if (!is_device_ptr)
     {
         HIPCHK(hipMemcpyAsync(bits_out, d_out, out_bytes, hipMemcpyDeviceToHost, st));

@@ -1,8 +1,15 @@
-"""GPU (-m gpu): batched wave-per-block Viterbi kernel vs the libcorrect restatement (integer: bit-exact)."""
+"""GPU (-m gpu): the batched Viterbi kernels -- one block per wavefront (k_viterbi) and one block per lane (k_viterbi_lanes, what
+banks of >= 16384 blocks use) -- vs the libcorrect restatement (integer: bit-exact).  JAERO_VITERBI_LAYOUT forces a layout."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["wave", "lanes"])
+def layout(request, monkeypatch):
+    monkeypatch.setenv("JAERO_VITERBI_LAYOUT", request.param)
+    return request.param
 
 
 def _soft(coded, rng, sigma, amp=64):
@@ -10,8 +17,8 @@ def _soft(coded, rng, sigma, amp=64):
     return np.clip(np.round(x * amp + 128), 0, 255).astype(np.uint8)
 
 
-@pytest.mark.parametrize("nsoft,nblk", [(5078, 9), (662, 33), (320, 5), (6080, 3), (64, 2)])
-def test_decode_soft_blocks(oracle_mod, nsoft, nblk):
+@pytest.mark.parametrize("nsoft,nblk", [(5078, 9), (662, 133), (320, 5), (6080, 3), (64, 2), (4992, 70), (1152, 3)])
+def test_decode_soft_blocks(oracle_mod, layout, nsoft, nblk):
     from jaero_amd import capi
 
     O, L = oracle_mod, capi.lib()
@@ -31,18 +38,21 @@ def test_decode_soft_blocks(oracle_mod, nsoft, nblk):
         assert np.array_equal(ref[: nsoft // 2 - 6], out[b, : nsoft // 2 - 6]), b
 
 
-def test_continuous_streams(oracle_mod):
+def test_continuous_streams(oracle_mod, layout):
     """= JConvolutionalCodec::Decode_Continuous per stream, overlap state carried across calls; full-size 10.5k blocks
     (5078 soft bytes) and 1200 bps blocks (662)."""
     from jaero_amd import capi
 
     O, L = oracle_mod, capi.lib()
-    for nsoft in (5078, 662):
+    for nsoft in (5078, 662, 4992):
         nstreams = 7
         rng = np.random.default_rng(nsoft + 1)
         ov = np.zeros((nstreams, 64), np.uint8)
         codecs = [O.Codec(24) for _ in range(nstreams)]
         for it in range(4):
+            if it == 2:  # streams 4.. restart: blocks with and without an overlap prefix in the same launch
+                ov[4:] = 0
+                codecs[4:] = [O.Codec(24) for _ in range(nstreams - 4)]
             soft = rng.integers(0, 256, size=(nstreams, nsoft), dtype=np.uint8)
             out = np.zeros((nstreams, nsoft // 2), np.uint8)
             nb = np.zeros(nstreams, np.int32)
@@ -51,7 +61,7 @@ def test_continuous_streams(oracle_mod):
             for s in range(nstreams):
                 ref = codecs[s].decode_continuous(soft[s])
                 assert len(ref) == nb[s]
-                k = nb[s] - 8 if it == 0 else nb[s]  # tail of the very first block is undefined in the reference
+                k = nb[s] - 8 if (it == 0 or (it == 2 and s >= 4)) else nb[s]  # tail of a stream's first block is undefined in the reference
                 assert np.array_equal(ref[:k], out[s, :k])
 
 
@@ -77,3 +87,36 @@ def test_device_pointers_and_roundtrip_property(oracle_mod):
     torch.cuda.synchronize()
     want = torch.from_numpy(np.unpackbits(msg)).cuda()
     assert bool((out[:, : want.numel()] == want[None, :]).all())
+
+
+def test_lane_layout_bank_vs_wave_layout(oracle_mod, monkeypatch):
+    """20000 blocks (the size at which the library switches to one block per lane by itself; last wavefront ragged): every decoded bit
+    equal to the one-block-per-wavefront kernel's, and a sample of blocks equal to the oracle's."""
+    import torch
+
+    from jaero_amd import capi
+
+    O, L = oracle_mod, capi.lib()
+    nblk, nsoft = 20000, 1210
+    g = torch.Generator(device="cuda").manual_seed(7)
+    soft = torch.randint(0, 256, (nblk, nsoft), device="cuda", dtype=torch.uint8, generator=g)
+    soft[::3] = (soft[::3] // 64) * 64 + 31   # coarse values: many exact metric ties
+    soft[5] = 128
+    soft[6] = 255
+    soft[7] = 0
+    outs = {}
+    for lay in ("wave", "auto"):
+        if lay == "auto":
+            monkeypatch.delenv("JAERO_VITERBI_LAYOUT", raising=False)
+        else:
+            monkeypatch.setenv("JAERO_VITERBI_LAYOUT", lay)
+        out = torch.zeros((nblk, nsoft // 2), dtype=torch.uint8, device="cuda")
+        capi.check(L.jaero_viterbi_decode_soft(0, soft.data_ptr(), nblk, nsoft, out.data_ptr(), 1, None))
+        torch.cuda.synchronize()
+        outs[lay] = out
+    assert bool((outs["wave"] == outs["auto"]).all())
+    h = soft.cpu().numpy()
+    o = outs["auto"].cpu().numpy()
+    for b in (0, 3, 5, 6, 7, 63, 64, 19999):
+        ref = O.Codec().decode_soft(h[b])
+        assert np.array_equal(ref[: nsoft // 2 - 6], o[b, : nsoft // 2 - 6]), b
