@@ -12,6 +12,11 @@
 // The 64 decision bits of a step are two VGPRs; the 140-slice history ring is [wave][slice][lane] uint64 in global memory (written
 // and read back as coalesced 512-byte rows -- libcorrect's traceback schedule depends only on the step count, so all lanes trace
 // back at the same steps).  Blocks whose overlap length differs (the first block of a stream has none) run as separate passes.
+// Soft bytes reach the steps through LDS (64-step chunks of every lane's row, [group][lane] uint4), so the step loop has no vmcnt
+// wait: the history store of a step is never waited for except in the traceback.
+// Measured (MI355X, 65536 blocks of 5078 soft bytes, one wavefront per SIMD): 1.77 ms per launch = 0.70 ns per block and step;
+// 1.35 ms of it is the step loop (a lone wavefront issues one VALU instruction per ~2.2 ns, 225 instructions per step), 0.4 ms the
+// tracebacks (5 x ~1.5 us of exposed history-load latency each).  k_viterbi.h on the same input: 11.5 ms.
 #pragma once
 #include "k_viterbi.h"
 #include <utility>
@@ -179,8 +184,10 @@ struct VlRun // wave-uniform bookkeeping of history_buffer
     int index, len, renorm, outpos;
 };
 
+#define VL_TB_BATCH 28 // history slices fetched together in the traceback (VT_CAP = 5 batches; 56 VGPRs)
+
 // hist: [gridDim.x][VT_CAP][64] uint64 scratch.  Same stream convention as k_viterbi (overlap ++ soft ++ pad x 128).
-__global__ __launch_bounds__(64) void k_viterbi_lanes(const uint8_t *__restrict__ soft, int nsoft, const uint8_t *__restrict__ overlap, int pad,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_viterbi_lanes(const uint8_t *__restrict__ soft, int nsoft, const uint8_t *__restrict__ overlap, int pad,
                                                       uint8_t *__restrict__ out, int out_stride, int out_start, int out_want, int nblocks,
                                                       const int *__restrict__ valid, unsigned long long *__restrict__ hist)
 {
@@ -195,25 +202,43 @@ __global__ __launch_bounds__(64) void k_viterbi_lanes(const uint8_t *__restrict_
     const int my_ovl = overlap ? (int)ov[62] : 0;
     uint8_t *o = out + (size_t)b * out_stride;
     unsigned long long *hw = hist + (size_t)blockIdx.x * VT_CAP * 64 + lane;
+    const bool rows16 = ((((size_t)soft) | (size_t)nsoft) & 15) == 0; // every row of the bank 16-byte aligned (the Aero-L bank's are)
+    __shared__ uint4 lds_soft[8 * 64];
 
     while (__any(todo))
     {
         // this pass: the lanes whose overlap length equals that of the first pending lane
-        const int ovl = __shfl(my_ovl, __ffsll((long long)__ballot(todo)) - 1);
+        const int ovl = __builtin_amdgcn_readfirstlane(__shfl(my_ovl, __ffsll((long long)__ballot(todo)) - 1)); // SGPR: all control flow below is scalar
         const bool mine = todo && my_ovl == ovl;
         todo = todo && !mine;
         const int total = ovl + nsoft + pad;
         const int sets = total / 2;
 
-        auto getpair = [&](int i, unsigned &s0, unsigned &s1) { // soft bytes 2i, 2i+1 of the stream (ovl is even: 0 or 62)
-            const int k = 2 * i;
-            if (k + 1 < ovl) { const unsigned v = *(const unsigned short *)(ov + k); s0 = v & 255u; s1 = v >> 8; }
-            else if (k >= ovl && k - ovl + 1 < nsoft) { const unsigned v = *(const unsigned short *)(in + (k - ovl)); s0 = v & 255u; s1 = v >> 8; }
-            else
+        auto getpair = [&](int i, unsigned &s0, unsigned &s1) { // soft bytes 2i, 2i+1 of the stream, any position (slow)
+            auto one = [&](int q) -> unsigned { return q < ovl ? ov[q] : (q - ovl < nsoft ? in[q - ovl] : 128u); };
+            s0 = one(2 * i); s1 = one(2 * i + 1);
+        };
+        // Fast source for the steps whose two soft bytes lie inside a 16-byte aligned block: 128-byte chunks (64 steps) of every lane's
+        // row are staged in LDS as [group][lane] uint4, fetched one chunk ahead into registers.  The per-step reads are then LDS reads
+        // (lgkmcnt): the history store of every step (vmcnt) is never waited for outside the traceback.
+        const int fast_lo = (ovl + 1) / 2, fast_hi = (rows16 && (ovl & 1) == 0) ? (ovl + nsoft) / 2 : 0; // steps [fast_lo, fast_hi)
+        const uint4 *cp = (const uint4 *)__builtin_assume_aligned(in, 16);
+        const int ngroups = nsoft / 16;
+        const unsigned short *lp = (const unsigned short *)lds_soft + lane * 8;
+        int chunk = -1;
+        auto need_chunk = [&](int c) { // one exposed load latency per 64 steps (the compiler sinks any earlier prefetch down to here)
+            if (c == chunk) return;
+#pragma unroll
+            for (int g = 0; g < 8; g++)
             {
-                auto one = [&](int q) -> unsigned { return q < ovl ? ov[q] : (q - ovl < nsoft ? in[q - ovl] : 128u); };
-                s0 = one(k); s1 = one(k + 1);
+                const int gi = c * 8 + g;
+                lds_soft[g * 64 + lane] = cp[gi < ngroups ? gi : ngroups - 1];
             }
+            chunk = c;
+        };
+        auto ldspair = [&](int t, unsigned &s0, unsigned &s1) { // step slot t of the staged chunk
+            const unsigned v = lp[(t >> 3) * 512 + (t & 7)];
+            s0 = v & 255u; s1 = v >> 8;
         };
 
         unsigned R[32], T[32];
@@ -221,60 +246,60 @@ __global__ __launch_bounds__(64) void k_viterbi_lanes(const uint8_t *__restrict_
         for (int k = 0; k < 32; k++) R[k] = 0;
         VlRun h = {0, 0, 0, 0};
 
+        // history_buffer_traceback.  Slices are fetched VL_TB_BATCH at a time (their addresses do not depend on the path).  Iteration j
+        // (newest slice first) yields decoded bit k(j) = K0 - j once j >= min_tb; four iterations make one 4-byte store (one bit per
+        // byte, ascending k = descending j); groups that straddle min_tb, len or the output window go byte by byte.
         auto traceback = [&](unsigned bestpath, int min_tb) {
+            const int len = h.len, f = len - min_tb;
+            const int K0 = h.outpos + f - 1 + min_tb - out_start;
             int index = h.index;
-            const int f = h.len - min_tb;
-            unsigned word = 0; // decoded bits (one per byte) collected newest first = descending output index; stored four at a time
-            int cnt = 0;
-#pragma unroll 4
-            for (int j = 0; j < h.len; j++)
+#pragma nounroll
+            for (int j0 = 0; j0 < len; j0 += VL_TB_BATCH)
             {
-                index = (index == 0) ? VT_CAP - 1 : index - 1;
-                const unsigned long long w = hw[(size_t)index * 64];
-                const unsigned hb = (unsigned)(w >> vl_bitpos(bestpath)) & 1u;
-                bestpath = (bestpath | (hb << 6)) >> 1;
-                if (j >= min_tb)
+                unsigned long long wv[VL_TB_BATCH];
+#pragma unroll
+                for (int u = 0; u < VL_TB_BATCH; u++)
                 {
-                    const int k = h.outpos + (f - 1 - (j - min_tb)) - out_start; // fetched[] is newest first, written reversed
-                    word = (word << 8) | hb;
-                    cnt++;
-                    if (cnt == 4 || j == h.len - 1)
+                    index = (index == 0) ? VT_CAP - 1 : index - 1;
+                    wv[u] = hw[(size_t)index * 64]; // slices beyond len are read (valid scratch) and their bits discarded
+                }
+#pragma unroll
+                for (int g = 0; g < VL_TB_BATCH / 4; g++)
+                {
+                    unsigned word = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
                     {
-                        if (mine)
+                        const unsigned hb = (unsigned)(wv[4 * g + u] >> vl_bitpos(bestpath)) & 1u;
+                        bestpath = (bestpath | (hb << 6)) >> 1;
+                        word = (word << 8) | hb;
+                    }
+                    const int j = j0 + 4 * g, klow = K0 - (j + 3);
+                    if (j >= min_tb && j + 3 < len && klow >= 0 && klow + 3 < out_want)
+                    {
+                        if (mine) __builtin_memcpy(o + klow, &word, 4);
+                    }
+                    else
+                    {
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
                         {
-                            if (cnt == 4 && k >= 0 && k + 3 < out_want) __builtin_memcpy(o + k, &word, 4);
-                            else
-                                for (int t = 0; t < cnt; t++)
-                                    if (k + t >= 0 && k + t < out_want) o[k + t] = (uint8_t)(word >> (8 * t));
+                            const int jj = j + u, k = K0 - jj;
+                            if (jj >= min_tb && jj < len && k >= 0 && k < out_want && mine) o[k] = (uint8_t)(word >> (8 * (3 - u)));
                         }
-                        cnt = 0;
-                        word = 0;
                     }
                 }
             }
             h.outpos += f;
             h.len -= f;
+            // slices fetched beyond len are never read: retire them here, or the compiler guards the first reuse of their registers --
+            // inside the step loop -- with a vmcnt(0) that then also waits for every step's history store
+            __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
         };
-        auto after = [&](unsigned (&P)[32], unsigned long long w, unsigned skip) { // history_buffer_process_skip
+        auto record = [&](unsigned long long w) { // history_buffer_process_skip minus the renormalise / traceback events
             hw[(size_t)h.index * 64] = w;
             h.index++;
             if (h.index == VT_CAP) h.index = 0;
-            h.renorm++;
-            h.len++;
-            if (h.renorm == VT_RENORM)
-            {
-                h.renorm = 0;
-                unsigned sub;
-                const unsigned best = vl_search(P, skip, sub);
-                vl_renorm(P, skip, sub);
-                if (h.len == VT_CAP) traceback(best, VT_MINTB);
-            }
-            else if (h.len == VT_CAP)
-            {
-                unsigned sub;
-                const unsigned best = vl_search(P, skip, sub);
-                traceback(best, VT_MINTB);
-            }
         };
         auto copy = [&]() {
 #pragma unroll
@@ -282,7 +307,7 @@ __global__ __launch_bounds__(64) void k_viterbi_lanes(const uint8_t *__restrict_
         };
 
         int i = 0;
-        unsigned s0, s1;
+        unsigned s0, s1, c0, c1;
         for (; i < VT_ORDER - 1 && i < sets; i++) // warm-up
         {
             getpair(i, s0, s1);
@@ -290,57 +315,93 @@ __global__ __launch_bounds__(64) void k_viterbi_lanes(const uint8_t *__restrict_
             copy();
         }
         const int nend = sets - VT_ORDER + 1; // first tail step
-        auto single = [&]() {
-            getpair(i, s0, s1);
-            const unsigned long long w = vl_step<0>(R, T, s0, s1);
-            copy();
-            after(R, w, 1);
-            i++;
-        };
-        // steady state.  Rows that are 16-byte aligned (the Aero-L bank's are): single steps until step i starts a 16-byte group of
-        // the block, then 8 steps per 16-byte load (the next group requested while this one is decoded), two steps per iteration
-        // (R -> T -> R).  Everything else, and the ends, one step at a time.
-        const bool rows16 = ((((size_t)soft) | (size_t)nsoft) & 15) == 0;
-        if (rows16)
+        // Steady state + tail.  libcorrect renormalises every VT_RENORM steps and traces back whenever VT_CAP slices are buffered: both
+        // are functions of the step count alone, so the steps run in event-free stretches (two per iteration, R -> T -> R) and the
+        // events are handled at one place, on R.
+        for (;;)
         {
-            while (i < nend && (2 * i < ovl || ((2 * i - ovl) & 15) != 0)) single();
-            int ngroups = 0;
-            if (i < nend) ngroups = min((nend - i) / 8, (nsoft - (2 * i - ovl)) / 16);
-            if (ngroups > 0)
+            unsigned skip = 1;
+            if (i < nend)
             {
-                const uint4 *cp = (const uint4 *)__builtin_assume_aligned(in + (2 * i - ovl), 16);
-                uint4 nx = cp[0];
-                for (int c = 0; c < ngroups; c++)
+                int run = min(nend - i, min(VT_RENORM - h.renorm, VT_CAP - h.len));
+                if (i >= fast_lo && i < fast_hi)
                 {
-                    uint4 cur = nx;
-                    if (c + 1 < ngroups) nx = cp[c + 1];
-#pragma nounroll
-                    for (int q = 0; q < 4; q++)
+                    const int pbyte = 2 * i - ovl;
+                    need_chunk(pbyte >> 7);
+                    int t = (pbyte & 127) >> 1;
+                    run = min(run, min(64 - t, fast_hi - i));
+                    h.renorm += run;
+                    h.len += run;
+                    i += run;
+                    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) here, so that no wait for an older load lands inside the step loop
+                    unsigned ra = 0x8080u, rb = 0x8080u; // raw byte pairs; split at use so the LDS latency hides behind a pair of steps
+                    if (run >= 2) { ra = lp[(t >> 3) * 512 + (t & 7)]; rb = lp[((t + 1) >> 3) * 512 + ((t + 1) & 7)]; }
+                    for (; run >= 2; run -= 2, t += 2)
                     {
-                        const unsigned wd = cur.x;
-                        cur.x = cur.y; cur.y = cur.z; cur.z = cur.w;
-                        unsigned long long w = vl_step<0>(R, T, wd & 255u, (wd >> 8) & 255u);
-                        after(T, w, 1);
-                        w = vl_step<0>(T, R, (wd >> 16) & 255u, wd >> 24);
-                        after(R, w, 1);
+                        unsigned na = 0x8080u, nb = 0x8080u;
+                        if (run >= 4) { na = lp[((t + 2) >> 3) * 512 + ((t + 2) & 7)]; nb = lp[((t + 3) >> 3) * 512 + ((t + 3) & 7)]; }
+                        unsigned long long w = vl_step<0>(R, T, ra & 255u, ra >> 8);
+                        record(w);
+                        w = vl_step<0>(T, R, rb & 255u, rb >> 8);
+                        record(w);
+                        ra = na; rb = nb;
                     }
-                    i += 8;
+                    if (run)
+                    {
+                        ldspair(t, s0, s1);
+                        const unsigned long long w = vl_step<0>(R, T, s0, s1);
+                        copy();
+                        record(w);
+                    }
+                }
+                else
+                {
+                    getpair(i, s0, s1);
+                    const unsigned long long w = vl_step<0>(R, T, s0, s1);
+                    copy();
+                    record(w);
+                    h.renorm++;
+                    h.len++;
+                    i++;
                 }
             }
+            else
+            {
+                // tail: i = sets-6 .. sets-1, only multiples of skip = 2, 4, .. 64 are updated
+                getpair(i, s0, s1);
+                const int kk = VT_ORDER - (sets - i);
+                unsigned long long w = 0;
+                switch (kk)
+                {
+                case 1: w = vl_step<1>(R, T, s0, s1); break;
+                case 2: w = vl_step<2>(R, T, s0, s1); break;
+                case 3: w = vl_step<3>(R, T, s0, s1); break;
+                case 4: w = vl_step<4>(R, T, s0, s1); break;
+                case 5: w = vl_step<5>(R, T, s0, s1); break;
+                default: w = vl_step<6>(R, T, s0, s1); break;
+                }
+                copy();
+                record(w);
+                skip = 1u << kk;
+                h.renorm++;
+                h.len++;
+                i++;
+            }
+            // events, one code site each (the traceback is large): renormalise every VT_RENORM steps, trace back when VT_CAP slices are
+            // buffered, and after the last step flush from state 0 (history_buffer_flush)
+            const bool last = i >= sets;
+            const bool ren = h.renorm == VT_RENORM, full = h.len == VT_CAP;
+            unsigned best = 0;
+            if (ren || full)
+            {
+                unsigned sub;
+                best = vl_search(R, skip, sub);
+                if (ren) { h.renorm = 0; vl_renorm(R, skip, sub); }
+            }
+#pragma nounroll
+            for (int pass = 0; pass < 2; pass++)
+                if (pass == 0 ? full : last) traceback(pass == 0 ? best : 0u, pass == 0 ? VT_MINTB : 0);
+            if (last) break;
         }
-        while (i < nend) single();
-        // tail: i = sets-6 .. sets-1, skip = 2, 4, .. 64
-#define VL_TAIL(K)                                               \
-    if (i < sets && sets - i == VT_ORDER - (K))                  \
-    {                                                            \
-        getpair(i, s0, s1);                                      \
-        const unsigned long long w = vl_step<K>(R, T, s0, s1);   \
-        copy();                                                  \
-        after(R, w, 1u << (K));                                  \
-        i++;                                                     \
-    }
-        VL_TAIL(1) VL_TAIL(2) VL_TAIL(3) VL_TAIL(4) VL_TAIL(5) VL_TAIL(6)
-#undef VL_TAIL
-        traceback(0u, 0); // history_buffer_flush
     }
 }
