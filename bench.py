@@ -196,20 +196,24 @@ def aerol_bench():
     fb, flen = 10500, 5250
     nuniq = 64
     streams = []
+    prng = np.random.default_rng(77 + rank)
     for u in range(nuniq):
-        bits, _ = AF.p_channel_bits(AF.random_payloads(K + W, fb, seed=900 + u + 1000 * rank), fb, invert_i=bool(u & 1), invert_q=bool(u & 2))
-        streams.append(AF.to_soft(bits, sigma=25.0, seed=u))
+        # every channel of a wavefront at its own frame phase (a random-length prefix of noise), as unsynchronised satellites would be
+        bits, _ = AF.p_channel_bits(AF.random_payloads(K + W + 1, fb, seed=900 + u + 1000 * rank), fb, invert_i=bool(u & 1), invert_q=bool(u & 2))
+        pre = prng.integers(0, 2, size=int(prng.integers(0, flen)), dtype=np.uint8)
+        streams.append(AF.to_soft(np.concatenate([pre, bits])[: (K + W) * flen], sigma=25.0, seed=u))
     host = np.stack(streams)  # [nuniq, (K+W)*5250]
     soft = torch.from_numpy(host).to(dev)
     idx = torch.arange(nch, device=dev) % nuniq
     counts = torch.full((nch,), flen, dtype=torch.int32, device=dev)
-    bank = AeroLBank(nch, fb, device=local, max_softbits_per_write=flen, su_capacity=26 * (K + W) + 8)
+    bank = AeroLBank(nch, fb, device=local, max_softbits_per_write=flen + 8, su_capacity=26 * (K + W) + 8)
     stream = torch.cuda.current_stream().cuda_stream
-    frame = torch.empty((nch, flen), dtype=torch.int16, device=dev)
+    pitch = (flen + 7) // 8 * 8  # 16-byte aligned rows, as a demodulator bank's soft-bit buffer has
+    frame = torch.empty((nch, pitch), dtype=torch.int16, device=dev)
 
     def step(i):
-        frame.copy_(soft[idx, i * flen:(i + 1) * flen])  # staging of the synthetic input (a demodulator bank writes it in place)
-        bank.write_device(frame.data_ptr(), counts.data_ptr(), flen, flen, stream)
+        frame[:, :flen].copy_(soft[idx, i * flen:(i + 1) * flen])  # staging of the synthetic input (a demodulator bank writes it in place)
+        bank.write_device(frame.data_ptr(), counts.data_ptr(), pitch, flen, stream)
 
     for i in range(W):
         step(i)
@@ -248,7 +252,7 @@ def aerol_bench():
             "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{nch}-channel-per-GPU 10.5 kbps P-channel frames (5250 soft bits = 0.5 s per step and channel), "
-                                   f"{nuniq} distinct noisy frame streams replicated over the channels, arm inversions mixed",
+                                   f"{nuniq} distinct noisy frame streams at random frame phases replicated over the channels, arm inversions mixed",
                        "channels_per_gpu": nch, "total_channels": nch * world, "realtime_channel_equivalents": int(value * 1e6 / 10500),
                        "crc_clean_units_in_first_channels": good, "channels_checked": min(4, nch),
                        "kernel_ms_total": {k: round(v, 3) for k, v in ms.items()}, "kernel_launches": nl},

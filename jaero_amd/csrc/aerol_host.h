@@ -109,12 +109,14 @@ extern "C" int jaero_aerol_create(int device, int nchannels, int fb, int max_sof
     default: g.N = 78; g.dl2_sz = 4992 - 6 + 1; g.NumberOfBits = 4992; g.BitsInHeader = 16 + 178; g.TotalNumberOfBits = 16 + 178 + 4992 + 64; g.oqpsk = 1; break;
     }
     g.blocksz = g.N * 64;
+    g.idx_sat = (1000000000 - g.BitsInHeader) % g.blocksz;
     g.info_cap = g.NumberOfBits / 16 + 16;
     if (su_capacity <= 0) su_capacity = 32 * (g.NumberOfBits / 2 / 96) + 8; // 32 frames between reads
     g.su_cap = su_capacity; g.ev_cap = 256;
     int rc;
 #define AA(ptr, count) do { if ((rc = aalloc(c, &(ptr), (size_t)(count)))) { jaero_aerol_destroy(c); return rc; } } while (0)
     AA(c->p.I, (size_t)AI_NFIELDS * g.nchp);
+    AA(c->p.rx, (size_t)g.nchp * g.blocksz);
     AA(c->p.deint, (size_t)g.nchp * g.blocksz);
     AA(c->p.vbits, (size_t)g.nchp * (g.blocksz / 2));
     AA(c->p.overlap, (size_t)g.nchp * 64);
@@ -182,10 +184,13 @@ extern "C" int jaero_aerol_write(jaero_aerol_ctx *c, const int16_t *soft, const 
     const int rounds = max_count / g.blocksz + 2;
     const int *valid = c->p.I + (size_t)AI_HAS_BLOCK * g.nchp;
     const dim3 grid(g.nchp / 64), block(64);
+    const bool rows16 = ((((size_t)dsoft) | ((size_t)stride * 2)) & 15) == 0 && stride >= 8; // 16-byte aligned rows: LDS-staged input
     for (int r = 0; r < rounds; r++)
     {
         aprof_begin(c, 0, st);
-        hipLaunchKernelGGL(k_aerol_bits, grid, block, 0, st, g, c->p, dsoft, dcounts, stride);
+        if (rows16) hipLaunchKernelGGL(k_aerol_bits<true>, grid, block, 0, st, g, c->p, dsoft, dcounts, stride);
+        else hipLaunchKernelGGL(k_aerol_bits<false>, grid, block, 0, st, g, c->p, dsoft, dcounts, stride);
+        hipLaunchKernelGGL(k_aerol_deint, dim3((g.nch + 3) / 4), dim3(256), 0, st, g, c->p);
         aprof_end(c, st);
         aprof_begin(c, 1, st);
         viterbi_launch(st, (const uint8_t *)c->p.deint, g.blocksz, (const uint8_t *)c->p.overlap, 24, c->p.vbits, g.blocksz / 2, 25, g.blocksz / 2,

@@ -473,7 +473,7 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
     JGeom &g = c->g;
     if (softbit_capacity <= 0)
         softbit_capacity = (int)ceil(2.0 * max_write_samples * g.fb / g.Fs) + 64;
-    g.soft_cap = (softbit_capacity + 1) & ~1;
+    g.soft_cap = (softbit_capacity + 7) & ~7; // 16-byte aligned rows: what the Aero-L bank's fast input path wants when it reads this buffer in place
     g.sym_cap = (flags & JAERO_FLAG_CAPTURE_SYMBOLS) ? g.soft_cap / 2 + 8 : 0;
     g.log_cap = (flags & JAERO_FLAG_STATUS_LOG) ? (int)ceil(g.soft_cap * g.Fs / g.fb / (g.nfft / 4)) + 16 : 0;
     const int nchp = g.nchp, ng = g.ngroups;

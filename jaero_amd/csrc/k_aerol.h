@@ -1,8 +1,8 @@
 // k_aerol.h -- the Aero-L bit pipeline around the Viterbi decoder, continuous P-channel path of
 // AeroL::Decode(bits, soft=true) (JAERO/aerol.cpp:1124-2039) for 600 / 1200 / 10500 bps, one channel per lane:
 //   k_aerol_bits : unique-word detection + I/Q ambiguity (PreambleDetector / PreambleDetectorPhaseInvariant, aerol.cpp:744-804),
-//                  frame counter and header (:1274-1322), block fill straight into DEINTERLEAVED order (AeroLInterleaver::
-//                  deinterleave_ba, :603-625, folded into the store address), runs until the channel has a full block
+//                  frame counter and header (:1274-1322), block fill in received order; runs until the channel has a full block
+//   k_aerol_deint: AeroLInterleaver::deinterleave_ba (:603-625) of the completed blocks, one wavefront per channel through LDS
 //   k_viterbi    : JConvolutionalCodec::Decode_Continuous for the channels that completed a block (k_viterbi.h)
 //   k_aerol_post : DelayLine dl2 (:1560), AeroLScrambler (:1563), byte packing (:1566-1578), and at the end of a frame the CRC-16
 //                  of every 12-byte signal unit with the data-carrier-detect bookkeeping (:1583-1600)
@@ -18,17 +18,18 @@ enum
 {
     AI_CNTR, AI_DATACD, AI_DCDCOUNT, AI_GOTSYNC_LAST, AI_REALIMAG, AI_BLOCKCNT, AI_MUW, AI_FRAMEINFO, AI_LASTFRAMEINFO,
     AI_PD_EXACT, AI_PD_IMAG, AI_PD_REAL, AI_INV_IMAG, AI_INV_REAL, AI_SCR_POS, AI_DL2_PTR, AI_NINFO, AI_NFRAMES,
-    AI_IN_POS, AI_RESUME, AI_RESUME_GOTSYNC, AI_HAS_BLOCK, AI_VBLOCKS, AI_SU_CNT, AI_EV_CNT, AI_OVERFLOW, AI_NBITS_LO, AI_NBITS_HI,
+    AI_IN_POS, AI_RESUME, AI_RESUME_GOTSYNC, AI_HAS_BLOCK, AI_VBLOCKS, AI_SU_CNT, AI_EV_CNT, AI_OVERFLOW, AI_NBITS_LO, AI_NBITS_HI, AI_ACC,
     AI_NFIELDS
 };
 struct AGeom
 {
-    int nch, nchp, fb, oqpsk, N, blocksz, dl2_sz, NumberOfBits, BitsInHeader, TotalNumberOfBits, su_cap, ev_cap, info_cap;
+    int nch, nchp, fb, oqpsk, N, blocksz, dl2_sz, NumberOfBits, BitsInHeader, TotalNumberOfBits, su_cap, ev_cap, info_cap, idx_sat;
 };
 struct APtrs
 {
     int *I;              // [AI_NFIELDS][nchp]
-    uint8_t *deint;      // [nchp][blocksz]   deinterleaved soft bytes of the block being filled
+    uint8_t *rx;         // [nchp][blocksz]   soft bytes of the block being filled, received order
+    uint8_t *deint;      // [nchp][blocksz]   the last completed block, deinterleaved
     uint8_t *vbits;      // [nchp][blocksz/2] decoded bits of the last completed block
     uint8_t *overlap;    // [nchp][64]        Decode_Continuous overlap state (k_viterbi convention)
     uint8_t *dl2;        // [nchp][dl2_sz]
@@ -50,113 +51,221 @@ __device__ __forceinline__ void aerol_event(const AGeom &g, const APtrs &p, int 
     else overflow |= 2;
 }
 
-__global__ void k_aerol_bits(const AGeom g, const APtrs p, const int16_t *__restrict__ soft, const int *__restrict__ counts, int stride)
+// One soft bit of AeroL::Decode for one channel, in two parts: everything up to and including the block store (part A; returns true
+// when the store completed an interleaver block -- the rest of this soft bit then waits for the block's Viterbi + post pass), and
+// the unique-word / frame-length handling after it (part B).
+struct ABitState
 {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= g.nch) return;
-    int cntr = ALD(AI_CNTR), datacd = ALD(AI_DATACD), gotsync_last = ALD(AI_GOTSYNC_LAST), realimag = ALD(AI_REALIMAG);
-    int blockcnt = ALD(AI_BLOCKCNT), muw = ALD(AI_MUW), ninfo = ALD(AI_NINFO);
-    unsigned frameinfo = (unsigned)ALD(AI_FRAMEINFO), lastframeinfo = (unsigned)ALD(AI_LASTFRAMEINFO);
-    unsigned pd_exact = (unsigned)ALD(AI_PD_EXACT), pd_imag = (unsigned)ALD(AI_PD_IMAG), pd_real = (unsigned)ALD(AI_PD_REAL);
-    int inv_imag = ALD(AI_INV_IMAG), inv_real = ALD(AI_INV_REAL), scr_pos = ALD(AI_SCR_POS), dcdcount = ALD(AI_DCDCOUNT);
-    int pos = ALD(AI_IN_POS), resume = ALD(AI_RESUME), ev_cnt = ALD(AI_EV_CNT), overflow = ALD(AI_OVERFLOW);
-    const long long nbits0 = ((long long)(unsigned)ALD(AI_NBITS_LO)) | ((long long)ALD(AI_NBITS_HI) << 32);
-    const int n = counts[ch];
-    const int16_t *sb = soft + (size_t)ch * stride;
-    uint8_t *deint = p.deint + (size_t)ch * g.blocksz;
-    int has_block = 0;
-    int gotsync = resume ? ALD(AI_RESUME_GOTSYNC) : 0;
-
-    while (pos < n || resume)
+    int cntr, datacd, gotsync_last, realimag, blockcnt, muw, ninfo, inv_imag, inv_real, scr_pos, dcdcount, ev_cnt, overflow;
+    unsigned frameinfo, lastframeinfo, pd_exact, pd_imag, pd_real, acc;
+};
+__device__ __forceinline__ bool aerol_bit_a(const AGeom &g, ABitState &s, int v, int &gotsync, uint8_t *rx)
+{
+    int bit = (((unsigned)v & 0xFFu) >= 128u) ? 1 : 0;
+    unsigned soft_bit = (unsigned)v & 0xFFFFu;
+    if (s.muw < 100000) s.muw++;
+    if (g.oqpsk)
     {
-        const long long bitidx = nbits0 + pos;
-        if (!resume)
+        s.realimag ^= 1;
+        unsigned pd = s.realimag ? s.pd_imag : s.pd_real;
+        int inverted = s.realimag ? s.inv_imag : s.inv_real;
+        if (s.cntr > g.NumberOfBits - 68 || s.cntr <= 0 || !s.datacd)
         {
-            const int v = sb[pos];
-            if (v < 0) { muw = 0; pos++; continue; } // start-of-burst marker (aerol.cpp:1146-1152)
-            int bit = (((unsigned)v & 0xFFu) >= 128u) ? 1 : 0;
-            unsigned soft_bit = (unsigned)v & 0xFFFFu;
-            if (muw < 100000) muw++;
-            if (g.oqpsk)
-            {
-                realimag++; realimag %= 2;
-                unsigned &pd = realimag ? pd_imag : pd_real;
-                int &inverted = realimag ? inv_imag : inv_real;
-                if (cntr > g.NumberOfBits - 68 || cntr <= 0 || !datacd)
-                {
-                    // PreambleDetectorPhaseInvariant::Update, tolerance 0 outside burst mode (aerol.cpp:781-804, 1009-1016)
-                    pd = (pd << 1) | (unsigned)bit;
-                    const int xorsum = __popc(pd ^ AEROL_UW);
-                    gotsync = 0;
-                    if (xorsum >= 32) { inverted = 1; gotsync = 1; }
-                    else if (xorsum <= 0) { inverted = 0; gotsync = 1; }
-                    if (!gotsync_last) { gotsync_last = gotsync; gotsync = 0; }
-                    else gotsync_last = 0;
-                }
-                else { gotsync = 0; gotsync_last = 0; }
-                if (inverted)
-                {
-                    bit = 1 - bit;
-                    if (soft_bit > 128) soft_bit = 255 - soft_bit;
-                    else if (soft_bit < 128) soft_bit = 255 - soft_bit;
-                }
-            }
-            else
-            {
-                // PreambleDetector::Update (aerol.cpp:744-750): exact match, buffer cleared on a hit
-                pd_exact = (pd_exact << 1) | (unsigned)bit;
-                gotsync = 0;
-                if (pd_exact == AEROL_UW) { pd_exact = 0; gotsync = 1; }
-            }
-            if (cntr < 1000000000) cntr++;
-            if (cntr < 16)
-            {
-                if (cntr == 0) { frameinfo = (unsigned)bit; ninfo = 0; }
-                else { frameinfo = ((frameinfo << 1) | (unsigned)bit) & 0xFFFFu; }
-            }
-            if (cntr == 15)
-            {
-                const unsigned tval = frameinfo;
-                frameinfo = lastframeinfo;
-                lastframeinfo = tval;
-            }
-            if (cntr >= 16)
-            {
-                if (cntr == 16) blockcnt = -1;
-                int idx = (cntr - g.BitsInHeader) % g.blocksz;
-                if (idx < 0) idx = 0;
-                // deinterleave_ba: out[j*64 + i] = block[((i*27)%64)*N + j]  <=>  block[idx] goes to (idx%N)*64 + ((idx/N)*19)%64
-                deint[(idx % g.N) * 64 + (((idx / g.N) * 19) & 63)] = (uint8_t)soft_bit;
-                if (idx == g.blocksz - 1)
-                {
-                    blockcnt++;
-                    has_block = 1;
-                    resume = 1; // the rest of this soft bit (gotsync / frame-length handling) runs after the block's Viterbi + post pass
-                    break;
-                }
-            }
+            // PreambleDetectorPhaseInvariant::Update, tolerance 0 outside burst mode (aerol.cpp:781-804, 1009-1016)
+            pd = (pd << 1) | (unsigned)bit;
+            const int xorsum = __popc(pd ^ AEROL_UW);
+            gotsync = 0;
+            if (xorsum >= 32) { inverted = 1; gotsync = 1; }
+            else if (xorsum <= 0) { inverted = 0; gotsync = 1; }
+            if (!s.gotsync_last) { s.gotsync_last = gotsync; gotsync = 0; }
+            else s.gotsync_last = 0;
         }
-        resume = 0;
-        if (gotsync)
+        else { gotsync = 0; s.gotsync_last = 0; }
+        if (s.realimag) { s.pd_imag = pd; s.inv_imag = inverted; }
+        else { s.pd_real = pd; s.inv_real = inverted; }
+        if (inverted)
         {
-            if (cntr + 1 != g.TotalNumberOfBits) aerol_event(g, p, ch, ev_cnt, overflow, bitidx, 1, cntr + 1);
-            cntr = -1;
-            datacd = 1; dcdcount = 12;
-            aerol_event(g, p, ch, ev_cnt, overflow, bitidx, 0, 1);
-            aerol_event(g, p, ch, ev_cnt, overflow, bitidx, 2, 0);
-            scr_pos = 0;
+            bit = 1 - bit;
+            if (soft_bit != 128u) soft_bit = 255u - soft_bit;
         }
-        if (cntr + 1 == g.TotalNumberOfBits) { scr_pos = 0; cntr = -1; }
-        gotsync = 0;
-        pos++;
     }
-    ALD(AI_CNTR) = cntr; ALD(AI_DATACD) = datacd; ALD(AI_GOTSYNC_LAST) = gotsync_last; ALD(AI_REALIMAG) = realimag;
-    ALD(AI_BLOCKCNT) = blockcnt; ALD(AI_MUW) = muw; ALD(AI_NINFO) = ninfo;
-    ALD(AI_FRAMEINFO) = (int)frameinfo; ALD(AI_LASTFRAMEINFO) = (int)lastframeinfo;
-    ALD(AI_PD_EXACT) = (int)pd_exact; ALD(AI_PD_IMAG) = (int)pd_imag; ALD(AI_PD_REAL) = (int)pd_real;
-    ALD(AI_INV_IMAG) = inv_imag; ALD(AI_INV_REAL) = inv_real; ALD(AI_SCR_POS) = scr_pos; ALD(AI_DCDCOUNT) = dcdcount;
+    else
+    {
+        // PreambleDetector::Update (aerol.cpp:744-750): exact match, buffer cleared on a hit
+        s.pd_exact = (s.pd_exact << 1) | (unsigned)bit;
+        gotsync = 0;
+        if (s.pd_exact == AEROL_UW) { s.pd_exact = 0; gotsync = 1; }
+    }
+    if (s.cntr < 1000000000) s.cntr++;
+    if (s.cntr < 16)
+    {
+        if (s.cntr == 0) { s.frameinfo = (unsigned)bit; s.ninfo = 0; }
+        else { s.frameinfo = ((s.frameinfo << 1) | (unsigned)bit) & 0xFFFFu; }
+    }
+    if (s.cntr == 15)
+    {
+        const unsigned tval = s.frameinfo;
+        s.frameinfo = s.lastframeinfo;
+        s.lastframeinfo = tval;
+    }
+    if (s.cntr >= 16)
+    {
+        if (s.cntr == 16) s.blockcnt = -1;
+        // idx = (cntr - BitsInHeader) % blocksz, clamped at 0 (aerol.cpp:1330-1332).  cntr never exceeds TotalNumberOfBits except for
+        // its saturated start value, whose remainder the host precomputed.
+        int idx;
+        if (s.cntr >= 1000000000) idx = g.idx_sat;
+        else
+        {
+            idx = s.cntr - g.BitsInHeader;
+            if (idx < 0) idx = 0;
+            if (idx >= g.blocksz) idx -= g.blocksz;
+            if (idx >= g.blocksz) idx -= g.blocksz;
+            if (idx >= g.blocksz) idx -= g.blocksz;
+        }
+        // the block is kept in RECEIVED order, four soft bytes per store (idx runs 0, 1, 2, .. within a block, so the three bytes
+        // before an idx with (idx & 3) == 3 are the block's idx-3 .. idx-1); k_aerol_deint reorders completed blocks
+        s.acc = (s.acc >> 8) | (soft_bit << 24);
+        if ((idx & 3) == 3) *(unsigned *)(rx + (idx - 3)) = s.acc;
+        if (idx == g.blocksz - 1)
+        {
+            s.blockcnt++;
+            return true;
+        }
+    }
+    return false;
+}
+__device__ __forceinline__ void aerol_bit_b(const AGeom &g, const APtrs &p, int ch, ABitState &s, int &gotsync, long long bitidx)
+{
+    if (gotsync)
+    {
+        if (s.cntr + 1 != g.TotalNumberOfBits) aerol_event(g, p, ch, s.ev_cnt, s.overflow, bitidx, 1, s.cntr + 1);
+        s.cntr = -1;
+        s.datacd = 1; s.dcdcount = 12;
+        aerol_event(g, p, ch, s.ev_cnt, s.overflow, bitidx, 0, 1);
+        aerol_event(g, p, ch, s.ev_cnt, s.overflow, bitidx, 2, 0);
+        s.scr_pos = 0;
+    }
+    if (s.cntr + 1 == g.TotalNumberOfBits) { s.scr_pos = 0; s.cntr = -1; }
+    gotsync = 0;
+}
+
+// One wavefront = 64 channels, all walking the same input position P (a channel is live while P is its own position: it stops at
+// its count or when it completes a block).  The soft bits of the 64 rows are staged through LDS in chunks of 64 positions:
+// [group][lane] uint4 from 16-byte row loads when the rows are 16-byte aligned (ROWS16), [position][lane] from 2-byte loads otherwise.
+template <bool ROWS16>
+__global__ __launch_bounds__(64) void k_aerol_bits(const AGeom g, const APtrs p, const int16_t *__restrict__ soft, const int *__restrict__ counts, int stride)
+{
+    __shared__ uint4 lds_in[8 * 64 + 64]; // + one row: the look-ahead read of slot 64
+    const int lane = threadIdx.x;
+    const int ch0 = blockIdx.x * 64 + lane;
+    const bool valid = ch0 < g.nch;
+    const int ch = valid ? ch0 : 0;
+    ABitState s;
+    s.cntr = ALD(AI_CNTR); s.datacd = ALD(AI_DATACD); s.gotsync_last = ALD(AI_GOTSYNC_LAST); s.realimag = ALD(AI_REALIMAG);
+    s.blockcnt = ALD(AI_BLOCKCNT); s.muw = ALD(AI_MUW); s.ninfo = ALD(AI_NINFO);
+    s.frameinfo = (unsigned)ALD(AI_FRAMEINFO); s.lastframeinfo = (unsigned)ALD(AI_LASTFRAMEINFO);
+    s.pd_exact = (unsigned)ALD(AI_PD_EXACT); s.pd_imag = (unsigned)ALD(AI_PD_IMAG); s.pd_real = (unsigned)ALD(AI_PD_REAL);
+    s.inv_imag = ALD(AI_INV_IMAG); s.inv_real = ALD(AI_INV_REAL); s.scr_pos = ALD(AI_SCR_POS); s.dcdcount = ALD(AI_DCDCOUNT);
+    s.ev_cnt = ALD(AI_EV_CNT); s.overflow = ALD(AI_OVERFLOW); s.acc = (unsigned)ALD(AI_ACC);
+    int pos = ALD(AI_IN_POS), resume = ALD(AI_RESUME);
+    const long long nbits0 = ((long long)(unsigned)ALD(AI_NBITS_LO)) | ((long long)ALD(AI_NBITS_HI) << 32);
+    const int n = valid ? counts[ch] : 0;
+    const int16_t *sb = soft + (size_t)ch * stride;
+    uint8_t *rx = p.rx + (size_t)ch * g.blocksz;
+    int has_block = 0;
+    int gotsync = 0;
+    if (resume && valid)
+    {
+        // second half of the soft bit whose block store completed a block in the previous round
+        gotsync = ALD(AI_RESUME_GOTSYNC);
+        aerol_bit_b(g, p, ch, s, gotsync, nbits0 + pos);
+        pos++;
+        resume = 0;
+    }
+    bool live = valid && pos < n;
+    // wave-uniform range of positions still to be visited
+    int pmin = live ? pos : 0x7fffffff, pmax = live ? n : 0;
+    for (int o = 32; o > 0; o >>= 1) { pmin = min(pmin, __shfl_xor(pmin, o)); pmax = max(pmax, __shfl_xor(pmax, o)); }
+    pmin = __builtin_amdgcn_readfirstlane(pmin);
+    pmax = __builtin_amdgcn_readfirstlane(pmax);
+    const unsigned short *lp = (const unsigned short *)lds_in + lane * 8;
+    for (int base = pmin & ~63; base < pmax; base += 64)
+    {
+        if (!__any(live)) break;
+        if (ROWS16)
+        {
+#pragma unroll
+            for (int gq = 0; gq < 8; gq++)
+            {
+                int e = base + 8 * gq;
+                if (e + 8 > stride) e = stride - 8; // positions at or beyond the row end are never used (counts <= stride)
+                lds_in[gq * 64 + lane] = *(const uint4 *)(sb + e);
+            }
+        }
+        else
+        {
+            // rows of any alignment: 64 two-byte loads per lane, issued together ([position][lane] in LDS)
+            unsigned short *l16 = (unsigned short *)lds_in;
+#pragma unroll 16
+            for (int k = 0; k < 64; k++) l16[k * 64 + lane] = (unsigned short)sb[min(base + k, stride - 1)];
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): nothing older than this chunk is waited for inside the bit loop
+        const int tend = min(64, pmax - base);
+        const unsigned short *l16r = (const unsigned short *)lds_in + lane;
+        int vn = ROWS16 ? (int)(short)lp[0] : (int)(short)l16r[0]; // the LDS read of a position is issued one position ahead
+        for (int t = 0; t < tend; t++)
+        {
+            const int P = base + t;
+            const int v = vn;
+            // (slot 64 = one row past the chunk: inside the array, never used)
+            vn = ROWS16 ? (int)(short)lp[((t + 1) >> 3) * 512 + ((t + 1) & 7)] : (int)(short)l16r[(t + 1) * 64];
+            if (live && pos == P)
+            {
+                if (v < 0) { s.muw = 0; pos++; } // start-of-burst marker (aerol.cpp:1146-1152)
+                else if (aerol_bit_a(g, s, v, gotsync, rx)) { has_block = 1; resume = 1; live = false; }
+                else
+                {
+                    aerol_bit_b(g, p, ch, s, gotsync, nbits0 + P);
+                    pos++;
+                }
+                if (pos >= n) live = false;
+            }
+        }
+    }
+    if (!valid) return;
+    ALD(AI_CNTR) = s.cntr; ALD(AI_DATACD) = s.datacd; ALD(AI_GOTSYNC_LAST) = s.gotsync_last; ALD(AI_REALIMAG) = s.realimag;
+    ALD(AI_BLOCKCNT) = s.blockcnt; ALD(AI_MUW) = s.muw; ALD(AI_NINFO) = s.ninfo;
+    ALD(AI_FRAMEINFO) = (int)s.frameinfo; ALD(AI_LASTFRAMEINFO) = (int)s.lastframeinfo;
+    ALD(AI_PD_EXACT) = (int)s.pd_exact; ALD(AI_PD_IMAG) = (int)s.pd_imag; ALD(AI_PD_REAL) = (int)s.pd_real;
+    ALD(AI_INV_IMAG) = s.inv_imag; ALD(AI_INV_REAL) = s.inv_real; ALD(AI_SCR_POS) = s.scr_pos; ALD(AI_DCDCOUNT) = s.dcdcount;
     ALD(AI_IN_POS) = pos; ALD(AI_RESUME) = resume; ALD(AI_RESUME_GOTSYNC) = gotsync; ALD(AI_HAS_BLOCK) = has_block;
-    ALD(AI_EV_CNT) = ev_cnt; ALD(AI_OVERFLOW) = overflow;
+    ALD(AI_EV_CNT) = s.ev_cnt; ALD(AI_OVERFLOW) = s.overflow; ALD(AI_ACC) = (int)s.acc;
+}
+
+// AeroLInterleaver::deinterleave_ba (aerol.cpp:603-625) for the channels that completed a block this round, one wavefront per
+// channel: out[j*64 + i] = block[((i*27) % 64) * N + j].  The block goes through LDS (coalesced 16-byte reads of the received-order
+// row, 4-byte coalesced writes of the deinterleaved row).
+__global__ __launch_bounds__(256) void k_aerol_deint(const AGeom g, const APtrs p)
+{
+    __shared__ uint8_t blk[4][4992 + 16];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ch = blockIdx.x * 4 + w;
+    if (ch >= g.nch) return;
+    if (!ALD(AI_HAS_BLOCK)) return; // wave-uniform
+    const uint4 *src = (const uint4 *)(p.rx + (size_t)ch * g.blocksz);
+    uint4 *b16 = (uint4 *)blk[w];
+    for (int q = lane; q < g.blocksz / 16; q += 64) b16[q] = src[q];
+    // (one wavefront per block buffer: LDS accesses of a wave are in order, no barrier needed)
+    unsigned *dst = (unsigned *)(p.deint + (size_t)ch * g.blocksz);
+    const int i0 = (lane & 15) * 4;
+    const int r0 = ((i0 * 27) & 63) * g.N, r1 = (((i0 + 1) * 27) & 63) * g.N, r2 = (((i0 + 2) * 27) & 63) * g.N, r3 = (((i0 + 3) * 27) & 63) * g.N;
+    const uint8_t *bb = blk[w];
+    for (int j = lane >> 4; j < g.N; j += 4)
+    {
+        const unsigned v = (unsigned)bb[r0 + j] | ((unsigned)bb[r1 + j] << 8) | ((unsigned)bb[r2 + j] << 16) | ((unsigned)bb[r3 + j] << 24);
+        dst[j * 16 + (lane & 15)] = v;
+    }
 }
 
 __device__ __forceinline__ unsigned aerol_crc16(const uint8_t *bytes, int n) // AeroLcrc16::calcusingbytes (aerol.h:333-360)
@@ -192,9 +301,49 @@ __global__ void k_aerol_post(const AGeom g, const APtrs p)
     const int vblocks = ALD(AI_VBLOCKS);
     const int nb = vblocks ? g.blocksz / 2 : (g.blocksz + 24) / 2 - 25;
     ALD(AI_VBLOCKS) = vblocks + 1;
+    // DelayLine::update (aerol.h: write at the pointer, advance, read at the new pointer) + descrambler + LSB-first byte packing.
+    // A block is shorter than the delay line, so every bit read in this pass predates it: 16 decoded bits per step -- one 16-byte
+    // read of the line (the bits leaving it), one 16-byte write (the bits entering), 16 scrambler bytes, two packed bytes out.
+    // Steps that would wrap the line, run off the scrambler table or the info buffer go bit by bit.
+    int h = 0;
+    for (; h + 16 <= nb; h += 16)
+    {
+        if (dl2_ptr + 17 <= g.dl2_sz && scr_pos + 16 <= 5000 && ninfo + 2 <= g.info_cap)
+        {
+            uint4 in4, old4, sc4;
+            __builtin_memcpy(&in4, vb + h, 16);
+            __builtin_memcpy(&old4, dl2 + dl2_ptr + 1, 16);
+            __builtin_memcpy(&sc4, p.scr + scr_pos, 16);
+            __builtin_memcpy(dl2 + dl2_ptr, &in4, 16);
+            dl2_ptr += 16; if (dl2_ptr >= g.dl2_sz) dl2_ptr = 0;
+            scr_pos += 16;
+            const unsigned x0 = old4.x ^ sc4.x, x1 = old4.y ^ sc4.y, x2 = old4.z ^ sc4.z, x3 = old4.w ^ sc4.w;
+            // four 0/1 bytes -> a nibble, first byte in bit 0
+            const unsigned b0 = ((x0 * 0x01020408u) >> 24) & 15u, b1 = ((x1 * 0x01020408u) >> 24) & 15u;
+            const unsigned b2 = ((x2 * 0x01020408u) >> 24) & 15u, b3 = ((x3 * 0x01020408u) >> 24) & 15u;
+            info[ninfo] = (uint8_t)(b0 | (b1 << 4));
+            info[ninfo + 1] = (uint8_t)(b2 | (b3 << 4));
+            ninfo += 2;
+        }
+        else
+        {
+            unsigned chv = 0;
+            for (int q = 0; q < 16; q++)
+            {
+                dl2[dl2_ptr] = vb[h + q];
+                dl2_ptr++; if (dl2_ptr >= g.dl2_sz) dl2_ptr = 0;
+                unsigned v = dl2[dl2_ptr];
+                v ^= p.scr[scr_pos < 5000 ? scr_pos : 4999];
+                scr_pos++;
+                chv |= v * 128u;
+                if ((q & 7) == 7) { if (ninfo < g.info_cap) info[ninfo++] = (uint8_t)chv; chv = 0; }
+                else chv >>= 1;
+            }
+        }
+    }
     int charptr = 0;
     unsigned chv = 0;
-    for (int h = 0; h < nb; h++)
+    for (; h < nb; h++)
     {
         dl2[dl2_ptr] = vb[h];
         dl2_ptr++; if (dl2_ptr >= g.dl2_sz) dl2_ptr = 0;
