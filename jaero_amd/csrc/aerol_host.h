@@ -129,7 +129,7 @@ extern "C" int jaero_aerol_create(int device, int nchannels, int fb, int max_sof
     c->stage_stride = max_softbits_per_write;
     AA(c->d_soft, (size_t)g.nch * max_softbits_per_write);
     AA(c->d_counts, g.nchp);
-    if (viterbi_use_lanes(g.nch, g.blocksz, 24)) AA(c->d_vhist, viterbi_hist_bytes(g.nch) / sizeof(unsigned long long));
+    if (viterbi_use_lanes(g.nch, g.blocksz, 24)) { AA(c->d_vhist, viterbi_hist_bytes(g.nch) / sizeof(unsigned long long)); g.tiled = 1; }
 #undef AA
     c->p.scr = d_scr;
     {
@@ -184,18 +184,23 @@ extern "C" int jaero_aerol_write(jaero_aerol_ctx *c, const int16_t *soft, const 
     const int rounds = max_count / g.blocksz + 2;
     const int *valid = c->p.I + (size_t)AI_HAS_BLOCK * g.nchp;
     const dim3 grid(g.nchp / 64), block(64);
-    const bool rows16 = ((((size_t)dsoft) | ((size_t)stride * 2)) & 15) == 0 && stride >= 8; // 16-byte aligned rows: LDS-staged input
+    const bool bulk = g.oqpsk != 0; // 10.5 kbps: locked channels jump over the body of a frame (k_aerol_bits / k_aerol_bulk)
+    if (bulk) hipLaunchKernelGGL(k_aerol_scan, dim3((g.nch + 3) / 4), dim3(256), 0, st, g, c->p, dsoft, dcounts, stride);
     for (int r = 0; r < rounds; r++)
     {
         aprof_begin(c, 0, st);
-        if (rows16) hipLaunchKernelGGL(k_aerol_bits<true>, grid, block, 0, st, g, c->p, dsoft, dcounts, stride);
+        if (bulk)
+        {
+            hipLaunchKernelGGL(k_aerol_bits<true>, grid, block, 0, st, g, c->p, dsoft, dcounts, stride);
+            hipLaunchKernelGGL(k_aerol_bulk, dim3((g.nch + 3) / 4), dim3(256), 0, st, g, c->p, dsoft, stride);
+        }
         else hipLaunchKernelGGL(k_aerol_bits<false>, grid, block, 0, st, g, c->p, dsoft, dcounts, stride);
         hipLaunchKernelGGL(k_aerol_deint, dim3((g.nch + 3) / 4), dim3(256), 0, st, g, c->p);
         aprof_end(c, st);
         aprof_begin(c, 1, st);
         viterbi_launch(st, (const uint8_t *)c->p.deint, g.blocksz, (const uint8_t *)c->p.overlap, 24, c->p.vbits, g.blocksz / 2, 25, g.blocksz / 2,
-                       g.nch, valid, c->d_vhist);
-        hipLaunchKernelGGL(k_viterbi_overlap_update, dim3(g.nch), dim3(64), 0, st, (const uint8_t *)c->p.deint, g.blocksz, c->p.overlap, g.nch, valid);
+                       g.nch, valid, c->d_vhist, g.tiled);
+        hipLaunchKernelGGL(k_viterbi_overlap_update, dim3(g.nch), dim3(64), 0, st, (const uint8_t *)c->p.deint, g.blocksz, c->p.overlap, g.nch, valid, g.tiled);
         aprof_end(c, st);
         aprof_begin(c, 2, st);
         hipLaunchKernelGGL(k_aerol_post, grid, block, 0, st, g, c->p);

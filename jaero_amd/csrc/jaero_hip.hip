@@ -1030,11 +1030,11 @@ static inline bool viterbi_use_lanes(int nblocks, int nsoft, int pad)
     return nblocks >= VL_MIN_BLOCKS;
 }
 static void viterbi_launch(hipStream_t st, const uint8_t *d_soft, int nsoft, const uint8_t *d_ov, int pad, uint8_t *d_out, int out_stride,
-                           int out_start, int out_want, int nblocks, const int *valid, unsigned long long *hist)
+                           int out_start, int out_want, int nblocks, const int *valid, unsigned long long *hist, int tiled = 0)
 {
-    if (hist && viterbi_use_lanes(nblocks, nsoft, pad))
+    if (hist && (tiled || viterbi_use_lanes(nblocks, nsoft, pad))) // tiled input exists only in the lane layout
         hipLaunchKernelGGL(k_viterbi_lanes, dim3((nblocks + 63) / 64), dim3(64), 0, st, d_soft, nsoft, d_ov, pad, d_out, out_stride, out_start, out_want,
-                           nblocks, valid, hist);
+                           nblocks, valid, hist, tiled);
     else
         hipLaunchKernelGGL(k_viterbi, dim3(nblocks), dim3(64), 0, st, d_soft, nsoft, d_ov, pad, d_out, out_stride, out_start, out_want, nblocks, valid);
 }
@@ -1082,7 +1082,7 @@ extern "C" int jaero_viterbi_decode_soft(int device, const uint8_t *soft, int nb
 }
 
 __global__ void k_viterbi_overlap_update(const uint8_t *__restrict__ soft, int nsoft, uint8_t *__restrict__ overlap, int nstreams,
-                                         const int *__restrict__ valid = nullptr)
+                                         const int *__restrict__ valid = nullptr, int tiled = 0)
 {
     // soft_bits_overlap_buffer_uchar = soft_bits_in.right(62); resize(62)  (jconvolutionalcodec.cpp:197-198)
     const int b = blockIdx.x;
@@ -1093,8 +1093,12 @@ __global__ void k_viterbi_overlap_update(const uint8_t *__restrict__ soft, int n
     if (t < k)
     {
         uint8_t v = 0;
-        if (nsoft >= k) v = soft[(size_t)b * nsoft + nsoft - k + t];
-        else if (t < nsoft) v = soft[(size_t)b * nsoft + t];
+        // byte q of row b: row-major, or the tiled layout of k_viterbi_lanes ([wavefront][16-byte group][lane][16])
+        auto at = [&](int q) -> uint8_t {
+            return tiled ? soft[(size_t)(b >> 6) * 64 * nsoft + ((size_t)(q >> 4) * 64 + (b & 63)) * 16 + (q & 15)] : soft[(size_t)b * nsoft + q];
+        };
+        if (nsoft >= k) v = at(nsoft - k + t);
+        else if (t < nsoft) v = at(t);
         overlap[(size_t)b * 64 + t] = v;
     }
     if (t == 62) overlap[(size_t)b * 64 + 62] = (uint8_t)k;

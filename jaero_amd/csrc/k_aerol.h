@@ -1,7 +1,10 @@
 // k_aerol.h -- the Aero-L bit pipeline around the Viterbi decoder, continuous P-channel path of
 // AeroL::Decode(bits, soft=true) (JAERO/aerol.cpp:1124-2039) for 600 / 1200 / 10500 bps, one channel per lane:
+//   k_aerol_scan : once per write, does a channel's input hold a start-of-burst marker (those channels go bit by bit throughout)
 //   k_aerol_bits : unique-word detection + I/Q ambiguity (PreambleDetector / PreambleDetectorPhaseInvariant, aerol.cpp:744-804),
-//                  frame counter and header (:1274-1322), block fill in received order; runs until the channel has a full block
+//                  frame counter and header (:1274-1322), block fill in received order; runs until the channel has a full block;
+//                  jumps over the body of a frame while the channel is locked
+//   k_aerol_bulk : copies the jumped-over soft bits into the block, one wavefront per channel
 //   k_aerol_deint: AeroLInterleaver::deinterleave_ba (:603-625) of the completed blocks, one wavefront per channel through LDS
 //   k_viterbi    : JConvolutionalCodec::Decode_Continuous for the channels that completed a block (k_viterbi.h)
 //   k_aerol_post : DelayLine dl2 (:1560), AeroLScrambler (:1563), byte packing (:1566-1578), and at the end of a frame the CRC-16
@@ -18,12 +21,13 @@ enum
 {
     AI_CNTR, AI_DATACD, AI_DCDCOUNT, AI_GOTSYNC_LAST, AI_REALIMAG, AI_BLOCKCNT, AI_MUW, AI_FRAMEINFO, AI_LASTFRAMEINFO,
     AI_PD_EXACT, AI_PD_IMAG, AI_PD_REAL, AI_INV_IMAG, AI_INV_REAL, AI_SCR_POS, AI_DL2_PTR, AI_NINFO, AI_NFRAMES,
-    AI_IN_POS, AI_RESUME, AI_RESUME_GOTSYNC, AI_HAS_BLOCK, AI_VBLOCKS, AI_SU_CNT, AI_EV_CNT, AI_OVERFLOW, AI_NBITS_LO, AI_NBITS_HI, AI_ACC,
+    AI_IN_POS, AI_RESUME, AI_RESUME_GOTSYNC, AI_HAS_BLOCK, AI_VBLOCKS, AI_SU_CNT, AI_EV_CNT, AI_OVERFLOW, AI_NBITS_LO, AI_NBITS_HI, AI_ACC, AI_ACCBAD,
+    AI_MARKER, AI_BULK_LEN, AI_BULK_SRC, AI_BULK_DST, AI_BULK_FLAGS,
     AI_NFIELDS
 };
 struct AGeom
 {
-    int nch, nchp, fb, oqpsk, N, blocksz, dl2_sz, NumberOfBits, BitsInHeader, TotalNumberOfBits, su_cap, ev_cap, info_cap, idx_sat;
+    int nch, nchp, fb, oqpsk, N, blocksz, dl2_sz, NumberOfBits, BitsInHeader, TotalNumberOfBits, su_cap, ev_cap, info_cap, idx_sat, tiled;
 };
 struct APtrs
 {
@@ -58,6 +62,7 @@ struct ABitState
 {
     int cntr, datacd, gotsync_last, realimag, blockcnt, muw, ninfo, inv_imag, inv_real, scr_pos, dcdcount, ev_cnt, overflow;
     unsigned frameinfo, lastframeinfo, pd_exact, pd_imag, pd_real, acc;
+    int accbad;
 };
 __device__ __forceinline__ bool aerol_bit_a(const AGeom &g, ABitState &s, int v, int &gotsync, uint8_t *rx)
 {
@@ -126,7 +131,9 @@ __device__ __forceinline__ bool aerol_bit_a(const AGeom &g, ABitState &s, int v,
         // the block is kept in RECEIVED order, four soft bytes per store (idx runs 0, 1, 2, .. within a block, so the three bytes
         // before an idx with (idx & 3) == 3 are the block's idx-3 .. idx-1); k_aerol_deint reorders completed blocks
         s.acc = (s.acc >> 8) | (soft_bit << 24);
-        if ((idx & 3) == 3) *(unsigned *)(rx + (idx - 3)) = s.acc;
+        if ((idx & 3) == 0) s.accbad = 0;                     // a fresh group of four starts here
+        if (s.accbad) rx[idx] = (uint8_t)soft_bit;            // group entered in the middle (after a bulk run): byte by byte
+        else if ((idx & 3) == 3) *(unsigned *)(rx + (idx - 3)) = s.acc;
         if (idx == g.blocksz - 1)
         {
             s.blockcnt++;
@@ -150,13 +157,16 @@ __device__ __forceinline__ void aerol_bit_b(const AGeom &g, const APtrs &p, int 
     gotsync = 0;
 }
 
-// One wavefront = 64 channels, all walking the same input position P (a channel is live while P is its own position: it stops at
-// its count or when it completes a block).  The soft bits of the 64 rows are staged through LDS in chunks of 64 positions:
-// [group][lane] uint4 from 16-byte row loads when the rows are 16-byte aligned (ROWS16), [position][lane] from 2-byte loads otherwise.
-template <bool ROWS16>
+// Lane = channel, every lane at its own input position.  A locked 10.5 kbps channel (data carrier detected, no start-of-burst
+// marker in this write -- k_aerol_scan) spends 4909 of the 5250 soft bits of a frame where AeroL::Decode does nothing but count,
+// toggle the I/Q arm and copy the (possibly inverted) soft bit into the block: pre-increment cntr in [16, NumberOfBits-68]
+// (aerol.cpp:1256-1345: no unique-word detection, header done, block not complete).  Such a stretch is not walked: the lane jumps
+// over it and leaves a descriptor for k_aerol_bulk, which copies it with a whole wavefront.  Everything else (unique-word windows,
+// headers, unlocked channels, 600/1200 bps, writes with markers) goes bit by bit.
+#define AEROL_MINRUN 32
+template <bool BULK>
 __global__ __launch_bounds__(64) void k_aerol_bits(const AGeom g, const APtrs p, const int16_t *__restrict__ soft, const int *__restrict__ counts, int stride)
 {
-    __shared__ uint4 lds_in[8 * 64 + 64]; // + one row: the look-ahead read of slot 64
     const int lane = threadIdx.x;
     const int ch0 = blockIdx.x * 64 + lane;
     const bool valid = ch0 < g.nch;
@@ -167,14 +177,14 @@ __global__ __launch_bounds__(64) void k_aerol_bits(const AGeom g, const APtrs p,
     s.frameinfo = (unsigned)ALD(AI_FRAMEINFO); s.lastframeinfo = (unsigned)ALD(AI_LASTFRAMEINFO);
     s.pd_exact = (unsigned)ALD(AI_PD_EXACT); s.pd_imag = (unsigned)ALD(AI_PD_IMAG); s.pd_real = (unsigned)ALD(AI_PD_REAL);
     s.inv_imag = ALD(AI_INV_IMAG); s.inv_real = ALD(AI_INV_REAL); s.scr_pos = ALD(AI_SCR_POS); s.dcdcount = ALD(AI_DCDCOUNT);
-    s.ev_cnt = ALD(AI_EV_CNT); s.overflow = ALD(AI_OVERFLOW); s.acc = (unsigned)ALD(AI_ACC);
+    s.ev_cnt = ALD(AI_EV_CNT); s.overflow = ALD(AI_OVERFLOW); s.acc = (unsigned)ALD(AI_ACC); s.accbad = ALD(AI_ACCBAD);
     int pos = ALD(AI_IN_POS), resume = ALD(AI_RESUME);
     const long long nbits0 = ((long long)(unsigned)ALD(AI_NBITS_LO)) | ((long long)ALD(AI_NBITS_HI) << 32);
     const int n = valid ? counts[ch] : 0;
     const int16_t *sb = soft + (size_t)ch * stride;
     uint8_t *rx = p.rx + (size_t)ch * g.blocksz;
-    int has_block = 0;
-    int gotsync = 0;
+    const bool may_bulk = BULK && !ALD(AI_MARKER);
+    int has_block = 0, gotsync = 0, bulk_len = 0, bulk_src = 0, bulk_dst = 0, bulk_flags = 0;
     if (resume && valid)
     {
         // second half of the soft bit whose block store completed a block in the previous round
@@ -184,53 +194,55 @@ __global__ __launch_bounds__(64) void k_aerol_bits(const AGeom g, const APtrs p,
         resume = 0;
     }
     bool live = valid && pos < n;
-    // wave-uniform range of positions still to be visited
-    int pmin = live ? pos : 0x7fffffff, pmax = live ? n : 0;
-    for (int o = 32; o > 0; o >>= 1) { pmin = min(pmin, __shfl_xor(pmin, o)); pmax = max(pmax, __shfl_xor(pmax, o)); }
-    pmin = __builtin_amdgcn_readfirstlane(pmin);
-    pmax = __builtin_amdgcn_readfirstlane(pmax);
-    const unsigned short *lp = (const unsigned short *)lds_in + lane * 8;
-    for (int base = pmin & ~63; base < pmax; base += 64)
+    const int zone_hi = g.NumberOfBits - 68; // last pre-increment cntr without unique-word detection
+    int vnext = live ? (int)sb[pos] : 0;
+    while (__any(live))
     {
-        if (!__any(live)) break;
-        if (ROWS16)
+        if (live)
         {
-#pragma unroll
-            for (int gq = 0; gq < 8; gq++)
+            bool jumped = false;
+            if (may_bulk && s.datacd && bulk_len == 0 && s.cntr >= 16 && s.cntr <= zone_hi)
             {
-                int e = base + 8 * gq;
-                if (e + 8 > stride) e = stride - 8; // positions at or beyond the row end are never used (counts <= stride)
-                lds_in[gq * 64 + lane] = *(const uint4 *)(sb + e);
+                const int L = min(zone_hi - s.cntr + 1, n - pos);
+                if (L >= AEROL_MINRUN)
+                {
+                    // L soft bits with pre-increment cntr = c .. c+L-1: bit i has arm parity realimag ^ ((i+1)&1) and goes to
+                    // block index max(0, c+1+i - BitsInHeader); the dummy bits in front of the block all land on index 0 and are
+                    // overwritten by the first real one, so only i >= i0 is copied
+                    const int c = s.cntr;
+                    const int i0 = max(0, g.BitsInHeader - (c + 1));
+                    if (i0 < L)
+                    {
+                        bulk_src = pos + i0;
+                        bulk_dst = c + 1 + i0 - g.BitsInHeader;
+                        bulk_len = L - i0;
+                        bulk_flags = ((s.realimag ^ ((i0 + 1) & 1)) & 1) | (s.inv_imag ? 2 : 0) | (s.inv_real ? 4 : 0);
+                    }
+                    else bulk_len = -1; // nothing to copy, but only one jump per round (one descriptor slot)
+                    s.cntr += L;
+                    s.realimag ^= (L & 1);
+                    s.muw = min(100000, s.muw + L);
+                    s.gotsync_last = 0;
+                    gotsync = 0;
+                    s.accbad = 1; // the per-bit path may resume inside a group of four
+                    pos += L;
+                    jumped = true;
+                    if (pos < n) vnext = (int)sb[pos];
+                }
             }
-        }
-        else
-        {
-            // rows of any alignment: 64 two-byte loads per lane, issued together ([position][lane] in LDS)
-            unsigned short *l16 = (unsigned short *)lds_in;
-#pragma unroll 16
-            for (int k = 0; k < 64; k++) l16[k * 64 + lane] = (unsigned short)sb[min(base + k, stride - 1)];
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): nothing older than this chunk is waited for inside the bit loop
-        const int tend = min(64, pmax - base);
-        const unsigned short *l16r = (const unsigned short *)lds_in + lane;
-        int vn = ROWS16 ? (int)(short)lp[0] : (int)(short)l16r[0]; // the LDS read of a position is issued one position ahead
-        for (int t = 0; t < tend; t++)
-        {
-            const int P = base + t;
-            const int v = vn;
-            // (slot 64 = one row past the chunk: inside the array, never used)
-            vn = ROWS16 ? (int)(short)lp[((t + 1) >> 3) * 512 + ((t + 1) & 7)] : (int)(short)l16r[(t + 1) * 64];
-            if (live && pos == P)
+            if (!jumped)
             {
+                const int v = vnext;
+                if (pos + 1 < n) vnext = (int)sb[pos + 1];
                 if (v < 0) { s.muw = 0; pos++; } // start-of-burst marker (aerol.cpp:1146-1152)
                 else if (aerol_bit_a(g, s, v, gotsync, rx)) { has_block = 1; resume = 1; live = false; }
                 else
                 {
-                    aerol_bit_b(g, p, ch, s, gotsync, nbits0 + P);
+                    aerol_bit_b(g, p, ch, s, gotsync, nbits0 + pos);
                     pos++;
                 }
-                if (pos >= n) live = false;
             }
+            if (pos >= n) live = false;
         }
     }
     if (!valid) return;
@@ -240,7 +252,53 @@ __global__ __launch_bounds__(64) void k_aerol_bits(const AGeom g, const APtrs p,
     ALD(AI_PD_EXACT) = (int)s.pd_exact; ALD(AI_PD_IMAG) = (int)s.pd_imag; ALD(AI_PD_REAL) = (int)s.pd_real;
     ALD(AI_INV_IMAG) = s.inv_imag; ALD(AI_INV_REAL) = s.inv_real; ALD(AI_SCR_POS) = s.scr_pos; ALD(AI_DCDCOUNT) = s.dcdcount;
     ALD(AI_IN_POS) = pos; ALD(AI_RESUME) = resume; ALD(AI_RESUME_GOTSYNC) = gotsync; ALD(AI_HAS_BLOCK) = has_block;
-    ALD(AI_EV_CNT) = s.ev_cnt; ALD(AI_OVERFLOW) = s.overflow; ALD(AI_ACC) = (int)s.acc;
+    ALD(AI_EV_CNT) = s.ev_cnt; ALD(AI_OVERFLOW) = s.overflow; ALD(AI_ACC) = (int)s.acc; ALD(AI_ACCBAD) = s.accbad;
+    ALD(AI_BULK_LEN) = bulk_len > 0 ? bulk_len : 0; ALD(AI_BULK_SRC) = bulk_src; ALD(AI_BULK_DST) = bulk_dst; ALD(AI_BULK_FLAGS) = bulk_flags;
+}
+
+// does this write hold a start-of-burst marker (a negative soft value) for the channel?  One wavefront per channel, coalesced.
+__global__ __launch_bounds__(256) void k_aerol_scan(const AGeom g, const APtrs p, const int16_t *__restrict__ soft, const int *__restrict__ counts, int stride)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ch = blockIdx.x * 4 + w;
+    if (ch >= g.nch) return;
+    const int n = counts[ch];
+    const int16_t *sb = soft + (size_t)ch * stride;
+    int neg = 0;
+    for (int k = lane; k < n; k += 64) neg |= (sb[k] < 0) ? 1 : 0;
+    const int any = __any(neg) ? 1 : 0;
+    if (lane == 0) ALD(AI_MARKER) = any;
+}
+
+// the stretches k_aerol_bits jumped over: rx[dst + i] = soft bit (src + i), inverted per arm, i < len.  One wavefront per channel,
+// four soft bits per lane and step.
+__global__ __launch_bounds__(256) void k_aerol_bulk(const AGeom g, const APtrs p, const int16_t *__restrict__ soft, int stride)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ch = blockIdx.x * 4 + w;
+    if (ch >= g.nch) return;
+    const int len = ALD(AI_BULK_LEN);
+    if (len <= 0) return; // wave-uniform
+    const int flags = ALD(AI_BULK_FLAGS);
+    const int16_t *src = soft + (size_t)ch * stride + ALD(AI_BULK_SRC);
+    uint8_t *dst = p.rx + (size_t)ch * g.blocksz + ALD(AI_BULK_DST);
+    const int inv_first = (flags & 1) ? (flags >> 1) & 1 : (flags >> 2) & 1;   // arm of bit 0: imag if parity 1
+    const int inv_second = (flags & 1) ? (flags >> 2) & 1 : (flags >> 1) & 1;
+    auto conv = [](int v, int inv) -> unsigned {
+        unsigned sbit = (unsigned)v & 0xFFFFu;
+        if (inv && sbit != 128u) sbit = 255u - sbit;
+        return sbit & 255u;
+    };
+    const int n4 = len & ~3;
+    for (int i = lane * 4; i < n4; i += 256)
+    {
+        short q[4];
+        __builtin_memcpy(q, src + i, 8);
+        const unsigned o = conv(q[0], inv_first) | (conv(q[1], inv_second) << 8) | (conv(q[2], inv_first) << 16) | (conv(q[3], inv_second) << 24);
+        __builtin_memcpy(dst + i, &o, 4);
+    }
+    const int i = n4 + lane;
+    if (i < len) dst[i] = (uint8_t)conv(src[i], (i & 1) ? inv_second : inv_first);
 }
 
 // AeroLInterleaver::deinterleave_ba (aerol.cpp:603-625) for the channels that completed a block this round, one wavefront per
@@ -257,14 +315,16 @@ __global__ __launch_bounds__(256) void k_aerol_deint(const AGeom g, const APtrs 
     uint4 *b16 = (uint4 *)blk[w];
     for (int q = lane; q < g.blocksz / 16; q += 64) b16[q] = src[q];
     // (one wavefront per block buffer: LDS accesses of a wave are in order, no barrier needed)
-    unsigned *dst = (unsigned *)(p.deint + (size_t)ch * g.blocksz);
+    // row-major [channel][blocksz] for k_viterbi, or k_viterbi_lanes' tiled layout [wavefront][16-byte group][lane][16]
+    unsigned *dst = (unsigned *)(g.tiled ? p.deint + (size_t)(ch >> 6) * 64 * g.blocksz + (ch & 63) * 16 : p.deint + (size_t)ch * g.blocksz);
+    const int gmul = g.tiled ? 64 : 1;
     const int i0 = (lane & 15) * 4;
     const int r0 = ((i0 * 27) & 63) * g.N, r1 = (((i0 + 1) * 27) & 63) * g.N, r2 = (((i0 + 2) * 27) & 63) * g.N, r3 = (((i0 + 3) * 27) & 63) * g.N;
     const uint8_t *bb = blk[w];
     for (int j = lane >> 4; j < g.N; j += 4)
     {
         const unsigned v = (unsigned)bb[r0 + j] | ((unsigned)bb[r1 + j] << 8) | ((unsigned)bb[r2 + j] << 16) | ((unsigned)bb[r3 + j] << 24);
-        dst[j * 16 + (lane & 15)] = v;
+        dst[((j * 4 + ((lane & 15) >> 2)) * gmul) * 4 + (lane & 3)] = v; // byte j*64 + 4*(lane&15): group j*4 + (lane&15)/4, dword lane&3
     }
 }
 

@@ -189,7 +189,7 @@ struct VlRun // wave-uniform bookkeeping of history_buffer
 // hist: [gridDim.x][VT_CAP][64] uint64 scratch.  Same stream convention as k_viterbi (overlap ++ soft ++ pad x 128).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_viterbi_lanes(const uint8_t *__restrict__ soft, int nsoft, const uint8_t *__restrict__ overlap, int pad,
                                                       uint8_t *__restrict__ out, int out_stride, int out_start, int out_want, int nblocks,
-                                                      const int *__restrict__ valid, unsigned long long *__restrict__ hist)
+                                                      const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled)
 {
     const unsigned lane = threadIdx.x;
     const int b0 = blockIdx.x * 64 + (int)lane;
@@ -197,12 +197,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     const int b = inrange ? b0 : 0;
     bool todo = inrange && (!valid || valid[b] != 0);
     if (!__any(todo)) return;
-    const uint8_t *in = soft + (size_t)b * nsoft;
+    // input rows: row-major [block][nsoft], or (tiled; nsoft a multiple of 16) [wavefront][16-byte group][lane][16]: the 64 rows a
+    // wavefront decodes interleaved in 16-byte pieces, so that every chunk load is 8 x 1 KiB contiguous (the Aero-L deinterleaver
+    // writes this layout; with one row per lane a load touches 64 pages and the same kernel runs 0.85 ms slower on cold rows)
+    const uint8_t *in = tiled ? soft + (size_t)blockIdx.x * 64 * nsoft + lane * 16 : soft + (size_t)b * nsoft;
+    const int gstride = tiled ? 64 : 1; // distance between consecutive 16-byte groups of a row, in groups
+    auto inbyte = [&](int q) -> unsigned { return in[(size_t)(q >> 4) * gstride * 16 + (q & 15)]; };
     const uint8_t *ov = overlap ? overlap + (size_t)b * 64 : in;
     const int my_ovl = overlap ? (int)ov[62] : 0;
     uint8_t *o = out + (size_t)b * out_stride;
     unsigned long long *hw = hist + (size_t)blockIdx.x * VT_CAP * 64 + lane;
-    const bool rows16 = ((((size_t)soft) | (size_t)nsoft) & 15) == 0; // every row of the bank 16-byte aligned (the Aero-L bank's are)
+    const bool rows16 = ((((size_t)soft) | (size_t)nsoft) & 15) == 0; // every row of the bank 16-byte aligned (always so when tiled)
     __shared__ uint4 lds_soft[8 * 64];
 
     while (__any(todo))
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         const int sets = total / 2;
 
         auto getpair = [&](int i, unsigned &s0, unsigned &s1) { // soft bytes 2i, 2i+1 of the stream, any position (slow)
-            auto one = [&](int q) -> unsigned { return q < ovl ? ov[q] : (q - ovl < nsoft ? in[q - ovl] : 128u); };
+            auto one = [&](int q) -> unsigned { return q < ovl ? ov[q] : (q - ovl < nsoft ? inbyte(q - ovl) : 128u); };
             s0 = one(2 * i); s1 = one(2 * i + 1);
         };
         // Fast source for the steps whose two soft bytes lie inside a 16-byte aligned block: 128-byte chunks (64 steps) of every lane's
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
             for (int g = 0; g < 8; g++)
             {
                 const int gi = c * 8 + g;
-                lds_soft[g * 64 + lane] = cp[gi < ngroups ? gi : ngroups - 1];
+                lds_soft[g * 64 + lane] = cp[(size_t)(gi < ngroups ? gi : ngroups - 1) * gstride];
             }
             chunk = c;
         };

@@ -68,6 +68,35 @@ def test_bank_vs_oracle(B, oracle_mod, monkeypatch, fb, layout):
     bank.close()
 
 
+def test_start_of_burst_markers(B, oracle_mod):
+    """Negative soft values (the burst demodulators' start-of-burst marker, aerol.cpp:1146-1152) in some channels' input: those
+    channels are walked bit by bit for that write, their neighbours in the same wavefront keep jumping over locked frame bodies."""
+    fb, nch = 10500, 12
+    rng = np.random.default_rng(5)
+    streams = []
+    for c in range(nch):
+        bits, _ = AF.p_channel_bits(AF.random_payloads(5, fb, seed=300 + c), fb, invert_i=bool(c & 1), invert_q=bool(c & 2))
+        x = AF.to_soft(bits, sigma=20.0, seed=c)
+        if c % 3 == 0:
+            x = np.insert(x, np.sort(rng.integers(0, len(x), size=4)), -1)
+        streams.append(x)
+    n = max(len(x) for x in streams)
+    bank = B.AeroLBank(nch, fb, max_softbits_per_write=4096, su_capacity=400)
+    for s0 in range(0, n, 4096):
+        buf = np.zeros((nch, 4096), np.int16)
+        cnt = np.zeros(nch, np.int32)
+        for c in range(nch):
+            seg = streams[c][s0:s0 + 4096]
+            buf[c, :len(seg)] = seg
+            cnt[c] = len(seg)
+        bank.write(buf, cnt)
+    for c in range(nch):
+        o = oracle_mod.run_aerol(fb, streams[c], 1 << 20)
+        assert np.array_equal(bank.read_sus(c), o["sus"]), c
+        assert np.array_equal(bank.read_events(c), o["events"]), c
+    bank.close()
+
+
 def test_tick_dcd(B):
     g = load_golden("aerol_1200")
     bank = B.AeroLBank(1, 1200, max_softbits_per_write=16384)
