@@ -21,3 +21,21 @@ for it in range(6):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"call {it}: {dt * 1e3:.3f} ms  ({nblk * nsoft / dt / 1e9:.2f} Gsoftbits/s)")
+# the same calls with 2 GiB of unrelated memory traffic in between (what the decoder sees inside the Aero-L pipeline)
+big = torch.empty(1 << 31, dtype=torch.uint8, device="cuda")
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+for it in range(4):
+    big.add_(1)
+    torch.cuda.synchronize()
+    ev[0].record()
+    capi.check(L.jaero_viterbi_continuous(0, soft.data_ptr(), nblk, nsoft, 24, ov.data_ptr(), out.data_ptr(), None, 1, None))
+    ev[1].record()
+    torch.cuda.synchronize()
+    print(f"after 2 GiB of other traffic, call {it}: {ev[0].elapsed_time(ev[1]):.3f} ms")
+for it in range(3):
+    torch.cuda.synchronize()
+    ev[0].record()
+    capi.check(L.jaero_viterbi_continuous(0, soft.data_ptr(), nblk, nsoft, 24, ov.data_ptr(), out.data_ptr(), None, 1, None))
+    ev[1].record()
+    torch.cuda.synchronize()
+    print(f"back to back, call {it}: {ev[0].elapsed_time(ev[1]):.3f} ms")
