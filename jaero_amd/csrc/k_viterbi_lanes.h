@@ -14,9 +14,12 @@
 // back at the same steps).  Blocks whose overlap length differs (the first block of a stream has none) run as separate passes.
 // Soft bytes reach the steps through LDS (64-step chunks of every lane's row, [group][lane] uint4), so the step loop has no vmcnt
 // wait: the history store of a step is never waited for except in the traceback.
-// Measured (MI355X, 65536 blocks of 5078 soft bytes, one wavefront per SIMD): 1.77 ms per launch = 0.70 ns per block and step;
-// 1.35 ms of it is the step loop (a lone wavefront issues one VALU instruction per ~2.2 ns, 225 instructions per step), 0.4 ms the
-// tracebacks (5 x ~1.5 us of exposed history-load latency each).  k_viterbi.h on the same input: 11.5 ms.
+// Measured (MI355X, 65536 blocks of 5078 soft bytes, one wavefront per SIMD): 1.7-1.8 ms per launch = 0.70 ns per block and
+// step, of which ~1.35 ms is the step loop (a lone wavefront issues one VALU instruction per ~2.2 ns, 225 instructions per step) and
+// the rest the tracebacks (2 x one history-load latency each, ~10 instructions per slice).  Every load whose latency is exposed is
+// either prefetched (soft chunks, hand-issued into AGPRs) or batched (history slices, 70 at a time): with the compiler's own
+// placement the same kernel took 2.5-2.7 ms whenever its rows and history were cold, 1.8 ms warm.  k_viterbi.h on the same input:
+// 11.5 ms.
 #pragma once
 #include "k_viterbi.h"
 #include <utility>
@@ -184,7 +187,7 @@ struct VlRun // wave-uniform bookkeeping of history_buffer
     int index, len, renorm, outpos;
 };
 
-#define VL_TB_BATCH 28 // history slices fetched together in the traceback (VT_CAP = 5 batches; 56 VGPRs)
+#define VL_TB_BATCH 70 // history slices fetched together in the traceback (VT_CAP = 2 batches; 140 VGPRs)
 
 // hist: [gridDim.x][VT_CAP][64] uint64 scratch.  Same stream convention as k_viterbi (overlap ++ soft ++ pad x 128).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_viterbi_lanes(const uint8_t *__restrict__ soft, int nsoft, const uint8_t *__restrict__ overlap, int pad,
@@ -230,16 +233,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         const uint4 *cp = (const uint4 *)__builtin_assume_aligned(in, 16);
         const int ngroups = nsoft / 16;
         const unsigned short *lp = (const unsigned short *)lds_soft + lane * 8;
-        int chunk = -1;
-        auto need_chunk = [&](int c) { // one exposed load latency per 64 steps (the compiler sinks any earlier prefetch down to here)
-            if (c == chunk) return;
+        // The next chunk is requested as soon as the current one is in LDS, into registers, with hand-written loads: the compiler
+        // sinks an ordinary prefetch down to its use (and then every chunk costs a full memory latency, ~0.9 ms per launch when the
+        // rows are cold).  They land in accumulation VGPRs, which nothing else here uses, and are not touched before the explicit
+        // vmcnt(0) below.
+        typedef unsigned vl_u4 __attribute__((ext_vector_type(4)));
+        vl_u4 pre[8];
+        int chunk = -1, pre_chunk = -1;
+        auto issue = [&](int c) {
 #pragma unroll
             for (int g = 0; g < 8; g++)
             {
                 const int gi = c * 8 + g;
-                lds_soft[g * 64 + lane] = cp[(size_t)(gi < ngroups ? gi : ngroups - 1) * gstride];
+                const uint4 *a = cp + (size_t)(gi < ngroups ? gi : ngroups - 1) * gstride;
+                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=a"(pre[g]) : "v"(a) : "memory"); // straight into accumulation VGPRs
             }
+            pre_chunk = c;
+        };
+        auto need_chunk = [&](int c) {
+            if (c == chunk) return;
+            if (pre_chunk != c) issue(c);
+            // the wait "produces" the eight values, so that no copy of them can be scheduled above it
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+a"(pre[0]), "+a"(pre[1]), "+a"(pre[2]), "+a"(pre[3]), "+a"(pre[4]), "+a"(pre[5]), "+a"(pre[6]), "+a"(pre[7])
+                         :
+                         : "memory");
+#pragma unroll
+            for (int g = 0; g < 8; g++) ((vl_u4 *)lds_soft)[g * 64 + lane] = pre[g];
             chunk = c;
+            if ((c + 1) * 8 < ngroups) issue(c + 1);
         };
         auto ldspair = [&](int t, unsigned &s0, unsigned &s1) { // step slot t of the staged chunk
             const unsigned v = lp[(t >> 3) * 512 + (t & 7)];
@@ -338,7 +360,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                     h.renorm += run;
                     h.len += run;
                     i += run;
-                    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) here, so that no wait for an older load lands inside the step loop
                     unsigned ra = 0x8080u, rb = 0x8080u; // raw byte pairs; split at use so the LDS latency hides behind a pair of steps
                     if (run >= 2) { ra = lp[(t >> 3) * 512 + (t & 7)]; rb = lp[((t + 1) >> 3) * 512 + ((t + 1) & 7)]; }
                     for (; run >= 2; run -= 2, t += 2)
