@@ -17,7 +17,7 @@
 // Measured (MI355X, 65536 blocks of 5078 soft bytes, one wavefront per SIMD): 1.7-1.8 ms per launch = 0.70 ns per block and
 // step, of which ~1.35 ms is the step loop (a lone wavefront issues one VALU instruction per ~2.2 ns, 225 instructions per step) and
 // the rest the tracebacks (2 x one history-load latency each, ~10 instructions per slice).  Every load whose latency is exposed is
-// either prefetched (soft chunks, hand-issued into AGPRs) or batched (history slices, 70 at a time): with the compiler's own
+// either prefetched (soft chunks, hand-issued into AGPRs) or batched (history slices, 72 at a time): with the compiler's own
 // placement the same kernel took 2.5-2.7 ms whenever its rows and history were cold, 1.8 ms warm.  k_viterbi.h on the same input:
 // 11.5 ms.
 #pragma once
@@ -187,12 +187,13 @@ struct VlRun // wave-uniform bookkeeping of history_buffer
     int index, len, renorm, outpos;
 };
 
-#define VL_TB_BATCH 70 // history slices fetched together in the traceback (VT_CAP = 2 batches; 140 VGPRs)
+#define VL_TB_BATCH 72 // history slices fetched together in the traceback (a multiple of 4; VT_CAP = 2 batches, 144 VGPRs)
+static_assert(VL_TB_BATCH % 4 == 0, "the traceback stores four decoded bits at a time");
 
 // hist: [gridDim.x][VT_CAP][64] uint64 scratch.  Same stream convention as k_viterbi (overlap ++ soft ++ pad x 128).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_viterbi_lanes(const uint8_t *__restrict__ soft, int nsoft, const uint8_t *__restrict__ overlap, int pad,
-                                                      uint8_t *__restrict__ out, int out_stride, int out_start, int out_want, int nblocks,
-                                                      const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled)
+__device__ __forceinline__ void vl_decode(const uint8_t *__restrict__ soft, int nsoft, const uint8_t *__restrict__ overlap, int pad,
+                                          uint8_t *__restrict__ out, int out_stride, int out_start, int out_want, int nblocks,
+                                          const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled, uint4 *lds_soft)
 {
     const unsigned lane = threadIdx.x;
     const int b0 = blockIdx.x * 64 + (int)lane;
@@ -211,7 +212,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     uint8_t *o = out + (size_t)b * out_stride;
     unsigned long long *hw = hist + (size_t)blockIdx.x * VT_CAP * 64 + lane;
     const bool rows16 = ((((size_t)soft) | (size_t)nsoft) & 15) == 0; // every row of the bank 16-byte aligned (always so when tiled)
-    __shared__ uint4 lds_soft[8 * 64];
 
     while (__any(todo))
     {
@@ -430,4 +430,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
             if (last) break;
         }
     }
+}
+
+// Two entry points over the same body.  The decoder needs ~240 registers, so two wavefronts fit on a SIMD -- and for a bank of
+// <= 1024 wavefronts (one per SIMD of an MI355X) the dispatcher then stacks pairs on some SIMDs while others idle: 2.5 ms instead
+// of 1.7 ms per launch.  amdgpu_waves_per_eu(1, 1) makes the register allocation large enough that only one fits (capping the CU at
+// four workgroups through the LDS request does not help, the four still share SIMDs); banks that need more than one wavefront
+// per SIMD use the (1, 2) entry.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_viterbi_lanes(
+    const uint8_t *__restrict__ soft, int nsoft, const uint8_t *__restrict__ overlap, int pad, uint8_t *__restrict__ out, int out_stride, int out_start,
+    int out_want, int nblocks, const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled)
+{
+    __shared__ uint4 lds_soft[8 * 64];
+    vl_decode(soft, nsoft, overlap, pad, out, out_stride, out_start, out_want, nblocks, valid, hist, tiled, lds_soft);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_viterbi_lanes_x2(
+    const uint8_t *__restrict__ soft, int nsoft, const uint8_t *__restrict__ overlap, int pad, uint8_t *__restrict__ out, int out_stride, int out_start,
+    int out_want, int nblocks, const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled)
+{
+    __shared__ uint4 lds_soft[8 * 64];
+    vl_decode(soft, nsoft, overlap, pad, out, out_stride, out_start, out_want, nblocks, valid, hist, tiled, lds_soft);
 }
