@@ -132,6 +132,7 @@ struct jaero_ctx
     int16_t *d_pcm_raw = nullptr;    // [nch*max_write] staging for host input
     double2 *d_scratch = nullptr;
     double2 *d_tw = nullptr;
+    bool coarse_v2 = false; int coarse3_grid = 256;
     int *d_chanlist = nullptr;
     int coarse_grid = 0;
     bool coarse_v1 = false;  // JAERO_COARSE_V1=1 selects the four-step LDS/scratch FFT (kept for A/B validation)
@@ -571,7 +572,14 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     }
-    if (g.nfft_log2 == 14) HIPCHK(hipFuncSetAttribute((const void *)k_coarse2<14>, hipFuncAttributeMaxDynamicSharedMemorySize, c->coarse2_lds));
+    if (g.nfft_log2 == 14)
+    {
+        HIPCHK(hipFuncSetAttribute((const void *)k_coarse2<14>, hipFuncAttributeMaxDynamicSharedMemorySize, c->coarse2_lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_coarse3, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 34 * (int)sizeof(double)));
+        const char *e = getenv("JAERO_COARSE_KERNEL"); // "2" = the single 2^14-point transform (k_coarse2<14>), for comparison
+        c->coarse_v2 = e && !strcmp(e, "2");
+        c->coarse3_grid = c->coarse2_grid;
+    }
     else HIPCHK(hipFuncSetAttribute((const void *)k_coarse2<13>, hipFuncAttributeMaxDynamicSharedMemorySize, c->coarse2_lds));
     HIPCHK(hipDeviceSynchronize());
     *out = c;
@@ -764,7 +772,13 @@ static void launch_coarse(jaero_ctx *c, const int *d_list, int nlist, hipStream_
     {
         // register-resident FFT: one workgroup per CU (512-VGPR budget, ~140 KB LDS), persistent over the list
         const int grid2 = nlist < c->coarse2_grid ? nlist : c->coarse2_grid;
-        if (c->g.nfft_log2 == 14)
+        if (c->g.nfft_log2 == 14 && !c->coarse_v2)
+        {
+            // 2^14 as pairs of 2^13-point transforms run together (k_coarse3, wg_fft13x2); two 68 KiB exchange buffers in LDS
+            const int lds3 = 512 * 34 * (int)sizeof(double);
+            hipLaunchKernelGGL(k_coarse3, dim3(nlist < c->coarse3_grid ? nlist : c->coarse3_grid), dim3(C2_THREADS), lds3, st, c->g, c->p, d_list, nlist, c->d_tw);
+        }
+        else if (c->g.nfft_log2 == 14)
             hipLaunchKernelGGL((k_coarse2<14>), dim3(grid2), dim3(C2_THREADS), c->coarse2_lds, st, c->g, c->p, d_list, nlist, c->d_tw);
         else
             hipLaunchKernelGGL((k_coarse2<13>), dim3(grid2), dim3(C2_THREADS), c->coarse2_lds, st, c->g, c->p, d_list, nlist, c->d_tw);
