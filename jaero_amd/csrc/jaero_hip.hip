@@ -132,7 +132,7 @@ struct jaero_ctx
     int16_t *d_pcm_raw = nullptr;    // [nch*max_write] staging for host input
     double2 *d_scratch = nullptr;
     double2 *d_tw = nullptr;
-    bool coarse_v2 = false; int coarse3_grid = 256;
+    bool coarse_v2 = false; int coarse3_grid = 256, coarse_ver = 4;
     int *d_chanlist = nullptr;
     int coarse_grid = 0;
     bool coarse_v1 = false;  // JAERO_COARSE_V1=1 selects the four-step LDS/scratch FFT (kept for A/B validation)
@@ -578,6 +578,8 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         HIPCHK(hipFuncSetAttribute((const void *)k_coarse3, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 34 * (int)sizeof(double)));
         const char *e = getenv("JAERO_COARSE_KERNEL"); // "2" = the single 2^14-point transform (k_coarse2<14>), for comparison
         c->coarse_v2 = e && !strcmp(e, "2");
+        c->coarse_ver = (e && !strcmp(e, "3")) ? 3 : (c->coarse_v2 ? 2 : 4); // "3" = pairs of 2^13-point transforms (k_coarse3)
+        HIPCHK(hipFuncSetAttribute((const void *)k_coarse4, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 257 * (int)sizeof(double)));
         c->coarse3_grid = c->coarse2_grid;
     }
     else HIPCHK(hipFuncSetAttribute((const void *)k_coarse2<13>, hipFuncAttributeMaxDynamicSharedMemorySize, c->coarse2_lds));
@@ -772,7 +774,13 @@ static void launch_coarse(jaero_ctx *c, const int *d_list, int nlist, hipStream_
     {
         // register-resident FFT: one workgroup per CU (512-VGPR budget, ~140 KB LDS), persistent over the list
         const int grid2 = nlist < c->coarse2_grid ? nlist : c->coarse2_grid;
-        if (c->g.nfft_log2 == 14 && !c->coarse_v2)
+        if (c->g.nfft_log2 == 14 && c->coarse_ver == 4)
+        {
+            // 2^14 = 16 x 16 x 16 x 4, 16-point register FFTs only (k_coarse4); one padded plane of 64*257 doubles in LDS
+            hipLaunchKernelGGL(k_coarse4, dim3(nlist < c->coarse3_grid ? nlist : c->coarse3_grid), dim3(C2_THREADS), 64 * 257 * (int)sizeof(double), st, c->g, c->p,
+                               d_list, nlist, c->d_tw);
+        }
+        else if (c->g.nfft_log2 == 14 && !c->coarse_v2)
         {
             // 2^14 as pairs of 2^13-point transforms run together (k_coarse3, wg_fft13x2); two 68 KiB exchange buffers in LDS
             const int lds3 = 512 * 34 * (int)sizeof(double);

@@ -689,3 +689,295 @@ __global__ __launch_bounds__(C2_THREADS) void k_coarse3(const JGeom g, const JPt
         __syncthreads();
     }
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 2^14-point transform out of 16-point pieces only: 16384 = 16 x 16 x 16 x 4, four passes, natural order in AND out, all 512
+// threads busy in every pass, never more than one 16-point FFT's worth of temporaries on top of the 32 points a thread holds
+// (wg_fft<14> and the middle pass of wg_fft<13> run 32-point FFTs in registers -- 32 in, 32 out, 256 VGPRs -- and spill).
+//   n = n1*1024 + n2*64 + n3*4 + n4,   k = k1 + 16*k2 + 256*k3 + 4096*k4      (n1, n2, n3, k1, k2, k3 < 16;  n4, k4 < 4)
+//   pass 1: FFT16 over n1, x W_16384^(k1*(n mod 1024))     pass 2: FFT16 over n2, x W_1024^(k2*(n mod 64))
+//   pass 3: FFT16 over n3, x W_64^(k3*n4)                  pass 4: radix-4 over n4
+// A thread always holds 32 points = the 16 values of the digit being transformed x one more bit:
+//   in     slot 2*n1+b   b = n2>>3          thread t  = (n2&7)*64 + n3*4 + n4                (= natural: n = slot*512 + t)
+//   pass 2 slot 2*n2+c   c = k1&1           thread t' = (k1>>1)*64 + n3*4 + n4
+//   pass 3 slot 2*n3+b1  b1 = n4>>1         thread t''= (n4&1)*256 + k2*16 + k1
+//   pass 4 slot n4*8+h   h = k3>>1          thread    = (k3&1)*256 + k2*16 + k1    -> out slot k4*8+h  (= natural: k = slot*512 + t)
+// The three exchanges go through LDS one plane at a time; index maps chosen so that a wavefront's 64 lanes always touch 64
+// consecutive doubles, except the writes of exchange 2 (row stride 257 doubles: two lanes per 8-byte bank, the minimum).
+// xch: 64*257 doubles.
+__device__ __forceinline__ void c4_twiddle16(CV<16> &v, const double2 step) // v[k] *= step^k
+{
+#pragma clang fp contract(fast)
+    double2 B[4], A[8];
+    twiddle_powers<16>(make_double2(1.0, 0.0), step, B, A);
+#pragma unroll
+    for (int k = 1; k < 16; k++)
+    {
+        const double2 w = (k < 4) ? B[k & 3] : cmul2(A[k >> 2], B[k & 3]);
+        const double r = v.r[k] * w.x - v.i[k] * w.y, i = v.r[k] * w.y + v.i[k] * w.x;
+        v.r[k] = r; v.i[k] = i;
+    }
+}
+
+__device__ __forceinline__ void wg_fft14_r16(CV<32> &d, double *xch, const double2 *__restrict__ tw, int t)
+{
+#pragma clang fp contract(fast)
+    constexpr int S2 = 257;
+    // ---- pass 1 ----
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+    {
+        CV<16> in, out;
+#pragma unroll
+        for (int j = 0; j < 16; j++) { in.r[j] = d.r[2 * j + b]; in.i[j] = d.i[2 * j + b]; }
+        regfft<16>(in, out);
+        c4_twiddle16(out, tw[b * 512 + t]);
+#pragma unroll
+        for (int j = 0; j < 16; j++) { d.r[2 * j + b] = out.r[j]; d.i[2 * j + b] = out.i[j]; }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- exchange 1: L[(k1*16 + n2)*64 + r2] ----
+    {
+        const int rbase = (t >> 6) * 2048 + (t & 63); // reader: ((2*k1hi + c)*16 + n2)*64 + r2
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 32; s++) xch[((s >> 1) * 16 + (s & 1) * 8) * 64 + t] = d.r[s];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 32; s++) d.r[s] = xch[rbase + ((s & 1) * 16 + (s >> 1)) * 64];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 32; s++) xch[((s >> 1) * 16 + (s & 1) * 8) * 64 + t] = d.i[s];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 32; s++) d.i[s] = xch[rbase + ((s & 1) * 16 + (s >> 1)) * 64];
+    }
+    // ---- pass 2 ----
+    {
+        const double2 step = tw[16 * (t & 63)];
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+        {
+            CV<16> in, out;
+#pragma unroll
+            for (int j = 0; j < 16; j++) { in.r[j] = d.r[2 * j + c]; in.i[j] = d.i[2 * j + c]; }
+            regfft<16>(in, out);
+            c4_twiddle16(out, step);
+#pragma unroll
+            for (int j = 0; j < 16; j++) { d.r[2 * j + c] = out.r[j]; d.i[2 * j + c] = out.i[j]; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- exchange 2: L[r2*257 + k2*16 + k1] ----
+    {
+        const int wbase = (t & 63) * S2 + (t >> 6) * 2; // writer: r2*257 + k2*16 + 2*k1hi + c
+        const int rbase = (t >> 8) * S2 + (t & 255);     // reader: (n3*4 + 2*b1 + b0)*257 + u
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 32; s++) xch[wbase + (s >> 1) * 16 + (s & 1)] = d.r[s];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 32; s++) d.r[s] = xch[rbase + ((s >> 1) * 4 + (s & 1) * 2) * S2];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 32; s++) xch[wbase + (s >> 1) * 16 + (s & 1)] = d.i[s];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 32; s++) d.i[s] = xch[rbase + ((s >> 1) * 4 + (s & 1) * 2) * S2];
+    }
+    // ---- pass 3: twiddle W_64^(k3*n4), n4 = 2*b1 + b0, b0 = t >> 8 ----
+    {
+        const bool b0 = (t >> 8) != 0;
+#pragma unroll
+        for (int b1 = 0; b1 < 2; b1++)
+        {
+            CV<16> in, out;
+#pragma unroll
+            for (int j = 0; j < 16; j++) { in.r[j] = d.r[2 * j + b1]; in.i[j] = d.i[2 * j + b1]; }
+            regfft<16>(in, out);
+#pragma unroll
+            for (int k3 = 0; k3 < 16; k3++)
+            {
+                const int e0 = (k3 * (2 * b1)) & 63, e1 = (k3 * (2 * b1 + 1)) & 63;
+                const double wr = b0 ? JD_W64R[e1] : JD_W64R[e0], wi = b0 ? JD_W64I[e1] : JD_W64I[e0];
+                d.r[2 * k3 + b1] = out.r[k3] * wr - out.i[k3] * wi;
+                d.i[2 * k3 + b1] = out.r[k3] * wi + out.i[k3] * wr;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- exchange 3: L[(k3*4 + n4)*256 + u] ----
+    {
+        const int u = t & 255, q = t >> 8; // writer: n4 = 2*b1 + q; reader: k3 = 2*h + q
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 32; s++) xch[((s >> 1) * 4 + (s & 1) * 2 + q) * 256 + u] = d.r[s];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 32; s++) d.r[s] = xch[((2 * (s & 7) + q) * 4 + (s >> 3)) * 256 + u];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 32; s++) xch[((s >> 1) * 4 + (s & 1) * 2 + q) * 256 + u] = d.i[s];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 32; s++) d.i[s] = xch[((2 * (s & 7) + q) * 4 + (s >> 3)) * 256 + u];
+    }
+    // ---- pass 4: radix-4 over n4 (slots h, h+8, h+16, h+24) ----
+#pragma unroll
+    for (int h = 0; h < 8; h++)
+    {
+        const double ar = d.r[h], ai = d.i[h], br = d.r[h + 8], bi = d.i[h + 8];
+        const double cr = d.r[h + 16], ci = d.i[h + 16], er = d.r[h + 24], ei = d.i[h + 24];
+        const double t0r = ar + cr, t0i = ai + ci, t1r = ar - cr, t1i = ai - ci;
+        const double t2r = br + er, t2i = bi + ei;
+        const double t3r = (bi - ei), t3i = -(br - er); // -i (b - e)
+        d.r[h] = t0r + t2r; d.i[h] = t0i + t2i;
+        d.r[h + 8] = t1r + t3r; d.i[h + 8] = t1i + t3i;
+        d.r[h + 16] = t0r - t2r; d.i[h + 16] = t0i - t2i;
+        d.r[h + 24] = t1r - t3r; d.i[h + 24] = t1i - t3i;
+    }
+}
+
+// one transform; the thread index is laundered per call so that nothing derived from it inside is shared between the three calls
+// of an estimate and kept live (spilled) across everything in between
+__device__ __forceinline__ void c4_fft(CV<32> &d, double *xch, const double2 *__restrict__ tw, int t)
+{
+    int tt = t;
+    asm volatile("" : "+v"(tt));
+    wg_fft14_r16(d, xch, tw, tt);
+}
+
+// k_coarse2<14> with the radix-16 transform above, the per-estimate opaque thread index and the fold from LDS of k_coarse3.
+// Measured (MI355X, 65536 estimates per launch): 20.2 ms (k_coarse3 24.7, k_coarse2<14> 28.5); 64 bytes of scratch per thread
+// instead of ~500, i.e. the ~48 GB of spill traffic per launch are gone.
+__global__ __launch_bounds__(C2_THREADS) void k_coarse4(const JGeom g, const JPtrs p, const int *__restrict__ chan_list,
+                                                           int nlist, const double2 *__restrict__ tw)
+{
+    constexpr int N = 1 << 14;
+    constexpr int E = 32;
+    extern __shared__ __attribute__((aligned(16))) double xch[];
+    __shared__ double red_val[C2_THREADS];
+    __shared__ int red_idx[C2_THREADS];
+    __shared__ int sh_bigchange;
+    const int t0 = threadIdx.x;
+    const int nchp = g.nchp;
+
+    CV<E> d;
+    for (int li = blockIdx.x; li < nlist; li += gridDim.x)
+    {
+        int t = t0; // opaque once per estimate: see k_coarse3
+        asm volatile("" : "+v"(t));
+        const int ch = chan_list ? chan_list[li] : li;
+        const double2 *__restrict__ ring = p.bbring + (size_t)ch * N;
+        const int bb_ptr = p.I[(size_t)I_BB_PTR * nchp + ch];
+        const double lockingbw = p.S[(size_t)S_LOCKINGBW * nchp + ch];
+        const double hzperbin = g.Fs / ((double)N);
+        const int startbin = (int)fmax(round(lockingbw / hzperbin), 1.0);
+        const int stopbin = N - startbin;
+        const int expectedpeakbin = (int)round(g.fb / (2.0 * hzperbin));
+        double *__restrict__ y = p.y + (size_t)ch * N;
+
+        // bbtmpbuff[j] = bbcycbuff[(ptr+j)%N] (time order); for every list entry but the first, these loads were issued
+        // while the previous estimate was in its peak search / state machine (d is free there), hiding the HBM latency
+        if (li == (int)blockIdx.x)
+        {
+#pragma unroll
+            for (int s = 0; s < E; s++)
+            {
+                const double2 v = ring[(bb_ptr + s * C2_THREADS + t) & (N - 1)];
+                d.r[s] = v.x; d.i[s] = v.y;
+            }
+        }
+        c4_fft(d, xch, tw, t);
+        // band limit (fb != 8400 boxcar, coarsefreqestimate.cpp:99) then inverse transform = forward on swapped planes
+#pragma unroll
+        for (int s = 0; s < E; s++)
+        {
+            const int k = s * C2_THREADS + t;
+            const bool z = (k >= startbin) && (k <= stopbin);
+            const double re = z ? 0.0 : d.r[s], im = z ? 0.0 : d.i[s];
+            d.r[s] = im; d.i[s] = re;
+        }
+        c4_fft(d, xch, tw, t);
+        // swap back (x N / N = 1), square
+#pragma unroll
+        for (int s = 0; s < E; s++)
+        {
+            const double re = d.i[s], im = d.r[s];
+            d.r[s] = re * re - im * im;
+            d.i[s] = re * im + im * re;
+        }
+        c4_fft(d, xch, tw, t);
+        __syncthreads(); // the exchange buffer is free: it receives a copy of y for the fold below
+        // smooth with fftshift: y[i] = y[i]*0.9 + 0.1*10*log10(fmax(abs(out[i]),1)), out[i] = X[i ^ N/2]
+#pragma unroll
+        for (int s = 0; s < E; s++)
+        {
+            const int k = s * C2_THREADS + t;
+            const int i = k ^ (N / 2);
+            // 10*log10(max(|X|,1)) == 5*log10(max(|X|^2,1)): no hypot; differs from the reference expression by <= 1 ulp
+            const double yn = y[i] * 0.9 + 5.0 * c2_log10(fmax(d.r[s] * d.r[s] + d.i[s] * d.i[s], 1.0));
+            y[i] = yn;
+            xch[i] = yn;
+        }
+        __syncthreads();
+        {
+            const int ln = li + (int)gridDim.x;
+            if (ln < nlist)
+            {
+                const int chn = chan_list ? chan_list[ln] : ln;
+                const double2 *__restrict__ ringn = p.bbring + (size_t)chn * N;
+                const int bpn = p.I[(size_t)I_BB_PTR * nchp + chn];
+#pragma unroll
+                for (int s = 0; s < E; s++)
+                {
+                    const double2 v = ringn[(bpn + s * C2_THREADS + t) & (N - 1)];
+                    d.r[s] = v.x; d.i[s] = v.y;
+                }
+            }
+        }
+
+        // fold + peak search (:116-131)
+        const int i0 = (int)round((-lockingbw / hzperbin) + ((double)(N / 2)));
+        const int i1 = (int)round((lockingbw / hzperbin) + ((double)(N / 2)));
+        double best = 0;
+        int besti = -1;
+        for (int i = i0 + t; i < i1; i += C2_THREADS)
+        {
+            if ((i < 0) || (i >= N)) continue;
+            double val = 0;
+            for (int j = -1; j <= 1; j++)
+            {
+                if (((i - expectedpeakbin - j) < 0) || ((i + expectedpeakbin + j) >= N)) continue;
+                val += (xch[i - expectedpeakbin - j] + xch[i + expectedpeakbin + j]);
+            }
+            if (val > best) { best = val; besti = i; }
+        }
+        red_val[t] = best;
+        red_idx[t] = besti;
+        __syncthreads();
+        for (int s = C2_THREADS / 2; s > 0; s >>= 1)
+        {
+            if (t < s)
+            {
+                const double ov = red_val[t + s];
+                const int oi = red_idx[t + s];
+                const double mv = red_val[t];
+                const int mi = red_idx[t];
+                if (oi >= 0 && (mi < 0 || ov > mv || (ov == mv && oi < mi))) { red_val[t] = ov; red_idx[t] = oi; }
+            }
+            __syncthreads();
+        }
+        if (t == 0) sh_bigchange = coarse_slot(g, p, ch, (red_idx[0] >= 0) ? red_idx[0] : (N / 2), N, hzperbin, lockingbw);
+        __syncthreads();
+        if (sh_bigchange)
+        {
+            double2 *ringw = p.bbring + (size_t)ch * N;
+            for (int i = t; i < N; i += C2_THREADS) { y[i] = 20; ringw[i] = make_double2(0.0, 0.0); }
+        }
+        __syncthreads();
+    }
+}
+
+
