@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--chunk", type=int, default=4096)
     ap.add_argument("--ebno", type=int, default=1, help="run the EbNo meters (the reference always does)")
     ap.add_argument("--ebno-db", type=float, default=10.0)
+    ap.add_argument("--idle-frac", type=float, default=0.0, help="aerol workload: fraction of channels that carry noise only (never lock)")
     ap.add_argument("--workload", default="oqpsk", choices=["oqpsk", "burst_oqpsk", "aerol"],
                     help="oqpsk = BASELINE configs[2] (continuous, the headline); burst_oqpsk = configs[3] (one burst per second per "
                          "channel); aerol = the 10.5 kbps P-channel bit pipeline behind the demodulator (SURVEY 8 row f1), one frame per step")
@@ -205,6 +206,12 @@ def aerol_bench():
     host = np.stack(streams)  # [nuniq, (K+W)*5250]
     soft = torch.from_numpy(host).to(dev)
     idx = torch.arange(nch, device=dev) % nuniq
+    if ARGS.idle_frac > 0:  # noise-only channels scattered over the bank (every wavefront gets some): stream index nuniq = noise
+        noise = np.clip(np.round(128 + prng.normal(0.0, 40.0, size=host.shape[1])), 0, 255).astype(np.int16)
+        soft = torch.cat([soft, torch.from_numpy(noise[None, :]).to(dev)])
+        g = torch.Generator(device="cpu").manual_seed(5)
+        idle = (torch.rand(nch, generator=g) < ARGS.idle_frac).to(dev)
+        idx = torch.where(idle, torch.full_like(idx, nuniq), idx)
     counts = torch.full((nch,), flen, dtype=torch.int32, device=dev)
     bank = AeroLBank(nch, fb, device=local, max_softbits_per_write=flen + 8, su_capacity=26 * (K + W) + 8)
     stream = torch.cuda.current_stream().cuda_stream
@@ -258,6 +265,7 @@ def aerol_bench():
             "config": {"workload": f"{nch}-channel-per-GPU 10.5 kbps P-channel frames (5250 soft bits = 0.5 s per step and channel), "
                                    f"{nuniq} distinct noisy frame streams at random frame phases replicated over the channels, arm inversions mixed",
                        "channels_per_gpu": nch, "total_channels": nch * world, "realtime_channel_equivalents": int(value * 1e6 / 10500),
+                       "idle_channel_fraction": ARGS.idle_frac,
                        "crc_clean_units_in_first_channels": good, "channels_checked": min(4, nch),
                        "kernel_ms_per_step": {k: round(v / K, 4) for k, v in ms.items()}, "kernel_launches": nl},
             "roofline": {"bound": "hbm", "kernel": {"bits": "k_aerol_bits+k_aerol_bulk+k_aerol_deint", "viterbi": "k_viterbi_lanes", "post": "k_aerol_post"}[dom],
