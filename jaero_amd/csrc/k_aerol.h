@@ -22,7 +22,7 @@ enum
     AI_CNTR, AI_DATACD, AI_DCDCOUNT, AI_GOTSYNC_LAST, AI_REALIMAG, AI_BLOCKCNT, AI_MUW, AI_FRAMEINFO, AI_LASTFRAMEINFO,
     AI_PD_EXACT, AI_PD_IMAG, AI_PD_REAL, AI_INV_IMAG, AI_INV_REAL, AI_SCR_POS, AI_DL2_PTR, AI_NINFO, AI_NFRAMES,
     AI_IN_POS, AI_RESUME, AI_RESUME_GOTSYNC, AI_HAS_BLOCK, AI_VBLOCKS, AI_SU_CNT, AI_EV_CNT, AI_OVERFLOW, AI_NBITS_LO, AI_NBITS_HI, AI_ACC, AI_ACCBAD,
-    AI_MARKER, AI_BULK_LEN, AI_BULK_SRC, AI_BULK_DST, AI_BULK_FLAGS,
+    AI_MARKER, AI_BULK_LEN, AI_BULK_SRC, AI_BULK_DST, AI_BULK_FLAGS, AI_NMATCH, AI_MATCH0, AI_MATCH1, AI_MATCH2, AI_MATCH3,
     AI_NFIELDS
 };
 struct AGeom
@@ -164,6 +164,7 @@ __device__ __forceinline__ void aerol_bit_b(const AGeom &g, const APtrs &p, int 
 // over it and leaves a descriptor for k_aerol_bulk, which copies it with a whole wavefront.  Everything else (unique-word windows,
 // headers, unlocked channels, 600/1200 bps, writes with markers) goes bit by bit.
 #define AEROL_MINRUN 32
+#define AEROL_NMATCH 4 // potential unique-word positions k_aerol_scan records per channel and write
 template <bool BULK>
 __global__ __launch_bounds__(64) void k_aerol_bits(const AGeom g, const APtrs p, const int16_t *__restrict__ soft, const int *__restrict__ counts, int stride)
 {
@@ -195,40 +196,92 @@ __global__ __launch_bounds__(64) void k_aerol_bits(const AGeom g, const APtrs p,
     }
     bool live = valid && pos < n;
     const int zone_hi = g.NumberOfBits - 68; // last pre-increment cntr without unique-word detection
+    const int block_last = g.BitsInHeader + g.blocksz - 2; // pre-increment cntr of the bit that completes the (only) block of a frame
+    const int scan_hi = 32768; // k_aerol_scan covers this many positions of a write
+    // first position >= pos at which the detector of an unlocked channel could fire; -1: none in this write
+    const int nmatch = BULK ? ALD(AI_NMATCH) : 0;
+    int match[AEROL_NMATCH];
+#pragma unroll
+    for (int k = 0; k < AEROL_NMATCH; k++) match[k] = (BULK && k < nmatch) ? p.I[(size_t)(AI_MATCH0 + k) * g.nchp + ch] : 0x7fffffff;
+    int next_match = -1;
     int vnext = live ? (int)sb[pos] : 0;
     while (__any(live))
     {
         if (live)
         {
-            bool jumped = false;
-            if (may_bulk && s.datacd && bulk_len == 0 && s.cntr >= 16 && s.cntr <= zone_hi)
+            // next potential unique-word position at or after pos (beyond the AEROL_NMATCH-th known one: walk bit by bit)
+            next_match = -1;
             {
-                const int L = min(zone_hi - s.cntr + 1, n - pos);
-                if (L >= AEROL_MINRUN)
+                bool found = false;
+#pragma unroll
+                for (int k = 0; k < AEROL_NMATCH; k++)
+                    if (!found && match[k] != 0x7fffffff && match[k] >= pos) { next_match = match[k]; found = true; }
+                if (!found && nmatch > AEROL_NMATCH) next_match = pos; // more hits than recorded: no jumps past the last known one
+            }
+            bool jumped = false;
+            // Two kinds of stretch in which AeroL::Decode only counts, toggles the arm and copies the soft bit:
+            //  locked   (data carrier): pre-increment cntr in [16, NumberOfBits-68] -- no unique-word detection, header done
+            //  unlocked (no carrier, detector on every bit): up to the bit before the next position at which the detector could
+            //           fire (k_aerol_scan) and before the bit that completes the block; cntr >= 16 (or still saturated)
+            int L = 0;
+            bool unlocked_jump = false;
+            if (may_bulk && bulk_len == 0 && s.cntr >= 16)
+            {
+                if (s.datacd) { if (s.cntr <= zone_hi) L = min(zone_hi - s.cntr + 1, n - pos); }
+                else if (pos >= 64 && pos < scan_hi)
                 {
-                    // L soft bits with pre-increment cntr = c .. c+L-1: bit i has arm parity realimag ^ ((i+1)&1) and goes to
-                    // block index max(0, c+1+i - BitsInHeader); the dummy bits in front of the block all land on index 0 and are
-                    // overwritten by the first real one, so only i >= i0 is copied
-                    const int c = s.cntr;
-                    const int i0 = max(0, g.BitsInHeader - (c + 1));
-                    if (i0 < L)
-                    {
-                        bulk_src = pos + i0;
-                        bulk_dst = c + 1 + i0 - g.BitsInHeader;
-                        bulk_len = L - i0;
-                        bulk_flags = ((s.realimag ^ ((i0 + 1) & 1)) & 1) | (s.inv_imag ? 2 : 0) | (s.inv_real ? 4 : 0);
-                    }
-                    else bulk_len = -1; // nothing to copy, but only one jump per round (one descriptor slot)
-                    s.cntr += L;
-                    s.realimag ^= (L & 1);
-                    s.muw = min(100000, s.muw + L);
-                    s.gotsync_last = 0;
-                    gotsync = 0;
-                    s.accbad = 1; // the per-bit path may resume inside a group of four
-                    pos += L;
-                    jumped = true;
-                    if (pos < n) vnext = (int)sb[pos];
+                    int lim = min(n, scan_hi) - pos;
+                    if (next_match >= pos) lim = min(lim, next_match - pos);
+                    if (s.cntr < 1000000000) lim = min(lim, block_last - s.cntr); // pre-increment cntr of the completing bit = block_last
+                    L = lim;
+                    unlocked_jump = true;
                 }
+            }
+            if (L >= AEROL_MINRUN)
+            {
+                // L soft bits with pre-increment cntr = c .. c+L-1: bit i has arm parity realimag ^ ((i+1)&1) and goes to block
+                // index max(0, c+1+i - BitsInHeader); the dummy bits in front of the block all land on index 0 and are overwritten
+                // by the first real one, so only i >= i0 is copied.  (Saturated cntr: every bit lands on one index; nothing to copy.)
+                const int c = s.cntr;
+                const bool sat = c >= 1000000000;
+                // soft bytes of a group of four that the bit-by-bit path has collected but not stored yet
+                if (!sat && !s.accbad)
+                {
+                    const int idx_next = c + 1 - g.BitsInHeader, k = idx_next & 3;
+                    if (idx_next > 0)
+                        for (int j = 0; j < k; j++) rx[idx_next - k + j] = (uint8_t)(s.acc >> (8 * (4 - k + j)));
+                }
+                const int i0 = sat ? L : max(0, g.BitsInHeader - (c + 1));
+                if (i0 < L)
+                {
+                    bulk_src = pos + i0;
+                    bulk_dst = c + 1 + i0 - g.BitsInHeader;
+                    bulk_len = L - i0;
+                    bulk_flags = ((s.realimag ^ ((i0 + 1) & 1)) & 1) | (s.inv_imag ? 2 : 0) | (s.inv_real ? 4 : 0);
+                }
+                else bulk_len = -1; // nothing to copy, but only one jump per round (one descriptor slot)
+                if (unlocked_jump)
+                {
+                    // the detector ran over every jumped bit: bring both arms' shift registers up to date from the last 64 of them
+                    const int m = min(L, 64);
+                    int r = s.realimag ^ ((L - m) & 1);
+                    for (int i = L - m; i < L; i++)
+                    {
+                        r ^= 1;
+                        const unsigned bitv = (((unsigned)(int)sb[pos + i] & 0xFFu) >= 128u) ? 1u : 0u;
+                        if (r) s.pd_imag = (s.pd_imag << 1) | bitv;
+                        else s.pd_real = (s.pd_real << 1) | bitv;
+                    }
+                }
+                if (!sat) s.cntr += L;
+                s.realimag ^= (L & 1);
+                s.muw = min(100000, s.muw + L);
+                s.gotsync_last = 0;
+                gotsync = 0;
+                s.accbad = 1; // the per-bit path may resume inside a group of four
+                pos += L;
+                jumped = true;
+                if (pos < n) vnext = (int)sb[pos];
             }
             if (!jumped)
             {
@@ -256,18 +309,75 @@ __global__ __launch_bounds__(64) void k_aerol_bits(const AGeom g, const APtrs p,
     ALD(AI_BULK_LEN) = bulk_len > 0 ? bulk_len : 0; ALD(AI_BULK_SRC) = bulk_src; ALD(AI_BULK_DST) = bulk_dst; ALD(AI_BULK_FLAGS) = bulk_flags;
 }
 
-// does this write hold a start-of-burst marker (a negative soft value) for the channel?  One wavefront per channel, coalesced.
+// Per write and channel, one wavefront per channel: (1) does the input hold a start-of-burst marker (a negative soft value); (2) the
+// first positions q >= 62 at which the unique-word detector of q's arm WOULD see the word or its complement if it had been running
+// over the last 32 soft bits of that arm (q, q-2, .., q-62) -- which is the case for a channel without data carrier, whose detector
+// runs on every bit.  k_aerol_bits uses them to jump over the stretches of such a channel in which nothing can happen.
+// Hard bits are packed per position parity into LDS; a window of 32 consecutive bits of one parity, oldest in bit 0, equals the
+// detector's shift register bit-reversed, so it is compared with the bit-reversed word.
 __global__ __launch_bounds__(256) void k_aerol_scan(const AGeom g, const APtrs p, const int16_t *__restrict__ soft, const int *__restrict__ counts, int stride)
 {
+    __shared__ unsigned par[4][2][512 + 2]; // [wave][position parity][32 positions of that parity per word]
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ch = blockIdx.x * 4 + w;
     if (ch >= g.nch) return;
-    const int n = counts[ch];
+    const int nall = counts[ch];
+    const int n = min(nall, 32768);
     const int16_t *sb = soft + (size_t)ch * stride;
+    // only a channel without data carrier consults the positions (a carrier cannot be lost inside a write: updateDCD runs between)
+    const bool want = g.oqpsk && !ALD(AI_DATACD);
     int neg = 0;
-    for (int k = lane; k < n; k += 64) neg |= (sb[k] < 0) ? 1 : 0;
+    for (int q = n + lane; q < nall; q += 64) neg |= (sb[q] < 0) ? 1 : 0; // beyond the scanned range: markers only
+    for (int base = 0; base < n; base += 64)
+    {
+        const int q = base + lane;
+        const int v = q < n ? (int)sb[q] : 0;
+        neg |= (v < 0) ? 1 : 0;
+        if (!want) continue;
+        const unsigned long long m = __ballot((((unsigned)v & 0xFFu) >= 128u) && q < n);
+        if (lane < 2)
+        {
+            // the 32 bits of parity `lane` out of the 64 of this block, in order
+            unsigned long long x = (m >> lane) & 0x5555555555555555ull;
+            x = (x | (x >> 1)) & 0x3333333333333333ull;
+            x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+            x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+            x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+            x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+            par[w][lane][base >> 6] = (unsigned)x;
+        }
+    }
     const int any = __any(neg) ? 1 : 0;
-    if (lane == 0) ALD(AI_MARKER) = any;
+    int nmatch = 0;
+    if (want)
+    {
+        const unsigned ruw = __brev(AEROL_UW);
+        for (int base = 0; base < n; base += 64)
+        {
+            const int q = base + lane;
+            bool hit = false;
+            if (q >= 62 && q < n)
+            {
+                const int j = q >> 1; // index within the parity stream; window = stream bits j-31 .. j
+                const unsigned *pw = par[w][q & 1];
+                const int lo = j - 31;
+                const unsigned long long two = (unsigned long long)pw[lo >> 5] | ((unsigned long long)pw[(lo >> 5) + 1] << 32);
+                const unsigned win = (unsigned)(two >> (lo & 31));
+                hit = (win == ruw) || (win == ~ruw);
+            }
+            const unsigned long long hm = __ballot(hit);
+            if (hm)
+            {
+                if (hit)
+                {
+                    const int r = nmatch + __popcll(hm & ((1ull << lane) - 1ull));
+                    if (r < AEROL_NMATCH) p.I[(size_t)(AI_MATCH0 + r) * g.nchp + ch] = q;
+                }
+                nmatch += __popcll(hm);
+            }
+        }
+    }
+    if (lane == 0) { ALD(AI_MARKER) = any; ALD(AI_NMATCH) = nmatch; }
 }
 
 // the stretches k_aerol_bits jumped over: rx[dst + i] = soft bit (src + i), inverted per arm, i < len.  One wavefront per channel,

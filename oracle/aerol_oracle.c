@@ -148,6 +148,20 @@ void jo_aerol_destroy(jo_aerol *a)
     free(a->block); free(a->dl2); jo_codec_destroy(a->codec); free(a->sus.p); free(a->events.p); free(a);
 }
 int jo_aerol_dcd(jo_aerol *a) { return a->datacd; }
+
+/* AeroL::updateDCD (aerol.cpp:1109-1122); the reference calls it from a 1 s wall-clock QTimer, tests call it at chosen points of
+ * the stream.  The DataCarrierDetect(false) it may emit is logged with the index of the next soft bit. */
+int jo_aerol_tick_dcd(jo_aerol *a)
+{
+    if (a->datacdcountdown > 0) a->datacdcountdown -= 3;
+    else if (a->datacdcountdown < 0) a->datacdcountdown = 0;
+    if (a->datacd && !a->datacdcountdown)
+    {
+        a->datacd = 0;
+        ev(a, a->nbits_total, 0, 0);
+    }
+    return a->datacd;
+}
 long jo_aerol_take_sus(jo_aerol *a, int32_t *dst, long cap) { return gb_take(&a->sus, dst, 16 * sizeof(int32_t), cap); }
 long jo_aerol_take_events(jo_aerol *a, int64_t *dst, long cap) { return gb_take(&a->events, dst, 3 * sizeof(int64_t), cap); }
 

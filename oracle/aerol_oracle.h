@@ -17,6 +17,7 @@ long jo_aerol_take_sus(jo_aerol *a, int32_t *dst, long caprows);
 /* rows of 3 int64: [index of the soft bit, kind, value]; kind 0 = DataCarrierDetect(value), 1 = "Error short frame" , 2 = gotsync */
 long jo_aerol_take_events(jo_aerol *a, int64_t *dst, long caprows);
 int jo_aerol_dcd(jo_aerol *a);
+int jo_aerol_tick_dcd(jo_aerol *a); /* AeroL::updateDCD, returns the data-carrier-detect flag afterwards */
 #ifdef __cplusplus
 }
 #endif

@@ -138,6 +138,8 @@ def lib():
         L.jo_aerol_take_events.restype = C.c_long
         L.jo_aerol_take_events.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.jo_aerol_dcd.argtypes = [C.c_void_p]
+        L.jo_aerol_tick_dcd.argtypes = [C.c_void_p]
+        L.jo_aerol_tick_dcd.restype = C.c_int
         _lib = L
     return _lib
 
@@ -355,6 +357,10 @@ class AeroL:
     @property
     def dcd(self):
         return self.L.jo_aerol_dcd(self.h)
+
+    def tick_dcd(self) -> int:
+        """AeroL::updateDCD (the reference's 1 s timer)."""
+        return self.L.jo_aerol_tick_dcd(self.h)
 
 
 def run_aerol(fb: int, soft: np.ndarray, group: int = 32):

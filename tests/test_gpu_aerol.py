@@ -97,6 +97,56 @@ def test_start_of_burst_markers(B, oracle_mod):
     bank.close()
 
 
+def test_carrier_loss_noise_and_reacquisition(B, oracle_mod):
+    """Channels that lose their carrier (updateDCD ticks drop DataCarrierDetect), free-run over noise -- decoding junk blocks, as the
+    reference does -- and re-acquire; and channels that never see anything but noise.  Unlocked channels jump over the stretches
+    between the positions k_aerol_scan marks as possible unique words; one channel gets a planted unique word in its noise."""
+    fb, nch, W = 10500, 9, 5250
+    rng = np.random.default_rng(11)
+    streams = []
+    for c in range(nch):
+        noise = lambda n: np.clip(np.round(128 + rng.normal(0, 45, n)), 0, 255).astype(np.int16)
+        if c % 3 == 2:
+            x = noise(11 * W)
+            if c == 5:  # a perfect unique word on both arms in the middle of noise: a false sync, then junk frames
+                uw = np.repeat([(AF.UW >> (31 - k)) & 1 for k in range(32)], 2)
+                x[20011:20011 + 64] = np.where(uw > 0, 200, 55)
+        else:
+            a, _ = AF.p_channel_bits(AF.random_payloads(3, fb, seed=500 + c), fb, invert_i=bool(c & 1), invert_q=bool(c & 2))
+            b, _ = AF.p_channel_bits(AF.random_payloads(3, fb, seed=600 + c), fb, first_counter=7)
+            x = np.concatenate([noise(int(rng.integers(0, 700))), AF.to_soft(a, sigma=25.0, seed=c), noise(4 * W + int(rng.integers(0, 999))),
+                                AF.to_soft(b, sigma=25.0, seed=c + 50)])
+        streams.append(x)
+    n = max(len(x) for x in streams)
+    bank = B.AeroLBank(nch, fb, max_softbits_per_write=W, su_capacity=600)
+    orc = [oracle_mod.AeroL(fb) for _ in range(nch)]
+    step = 0
+    for s0 in range(0, n, W):
+        buf = np.zeros((nch, W), np.int16)
+        cnt = np.zeros(nch, np.int32)
+        for c in range(nch):
+            seg = streams[c][s0:s0 + W]
+            buf[c, :len(seg)] = seg
+            cnt[c] = len(seg)
+            for g0 in range(0, len(seg), 32):
+                orc[c].write(seg[g0:g0 + 32])
+        bank.write(buf, cnt)
+        step += 1
+        if step >= 4:  # from the fourth write on the 1 s timer fires twice per write: the carrier detect of silent channels drops
+            for _ in range(2):
+                d = bank.tick_dcd()
+                for c in range(nch):
+                    assert orc[c].tick_dcd() == int(d[c])
+    nclean = 0
+    for c in range(nch):
+        sus, ev = orc[c].take_sus(), orc[c].take_events()
+        assert np.array_equal(bank.read_sus(c, 600), sus), c
+        assert np.array_equal(bank.read_events(c), ev), c
+        nclean += int(sus[:, 14].sum()) if len(sus) else 0
+    assert nclean > 100
+    bank.close()
+
+
 def test_tick_dcd(B):
     g = load_golden("aerol_1200")
     bank = B.AeroLBank(1, 1200, max_softbits_per_write=16384)
