@@ -260,6 +260,7 @@ int main(int argc, char **argv)
         QObject::connect(&a, &AeroL::DataCarrierDetect, [&](bool d) { sink.write(QString("#DCD %1 %2\n").arg(d ? 1 : 0).arg(gstart).toLatin1()); });
         a.setSettings(getd("fb", 10500), geti("burst", 0) != 0);
         int group = geti("group", 32);
+        auto t0 = std::chrono::steady_clock::now();
         for (long s = 0; s < n; s += group)
         {
             long m = (s + group <= n) ? group : n - s;
@@ -268,7 +269,9 @@ int main(int argc, char **argv)
             gstart = s;
             a.processDemodulatedSoftBits(v);
         }
+        double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         writeall(argv[3], sink.data().constData(), sink.data().size());
+        printf("%.6f %ld\n", secs, n); // seconds inside processDemodulatedSoftBits (bench.py's cpu_baseline)
         return 0;
     }
     if (mode == "time")
