@@ -135,3 +135,64 @@ def random_payloads(nframes: int, fb: int, seed: int = 0):
     nsu = g["nbits"] // 2 // 8 // 12
     rng = np.random.default_rng(seed)
     return [[bytes(rng.integers(0, 256, size=10, dtype=np.uint8)) for _ in range(nsu)] for _ in range(nframes)]
+
+
+# ------------------------------------------------------------------------------------------------- R / T channel bursts (10500 bps)
+def crc16_bits(bits: np.ndarray) -> np.ndarray:
+    """The 16 CRC bits AeroLcrc16::calcusingbitsandcheck expects after `bits` (aerol.h:287-315): ~crc, least significant bit first."""
+    crc = 0xFFFF
+    for b in bits:
+        c = crc & 1
+        crc >>= 1
+        if c ^ int(b):
+            crc ^= 0x8408
+    crc = (~crc) & 0xFFFF
+    return np.array([(crc >> k) & 1 for k in range(16)], dtype=np.uint8)
+
+
+def _bytes_to_bits(data: bytes) -> np.ndarray:
+    return np.unpackbits(np.frombuffer(data, dtype=np.uint8), bitorder="little")
+
+
+def rt_packet_bits(kind: str, payload) -> np.ndarray:
+    """Channel bits of one R packet (`payload`: 17 bytes) or T packet (`payload`: (4-byte header, [10-byte SUs], at least two)) as
+    RTChannelDeleaveFECScram::update expects them (aerol.h:785-873): [fields + CRC-16 each] -> scrambled -> K=7 r=1/2 from the zero
+    state, flushed -> 64 x cols block interleaver with cols = 5 (R) or 5 + 3 (n - 1) (T with n signal units)."""
+    if kind == "R":
+        assert len(payload) == 17
+        b = _bytes_to_bits(bytes(payload))
+        info = np.concatenate([b, crc16_bits(b)])
+        cols = 5
+    else:
+        hdr, sus = payload
+        assert len(hdr) == 4 and len(sus) >= 2 and all(len(x) == 10 for x in sus)
+        parts = []
+        for field in [bytes(hdr)] + [bytes(x) for x in sus]:
+            b = _bytes_to_bits(field)
+            parts += [b, crc16_bits(b)]
+        info = np.concatenate(parts)
+        cols = 5 + 3 * (len(sus) - 1)
+    ndec = 32 * cols
+    assert len(info) + 6 <= ndec
+    msg = np.zeros(ndec, dtype=np.uint8)
+    msg[: len(info)] = info ^ scrambler_sequence(len(info))
+    coded = conv_encode(msg)
+    return interleave(coded, cols)
+
+
+def rt_burst_stream(packets, *, gap: int = 12000, lead: int = 80, sigma: float = 20.0, seed: int = 0, invert_i=False, invert_q=False):
+    """Soft-bit stream of a burst demodulator carrying the given packets [(kind, payload), ..]: noise, then per burst the start-of-burst
+    marker (-1), `lead` soft bits of noise, the unique word on both arms, the packet, and `gap` soft bits of noise."""
+    rng = np.random.default_rng(seed)
+    noise = lambda n: np.clip(np.round(128 + rng.normal(0, 40, n)), 0, 255).astype(np.int16)
+    uwbits = np.repeat(np.array([(UW >> (31 - k)) & 1 for k in range(32)], dtype=np.uint8), 2)
+    out = [noise(64)]
+    for kind, payload in packets:
+        bits = np.concatenate([uwbits, rt_packet_bits(kind, payload)])
+        if invert_i:
+            bits[0::2] ^= 1
+        if invert_q:
+            bits[1::2] ^= 1
+        ld = lead + (lead & 1)
+        out += [np.array([-1], dtype=np.int16), noise(ld), to_soft(bits, sigma=sigma, seed=int(rng.integers(1 << 30))), noise(gap + (gap & 1))]
+    return np.concatenate(out)

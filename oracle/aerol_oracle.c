@@ -99,7 +99,15 @@ struct jo_aerol
     int depermute[64];
     long nbits_total, nframes;
     gb sus, events;
+    /* burst mode (R/T channel packets): RTChannelDeleaveFECScram aerol.h:554-873 */
+    int burstmode;
+    int *rt_block; int rt_blockptr, rt_last, rt_scr_pos, rt_numberofsus;
+    jo_codec *rt_codec;
+    long npackets;
+    gb packets;
 };
+#define RT_BLOCKSZ (64 * 95)
+enum { RT_OK_R = 3, RT_OK_T = 5, RT_BAD = 0, RT_TEST_FAILED = 32, RT_NOTHING = 8, RT_FULL = 16 };
 
 static void ev(jo_aerol *a, long idx, int kind, long value)
 {
@@ -142,9 +150,26 @@ jo_aerol *jo_aerol_create(int fb)
     ev(a, 0, 0, 0); /* emit DataCarrierDetect(false) in the ctor */
     return a;
 }
+/* AeroL(parent) + setSettings(fb, true): the R/T-channel (burst) decoder for 10500 bps.  The phase-invariant unique-word detectors get
+ * tolerance 4, the frame countdown becomes one second of bits (aerol.cpp:996-1003,1062-1070). */
+jo_aerol *jo_aerol_create_burst(int fb)
+{
+    if (fb != 10500) return NULL; /* 600/1200 bps bursts (updateMSK, mskBurstDetector) are not restated */
+    jo_aerol *a = jo_aerol_create(fb);
+    a->burstmode = 1;
+    a->pd_imag.tollerence = 4; a->pd_real.tollerence = 4;
+    a->TotalNumberOfBits = a->ifb;
+    a->rt_block = (int *)calloc(RT_BLOCKSZ, sizeof(int));
+    a->rt_codec = jo_codec_create(24);
+    a->rt_last = RT_NOTHING;
+    return a;
+}
+long jo_aerol_take_packets(jo_aerol *a, int32_t *dst, long cap) { return gb_take(&a->packets, dst, 16 * sizeof(int32_t), cap); }
+
 void jo_aerol_destroy(jo_aerol *a)
 {
     if (!a) return;
+    free(a->rt_block); if (a->rt_codec) jo_codec_destroy(a->rt_codec); free(a->packets.p);
     free(a->block); free(a->dl2); jo_codec_destroy(a->codec); free(a->sus.p); free(a->events.p); free(a);
 }
 int jo_aerol_dcd(jo_aerol *a) { return a->datacd; }
@@ -224,6 +249,92 @@ static void block_done(jo_aerol *a, long bitidx) /* aerol.cpp:1553-1600 */
     }
 }
 
+static int crc16_bits_check(const unsigned char *bits, int numberofbits) /* AeroLcrc16::calcusingbitsandcheck aerol.h:287-315 */
+{
+    uint16_t crc_rec = 0;
+    for (int i = numberofbits - 1; i >= numberofbits - 16; i--) { crc_rec <<= 1; crc_rec |= bits[i]; }
+    numberofbits -= 16;
+    uint16_t crc = 0xFFFF;
+    for (int i = 0; i < numberofbits; i++)
+    {
+        int crc_bit = crc & 1;
+        crc >>= 1;
+        if (crc_bit ^ bits[i]) crc = crc ^ 0x8408;
+    }
+    crc = (uint16_t)~crc;
+    return crc_rec == crc;
+}
+static int rt_reset(jo_aerol *a) /* resetblockptr aerol.h:591-602 */
+{
+    a->rt_blockptr = 0;
+    if (a->rt_last == RT_TEST_FAILED) { a->rt_last = RT_NOTHING; return RT_BAD; }
+    a->rt_last = RT_NOTHING;
+    return RT_NOTHING;
+}
+/* a decoded packet goes out as rows [packet, chunk, 12 bytes (zero padded), total bytes, type]; type 1 = R, 2 = T */
+static void rt_emit(jo_aerol *a, const unsigned char *deconvol, int ndeconvol, int chop, int type)
+{
+    unsigned char info[1024];
+    int ninfo = 0, charptr = 0; unsigned char ch = 0;
+    for (int h = 0; h < ndeconvol; h++) /* packintobytes aerol.h:603-628 */
+    {
+        ch |= deconvol[h] * 128;
+        charptr++; charptr %= 8;
+        if (charptr == 0) { info[ninfo++] = ch; ch = 0; }
+        else ch >>= 1;
+    }
+    ninfo -= chop; /* infofield.chop(1) for T packets */
+    for (int c = 0; c * 12 < ninfo; c++)
+    {
+        int32_t row[16];
+        row[0] = (int32_t)a->npackets; row[1] = c;
+        for (int j = 0; j < 12; j++) row[2 + j] = (c * 12 + j < ninfo) ? info[c * 12 + j] : 0;
+        row[14] = ninfo; row[15] = type;
+        gb_push(&a->packets, row, sizeof(row));
+    }
+    a->npackets++;
+}
+static int rt_update(jo_aerol *a, int bit) /* RTChannelDeleaveFECScram::update aerol.h:785-873 */
+{
+    if (a->rt_blockptr >= RT_BLOCKSZ) return RT_FULL;
+    a->rt_block[a->rt_blockptr] = bit;
+    a->rt_blockptr++;
+    if (((a->rt_blockptr - (64 * 5)) % (64 * 3)) != 0) return RT_NOTHING; /* C '%': also true for negative multiples -- none occur below 64*5 except 128 */
+    const int blockptr = a->rt_blockptr, cols = blockptr / 64;
+    /* deinterleave_ba(block, cols) aerol.cpp:603-625 */
+    unsigned char *del = (unsigned char *)malloc((size_t)blockptr);
+    int k = 0;
+    for (int j = 0; j < cols; j++)
+        for (int i = 0; i < 64; i++) del[k++] = (unsigned char)a->rt_block[a->depermute[i] * cols + j];
+    unsigned char *dec = (unsigned char *)malloc((size_t)blockptr);
+    const int nd = jo_decode_soft(a->rt_codec, del, blockptr, dec); /* Decode_soft(delBlock, blockptr) */
+    a->rt_scr_pos = 0; /* scrambler.reset(); scrambler.update(deconvol) */
+    for (int h = 0; h < nd; h++) dec[h] ^= a->scr[a->rt_scr_pos < 5000 ? a->rt_scr_pos : 4999], a->rt_scr_pos++;
+    int result;
+    if (blockptr == 64 * 5)
+    {
+        if (!crc16_bits_check(dec, 8 * 19)) { a->rt_last = RT_TEST_FAILED; result = RT_TEST_FAILED; }
+        else { rt_emit(a, dec, nd, 0, 1); a->rt_blockptr = RT_BLOCKSZ; a->rt_last = RT_OK_R; result = RT_OK_R; }
+    }
+    else
+    {
+        int ok = crc16_bits_check(dec, 8 * 6);
+        if (ok)
+        {
+            a->rt_numberofsus = 1 + (blockptr - (64 * 5)) / (64 * 3);
+            for (int i = 0; i < a->rt_numberofsus && ok; i++) ok = crc16_bits_check(dec + (8 * 6) + (8 * 12) * i, 8 * 12);
+        }
+        if (!ok)
+        {
+            if (blockptr >= RT_BLOCKSZ) { a->rt_last = RT_BAD; result = RT_BAD; }
+            else { a->rt_last = RT_TEST_FAILED; result = RT_TEST_FAILED; }
+        }
+        else { rt_emit(a, dec, nd, 1, 2); a->rt_blockptr = RT_BLOCKSZ; a->rt_last = RT_OK_T; result = RT_OK_T; }
+    }
+    free(del); free(dec);
+    return result;
+}
+
 void jo_aerol_write(jo_aerol *a, const int16_t *sb, long n)
 {
     /* Decode(): decodedbytes.clear() etc. are text; the loop :1131-2027 */
@@ -246,6 +357,8 @@ void jo_aerol_write(jo_aerol *a, const int16_t *sb, long n)
                 else a->gotsync_last = 0;
             }
             else { gotsync = 0; a->gotsync_last = 0; }
+            /* burst mode: the unique word has to come about 80 soft bits after the demodulator's start-of-burst marker :1192-1200 */
+            if (gotsync && a->burstmode && a->ifb == 10500 && abs(a->muw - 80) > 150) gotsync = 0;
             if (pd->inverted)
             {
                 bit = 1 - bit;
@@ -258,7 +371,16 @@ void jo_aerol_write(jo_aerol *a, const int16_t *sb, long n)
         if (a->cntr < 1000000000) a->cntr++;
         if (a->cntr < 16)
         {
-            if (a->cntr == 0) { a->frameinfo = (uint16_t)bit; a->ninfo = 0; }
+            if (a->cntr == 0)
+            {
+                a->frameinfo = (uint16_t)bit; a->ninfo = 0;
+                if (a->burstmode) /* R and T channels have no header: a dummy one :1281-1294 */
+                {
+                    a->formatid = 1; a->supfrmaker = 0; a->framecounter1 = 0; a->framecounter2 = 0;
+                    a->cntr = 16;
+                    if (rt_reset(a) == RT_BAD) ev(a, bitidx, 3, 0); /* " Bad R/T Packet" */
+                }
+            }
             else { a->frameinfo <<= 1; a->frameinfo |= (uint16_t)bit; }
         }
         if (a->cntr == 15)
@@ -269,7 +391,11 @@ void jo_aerol_write(jo_aerol *a, const int16_t *sb, long n)
             a->formatid = (a->frameinfo >> 12) & 0xF; a->supfrmaker = (a->frameinfo >> 8) & 0xF;
             a->framecounter1 = (a->frameinfo >> 4) & 0xF; a->framecounter2 = a->frameinfo & 0xF;
         }
-        if (a->cntr >= 16)
+        if (a->cntr >= 16 && a->burstmode)
+        {
+            if (rt_update(a, soft_bit) == RT_BAD) ev(a, bitidx, 3, 0); /* :1531 " Bad R/T Packet" */
+        }
+        else if (a->cntr >= 16)
         {
             if (a->cntr == 16) a->blockcnt = -1;
             int idx = (a->cntr - a->BitsInHeader) % a->blocksz;
@@ -279,14 +405,24 @@ void jo_aerol_write(jo_aerol *a, const int16_t *sb, long n)
         }
         if (gotsync)
         {
-            if (a->cntr + 1 != a->TotalNumberOfBits) ev(a, bitidx, 1, a->cntr + 1); /* "Error short frame!!!" (isudata.reset()) */
+            if (!a->burstmode && a->cntr + 1 != a->TotalNumberOfBits) ev(a, bitidx, 1, a->cntr + 1); /* "Error short frame!!!" (isudata.reset()) */
             a->cntr = -1;
             a->datacd = 1; a->datacdcountdown = 12;
             ev(a, bitidx, 0, 1);
             ev(a, bitidx, 2, 0);
             a->scr_pos = 0;
         }
-        if (a->cntr + 1 == a->TotalNumberOfBits) { a->scr_pos = 0; a->cntr = -1; }
+        if (a->cntr + 1 == a->TotalNumberOfBits)
+        {
+            a->scr_pos = 0; a->cntr = -1;
+            if (a->burstmode) /* end of signal :2018-2027: stop, carrier detect low, and the REST OF THIS GROUP of soft bits is dropped */
+            {
+                a->cntr = 1000000000;
+                a->datacd = 0; a->datacdcountdown = 0;
+                ev(a, bitidx, 0, 0);
+                break;
+            }
+        }
     }
     a->nbits_total += n;
 }

@@ -8,6 +8,8 @@ extern "C" {
 typedef struct jo_aerol jo_aerol;
 /* = AeroL(parent) + setSettings(fb, burstmode=false); fb in {600, 1200, 10500} */
 jo_aerol *jo_aerol_create(int fb);
+jo_aerol *jo_aerol_create_burst(int fb); /* setSettings(fb, burstmode = true): R/T packets, 10500 bps only */
+long jo_aerol_take_packets(jo_aerol *a, int32_t *dst, long caprows); /* rows of 16 int32: packet, chunk, 12 bytes, total bytes, type (1 R, 2 T) */
 void jo_aerol_destroy(jo_aerol *a);
 /* = processDemodulatedSoftBits(soft_bits): Decode(bits, soft=true), continuous (P-channel) path */
 void jo_aerol_write(jo_aerol *a, const int16_t *soft, long n);

@@ -131,6 +131,10 @@ def lib():
         L.jo_hilbert_update.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
         L.jo_aerol_create.restype = C.c_void_p
         L.jo_aerol_create.argtypes = [C.c_int]
+        L.jo_aerol_create_burst.restype = C.c_void_p
+        L.jo_aerol_create_burst.argtypes = [C.c_int]
+        L.jo_aerol_take_packets.restype = C.c_long
+        L.jo_aerol_take_packets.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.jo_aerol_destroy.argtypes = [C.c_void_p]
         L.jo_aerol_write.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.jo_aerol_take_sus.restype = C.c_long
@@ -334,9 +338,10 @@ def hilbert_stream(pcm: np.ndarray, chunk: int = 4096, N=2048):
 class AeroL:
     """Continuous (P-channel) path of the reference's AeroL bit pipeline: soft bits -> signal units."""
 
-    def __init__(self, fb: int):
+    def __init__(self, fb: int, burst: bool = False):
         self.L = lib()
-        self.h = self.L.jo_aerol_create(int(fb))
+        self.h = self.L.jo_aerol_create_burst(int(fb)) if burst else self.L.jo_aerol_create(int(fb))
+        assert self.h
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -354,6 +359,10 @@ class AeroL:
     def take_events(self) -> np.ndarray:
         return _drain(self.L.jo_aerol_take_events, self.h, 3, np.int64)
 
+    def take_packets(self) -> np.ndarray:
+        """burst mode: rows [packet, chunk, 12 bytes, total bytes, type (1 R, 2 T)]"""
+        return _drain(self.L.jo_aerol_take_packets, self.h, 16, np.int32)
+
     @property
     def dcd(self):
         return self.L.jo_aerol_dcd(self.h)
@@ -368,6 +377,74 @@ def run_aerol(fb: int, soft: np.ndarray, group: int = 32):
     for s in range(0, soft.shape[0], group):
         a.write(soft[s:s + group])
     return {"sus": a.take_sus(), "events": a.take_events(), "dcd": a.dcd}
+
+
+def demod_groups(soft: np.ndarray):
+    """(start, end) of the groups a burst demodulator hands to processDemodulatedSoftBits (burstoqpskdemodulator.cpp:546-585): a
+    start-of-burst marker (negative) is one entry, soft bits come in pairs, a group goes out once it holds >= 32 entries after a pair."""
+    out, s, n = [], 0, len(soft)
+    while s < n:
+        e, cnt = s, 0
+        while e < n:
+            if soft[e] < 0:
+                e += 1; cnt += 1
+                continue
+            step = 2 if e + 1 < n else 1
+            e += step; cnt += step
+            if cnt >= 32:
+                break
+        out.append((s, e))
+        s = e
+    return out
+
+
+def run_aerol_burst(fb: int, soft: np.ndarray):
+    a = AeroL(fb, burst=True)
+    for s, e in demod_groups(soft):
+        a.write(soft[s:e])
+    return {"packets": a.take_packets(), "events": a.take_events(), "dcd": a.dcd}
+
+
+def packets_from_rows(rows: np.ndarray):
+    """[(type, bytes)] from take_packets rows."""
+    out = []
+    for pk in sorted(set(rows[:, 0].tolist())) if len(rows) else []:
+        r = rows[rows[:, 0] == pk]
+        r = r[np.argsort(r[:, 1])]
+        data = bytes(int(v) for v in r[:, 2:14].reshape(-1))[: int(r[0, 14])]
+        out.append((int(r[0, 15]), data))
+    return out
+
+
+def run_ref_aerol_burst(fb: int, soft: np.ndarray):
+    """The unmodified AeroL in burst mode on demodulator-style groups: ([('R', 17 bytes) | ('T', 4 header bytes, n, [10-byte SUs])],
+    number of ' Bad R/T Packet' lines, raw text)."""
+    import re
+
+    assert have_ref()
+    with tempfile.TemporaryDirectory() as td:
+        inp, outp = os.path.join(td, "soft.s16"), os.path.join(td, "out.txt")
+        np.ascontiguousarray(soft, dtype=np.int16).tofile(inp)
+        env = dict(os.environ)
+        env["QT_QPA_PLATFORM"] = "offscreen"
+        subprocess.check_call([REF_BIN, "aerol", inp, outp, f"fb={fb}", "group=0", "burst=1"], env=env, stdout=subprocess.DEVNULL)
+        txt = open(outp, "rb").read().decode("latin1")
+    pk, bad = [], 0
+    for line in txt.split("\n"):
+        if "Bad R/T Packet" in line:
+            bad += 1
+        m = re.match(r"^((?: 0x[0-9A-F]{2}){17}) ", line)
+        if m:
+            pk.append(("R", bytes(int(x, 16) for x in m.group(1).split())))
+            continue
+        m = re.match(r"^ T Packet from AES: ([0-9A-F]{6}) to GES: ([0-9A-F]{2}) with (\d+) SUs", line)
+        if m:
+            pk.append(["T", bytes.fromhex(m.group(1) + m.group(2)), int(m.group(3)), []])
+            continue
+        m = re.match(r"^((?: 0x[0-9A-F]{2}){10})( |$)", line)
+        if m and pk and isinstance(pk[-1], list):
+            pk[-1][3].append(bytes(int(x, 16) for x in m.group(1).split()))
+    return pk, bad, txt
 
 
 def run_ref_aerol(fb: int, soft: np.ndarray, group: int = 32):

@@ -260,14 +260,29 @@ int main(int argc, char **argv)
         QObject::connect(&a, &AeroL::DataCarrierDetect, [&](bool d) { sink.write(QString("#DCD %1 %2\n").arg(d ? 1 : 0).arg(gstart).toLatin1()); });
         a.setSettings(getd("fb", 10500), geti("burst", 0) != 0);
         int group = geti("group", 32);
+        // group=0: the groups a burst demodulator emits (burstoqpskdemodulator.cpp:546-585): a start-of-burst marker (negative) is one
+        // entry, soft bits come in pairs, and a group is handed over once it holds >= 32 entries after a pair
         auto t0 = std::chrono::steady_clock::now();
-        for (long s = 0; s < n; s += group)
+        for (long s = 0; s < n;)
         {
-            long m = (s + group <= n) ? group : n - s;
+            long m;
+            if (group > 0) m = (s + group <= n) ? group : n - s;
+            else
+            {
+                long e = s; int cnt = 0;
+                while (e < n)
+                {
+                    if (sp[e] < 0) { e++; cnt++; continue; }
+                    if (e + 1 < n) { e += 2; cnt += 2; } else { e++; cnt++; }
+                    if (cnt >= 32) break;
+                }
+                m = e - s;
+            }
             QVector<short> v(m);
             for (long i = 0; i < m; i++) v[i] = sp[s + i];
             gstart = s;
             a.processDemodulatedSoftBits(v);
+            s += m;
         }
         double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         writeall(argv[3], sink.data().constData(), sink.data().size());

@@ -132,8 +132,51 @@ def aerol():
         print("aerol", fb, soft.shape, rows.shape, "crc ok", int(rows[:, 11].sum()))
 
 
+def rt_case(seed, sigma, inv=(False, False), cut=False):
+    """A burst-demodulator soft-bit stream with R and T packets (see aerol_frames.rt_burst_stream)."""
+    from jaero_amd import aerol_frames as AF
+    rng = np.random.default_rng(seed)
+    rb = lambda n: bytes(rng.integers(0, 256, n, dtype=np.uint8))
+    pk = [("R", rb(17)), ("T", (rb(4), [rb(10) for _ in range(2)])), ("T", (rb(4), [rb(10) for _ in range(7)])), ("R", rb(17)),
+          ("T", (rb(4), [rb(10) for _ in range(31)]))]
+    x = AF.rt_burst_stream(pk, sigma=sigma, seed=seed, invert_i=inv[0], invert_q=inv[1], gap=11000 + 37 * seed)
+    if cut:  # a burst whose tail is lost (the T packet never passes its CRCs) and one whose unique word comes too late after the marker
+        k = int(np.where(x < 0)[0][2])
+        x = np.concatenate([x[: k + 500], x[k + 2600:]])
+        k = int(np.where(x < 0)[0][3])
+        x = np.concatenate([x[: k + 1], np.full(300, 128, np.int16), x[k + 1:]])
+    return pk, x
+
+
+def ref_packets_as_rows(ref):
+    """reference text -> comparable tuples: ('R', 17 bytes) / ('T', 4 header bytes, n, tuple of 10-byte SUs)"""
+    return [tuple(p) if p[0] == "R" else (p[0], p[1], p[2], tuple(p[3])) for p in ref]
+
+
+def aerol_burst():
+    """Row f2: what the UNMODIFIED AeroL in burst mode (R/T channel packets, 10500 bps) makes of generated bursts, fed in the groups a
+    burst demodulator emits."""
+    assert O.have_ref()
+    for name, (seed, sigma, inv, cut) in {"a": (1, 18.0, (False, False), False), "b": (2, 30.0, (True, False), True)}.items():
+        pk, x = rt_case(seed, sigma, inv, cut)
+        ref, bad, txt = O.run_ref_aerol_burst(10500, x)
+        dcd = [(int(a), int(b)) for a, b in __import__("re").findall(r"#DCD (\d) (\d+)", txt)]
+        rows = []
+        for p in ref:
+            if p[0] == "R":
+                rows.append([1, 17, 0] + list(p[1]) + [0] * (10 * 31 + 4 - 17))
+            else:
+                flat = [v for su in p[3] for v in su]
+                rows.append([2, len(p[3]), p[2]] + list(p[1]) + flat + [0] * (10 * 31 - len(flat)))
+        np.savez_compressed(os.path.join(HERE, f"aerol_burst_10500_{name}.npz"), soft=x, packets=np.array(rows, dtype=np.int32), bad=bad,
+                            dcd=np.array(dcd, dtype=np.int64))
+        print("aerol burst", name, x.shape, [(r[0], r[1]) for r in rows], "bad", bad, "dcd", len(dcd))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "burst":
+    if len(sys.argv) > 1 and sys.argv[1] == "aerolburst":
+        aerol_burst()
+    elif len(sys.argv) > 1 and sys.argv[1] == "burst":
         burst()
     elif len(sys.argv) > 1 and sys.argv[1] == "aerol":
         aerol()
@@ -141,3 +184,4 @@ if __name__ == "__main__":
         main()
         burst()
         aerol()
+        aerol_burst()

@@ -1,5 +1,7 @@
 """CPU: the Aero-L bit-pipeline restatement (oracle/aerol_oracle.c) pinned against what the UNMODIFIED AeroL printed
 (tests/golden/aerol_*.npz, made by oracle/_ref) and, where oracle/_ref can run, against AeroL itself on fresh frames."""
+import os
+
 import numpy as np
 import pytest
 
@@ -73,3 +75,63 @@ def test_oracle_vs_unmodified_aerol(R, fb, sigma, inv):
     o = R.run_aerol(fb, soft, grp)
     mine = [(int(r[1]), bytes(r[2:12].astype(np.uint8)), bool(r[14])) for r in o["sus"]]
     assert ref == mine
+
+
+# ---------------------------------------------------------------------------------------------- burst mode (R / T channel packets)
+def burst_rows(packets):
+    """oracle / GPU packet list [(type, bytes)] -> the golden files' row form [type, n, n_printed, header/payload bytes ...]"""
+    rows = []
+    for typ, data in packets:
+        if typ == 1:
+            rows.append([1, 17, 0] + list(data[:17]) + [0] * (10 * 31 + 4 - 17))
+        else:
+            n = (len(data) + 1 - 6) // 12
+            flat = [v for k in range(n) for v in data[6 + 12 * k: 6 + 12 * k + 10]]
+            rows.append([2, n, n] + list(data[:4]) + flat + [0] * (10 * 31 - len(flat)))
+    return np.array(rows, dtype=np.int32).reshape(-1, 3 + 4 + 310)
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_burst_oracle_matches_reference_golden(oracle_mod, name):
+    """R/T packets: the oracle's burst mode against what the unmodified AeroL (setSettings(10500, true)) printed for the same soft
+    bits in the same (burst demodulator) groups: packet bytes, ' Bad R/T Packet' notices, DataCarrierDetect edges."""
+    g = load_golden(f"aerol_burst_10500_{name}")
+    o = oracle_mod.run_aerol_burst(10500, g["soft"])
+    assert np.array_equal(burst_rows(oracle_mod.packets_from_rows(o["packets"])), g["packets"])
+    ev = o["events"]
+    assert int((ev[:, 1] == 3).sum()) == int(g["bad"])
+    # the driver stamps a DCD edge with the first soft bit of the group that carried it
+    starts = np.array([s for s, _ in oracle_mod.demod_groups(g["soft"])])
+    dcd = [(int(v), int(starts[np.searchsorted(starts, i, side="right") - 1])) for i, k, v in ev[1:] if k == 0]
+    assert dcd == [tuple(r) for r in g["dcd"].tolist()]
+
+
+def test_burst_generator_round_trip(oracle_mod):
+    rng = np.random.default_rng(9)
+    rb = lambda n: bytes(rng.integers(0, 256, n, dtype=np.uint8))
+    pk = [("T", (rb(4), [rb(10) for _ in range(5)])), ("R", rb(17))]
+    x = AF.rt_burst_stream(pk, sigma=25.0, seed=4, invert_i=True, invert_q=True)
+    got = oracle_mod.packets_from_rows(oracle_mod.run_aerol_burst(10500, x)["packets"])
+    assert [t for t, _ in got] == [2, 1]
+    assert got[1][1][:17] == pk[1][1] and got[0][1][:4] == pk[0][1][0]
+    assert [got[0][1][6 + 12 * k: 16 + 12 * k] for k in range(5)] == pk[0][1][1]
+
+
+def test_burst_oracle_vs_unmodified_aerol(R):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    mk = importlib.util.module_from_spec(spec); spec.loader.exec_module(mk)
+    for seed, sigma, inv, cut in ((5, 35.0, (False, True), True), (6, 12.0, (True, True), False)):
+        _, x = mk.rt_case(seed, sigma, inv, cut)
+        ref, bad, _ = R.run_ref_aerol_burst(10500, x)
+        o = R.run_aerol_burst(10500, x)
+        got = burst_rows(R.packets_from_rows(o["packets"]))
+        want = []
+        for p in ref:
+            if p[0] == "R":
+                want.append([1, 17, 0] + list(p[1]) + [0] * (10 * 31 + 4 - 17))
+            else:
+                flat = [v for su in p[3] for v in su]
+                want.append([2, len(p[3]), p[2]] + list(p[1]) + flat + [0] * (10 * 31 - len(flat)))
+        assert np.array_equal(got, np.array(want, dtype=np.int32).reshape(-1, 317))
+        assert int((o["events"][:, 1] == 3).sum()) == bad
