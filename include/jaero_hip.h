@@ -186,6 +186,18 @@ int jaero_aerol_write(jaero_aerol_ctx *ctx, const int16_t *soft, const int *coun
 int jaero_aerol_read_sus(jaero_aerol_ctx *ctx, int channel, int32_t *rows, int caprows, int *nrows);
 int jaero_aerol_read_events(jaero_aerol_ctx *ctx, int channel, long long *rows, int caprows, int *nrows);
 int jaero_aerol_tick_dcd(jaero_aerol_ctx *ctx, int *dcd_out /* optional [nchannels] */);
+/* ---- burst mode: R / T channel packets (AeroL with setSettings(fb, burstmode = true), JAERO/aerol.cpp:996-1003,1062-1070) ----
+ * The bank behind a burst demodulator bank (JAERO_KIND_BURST_OQPSK): unique word with tolerance 4 that has to come ~80 soft bits after
+ * the demodulator's start-of-burst marker (JAERO/aerol.cpp:1192-1200), RTChannelDeleaveFECScram::update (JAERO/aerol.h:785-873: trial
+ * decodes of the collected block at 2, 5, 8 .. 95 interleaver columns until the CRCs of an R packet or of a T packet's header and
+ * signal units pass), end of signal after one second of bits.  10500 bps; 600/1200 bps bursts (updateMSK) are not built.
+ *   jaero_aerol_read_packets: rows of 16 int32 [packet number, chunk, 12 bytes (zero padded), total bytes of the packet, type]
+ *       type 1 = R packet (20 bytes: 17 + CRC + the flush byte), 2 = T packet (6 header bytes incl. CRC, then 12 per signal unit)
+ *   jaero_aerol_read_events additionally reports kind 3 = the " Bad R/T Packet" notice (JAERO/aerol.cpp:1289-1293,1531)
+ * The reference drops the rest of the demodulator's current group of soft bits at the end of a signal; the bank re-derives the groups
+ * from the stream (a marker is one entry, soft bits come in pairs, a group is complete at >= 32 entries after a pair). */
+int jaero_aerol_create_burst(int device, int nchannels, int fb, int max_softbits_per_write, int packet_row_capacity, jaero_aerol_ctx **out);
+int jaero_aerol_read_packets(jaero_aerol_ctx *ctx, int channel, int32_t *rows, int caprows, int *nrows);
 /* HIP-event time per kernel class since the last reset: which 0 = k_aerol_bits, 1 = Viterbi, 2 = k_aerol_post */
 int jaero_aerol_profile_enable(jaero_aerol_ctx *ctx, int on);
 int jaero_aerol_profile_read(jaero_aerol_ctx *ctx, int which, double *total_ms, int *launches, int reset);

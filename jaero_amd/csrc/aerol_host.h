@@ -88,11 +88,12 @@ extern "C" void jaero_aerol_destroy(jaero_aerol_ctx *c)
     delete c;
 }
 
-extern "C" int jaero_aerol_create(int device, int nchannels, int fb, int max_softbits_per_write, int su_capacity, jaero_aerol_ctx **out)
+static int aerol_create(int device, int nchannels, int fb, int max_softbits_per_write, int su_capacity, int burst, jaero_aerol_ctx **out)
 {
     if (!out || nchannels <= 0 || max_softbits_per_write <= 0) return fail(JAERO_EINVAL, "jaero_aerol_create: bad arguments");
     *out = nullptr;
     if (fb != 600 && fb != 1200 && fb != 10500) return fail(JAERO_ENOTSUP, "jaero_aerol_create: fb must be 600, 1200 or 10500 (8400 C-channel: SURVEY 8f4)");
+    if (burst && fb != 10500) return fail(JAERO_ENOTSUP, "jaero_aerol_create_burst: R/T packet search is built for 10500 bps (600/1200 bps bursts: updateMSK, not yet)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(JAERO_ENODEV, "no HIP device available (this library has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(JAERO_ENODEV, "device %d out of range", device);
@@ -109,9 +110,17 @@ extern "C" int jaero_aerol_create(int device, int nchannels, int fb, int max_sof
     default: g.N = 78; g.dl2_sz = 4992 - 6 + 1; g.NumberOfBits = 4992; g.BitsInHeader = 16 + 178; g.TotalNumberOfBits = 16 + 178 + 4992 + 64; g.oqpsk = 1; break;
     }
     g.blocksz = g.N * 64;
+    g.burst = burst ? 1 : 0;
+    if (burst)
+    {
+        // setSettings(fb, true) (aerol.cpp:996-1003,1062-1070): one second of bits as frame countdown; the block is the R/T packet
+        // collector's (RTChannelDeleaveFECScram: up to 95 interleaver columns)
+        g.TotalNumberOfBits = fb;
+        g.blocksz = RT_BLOCKSZ;
+    }
     g.idx_sat = (1000000000 - g.BitsInHeader) % g.blocksz;
     g.info_cap = g.NumberOfBits / 16 + 16;
-    if (su_capacity <= 0) su_capacity = 32 * (g.NumberOfBits / 2 / 96) + 8; // 32 frames between reads
+    if (su_capacity <= 0) su_capacity = burst ? 256 : 32 * (g.NumberOfBits / 2 / 96) + 8; // 32 frames (burst: 256 packet rows) between reads
     g.su_cap = su_capacity; g.ev_cap = 256;
     int rc;
 #define AA(ptr, count) do { if ((rc = aalloc(c, &(ptr), (size_t)(count)))) { jaero_aerol_destroy(c); return rc; } } while (0)
@@ -129,7 +138,7 @@ extern "C" int jaero_aerol_create(int device, int nchannels, int fb, int max_sof
     c->stage_stride = max_softbits_per_write;
     AA(c->d_soft, (size_t)g.nch * max_softbits_per_write);
     AA(c->d_counts, g.nchp);
-    if (viterbi_use_lanes(g.nch, g.blocksz, 24)) { AA(c->d_vhist, viterbi_hist_bytes(g.nch) / sizeof(unsigned long long)); g.tiled = 1; }
+    if (!burst && viterbi_use_lanes(g.nch, g.blocksz, 24)) { AA(c->d_vhist, viterbi_hist_bytes(g.nch) / sizeof(unsigned long long)); g.tiled = 1; }
 #undef AA
     c->p.scr = d_scr;
     {
@@ -153,6 +162,12 @@ extern "C" int jaero_aerol_create(int device, int nchannels, int fb, int max_sof
             I[(size_t)AI_BLOCKCNT * g.nchp + ch] = -1;
             I[(size_t)AI_EV_CNT * g.nchp + ch] = 1; // row 0 = [0, DCD, 0]
         }
+        if (burst)
+            for (int ch = 0; ch < g.nchp; ch++)
+            {
+                I[(size_t)BI_RT_BLOCKPTR * g.nchp + ch] = 0;       // RTChannelDeleaveFECScram(): resetblockptr()
+                I[(size_t)BI_RT_LAST * g.nchp + ch] = RT_NOTHING;
+            }
         HIPCHK(hipMemcpy(c->p.I, I.data(), I.size() * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->p.events, ev.data(), ev.size() * sizeof(long long), hipMemcpyHostToDevice));
     }
@@ -160,6 +175,16 @@ extern "C" int jaero_aerol_create(int device, int nchannels, int fb, int max_sof
     *out = c;
     return 0;
 }
+
+extern "C" int jaero_aerol_create(int device, int nchannels, int fb, int max_softbits_per_write, int su_capacity, jaero_aerol_ctx **out)
+{
+    return aerol_create(device, nchannels, fb, max_softbits_per_write, su_capacity, 0, out);
+}
+extern "C" int jaero_aerol_create_burst(int device, int nchannels, int fb, int max_softbits_per_write, int packet_row_capacity, jaero_aerol_ctx **out)
+{
+    return aerol_create(device, nchannels, fb, max_softbits_per_write, packet_row_capacity, 1, out);
+}
+extern "C" int jaero_aerol_read_packets(jaero_aerol_ctx *c, int ch, int32_t *rows, int caprows, int *nrows);
 
 // = processDemodulatedSoftBits for every channel: soft[ch * stride + k], k < counts[ch]
 extern "C" int jaero_aerol_write(jaero_aerol_ctx *c, const int16_t *soft, const int *counts, int stride, int max_count, int is_device_ptr, void *stream)
@@ -179,6 +204,25 @@ extern "C" int jaero_aerol_write(jaero_aerol_ctx *c, const int16_t *soft, const 
         dsoft = c->d_soft; dcounts = c->d_counts;
     }
     if (max_count == 0) return 0;
+    if (g.burst)
+    {
+        // R/T packet search: a round per trial length a channel can reach in this write (every 192 soft bits, plus 128 and 320)
+        const int rounds = max_count / 192 + 4;
+        const int *valid = c->p.I + (size_t)AI_HAS_BLOCK * g.nchp;
+        const int *lens = c->p.I + (size_t)BI_TRIAL_LEN * g.nchp;
+        const dim3 grid(g.nchp / 64), block(64);
+        for (int r = 0; r < rounds; r++)
+        {
+            hipLaunchKernelGGL(k_aerolb_bits, grid, block, 0, st, g, c->p, dsoft, dcounts, stride);
+            hipLaunchKernelGGL(k_aerolb_deint, dim3((g.nch + 3) / 4), dim3(256), 0, st, g, c->p);
+            hipLaunchKernelGGL(k_viterbi, dim3(g.nch), dim3(64), 0, st, (const uint8_t *)c->p.deint, RT_BLOCKSZ, (const uint8_t *)nullptr, 0, c->p.vbits,
+                               RT_BLOCKSZ / 2, 0, RT_BLOCKSZ / 2, g.nch, valid, lens);
+            hipLaunchKernelGGL(k_aerolb_post, grid, block, 0, st, g, c->p);
+        }
+        hipLaunchKernelGGL(k_aerol_end_write, grid, block, 0, st, g, c->p, dcounts);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     // every round finishes at most one interleaver block per channel (the reference completes a block -- Viterbi, descrambling,
     // CRC and its data-carrier-detect update -- before it looks at the next soft bit)
     const int rounds = max_count / g.blocksz + 2;
@@ -244,6 +288,12 @@ static int aerol_read_rows(jaero_aerol_ctx *c, int ch, void *rows, int caprows, 
 }
 extern "C" int jaero_aerol_read_sus(jaero_aerol_ctx *c, int ch, int32_t *rows, int caprows, int *nrows)
 {
+    if (c && c->g.burst) return fail(JAERO_ENOTSUP, "jaero_aerol_read_sus: burst-mode bank (use jaero_aerol_read_packets)");
+    return aerol_read_rows(c, ch, rows, caprows, nrows, AI_SU_CNT, c ? c->p.sus : nullptr, c ? c->g.su_cap : 0, 16 * sizeof(int32_t), 1);
+}
+extern "C" int jaero_aerol_read_packets(jaero_aerol_ctx *c, int ch, int32_t *rows, int caprows, int *nrows)
+{
+    if (c && !c->g.burst) return fail(JAERO_ENOTSUP, "jaero_aerol_read_packets: not a burst-mode bank (use jaero_aerol_read_sus)");
     return aerol_read_rows(c, ch, rows, caprows, nrows, AI_SU_CNT, c ? c->p.sus : nullptr, c ? c->g.su_cap : 0, 16 * sizeof(int32_t), 1);
 }
 extern "C" int jaero_aerol_read_events(jaero_aerol_ctx *c, int ch, long long *rows, int caprows, int *nrows)

@@ -28,6 +28,7 @@
 #include "k_burst_front.h"
 #include "k_burst_demod.h"
 #include "k_aerol.h"
+#include "k_aerol_burst.h"
 
 static thread_local std::string g_last_error;
 static int fail(int code, const char *fmt, ...)

@@ -1,0 +1,232 @@
+// k_aerol_burst.h -- AeroL in burst mode: the R / T channel packet search of SURVEY.md section 8 row f2 (10500 bps).
+//   AeroL::Decode with burstmode = true        JAERO/aerol.cpp:1124-1345,1985-2030 (unique word with tolerance 4 and the
+//                                              "about 80 soft bits after the start-of-burst marker" rule, dummy header, end of signal)
+//   RTChannelDeleaveFECScram::update           JAERO/aerol.h:785-873 (block fill, trial decodes at 2, 5, 8, .. 95 interleaver columns)
+//   AeroLInterleaver::deinterleave_ba(.,cols)  JAERO/aerol.cpp:603-625;  JConvolutionalCodec::Decode_soft jconvolutionalcodec.cpp:90-119
+//   AeroLcrc16::calcusingbitsandcheck          JAERO/aerol.h:287-315
+// One channel per lane walks its soft bits until the block reaches a length at which the reference tries to decode it; the trial
+// (deinterleave -> k_viterbi with that channel's length -> descramble -> CRCs -> R packet / T packet / keep collecting) runs for all
+// such channels at once, then the lanes go on: rounds, as in the continuous pipeline.  Bursts are rare and short, so nothing here is
+// tuned beyond that.  The reference drops the rest of the demodulator's current group of soft bits when the one-second frame
+// countdown ends; the groups are re-derived from the stream with the demodulator's rule (a marker is one entry, soft bits come in
+// pairs, a group is complete at >= 32 entries after a pair; JAERO/burstoqpskdemodulator.cpp:546-585).
+#pragma once
+#include "k_aerol.h"
+
+#define RT_BLOCKSZ (64 * 95)
+enum { RT_NOTHING = 8, RT_TEST_FAILED = 32, RT_BAD = 0, RT_OK_R = 3, RT_OK_T = 5 };
+enum // burst-only fields, stored in slots the continuous pipeline uses for its own block bookkeeping
+{
+    BI_RT_BLOCKPTR = AI_BLOCKCNT, BI_RT_LAST = AI_NINFO, BI_GRP_CNT = AI_SCR_POS, BI_GRP_PAIR = AI_DL2_PTR, BI_GRP_SKIP = AI_VBLOCKS,
+    BI_TRIAL_LEN = AI_BULK_LEN, BI_RESUME_GEND = AI_BULK_SRC, BI_NPACKETS = AI_NFRAMES
+};
+
+__global__ __launch_bounds__(64) void k_aerolb_bits(const AGeom g, const APtrs p, const int16_t *__restrict__ soft, const int *__restrict__ counts, int stride)
+{
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= g.nch) return;
+    int cntr = ALD(AI_CNTR), datacd = ALD(AI_DATACD), dcdcount = ALD(AI_DCDCOUNT), gotsync_last = ALD(AI_GOTSYNC_LAST), realimag = ALD(AI_REALIMAG);
+    int muw = ALD(AI_MUW), inv_imag = ALD(AI_INV_IMAG), inv_real = ALD(AI_INV_REAL), ev_cnt = ALD(AI_EV_CNT), overflow = ALD(AI_OVERFLOW);
+    unsigned pd_imag = (unsigned)ALD(AI_PD_IMAG), pd_real = (unsigned)ALD(AI_PD_REAL);
+    int blockptr = ALD(BI_RT_BLOCKPTR), rt_last = ALD(BI_RT_LAST), gcnt = ALD(BI_GRP_CNT), pair = ALD(BI_GRP_PAIR), skip = ALD(BI_GRP_SKIP);
+    int pos = ALD(AI_IN_POS), resume = ALD(AI_RESUME);
+    const long long nbits0 = ((long long)(unsigned)ALD(AI_NBITS_LO)) | ((long long)ALD(AI_NBITS_HI) << 32);
+    const int n = counts[ch];
+    const int16_t *sb = soft + (size_t)ch * stride;
+    uint8_t *blk = p.rx + (size_t)ch * RT_BLOCKSZ;
+    int has_trial = 0, gotsync = 0, gend = 0;
+
+    auto part_b = [&](long long bitidx) { // aerol.cpp:1985-2030
+        if (gotsync)
+        {
+            cntr = -1;
+            datacd = 1; dcdcount = 12;
+            aerol_event(g, p, ch, ev_cnt, overflow, bitidx, 0, 1);
+            aerol_event(g, p, ch, ev_cnt, overflow, bitidx, 2, 0);
+        }
+        if (cntr + 1 == g.TotalNumberOfBits)
+        {
+            // end of signal: stop, data carrier detect low, and the rest of this group of soft bits is dropped
+            cntr = 1000000000;
+            datacd = 0; dcdcount = 0;
+            aerol_event(g, p, ch, ev_cnt, overflow, bitidx, 0, 0);
+            skip = 1;
+        }
+        gotsync = 0;
+        if (gend) { gcnt = 0; skip = 0; }
+    };
+    if (resume)
+    {
+        gotsync = ALD(AI_RESUME_GOTSYNC); gend = ALD(BI_RESUME_GEND);
+        part_b(nbits0 + pos);
+        pos++;
+        resume = 0;
+    }
+    while (pos < n)
+    {
+        const int v = sb[pos];
+        const long long bitidx = nbits0 + pos;
+        const bool isneg = v < 0;
+        if (!isneg) pair ^= 1;
+        gcnt++;
+        gend = (!isneg && pair == 0 && gcnt >= 32) ? 1 : 0;
+        if (skip || isneg)
+        {
+            if (isneg && !skip) muw = 0; // start-of-burst marker (aerol.cpp:1146-1152)
+            if (gend) { gcnt = 0; skip = 0; }
+            pos++;
+            continue;
+        }
+        int bit = (((unsigned)v & 0xFFu) >= 128u) ? 1 : 0;
+        unsigned soft_bit = (unsigned)v & 0xFFFFu;
+        if (muw < 100000) muw++;
+        realimag ^= 1;
+        unsigned pd = realimag ? pd_imag : pd_real;
+        int inverted = realimag ? inv_imag : inv_real;
+        if (cntr > g.NumberOfBits - 68 || cntr <= 0 || !datacd)
+        {
+            // PreambleDetectorPhaseInvariant::Update with tolerance 4 (aerol.cpp:781-804, 996-1003)
+            pd = (pd << 1) | (unsigned)bit;
+            const int xorsum = __popc(pd ^ AEROL_UW);
+            gotsync = 0;
+            if (xorsum >= 32 - 4) { inverted = 1; gotsync = 1; }
+            else if (xorsum <= 4) { inverted = 0; gotsync = 1; }
+            if (!gotsync_last) { gotsync_last = gotsync; gotsync = 0; }
+            else gotsync_last = 0;
+        }
+        else { gotsync = 0; gotsync_last = 0; }
+        if (realimag) { pd_imag = pd; inv_imag = inverted; }
+        else { pd_real = pd; inv_real = inverted; }
+        if (gotsync && abs(muw - 80) > 150) gotsync = 0; // the unique word comes ~80 soft bits after the marker (:1192-1200)
+        if (inverted)
+        {
+            bit = 1 - bit;
+            if (soft_bit != 128u) soft_bit = 255u - soft_bit;
+        }
+        if (cntr < 1000000000) cntr++;
+        if (cntr == 0)
+        {
+            // R and T channels have no header: dummy one, and the packet collector starts over (:1281-1294; resetblockptr aerol.h:591)
+            cntr = 16;
+            blockptr = 0;
+            if (rt_last == RT_TEST_FAILED) aerol_event(g, p, ch, ev_cnt, overflow, bitidx, 3, 0); // " Bad R/T Packet"
+            rt_last = RT_NOTHING;
+        }
+        bool trial = false;
+        if (cntr >= 16 && blockptr < RT_BLOCKSZ)
+        {
+            blk[blockptr] = (uint8_t)soft_bit;
+            blockptr++;
+            // ((blockptr - 64*5) % (64*3)) == 0 in C: also -192, i.e. two columns
+            trial = (blockptr == 128) || (blockptr >= 320 && ((blockptr - 320) % 192) == 0);
+        }
+        if (trial)
+        {
+            has_trial = 1; resume = 1;
+            break; // the verdict on this length (k_aerolb_post) comes before the rest of this soft bit
+        }
+        part_b(bitidx);
+        pos++;
+    }
+    ALD(AI_CNTR) = cntr; ALD(AI_DATACD) = datacd; ALD(AI_DCDCOUNT) = dcdcount; ALD(AI_GOTSYNC_LAST) = gotsync_last; ALD(AI_REALIMAG) = realimag;
+    ALD(AI_MUW) = muw; ALD(AI_INV_IMAG) = inv_imag; ALD(AI_INV_REAL) = inv_real; ALD(AI_EV_CNT) = ev_cnt; ALD(AI_OVERFLOW) = overflow;
+    ALD(AI_PD_IMAG) = (int)pd_imag; ALD(AI_PD_REAL) = (int)pd_real;
+    ALD(BI_RT_BLOCKPTR) = blockptr; ALD(BI_RT_LAST) = rt_last; ALD(BI_GRP_CNT) = gcnt; ALD(BI_GRP_PAIR) = pair; ALD(BI_GRP_SKIP) = skip;
+    ALD(AI_IN_POS) = pos; ALD(AI_RESUME) = resume; ALD(AI_RESUME_GOTSYNC) = gotsync; ALD(BI_RESUME_GEND) = gend;
+    ALD(AI_HAS_BLOCK) = has_trial; ALD(BI_TRIAL_LEN) = has_trial ? blockptr : 0;
+}
+
+// deinterleave_ba(block, cols) of the channels that reached a trial length: out[j*64 + i] = block[((i*27) % 64) * cols + j]
+__global__ __launch_bounds__(256) void k_aerolb_deint(const AGeom g, const APtrs p)
+{
+    __shared__ uint8_t blk[4][RT_BLOCKSZ];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ch = blockIdx.x * 4 + w;
+    if (ch >= g.nch) return;
+    if (!ALD(AI_HAS_BLOCK)) return; // wave-uniform
+    const int len = ALD(BI_TRIAL_LEN), cols = len / 64;
+    const uint8_t *src = p.rx + (size_t)ch * RT_BLOCKSZ;
+    for (int q = lane; q < len; q += 64) blk[w][q] = src[q];
+    uint8_t *dst = p.deint + (size_t)ch * RT_BLOCKSZ;
+    const int row = ((lane * 27) & 63) * cols;
+    for (int j = 0; j < cols; j++) dst[j * 64 + lane] = blk[w][row + j];
+}
+
+__device__ __forceinline__ bool aerolb_crc_bits(const uint8_t *bits, int numberofbits) // calcusingbitsandcheck
+{
+    unsigned crc_rec = 0;
+    for (int i = numberofbits - 1; i >= numberofbits - 16; i--) { crc_rec <<= 1; crc_rec |= bits[i]; }
+    numberofbits -= 16;
+    unsigned crc = 0xFFFFu;
+    for (int i = 0; i < numberofbits; i++)
+    {
+        const unsigned crc_bit = crc & 1u;
+        crc >>= 1;
+        if (crc_bit ^ bits[i]) crc ^= 0x8408u;
+    }
+    crc = (~crc) & 0xFFFFu;
+    return crc_rec == crc;
+}
+
+// the verdict on a trial length: descramble, CRCs, emit the packet (rows [packet, chunk, 12 bytes, total bytes, type]) or keep collecting
+__global__ __launch_bounds__(64) void k_aerolb_post(const AGeom g, const APtrs p)
+{
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= g.nch) return;
+    if (!ALD(AI_HAS_BLOCK)) return;
+    const int blockptr = ALD(BI_TRIAL_LEN), nd = blockptr / 2;
+    uint8_t *dec = p.vbits + (size_t)ch * (RT_BLOCKSZ / 2);
+    for (int h = nd - 6; h < nd; h++) dec[h] = 0;   // the decoder leaves the last K-1 bits of its zero-initialised output untouched
+    for (int h = 0; h < nd; h++) dec[h] ^= p.scr[h]; // scrambler.reset(); scrambler.update(deconvol)   (nd <= 3040 < 5000)
+    int result, type = 0, chop = 0;
+    if (blockptr == 64 * 5)
+    {
+        if (!aerolb_crc_bits(dec, 8 * 19)) result = RT_TEST_FAILED;
+        else { result = RT_OK_R; type = 1; }
+    }
+    else
+    {
+        bool ok = aerolb_crc_bits(dec, 8 * 6);
+        if (ok)
+        {
+            const int numberofsus = 1 + (blockptr - (64 * 5)) / (64 * 3); // C division: 0 at two columns
+            for (int i = 0; i < numberofsus && ok; i++) ok = aerolb_crc_bits(dec + (8 * 6) + (8 * 12) * i, 8 * 12);
+        }
+        if (!ok) result = (blockptr >= RT_BLOCKSZ) ? RT_BAD : RT_TEST_FAILED;
+        else { result = RT_OK_T; type = 2; chop = 1; }
+    }
+    int ev_cnt = ALD(AI_EV_CNT), overflow = ALD(AI_OVERFLOW);
+    if (type)
+    {
+        const int ninfo = nd / 8 - chop; // packintobytes (+ infofield.chop(1) for T packets)
+        int row_cnt = ALD(AI_SU_CNT);
+        const int npk = ALD(BI_NPACKETS);
+        for (int c = 0; c * 12 < ninfo; c++)
+        {
+            if (row_cnt < g.su_cap)
+            {
+                int32_t *row = p.sus + ((size_t)ch * g.su_cap + row_cnt) * 16;
+                row[0] = npk; row[1] = c;
+                for (int j = 0; j < 12; j++)
+                {
+                    int b = 0;
+                    if (c * 12 + j < ninfo)
+                        for (int k = 0; k < 8; k++) b |= (int)dec[(c * 12 + j) * 8 + k] << k; // first bit of a byte is its LSB
+                    row[2 + j] = b;
+                }
+                row[14] = ninfo; row[15] = type;
+                row_cnt++;
+            }
+            else overflow |= 1;
+        }
+        ALD(AI_SU_CNT) = row_cnt; ALD(BI_NPACKETS) = npk + 1;
+        ALD(BI_RT_BLOCKPTR) = RT_BLOCKSZ; // stop further testing
+    }
+    if (result == RT_BAD)
+    {
+        const long long bitidx = (((long long)(unsigned)ALD(AI_NBITS_LO)) | ((long long)ALD(AI_NBITS_HI) << 32)) + ALD(AI_IN_POS);
+        aerol_event(g, p, ch, ev_cnt, overflow, bitidx, 3, 0); // " Bad R/T Packet" (aerol.cpp:1531)
+    }
+    ALD(BI_RT_LAST) = result;
+    ALD(AI_EV_CNT) = ev_cnt; ALD(AI_OVERFLOW) = overflow;
+}

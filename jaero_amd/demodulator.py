@@ -387,11 +387,15 @@ class AeroLBank:
     """A bank of AeroL bit pipelines (continuous P-channel path of JAERO/aerol.cpp AeroL::Decode): soft bits in, CRC-checked
     12-byte signal units out.  Thin wrapper over jaero_aerol_ctx."""
 
-    def __init__(self, nchannels: int, fb: int, device: int = 0, max_softbits_per_write: int = 1 << 16, su_capacity: int = 0):
+    def __init__(self, nchannels: int, fb: int, device: int = 0, max_softbits_per_write: int = 1 << 16, su_capacity: int = 0,
+                 burst: bool = False):
+        """burst=True: AeroL::setSettings(fb, burstmode=true), the R/T channel packet search behind a burst demodulator bank
+        (read_packets instead of read_sus)."""
         self.L = capi.lib()
         h = C.c_void_p()
-        capi.check(self.L.jaero_aerol_create(device, nchannels, int(fb), max_softbits_per_write, su_capacity, C.byref(h)))
-        self.h, self.nch, self.fb = h, nchannels, int(fb)
+        create = self.L.jaero_aerol_create_burst if burst else self.L.jaero_aerol_create
+        capi.check(create(device, nchannels, int(fb), max_softbits_per_write, su_capacity, C.byref(h)))
+        self.h, self.nch, self.fb, self.burst = h, nchannels, int(fb), burst
 
     def close(self):
         if getattr(self, "h", None):
@@ -424,6 +428,18 @@ class AeroLBank:
         n = C.c_int(0)
         capi.check(self.L.jaero_aerol_read_sus(self.h, channel, buf.ctypes.data, caprows, C.byref(n)))
         return buf[: n.value].copy()
+
+    def read_packets(self, channel: int, caprows: int = 4096):
+        """burst mode: [(type, bytes)] with type 1 = R packet, 2 = T packet (header 6 bytes, then 12 per signal unit)."""
+        buf = np.empty((caprows, 16), dtype=np.int32)
+        n = C.c_int(0)
+        capi.check(self.L.jaero_aerol_read_packets(self.h, channel, buf.ctypes.data, caprows, C.byref(n)))
+        rows, out = buf[: n.value], []
+        for pk in sorted(set(rows[:, 0].tolist())) if len(rows) else []:
+            r = rows[rows[:, 0] == pk]
+            r = r[np.argsort(r[:, 1])]
+            out.append((int(r[0, 15]), bytes(int(v) for v in r[:, 2:14].reshape(-1))[: int(r[0, 14])]))
+        return out
 
     def read_events(self, channel: int, caprows: int = 256) -> np.ndarray:
         buf = np.empty((caprows, 3), dtype=np.int64)
