@@ -48,9 +48,10 @@ def parse():
     ap.add_argument("--ebno", type=int, default=1, help="run the EbNo meters (the reference always does)")
     ap.add_argument("--ebno-db", type=float, default=10.0)
     ap.add_argument("--idle-frac", type=float, default=0.0, help="aerol workload: fraction of channels that carry noise only (never lock)")
-    ap.add_argument("--workload", default="oqpsk", choices=["oqpsk", "burst_oqpsk", "aerol"],
+    ap.add_argument("--workload", default="oqpsk", choices=["oqpsk", "burst_oqpsk", "aerol", "aerol_burst"],
                     help="oqpsk = BASELINE configs[2] (continuous, the headline); burst_oqpsk = configs[3] (one burst per second per "
-                         "channel); aerol = the 10.5 kbps P-channel bit pipeline behind the demodulator (SURVEY 8 row f1), one frame per step")
+                         "channel); aerol = the 10.5 kbps P-channel bit pipeline behind the demodulator (SURVEY 8 row f1), one frame per step; "
+                         "aerol_burst = the R/T channel packet search behind a burst demodulator (row f2), one burst per channel and step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=1_000_000, help="samples per core for the CPU baseline leg")
     return ap.parse_args()
@@ -307,6 +308,115 @@ def aerol_bench():
         dist.destroy_process_group()
 
 
+def aerol_burst_bench():
+    """Row f2: a step = what a burst demodulator bank emits for one burst per channel (start-of-burst marker, ~80 soft bits, unique word,
+    a T packet of 7 signal units = 1472 channel bits, then noise up to 5248 entries = half a second), soft bits resident in HBM.  Metric: soft bits per
+    second (and packets per second) through unique word search, trial deinterleave / Viterbi / CRC rounds."""
+    import torch
+    import torch.distributed as dist
+
+    from jaero_amd import aerol_frames as AF
+    from jaero_amd import capi
+    from jaero_amd import dist as jd
+    from jaero_amd.demodulator import AeroLBank
+
+    capi.lib()
+    rank, world, local = jd.init_from_env()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    nch, K, W = ARGS.channels, ARGS.steps, ARGS.warmup
+    per, nuniq = 5248, 32  # the reference ignores a unique word for NumberOfBits-68 = 4924 soft bits after the previous one
+    rng = np.random.default_rng(5 + rank)
+    rb = lambda k: bytes(rng.integers(0, 256, k, dtype=np.uint8))
+    streams = []
+    for u in range(nuniq):
+        segs = []
+        for _ in range(K + W):
+            x = AF.rt_burst_stream([("T", (rb(4), [rb(10) for _ in range(7)]))], gap=3600, lead=80, sigma=25.0, seed=int(rng.integers(1 << 30)),
+                                   invert_i=bool(u & 1), invert_q=bool(u & 2))[64:]  # from the marker on
+            segs.append(np.concatenate([x, np.full(per, 128, np.int16)])[:per])
+        streams.append(np.concatenate(segs))
+    host = np.stack(streams)
+    soft = torch.from_numpy(host).to(dev)
+    idx = torch.arange(nch, device=dev) % nuniq
+    frames = torch.empty((K + W, nch, per), dtype=torch.int16, device=dev)
+    for i in range(K + W):
+        frames[i].copy_(soft[idx, i * per:(i + 1) * per])
+    del soft
+    counts = torch.full((nch,), per, dtype=torch.int32, device=dev)
+    bank = AeroLBank(nch, 10500, device=local, max_softbits_per_write=per, su_capacity=8 * (K + W) + 8, burst=True)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        bank.write_device(frames[i].data_ptr(), counts.data_ptr(), per, per, stream)
+
+    for i in range(W):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    npk = sum(len(bank.read_packets(c)) for c in range(min(4, nch)))
+    if rank == 0:
+        value = float(K) * per * nch * world / dt / 1e6
+        # algorithmic bytes per soft bit: 2 (int16 in) + 1 (block write); every trial re-reads the block, deinterleaves and decodes it:
+        # a T packet of n signal units is tried at 2, 5, 8 .. 5+3(n-1) columns = sum of 64*cols bytes read + written + read again
+        trial_bytes = sum(3 * 64 * c for c in [2] + list(range(5, 5 + 3 * 6 + 1, 3)))
+        alg = 3.0 + trial_bytes / float(per)
+        line = {
+            "metric": "Msoftbits/s through the Aero-L burst-mode (R/T channel) packet search", "value": round(value, 2), "unit": "Msoftbits/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{nch}-channel-per-GPU 10.5 kbps R/T bursts: per step and channel one burst as the burst demodulator emits it "
+                                   f"(marker, lead-in, unique word, T packet with 7 signal units, noise; {per} entries), {nuniq} distinct streams",
+                       "channels_per_gpu": nch, "total_channels": nch * world, "packets_per_s": round(float(K) * nch * world / dt, 1),
+                       "packets_decoded_in_first_channels": npk, "channels_checked": min(4, nch), "expected": (K + W) * min(4, nch)},
+            "roofline": {"bound": "hbm", "kernel": "k_viterbi (trial decodes, one block per wavefront)", "achieved": round(alg * value * 1e6 / 1e9, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * value * 1e6 / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                         "alg_bytes_per_softbit": round(alg, 2),
+                         "note": "whole-step figure (the step is launch- and latency-bound: 31 rounds of 4 small kernels); the Viterbi trials "
+                                 "are integer-VALU work, see the aerol workload"},
+        }
+        if world == 1 and not ARGS.no_cpu_baseline:
+            from oracle import oracle as O  # cpu_baseline leg only
+            x = np.tile(host[0], max(1, int(1_000_000 / host.shape[1]) + 1))[:1_000_000]
+            ncores = os.cpu_count() or 1
+            if O.have_ref():
+                with tempfile.TemporaryDirectory() as td:
+                    path = os.path.join(td, "in.s16")
+                    x.tofile(path)
+                    t1 = time.time()
+                    procs = [subprocess.Popen([O.REF_BIN, "aerol", path, os.path.join(td, f"o{i}.txt"), "fb=10500", "group=0", "burst=1"],
+                                              stdout=subprocess.PIPE) for i in range(ncores)]
+                    inner = [float(pp.communicate()[0].split()[0]) for pp in procs]
+                    wall = time.time() - t1
+                line["cpu_baseline"] = {"value": round(sum(len(x) / t for t in inner) / 1e6, 3), "unit": "Msoftbits/s", "cores": ncores, "kind": "reference",
+                                        "sample": f"{len(x)} soft bits (bursts of channel 0, repeated) per core through the unmodified AeroL in burst mode, "
+                                                  f"demodulator-style groups; one process per core ({wall:.1f} s wall)"}
+            else:
+                t1 = time.perf_counter()
+                O.run_aerol_burst(10500, x)
+                ct = time.perf_counter() - t1
+                line["cpu_baseline"] = {"value": round(len(x) / ct / 1e6, 3), "unit": "Msoftbits/s", "cores": 1, "kind": "port",
+                                        "sample": f"{len(x)} soft bits through oracle/aerol_oracle.c in burst mode, one thread"}
+        print(json.dumps(line), flush=True)
+    bank.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     import torch
     import torch.distributed as dist
@@ -433,5 +543,9 @@ if __name__ == "__main__":
     ARGS = parse()
     if ARGS.workload == "aerol":
         aerol_bench()
+    elif ARGS.workload == "aerol_burst":
+        if ARGS.channels == 65536:
+            ARGS.channels = 16384
+        aerol_burst_bench()
     else:
         main()

@@ -133,6 +133,7 @@ struct jaero_ctx
     int16_t *d_pcm_raw = nullptr;    // [nch*max_write] staging for host input
     double2 *d_scratch = nullptr;
     double2 *d_tw = nullptr;
+    int *d_emitted = nullptr; // burst banks: per-channel count of soft bits already emitted (jaero_softbits_view)
     bool coarse_v2 = false; int coarse3_grid = 256, coarse_ver = 4;
     int *d_chanlist = nullptr;
     int coarse_grid = 0;
@@ -970,10 +971,47 @@ extern "C" int jaero_read_softbits_all(jaero_ctx *c, int16_t *dst, int capc, int
     return 0;
 }
 
+// burst banks: only what the reference would have emitted (groups completed so far) is handed on; the pending tail stays
+__global__ void k_burst_emitted(const int *__restrict__ cnt, const int *__restrict__ nrx, int *__restrict__ emitted, int nch)
+{
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch < nch) emitted[ch] = cnt[ch] - nrx[ch];
+}
+// after the emitted part was consumed: move the pending tail to the front of the channel's buffer
+__global__ void k_burst_keep_tail(int *__restrict__ cnt, const int *__restrict__ nrx, int16_t *__restrict__ soft, int cap, int nch)
+{
+    const int ch = blockIdx.x;
+    if (ch >= nch) return;
+    const int c = cnt[ch], pend = nrx[ch], first = c - pend;
+    int16_t *row = soft + (size_t)ch * cap;
+    // pend is at most one group (< 64 entries): one wavefront, read everything before writing
+    const int t = threadIdx.x;
+    int16_t v = 0;
+    if (t < pend) v = row[first + t];
+    __syncthreads();
+    if (t < pend) row[t] = v;
+    if (t == 0) cnt[ch] = pend;
+}
+
 extern "C" int jaero_softbits_view(jaero_ctx *c, void **dev_softbits, void **dev_counts, int *capacity)
 {
     if (!c) return fail(JAERO_EINVAL, "null ctx");
     if (dev_softbits) *dev_softbits = c->o_soft;
+    if (c->burst && dev_counts)
+    {
+        HIPCHK(hipSetDevice(c->device));
+        if (!c->d_emitted)
+        {
+            void *q = nullptr;
+            if (hipMalloc(&q, sizeof(int) * c->o_nchp) != hipSuccess) return fail(JAERO_ENOMEM, "emitted counts");
+            c->allocs.push_back(q);
+            c->d_emitted = (int *)q;
+        }
+        hipLaunchKernelGGL(k_burst_emitted, dim3((c->o_nch + 255) / 256), dim3(256), 0, c->last_stream, c->o_soft_cnt, c->o_nrx, c->d_emitted, c->o_nch);
+        *dev_counts = c->d_emitted;
+        if (capacity) *capacity = c->o_soft_cap;
+        return 0;
+    }
     if (dev_counts) *dev_counts = c->o_soft_cnt;
     if (capacity) *capacity = c->o_soft_cap;
     return 0;
@@ -983,7 +1021,13 @@ extern "C" int jaero_discard_softbits(jaero_ctx *c, void *stream)
 {
     if (!c) return fail(JAERO_EINVAL, "null ctx");
     HIPCHK(hipSetDevice(c->device));
-    if (c->burst) return fail(JAERO_ENOTSUP, "jaero_discard_softbits: not for burst banks (pending tail); use jaero_read_softbits");
+    if (c->burst)
+    {
+        // what jaero_softbits_view reported as emitted is gone; the not yet emitted tail of every channel moves to the front
+        hipLaunchKernelGGL(k_burst_keep_tail, dim3(c->o_nch), dim3(64), 0, (hipStream_t)stream, c->o_soft_cnt, c->o_nrx, c->o_soft, c->o_soft_cap, c->o_nch);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     HIPCHK(hipMemsetAsync(c->o_soft_cnt, 0, sizeof(int) * c->o_nchp, (hipStream_t)stream));
     HIPCHK(hipMemsetAsync(c->o_sym_cnt, 0, sizeof(int) * c->o_nchp, (hipStream_t)stream));
     return 0;

@@ -106,7 +106,7 @@ def msk(nsamples: int, *, fb: float = 1200.0, Fs: float = 48000.0, fc: float = 1
 
 
 def burst_oqpsk(nsamples: int, *, burst_starts, ndata_sym: int = 1500, fb: float = 10500.0, Fs: float = 48000.0, fc: float = 8000.0,
-                ebno_db: float | None = 15.0, peak: float = 0.3, seed: int = SEED_BASE, noise_in_gaps: bool = True):
+                ebno_db: float | None = 15.0, peak: float = 0.3, seed: int = SEED_BASE, noise_in_gaps: bool = True, data=None):
     """10.5 kbps burst OQPSK: per burst 128 symbols of constant (+1,+1) [carrier burst],
     128 symbols alternating +1,-1 on both arms [tones at fc +- fb/4: the "trident"], then `ndata_sym` random symbols
     per arm; same RRC alpha=1 pulse / half-symbol Q offset / passband law as `oqpsk`.  `burst_starts` are sample
@@ -123,6 +123,9 @@ def burst_oqpsk(nsamples: int, *, burst_starts, ndata_sym: int = 1500, fb: float
         if k0 + nb > nsym:
             break
         bits = rng.integers(0, 2, size=2 * ndata_sym, dtype=np.uint8)
+        if data is not None:  # caller's channel bits for this burst (e.g. unique word + an R/T packet), random fill behind them
+            d = np.asarray(data[len(bursts)], dtype=np.uint8)
+            bits[: len(d)] = d[: len(bits)]
         pre = np.concatenate([np.ones(128), np.where(np.arange(128) % 2 == 0, 1.0, -1.0)])
         a_i[k0:k0 + nb] = np.concatenate([pre, 2.0 * bits[0::2] - 1.0])
         a_q[k0:k0 + nb] = np.concatenate([pre, 2.0 * bits[1::2] - 1.0])

@@ -76,3 +76,46 @@ def test_bank_vs_oracle(B, oracle_mod):
         npk += len(want)
     assert npk > 150
     bank.close()
+
+
+def test_pcm_to_packets_on_device(B, oracle_mod):
+    """R and T packets -> burst OQPSK passband PCM (carrier, alternating preamble, unique word, packet) -> burst demodulator bank ->
+    the emitted soft bits stay in HBM -> burst-mode Aero-L bank.  The packets that come out equal what the oracle chain (demodulator
+    restatement -> AeroL restatement) produces from the same PCM, and each of them is one of the transmitted ones, in order.  (Not every
+    burst survives the reference's burst demodulator at this Eb/N0 -- that is its property, and the same on both sides.)"""
+    from jaero_amd import signalgen as G
+
+    nch, n = 3, 48000 * 5
+    rng = np.random.default_rng(21)
+    rb = lambda k: bytes(rng.integers(0, 256, k, dtype=np.uint8))
+    uw = np.repeat(np.array([(AF.UW >> (31 - k)) & 1 for k in range(32)], dtype=np.uint8), 2)
+    sent, pcm = [], np.zeros((nch, n), np.int16)
+    for c in range(nch):
+        pk = [("R", rb(17)), ("T", (rb(4), [rb(10) for _ in range(3 + c)])), ("R", rb(17))]
+        data = [np.concatenate([uw, AF.rt_packet_bits(k, p)]) for k, p in pk]
+        pcm[c], _ = G.burst_oqpsk(n, burst_starts=[40000 + 777 * c, 100000 + 555 * c, 185000], ndata_sym=900, fc=8000.0 + 15.0 * c, ebno_db=16.0,
+                                  seed=G.SEED_BASE + 300 + c, data=data)
+        sent.append(pk)
+    chunk = 4096
+    demod = B.DemodulatorBank(B.BurstOqpskSettings(), nch, device=0, max_write_samples=chunk, softbit_capacity=16384)
+    aerol = B.AeroLBank(nch, 10500, max_softbits_per_write=16384, su_capacity=400, burst=True)
+    for s in range(0, n, chunk):
+        demod.write(pcm[:, s:s + chunk])
+        aerol.write_from_bank(demod, 4096)
+    total = 0
+    for c in range(nch):
+        got = aerol.read_packets(c)
+        soft = oracle_mod.run_burst(oracle_mod.burst_oqpsk_settings(), pcm[c], chunk=chunk)["soft"]
+        want = oracle_mod.packets_from_rows(oracle_mod.run_aerol_burst(10500, soft)["packets"])
+        assert got == want, c
+        k0 = 0
+        for typ, data in got:  # each decoded packet is the next transmitted one of its kind that it equals
+            hits = [k for k in range(k0, len(sent[c])) if (typ == 1 and sent[c][k][0] == "R" and data[:17] == sent[c][k][1])
+                    or (typ == 2 and sent[c][k][0] == "T" and data[:4] == sent[c][k][1][0]
+                        and [data[6 + 12 * j: 16 + 12 * j] for j in range(len(sent[c][k][1][1]))] == sent[c][k][1][1])]
+            assert hits, (c, typ)
+            k0 = hits[0] + 1
+        total += len(got)
+    assert total >= 5
+    demod.close()
+    aerol.close()
