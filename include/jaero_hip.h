@@ -190,7 +190,9 @@ int jaero_aerol_tick_dcd(jaero_aerol_ctx *ctx, int *dcd_out /* optional [nchanne
  * The bank behind a burst demodulator bank (JAERO_KIND_BURST_OQPSK): unique word with tolerance 4 that has to come ~80 soft bits after
  * the demodulator's start-of-burst marker (JAERO/aerol.cpp:1192-1200), RTChannelDeleaveFECScram::update (JAERO/aerol.h:785-873: trial
  * decodes of the collected block at 2, 5, 8 .. 95 interleaver columns until the CRCs of an R packet or of a T packet's header and
- * signal units pass), end of signal after one second of bits.  10500 bps; 600/1200 bps bursts (updateMSK) are not built.
+ * signal units pass), end of signal after one second of bits.  At 600 / 1200 bps (behind JAERO_KIND_BURST_MSK): one detector, the word
+ * within 250 soft bits of the marker, RTChannelDeleaveFECScram::updateMSK (aerol.h:631-782: R test at 5 blocks, the unit count read at 11,
+ * the T packet decoded at the announced length), three seconds of bits.
  *   jaero_aerol_read_packets: rows of 16 int32 [packet number, chunk, 12 bytes (zero padded), total bytes of the packet, type]
  *       type 1 = R packet (20 bytes: 17 + CRC + the flush byte), 2 = T packet (6 header bytes incl. CRC, then 12 per signal unit)
  *   jaero_aerol_read_events additionally reports kind 3 = the " Bad R/T Packet" notice (JAERO/aerol.cpp:1289-1293,1531)

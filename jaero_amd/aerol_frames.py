@@ -196,3 +196,64 @@ def rt_burst_stream(packets, *, gap: int = 12000, lead: int = 80, sigma: float =
         ld = lead + (lead & 1)
         out += [np.array([-1], dtype=np.int16), noise(ld), to_soft(bits, sigma=sigma, seed=int(rng.integers(1 << 30))), noise(gap + (gap & 1))]
     return np.concatenate(out)
+
+
+def interleave_msk(coded: np.ndarray) -> np.ndarray:
+    """The inverse of AeroLInterleaver::deinterleaveMSK_ba (aerol.cpp:671-711): the first five 64-bit columns form one 64 x 5 block,
+    every following three columns a 64 x 3 block of their own."""
+    assert len(coded) % 64 == 0 and (len(coded) // 64 - 5) % 3 == 0
+    out = np.zeros_like(coded)
+    i = np.arange(64)
+    k = 0
+    for j in range(5):
+        out[((i * 27) % 64) * 5 + j] = coded[k + i]
+        k += 64
+    proc = 5
+    while k < len(coded):
+        for j in range(3):
+            out[64 * proc + ((i * 27) % 64) * 3 + j] = coded[k + i]
+            k += 64
+        proc += 3
+    return out
+
+
+def rt_packet_bits_msk(kind: str, payload) -> np.ndarray:
+    """600 / 1200 bps R or T packet for RTChannelDeleaveFECScram::updateMSK (aerol.h:631-782).  A T packet is found through the count
+    its SECOND signal unit carries in the low six bits of its first byte: targetSUSize = 2 + count (halved + 1 from 16 up), and the
+    block is decoded at (targetSUSize + 1) * 3 + 2 columns, which hold targetSUSize + 1 units.  `payload` for T: (4-byte header,
+    list of 10-byte units, at least 4); the count field of unit 1 is overwritten accordingly."""
+    if kind == "R":
+        b = _bytes_to_bits(bytes(payload))
+        info = np.concatenate([b, crc16_bits(b)])
+        cols = 5
+    else:
+        hdr, sus = payload
+        sus = [bytearray(x) for x in sus]
+        T = len(sus) - 1
+        assert 3 <= T < 16
+        sus[1][0] = (sus[1][0] & 0xC0) | (T - 2)
+        parts = []
+        for field in [bytes(hdr)] + [bytes(x) for x in sus]:
+            b = _bytes_to_bits(field)
+            parts += [b, crc16_bits(b)]
+        info = np.concatenate(parts)
+        cols = (T + 1) * 3 + 2
+    ndec = 32 * cols
+    assert len(info) + 6 <= ndec
+    msg = np.zeros(ndec, dtype=np.uint8)
+    msg[: len(info)] = info ^ scrambler_sequence(len(info))
+    return interleave_msk(conv_encode(msg))
+
+
+def rt_burst_stream_msk(packets, *, gap: int = 4200, lead: int = 80, sigma: float = 20.0, seed: int = 0, invert=False):
+    """As rt_burst_stream, for the 600 / 1200 bps burst demodulators: one bit stream, the unique word once."""
+    rng = np.random.default_rng(seed)
+    noise = lambda n: np.clip(np.round(128 + rng.normal(0, 40, n)), 0, 255).astype(np.int16)
+    uwbits = np.array([(UW >> (31 - k)) & 1 for k in range(32)], dtype=np.uint8)
+    out = [noise(64)]
+    for kind, payload in packets:
+        bits = np.concatenate([uwbits, rt_packet_bits_msk(kind, payload)])
+        if invert:
+            bits = bits ^ 1
+        out += [np.array([-1], dtype=np.int16), noise(lead + (lead & 1)), to_soft(bits, sigma=sigma, seed=int(rng.integers(1 << 30))), noise(gap + (gap & 1))]
+    return np.concatenate(out)

@@ -93,7 +93,6 @@ static int aerol_create(int device, int nchannels, int fb, int max_softbits_per_
     if (!out || nchannels <= 0 || max_softbits_per_write <= 0) return fail(JAERO_EINVAL, "jaero_aerol_create: bad arguments");
     *out = nullptr;
     if (fb != 600 && fb != 1200 && fb != 10500) return fail(JAERO_ENOTSUP, "jaero_aerol_create: fb must be 600, 1200 or 10500 (8400 C-channel: SURVEY 8f4)");
-    if (burst && fb != 10500) return fail(JAERO_ENOTSUP, "jaero_aerol_create_burst: R/T packet search is built for 10500 bps (600/1200 bps bursts: updateMSK, not yet)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(JAERO_ENODEV, "no HIP device available (this library has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(JAERO_ENODEV, "device %d out of range", device);
@@ -115,7 +114,7 @@ static int aerol_create(int device, int nchannels, int fb, int max_softbits_per_
     {
         // setSettings(fb, true) (aerol.cpp:996-1003,1062-1070): one second of bits as frame countdown; the block is the R/T packet
         // collector's (RTChannelDeleaveFECScram: up to 95 interleaver columns)
-        g.TotalNumberOfBits = fb;
+        g.TotalNumberOfBits = g.oqpsk ? fb : 3 * fb; // 1 s (10500 bps) / 3 s (600, 1200 bps) of bits
         g.blocksz = RT_BLOCKSZ;
     }
     g.idx_sat = (1000000000 - g.BitsInHeader) % g.blocksz;

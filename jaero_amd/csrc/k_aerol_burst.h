@@ -18,7 +18,7 @@ enum { RT_NOTHING = 8, RT_TEST_FAILED = 32, RT_BAD = 0, RT_OK_R = 3, RT_OK_T = 5
 enum // burst-only fields, stored in slots the continuous pipeline uses for its own block bookkeeping
 {
     BI_RT_BLOCKPTR = AI_BLOCKCNT, BI_RT_LAST = AI_NINFO, BI_GRP_CNT = AI_SCR_POS, BI_GRP_PAIR = AI_DL2_PTR, BI_GRP_SKIP = AI_VBLOCKS,
-    BI_TRIAL_LEN = AI_BULK_LEN, BI_RESUME_GEND = AI_BULK_SRC, BI_NPACKETS = AI_NFRAMES
+    BI_TRIAL_LEN = AI_BULK_LEN, BI_RESUME_GEND = AI_BULK_SRC, BI_NPACKETS = AI_NFRAMES, BI_TARGET_BLOCKS = AI_BULK_DST, BI_TARGET_SUS = AI_BULK_FLAGS
 };
 
 __global__ __launch_bounds__(64) void k_aerolb_bits(const AGeom g, const APtrs p, const int16_t *__restrict__ soft, const int *__restrict__ counts, int stride)
@@ -30,6 +30,7 @@ __global__ __launch_bounds__(64) void k_aerolb_bits(const AGeom g, const APtrs p
     unsigned pd_imag = (unsigned)ALD(AI_PD_IMAG), pd_real = (unsigned)ALD(AI_PD_REAL);
     int blockptr = ALD(BI_RT_BLOCKPTR), rt_last = ALD(BI_RT_LAST), gcnt = ALD(BI_GRP_CNT), pair = ALD(BI_GRP_PAIR), skip = ALD(BI_GRP_SKIP);
     int pos = ALD(AI_IN_POS), resume = ALD(AI_RESUME);
+    const int target_blocks = ALD(BI_TARGET_BLOCKS); // 600 / 1200 bps T packets: set by k_aerolb_post at 11 blocks
     const long long nbits0 = ((long long)(unsigned)ALD(AI_NBITS_LO)) | ((long long)ALD(AI_NBITS_HI) << 32);
     const int n = counts[ch];
     const int16_t *sb = soft + (size_t)ch * stride;
@@ -80,9 +81,25 @@ __global__ __launch_bounds__(64) void k_aerolb_bits(const AGeom g, const APtrs p
         int bit = (((unsigned)v & 0xFFu) >= 128u) ? 1 : 0;
         unsigned soft_bit = (unsigned)v & 0xFFFFu;
         if (muw < 100000) muw++;
+        int inverted;
+        if (!g.oqpsk)
+        {
+            // 600 / 1200 bps: one phase-invariant detector (tolerance 4) on every bit; a word later than 250 soft bits after the
+            // marker is refused and leaves the inversion as it was (aerol.cpp:1235-1267).  State in the imag-arm slots.
+            const int inv_before = inv_imag;
+            pd_imag = (pd_imag << 1) | (unsigned)bit;
+            const int xorsum = __popc(pd_imag ^ AEROL_UW);
+            gotsync = 0;
+            if (xorsum >= 32 - 4) { inv_imag = 1; gotsync = 1; }
+            else if (xorsum <= 4) { inv_imag = 0; gotsync = 1; }
+            if (muw > 250 && gotsync) { inv_imag = inv_before; gotsync = 0; }
+            inverted = inv_imag;
+        }
+        else
+        {
         realimag ^= 1;
         unsigned pd = realimag ? pd_imag : pd_real;
-        int inverted = realimag ? inv_imag : inv_real;
+        inverted = realimag ? inv_imag : inv_real;
         if (cntr > g.NumberOfBits - 68 || cntr <= 0 || !datacd)
         {
             // PreambleDetectorPhaseInvariant::Update with tolerance 4 (aerol.cpp:781-804, 996-1003)
@@ -98,6 +115,7 @@ __global__ __launch_bounds__(64) void k_aerolb_bits(const AGeom g, const APtrs p
         if (realimag) { pd_imag = pd; inv_imag = inverted; }
         else { pd_real = pd; inv_real = inverted; }
         if (gotsync && abs(muw - 80) > 150) gotsync = 0; // the unique word comes ~80 soft bits after the marker (:1192-1200)
+        }
         if (inverted)
         {
             bit = 1 - bit;
@@ -119,6 +137,11 @@ __global__ __launch_bounds__(64) void k_aerolb_bits(const AGeom g, const APtrs p
             blockptr++;
             // ((blockptr - 64*5) % (64*3)) == 0 in C: also -192, i.e. two columns
             trial = (blockptr == 128) || (blockptr >= 320 && ((blockptr - 320) % 192) == 0);
+            if (!g.oqpsk) // updateMSK (aerol.h:649): only at 5, 11, 50 and the announced number of 64-bit blocks
+            {
+                const int nb = blockptr / 64;
+                trial = trial && (nb == 5 || nb == target_blocks || nb == 11 || nb == 50);
+            }
         }
         if (trial)
         {
@@ -148,8 +171,16 @@ __global__ __launch_bounds__(256) void k_aerolb_deint(const AGeom g, const APtrs
     const uint8_t *src = p.rx + (size_t)ch * RT_BLOCKSZ;
     for (int q = lane; q < len; q += 64) blk[w][q] = src[q];
     uint8_t *dst = p.deint + (size_t)ch * RT_BLOCKSZ;
-    const int row = ((lane * 27) & 63) * cols;
-    for (int j = 0; j < cols; j++) dst[j * 64 + lane] = blk[w][row + j];
+    const int perm = (lane * 27) & 63;
+    if (g.oqpsk)
+        for (int j = 0; j < cols; j++) dst[j * 64 + lane] = blk[w][perm * cols + j];
+    else
+    {
+        // deinterleaveMSK_ba (aerol.cpp:671-711): the first five columns are one 64 x 5 block, every following three a 64 x 3 block
+        for (int j = 0; j < 5 && j < cols; j++) dst[j * 64 + lane] = blk[w][perm * 5 + j];
+        for (int proc = 5; proc + 3 <= cols; proc += 3)
+            for (int j = 0; j < 3; j++) dst[(proc + j) * 64 + lane] = blk[w][64 * proc + perm * 3 + j];
+    }
 }
 
 __device__ __forceinline__ bool aerolb_crc_bits(const uint8_t *bits, int numberofbits) // calcusingbitsandcheck
@@ -179,7 +210,30 @@ __global__ __launch_bounds__(64) void k_aerolb_post(const AGeom g, const APtrs p
     for (int h = nd - 6; h < nd; h++) dec[h] = 0;   // the decoder leaves the last K-1 bits of its zero-initialised output untouched
     for (int h = 0; h < nd; h++) dec[h] ^= p.scr[h]; // scrambler.reset(); scrambler.update(deconvol)   (nd <= 3040 < 5000)
     int result, type = 0, chop = 0;
-    if (blockptr == 64 * 5)
+    bool keep_last = false;
+    if (!g.oqpsk)
+    {
+        // RTChannelDeleaveFECScram::updateMSK (aerol.h:655-782)
+        const int nb = blockptr / 64;
+        result = RT_NOTHING;
+        keep_last = true; // "Nothing" leaves lastpacketstate alone
+        if (nb == 5)
+        {
+            ALD(BI_TARGET_SUS) = 0; ALD(BI_TARGET_BLOCKS) = 0;
+            if (aerolb_crc_bits(dec, 8 * 19)) { result = RT_OK_R; type = 1; keep_last = false; }
+        }
+        else if (!aerolb_crc_bits(dec, 8 * 6)) { result = RT_BAD; keep_last = false; }
+        else if (nb == 11)
+        {
+            // the signal unit after the initial one announces how many there are (:709-729)
+            const uint8_t *isu = dec + (8 * 6) + (8 * 12) * 1;
+            int tsus = 2 + (isu[0] * 1 + isu[1] * 2 + isu[2] * 4 + isu[3] * 8 + isu[4] * 16 + isu[5] * 32);
+            if (tsus >= 16) tsus = tsus / 2 + 1;
+            ALD(BI_TARGET_SUS) = tsus; ALD(BI_TARGET_BLOCKS) = ((tsus + 1) * 3) + 2;
+        }
+        else if (nb == ALD(BI_TARGET_BLOCKS)) { result = RT_OK_T; type = 2; chop = 1; keep_last = false; } // the per-unit CRCs cannot fail it (:732-766)
+    }
+    else if (blockptr == 64 * 5)
     {
         if (!aerolb_crc_bits(dec, 8 * 19)) result = RT_TEST_FAILED;
         else { result = RT_OK_R; type = 1; }
@@ -227,6 +281,6 @@ __global__ __launch_bounds__(64) void k_aerolb_post(const AGeom g, const APtrs p
         const long long bitidx = (((long long)(unsigned)ALD(AI_NBITS_LO)) | ((long long)ALD(AI_NBITS_HI) << 32)) + ALD(AI_IN_POS);
         aerol_event(g, p, ch, ev_cnt, overflow, bitidx, 3, 0); // " Bad R/T Packet" (aerol.cpp:1531)
     }
-    ALD(BI_RT_LAST) = result;
+    if (!keep_last) ALD(BI_RT_LAST) = result;
     ALD(AI_EV_CNT) = ev_cnt; ALD(AI_OVERFLOW) = overflow;
 }

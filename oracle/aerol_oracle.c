@@ -101,7 +101,8 @@ struct jo_aerol
     gb sus, events;
     /* burst mode (R/T channel packets): RTChannelDeleaveFECScram aerol.h:554-873 */
     int burstmode;
-    int *rt_block; int rt_blockptr, rt_last, rt_scr_pos, rt_numberofsus;
+    int *rt_block; int rt_blockptr, rt_last, rt_scr_pos, rt_numberofsus, rt_targetSUSize, rt_targetBlocks;
+    pdet_t pd_msk; /* mskBurstDetector */
     jo_codec *rt_codec;
     long npackets;
     gb packets;
@@ -154,11 +155,12 @@ jo_aerol *jo_aerol_create(int fb)
  * tolerance 4, the frame countdown becomes one second of bits (aerol.cpp:996-1003,1062-1070). */
 jo_aerol *jo_aerol_create_burst(int fb)
 {
-    if (fb != 10500) return NULL; /* 600/1200 bps bursts (updateMSK, mskBurstDetector) are not restated */
+    if (fb != 10500 && fb != 1200 && fb != 600) return NULL;
     jo_aerol *a = jo_aerol_create(fb);
     a->burstmode = 1;
     a->pd_imag.tollerence = 4; a->pd_real.tollerence = 4;
-    a->TotalNumberOfBits = a->ifb;
+    pdet_set(&a->pd_msk, 3780831379ULL, 32); a->pd_msk.tollerence = 4; /* :963,1002 */
+    a->TotalNumberOfBits = a->useingOQPSK ? a->ifb : a->ifb * 3;    /* 1 s / 3 s countdown :1062-1070 */
     a->rt_block = (int *)calloc(RT_BLOCKSZ, sizeof(int));
     a->rt_codec = jo_codec_create(24);
     a->rt_last = RT_NOTHING;
@@ -335,6 +337,54 @@ static int rt_update(jo_aerol *a, int bit) /* RTChannelDeleaveFECScram::update a
     return result;
 }
 
+static int rt_update_msk(jo_aerol *a, int bit) /* RTChannelDeleaveFECScram::updateMSK aerol.h:631-782 */
+{
+    if (a->rt_blockptr >= RT_BLOCKSZ) return RT_FULL;
+    a->rt_block[a->rt_blockptr] = bit;
+    a->rt_blockptr++;
+    const int blockptr = a->rt_blockptr, nb = blockptr / 64;
+    if (!((((blockptr - (64 * 5)) % (64 * 3)) == 0) && (nb == 5 || nb == a->rt_targetBlocks || nb == 11 || nb == 50))) return RT_NOTHING;
+    /* deinterleaveMSK_ba(block, blocks) aerol.cpp:671-711: 5 columns, then groups of 3 */
+    unsigned char *del = (unsigned char *)malloc((size_t)blockptr);
+    int k = 0;
+    for (int j = 0; j < 5; j++)
+        for (int i = 0; i < 64; i++) del[k++] = (unsigned char)a->rt_block[a->depermute[i] * 5 + j];
+    for (int proc = 5; k < nb * 64; proc += 3)
+        for (int j = 0; j < 3; j++)
+            for (int i = 0; i < 64; i++) del[k++] = (unsigned char)a->rt_block[64 * proc + a->depermute[i] * 3 + j];
+    unsigned char *dec = (unsigned char *)malloc((size_t)blockptr);
+    const int nd = jo_decode_soft(a->rt_codec, del, blockptr, dec);
+    a->rt_scr_pos = 0;
+    for (int h = 0; h < nd; h++) dec[h] ^= a->scr[a->rt_scr_pos < 5000 ? a->rt_scr_pos : 4999], a->rt_scr_pos++;
+    int result = RT_NOTHING;
+    if (blockptr == 64 * 5)
+    {
+        a->rt_targetSUSize = 0; a->rt_targetBlocks = 0;
+        if (crc16_bits_check(dec, 8 * 19)) { rt_emit(a, dec, nd, 0, 1); a->rt_blockptr = RT_BLOCKSZ; a->rt_last = RT_OK_R; result = RT_OK_R; }
+        else result = RT_NOTHING; /* lastpacketstate untouched */
+    }
+    else if (!crc16_bits_check(dec, 8 * 6)) { a->rt_last = RT_BAD; result = RT_BAD; }
+    else if (nb == 11)
+    {
+        /* the signal unit after the initial one tells how many there are :709-729 */
+        const unsigned char *isu = dec + (8 * 6) + (8 * 12) * 1;
+        int bin = 2 + (isu[0] * 1 + isu[1] * 2 + isu[2] * 4 + isu[3] * 8 + isu[4] * 16 + isu[5] * 32);
+        a->rt_targetSUSize = bin;
+        if (a->rt_targetSUSize >= 16) a->rt_targetSUSize = a->rt_targetSUSize / 2 + 1;
+        a->rt_targetBlocks = ((a->rt_targetSUSize + 1) * 3) + 2;
+        result = RT_NOTHING;
+    }
+    else if (nb == a->rt_targetBlocks)
+    {
+        /* the per-unit CRCs are counted but cannot fail the packet (ok <= targetSUSize always) :732-766 */
+        rt_emit(a, dec, nd, 1, 2);
+        a->rt_numberofsus = a->rt_targetSUSize;
+        a->rt_blockptr = RT_BLOCKSZ; a->rt_last = RT_OK_T; result = RT_OK_T;
+    }
+    free(del); free(dec);
+    return result;
+}
+
 void jo_aerol_write(jo_aerol *a, const int16_t *sb, long n)
 {
     /* Decode(): decodedbytes.clear() etc. are text; the loop :1131-2027 */
@@ -360,6 +410,18 @@ void jo_aerol_write(jo_aerol *a, const int16_t *sb, long n)
             /* burst mode: the unique word has to come about 80 soft bits after the demodulator's start-of-burst marker :1192-1200 */
             if (gotsync && a->burstmode && a->ifb == 10500 && abs(a->muw - 80) > 150) gotsync = 0;
             if (pd->inverted)
+            {
+                bit = 1 - bit;
+                if (soft_bit > 128) soft_bit = 255 - soft_bit;
+                else if (soft_bit < 128) soft_bit = 255 - soft_bit;
+            }
+        }
+        else if (a->burstmode) /* 600/1200 bps bursts: phase-invariant detector, the word has to come within 250 soft bits of the marker :1235-1267 */
+        {
+            const int inverted = a->pd_msk.inverted;
+            gotsync = pdet_update_pi(&a->pd_msk, bit);
+            if (a->muw > 250 && gotsync) { a->pd_msk.inverted = inverted; gotsync = 0; }
+            if (a->pd_msk.inverted)
             {
                 bit = 1 - bit;
                 if (soft_bit > 128) soft_bit = 255 - soft_bit;
@@ -393,7 +455,7 @@ void jo_aerol_write(jo_aerol *a, const int16_t *sb, long n)
         }
         if (a->cntr >= 16 && a->burstmode)
         {
-            if (rt_update(a, soft_bit) == RT_BAD) ev(a, bitidx, 3, 0); /* :1531 " Bad R/T Packet" */
+            if ((a->useingOQPSK ? rt_update(a, soft_bit) : rt_update_msk(a, soft_bit)) == RT_BAD) ev(a, bitidx, 3, 0); /* :1531 " Bad R/T Packet" */
         }
         else if (a->cntr >= 16)
         {

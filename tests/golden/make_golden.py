@@ -153,6 +153,33 @@ def ref_packets_as_rows(ref):
     return [tuple(p) if p[0] == "R" else (p[0], p[1], p[2], tuple(p[3])) for p in ref]
 
 
+def rt_case_msk(seed, sigma, invert=False, cut=False):
+    """600 / 1200 bps burst-demodulator stream with R packets and T packets of 4, 9 and 15 units + one unit too many for a count."""
+    from jaero_amd import aerol_frames as AF
+    rng = np.random.default_rng(seed)
+    rb = lambda n: bytes(rng.integers(0, 256, n, dtype=np.uint8))
+    pk = [("R", rb(17)), ("T", (rb(4), [rb(10) for _ in range(4)])), ("T", (rb(4), [rb(10) for _ in range(9)])), ("R", rb(17)),
+          ("T", (rb(4), [rb(10) for _ in range(16)]))]
+    x = AF.rt_burst_stream_msk(pk, sigma=sigma, seed=seed, invert=invert, gap=4000 + 31 * seed)
+    if cut:  # a T packet that loses its tail and an R packet whose unique word comes more than 250 soft bits after the marker
+        k = int(np.where(x < 0)[0][2])
+        x = np.concatenate([x[: k + 700], x[k + 1500:]])
+        k = int(np.where(x < 0)[0][3])
+        x = np.concatenate([x[: k + 1], np.full(300, 128, np.int16), x[k + 1:]])
+    return pk, x
+
+
+def ref_rows(ref):
+    rows = []
+    for p in ref:
+        if p[0] == "R":
+            rows.append([1, 17, 0] + list(p[1]) + [0] * (10 * 31 + 4 - 17))
+        else:
+            flat = [v for su in p[3] for v in su]
+            rows.append([2, len(p[3]), p[2]] + list(p[1]) + flat + [0] * (10 * 31 - len(flat)))
+    return np.array(rows, dtype=np.int32).reshape(-1, 317)
+
+
 def aerol_burst():
     """Row f2: what the UNMODIFIED AeroL in burst mode (R/T channel packets, 10500 bps) makes of generated bursts, fed in the groups a
     burst demodulator emits."""
@@ -171,6 +198,13 @@ def aerol_burst():
         np.savez_compressed(os.path.join(HERE, f"aerol_burst_10500_{name}.npz"), soft=x, packets=np.array(rows, dtype=np.int32), bad=bad,
                             dcd=np.array(dcd, dtype=np.int64))
         print("aerol burst", name, x.shape, [(r[0], r[1]) for r in rows], "bad", bad, "dcd", len(dcd))
+    for fb, seed, inv in ((1200, 3, False), (600, 4, True)):
+        pk, x = rt_case_msk(seed, 22.0, invert=inv, cut=(fb == 600))
+        ref, bad, txt = O.run_ref_aerol_burst(fb, x)
+        dcd = [(int(a), int(b)) for a, b in __import__("re").findall(r"#DCD (\d) (\d+)", txt)]
+        rows = ref_rows(ref)
+        np.savez_compressed(os.path.join(HERE, f"aerol_burst_{fb}_a.npz"), soft=x, packets=rows, bad=bad, dcd=np.array(dcd, dtype=np.int64))
+        print("aerol burst", fb, x.shape, [(int(r[0]), int(r[1])) for r in rows], "bad", bad, "dcd", len(dcd))
 
 
 if __name__ == "__main__":

@@ -78,26 +78,29 @@ def test_oracle_vs_unmodified_aerol(R, fb, sigma, inv):
 
 
 # ---------------------------------------------------------------------------------------------- burst mode (R / T channel packets)
-def burst_rows(packets):
-    """oracle / GPU packet list [(type, bytes)] -> the golden files' row form [type, n, n_printed, header/payload bytes ...]"""
+def burst_rows(packets, msk=False):
+    """oracle / GPU packet list [(type, bytes)] -> the golden files' row form [type, n, n_printed, header/payload bytes ...].
+    The reference prints `numberofsus` signal units of a T packet: all of them at 10500 bps, one less than the block holds at 600 / 1200
+    bps (updateMSK sets numberofsus = targetSUSize, aerol.h:759)."""
     rows = []
     for typ, data in packets:
         if typ == 1:
             rows.append([1, 17, 0] + list(data[:17]) + [0] * (10 * 31 + 4 - 17))
         else:
-            n = (len(data) + 1 - 6) // 12
+            n = (len(data) + 1 - 6) // 12 - (1 if msk else 0)
             flat = [v for k in range(n) for v in data[6 + 12 * k: 6 + 12 * k + 10]]
             rows.append([2, n, n] + list(data[:4]) + flat + [0] * (10 * 31 - len(flat)))
     return np.array(rows, dtype=np.int32).reshape(-1, 3 + 4 + 310)
 
 
-@pytest.mark.parametrize("name", ["a", "b"])
+@pytest.mark.parametrize("name", ["10500_a", "10500_b", "1200_a", "600_a"])
 def test_burst_oracle_matches_reference_golden(oracle_mod, name):
     """R/T packets: the oracle's burst mode against what the unmodified AeroL (setSettings(10500, true)) printed for the same soft
     bits in the same (burst demodulator) groups: packet bytes, ' Bad R/T Packet' notices, DataCarrierDetect edges."""
-    g = load_golden(f"aerol_burst_10500_{name}")
-    o = oracle_mod.run_aerol_burst(10500, g["soft"])
-    assert np.array_equal(burst_rows(oracle_mod.packets_from_rows(o["packets"])), g["packets"])
+    g = load_golden(f"aerol_burst_{name}")
+    fb = int(name.split("_")[0])
+    o = oracle_mod.run_aerol_burst(fb, g["soft"])
+    assert np.array_equal(burst_rows(oracle_mod.packets_from_rows(o["packets"]), msk=fb != 10500), g["packets"])
     ev = o["events"]
     assert int((ev[:, 1] == 3).sum()) == int(g["bad"])
     # the driver stamps a DCD edge with the first soft bit of the group that carried it
@@ -134,4 +137,11 @@ def test_burst_oracle_vs_unmodified_aerol(R):
                 flat = [v for su in p[3] for v in su]
                 want.append([2, len(p[3]), p[2]] + list(p[1]) + flat + [0] * (10 * 31 - len(flat)))
         assert np.array_equal(got, np.array(want, dtype=np.int32).reshape(-1, 317))
+        assert int((o["events"][:, 1] == 3).sum()) == bad
+    for fb, seed in ((1200, 7), (600, 8)):
+        _, x = mk.rt_case_msk(seed, 30.0, invert=bool(seed & 1), cut=True)
+        ref, bad, _ = R.run_ref_aerol_burst(fb, x)
+        o = R.run_aerol_burst(fb, x)
+        got = burst_rows(R.packets_from_rows(o["packets"]), msk=True)
+        assert np.array_equal(got, mk.ref_rows(ref))
         assert int((o["events"][:, 1] == 3).sum()) == bad

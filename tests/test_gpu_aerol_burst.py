@@ -36,12 +36,13 @@ def feed(bank, streams, chunk, rng=None):
         pos += cnt
 
 
-@pytest.mark.parametrize("name", ["a", "b"])
+@pytest.mark.parametrize("name", ["10500_a", "10500_b", "1200_a", "600_a"])
 def test_against_reference_golden(B, oracle_mod, name):
-    g = load_golden(f"aerol_burst_10500_{name}")
-    bank = B.AeroLBank(1, 10500, max_softbits_per_write=4000, su_capacity=600, burst=True)
+    g = load_golden(f"aerol_burst_{name}")
+    fb = int(name.split("_")[0])
+    bank = B.AeroLBank(1, fb, max_softbits_per_write=4000, su_capacity=600, burst=True)
     feed(bank, [g["soft"]], 4000)
-    assert np.array_equal(burst_rows(bank.read_packets(0)), g["packets"])
+    assert np.array_equal(burst_rows(bank.read_packets(0), msk=fb != 10500), g["packets"])
     ev = bank.read_events(0)
     assert int((ev[:, 1] == 3).sum()) == int(g["bad"])
     starts = np.array([s for s, _ in oracle_mod.demod_groups(g["soft"])])
@@ -70,6 +71,35 @@ def test_bank_vs_oracle(B, oracle_mod):
     npk = 0
     for c in range(nch):
         o = oracle_mod.run_aerol_burst(10500, streams[c])
+        want = oracle_mod.packets_from_rows(o["packets"])
+        assert bank.read_packets(c) == want, c
+        assert np.array_equal(bank.read_events(c), o["events"]), c
+        npk += len(want)
+    assert npk > 150
+    bank.close()
+
+
+@pytest.mark.parametrize("fb", [1200, 600])
+def test_msk_bank_vs_oracle(B, oracle_mod, fb):
+    """600 / 1200 bps bursts (updateMSK: R test at 5 blocks, count peek at 11, decode at the announced length): 66 channels, ragged
+    writes, inverted streams, lost tails, late unique words, noise-only channels."""
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    nch = 66
+    rng = np.random.default_rng(fb)
+    streams = []
+    for c in range(nch):
+        if c % 11 == 10:
+            streams.append(np.clip(np.round(128 + rng.normal(0, 40, 20000)), 0, 255).astype(np.int16))
+        else:
+            _, x = mk.rt_case_msk(200 + c, float(rng.uniform(8, 40)), invert=bool(c & 1), cut=(c % 3 == 0))
+            streams.append(x)
+    bank = B.AeroLBank(nch, fb, max_softbits_per_write=2500, su_capacity=700, burst=True)
+    feed(bank, streams, 2500, rng)
+    npk = 0
+    for c in range(nch):
+        o = oracle_mod.run_aerol_burst(fb, streams[c])
         want = oracle_mod.packets_from_rows(o["packets"])
         assert bank.read_packets(c) == want, c
         assert np.array_equal(bank.read_events(c), o["events"]), c
