@@ -48,8 +48,8 @@ def parse():
     ap.add_argument("--ebno", type=int, default=1, help="run the EbNo meters (the reference always does)")
     ap.add_argument("--ebno-db", type=float, default=10.0)
     ap.add_argument("--idle-frac", type=float, default=0.0, help="aerol workload: fraction of channels that carry noise only (never lock)")
-    ap.add_argument("--workload", default="oqpsk", choices=["oqpsk", "burst_oqpsk", "aerol", "aerol_burst"],
-                    help="oqpsk = BASELINE configs[2] (continuous, the headline); burst_oqpsk = configs[3] (one burst per second per "
+    ap.add_argument("--workload", default="oqpsk", choices=["oqpsk", "msk", "burst_oqpsk", "aerol", "aerol_burst"],
+                    help="oqpsk = BASELINE configs[2] (continuous, the headline); msk = configs[1] shape (1200 bps MSK) scaled to a bank that fills the chip; burst_oqpsk = configs[3] (one burst per second per "
                          "channel); aerol = the 10.5 kbps P-channel bit pipeline behind the demodulator (SURVEY 8 row f1), one frame per step; "
                          "aerol_burst = the R/T channel packet search behind a burst demodulator (row f2), one burst per channel and step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -308,6 +308,106 @@ def aerol_bench():
         dist.destroy_process_group()
 
 
+def msk_bench():
+    """Row a2: the MSK demodulator (BASELINE configs[1] shape: synthetic 48 kHz 1200 bps MSK, scaled from 256 channels to a bank that
+    fills the chip).  A step = one 4096-sample write for every channel (coarse 2^13 FFT every 2048 samples).  The MSK sample kernel keeps
+    its 2 x 40-tap... matched-filter and delay rings in LDS: 80 KiB per wavefront at 1200 bps, i.e. one wavefront per CU."""
+    import torch
+    import torch.distributed as dist
+
+    from jaero_amd import capi, signalgen
+    from jaero_amd import dist as jd
+    from jaero_amd.demodulator import DemodulatorBank, MskSettings
+
+    capi.lib()
+    rank, world, local = jd.init_from_env()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    nch, chunk, K, W = ARGS.channels, ARGS.chunk, ARGS.steps, ARGS.warmup
+    nsamp, nuniq = (K + W) * chunk, 32
+    uniq = np.stack([signalgen.msk(nsamp, fb=1200.0, fc=1000.0 + 7.0 * u, ebno_db=ARGS.ebno_db, seed=signalgen.SEED_BASE + 900 + u + 100 * rank)[0]
+                     for u in range(nuniq)])  # [nuniq, nsamp]
+    idx = torch.arange(nch, device=dev) % nuniq
+    pcm = torch.from_numpy(np.ascontiguousarray(uniq.T)).to(dev)[:, idx].contiguous()  # frame-major [nsamp, nch], resident before the clock starts
+    soft_cap = int(nsamp * 1200 / 48000) + 64
+    bank = DemodulatorBank(MskSettings(fb=1200.0, lockingbw=1800.0, freq_center=1000.0), nch, device=local, ebno=bool(ARGS.ebno), max_write_samples=chunk,
+                           softbit_capacity=soft_cap)
+    bank.set_flags(afc=False, sql=False, cpu_reduce=False)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        bank.write(pcm[i * chunk:(i + 1) * chunk], layout=capi.PCM_FRAME_MAJOR, stream=stream)
+
+    for i in range(W):
+        step(i)
+    torch.cuda.synchronize()
+    bank.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    samp_ms, samp_n = bank.profile_read(0)
+    coarse_ms, coarse_n = bank.profile_read(1)
+    st = [bank.read_status(c) for c in range(min(8, nch))]
+    if rank == 0:
+        value = float(K) * chunk * nch * world / dt / 1e6
+        dom = "sample_loop" if samp_ms >= coarse_ms else "coarse_freq"
+        # algorithmic bytes per sample (SURVEY 8(d), MSK): PCM 2 + AGC ring r/w 16 + coarse ring write 16 + soft/state ~0.5 (+32 EbNo);
+        # coarse: (ring 128 KiB + y r/w 128 KiB) per 2048 samples = 128 B/sample
+        per_sample = (34.5 + (32.0 if ARGS.ebno else 0.0)) if dom == "sample_loop" else 128.0
+        dom_ms, launches = (samp_ms, samp_n) if dom == "sample_loop" else (coarse_ms, coarse_n)
+        avg_ms = dom_ms / max(launches, 1)
+        units = K * chunk * nch / max(launches, 1)
+        achieved = per_sample * units / (avg_ms * 1e-3) / 1e9
+        line = {
+            "metric": "Msamples/s of real 48 kHz PCM through the 1200 bps MSK demodulator hot path", "value": round(value, 2), "unit": "Msamples/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{nch}-channel-per-GPU synthetic 48 kHz 1200 bps MSK continuous (BASELINE configs[1] shape, scaled from 256 channels), "
+                                   f"{chunk}-sample writes, coarse 2^13 FFT every 2048 samples, AFC off, EbNo meters {'on' if ARGS.ebno else 'off'}, "
+                                   f"Eb/N0 {ARGS.ebno_db} dB, {nuniq} distinct signals replicated over the channels",
+                       "channels_per_gpu": nch, "total_channels": nch * world, "chunk": chunk, "realtime_channel_equivalents": int(value * 1e6 / 48000),
+                       "locked_of_checked": int(sum(int(x.signal) for x in st)), "channels_checked": len(st),
+                       "kernel_ms_total": {"sample_loop": round(samp_ms, 3), "coarse_freq": round(coarse_ms, 3)},
+                       "kernel_launches": {"sample_loop": samp_n, "coarse_freq": coarse_n}},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "alg_bytes_per_sample": per_sample,
+                         "samples_per_launch": units, "avg_launch_ms": round(avg_ms, 4)},
+        }
+        if world == 1 and not ARGS.no_cpu_baseline:
+            from oracle import oracle as O  # cpu_baseline leg only
+            ncores = os.cpu_count() or 1
+            n1 = min(ARGS.cpu_samples, 2_000_000)
+            x, _ = signalgen.msk(n1, fb=1200.0, fc=1000.0, ebno_db=ARGS.ebno_db, seed=signalgen.SEED_BASE + 77)
+            if O.have_ref():
+                with tempfile.TemporaryDirectory() as td:
+                    path = os.path.join(td, "in.s16")
+                    x.tofile(path)
+                    t1 = time.time()
+                    procs = [subprocess.Popen([O.REF_BIN, "time", "msk", path, f"chunk={chunk}", "fb=1200", "lockingbw=1800", "freq_center=1000"], stdout=subprocess.PIPE)
+                             for _ in range(ncores)]
+                    inner = [float(pp.communicate()[0].split()[0]) for pp in procs]
+                    wall = time.time() - t1
+                line["cpu_baseline"] = {"value": round(sum(n1 / t for t in inner) / 1e6, 3), "unit": "Msamples/s", "cores": ncores, "kind": "reference",
+                                        "sample": f"{n1} samples of 48 kHz 1200 bps MSK per core through the unmodified MskDemodulator, {chunk}-sample writes, "
+                                                  f"one process per core ({wall:.1f} s wall)"}
+        print(json.dumps(line), flush=True)
+    bank.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def aerol_burst_bench():
     """Row f2: a step = what a burst demodulator bank emits for one burst per channel (start-of-burst marker, ~80 soft bits, unique word,
     a T packet of 7 signal units = 1472 channel bits, then noise up to 5248 entries = half a second), soft bits resident in HBM.  Metric: soft bits per
@@ -541,7 +641,11 @@ def main():
 
 if __name__ == "__main__":
     ARGS = parse()
-    if ARGS.workload == "aerol":
+    if ARGS.workload == "msk":
+        if ARGS.channels == 65536:
+            ARGS.channels = 16384  # one wavefront per CU (80 KiB of LDS rings each)
+        msk_bench()
+    elif ARGS.workload == "aerol":
         aerol_bench()
     elif ARGS.workload == "aerol_burst":
         if ARGS.channels == 65536:
