@@ -137,7 +137,16 @@ static int aerol_create(int device, int nchannels, int fb, int max_softbits_per_
     c->stage_stride = max_softbits_per_write;
     AA(c->d_soft, (size_t)g.nch * max_softbits_per_write);
     AA(c->d_counts, g.nchp);
-    if (!burst && viterbi_use_lanes(g.nch, g.blocksz, 24)) { AA(c->d_vhist, viterbi_hist_bytes(g.nch) / sizeof(unsigned long long)); g.tiled = 1; }
+    unsigned *d_scrw = nullptr;
+    AA(d_scrw, 5000 / 32 + 2);
+    if (!burst && viterbi_use_lanes(g.nch, g.blocksz, 24))
+    {
+        // large bank: one block per lane in the Viterbi, tiled deinterleaver output, decoded bits and delay line packed 32 per word
+        AA(c->d_vhist, viterbi_hist_bytes(g.nch) / sizeof(unsigned long long));
+        g.tiled = 1;
+        g.dl2_words = (g.dl2_sz + 31) / 32 + 1;
+        AA(c->p.dl2w, (size_t)g.nchp * g.dl2_words);
+    }
 #undef AA
     c->p.scr = d_scr;
     {
@@ -152,6 +161,10 @@ static int aerol_create(int device, int nchannels, int fb, int max_softbits_per_
             state[0] = val0;
         }
         HIPCHK(hipMemcpy(d_scr, scr.data(), 5000, hipMemcpyHostToDevice));
+        std::vector<unsigned> scrw(5000 / 32 + 2, 0u);
+        for (int k = 0; k < 5000; k++) scrw[k >> 5] |= (unsigned)scr[k] << (k & 31);
+        HIPCHK(hipMemcpy(d_scrw, scrw.data(), scrw.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        c->p.scrw = d_scrw;
         // AeroL constructor state (aerol.cpp:904-977): cntr = 1000000000, blockcnt = -1, DataCarrierDetect(false) emitted
         std::vector<int> I((size_t)AI_NFIELDS * g.nchp, 0);
         std::vector<long long> ev((size_t)g.nchp * g.ev_cap * 3, 0);
@@ -242,11 +255,12 @@ extern "C" int jaero_aerol_write(jaero_aerol_ctx *c, const int16_t *soft, const 
         aprof_end(c, st);
         aprof_begin(c, 1, st);
         viterbi_launch(st, (const uint8_t *)c->p.deint, g.blocksz, (const uint8_t *)c->p.overlap, 24, c->p.vbits, g.blocksz / 2, 25, g.blocksz / 2,
-                       g.nch, valid, c->d_vhist, g.tiled);
+                       g.nch, valid, c->d_vhist, g.tiled, g.tiled /* packed bits out */);
         hipLaunchKernelGGL(k_viterbi_overlap_update, dim3(g.nch), dim3(64), 0, st, (const uint8_t *)c->p.deint, g.blocksz, c->p.overlap, g.nch, valid, g.tiled);
         aprof_end(c, st);
         aprof_begin(c, 2, st);
-        hipLaunchKernelGGL(k_aerol_post, grid, block, 0, st, g, c->p);
+        if (g.tiled) hipLaunchKernelGGL(k_aerol_post_packed, grid, block, 0, st, g, c->p);
+        else hipLaunchKernelGGL(k_aerol_post, grid, block, 0, st, g, c->p);
         aprof_end(c, st);
     }
     hipLaunchKernelGGL(k_aerol_end_write, grid, block, 0, st, g, c->p, dcounts);

@@ -1097,7 +1097,7 @@ static inline bool viterbi_use_lanes(int nblocks, int nsoft, int pad)
     return nblocks >= VL_MIN_BLOCKS;
 }
 static void viterbi_launch(hipStream_t st, const uint8_t *d_soft, int nsoft, const uint8_t *d_ov, int pad, uint8_t *d_out, int out_stride,
-                           int out_start, int out_want, int nblocks, const int *valid, unsigned long long *hist, int tiled = 0)
+                           int out_start, int out_want, int nblocks, const int *valid, unsigned long long *hist, int tiled = 0, int packed = 0)
 {
     if (hist && (tiled || viterbi_use_lanes(nblocks, nsoft, pad))) // tiled input exists only in the lane layout
     {
@@ -1106,10 +1106,10 @@ static void viterbi_launch(hipStream_t st, const uint8_t *d_soft, int nsoft, con
         hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
         if (waves <= ncu * 4) // one wavefront per SIMD is enough: use the entry point that cannot be stacked two to a SIMD
             hipLaunchKernelGGL(k_viterbi_lanes, dim3(waves), dim3(64), 0, st, d_soft, nsoft, d_ov, pad, d_out, out_stride, out_start, out_want, nblocks,
-                               valid, hist, tiled);
+                               valid, hist, tiled, packed);
         else
             hipLaunchKernelGGL(k_viterbi_lanes_x2, dim3(waves), dim3(64), 0, st, d_soft, nsoft, d_ov, pad, d_out, out_stride, out_start, out_want, nblocks,
-                               valid, hist, tiled);
+                               valid, hist, tiled, packed);
     }
     else
         hipLaunchKernelGGL(k_viterbi, dim3(nblocks), dim3(64), 0, st, d_soft, nsoft, d_ov, pad, d_out, out_stride, out_start, out_want, nblocks, valid);

@@ -27,7 +27,7 @@ enum
 };
 struct AGeom
 {
-    int nch, nchp, fb, oqpsk, N, blocksz, dl2_sz, NumberOfBits, BitsInHeader, TotalNumberOfBits, su_cap, ev_cap, info_cap, idx_sat, tiled, burst;
+    int nch, nchp, fb, oqpsk, N, blocksz, dl2_sz, NumberOfBits, BitsInHeader, TotalNumberOfBits, su_cap, ev_cap, info_cap, idx_sat, tiled, burst, dl2_words;
 };
 struct APtrs
 {
@@ -41,6 +41,8 @@ struct APtrs
     int32_t *sus;        // [nchp][su_cap][16]
     long long *events;   // [nchp][ev_cap][3]
     const uint8_t *scr;  // [5000] scrambler sequence
+    const unsigned *scrw; // the same, 32 per word (bit k of the sequence = bit k&31 of word k>>5), one spare word
+    unsigned *dl2w;      // [nchp][dl2_words] the delay line as a bit ring (large banks: k_aerol_post_packed)
 };
 #define ALD(f) (p.I[(size_t)(f) * g.nchp + ch])
 
@@ -456,6 +458,43 @@ __device__ __forceinline__ unsigned aerol_crc16(const uint8_t *bytes, int n) // 
     return (~crc) & 0xFFFFu;
 }
 
+// end of a frame: CRC-16 of every 12-byte signal unit, data-carrier-detect bookkeeping, output rows (aerol.cpp:1583-1600)
+__device__ __forceinline__ void aerol_frame_end(const AGeom &g, const APtrs &p, int ch)
+{
+    uint8_t *info = p.info + (size_t)ch * g.info_cap;
+    const int ninfo = ALD(AI_NINFO);
+    int datacd = ALD(AI_DATACD), dcdcount = ALD(AI_DCDCOUNT), su_cnt = ALD(AI_SU_CNT), ev_cnt = ALD(AI_EV_CNT), overflow = ALD(AI_OVERFLOW);
+    const int nframes = ALD(AI_NFRAMES);
+    const int frameinfo = ALD(AI_FRAMEINFO);
+    const long long bitidx = (((long long)(unsigned)ALD(AI_NBITS_LO)) | ((long long)ALD(AI_NBITS_HI) << 32)) + ALD(AI_IN_POS);
+    for (int kk = 0; kk < ninfo / 12; kk++)
+    {
+        const uint8_t *su = info + kk * 12;
+        unsigned crc_calc = aerol_crc16(su, 10);
+        const unsigned crc_rec = ((unsigned)su[11] << 8) | su[10];
+        if ((!crc_rec) && (crc_calc != crc_rec))
+        {
+            int tsum = 0;
+            for (int ii = 0; ii < 10; ii++) tsum += su[ii];
+            if (tsum == 0) crc_calc = 0; // some SUs are just zeros
+        }
+        if (crc_calc == crc_rec) { if (dcdcount < 12) dcdcount += 2; }
+        else { if (dcdcount > 0) dcdcount -= 3; }
+        if (!datacd && dcdcount > 2) { datacd = 1; aerol_event(g, p, ch, ev_cnt, overflow, bitidx, 0, 1); }
+        if (su_cnt < g.su_cap)
+        {
+            int32_t *row = p.sus + ((size_t)ch * g.su_cap + su_cnt) * 16;
+            row[0] = nframes; row[1] = kk;
+            for (int j = 0; j < 12; j++) row[2 + j] = su[j];
+            row[14] = (crc_calc == crc_rec); row[15] = frameinfo;
+            su_cnt++;
+        }
+        else overflow |= 1;
+    }
+    ALD(AI_DATACD) = datacd; ALD(AI_DCDCOUNT) = dcdcount; ALD(AI_SU_CNT) = su_cnt; ALD(AI_EV_CNT) = ev_cnt; ALD(AI_OVERFLOW) = overflow;
+    ALD(AI_NFRAMES) = nframes + 1;
+}
+
 __global__ void k_aerol_post(const AGeom g, const APtrs p)
 {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
@@ -526,39 +565,74 @@ __global__ void k_aerol_post(const AGeom g, const APtrs p)
         else chv >>= 1;
     }
     ALD(AI_DL2_PTR) = dl2_ptr; ALD(AI_SCR_POS) = scr_pos; ALD(AI_NINFO) = ninfo;
-    if ((cntr - g.BitsInHeader) == (g.NumberOfBits - 1))
+    if ((cntr - g.BitsInHeader) == (g.NumberOfBits - 1)) aerol_frame_end(g, p, ch);
+}
+
+// ---- the same pass on packed bits (large banks: k_viterbi_lanes writes one bit per decoded bit) ----
+// bits [q, q+m) of a little-endian bit array, m <= 32, no wrap (one spare word behind the array)
+__device__ __forceinline__ unsigned abits_get(const unsigned *w, int q, int m)
+{
+    const unsigned long long two = (unsigned long long)w[q >> 5] | ((unsigned long long)w[(q >> 5) + 1] << 32);
+    const unsigned v = (unsigned)(two >> (q & 31));
+    return m >= 32 ? v : (v & ((1u << m) - 1u));
+}
+__device__ __forceinline__ void abits_put(unsigned *w, int q, int m, unsigned val)
+{
+    const unsigned long long mask = (m >= 32 ? 0xFFFFFFFFull : ((1ull << m) - 1ull)) << (q & 31);
+    const unsigned long long v = ((unsigned long long)val << (q & 31)) & mask;
+    unsigned long long two = (unsigned long long)w[q >> 5] | ((unsigned long long)w[(q >> 5) + 1] << 32);
+    two = (two & ~mask) | v;
+    w[q >> 5] = (unsigned)two;
+    w[(q >> 5) + 1] = (unsigned)(two >> 32);
+}
+// DelayLine + scrambler + byte packing, 32 decoded bits per step: the bits leaving the line are the line's content from the read
+// position on (a block is shorter than the line), the block's bits go in behind; packed LSB-first bits ARE the information bytes.
+__global__ void k_aerol_post_packed(const AGeom g, const APtrs p)
+{
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= g.nch) return;
+    if (!ALD(AI_HAS_BLOCK)) return;
+    int dl2_ptr = ALD(AI_DL2_PTR), scr_pos = ALD(AI_SCR_POS), ninfo = ALD(AI_NINFO);
+    const int cntr = ALD(AI_CNTR);
+    unsigned *ring = p.dl2w + (size_t)ch * g.dl2_words;
+    uint8_t *info = p.info + (size_t)ch * g.info_cap;
+    const unsigned *vbw = (const unsigned *)(p.vbits + (size_t)ch * (g.blocksz / 2));
+    const int vblocks = ALD(AI_VBLOCKS);
+    const int nb = vblocks ? g.blocksz / 2 : (g.blocksz + 24) / 2 - 25; // see k_aerol_post
+    ALD(AI_VBLOCKS) = vblocks + 1;
+    const int sz = g.dl2_sz;
+    auto ring_get = [&](int q, int m) -> unsigned { // m bits from ring position q, wrapping at sz
+        if (q + m <= sz) return abits_get(ring, q, m);
+        const int m1 = sz - q;
+        return abits_get(ring, q, m1) | (abits_get(ring, 0, m - m1) << m1);
+    };
+    auto ring_put = [&](int q, int m, unsigned v) {
+        if (q + m <= sz) { abits_put(ring, q, m, v); return; }
+        const int m1 = sz - q;
+        abits_put(ring, q, m1, v);
+        abits_put(ring, 0, m - m1, v >> m1);
+    };
+    const int nbytes = nb / 8; // bits beyond the last whole byte are dropped (charptr starts at 0 in every block)
+    for (int h = 0; h < nb; h += 32)
     {
-        int datacd = ALD(AI_DATACD), dcdcount = ALD(AI_DCDCOUNT), su_cnt = ALD(AI_SU_CNT), ev_cnt = ALD(AI_EV_CNT), overflow = ALD(AI_OVERFLOW);
-        const int nframes = ALD(AI_NFRAMES);
-        const int frameinfo = ALD(AI_FRAMEINFO);
-        const long long bitidx = (((long long)(unsigned)ALD(AI_NBITS_LO)) | ((long long)ALD(AI_NBITS_HI) << 32)) + ALD(AI_IN_POS);
-        for (int kk = 0; kk < ninfo / 12; kk++)
-        {
-            const uint8_t *su = info + kk * 12;
-            unsigned crc_calc = aerol_crc16(su, 10);
-            const unsigned crc_rec = ((unsigned)su[11] << 8) | su[10];
-            if ((!crc_rec) && (crc_calc != crc_rec))
-            {
-                int tsum = 0;
-                for (int ii = 0; ii < 10; ii++) tsum += su[ii];
-                if (tsum == 0) crc_calc = 0; // some SUs are just zeros
-            }
-            if (crc_calc == crc_rec) { if (dcdcount < 12) dcdcount += 2; }
-            else { if (dcdcount > 0) dcdcount -= 3; }
-            if (!datacd && dcdcount > 2) { datacd = 1; aerol_event(g, p, ch, ev_cnt, overflow, bitidx, 0, 1); }
-            if (su_cnt < g.su_cap)
-            {
-                int32_t *row = p.sus + ((size_t)ch * g.su_cap + su_cnt) * 16;
-                row[0] = nframes; row[1] = kk;
-                for (int j = 0; j < 12; j++) row[2 + j] = su[j];
-                row[14] = (crc_calc == crc_rec); row[15] = frameinfo;
-                su_cnt++;
-            }
-            else overflow |= 1;
-        }
-        ALD(AI_DATACD) = datacd; ALD(AI_DCDCOUNT) = dcdcount; ALD(AI_SU_CNT) = su_cnt; ALD(AI_EV_CNT) = ev_cnt; ALD(AI_OVERFLOW) = overflow;
-        ALD(AI_NFRAMES) = nframes + 1;
+        const int m = min(32, nb - h);
+        const unsigned in = vbw[h >> 5] & (m >= 32 ? 0xFFFFFFFFu : ((1u << m) - 1u));
+        // update(): write at the pointer, advance, read at the new pointer -- for bit i of this step: write (ptr+i), read (ptr+i+1)
+        int rq = dl2_ptr + 1; if (rq >= sz) rq -= sz;
+        unsigned outw = ring_get(rq, m);
+        ring_put(dl2_ptr, m, in);
+        dl2_ptr += m; if (dl2_ptr >= sz) dl2_ptr -= sz;
+        // descramble (scr_pos + m <= 5000 in every frame the reference can produce; the clamp of the table index is kept for the rest)
+        if (scr_pos + m <= 5000) outw ^= abits_get(p.scrw, scr_pos, m);
+        else
+            for (int i = 0; i < m; i++) outw ^= (unsigned)p.scr[scr_pos + i < 5000 ? scr_pos + i : 4999] << i;
+        scr_pos += m;
+        const int nby = min(4, nbytes - (h >> 3)); // whole bytes of this step
+        for (int b = 0; b < nby; b++)
+            if (ninfo < g.info_cap) info[ninfo++] = (uint8_t)(outw >> (8 * b));
     }
+    ALD(AI_DL2_PTR) = dl2_ptr; ALD(AI_SCR_POS) = scr_pos; ALD(AI_NINFO) = ninfo;
+    if ((cntr - g.BitsInHeader) == (g.NumberOfBits - 1)) aerol_frame_end(g, p, ch);
 }
 
 // after a write: input positions back to 0, absolute bit counter advanced by this write's counts

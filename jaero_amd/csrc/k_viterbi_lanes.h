@@ -193,7 +193,7 @@ static_assert(VL_TB_BATCH % 4 == 0, "the traceback stores four decoded bits at a
 // hist: [gridDim.x][VT_CAP][64] uint64 scratch.  Same stream convention as k_viterbi (overlap ++ soft ++ pad x 128).
 __device__ __forceinline__ void vl_decode(const uint8_t *__restrict__ soft, int nsoft, const uint8_t *__restrict__ overlap, int pad,
                                           uint8_t *__restrict__ out, int out_stride, int out_start, int out_want, int nblocks,
-                                          const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled, uint4 *lds_soft)
+                                          const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled, uint4 *lds_soft, int packed)
 {
     const unsigned lane = threadIdx.x;
     const int b0 = blockIdx.x * 64 + (int)lane;
@@ -276,6 +276,34 @@ __device__ __forceinline__ void vl_decode(const uint8_t *__restrict__ soft, int 
         // history_buffer_traceback.  Slices are fetched VL_TB_BATCH at a time (their addresses do not depend on the path).  Iteration j
         // (newest slice first) yields decoded bit k(j) = K0 - j once j >= min_tb; four iterations make one 4-byte store (one bit per
         // byte, ascending k = descending j); groups that straddle min_tb, len or the output window go byte by byte.
+        // packed output (one bit per decoded bit, 32-bit words, bit k of a row in word k>>5 at position k&31): the decoded index is the
+        // same for all lanes, so word boundaries are wave-uniform.  A traceback hands down bits from high k to low k; the word it starts
+        // in is finished by the NEXT traceback (which continues above it), the word it ends in was started by the previous one.
+        unsigned pk_cur = 0, pk_top = 0, pk_pend = 0;
+        int pk_cur_idx = -1, pk_top_idx = -1, pk_pend_idx = -1;
+        bool pk_is_top = false;
+        unsigned *ow = (unsigned *)o;
+        auto pk_store = [&](int idx, unsigned v) { if (mine) ow[idx] = v; };
+        auto pk_bits = [&](int k, unsigned v) { // k descending within a traceback; v = the bits k, k+1, .. (all in word k>>5)
+            const int widx = k >> 5;
+            if (pk_cur_idx < 0) { pk_cur = 0; pk_cur_idx = widx; pk_is_top = true; }
+            else if (widx != pk_cur_idx)
+            {
+                if (pk_is_top) { pk_top = pk_cur; pk_top_idx = pk_cur_idx; pk_is_top = false; }
+                else pk_store(pk_cur_idx, pk_cur);
+                pk_cur = 0; pk_cur_idx = widx;
+            }
+            pk_cur |= v << (k & 31);
+        };
+        auto pk_end = [&]() { // after the last bit of a traceback
+            if (pk_cur_idx < 0) return;
+            if (pk_pend_idx == pk_cur_idx) pk_cur |= pk_pend;
+            else if (pk_pend_idx >= 0) pk_store(pk_pend_idx, pk_pend);
+            if (pk_is_top) { pk_pend = pk_cur; pk_pend_idx = pk_cur_idx; }
+            else { pk_store(pk_cur_idx, pk_cur); pk_pend = pk_top; pk_pend_idx = pk_top_idx; }
+            pk_cur_idx = -1; pk_is_top = false;
+        };
+
         auto traceback = [&](unsigned bestpath, int min_tb) {
             const int len = h.len, f = len - min_tb;
             const int K0 = h.outpos + f - 1 + min_tb - out_start;
@@ -302,7 +330,21 @@ __device__ __forceinline__ void vl_decode(const uint8_t *__restrict__ soft, int 
                         word = (word << 8) | hb;
                     }
                     const int j = j0 + 4 * g, klow = K0 - (j + 3);
-                    if (j >= min_tb && j + 3 < len && klow >= 0 && klow + 3 < out_want)
+                    if (packed)
+                    {
+                        if (j >= min_tb && j + 3 < len && klow >= 0 && klow + 3 < out_want && (klow >> 5) == ((klow + 3) >> 5))
+                            pk_bits(klow, ((word * 0x00204081u) >> 21) & 15u); // bytes 0..3 of `word` -> bits 0..3
+                        else
+                        {
+#pragma unroll
+                            for (int u = 0; u < 4; u++)
+                            {
+                                const int jj = j + u, k = K0 - jj;
+                                if (jj >= min_tb && jj < len && k >= 0 && k < out_want) pk_bits(k, (word >> (8 * (3 - u))) & 1u);
+                            }
+                        }
+                    }
+                    else if (j >= min_tb && j + 3 < len && klow >= 0 && klow + 3 < out_want)
                     {
                         if (mine) __builtin_memcpy(o + klow, &word, 4);
                     }
@@ -317,6 +359,7 @@ __device__ __forceinline__ void vl_decode(const uint8_t *__restrict__ soft, int 
                     }
                 }
             }
+            if (packed) pk_end();
             h.outpos += f;
             h.len -= f;
             // slices fetched beyond len are never read: retire them here, or the compiler guards the first reuse of their registers --
@@ -429,6 +472,7 @@ __device__ __forceinline__ void vl_decode(const uint8_t *__restrict__ soft, int 
                 if (pass == 0 ? full : last) traceback(pass == 0 ? best : 0u, pass == 0 ? VT_MINTB : 0);
             if (last) break;
         }
+        if (packed && pk_pend_idx >= 0) pk_store(pk_pend_idx, pk_pend);
     }
 }
 
@@ -439,15 +483,15 @@ __device__ __forceinline__ void vl_decode(const uint8_t *__restrict__ soft, int 
 // per SIMD use the (1, 2) entry.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_viterbi_lanes(
     const uint8_t *__restrict__ soft, int nsoft, const uint8_t *__restrict__ overlap, int pad, uint8_t *__restrict__ out, int out_stride, int out_start,
-    int out_want, int nblocks, const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled)
+    int out_want, int nblocks, const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled, int packed)
 {
     __shared__ uint4 lds_soft[8 * 64];
-    vl_decode(soft, nsoft, overlap, pad, out, out_stride, out_start, out_want, nblocks, valid, hist, tiled, lds_soft);
+    vl_decode(soft, nsoft, overlap, pad, out, out_stride, out_start, out_want, nblocks, valid, hist, tiled, lds_soft, packed);
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_viterbi_lanes_x2(
     const uint8_t *__restrict__ soft, int nsoft, const uint8_t *__restrict__ overlap, int pad, uint8_t *__restrict__ out, int out_stride, int out_start,
-    int out_want, int nblocks, const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled)
+    int out_want, int nblocks, const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled, int packed)
 {
     __shared__ uint4 lds_soft[8 * 64];
-    vl_decode(soft, nsoft, overlap, pad, out, out_stride, out_start, out_want, nblocks, valid, hist, tiled, lds_soft);
+    vl_decode(soft, nsoft, overlap, pad, out, out_stride, out_start, out_want, nblocks, valid, hist, tiled, lds_soft, packed);
 }
