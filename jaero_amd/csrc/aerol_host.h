@@ -143,7 +143,11 @@ static int aerol_create(int device, int nchannels, int fb, int max_softbits_per_
     {
         // large bank: one block per lane in the Viterbi, tiled deinterleaver output, decoded bits and delay line packed 32 per word
         AA(c->d_vhist, viterbi_hist_bytes(g.nch) / sizeof(unsigned long long));
-        g.tiled = 1;
+        g.packed = 1;
+        // deinterleaver output: row-major.  The tiled layout ([wavefront][16-byte group][lane][16], k_viterbi_lanes reads 8 x 1 KiB per chunk)
+        // was built when cold rows cost the decoder 0.85 ms; with its chunk prefetch it no longer gains anything and the tiled writes cost
+        // 0.14 ms (3.51 vs 3.36 ms per step), so it is only kept behind JAERO_AEROL_TILED for measurements.
+        g.tiled = getenv("JAERO_AEROL_TILED") ? 1 : 0;
         g.dl2_words = (g.dl2_sz + 31) / 32 + 1;
         AA(c->p.dl2w, (size_t)g.nchp * g.dl2_words);
     }
@@ -255,11 +259,11 @@ extern "C" int jaero_aerol_write(jaero_aerol_ctx *c, const int16_t *soft, const 
         aprof_end(c, st);
         aprof_begin(c, 1, st);
         viterbi_launch(st, (const uint8_t *)c->p.deint, g.blocksz, (const uint8_t *)c->p.overlap, 24, c->p.vbits, g.blocksz / 2, 25, g.blocksz / 2,
-                       g.nch, valid, c->d_vhist, g.tiled, g.tiled /* packed bits out */);
+                       g.nch, valid, c->d_vhist, g.tiled, g.packed /* bits out, 32 per word */, g.packed /* lane layout */);
         hipLaunchKernelGGL(k_viterbi_overlap_update, dim3(g.nch), dim3(64), 0, st, (const uint8_t *)c->p.deint, g.blocksz, c->p.overlap, g.nch, valid, g.tiled);
         aprof_end(c, st);
         aprof_begin(c, 2, st);
-        if (g.tiled) hipLaunchKernelGGL(k_aerol_post_packed, grid, block, 0, st, g, c->p);
+        if (g.packed) hipLaunchKernelGGL(k_aerol_post_packed, grid, block, 0, st, g, c->p);
         else hipLaunchKernelGGL(k_aerol_post, grid, block, 0, st, g, c->p);
         aprof_end(c, st);
     }

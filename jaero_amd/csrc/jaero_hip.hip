@@ -1097,9 +1097,9 @@ static inline bool viterbi_use_lanes(int nblocks, int nsoft, int pad)
     return nblocks >= VL_MIN_BLOCKS;
 }
 static void viterbi_launch(hipStream_t st, const uint8_t *d_soft, int nsoft, const uint8_t *d_ov, int pad, uint8_t *d_out, int out_stride,
-                           int out_start, int out_want, int nblocks, const int *valid, unsigned long long *hist, int tiled = 0, int packed = 0)
+                           int out_start, int out_want, int nblocks, const int *valid, unsigned long long *hist, int tiled = 0, int packed = 0, int force_lanes = 0)
 {
-    if (hist && (tiled || viterbi_use_lanes(nblocks, nsoft, pad))) // tiled input exists only in the lane layout
+    if (hist && (tiled || force_lanes || viterbi_use_lanes(nblocks, nsoft, pad))) // tiled input / packed output exist only in the lane layout
     {
         const int waves = (nblocks + 63) / 64;
         int ncu = 256;

@@ -27,7 +27,7 @@ enum
 };
 struct AGeom
 {
-    int nch, nchp, fb, oqpsk, N, blocksz, dl2_sz, NumberOfBits, BitsInHeader, TotalNumberOfBits, su_cap, ev_cap, info_cap, idx_sat, tiled, burst, dl2_words;
+    int nch, nchp, fb, oqpsk, N, blocksz, dl2_sz, NumberOfBits, BitsInHeader, TotalNumberOfBits, su_cap, ev_cap, info_cap, idx_sat, tiled, burst, dl2_words, packed;
 };
 struct APtrs
 {
