@@ -28,6 +28,19 @@ KERNEL(k_cmp_cnd, "v_cmp_lt_u32 vcc, %0, %4\n v_cndmask_b32 %0, %0, %1, vcc\n v_
 KERNEL(k_sad_u16, "v_sad_u16 %0, %0, %4, %1\n v_sad_u16 %1, %1, %4, %2\n v_sad_u16 %2, %2, %4, %3\n v_sad_u16 %3, %3, %4, %0")
 KERNEL(k_perm, "v_perm_b32 %0, %0, %4, %1\n v_perm_b32 %1, %1, %4, %2\n v_perm_b32 %2, %2, %4, %3\n v_perm_b32 %3, %3, %4, %0")
 
+// fp64: operands are register pairs
+#define KERNEL64(name, INSTR)                                                                     \
+    __global__ __launch_bounds__(64) void name(unsigned *out, int iters)                          \
+    {                                                                                             \
+        double a = threadIdx.x, b = 1.0 + threadIdx.x * 1e-3, c = 0.5, d = 0.25, k = 1.0 + out[0] * 1e-9; \
+        for (int i = 0; i < iters; i++) { REP64(asm volatile(INSTR : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(k));) } \
+        out[blockIdx.x * 64 + threadIdx.x] = (unsigned)(a + b + c + d);                           \
+    }
+KERNEL64(k_fma_f64, "v_fma_f64 %0, %0, %4, %4\n v_fma_f64 %1, %1, %4, %4\n v_fma_f64 %2, %2, %4, %4\n v_fma_f64 %3, %3, %4, %4")
+KERNEL64(k_add_f64, "v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4")
+KERNEL64(k_mul_f64, "v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4")
+KERNEL64(k_dep_f64, "v_fma_f64 %0, %0, %4, %1\n v_add_f64 %0, %0, %2\n v_mul_f64 %0, %0, %4\n v_fma_f64 %0, %0, %4, %3")
+
 template <class K> static void run(const char *name, K kern, unsigned *d, int waves)
 {
     const int iters = 2000;
@@ -65,6 +78,10 @@ int main()
         run("cmp+cndmask", k_cmp_cnd, d, waves);
         run("v_sad_u16", k_sad_u16, d, waves);
         run("v_perm_b32", k_perm, d, waves);
+        run("v_fma_f64", k_fma_f64, d, waves);
+        run("v_add_f64", k_add_f64, d, waves);
+        run("v_mul_f64", k_mul_f64, d, waves);
+        run("dep chain f64", k_dep_f64, d, waves);
     }
     return 0;
 }
