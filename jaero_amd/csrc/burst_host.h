@@ -96,7 +96,7 @@ static void burst_fill_geometry(BGeom &g, const jaero_settings &s, int nch, unsi
     if (g.maxseg > max_write) g.maxseg = (max_write + 15) / 16 * 16;
     g.bt_len = 2 * g.PL + 1;
     g.cv_len = g.D1 + (g.D2 > g.tri_sz ? g.D2 : g.tri_sz) + g.maxseg + 64;
-    g.hist_len = g.hil_lat + g.hil_ntaps + max_write + 64;
+    g.hist_len = (g.hil_lat + g.hil_ntaps + max_write + 64 + 3) & ~3; // whole cells of four samples (k_hilbert)
 }
 
 static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, const hipDeviceProp_t &prop, int softbit_capacity)
@@ -268,7 +268,18 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
         const long long n0 = c->nsamples_total;
         HIPCHK(hipMemsetAsync(p.ev_count, 0, sizeof(int), st));
         int pi = prof_begin(c, 3, st);
-        hipLaunchKernelGGL(k_hilbert, dim3(g.ngroups, (n + 4 * HB_R - 1) / (4 * HB_R)), dim3(256), 0, st, g, p, n, n0);
+        {
+            // every window of this launch starts at the same offset inside a four-sample cell of the history ring
+            const int ph = (int)(((n0 - g.hil_lat + 1) % 4 + 4) % 4);
+            const dim3 hgrid(g.ngroups, (n + 4 * HB_R - 1) / (4 * HB_R));
+            switch (ph)
+            {
+            case 0: hipLaunchKernelGGL(k_hilbert<0>, hgrid, dim3(256), 0, st, g, p, n, n0); break;
+            case 1: hipLaunchKernelGGL(k_hilbert<1>, hgrid, dim3(256), 0, st, g, p, n, n0); break;
+            case 2: hipLaunchKernelGGL(k_hilbert<2>, hgrid, dim3(256), 0, st, g, p, n, n0); break;
+            default: hipLaunchKernelGGL(k_hilbert<3>, hgrid, dim3(256), 0, st, g, p, n, n0); break;
+            }
+        }
         prof_end(c, pi, st);
         pi = prof_begin(c, 4, st);
         hipLaunchKernelGGL(k_burst_front, dim3(g.ngroups), dim3(64), 0, st, g, p, n, n0);

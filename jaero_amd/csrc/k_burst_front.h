@@ -15,16 +15,23 @@
 // So   re y[n] = -x[n-L-1024],   im y[n] = sum_{j<512} h[2j+1] (x[n-L-(2j+1)] - x[n-L-(2047-2j)])   (h[N-k] = -h[k]).
 // One wavefront = 64 channels (lane = channel) x HB_R consecutive outputs; taps are wave-uniform (scalar loads); the two input
 // windows of a block of HB_U tap pairs are loaded once into registers (static indices after unrolling, no shifting).
+// The PCM history ring is kept in cells of four consecutive samples per channel: int16 index ((slot >> 2) * nchp + ch) * 4 + (slot & 3).
+// A lane fetches four samples with one 8-byte load, a wavefront 512 contiguous bytes: with one 2-byte load per sample (the first
+// version) the kernel was bound by the texture-address unit, 60 load instructions per 256 of arithmetic.  All windows of a launch start
+// at the same offset inside a cell (PH = (n0 - latency + 1) & 3: block and tap offsets are multiples of 16), so PH is a template
+// parameter and every sample sits in a compile-time register and half-word.
 #define HB_R 16
 #define HB_U 8
+__device__ __forceinline__ size_t hb_idx(int slot, int nchp, int ch) { return ((size_t)(slot >> 2) * nchp + ch) * 4 + (slot & 3); }
+template <int PH>
 __global__ __launch_bounds__(256) void k_hilbert(const BGeom g, const BPtrs p, int ns, long long n0)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int grp = blockIdx.x, ch = grp * 64 + lane;
     const int i0 = (blockIdx.y * 4 + wv) * HB_R;
     if (i0 >= ns) return;
-    const int H = g.hist_len, nchp = g.nchp;
-    const int16_t *__restrict__ hist = p.pcmhist + ch;
+    const int H = g.hist_len, HC = H >> 2, nchp = g.nchp;
+    const uint2 *__restrict__ cells = (const uint2 *)p.pcmhist + ch;
     const double *__restrict__ taps = p.hil_taps;
     // index of x feeding tap k = 0 of output r = 0, made non-negative by a multiple of the ring length
     const long long nb0 = n0 + i0 - g.hil_lat + 4LL * H;
@@ -32,19 +39,28 @@ __global__ __launch_bounds__(256) void k_hilbert(const BGeom g, const BPtrs p, i
 #pragma unroll
     for (int r = 0; r < HB_R; r++) acc[r] = 0.0;
     constexpr int WN = HB_R + 2 * (HB_U - 1);
+    constexpr int NC = (PH + WN - 1) / 4 + 1; // cells a window touches
+    auto sample = [](const uint2 (&c)[NC], int m) -> double { // window sample m: compile-time cell and half-word
+        const int o = PH + m;
+        const unsigned w = (o & 2) ? c[o >> 2].y : c[o >> 2].x;
+        return (double)((o & 1) ? ((int)w >> 16) : (int)(short)(w & 0xFFFFu));
+    };
     for (int j0 = 0; j0 < 512; j0 += HB_U)
     {
-        double ea[WN], eb[WN];
-        int sa = (int)((nb0 - 2 * j0 - 1 - 2 * (HB_U - 1)) % H);
-        int sb = (int)((nb0 - 2047 + 2 * j0) % H);
+        int ca = (int)(((nb0 - 2 * j0 - 1 - 2 * (HB_U - 1)) % H) >> 2);
+        int cb = (int)(((nb0 - 2047 + 2 * j0) % H) >> 2);
+        uint2 wa[NC], wb[NC];
 #pragma unroll
-        for (int m = 0; m < WN; m++)
+        for (int q = 0; q < NC; q++)
         {
-            ea[m] = (double)hist[(size_t)sa * nchp];
-            eb[m] = (double)hist[(size_t)sb * nchp];
-            sa++; if (sa >= H) sa = 0;
-            sb++; if (sb >= H) sb = 0;
+            wa[q] = cells[(size_t)ca * nchp];
+            wb[q] = cells[(size_t)cb * nchp];
+            ca++; if (ca >= HC) ca = 0;
+            cb++; if (cb >= HC) cb = 0;
         }
+        double ea[WN], eb[WN];
+#pragma unroll
+        for (int m = 0; m < WN; m++) { ea[m] = sample(wa, m); eb[m] = sample(wb, m); }
 #pragma unroll
         for (int u = 0; u < HB_U; u++)
         {
@@ -54,6 +70,7 @@ __global__ __launch_bounds__(256) void k_hilbert(const BGeom g, const BPtrs p, i
         }
     }
     int sr = (int)((nb0 - 1024) % H);
+    const int16_t *__restrict__ hist = p.pcmhist;
     double *__restrict__ ore = p.hre + ((size_t)grp * g.maxseg + i0) * 64 + lane;
     double *__restrict__ oim = p.him + ((size_t)grp * g.maxseg + i0) * 64 + lane;
 #pragma unroll
@@ -62,14 +79,14 @@ __global__ __launch_bounds__(256) void k_hilbert(const BGeom g, const BPtrs p, i
         if (i0 + r < ns)
         {
             // PCM -> double as the reference does (x/32768.0); the taps carry no scaling, so scale the sums here
-            ore[(size_t)r * 64] = -(((double)hist[(size_t)sr * nchp]) / 32768.0);
+            ore[(size_t)r * 64] = -(((double)hist[hb_idx(sr, nchp, ch)]) / 32768.0);
             oim[(size_t)r * 64] = acc[r] / 32768.0;
         }
         sr++; if (sr >= H) sr = 0;
     }
 }
 
-// PCM frames -> history ring rows (frame-major [n][stride] -> ring [slot][nchp])
+// PCM frames -> history ring cells (frame-major [n][stride])
 __global__ void k_hist_push_frames(const int16_t *__restrict__ src, int stride, int nch, int16_t *__restrict__ hist, int nchp, int H,
                                    int slot0, int n)
 {
@@ -77,9 +94,9 @@ __global__ void k_hist_push_frames(const int16_t *__restrict__ src, int stride, 
     const int i = blockIdx.y;
     if (c >= nchp || i >= n) return;
     int slot = slot0 + i; if (slot >= H) slot -= H;
-    hist[(size_t)slot * nchp + c] = (c < nch) ? src[(size_t)i * stride + c] : (int16_t)0;
+    hist[hb_idx(slot, nchp, c)] = (c < nch) ? src[(size_t)i * stride + c] : (int16_t)0;
 }
-// channel-major [nch][n] -> ring rows, through a 64x64 LDS tile
+// channel-major [nch][n] -> ring cells, through a 64x64 LDS tile
 __global__ void k_hist_push_chmajor(const int16_t *__restrict__ src, int nch, int n, int16_t *__restrict__ hist, int nchp, int H, int slot0)
 {
     __shared__ int16_t tile[64][65];
@@ -97,7 +114,7 @@ __global__ void k_hist_push_chmajor(const int16_t *__restrict__ src, int nch, in
         if (i < n && c < nchp)
         {
             int slot = (slot0 + i) % H;
-            hist[(size_t)slot * nchp + c] = tile[tx][r];
+            hist[hb_idx(slot, nchp, c)] = tile[tx][r];
         }
     }
 }
