@@ -68,6 +68,7 @@ extern "C" {
 #define JAERO_EHIP (-4)     /* a HIP runtime call failed (see jaero_last_error)        */
 #define JAERO_EOVERFLOW (-5)/* soft-bit / log capacity exceeded since the last read    */
 #define JAERO_ENOTSUP (-6)  /* kind / rate not implemented                             */
+#define JAERO_W_RATE 1      /* (jaero_ingest_push only) warning: sample rate differs, data queued anyway */
 
 /* jaero_create flags */
 #define JAERO_FLAG_EBNO 1u            /* run the EbNo meters (OQPSKEbNoMeasure/MSKEbNoMeasure, diagnostic only)   */
@@ -203,6 +204,26 @@ int jaero_aerol_read_packets(jaero_aerol_ctx *ctx, int channel, int32_t *rows, i
 /* HIP-event time per kernel class since the last reset: which 0 = k_aerol_bits, 1 = Viterbi, 2 = k_aerol_post */
 int jaero_aerol_profile_enable(jaero_aerol_ctx *ctx, int on);
 int jaero_aerol_profile_read(jaero_aerol_ctx *ctx, int which, double *total_ms, int *launches, int reset);
+
+/* ---- batched ingest: the recAudio(QByteArray, quint32 sampleRate) -> dataReceived slot of every channel
+ * (JAERO/zmq_audioreceiver.cpp:40-79 -> oqpskdemodulator.cpp:686-693, mskdemodulator.cpp:528-537) in front of one bank.
+ * Messages arrive per channel, any size (<= 192000 bytes are taken, as the reference's receive buffer), any order;
+ * jaero_ingest_pump turns what all channels have in common into jaero_write calls of chunk_samples from pinned memory.
+ *   jaero_ingest_push   = dataReceived of one channel.  Returns 0; JAERO_W_RATE (> 0) when sample_rate != Fs for the OQPSK
+ *                         kinds (the reference only logs "Sample rate not supported by demodulator" and demodulates anyway);
+ *                         JAERO_ENOTSUP for the MSK kinds (the reference would re-apply its settings at the new rate; a bank
+ *                         shares Fs); JAERO_EOVERFLOW when the channel's FIFO cannot take the message (nothing queued).
+ *   jaero_ingest_queued = samples queued for `channel`, or (channel = -1) the count every channel has in common
+ *   jaero_ingest_pump   = flush != 0 also writes the common remainder below one chunk; *chunks = jaero_write calls made
+ *   jaero_ingest_stats  = [rate warnings, samples refused, samples per channel written]
+ * The transport (sockets) is the caller's; nothing here blocks except on the staging buffer two chunks back. */
+typedef struct jaero_ingest jaero_ingest;
+int jaero_ingest_create(jaero_ctx *bank, int chunk_samples, int capacity_samples, jaero_ingest **out);
+void jaero_ingest_destroy(jaero_ingest *ing);
+int jaero_ingest_push(jaero_ingest *ing, int channel, const void *pcm_bytes, int nbytes, unsigned sample_rate);
+int jaero_ingest_queued(const jaero_ingest *ing, int channel);
+int jaero_ingest_pump(jaero_ingest *ing, int flush, void *stream, int *chunks);
+int jaero_ingest_stats(const jaero_ingest *ing, long long *three);
 
 /* Host-only debugging aid (no device needed): the sample indices at which jaero_write would run the coarse-frequency
  * estimate for a fresh channel fed `nwrites` writes of write_sizes[i] samples.  Returns the number of triggers

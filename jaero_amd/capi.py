@@ -16,6 +16,7 @@ KIND_MSK, KIND_OQPSK, KIND_BURST_MSK, KIND_BURST_OQPSK = 0, 1, 2, 3
 FLAG_EBNO, FLAG_STATUS_LOG, FLAG_CAPTURE_SYMBOLS, FLAG_TRACE = 1, 2, 4, 8
 EV_SIGNAL, EV_EBNO, EV_FREQ, EV_PEAK, EV_TRIDENT = 0, 1, 2, 3, 4
 PCM_CHANNEL_MAJOR, PCM_FRAME_MAJOR = 0, 1
+W_RATE = 1  # jaero_ingest_push: sample rate differs from the bank (warning, data queued)
 E_OK, E_INVAL, E_NODEV, E_NOMEM, E_HIP, E_OVERFLOW, E_NOTSUP = 0, -1, -2, -3, -4, -5, -6
 
 EXPORTS = [
@@ -27,6 +28,8 @@ EXPORTS = [
     "jaero_debug_schedule", "jaero_read_events",
     "jaero_aerol_create", "jaero_aerol_create_burst", "jaero_aerol_read_packets", "jaero_aerol_destroy", "jaero_aerol_write", "jaero_aerol_read_sus", "jaero_aerol_read_events",
     "jaero_aerol_tick_dcd", "jaero_aerol_profile_enable", "jaero_aerol_profile_read",
+    "jaero_ingest_create", "jaero_ingest_destroy", "jaero_ingest_push", "jaero_ingest_queued", "jaero_ingest_pump",
+    "jaero_ingest_stats",
 ]
 
 
@@ -120,6 +123,13 @@ def lib():
     L.jaero_aerol_tick_dcd.argtypes = [vp, vp]
     L.jaero_aerol_profile_enable.argtypes = [vp, ip]
     L.jaero_aerol_profile_read.argtypes = [vp, ip, C.POINTER(dp), C.POINTER(ip), ip]
+    L.jaero_ingest_create.argtypes = [vp, ip, ip, C.POINTER(vp)]
+    L.jaero_ingest_destroy.argtypes = [vp]
+    L.jaero_ingest_destroy.restype = None
+    L.jaero_ingest_push.argtypes = [vp, ip, vp, ip, C.c_uint]
+    L.jaero_ingest_queued.argtypes = [vp, ip]
+    L.jaero_ingest_pump.argtypes = [vp, ip, vp, C.POINTER(ip)]
+    L.jaero_ingest_stats.argtypes = [vp, vp]
     for name in EXPORTS:
         getattr(L, name)  # raises AttributeError if a declared symbol is not exported
     _lib = L

@@ -1228,3 +1228,4 @@ extern "C" int jaero_viterbi_continuous(int device, const uint8_t *soft, int nst
 }
 
 #include "aerol_host.h"
+#include "ingest_host.h"

@@ -208,6 +208,51 @@ class DemodulatorBank:
         return ms.value, n.value
 
 
+class Ingest:
+    """Batched ingest in front of a DemodulatorBank (jaero_ingest_*): dataReceived(audio, sampleRate) per channel
+    (JAERO/zmq_audioreceiver.cpp:40-79 -> oqpskdemodulator.cpp:686-693), pump() turns what all channels have in common
+    into bank writes of `chunk_samples`."""
+
+    def __init__(self, bank: DemodulatorBank, chunk_samples: int, capacity_samples: int = 0):
+        self.L = bank.L
+        self.bank = bank
+        h = C.c_void_p()
+        capi.check(self.L.jaero_ingest_create(bank.h, chunk_samples, capacity_samples, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.jaero_ingest_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def dataReceived(self, channel: int, audio, sampleRate: int = 48000) -> int:
+        """audio: bytes (little-endian int16 mono).  Returns 0 or capi.W_RATE; raises on overflow / unsupported rate."""
+        buf = bytes(audio) if not isinstance(audio, bytes) else audio
+        rc = self.L.jaero_ingest_push(self.h, channel, buf, len(buf), sampleRate)
+        if rc < 0:
+            capi.check(rc)
+        return rc
+
+    def queued(self, channel: int = -1) -> int:
+        return self.L.jaero_ingest_queued(self.h, channel)
+
+    def pump(self, flush: bool = False, stream: int = 0) -> int:
+        n = C.c_int(0)
+        capi.check(self.L.jaero_ingest_pump(self.h, 1 if flush else 0, C.c_void_p(stream), C.byref(n)))
+        return n.value
+
+    def stats(self):
+        a = np.zeros(3, np.int64)
+        capi.check(self.L.jaero_ingest_stats(self.h, a.ctypes.data_as(C.c_void_p)))
+        return {"rate_warnings": int(a[0]), "refused_samples": int(a[1]), "samples_written": int(a[2])}
+
+
 class _SingleChannelDemodulator:
     """QIODevice-shaped single-channel demodulator (one-channel bank)."""
 

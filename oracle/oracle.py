@@ -226,13 +226,19 @@ class Demod:
         return self.L.jo_demod_pending_soft(self.h)
 
 
-def run_demod(settings: Settings, pcm: np.ndarray, chunk: int = 4096, afc=False, cpu_reduce=False,
+def run_demod(settings: Settings, pcm: np.ndarray, chunk=4096, afc=False, cpu_reduce=False,
               dcd_at: int = -1, capture_symbols=False, center_at: int = -1, center_hz: float = 0.0):
-    """Convenience: feed pcm in `chunk`-sample writes, return dict(soft, status[, symbols])."""
+    """Convenience: feed pcm in `chunk`-sample writes (an int, or the list of successive write sizes),
+    return dict(soft, status[, symbols])."""
     d = Demod(settings, afc=afc, cpu_reduce=cpu_reduce, capture_symbols=capture_symbols)
     n = pcm.shape[0]
     s = 0
+    sizes = None if isinstance(chunk, (int, np.integer)) else list(chunk)
+    k = 0
     while s < n:
+        if sizes is not None:
+            chunk = sizes[k] if k < len(sizes) else n - s
+            k += 1
         if dcd_at >= 0 and s >= dcd_at:
             d.set_dcd(1)
             dcd_at = -1
