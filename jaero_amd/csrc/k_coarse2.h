@@ -725,6 +725,7 @@ __device__ __forceinline__ void wg_fft14_r16(CV<32> &d, double *xch, const doubl
 #pragma clang fp contract(fast)
     constexpr int S2 = 257;
     // ---- pass 1 ----
+    const double2 tw1[2] = {tw[t], tw[512 + t]}; // both requested before the first butterfly
 #pragma unroll
     for (int b = 0; b < 2; b++)
     {
@@ -732,11 +733,12 @@ __device__ __forceinline__ void wg_fft14_r16(CV<32> &d, double *xch, const doubl
 #pragma unroll
         for (int j = 0; j < 16; j++) { in.r[j] = d.r[2 * j + b]; in.i[j] = d.i[2 * j + b]; }
         regfft<16>(in, out);
-        c4_twiddle16(out, tw[b * 512 + t]);
+        c4_twiddle16(out, tw1[b]);
 #pragma unroll
         for (int j = 0; j < 16; j++) { d.r[2 * j + b] = out.r[j]; d.i[2 * j + b] = out.i[j]; }
         __builtin_amdgcn_sched_barrier(0);
     }
+    const double2 step2 = tw[16 * (t & 63)]; // pass 2's twiddle base: in flight during exchange 1
     // ---- exchange 1: L[(k1*16 + n2)*64 + r2] ----
     {
         const int rbase = (t >> 6) * 2048 + (t & 63); // reader: ((2*k1hi + c)*16 + n2)*64 + r2
@@ -755,7 +757,7 @@ __device__ __forceinline__ void wg_fft14_r16(CV<32> &d, double *xch, const doubl
     }
     // ---- pass 2 ----
     {
-        const double2 step = tw[16 * (t & 63)];
+        const double2 step = step2;
 #pragma unroll
         for (int c = 0; c < 2; c++)
         {
@@ -788,7 +790,9 @@ __device__ __forceinline__ void wg_fft14_r16(CV<32> &d, double *xch, const doubl
     }
     // ---- pass 3: twiddle W_64^(k3*n4), n4 = 2*b1 + b0, b0 = t >> 8 ----
     {
-        const bool b0 = (t >> 8) != 0;
+        // wave-uniform (waves 0-3 / 4-7): as a scalar the twiddles below are selects between literals; as a per-lane
+        // value they were 64 dependent table loads per transform, each waited for on the spot
+        const bool b0 = __builtin_amdgcn_readfirstlane(t >> 8) != 0;
 #pragma unroll
         for (int b1 = 0; b1 < 2; b1++)
         {
@@ -800,7 +804,7 @@ __device__ __forceinline__ void wg_fft14_r16(CV<32> &d, double *xch, const doubl
             for (int k3 = 0; k3 < 16; k3++)
             {
                 const int e0 = (k3 * (2 * b1)) & 63, e1 = (k3 * (2 * b1 + 1)) & 63;
-                const double wr = b0 ? JD_W64R[e1] : JD_W64R[e0], wi = b0 ? JD_W64I[e1] : JD_W64I[e0];
+                const double wr = b0 ? jd_w64r(e1) : jd_w64r(e0), wi = b0 ? jd_w64i(e1) : jd_w64i(e0);
                 d.r[2 * k3 + b1] = out.r[k3] * wr - out.i[k3] * wi;
                 d.i[2 * k3 + b1] = out.r[k3] * wi + out.i[k3] * wr;
             }
@@ -911,15 +915,27 @@ __global__ __launch_bounds__(C2_THREADS) void k_coarse4(const JGeom g, const JPt
         c4_fft(d, xch, tw, t);
         __syncthreads(); // the exchange buffer is free: it receives a copy of y for the fold below
         // smooth with fftshift: y[i] = y[i]*0.9 + 0.1*10*log10(fmax(abs(out[i]),1)), out[i] = X[i ^ N/2]
-#pragma unroll
-        for (int s = 0; s < E; s++)
+        // all 32 old y values are requested before the log10s (64 registers, free once only |X|^2 is kept of d): written as one
+        // load-compute-store per element, every element waited out a full HBM round trip (vmcnt counts the stores too)
         {
-            const int k = s * C2_THREADS + t;
-            const int i = k ^ (N / 2);
+            double yv[E];
+#pragma unroll
+            for (int s = 0; s < E; s++) d.r[s] = d.r[s] * d.r[s] + d.i[s] * d.i[s];
+            __builtin_amdgcn_sched_barrier(0); // d.i is dead from here: its registers take the y values
+#pragma unroll
+            for (int s = 0; s < E; s++) yv[s] = (y + ((s * C2_THREADS) ^ (N / 2)))[t]; // (s*512 + t) ^ N/2: uniform base + t
+            __builtin_amdgcn_sched_barrier(0); // or the scheduler sinks every load to its use again
             // 10*log10(max(|X|,1)) == 5*log10(max(|X|^2,1)): no hypot; differs from the reference expression by <= 1 ulp
-            const double yn = y[i] * 0.9 + 5.0 * c2_log10(fmax(d.r[s] * d.r[s] + d.i[s] * d.i[s], 1.0));
-            y[i] = yn;
-            xch[i] = yn;
+#pragma unroll
+            for (int s = 0; s < E; s++) d.r[s] = 5.0 * c2_log10(fmax(d.r[s], 1.0));
+#pragma unroll
+            for (int s = 0; s < E; s++)
+            {
+                const int ib = (s * C2_THREADS) ^ (N / 2);
+                const double yn = yv[s] * 0.9 + d.r[s];
+                (y + ib)[t] = yn;
+                (xch + ib)[t] = yn;
+            }
         }
         __syncthreads();
         {
