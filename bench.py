@@ -311,7 +311,7 @@ def aerol_bench():
 def msk_bench():
     """Row a2: the MSK demodulator (BASELINE configs[1] shape: synthetic 48 kHz 1200 bps MSK, scaled from 256 channels to a bank that
     fills the chip).  A step = one 4096-sample write for every channel (coarse 2^13 FFT every 2048 samples).  The MSK sample kernel keeps
-    its 2 x 40-tap... matched-filter and delay rings in LDS: 80 KiB per wavefront at 1200 bps, i.e. one wavefront per CU."""
+    the newest 40 of its 80 matched-filter inputs in LDS (40 KiB per wavefront) and the older 40 in registers: four wavefronts per CU."""
     import torch
     import torch.distributed as dist
 
@@ -642,8 +642,7 @@ def main():
 if __name__ == "__main__":
     ARGS = parse()
     if ARGS.workload == "msk":
-        if ARGS.channels == 65536:
-            ARGS.channels = 16384  # one wavefront per CU (80 KiB of LDS rings each)
+        pass  # 65536 channels: four wavefronts per CU (40 KiB of LDS each, the older half of the filter history in registers)
         msk_bench()
     elif ARGS.workload == "aerol":
         aerol_bench()

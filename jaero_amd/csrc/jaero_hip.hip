@@ -48,6 +48,8 @@ static int fail(int code, const char *fmt, ...)
     } while (0)
 
 #define OQ_LDSN 40 // matched-filter history slots kept in LDS (rest in VGPRs): 40 KiB per wavefront -> 4 wavefronts per CU
+#define MSK_LDSN_1200 40 // of 80 taps: four wavefronts per CU
+#define MSK_LDSN_600 80  // of 160 taps: two wavefronts per CU
 
 struct ProfSlot { double ms = 0; int launches = 0; };
 
@@ -135,6 +137,7 @@ struct jaero_ctx
     double2 *d_tw = nullptr;
     int *d_emitted = nullptr; // burst banks: per-channel count of soft bits already emitted (jaero_softbits_view)
     bool coarse_v2 = false; int coarse3_grid = 256, coarse_ver = 4;
+    int msk_ldsn = 0; // MSK: matched-filter inputs kept in LDS (the rest of fir_n in registers)
     int *d_chanlist = nullptr;
     int coarse_grid = 0;
     bool coarse_v1 = false;  // JAERO_COARSE_V1=1 selects the four-step LDS/scratch FFT (kept for A/B validation)
@@ -566,13 +569,21 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
     c->m.nch = nchannels; c->m.nchp = nchp; c->m.nfft = g.nfft; c->m.Fs_int = g.Fs_int;
     c->m.flags.assign(nchp, 0); c->m.bbptr.assign(nchp, 0); c->m.cnt.assign(nchp, 0);
     // dynamic LDS for the matched-filter rings
-    const int lds_bytes = 2 * g.fir_n * 64 * (int)sizeof(double);
     if (g.kind == JAERO_KIND_MSK)
     {
-        HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        if (g.fir_n != 80 && g.fir_n != 160) return fail(JAERO_ENOTSUP, "MSK matched filter of %d taps (fb %g) has no kernel", g.fir_n, g.fb);
+#define MSK_ATTR(F, L) \
+    { \
+        const int lds_bytes = 2 * (L) * 64 * (int)sizeof(double); \
+        HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<F, L, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
+        HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<F, L, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
+        HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<F, L, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
+        HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<F, L, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
+    }
+        c->msk_ldsn = g.fir_n == 80 ? MSK_LDSN_1200 : MSK_LDSN_600;
+        if (const char *e = getenv("JAERO_MSK600_LDSN")) if (g.fir_n == 160 && atoi(e) == 160) c->msk_ldsn = 160; // A/B: whole history in LDS, one wavefront per CU
+        if (g.fir_n == 80) MSK_ATTR(80, MSK_LDSN_1200) else if (c->msk_ldsn == 160) MSK_ATTR(160, 160) else MSK_ATTR(160, MSK_LDSN_600)
+#undef MSK_ATTR
     }
     if (g.nfft_log2 == 14)
     {
@@ -751,11 +762,11 @@ extern "C" int jaero_profile_read(jaero_ctx *c, int which, double *total_ms, int
 static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int n, int skipA, int onlyA, hipStream_t st)
 {
     const JGeom &g = c->g;
-    const int lds = 2 * (g.kind == JAERO_KIND_OQPSK ? OQ_LDSN : g.fir_n) * 64 * (int)sizeof(double);
     const bool eb = (c->flags & JAERO_FLAG_EBNO) != 0, cs = (c->flags & JAERO_FLAG_CAPTURE_SYMBOLS) != 0;
     const dim3 grid(g.ngroups), block(64);
     if (g.kind == JAERO_KIND_OQPSK)
     {
+        const int lds = 2 * OQ_LDSN * 64 * (int)sizeof(double);
         const int fs = (int)(c->m.nB_total % OQ_LDSN);
 #define LO(E, C) hipLaunchKernelGGL((k_oqpsk_samples<55, OQ_LDSN, E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs)
         if (eb && cs) LO(true, true); else if (eb) LO(true, false); else if (cs) LO(false, true); else LO(false, false);
@@ -763,9 +774,13 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
     }
     else
     {
-        const int fs = (int)(c->m.nB_total % g.fir_n), ds = (int)(c->m.nB_total % (g.sps + 1)), d8 = (int)(c->m.nB_total % (g.sps2 + 1));
-#define LM(E, C) hipLaunchKernelGGL((k_msk_samples<E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs, ds, d8)
-        if (eb && cs) LM(true, true); else if (eb) LM(true, false); else if (cs) LM(false, true); else LM(false, false);
+        const int ldsn = c->msk_ldsn;
+        const int lds = 2 * ldsn * 64 * (int)sizeof(double);
+        const int fs = (int)(c->m.nB_total % ldsn), ds = (int)(c->m.nB_total % (g.sps + 1)), d8 = (int)(c->m.nB_total % (g.sps2 + 1));
+#define LM(F, L, E, C) hipLaunchKernelGGL((k_msk_samples<F, L, E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs, ds, d8)
+#define LMS(F, L) { if (eb && cs) LM(F, L, true, true); else if (eb) LM(F, L, true, false); else if (cs) LM(F, L, false, true); else LM(F, L, false, false); }
+        if (g.fir_n == 80) LMS(80, MSK_LDSN_1200) else if (ldsn == 160) LMS(160, 160) else LMS(160, MSK_LDSN_600)
+#undef LMS
 #undef LM
     }
 }

@@ -1,22 +1,31 @@
 // k_msk.h -- sample-loop kernel for the continuous 600/1200 bps MSK demodulator.
 //
 // Re-implements MskDemodulator::writeData's per-sample loop (JAERO/mskdemodulator.cpp:319-485) for 64 channels per
-// wavefront, one channel per lane: coarse ring fill, NCO mix, half-sine matched filter (2*SPS taps, ring in LDS),
+// wavefront, one channel per lane: coarse ring fill, NCO mix, half-sine matched filter (2*SPS taps),
 // MSKEbNoMeasure (optional), AGC + clip, SPS-sample delayed arm, |pt_msk| -> resonator -> quadrature delay -> symbol
 // PLL weighted by 1-|tanh(err)|, and at symbol instants the decision-directed carrier loop, residual rotation, MSE,
 // soft differential decode (DiffDecode::UpdateSoft) and soft-bit demap.
+//
+// Layout of the matched-filter history (as k_oqpsk_samples): the newest LDSN inputs in an LDS ring, the older
+// FIRN - LDSN in registers as a shift register.  1200 bps: 80 = 40 + 40 -> 40 KiB of LDS per wavefront, four wavefronts
+// per CU (one per SIMD); 600 bps: 160 = 80 + 80 -> two per CU.  The filter output of a sample does not contain that
+// sample (the reference evaluates, then inserts), so it is evaluated one iteration ahead, and everything a sample reads
+// from HBM (PCM, the rows leaving the AGC / EbNo windows, the two delay lines) is requested one iteration ahead too:
+// written in reference order, every one of those reads was waited for on the spot, ~8 memory round trips per sample.
 #pragma once
 #include "jaero_device.h"
 
-template <bool EBNO, bool CAPSYM>
+template <int FIRN, int LDSN, bool EBNO, bool CAPSYM>
 __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p, const int16_t *__restrict__ pcm, int pcm_stride,
                                                     int n, int skip_a_first, int only_a_last, int fir_slot0, int dly_slot0,
                                                     int d8_slot0)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int FIRN = g.fir_n;
-    double *lre = lds;
-    double *lim = lds + FIRN * 64;
+    double *lre = lds;             // [LDSN][64]
+    double *lim = lds + LDSN * 64; // [LDSN][64]
+    constexpr int TAILN = FIRN - LDSN;
+    constexpr int TAILA = TAILN > 0 ? TAILN : 1;
+    double tre[TAILA], tim[TAILA]; // tre[j] = x_re[n-LDSN-j] once x[n] has been pushed
 
     const int lane = threadIdx.x;
     const int grp = blockIdx.x;
@@ -24,7 +33,7 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
     const int nchp = g.nchp;
     const bool live = ch < g.nch;
     const double2 *__restrict__ cis = p.cis;
-    const double *taps = c_taps_msk[g.fb >= 1200 ? 0 : 1];
+    const double *taps = c_taps_msk[FIRN == 80 ? 0 : 1];
 
     double m2_ptr = LDF(S_M2_PTR), m2_step = LDF(S_M2_STEP), m2_freq = LDF(S_M2_FREQ);
     double mc_ptr = LDF(S_MC_PTR), mc_step = LDF(S_MC_STEP);
@@ -57,27 +66,91 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
 
     {
         const double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
-        for (int k = 0; k < FIRN; k++)
+        for (int k = 0; k < LDSN; k++)
         {
             lre[k * 64 + lane] = fs[(size_t)k * 64];
             lim[k * 64 + lane] = fs[(size_t)(FIRN + k) * 64];
         }
+#pragma unroll
+        for (int j = 0; j < TAILN; j++)
+        {
+            tre[j] = fs[(size_t)(LDSN + j) * 64];
+            tim[j] = fs[(size_t)(FIRN + LDSN + j) * 64];
+        }
     }
-    int fir_slot = fir_slot0, dly_slot = dly_slot0, d8_slot = d8_slot0;
+    int fir_slot = fir_slot0, dly_slot = dly_slot0, d8_slot = d8_slot0; // wave-uniform ring phases
     const double agc_len_d = (double)g.agc_len, eb_len_d = (double)g.ebno_len;
+
+    // filter output for the current sample from the history x[n-FIRN .. n-1]: taps[i] <-> x[n-FIRN+i], oldest first
+    auto fir_eval = [&](double &ore, double &oim) {
+        double are = 0, aim = 0;
+#pragma unroll
+        for (int j = TAILN - 1; j >= 0; j--)
+        {
+            const double tp = taps[TAILN - 1 - j];
+            are = fma(tp, tre[j], are);
+            aim = fma(tp, tim[j], aim);
+        }
+        int slot = fir_slot;
+#pragma unroll 8
+        for (int k = 0; k < LDSN; k++)
+        {
+            const double tp = taps[TAILN + k];
+            are = fma(tp, lre[slot * 64 + lane], are);
+            aim = fma(tp, lim[slot * 64 + lane], aim);
+            slot++;
+            if (slot >= LDSN) slot = 0;
+        }
+        ore = are; oim = aim;
+    };
+    double ycur_re, ycur_im;
+    fir_eval(ycur_re, ycur_im);
+
+    // inputs of sample i+1 are requested at the top of iteration i (see the file header)
+    auto ring_next = [](int pos, int len) { pos++; return pos >= len ? 0 : pos; };
+    short nx_pcm = (live && n > 0) ? pcm[ch] : (short)0;
+    double nx_agc = agc_ring[(size_t)agc_pos * 64];
+    double nx_e = 0, nx_e2 = 0;
+    if (EBNO) { nx_e = ebe_ring[(size_t)eb_pos * 64]; nx_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
+    double2 nx_cc = cis[jd_cisidx(mc_ptr)];
+    double2 nx_ptd = dly_ring[(size_t)ring_next(dly_slot, dly_len) * 64]; // slot read after this sample's write to dly_slot
+    double nx_d8 = d8_ring[(size_t)ring_next(d8_slot, d8_len) * 64];
 
     for (int i = 0; i < n; i++)
     {
-        const short s = live ? pcm[(size_t)i * pcm_stride + ch] : (short)0;
+        const short s = nx_pcm;
         const double dval = ((double)s) / 32768.0;
+        const double agc_old = nx_agc, e_old = nx_e, e2_old = nx_e2, d8out = nx_d8;
+        const double2 ptd = nx_ptd;
+        // this iteration's table look-ups and next iteration's streams, all independent of the chain below
+        const double2 c2 = cis[jd_cisidx(m2_ptr)];
+        const double2 c_st = cis[jd_cisidx(st_ptr)];
+        if (i + 1 < n)
+        {
+            nx_pcm = live ? pcm[(size_t)(i + 1) * pcm_stride + ch] : (short)0;
+            nx_agc = agc_ring[(size_t)ring_next(agc_pos, g.agc_len) * 64];
+            if (EBNO)
+            {
+                const int ep = ring_next(eb_pos, g.ebno_len);
+                nx_e = ebe_ring[(size_t)ep * 64];
+                nx_e2 = ebe2_ring[(size_t)ep * 64];
+            }
+            nx_ptd = dly_ring[(size_t)ring_next(ring_next(dly_slot, dly_len), dly_len) * 64]; // dly_len, d8_len >= 3
+            nx_d8 = d8_ring[(size_t)ring_next(ring_next(d8_slot, d8_len), d8_len) * 64];
+        }
 
         // coarse-frequency ring fill (mskdemodulator.cpp:350-355)
+        const double2 cc = nx_cc; // table entry of mixer_center for this sample, requested one iteration ago
+        {
+            double mcn = mc_ptr, mcs = mc_step;
+            jd_wt_next(mcn, mcs); // nothing but WTnextFrame moves mixer_center inside a launch
+            nx_cc = cis[jd_cisidx(mcn)];
+        }
         if (!(i == 0 && skip_a_first))
         {
             const bool fill = (coarse_cnt >= g.Fs_int) || !(flags & JF_CPUREDUCE);
             if (fill)
             {
-                const double2 cc = cis[jd_cisidx(mc_ptr)];
                 bbring[bb_ptr] = make_double2(cc.x * dval, cc.y * dval);
                 bb_ptr = (bb_ptr + 1) & nfft_mask;
             }
@@ -85,25 +158,8 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
         if (i == n - 1 && only_a_last) break;
         coarse_cnt++; // :368
 
-        // mix + matched filter (:369-370)
-        const double2 c2 = cis[jd_cisidx(m2_ptr)];
-        const double cre = c2.x * dval, cim = c2.y * dval;
-        double sre = 0, sim = 0;
-        {
-            int slot = fir_slot;
-            for (int t = 0; t < FIRN; t++)
-            {
-                const double tp = taps[t];
-                sre = fma(tp, lre[slot * 64 + lane], sre);
-                sim = fma(tp, lim[slot * 64 + lane], sim);
-                slot++;
-                if (slot >= FIRN) slot = 0;
-            }
-            lre[fir_slot * 64 + lane] = cre;
-            lim[fir_slot * 64 + lane] = cim;
-            fir_slot++;
-            if (fir_slot >= FIRN) fir_slot = 0;
-        }
+        // mix + matched filter (:369-370): this sample's output was evaluated one iteration ago; x[n] is pushed at the end
+        double sre = ycur_re, sim = ycur_im;
         const double dabval = sqrt(sre * sre + sim * sim);
 
         // MSKEbNoMeasure::Update (DSP.cpp:493-505)
@@ -112,8 +168,8 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
             const double sq = dabval * dabval;
             double *e2p = ebe2_ring + (size_t)eb_pos * 64;
             double *ep = ebe_ring + (size_t)eb_pos * 64;
-            eb_e2sum = eb_e2sum - *e2p; eb_e2sum = eb_e2sum + fabs(sq); *e2p = fabs(sq);
-            eb_esum = eb_esum - *ep; eb_esum = eb_esum + fabs(dabval); *ep = fabs(dabval);
+            eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq); *e2p = fabs(sq);
+            eb_esum = eb_esum - e_old; eb_esum = eb_esum + fabs(dabval); *ep = fabs(dabval);
             eb_pos++; if (eb_pos >= g.ebno_len) eb_pos = 0;
             if (i >= n - JD_EBNO_TAIL) // wave-uniform; see JD_EBNO_TAIL
             {
@@ -130,7 +186,7 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
         // AGC + clip (:378-382)
         {
             double *ap = agc_ring + (size_t)agc_pos * 64;
-            agc_sum = agc_sum - *ap;
+            agc_sum = agc_sum - agc_old;
             agc_sum = agc_sum + fabs(dabval);
             *ap = fabs(dabval);
             agc_pos++; if (agc_pos >= g.agc_len) agc_pos = 0;
@@ -142,11 +198,9 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
         if (abval > 2.84) { const double k = (2.84 / abval); sre = k * sre; sim = k * sim; }
 
         // pt_d = delayedsmpl.update_dont_touch(sig2) (:384): SPS-sample delay on a ring of SPS+1
-        double2 ptd;
         {
             dly_ring[(size_t)dly_slot * 64] = make_double2(sre, sim);
-            dly_slot++; if (dly_slot >= dly_len) dly_slot = 0;
-            ptd = dly_ring[(size_t)dly_slot * 64];
+            dly_slot++; if (dly_slot >= dly_len) dly_slot = 0; // ptd = the entry at the new dly_slot, requested one iteration ago
         }
         double q_re = sre, q_im = ptd.y; // pt_msk
 
@@ -160,15 +214,13 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
             res_x2 = res_x1; res_x1 = x0; res_y2 = res_y1; res_y1 = y;
             st_eta = y;
         }
-        double d8out;
         {
-            // Delay<double>(SPS/2): integer delay, weighting 0 -> returns x[n-SPS/2]
+            // Delay<double>(SPS/2): integer delay, weighting 0 -> returns x[n-SPS/2] (d8out, requested one iteration ago)
             d8_ring[(size_t)d8_slot * 64] = st_eta;
             d8_slot++; if (d8_slot >= d8_len) d8_slot = 0;
-            d8out = d8_ring[(size_t)d8_slot * 64];
         }
         {
-            const double2 so = cis[jd_cisidx(st_ptr)];
+            const double2 so = c_st;
             const double m_re = st_eta, m_im = -d8out;
             const double o_re = so.x * m_re - so.y * m_im;
             const double o_im = so.x * m_im + so.y * m_re;
@@ -261,6 +313,23 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
             else overflow |= 1;
         }
 
+        // push x[n] (mixed with the carrier phase this sample started with) and evaluate the filter for n+1
+        {
+            const double cre = c2.x * dval, cim = c2.y * dval;
+#pragma unroll
+            for (int j = TAILN - 1; j > 0; j--) { tre[j] = tre[j - 1]; tim[j] = tim[j - 1]; }
+            if (TAILN > 0)
+            {
+                tre[0] = lre[fir_slot * 64 + lane];
+                tim[0] = lim[fir_slot * 64 + lane];
+            }
+            lre[fir_slot * 64 + lane] = cre;
+            lim[fir_slot * 64 + lane] = cim;
+            fir_slot++;
+            if (fir_slot >= LDSN) fir_slot = 0;
+            fir_eval(ycur_re, ycur_im);
+        }
+
         jd_wt_next(m2_ptr, m2_step);
         jd_wt_next(mc_ptr, mc_step);
         if (st_step < 0) st_step = 0;
@@ -282,10 +351,16 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
     LDI(I_SOFT_CNT) = soft_cnt; LDI(I_SYM_CNT) = sym_cnt; LDI(I_OVERFLOW) = overflow;
     {
         double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
-        for (int k = 0; k < FIRN; k++)
+        for (int k = 0; k < LDSN; k++)
         {
             fs[(size_t)k * 64] = lre[k * 64 + lane];
             fs[(size_t)(FIRN + k) * 64] = lim[k * 64 + lane];
+        }
+#pragma unroll
+        for (int j = 0; j < TAILN; j++)
+        {
+            fs[(size_t)(LDSN + j) * 64] = tre[j];
+            fs[(size_t)(FIRN + LDSN + j) * 64] = tim[j];
         }
     }
 }
