@@ -34,7 +34,7 @@ __device__ __forceinline__ void cmul_w64(double &re, double &im, int idx)
     if (idx == 16) { const double t = re; re = im; im = -t; return; }   // * (-i)
     if (idx == 32) { re = -re; im = -im; return; }
     if (idx == 48) { const double t = re; re = -im; im = t; return; }   // * (+i)
-    const double wr = JD_W64R[idx], wi = JD_W64I[idx];
+    const double wr = jd_w64r(idx), wi = jd_w64i(idx); // literals (fft_consts.h), not table loads
     const double nr = re * wr - im * wi;
     const double ni = re * wi + im * wr;
     re = nr; im = ni;
@@ -140,6 +140,10 @@ __device__ __forceinline__ void wg_fft(CV<(1 << LOG2N) / C2_THREADS> &d, double 
     constexpr int G3 = E / 16;                 // 16-point FFTs per thread in pass 3
     constexpr int S1 = 528, S2 = E + 1;
     const int n3 = t & 15, n2 = t >> 4;        // pass-1 identity of this thread: (n2, n3) = n mod 512
+    // the three table values of this transform, requested before the first butterfly (each used to be loaded, and waited
+    // for, where it is consumed)
+    const double2 tw_p1 = tw[((16 * n2) & (N - 1)) * TWS];
+    const double2 tw_p2b = tw[((n3 * (t >> 4)) & (N - 1)) * TWS], tw_p2s = tw[((n3 * E) & (N - 1)) * TWS];
 
     // ---- pass 1: E-point FFT over n1, twiddle W_N^(16*n2*k1) ----
     {
@@ -147,7 +151,7 @@ __device__ __forceinline__ void wg_fft(CV<(1 << LOG2N) / C2_THREADS> &d, double 
         regfft<E>(d, a);
         __builtin_amdgcn_sched_barrier(0);
         double2 B[4], A[8];
-        twiddle_powers<E>(make_double2(1.0, 0.0), tw[((16 * n2) & (N - 1)) * TWS], B, A);
+        twiddle_powers<E>(make_double2(1.0, 0.0), tw_p1, B, A);
 #pragma unroll
         for (int k1 = 0; k1 < E; k1++)
         {
@@ -189,7 +193,7 @@ __device__ __forceinline__ void wg_fft(CV<(1 << LOG2N) / C2_THREADS> &d, double 
         regfft<32>(b, c);
         __builtin_amdgcn_sched_barrier(0);
         double2 B[4], A[8];
-        twiddle_powers<E>(tw[((n3 * k1u) & (N - 1)) * TWS], tw[((n3 * E) & (N - 1)) * TWS], B, A);
+        twiddle_powers<E>(tw_p2b, tw_p2s, B, A);
 #pragma unroll
         for (int k2 = 0; k2 < 32; k2++)
         {
@@ -276,12 +280,14 @@ __global__ __launch_bounds__(C2_THREADS) void k_coarse2(const JGeom g, const JPt
     __shared__ double red_val[C2_THREADS];
     __shared__ int red_idx[C2_THREADS];
     __shared__ int sh_bigchange;
-    const int t = threadIdx.x;
+    const int t0 = threadIdx.x;
     const int nchp = g.nchp;
 
     CV<E> d;
     for (int li = blockIdx.x; li < nlist; li += gridDim.x)
     {
+        int t = t0; // opaque once per estimate: what is derived from it is recomputed (1-2 instructions), not hoisted and spilled
+        asm volatile("" : "+v"(t));
         const int ch = chan_list ? chan_list[li] : li;
         const double2 *__restrict__ ring = p.bbring + (size_t)ch * N;
         const int bb_ptr = p.I[(size_t)I_BB_PTR * nchp + ch];
@@ -323,14 +329,29 @@ __global__ __launch_bounds__(C2_THREADS) void k_coarse2(const JGeom g, const JPt
             d.i[s] = re * im + im * re;
         }
         wg_fft<LOG2N>(d, xch, tw, t);
+        __syncthreads(); // the exchange buffer is free: it receives a copy of y for the fold below
         // smooth with fftshift: y[i] = y[i]*0.9 + 0.1*10*log10(fmax(abs(out[i]),1)), out[i] = X[i ^ N/2]
-#pragma unroll
-        for (int s = 0; s < E; s++)
+        // all old y values are requested before the log10s (their registers: d.i, dead once only |X|^2 is kept): written as
+        // one load-compute-store per element, every element waited out a full HBM round trip (vmcnt counts the stores too)
         {
-            const int k = s * C2_THREADS + t;
-            const int i = k ^ (N / 2);
+            double yv[E];
+#pragma unroll
+            for (int s = 0; s < E; s++) d.r[s] = d.r[s] * d.r[s] + d.i[s] * d.i[s];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < E; s++) yv[s] = (y + ((s * C2_THREADS) ^ (N / 2)))[t]; // (s*512 + t) ^ N/2: uniform base + t
+            __builtin_amdgcn_sched_barrier(0); // or the scheduler sinks every load to its use again
             // 10*log10(max(|X|,1)) == 5*log10(max(|X|^2,1)): no hypot; differs from the reference expression by <= 1 ulp
-            y[i] = y[i] * 0.9 + 5.0 * c2_log10(fmax(d.r[s] * d.r[s] + d.i[s] * d.i[s], 1.0));
+#pragma unroll
+            for (int s = 0; s < E; s++) d.r[s] = 5.0 * c2_log10(fmax(d.r[s], 1.0));
+#pragma unroll
+            for (int s = 0; s < E; s++)
+            {
+                const int ib = (s * C2_THREADS) ^ (N / 2);
+                const double yn = yv[s] * 0.9 + d.r[s];
+                (y + ib)[t] = yn;
+                (xch + ib)[t] = yn;
+            }
         }
         __syncthreads();
         {
@@ -361,7 +382,7 @@ __global__ __launch_bounds__(C2_THREADS) void k_coarse2(const JGeom g, const JPt
             for (int j = -1; j <= 1; j++)
             {
                 if (((i - expectedpeakbin - j) < 0) || ((i + expectedpeakbin + j) >= N)) continue;
-                val += (y[i - expectedpeakbin - j] + y[i + expectedpeakbin + j]);
+                val += (xch[i - expectedpeakbin - j] + xch[i + expectedpeakbin + j]);
             }
             if (val > best) { best = val; besti = i; }
         }
@@ -413,7 +434,7 @@ struct C2Half
 };
 __device__ __forceinline__ double2 c2_w32(int s) // W_32^s, s < 16
 {
-    return make_double2(JD_W64R[2 * s], JD_W64I[2 * s]);
+    return make_double2(jd_w64r(2 * s), jd_w64i(2 * s));
 }
 // natural (a = low half, b = high half) -> DIF inputs (a = sum, b = twiddled difference)
 __device__ __forceinline__ void c2_dif_split(C2Half &h, const double2 base)
