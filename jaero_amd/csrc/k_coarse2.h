@@ -875,7 +875,8 @@ __device__ __forceinline__ void c4_fft(CV<32> &d, double *xch, const double2 *__
 
 // k_coarse2<14> with the radix-16 transform above, the per-estimate opaque thread index and the fold from LDS of k_coarse3.
 // Measured (MI355X, 65536 estimates per launch): 20.2 ms (k_coarse3 24.7, k_coarse2<14> 28.5); 64 bytes of scratch per thread
-// instead of ~500, i.e. the ~48 GB of spill traffic per launch are gone.
+// instead of ~500, i.e. the ~48 GB of spill traffic per launch are gone.  Then 14.9 ms with no scratch at all, once no load is
+// waited for where it is issued (pass-3 twiddles as literals, table values and y[] requested ahead).
 __global__ __launch_bounds__(C2_THREADS) void k_coarse4(const JGeom g, const JPtrs p, const int *__restrict__ chan_list,
                                                            int nlist, const double2 *__restrict__ tw)
 {
