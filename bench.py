@@ -362,13 +362,24 @@ def msk_bench():
     if rank == 0:
         value = float(K) * chunk * nch * world / dt / 1e6
         dom = "sample_loop" if samp_ms >= coarse_ms else "coarse_freq"
-        # algorithmic bytes per sample (MSK): PCM 2 + AGC ring r/w 16 + coarse ring write 16 + soft/state ~0.5 (+32 EbNo);
+        # algorithmic bytes per sample (MSK): PCM 2 + AGC ring r/w 16 + coarse ring write 16 + the two delay lines
+        # (SPS-sample complex delay 16 + 16, SPS/2-sample real delay 8 + 8) 48 + soft/state ~0.5 (+32 EbNo);
         # coarse: (ring 128 KiB + y r/w 128 KiB) per 2048 samples = 128 B/sample
-        per_sample = (34.5 + (32.0 if ARGS.ebno else 0.0)) if dom == "sample_loop" else 128.0
+        per_sample = (82.5 + (32.0 if ARGS.ebno else 0.0)) if dom == "sample_loop" else 128.0
         dom_ms, launches = (samp_ms, samp_n) if dom == "sample_loop" else (coarse_ms, coarse_n)
         avg_ms = dom_ms / max(launches, 1)
         units = K * chunk * nch / max(launches, 1)
         achieved = per_sample * units / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary_msk.json")  # PMC pass of this workload (scripts/gpu_round.sh <tag> --workload msk)
+        if os.path.exists(pmc):
+            try:
+                pj = json.load(open(pmc))
+                traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic = traffic * nch / float(pj.get("channels_per_gpu", nch))
+            except Exception:
+                traffic = None
         line = {
             "metric": "Msamples/s of real 48 kHz PCM through the 1200 bps MSK demodulator hot path", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
@@ -381,7 +392,7 @@ def msk_bench():
                        "kernel_ms_total": {"sample_loop": round(samp_ms, 3), "coarse_freq": round(coarse_ms, 3)},
                        "kernel_launches": {"sample_loop": samp_n, "coarse_freq": coarse_n}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "alg_bytes_per_sample": per_sample,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "alg_bytes_per_sample": per_sample,
                          "samples_per_launch": units, "avg_launch_ms": round(avg_ms, 4)},
         }
         if world == 1 and not ARGS.no_cpu_baseline:
