@@ -173,3 +173,49 @@ __device__ __forceinline__ int jd_softbit(double v)
 // functions of (kind, fb, Fs) only, so banks of one process never disagree about them.
 __constant__ double c_taps_oqpsk[64];     // RRC alpha=1, 55 taps @ 48 kHz / 5250 sym/s (continuous and burst OQPSK)
 __constant__ double c_taps_msk[2][160];   // half-sine, [0] = 1200 bps (80 taps), [1] = 600 bps (160 taps)
+
+// Matched-filter evaluation for one sample of 64 channels (one per lane): sum over i of taps[i] * x[n-FIRN+i], oldest first,
+// re and im chains, one fma per tap and chain (the order and the fusing of DSP.cpp's FIR::FIRUpdateAndProcess).
+// History: the oldest TAILN = FIRN-LDSN inputs in registers (tre[j] = x[n-LDSN-1-j]), the newest LDSN in an LDS ring
+// ([slot][lane], oldest at fir_slot).  The taps are read from LDS too (ltap, a wave-uniform address: a broadcast), NOT from
+// the constant segment: LDS operations return in order, so the compiler can wait for exactly the read it needs (lgkmcnt(N))
+// while D steps are in flight; with one scalar load pending it has to drain everything (lgkmcnt(0)).  Written as a plain
+// loop, every tap was: ds_read, s_waitcnt lgkmcnt(0), 2 x v_fmac -- one LDS round trip per tap, 40 per sample, and with a
+// single wavefront per SIMD nothing else to run meanwhile (SQ_WAIT_ANY was 45 % of the wave's cycles).
+template <int FIRN, int LDSN, int D, int TAILA>
+__device__ __forceinline__ void jd_fir_eval(const double *lre, const double *lim, const double *ltap, const double (&tre)[TAILA],
+                                            const double (&tim)[TAILA], int fir_slot, int lane, double &ore, double &oim)
+{
+    constexpr int TAILN = FIRN - LDSN;
+    double pr[D], pi[D], pt[D];
+    int slot = fir_slot;
+    auto fetch = [&](int s, int q) {
+        pt[q] = ltap[s];
+        if (s >= TAILN)
+        {
+            pr[q] = lre[slot * 64 + lane];
+            pi[q] = lim[slot * 64 + lane];
+            slot++;
+            if (slot >= LDSN) slot = 0;
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < D; s++) fetch(s, s);
+    __builtin_amdgcn_sched_barrier(0);
+    double are = 0, aim = 0;
+#pragma unroll
+    for (int s = 0; s < FIRN; s++)
+    {
+        const int q = s % D;
+        const double xr = (s < TAILN) ? tre[(TAILN - 1 - s) < 0 ? 0 : (TAILN - 1 - s)] : pr[q];
+        const double xi = (s < TAILN) ? tim[(TAILN - 1 - s) < 0 ? 0 : (TAILN - 1 - s)] : pi[q];
+        are = fma(pt[q], xr, are);
+        aim = fma(pt[q], xi, aim);
+        // keep the software pipeline as written: the empty asm orders the two fmas before the next read (without it instruction
+        // selection places every pure arithmetic instruction after the last read: all 94 reads first, 260 registers of them)
+        asm volatile("" : "+v"(are), "+v"(aim));
+        if (s + D < FIRN) fetch(s + D, q);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    ore = are; oim = aim;
+}

@@ -47,9 +47,9 @@ static int fail(int code, const char *fmt, ...)
         if (_e != hipSuccess) return fail(JAERO_EHIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
-#define OQ_LDSN 40 // matched-filter history slots kept in LDS (rest in VGPRs): 40 KiB per wavefront -> 4 wavefronts per CU
-#define MSK_LDSN_1200 40 // of 80 taps: four wavefronts per CU
-#define MSK_LDSN_600 80  // of 160 taps: two wavefronts per CU
+#define OQ_LDSN 39 // matched-filter history slots kept in LDS (rest in VGPRs) + the taps: 39.5 KiB per wavefront -> 4 wavefronts per CU
+#define MSK_LDSN_1200 39 // of 80 taps: four wavefronts per CU (rings + the wavefront's copy of the taps: 39.6 KiB)
+#define MSK_LDSN_600 78  // of 160 taps: two wavefronts per CU (79.3 KiB)
 
 struct ProfSlot { double ms = 0; int launches = 0; };
 
@@ -574,15 +574,14 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         if (g.fir_n != 80 && g.fir_n != 160) return fail(JAERO_ENOTSUP, "MSK matched filter of %d taps (fb %g) has no kernel", g.fir_n, g.fb);
 #define MSK_ATTR(F, L) \
     { \
-        const int lds_bytes = 2 * (L) * 64 * (int)sizeof(double); \
+        const int lds_bytes = (2 * (L) * 64 + (F)) * (int)sizeof(double); \
         HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<F, L, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
         HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<F, L, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
         HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<F, L, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
         HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<F, L, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
     }
         c->msk_ldsn = g.fir_n == 80 ? MSK_LDSN_1200 : MSK_LDSN_600;
-        if (const char *e = getenv("JAERO_MSK600_LDSN")) if (g.fir_n == 160 && atoi(e) == 160) c->msk_ldsn = 160; // A/B: whole history in LDS, one wavefront per CU
-        if (g.fir_n == 80) MSK_ATTR(80, MSK_LDSN_1200) else if (c->msk_ldsn == 160) MSK_ATTR(160, 160) else MSK_ATTR(160, MSK_LDSN_600)
+        if (g.fir_n == 80) MSK_ATTR(80, MSK_LDSN_1200) else MSK_ATTR(160, MSK_LDSN_600)
 #undef MSK_ATTR
     }
     if (g.nfft_log2 == 14)
@@ -766,7 +765,7 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
     const dim3 grid(g.ngroups), block(64);
     if (g.kind == JAERO_KIND_OQPSK)
     {
-        const int lds = 2 * OQ_LDSN * 64 * (int)sizeof(double);
+        const int lds = (2 * OQ_LDSN * 64 + 64) * (int)sizeof(double); // rings + this wavefront's copy of the 55 taps
         const int fs = (int)(c->m.nB_total % OQ_LDSN);
 #define LO(E, C) hipLaunchKernelGGL((k_oqpsk_samples<55, OQ_LDSN, E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs)
         if (eb && cs) LO(true, true); else if (eb) LO(true, false); else if (cs) LO(false, true); else LO(false, false);
@@ -775,11 +774,11 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
     else
     {
         const int ldsn = c->msk_ldsn;
-        const int lds = 2 * ldsn * 64 * (int)sizeof(double);
+        const int lds = (2 * ldsn * 64 + g.fir_n) * (int)sizeof(double); // rings + this wavefront's copy of the taps
         const int fs = (int)(c->m.nB_total % ldsn), ds = (int)(c->m.nB_total % (g.sps + 1)), d8 = (int)(c->m.nB_total % (g.sps2 + 1));
 #define LM(F, L, E, C) hipLaunchKernelGGL((k_msk_samples<F, L, E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs, ds, d8)
 #define LMS(F, L) { if (eb && cs) LM(F, L, true, true); else if (eb) LM(F, L, true, false); else if (cs) LM(F, L, false, true); else LM(F, L, false, false); }
-        if (g.fir_n == 80) LMS(80, MSK_LDSN_1200) else if (ldsn == 160) LMS(160, 160) else LMS(160, MSK_LDSN_600)
+        if (g.fir_n == 80) LMS(80, MSK_LDSN_1200) else LMS(160, MSK_LDSN_600)
 #undef LMS
 #undef LM
     }

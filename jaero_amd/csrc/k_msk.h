@@ -7,8 +7,8 @@
 // soft differential decode (DiffDecode::UpdateSoft) and soft-bit demap.
 //
 // Layout of the matched-filter history (as k_oqpsk_samples): the newest LDSN inputs in an LDS ring, the older
-// FIRN - LDSN in registers as a shift register.  1200 bps: 80 = 40 + 40 -> 40 KiB of LDS per wavefront, four wavefronts
-// per CU (one per SIMD); 600 bps: 160 = 80 + 80 -> two per CU.  The filter output of a sample does not contain that
+// FIRN - LDSN in registers as a shift register.  1200 bps: 80 = 39 + 41 -> 39.6 KiB of LDS per wavefront with its copy of
+// the taps, four wavefronts per CU (one per SIMD); 600 bps: 160 = 78 + 82 -> two per CU.  The filter output of a sample does not contain that
 // sample (the reference evaluates, then inserts), so it is evaluated one iteration ahead, and everything a sample reads
 // from HBM (PCM, the rows leaving the AGC / EbNo windows, the two delay lines) is requested one iteration ahead too:
 // written in reference order, every one of those reads was waited for on the spot, ~8 memory round trips per sample.
@@ -81,28 +81,10 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
     int fir_slot = fir_slot0, dly_slot = dly_slot0, d8_slot = d8_slot0; // wave-uniform ring phases
     const double agc_len_d = (double)g.agc_len, eb_len_d = (double)g.ebno_len;
 
-    // filter output for the current sample from the history x[n-FIRN .. n-1]: taps[i] <-> x[n-FIRN+i], oldest first
-    auto fir_eval = [&](double &ore, double &oim) {
-        double are = 0, aim = 0;
-#pragma unroll
-        for (int j = TAILN - 1; j >= 0; j--)
-        {
-            const double tp = taps[TAILN - 1 - j];
-            are = fma(tp, tre[j], are);
-            aim = fma(tp, tim[j], aim);
-        }
-        int slot = fir_slot;
-#pragma unroll 8
-        for (int k = 0; k < LDSN; k++)
-        {
-            const double tp = taps[TAILN + k];
-            are = fma(tp, lre[slot * 64 + lane], are);
-            aim = fma(tp, lim[slot * 64 + lane], aim);
-            slot++;
-            if (slot >= LDSN) slot = 0;
-        }
-        ore = are; oim = aim;
-    };
+    // filter output for the current sample from the history x[n-FIRN .. n-1]: taps[i] <-> x[n-FIRN+i], oldest first (jd_fir_eval)
+    double *ltap = lds + 2 * LDSN * 64; // [FIRN] this wavefront's copy of the taps
+    for (int k = lane; k < FIRN; k += 64) ltap[k] = taps[k];
+    auto fir_eval = [&](double &ore, double &oim) { jd_fir_eval<FIRN, LDSN, 8>(lre, lim, ltap, tre, tim, fir_slot, lane, ore, oim); };
     double ycur_re, ycur_im;
     fir_eval(ycur_re, ycur_im);
 

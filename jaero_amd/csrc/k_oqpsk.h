@@ -68,7 +68,6 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
     double2 *__restrict__ dt_ring = p.dt + (size_t)ch * g.dt_len;
     double *__restrict__ pm_ring = p.pm + (size_t)ch * g.pm_len;
     double *__restrict__ msema_ring = p.msema + (size_t)ch * g.msema_len;
-    int16_t *__restrict__ soft = p.soft + (size_t)ch * g.soft_cap;
 
     // ---- matched-filter history -> LDS + registers (each lane owns one LDS column: no barrier needed) ----
     {
@@ -87,28 +86,10 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
     }
     int fir_slot = fir_slot0; // wave-uniform: LDS slot holding the oldest LDS entry, overwritten by the next input
 
-    // filter output for the current sample from the history x[n-FIRN .. n-1]: taps[i] <-> x[n-FIRN+i]
-    auto fir_eval = [&](double &ore, double &oim) {
-        double are = 0, aim = 0;
-#pragma unroll
-        for (int j = TAILN - 1; j >= 0; j--)
-        {
-            const double tp = taps[TAILN - 1 - j];
-            are = fma(tp, tre[j], are);
-            aim = fma(tp, tim[j], aim);
-        }
-        int slot = fir_slot;
-#pragma unroll 8
-        for (int k = 0; k < LDSN; k++)
-        {
-            const double tp = taps[TAILN + k];
-            are = fma(tp, lre[slot * 64 + lane], are);
-            aim = fma(tp, lim[slot * 64 + lane], aim);
-            slot++;
-            if (slot >= LDSN) slot = 0;
-        }
-        ore = are; oim = aim;
-    };
+    // filter output for the current sample from the history x[n-FIRN .. n-1]: taps[i] <-> x[n-FIRN+i] (jd_fir_eval)
+    double *ltap = lds + 2 * LDSN * 64; // [FIRN] this wavefront's copy of the taps
+    if (lane < FIRN) ltap[lane] = taps[lane];
+    auto fir_eval = [&](double &ore, double &oim) { jd_fir_eval<FIRN, LDSN, 8>(lre, lim, ltap, tre, tim, fir_slot, lane, ore, oim); };
     double ycur_re, ycur_im;
     fir_eval(ycur_re, ycur_im);
 
@@ -327,8 +308,13 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
                     const int b1 = jd_softbit(0.75 * q_re * 127.0 + 128.0);
                     if (soft_cnt + 2 <= g.soft_cap)
                     {
-                        soft[soft_cnt] = (int16_t)b0;
-                        soft[soft_cnt + 1] = (int16_t)b1;
+                        // address rebuilt from an opaque lane index here: kept live across the loop it is spilled, and the
+                        // reload sits in this block behind an s_waitcnt vmcnt(0) that drains every prefetch in flight
+                        int lx = lane;
+                        asm volatile("" : "+v"(lx));
+                        int16_t *sp = p.soft + (size_t)(grp * 64 + lx) * g.soft_cap + soft_cnt;
+                        sp[0] = (int16_t)b0;
+                        sp[1] = (int16_t)b1;
                         soft_cnt += 2;
                     }
                     else overflow |= 1;

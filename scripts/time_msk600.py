@@ -1,5 +1,5 @@
-"""A/B timing of the 600 bps MSK sample kernel: JAERO_MSK600_LDSN=160 (whole filter history in LDS, one wavefront per CU)
-against the default 80 + 80 split (two wavefronts per CU).  usage: python scripts/time_msk600.py [channels]"""
+"""Timing of the 600 bps MSK sample kernel (78 + 82 split of the filter history, two wavefronts per CU).
+usage: python scripts/time_msk600.py [channels]"""
 import os
 import sys
 import time
@@ -28,4 +28,4 @@ for _ in range(K):
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 ms, n = bank.profile_read(0)
-print({"ldsn": os.environ.get("JAERO_MSK600_LDSN", "80"), "channels": nch, "Msamples_s": round(K * chunk * nch / dt / 1e6, 1), "sample_loop_ms_per_launch": round(ms / max(n, 1), 3)})
+print({"channels": nch, "Msamples_s": round(K * chunk * nch / dt / 1e6, 1), "sample_loop_ms_per_launch": round(ms / max(n, 1), 3)})

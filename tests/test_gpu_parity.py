@@ -75,10 +75,9 @@ def test_against_reference_golden(B, name):
 
 
 @pytest.mark.parametrize("name,env", [("oqpsk_10k5_default", {"JAERO_COARSE_KERNEL": "2"}), ("oqpsk_10k5_default", {"JAERO_COARSE_KERNEL": "3"}),
-                                      ("oqpsk_10k5_default", {"JAERO_COARSE_V1": "1"}), ("msk_600_chunk777_dcd", {"JAERO_MSK600_LDSN": "160"}),
-                                      ("msk_1200_default", {"JAERO_COARSE_V1": "1"})])
+                                      ("oqpsk_10k5_default", {"JAERO_COARSE_V1": "1"}), ("msk_1200_default", {"JAERO_COARSE_V1": "1"})])
 def test_alternative_kernels_against_reference_golden(B, monkeypatch, name, env):
-    """The kernels kept for A/B measurements (earlier coarse-frequency kernels, the all-LDS 600 bps MSK filter history) produce the
+    """The kernels kept for A/B measurements (the earlier coarse-frequency kernels) produce the
     same stream as the defaults: same golden, selected by the environment variables jaero_create reads."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
