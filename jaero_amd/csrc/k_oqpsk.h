@@ -102,46 +102,40 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
     double nx_agc = agc_ring[(size_t)agc_pos * 64];
     double nx_e = 0, nx_e2 = 0;
     if (EBNO) { nx_e = ebe_ring[(size_t)eb_pos * 64]; nx_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
-    double2 nx_cc = cis[jd_cisidx(mc_ptr)];
+    // entries leaving the symbol-rate windows at this lane's next full symbol (see the symbol block)
+    double sx_marg = marg_ring[marg_pos], sx_pm = pm_ring[pm_pos], sx_ms = msema_ring[msema_pos];
+    double2 sx_dt;
+    {
+        int dn = dt_pos + 1; if (dn >= g.dt_len) dn = 0;
+        sx_dt = dt_ring[dn];
+    }
 
     for (int i = 0; i < n; i++)
     {
         const short s = nx_pcm;
         const double dval = ((double)s) / 32768.0;
         const double agc_old = nx_agc, e_old = nx_e, e2_old = nx_e2;
-        // requests for this iteration's table look-ups and next iteration's streams, all independent of the chain below
+        // requests for this iteration's table look-ups (L2 hits); the next iteration's streams (HBM misses) are requested further
+        // down, after c_st has been consumed: vmcnt retires in order, and the wait the compiler puts in front of c_st's use
+        // also waited for every younger request, i.e. for those misses, ~450 instructions after they were issued
         const double2 c_m2 = cis[jd_cisidx(m2_ptr)];
         const double2 c_st = cis[jd_cisidx(st_ptr)];
-        if (i + 1 < n)
-        {
-            nx_pcm = live ? pcm[(size_t)(i + 1) * pcm_stride + ch] : (short)0;
-            int ap = agc_pos + 1; if (ap >= g.agc_len) ap = 0;
-            nx_agc = agc_ring[(size_t)ap * 64];
-            if (EBNO)
-            {
-                int ep = eb_pos + 1; if (ep >= g.ebno_len) ep = 0;
-                nx_e = ebe_ring[(size_t)ep * 64];
-                nx_e2 = ebe2_ring[(size_t)ep * 64];
-            }
-        }
 
-        // ---- K3: coarse-frequency ring fill (oqpskdemodulator.cpp:410-415) ----
-        const double2 cc = nx_cc; // table entry of mixer_center for this sample, requested one iteration ago
+        // ---- K3: coarse-frequency ring fill (oqpskdemodulator.cpp:410-415): decided here, stored further down (before the push)
+        // so that cc, like c_m2 and c_st, is loaded and consumed within one iteration: a loaded value carried into the next
+        // iteration gets copied between registers at the loop latch, and the s_waitcnt vmcnt(0) in front of that copy drained
+        // every request in flight once per sample ----
+        const double2 cc = cis[jd_cisidx(mc_ptr)];
+        const bool do_fill = !(i == 0 && skip_a_first) && ((coarse_cnt >= g.Fs_int) || !(flags & JF_CPUREDUCE));
+        if (i == n - 1 && only_a_last) // the coarse estimate runs now, then the next launch resumes here
         {
-            double mcn = mc_ptr, mcs = mc_step;
-            jd_wt_next(mcn, mcs); // where mixer_center will be for the next sample (nothing but WTnextFrame moves it in here)
-            nx_cc = cis[jd_cisidx(mcn)];
-        }
-        if (!(i == 0 && skip_a_first))
-        {
-            const bool fill = (coarse_cnt >= g.Fs_int) || !(flags & JF_CPUREDUCE);
-            if (fill)
+            if (do_fill)
             {
                 bbring[bb_ptr] = make_double2(cc.x * dval, cc.y * dval);
                 bb_ptr = (bb_ptr + 1) & nfft_mask;
             }
+            break;
         }
-        if (i == n - 1 && only_a_last) break; // the coarse estimate runs now, then the next launch resumes here
         coarse_cnt++;                          // :431
 
         // ---- K2 mix + K6 matched filter (:453-456, DSP.cpp:292-304) ----
@@ -214,6 +208,20 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
             if (st_freq > (g.stref_freq + 0.1)) jd_wt_setfreq(st_freq, st_step, (g.stref_freq + 0.1), samplerate);
         }
 
+        // ---- next iteration's streams (see the top of the loop); agc_pos / eb_pos already point at the next sample's rows ----
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 < n)
+        {
+            nx_pcm = live ? pcm[(size_t)(i + 1) * pcm_stride + ch] : (short)0;
+            nx_agc = agc_ring[(size_t)agc_pos * 64];
+            if (EBNO)
+            {
+                nx_e = ebe_ring[(size_t)eb_pos * 64];
+                nx_e2 = ebe2_ring[(size_t)eb_pos * 64];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
         // ---- K10..K14 at symbol instants (:487-595) ----
         if (!sig2l_init) { sig2l_re = sre; sig2l_im = sim; sig2l_init = 1; }
         double frac;
@@ -223,17 +231,26 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
             const double pt_re = pt_this * sre + pt_last * sig2l_re;
             const double pt_im = pt_this * sim + pt_last * sig2l_im;
             yui++; yui %= 2;
-            // The four symbol-rate rings are per-channel arrays in HBM: request the entries that leave their windows now, all at
-            // once, so that one miss latency overlaps the tanh / loop-filter arithmetic instead of four serialised ones.
-            double marg_old = 0, pm_old = 0, ms_old = 0;
-            double2 dt_old = make_double2(0.0, 0.0);
+            // The four symbol-rate rings are per-channel arrays in HBM (every access a miss).  The entries that leave their windows
+            // at this symbol were requested at this lane's previous symbol (sx_*): requested here for this symbol, ~230 instructions
+            // did not cover the miss, and with some lane at a symbol instant in nearly
+            // every iteration the whole wavefront waited for it once per sample.
+            const double marg_old = sx_marg, pm_old = sx_pm, ms_old = sx_ms;
+            const double2 dt_old = sx_dt;
             if (yui)
             {
-                marg_old = marg_ring[marg_pos];
-                int dn = dt_pos + 1; if (dn >= g.dt_len) dn = 0;
-                dt_old = dt_ring[dn];
-                pm_old = pm_ring[pm_pos];
-                ms_old = msema_ring[msema_pos];
+                // next symbol's leaving entries: the slots after the ones this symbol rewrites (all four rings are longer than 2:
+                // 800 / 401 / 400 / 400), requested before this block's ~1000 instructions so that they have landed when the
+                // loop latch copies them between registers (the s_waitcnt vmcnt(0) in front of that copy is the one wait left)
+                int q = marg_pos + 1; if (q >= g.marg_len) q = 0;
+                sx_marg = marg_ring[q];
+                q = dt_pos + 1; if (q >= g.dt_len) q = 0;
+                q = q + 1; if (q >= g.dt_len) q = 0;
+                sx_dt = dt_ring[q];
+                q = pm_pos + 1; if (q >= g.pm_len) q = 0;
+                sx_pm = pm_ring[q];
+                q = msema_pos + 1; if (q >= g.msema_len) q = 0;
+                sx_ms = msema_ring[q];
             }
             if (!yui) { ptd_re = pt_re; ptd_im = pt_im; }
             else
@@ -322,6 +339,12 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
             }
         }
         sig2l_re = sre; sig2l_im = sim;
+
+        if (do_fill)
+        {
+            bbring[bb_ptr] = make_double2(cc.x * dval, cc.y * dval);
+            bb_ptr = (bb_ptr + 1) & nfft_mask;
+        }
 
         // ---- push x[n] (mixed with the carrier phase this sample started with) and evaluate the filter for n+1 ----
         {
