@@ -222,7 +222,7 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
     c->o_nrx = p.I + (size_t)BI_NRX * nchp;
     c->m.nch = nch; c->m.nchp = nchp;
     c->m.flags.assign(nchp, 0);
-    const int lds = 2 * (oq ? 40 : g.fir_n) * 64 * (int)sizeof(double); // burst OQPSK keeps 40 of its 55 history slots in LDS
+    const int lds = (oq ? 2 * 39 * 64 + 64 : 2 * g.fir_n * 64) * (int)sizeof(double); // burst OQPSK: 39 of its 55 history slots + the taps in LDS
     if (oq)
     {
         HIPCHK(hipFuncSetAttribute((const void *)k_burst_oqpsk_demod<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -260,7 +260,7 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
         prof_end(c, pi, st);
     }
     const bool cs = (c->flags & JAERO_FLAG_CAPTURE_SYMBOLS) != 0;
-    const int lds = 2 * (g.kind == JAERO_KIND_BURST_OQPSK ? 40 : g.fir_n) * 64 * (int)sizeof(double);
+    const int lds = (g.kind == JAERO_KIND_BURST_OQPSK ? 2 * 39 * 64 + 64 : 2 * g.fir_n * 64) * (int)sizeof(double);
     int first = 1;
     for (int pos = 0; pos < nsamples;)
     {

@@ -34,10 +34,10 @@ template <bool CAPSYM>
 __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const BPtrs p, int n, long long n0, int first_of_write)
 {
     // matched-filter history as in k_oqpsk.h: the LDSN newest entries of each arm in LDS ([slot][lane]), the FIRN-LDSN oldest in a
-    // VGPR shift register -> 40 KiB of LDS per wavefront, four wavefronts per CU
-    constexpr int FIRN = 55, LDSN = 40, TAILN = FIRN - LDSN;
+    // VGPR shift register, plus this wavefront's copy of the taps (jd_fir_eval) -> 39.5 KiB of LDS per wavefront, four per CU
+    constexpr int FIRN = 55, LDSN = 39, TAILN = FIRN - LDSN;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *lre = lds, *lim = lds + LDSN * 64;
+    double *lre = lds, *lim = lds + LDSN * 64, *ltap = lds + 2 * LDSN * 64;
     double tre[TAILN], tim[TAILN];
     const int lane = threadIdx.x, grp = blockIdx.x, ch = grp * 64 + lane, nchp = g.nchp;
     const double2 *__restrict__ cis = p.cis;
@@ -79,6 +79,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
 #pragma unroll
         for (int j = 0; j < TAILN; j++) { tre[j] = fs[(size_t)(LDSN + j) * 64]; tim[j] = fs[(size_t)(FIRN + LDSN + j) * 64]; }
     }
+    if (lane < FIRN) ltap[lane] = taps[lane];
     int fir_slot = (int)(n0 % LDSN), s_agc2 = (int)(n0 % g.agc2_len), s_eb = (int)(n0 % g.eb_len);
     int s_val = (int)((n0 - g.D1 - g.D2 + 8LL * g.cv_len) % g.cv_len);
     const double w4 = g.w4, w4c = 1.0 - g.w4, w8 = g.w8, w8c = 1.0 - g.w8, a1w = g.a1_w, a1wc = 1.0 - g.a1_w;
@@ -132,22 +133,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
         double sre = 0, sim = 0;
         {
             // output from x[n-FIRN .. n-1] (FIR::FIRUpdateAndProcess excludes the sample being pushed): taps[i] <-> x[n-FIRN+i]
-#pragma unroll
-            for (int j = TAILN - 1; j >= 0; j--)
-            {
-                const double tp = taps[TAILN - 1 - j];
-                sre = fma(tp, tre[j], sre);
-                sim = fma(tp, tim[j], sim);
-            }
-            int slot = fir_slot;
-#pragma unroll 8
-            for (int k = 0; k < LDSN; k++)
-            {
-                const double tp = taps[TAILN + k];
-                sre = fma(tp, lre[slot * 64 + lane], sre);
-                sim = fma(tp, lim[slot * 64 + lane], sim);
-                slot++; if (slot >= LDSN) slot = 0;
-            }
+            jd_fir_eval<FIRN, LDSN, 8>(lre, lim, ltap, tre, tim, fir_slot, lane, sre, sim);
             // push x[n]: the oldest LDS entry moves into the register tail
 #pragma unroll
             for (int j = TAILN - 1; j > 0; j--) { tre[j] = tre[j - 1]; tim[j] = tim[j - 1]; }
