@@ -17,7 +17,10 @@
  * JAERO/oqpskdemodulator.cpp:393,487,496,498,540,641,652; JAERO/mskdemodulator.cpp:434,493) are per-object
  * state here, which is what one-reference-process-per-channel computes.
  * GUI-only work (spectrum ring, scatter points, PeakVolume, QElapsedTimer gating) is omitted: it does not feed
- * back into the signal path.  8400 bps C-channel branches (fb==8400) are not restated (out of scope).
+ * back into the signal path.  The 8400 bps C-channel branches (fb==8400: JFastFir prefilter, centre-weighted coarse window,
+ * alpha-0.6 pulse, its own resonator and carrier-loop gains) are restated too; JFastFir itself is JFFT's
+ * (not in the reference tree): it is restated as oracle/ref/shim/jfft.h builds it, overlap-add with block nfft-K+1, the
+ * behaviour JAERO/tests/jfastfir_tests.cpp pins with exactly this kernel (RRC 0.6, 2049 taps, nfft 4096).
  *
  * Build: gcc -O2 -ffp-contract=off -fPIC -shared (see oracle/Makefile).  Do not add -ffast-math / -march=native.
  */
@@ -106,6 +109,12 @@ static cpx wt_cis(const wavetable *w) /* DSP.cpp:79-85 */
     if (tint < 0) tint = WTSIZE - 1;
     return CISWT[tint];
 }
+static cpx wt_cis_conj(const wavetable *w) /* DSP.cpp:87-93 */
+{
+    cpx c = wt_cis(w);
+    c.im = -c.im;
+    return c;
+}
 static void wt_increase_freq(wavetable *w, double freq_hz) /* DSP.cpp:163-167 */
 {
     freq_hz += w->freq;
@@ -117,6 +126,7 @@ static void wt_set_phase_deg(wavetable *w, double phase_deg) /* DSP.cpp:175-180 
     while (phase_deg < 0) phase_deg += 360.0;
     w->WTptr = (phase_deg / 360.0) * ((double)WTSIZE);
 }
+static double wt_get_phase_deg(const wavetable *w) { return (360.0 * w->WTptr / ((double)WTSIZE)); } /* DSP.cpp:192-195 */
 static void wt_increase_phase_deg(wavetable *w, double phase_deg) /* DSP.cpp:169-173 */
 {
     phase_deg += (360.0 * w->WTptr / ((double)WTSIZE));
@@ -435,7 +445,7 @@ struct jo_coarse
 {
     fftplan *plan;
     cpx *out, *in;
-    double *y, *z;
+    double *y, *z, *window;
     double nfft, Fs, hzperbin, lockingbw, fb, freq_offset_est;
     int startbin, stopbin, expectedpeakbin, emptyingcountdown;
     int ynalloc;
@@ -458,6 +468,19 @@ static void coarse_set_settings(jo_coarse *c, int power, double lockingbw, doubl
     c->startbin = (int)fmax(round(lockingbw / c->hzperbin), 1.0);
     c->stopbin = (int)(c->nfft - c->startbin);
     c->expectedpeakbin = (int)round(fb / (2.0 * c->hzperbin));
+    /* raised-cos window favouring the middle (:61-74), used by the fb==8400 branch of ProcessBasebandData */
+    c->window = (double *)realloc(c->window, sizeof(double) * (size_t)n);
+    for (int i = 0; i < n; i++) c->window[i] = 0;
+    c->window[0] = 1;
+    for (int i = 1; i <= c->startbin; i++)
+    {
+        double val = cos(M_PI_2 * ((double)i) / ((double)c->startbin));
+        val *= val;
+        if ((n - i) < 0) break;
+        if (i >= n) break;
+        c->window[n - i] = val;
+        c->window[i] = val;
+    }
 }
 jo_coarse *jo_coarse_create(int power, double lockingbw, double fb, double Fs)
 {
@@ -470,7 +493,7 @@ jo_coarse *jo_coarse_create(int power, double lockingbw, double fb, double Fs)
 void jo_coarse_destroy(jo_coarse *c)
 {
     if (!c) return;
-    fft_free(c->plan); free(c->out); free(c->in); free(c->y); free(c->z); free(c);
+    fft_free(c->plan); free(c->out); free(c->in); free(c->y); free(c->z); free(c->window); free(c);
 }
 void jo_coarse_bigchange(jo_coarse *c) /* :84-88 */
 {
@@ -483,7 +506,8 @@ static double coarse_process(jo_coarse *c, const cpx *data)
 {
     int n = (int)c->nfft;
     fftwrapper_transform(c->plan, data, c->out, 0);
-    for (int i = c->startbin; i <= c->stopbin; i++) { c->out[i].re = 0; c->out[i].im = 0; } /* fb!=8400 branch */
+    if (c->fb != 8400) { for (int i = c->startbin; i <= c->stopbin; i++) { c->out[i].re = 0; c->out[i].im = 0; } } /* :99 */
+    else { for (int i = 0; i < n; i++) c->out[i] = cscale(c->out[i], c->window[i]); }                               /* :100 */
     fftwrapper_transform(c->plan, c->out, c->in, 1);
     for (int i = 0; i < n; i++) c->in[i] = cmul(c->in[i], c->in[i]);
     fftwrapper_transform(c->plan, c->in, c->out, 0);
@@ -513,6 +537,80 @@ static double coarse_process(jo_coarse *c, const cpx *data)
 double jo_coarse_process(jo_coarse *c, const double *re_im) { return coarse_process(c, (const cpx *)re_im); }
 
 /* ------------------------------------------------------------------ growable capture buffers */
+/* ------------------------------------------------------------------ JFastFir (JFFT; restated as oracle/ref/shim/jfft.h builds it) */
+typedef struct
+{
+    fftplan *plan;
+    int nfft, K, L;
+    cpx *H, *inbuf, *tail, *blk;
+    int nin;
+    cpx *outq; long outq_len, outq_cap, outq_rd;
+} fastfir_t;
+static void fastfir_set_kernel(fastfir_t *f, const cpx *k, int K, int nfft)
+{
+    if (f->plan) fft_free(f->plan);
+    free(f->H); free(f->inbuf); free(f->tail); free(f->blk); free(f->outq);
+    f->K = K; f->nfft = nfft; f->L = nfft - K + 1;
+    f->plan = fft_plan(nfft);
+    f->H = (cpx *)calloc((size_t)nfft, sizeof(cpx));
+    for (int i = 0; i < K; i++) f->H[i] = k[i];
+    fft_run(f->plan, f->H, 0);
+    f->inbuf = (cpx *)calloc((size_t)f->L, sizeof(cpx)); f->nin = 0;
+    f->tail = (cpx *)calloc((size_t)nfft, sizeof(cpx));
+    f->blk = (cpx *)calloc((size_t)nfft, sizeof(cpx));
+    f->outq_cap = 4 * (long)nfft; f->outq = (cpx *)calloc((size_t)f->outq_cap, sizeof(cpx));
+    f->outq_len = f->L; f->outq_rd = 0; /* L samples of latency */
+}
+static void fastfir_processblock(fastfir_t *f)
+{
+    const int nfft = f->nfft, L = f->L;
+    for (int i = 0; i < nfft; i++) { f->blk[i].re = 0; f->blk[i].im = 0; }
+    for (int i = 0; i < L; i++) f->blk[i] = f->inbuf[i];
+    f->nin = 0;
+    fft_run(f->plan, f->blk, 0);
+    for (int i = 0; i < nfft; i++) f->blk[i] = cmul(f->blk[i], f->H[i]);
+    fft_run(f->plan, f->blk, 1);
+    double s = 1.0 / ((double)nfft);
+    for (int i = 0; i < nfft; i++) { f->blk[i].re *= s; f->blk[i].im *= s; }
+    for (int i = 0; i < nfft; i++) { f->tail[i].re += f->blk[i].re; f->tail[i].im += f->blk[i].im; }
+    if (f->outq_len + L > f->outq_cap)
+    {
+        f->outq_cap = 2 * (f->outq_len + L);
+        f->outq = (cpx *)realloc(f->outq, sizeof(cpx) * (size_t)f->outq_cap);
+    }
+    for (int i = 0; i < L; i++) f->outq[f->outq_len++] = f->tail[i];
+    for (int i = 0; i + L < nfft; i++) f->tail[i] = f->tail[i + L];
+    for (int i = nfft - L; i < nfft; i++) { f->tail[i].re = 0; f->tail[i].im = 0; }
+}
+static void fastfir_update(fastfir_t *f, cpx *data, long n)
+{
+    for (long i = 0; i < n; i++)
+    {
+        f->inbuf[f->nin++] = data[i];
+        if (f->nin == f->L) fastfir_processblock(f);
+        data[i] = f->outq[f->outq_rd++];
+    }
+    if (f->outq_rd > 0)
+    {
+        memmove(f->outq, f->outq + f->outq_rd, sizeof(cpx) * (size_t)(f->outq_len - f->outq_rd));
+        f->outq_len -= f->outq_rd; f->outq_rd = 0;
+    }
+}
+static void fastfir_free(fastfir_t *f)
+{
+    if (f->plan) fft_free(f->plan);
+    free(f->H); free(f->inbuf); free(f->tail); free(f->blk); free(f->outq);
+    memset(f, 0, sizeof(*f));
+}
+static void fastfir_set_kernel_real(fastfir_t *f, const double *pts, int K, int nfft) /* SetKernel(QVector<double>[, nfft]) */
+{
+    cpx *k = (cpx *)malloc(sizeof(cpx) * (size_t)K);
+    for (int i = 0; i < K; i++) { k[i].re = pts[i]; k[i].im = 0.0; }
+    if (nfft <= 0) { int pw = 1; while (pw < K) pw <<= 1; nfft = 4 * pw; } /* the 1-argument SetKernel */
+    fastfir_set_kernel(f, k, K, nfft);
+    free(k);
+}
+
 typedef struct { char *p; size_t len, cap; } gbuf;
 static void gpush(gbuf *g, const void *src, size_t n)
 {
@@ -545,7 +643,9 @@ struct jo_demod
     fir_t *fir_re, *fir_im;
     delay_t delays, delayt41, delayt42, delayt8;
     iir_t st_iir_resonator, ct_iir_loopfilter;
-    wavetable st_osc, st_osc_ref, mixer_center, mixer2;
+    wavetable st_osc, st_osc_ref, mixer_center, mixer2, mixer_fir_pre;
+    fastfir_t fir_pre;          /* fb==8400 prefilter */
+    cpx *prefilt; long prefilt_cap;
     jo_coarse *coarse;
     double mse;
     msecalc_t msecalc;      /* OQPSK */
@@ -617,6 +717,15 @@ static void oqpsk_ctor(jo_demod *d) /* oqpskdemodulator.cpp:8-117 */
     set_resonator(&d->ct_iir_loopfilter, 0.0010275610653672064, 0.0020551221307344128, 0.0010275610653672064, 1, -1.9207386815577139, 0.92509247310306331);
     iir_init(&d->ct_iir_loopfilter);
     d->countdown = 4; d->countdown2 = 5; d->yui = 0; d->pt_d.re = 0; d->pt_d.im = 0; d->sig2_last_init = 0;
+    /* just for 8400 (:110-115) */
+    {
+        double *pp = (double *)malloc(sizeof(double) * 1100);
+        int npp = jo_rrc_design(1, 1024, d->Fs, 10500 / 2, pp);
+        fastfir_set_kernel_real(&d->fir_pre, pp, npp, 0);
+        free(pp);
+        wt_init(&d->mixer_fir_pre);
+        wt_setfreq_sr(&d->mixer_fir_pre, d->freq_center, (int)d->Fs);
+    }
 }
 
 static void oqpsk_set_settings(jo_demod *d, const jo_settings *s) /* oqpskdemodulator.cpp:175-289 */
@@ -637,17 +746,33 @@ static void oqpsk_set_settings(jo_demod *d, const jo_settings *s) /* oqpskdemodu
     d->agc = agc_new(4, d->Fs);
     fir_free(d->fir_re); fir_free(d->fir_im);
     double pts[64];
-    int np = jo_rrc_design(1.0, 55, d->Fs, d->fb / 2, pts); /* fb==8400 (alpha 0.6) not restated */
+    int np = jo_rrc_design(d->fb == 8400 ? 0.6 : 1.0, 55, d->Fs, d->fb / 2, pts); /* :209-211 */
     d->fir_re = fir_new(np); d->fir_im = fir_new(np);
     for (int i = 0; i < np; i++) { d->fir_re->points[i] = pts[i]; d->fir_im->points[i] = pts[i]; }
     double T = d->Fs / (d->fb / 2);
     delay_set(&d->delays, 1); delay_set(&d->delayt41, T / 4.0); delay_set(&d->delayt42, T / 4.0); delay_set(&d->delayt8, T / 8.0);
-    set_resonator(&d->st_iir_resonator, 0.00032714218939589035, 0, 0.00032714218939589035, 1, -0.39005299948210803, 0.99934571562120822);
-    d->ee = 0.4;
+    if (d->fb == 8400)
+    {
+        /* the 10 Hz resonator that overwrites the 35 Hz one (:231-251) */
+        set_resonator(&d->st_iir_resonator, 0.0012845857864470789, 0, -0.0012845857864470789, 1, -0.90681461999279889, 0.99743082842710584);
+        d->ee = 0.65;
+    }
+    else
+    {
+        set_resonator(&d->st_iir_resonator, 0.00032714218939589035, 0, 0.00032714218939589035, 1, -0.39005299948210803, 0.99934571562120822);
+        d->ee = 0.4;
+    }
     iir_init(&d->st_iir_resonator);
     wt_setfreq_sr(&d->st_osc, d->fb, (int)d->Fs);
     wt_setfreq_sr(&d->st_osc_ref, d->fb, (int)d->Fs);
     d->ebno.Fs = d->Fs; d->ebno.fb = d->fb;
+    /* prefilter kernel (:278-283); built for every rate, used at 8400 */
+    {
+        double *pp = (double *)malloc(sizeof(double) * 2100);
+        int npp = jo_rrc_design(d->fb == 8400 ? 0.6 : 1.0, 2048, d->Fs, d->fb / 2, pp);
+        fastfir_set_kernel_real(&d->fir_pre, pp, npp, 4096);
+        free(pp);
+    }
     d->coarseCounter = 0;
 }
 
@@ -662,6 +787,8 @@ static void record_status(jo_demod *d)
 
 static void oqpsk_freq_offset_estimate_slot(jo_demod *d, double freq_offset_est) /* oqpskdemodulator.cpp:629-677 */
 {
+    /* update prefilter until we have dcd and a signal (:634-638) */
+    if ((d->mse > d->signalthreshold) || (!d->dcd)) wt_setfreq_sr(&d->mixer_fir_pre, d->mixer_center.freq + freq_offset_est, (int)d->Fs);
     if ((d->mse < d->signalthreshold) && (!d->dcd))
     {
         if (d->countdown2 > 0) d->countdown2--;
@@ -714,15 +841,44 @@ static void coarse_ring_step(jo_demod *d, double dval, int is_oqpsk)
 static void oqpsk_write(jo_demod *d, const int16_t *ptr, long n) /* oqpskdemodulator.cpp:334-627 */
 {
     if (!n) return;
+    /* prefilter (:343-381): down with mixer_fir_pre, JFastFir over the whole write, up again from the saved phase */
+    if (d->fb == 8400)
+    {
+        if (d->prefilt_cap < n) { d->prefilt = (cpx *)realloc(d->prefilt, sizeof(cpx) * (size_t)n); d->prefilt_cap = n; }
+        const double savedphase = wt_get_phase_deg(&d->mixer_fir_pre);
+        for (long i = 0; i < n; i++)
+        {
+            double dval = ((double)ptr[i]) / 32768.0;
+            d->prefilt[i] = cscale(wt_cis(&d->mixer_fir_pre), dval);
+            wt_next(&d->mixer_fir_pre);
+        }
+        fastfir_update(&d->fir_pre, d->prefilt, n);
+        wt_set_phase_deg(&d->mixer_fir_pre, savedphase);
+        for (long i = 0; i < n; i++)
+        {
+            cpx cj = wt_cis_conj(&d->mixer_fir_pre);
+            d->prefilt[i] = cmul(d->prefilt[i], cj);
+            wt_next(&d->mixer_fir_pre);
+        }
+    }
+    double mixer2_freq_sum = 0;
     for (long i = 0; i < n; i++)
     {
         double dval = ((double)ptr[i]) / 32768.0;
         coarse_ring_step(d, dval, 1);
 
-        cpx cval = cscale(wt_cis(&d->mixer2), dval);
         cpx sig2;
-        sig2.re = fir_update_and_process(d->fir_re, cval.re);
-        sig2.im = fir_update_and_process(d->fir_im, cval.im);
+        if (d->fb == 8400)
+        {
+            sig2 = cmul(wt_cis(&d->mixer2), d->prefilt[i]); /* :440 */
+            mixer2_freq_sum += d->mixer2.freq;              /* :447 */
+        }
+        else
+        {
+            cpx cval = cscale(wt_cis(&d->mixer2), dval);
+            sig2.re = fir_update_and_process(d->fir_re, cval.re);
+            sig2.im = fir_update_and_process(d->fir_im, cval.im);
+        }
 
         double dabval = sqrt(sig2.re * sig2.re + sig2.im * sig2.im);
         oqpsk_ebno_update(&d->ebno, dabval);
@@ -764,12 +920,19 @@ static void oqpsk_write(jo_demod *d, const int16_t *ptr, long n) /* oqpskdemodul
                 double ct_ec = ct_xt_d - ct_xt;
                 if (ct_ec > M_PI) ct_ec = M_PI;
                 if (ct_ec < -M_PI) ct_ec = -M_PI;
-                /* fb>8400 branch :518-525 */
-                ct_ec = iir_update(&d->ct_iir_loopfilter, ct_ec);
-                if (ct_ec > M_PI_2) ct_ec = M_PI_2;
-                if (ct_ec < -M_PI_2) ct_ec = -M_PI_2;
-                wt_increase_phase_deg(&d->mixer2, 1.0 * ct_ec);
-                wt_increase_freq(&d->mixer2, 0.01 * ct_ec);
+                if (d->fb > 8400) /* :518-525 */
+                {
+                    ct_ec = iir_update(&d->ct_iir_loopfilter, ct_ec);
+                    if (ct_ec > M_PI_2) ct_ec = M_PI_2;
+                    if (ct_ec < -M_PI_2) ct_ec = -M_PI_2;
+                    wt_increase_phase_deg(&d->mixer2, 1.0 * ct_ec);
+                    wt_increase_freq(&d->mixer2, 0.01 * ct_ec);
+                }
+                else /* 8400 works better with faster phase agility (:526-532) */
+                {
+                    wt_increase_phase_deg(&d->mixer2, 1.0 * ct_ec);
+                    wt_increase_freq(&d->mixer2, 0.5 * 0.01 * iir_update(&d->ct_iir_loopfilter, ct_ec));
+                }
 
                 ma_update_signed(d->marg, ct_ec);
                 delaything_update(&d->dt, &pt_qpsk);
@@ -800,14 +963,19 @@ static void oqpsk_write(jo_demod *d, const int16_t *ptr, long n) /* oqpskdemodul
         wt_next(&d->st_osc);
         wt_next(&d->st_osc_ref);
     }
+    /* update the 8400bps pre filter with better estimates of carrier (:607-608; runs at every rate) */
+    wt_setfreq(&d->mixer_fir_pre, mixer2_freq_sum / ((double)n));
 }
 
 static void center_freq_changed(jo_demod *d, double freq_center) /* oqpsk :291-310, msk :265-282 */
 {
     if (d->kind == JO_KIND_OQPSK)
     {
-        if (freq_center < (0.5 * d->fb)) freq_center = 0.5 * d->fb;
-        if (freq_center > (d->Fs / 2.0 - 0.5 * d->fb)) freq_center = d->Fs / 2.0 - 0.5 * d->fb;
+        if (d->fb != 8400) /* :293 */
+        {
+            if (freq_center < (0.5 * d->fb)) freq_center = 0.5 * d->fb;
+            if (freq_center > (d->Fs / 2.0 - 0.5 * d->fb)) freq_center = d->Fs / 2.0 - 0.5 * d->fb;
+        }
     }
     else
     {
@@ -1013,6 +1181,8 @@ void jo_demod_destroy(jo_demod *d)
 {
     if (!d) return;
     free(d->bbcycbuff); free(d->bbtmpbuff); fir_free(d->fir_re); fir_free(d->fir_im);
+    if (d->kind == JO_KIND_OQPSK) fastfir_free(&d->fir_pre);
+    free(d->prefilt);
     jo_coarse_destroy(d->coarse); agc_free(d->agc); ma_free(d->ebno.E); ma_free(d->ebno.E2); ma_free(d->marg);
     ma_free(d->msema); ma_free(d->msecalc.pointmean); ma_free(d->msecalc.msema);
     free(d->dt.buffer); free(d->delayedsmpl.buffer);

@@ -167,71 +167,7 @@ static int peakdet_update(peakdet_t *p, double *val) /* :528-560 */
     return 0;
 }
 
-/* ------------------------------------------------------------------ JFastFir (oracle/ref/shim/jfft.h) + QJHilbertFilter */
-typedef struct
-{
-    fftplan *plan;
-    int nfft, K, L;
-    cpx *H, *inbuf, *tail, *blk;
-    int nin;
-    cpx *outq; long outq_len, outq_cap, outq_rd;
-} fastfir_t;
-static void fastfir_set_kernel(fastfir_t *f, const cpx *k, int K, int nfft)
-{
-    if (f->plan) fft_free(f->plan);
-    free(f->H); free(f->inbuf); free(f->tail); free(f->blk); free(f->outq);
-    f->K = K; f->nfft = nfft; f->L = nfft - K + 1;
-    f->plan = fft_plan(nfft);
-    f->H = (cpx *)calloc((size_t)nfft, sizeof(cpx));
-    for (int i = 0; i < K; i++) f->H[i] = k[i];
-    fft_run(f->plan, f->H, 0);
-    f->inbuf = (cpx *)calloc((size_t)f->L, sizeof(cpx)); f->nin = 0;
-    f->tail = (cpx *)calloc((size_t)nfft, sizeof(cpx));
-    f->blk = (cpx *)calloc((size_t)nfft, sizeof(cpx));
-    f->outq_cap = 4 * (long)nfft; f->outq = (cpx *)calloc((size_t)f->outq_cap, sizeof(cpx));
-    f->outq_len = f->L; f->outq_rd = 0; /* L samples of latency */
-}
-static void fastfir_processblock(fastfir_t *f)
-{
-    const int nfft = f->nfft, L = f->L;
-    for (int i = 0; i < nfft; i++) { f->blk[i].re = 0; f->blk[i].im = 0; }
-    for (int i = 0; i < L; i++) f->blk[i] = f->inbuf[i];
-    f->nin = 0;
-    fft_run(f->plan, f->blk, 0);
-    for (int i = 0; i < nfft; i++) f->blk[i] = cmul(f->blk[i], f->H[i]);
-    fft_run(f->plan, f->blk, 1);
-    double s = 1.0 / ((double)nfft);
-    for (int i = 0; i < nfft; i++) { f->blk[i].re *= s; f->blk[i].im *= s; }
-    for (int i = 0; i < nfft; i++) { f->tail[i].re += f->blk[i].re; f->tail[i].im += f->blk[i].im; }
-    if (f->outq_len + L > f->outq_cap)
-    {
-        f->outq_cap = 2 * (f->outq_len + L);
-        f->outq = (cpx *)realloc(f->outq, sizeof(cpx) * (size_t)f->outq_cap);
-    }
-    for (int i = 0; i < L; i++) f->outq[f->outq_len++] = f->tail[i];
-    for (int i = 0; i + L < nfft; i++) f->tail[i] = f->tail[i + L];
-    for (int i = nfft - L; i < nfft; i++) { f->tail[i].re = 0; f->tail[i].im = 0; }
-}
-static void fastfir_update(fastfir_t *f, cpx *data, long n)
-{
-    for (long i = 0; i < n; i++)
-    {
-        f->inbuf[f->nin++] = data[i];
-        if (f->nin == f->L) fastfir_processblock(f);
-        data[i] = f->outq[f->outq_rd++];
-    }
-    if (f->outq_rd > 0)
-    {
-        memmove(f->outq, f->outq + f->outq_rd, sizeof(cpx) * (size_t)(f->outq_len - f->outq_rd));
-        f->outq_len -= f->outq_rd; f->outq_rd = 0;
-    }
-}
-static void fastfir_free(fastfir_t *f)
-{
-    if (f->plan) fft_free(f->plan);
-    free(f->H); free(f->inbuf); free(f->tail); free(f->blk); free(f->outq);
-    memset(f, 0, sizeof(*f));
-}
+/* ------------------------------------------------------------------ QJHilbertFilter on JFastFir (fastfir_t: jaero_oracle.c) */
 /* QJHilbertFilter::setSize (DSP.cpp:760-787) + JFastFir::SetKernel(kernel) default nfft */
 static void hilbert_set_size(fastfir_t *f, int N)
 {

@@ -36,7 +36,7 @@ def oracle_mod():
 def oracle_settings(O, kind, opts):
     if kind == "oqpsk":
         return O.oqpsk_settings(freq_center=opts.get("freq_center", 8000.0), lockingbw=opts.get("lockingbw", 10500.0),
-                                power=opts.get("power", 14), threshold=opts.get("threshold", 0.65))
+                                fb=opts.get("fb", 10500.0), power=opts.get("power", 14), threshold=opts.get("threshold", 0.65))
     return O.msk_settings(freq_center=opts.get("freq_center", 1000.0), lockingbw=opts.get("lockingbw", 1800.0),
                           fb=opts.get("fb", 1200.0), power=opts.get("power", 13), threshold=opts.get("threshold", 0.5))
 

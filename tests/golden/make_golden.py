@@ -42,6 +42,14 @@ def main():
     pcm, _ = G.oqpsk(120000, fc=8020.0, ebno_db=12.0, seed=G.SEED_BASE + 5)
     save("oqpsk_10k5_cpureduce", pcm, "oqpsk", opts, O.run_ref("oqpsk", pcm, **opts))
 
+    # 8400 bps C-channel branch of OqpskDemodulator (JFastFir prefilter, centre-weighted coarse window)
+    opts = dict(fb=8400, lockingbw=8400)
+    pcm, _ = G.oqpsk(150000, fb=8400.0, fc=8021.0, ebno_db=11.0, seed=G.SEED_BASE + 6)
+    save("oqpsk_8400_default", pcm, "oqpsk", opts, O.run_ref("oqpsk", pcm, **opts))
+    opts = dict(fb=8400, lockingbw=8400, afc=1, chunk=1500, dcd_at=90000)
+    pcm, _ = G.oqpsk(150000, fb=8400.0, fc=7968.0, ebno_db=9.0, seed=G.SEED_BASE + 7)
+    save("oqpsk_8400_afc_chunk1500_dcd", pcm, "oqpsk", opts, O.run_ref("oqpsk", pcm, **opts))
+
     # the reference's bundled recordings through the continuous MSK demodulator: outputs only (inputs stay in
     # /root/reference/samples; the test that uses them skips when that tree is absent)
     import wave

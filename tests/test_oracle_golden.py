@@ -8,7 +8,7 @@ import pytest
 from conftest import load_golden, oracle_settings
 
 CASES = ["oqpsk_10k5_default", "oqpsk_10k5_afc_chunk1000_dcd", "msk_1200_default", "msk_600_chunk777_dcd",
-         "oqpsk_10k5_cpureduce"]
+         "oqpsk_10k5_cpureduce", "oqpsk_8400_default", "oqpsk_8400_afc_chunk1500_dcd"]
 
 
 @pytest.mark.parametrize("name", CASES)

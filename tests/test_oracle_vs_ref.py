@@ -30,6 +30,16 @@ def test_oqpsk_random(O, seed, afc, cpu, chunk):
          O.run_demod(O.oqpsk_settings(), pcm, afc=bool(afc), cpu_reduce=bool(cpu), chunk=chunk))
 
 
+@pytest.mark.parametrize("seed,afc,cpu,chunk,center", [(31, 0, 0, 4096, False), (32, 1, 0, 1000, False), (33, 0, 1, 4096, False), (34, 0, 0, 2500, True)])
+def test_oqpsk_8400_random(O, seed, afc, cpu, chunk, center):
+    """fb == 8400: JFastFir prefilter with its per-write mixer update, centre-weighted coarse window, alpha-0.6 filters, the
+    carrier-loop gains of the <= 8400 branch (oqpskdemodulator.cpp:345-381,436-448,518-532,607-608, coarsefreqestimate.cpp:100)."""
+    pcm, _ = G.oqpsk(130000, fb=8400.0, fc=8000 + 3.0 * seed, ebno_db=8.0 + seed % 5, seed=seed)
+    kv = dict(center_at=60000, center_hz=8090) if center else {}
+    _cmp(O.run_ref("oqpsk", pcm, fb=8400, lockingbw=8400, afc=afc, cpureduce=cpu, chunk=chunk, dcd_at=100000, **kv),
+         O.run_demod(O.oqpsk_settings(fb=8400.0, lockingbw=8400.0), pcm, afc=bool(afc), cpu_reduce=bool(cpu), chunk=chunk, dcd_at=100000, **kv))
+
+
 @pytest.mark.parametrize("fb,seed", [(1200, 21), (600, 22)])
 def test_msk_random(O, fb, seed):
     pcm, _ = G.msk(60000, fb=fb, fc=1000 + seed, ebno_db=11.0, seed=seed)
