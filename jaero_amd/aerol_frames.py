@@ -257,3 +257,64 @@ def rt_burst_stream_msk(packets, *, gap: int = 4200, lead: int = 80, sigma: floa
             bits = bits ^ 1
         out += [np.array([-1], dtype=np.int16), noise(lead + (lead & 1)), to_soft(bits, sigma=sigma, seed=int(rng.integers(1 << 30))), noise(gap + (gap & 1))]
     return np.concatenate(out)
+
+
+# ------------------------------------------------------------------------------------------------ 8400 bps C channel
+# The inverse of AeroL::DecodeC (JAERO/aerol.cpp:2187-2502, setSettings case 8400 :1033-1043):
+#   frame = 104 unique-word channel bits (52 on each arm, real arm first: OQPSKPreambleDetectorAndAmbiguityCorrection accepts either
+#   of its two words, or its complement, on either arm, tolerance 6) + 4096 channel bits = 4200 bits = 0.5 s;
+#   the 4096 = 16 interleaver blocks of 64 x 4; deinterleaved they are the rate-3/4 punctured stream (every 4th coded bit of the
+#   K=7 rate-1/2 code is not sent; the decoder ignores the last channel bit: 4095 -> 5460 soft symbols -> 2730 bits, of which it
+#   keeps 2714);  the Viterbi's 6 bits + the 2708-bit delay line line the frames up one frame later, so bits 2708..2713 of a
+#   frame come out of the 16 dropped positions' successors: the six bits wanted there are sent at positions 2724..2729;
+#   the 2714 bits are scrambled (sequence restarted at every unique word) and hold 25 primary fields of 1 + 96 (voice) bits and
+#   24 sub-band fields of 12 bits: three 12-byte signal units (10 + CRC-16) per frame.
+C_UW1, C_UW2 = 216866263330005, 3012071630031408
+
+
+def c_channel_bits(frames, *, invert_real: bool = False, invert_imag: bool = False, uw=(C_UW1, C_UW2)):
+    """frames: list of (voice uint8[300], [three 10-byte payloads]) -> channel bits uint8 (4200 per frame).  The decoder hands out
+    frame f while it receives frame f + 1."""
+    scr = scrambler_sequence()
+    info = []
+    for voice, pays in frames:
+        vb = np.unpackbits(np.asarray(voice, dtype=np.uint8), bitorder="little")  # 2400 bits, LSB first per byte (aerol.cpp:2461-2469)
+        sub = np.unpackbits(np.frombuffer(b"".join(make_su(bytes(p)) for p in pays), dtype=np.uint8), bitorder="little")  # 288 bits
+        d = np.zeros(2714, dtype=np.uint8)
+        for y in range(25):
+            d[y * 109 + 1: y * 109 + 97] = vb[y * 96:(y + 1) * 96]
+            if y < 24:
+                d[y * 109 + 97: y * 109 + 109] = sub[y * 12:(y + 1) * 12]
+        d ^= scr[:2714]
+        info.append(np.concatenate([d[:2708], np.zeros(16, np.uint8), d[2708:]]))
+    coded = conv_encode(np.concatenate(info))
+    keep = (np.arange(5460) % 4) != 3
+    out = []
+    for f in range(len(frames)):
+        tx = coded[f * 5460:(f + 1) * 5460][keep]          # 4095 channel bits
+        tx = np.concatenate([tx, np.zeros(1, np.uint8)])      # the 4096th is never looked at
+        body = np.concatenate([interleave(tx[k * 256:(k + 1) * 256], 4) for k in range(16)])
+        wr = np.array([(uw[0] >> (51 - k)) & 1 for k in range(52)], dtype=np.uint8)
+        wi = np.array([(uw[1] >> (51 - k)) & 1 for k in range(52)], dtype=np.uint8)
+        u = np.empty(104, dtype=np.uint8)
+        u[0::2], u[1::2] = wr, wi
+        out.append(np.concatenate([u, body]))
+    bits = np.concatenate(out)
+    if invert_real:
+        bits[0::2] ^= 1  # the stream starts on the real arm (realimag toggles before it is tested, aerol.cpp:2208)
+    if invert_imag:
+        bits[1::2] ^= 1
+    return bits
+
+
+def c_channel_case(seed: int, nframes: int, sigma: float, inv=(False, False), lead: int = 74, types=(0x22, 0x30, 0x60, 0x01)):
+    """A test stream: ([(voice uint8[300], [three 10-byte payloads])] per frame, soft bits int16).  Message types that DecodeC prints
+    (and a fill-in unit now and then); `lead` random bits in front so that the unique word does not start the stream."""
+    rng = np.random.default_rng(seed)
+    frames = [(rng.integers(0, 256, 300, dtype=np.uint8),
+               [bytes([types[int(rng.integers(0, len(types)))]] + list(rng.integers(0, 256, 9, dtype=np.uint8))) for _ in range(3)])
+              for _ in range(nframes)]
+    bits = c_channel_bits(frames, invert_real=inv[0], invert_imag=inv[1])
+    soft = to_soft(np.concatenate([rng.integers(0, 2, lead, dtype=np.uint8), bits, np.zeros(300, np.uint8)]), sigma=sigma, seed=seed + 1)
+    return frames, soft
+

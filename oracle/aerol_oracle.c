@@ -13,6 +13,14 @@
  * (AeroL::updateDCD, aerol.cpp:1109-1122); a batch run has no event loop, so neither this file nor the _ref driver ticks it.
  * Members the reference never initialises (realimag, muw, lastframeinfo: aerol.h:956,975,990) start at 0, as in the _ref
  * driver's zeroed storage.  Pinned against the unmodified AeroL built into oracle/_ref (tests/test_aerol_oracle.py).
+ *
+ * 8400 bps C channel: AeroL::DecodeC (JAERO/aerol.cpp:2187-2502) with OQPSKPreambleDetectorAndAmbiguityCorrection
+ * (:811-900), deinterleave_ba(block, 4), PuncturedCode::depunture_soft_block (:2505-2518), the 2714-bit delay line / scrambler,
+ * the three sub-band signal units and the 300 voice bytes of a frame.  Pinned the same way (the _ref driver prints what DecodeC
+ * hands to Voicesignal).  One thing cannot be pinned: on the codec's FIRST call JConvolutionalCodec::Decode_Continuous returns bits
+ * 25..2741 of a buffer of which libcorrect wrote 2736, the rest being whatever QByteArray::resize left there
+ * (jconvolutionalcodec.cpp:165-191); they end up as the three low bits of the last voice byte of the second frame handed out.
+ * Here they are decoded zeros.
  */
 #include <stdlib.h>
 #include <string.h>
@@ -106,6 +114,11 @@ struct jo_aerol
     jo_codec *rt_codec;
     long npackets;
     gb packets;
+    /* 8400 bps C channel: DecodeC aerol.cpp:2187-2502 */
+    struct { int p1[64], p2[64], b1[64], b2[64], len, tol, inverted; } cpd[2]; /* [0] = preambledetectorreal, [1] = preambledetectorimag */
+    int cindex;
+    unsigned char cdel[16 * 256 + 256]; int ncdel;
+    gb voice;
 };
 #define RT_BLOCKSZ (64 * 95)
 enum { RT_OK_R = 3, RT_OK_T = 5, RT_BAD = 0, RT_TEST_FAILED = 32, RT_NOTHING = 8, RT_FULL = 16 };
@@ -142,6 +155,19 @@ jo_aerol *jo_aerol_create(int fb)
     {
     case 600: a->N = 6; a->dl2_len = 576 - 6; a->NumberOfBits = 1152; a->BitsInHeader = 16; a->TotalNumberOfBits = 16 + 1152 + 32; a->useingOQPSK = 0; break;
     case 1200: a->N = 9; a->dl2_len = 576 - 6; a->NumberOfBits = 1152; a->BitsInHeader = 16; a->TotalNumberOfBits = 16 + 1152 + 32; a->useingOQPSK = 0; break;
+    case 8400: /* :1033-1043 */
+        a->N = 4; a->dl2_len = 2714 - 6; a->NumberOfBits = 4096; a->BitsInHeader = 0; a->TotalNumberOfBits = 4096; a->useingOQPSK = 1;
+        for (int q = 0; q < 2; q++) /* ctor :953-954 + setSettings non-burst tolerance 6 :1008-1009 */
+        {
+            a->cpd[q].len = 52; a->cpd[q].tol = 6;
+            for (int i = 51, k = 0; i >= 0; i--, k++)
+            {
+                a->cpd[q].p1[k] = (int)((216866263330005ULL >> i) & 1);
+                a->cpd[q].p2[k] = (int)((3012071630031408ULL >> i) & 1);
+            }
+        }
+        a->ncdel = 16 * 4 * 64; /* deleaveredBlock.resize(16*4*64) */
+        break;
     default: a->N = 78; a->dl2_len = 4992 - 6; a->NumberOfBits = 4992; a->BitsInHeader = 16 + 178; a->TotalNumberOfBits = 16 + 178 + 4992 + 64; a->useingOQPSK = 1; a->ifb = 10500; break;
     }
     a->blocksz = a->N * 64;
@@ -170,6 +196,7 @@ long jo_aerol_take_packets(jo_aerol *a, int32_t *dst, long cap) { return gb_take
 
 void jo_aerol_destroy(jo_aerol *a)
 {
+    if (a) free(a->voice.p);
     if (!a) return;
     free(a->rt_block); if (a->rt_codec) jo_codec_destroy(a->rt_codec); free(a->packets.p);
     free(a->block); free(a->dl2); jo_codec_destroy(a->codec); free(a->sus.p); free(a->events.p); free(a);
@@ -191,6 +218,7 @@ int jo_aerol_tick_dcd(jo_aerol *a)
 }
 long jo_aerol_take_sus(jo_aerol *a, int32_t *dst, long cap) { return gb_take(&a->sus, dst, 16 * sizeof(int32_t), cap); }
 long jo_aerol_take_events(jo_aerol *a, int64_t *dst, long cap) { return gb_take(&a->events, dst, 3 * sizeof(int64_t), cap); }
+long jo_aerol_take_voice(jo_aerol *a, unsigned char *dst, long cap) { return gb_take(&a->voice, dst, 304, cap); }
 
 static void block_done(jo_aerol *a, long bitidx) /* aerol.cpp:1553-1600 */
 {
@@ -385,8 +413,150 @@ static int rt_update_msk(jo_aerol *a, int bit) /* RTChannelDeleaveFECScram::upda
     return result;
 }
 
+/* OQPSKPreambleDetectorAndAmbiguityCorrection::Update aerol.cpp:848-895 (q: 0 real, 1 imag) */
+static int cpd_update(jo_aerol *a, int q, int val)
+{
+    const int n = a->cpd[q].len, tol = a->cpd[q].tol;
+    int *b1 = a->cpd[q].b1, *b2 = a->cpd[q].b2;
+    int xorsum = 0;
+    for (int i = 0; i < n - 1; i++) { b1[i] = b1[i + 1]; xorsum += b1[i] ^ a->cpd[q].p1[i]; }
+    xorsum += val ^ a->cpd[q].p1[n - 1];
+    b1[n - 1] = val;
+    if (xorsum >= (n - tol)) { a->cpd[q].inverted = 1; return 1; }
+    if (xorsum <= tol) { a->cpd[q].inverted = 0; return 1; }
+    xorsum = 0;
+    for (int i = 0; i < n - 1; i++) { b2[i] = b2[i + 1]; xorsum += b2[i] ^ a->cpd[q].p2[i]; }
+    xorsum += val ^ a->cpd[q].p2[n - 1];
+    b2[n - 1] = val;
+    if (xorsum >= (n - tol)) { a->cpd[q].inverted = 1; return 1; }
+    if (xorsum <= tol) { a->cpd[q].inverted = 0; return 1; }
+    return 0;
+}
+
+/* end of a C-channel frame aerol.cpp:2318-2490: depuncture, Viterbi, delay line, scrambler, 3 sub-band signal units, 300 voice bytes */
+static void c_frame_done(jo_aerol *a, long bitidx)
+{
+    /* puncturedCode.depunture_soft_block(deleaveredBlock, depuncturedBlock, 4, true) :2505-2518 (the last source byte is not used) */
+    unsigned char *dep = (unsigned char *)malloc((size_t)a->ncdel * 2 + 16);
+    int nd = 0, ptr = 0;
+    for (int i = 0; i < a->ncdel - 1; i++)
+    {
+        ptr++;
+        dep[nd++] = a->cdel[i];
+        if (ptr >= 4 - 1) dep[nd++] = 128;
+        ptr %= (4 - 1);
+    }
+    unsigned char *bits = (unsigned char *)calloc((size_t)nd + 3000, 1);
+    int nb = jo_decode_continuous(a->codec, dep, nd, bits);
+    (void)nb; /* deconvol.resize(2714): drops the trailing dummy bits (or zero-extends a short first frame) */
+    for (int h = 0; h < 2714; h++)
+    {
+        int v = (h < nb) ? bits[h] : 0;
+        a->dl2[a->dl2_ptr] = v;
+        a->dl2_ptr++; a->dl2_ptr %= a->dl2_sz;
+        v = a->dl2[a->dl2_ptr];
+        v ^= a->scr[a->scr_pos < 5000 ? a->scr_pos : 4999];
+        a->scr_pos++;
+        bits[h] = (unsigned char)v;
+    }
+    int charptr = 0; unsigned char ch = 0;
+    unsigned char info[16]; int ninfo = 0, kk = 0;
+    for (int y = 0; y < 24; y++)
+    {
+        const int offset = y * (1 + 96 + 12);
+        for (int h = offset + 97; h < offset + 109; h++)
+        {
+            ch |= bits[h] * 128;
+            charptr++; charptr %= 8;
+            if (charptr == 0) { info[ninfo++] = ch; ch = 0; }
+            else ch >>= 1;
+        }
+        if (ninfo == 12)
+        {
+            uint16_t crc_calc = crc16_bytes(info, 10);
+            uint16_t crc_rec = (uint16_t)((info[11] << 8) | info[10]);
+            if (crc_calc == crc_rec) { if (a->datacdcountdown < 12) a->datacdcountdown += 2; }
+            else { if (a->datacdcountdown > 0) a->datacdcountdown -= 5; }
+            if (!a->datacd && a->datacdcountdown > 2) { a->datacd = 1; ev(a, bitidx, 0, 1); }
+            int32_t row[16];
+            row[0] = (int32_t)a->nframes; row[1] = kk++;
+            for (int j = 0; j < 12; j++) row[2 + j] = info[j];
+            row[14] = (crc_calc == crc_rec); row[15] = 0;
+            gb_push(&a->sus, row, sizeof(row));
+            ninfo = 0;
+        }
+    }
+    /* voice data :2454-2478 (ch / charptr carry on from above; both are 0 again after 288 bits) */
+    unsigned char row[304];
+    memset(row, 0, sizeof(row));
+    { const uint32_t f = (uint32_t)a->nframes; memcpy(row, &f, 4); }
+    int nv = 0, bitsin = 0;
+    for (int h = 1; h < 2714; h++)
+    {
+        ch |= bits[h] * 128;
+        charptr++; charptr %= 8;
+        if (charptr == 0) { if (nv < 300) row[4 + nv++] = ch; ch = 0; }
+        else ch >>= 1;
+        bitsin++;
+        if (bitsin == 96) { bitsin = 0; h += 13; }
+    }
+    gb_push(&a->voice, row, sizeof(row));
+    a->nframes++;
+    free(dep); free(bits);
+}
+
+/* DecodeC aerol.cpp:2187-2502 */
+static void c_write(jo_aerol *a, const int16_t *sb, long n)
+{
+    for (long i = 0; i < n; i++)
+    {
+        const long bitidx = a->nbits_total + i;
+        int bit = (((unsigned char)sb[i]) >= 128) ? 1 : 0;
+        unsigned short soft_bit = (unsigned short)sb[i];
+        int gotsync = 0;
+        a->realimag++; a->realimag %= 2;
+        const int q = a->realimag ? 0 : 1; /* realimag != 0: preambledetectorreal */
+        if (a->cntr > a->NumberOfBits - 112 || a->cntr <= 0)
+        {
+            gotsync = cpd_update(a, q, bit);
+            if (!a->gotsync_last) { a->gotsync_last = gotsync; gotsync = 0; }
+            else a->gotsync_last = 0;
+        }
+        else { gotsync = 0; a->gotsync_last = 0; }
+        if (a->cpd[q].inverted)
+        {
+            bit = 1 - bit;
+            if (soft_bit > 128) soft_bit = 255 - soft_bit;
+            else if (soft_bit < 128) soft_bit = 255 - soft_bit;
+        }
+        if (gotsync)
+        {
+            a->cntr = -1; a->cindex = -1;
+            a->ncdel = 0;
+            a->scr_pos = 0;
+            ev(a, bitidx, 2, 1);
+        }
+        else
+        {
+            if (a->cntr < 1000000000) a->cntr++;
+            if (a->cntr <= a->NumberOfBits - 1) { a->cindex++; a->block[a->cindex] = soft_bit; }
+            if (a->cindex == 255)
+            {
+                /* leaver.deinterleave_ba(block, 4) appended to deleaveredBlock :2306-2316 */
+                for (int j = 0; j < 4; j++)
+                    for (int k = 0; k < 64; k++)
+                        if (a->ncdel < (int)sizeof(a->cdel)) a->cdel[a->ncdel++] = (unsigned char)a->block[a->depermute[k] * 4 + j];
+                a->cindex = -1;
+            }
+            if (a->cntr == a->NumberOfBits - 1) { c_frame_done(a, bitidx); a->cindex = -1; }
+        }
+    }
+    a->nbits_total += n;
+}
+
 void jo_aerol_write(jo_aerol *a, const int16_t *sb, long n)
 {
+    if (a->ifb == 8400) { c_write(a, sb, n); return; } /* processDemodulatedSoftBits :2084-2087 */
     /* Decode(): decodedbytes.clear() etc. are text; the loop :1131-2027 */
     for (long i = 0; i < n; i++)
     {

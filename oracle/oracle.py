@@ -141,6 +141,8 @@ def lib():
         L.jo_aerol_take_sus.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.jo_aerol_take_events.restype = C.c_long
         L.jo_aerol_take_events.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        L.jo_aerol_take_voice.restype = C.c_long
+        L.jo_aerol_take_voice.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.jo_aerol_dcd.argtypes = [C.c_void_p]
         L.jo_aerol_tick_dcd.argtypes = [C.c_void_p]
         L.jo_aerol_tick_dcd.restype = C.c_int
@@ -369,6 +371,12 @@ class AeroL:
         """burst mode: rows [packet, chunk, 12 bytes, total bytes, type (1 R, 2 T)]"""
         return _drain(self.L.jo_aerol_take_packets, self.h, 16, np.int32)
 
+    def take_voice(self):
+        """C channel (fb 8400): (frame numbers uint32[n], voice bytes uint8[n, 300]) as handed to Voicesignal (aerol.cpp:2454-2481)"""
+        rows = _drain(self.L.jo_aerol_take_voice, self.h, 304, np.uint8)
+        rows = rows.reshape(-1, 304)
+        return rows[:, :4].copy().view(np.uint32).reshape(-1), rows[:, 4:]
+
     @property
     def dcd(self):
         return self.L.jo_aerol_dcd(self.h)
@@ -451,6 +459,32 @@ def run_ref_aerol_burst(fb: int, soft: np.ndarray):
         if m and pk and isinstance(pk[-1], list):
             pk[-1][3].append(bytes(int(x, 16) for x in m.group(1).split()))
     return pk, bad, txt
+
+
+def run_ref_aerol_c(soft: np.ndarray, group: int = 32):
+    """The unmodified AeroL at fb = 8400 (DecodeC): (voice uint8[nframes, 300] from the Voicesignal(data, hex) emissions, list of the
+    10 payload bytes of every sub-band signal unit it printed (crc ok, carrier detected, not a fill-in unit), DCD lines, raw text)."""
+    import re
+
+    assert have_ref()
+    with tempfile.TemporaryDirectory() as td:
+        inp, outp = os.path.join(td, "soft.s16"), os.path.join(td, "out.txt")
+        np.ascontiguousarray(soft, dtype=np.int16).tofile(inp)
+        env = dict(os.environ)
+        env["QT_QPA_PLATFORM"] = "offscreen"
+        subprocess.check_call([REF_BIN, "aerol", inp, outp, "fb=8400", f"group={group}"], env=env, stdout=subprocess.DEVNULL)
+        txt = open(outp, "rb").read().decode("latin1")
+    voice, sus, dcd = [], [], []
+    for line in txt.split("\n"):
+        if line.startswith("#V "):
+            voice.append(np.frombuffer(bytes.fromhex(line[3:].strip()), dtype=np.uint8))
+        elif line.startswith("#DCD"):
+            dcd.append(tuple(int(x) for x in line.split()[1:3]))
+        else:
+            m = re.match(r"^((?: 0x[0-9A-F]{2}){10}) ", line)
+            if m:
+                sus.append(bytes(int(x, 16) for x in m.group(1).split()))
+    return (np.stack(voice) if voice else np.zeros((0, 300), np.uint8)), sus, dcd, txt
 
 
 def run_ref_aerol(fb: int, soft: np.ndarray, group: int = 32):

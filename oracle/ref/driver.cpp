@@ -11,7 +11,7 @@
 //       same outputs; the soft stream keeps the -1 start-of-burst markers; one status row per SignalStatus emission,
 //       plus <outprefix>.events float64 rows [sample index of the write that carried it, kind, value]:
 //       kind 0 = SignalStatus(value), 1 = EbNoMeasurmentSignal(value), 2 = Plottables freq_est
-//   jaero_ref aerol <in.s16 soft bits> <out.txt> fb=10500|1200|600 [group=32] [burst=0]
+//   jaero_ref aerol <in.s16 soft bits> <out.txt> fb=10500|1200|600|8400 [group=32] [burst=0]
 //       the UNMODIFIED AeroL (JAERO/aerol.cpp): soft bits are handed to processDemodulatedSoftBits in groups, what it writes to its
 //       sink device (signal-unit dumps, "Bad CRC", ...) goes to <out.txt>; DataCarrierDetect emissions are interleaved as
 //       lines "#DCD <0|1> <index of the first soft bit of the group that carried it>"
@@ -258,6 +258,9 @@ int main(int argc, char **argv)
         long gstart = 0;
         QByteArray dcdlog;
         QObject::connect(&a, &AeroL::DataCarrierDetect, [&](bool d) { sink.write(QString("#DCD %1 %2\n").arg(d ? 1 : 0).arg(gstart).toLatin1()); });
+        // C channel (fb=8400): the voice bytes DecodeC hands to Voicesignal(data, hex), one "#V <hex>" line per frame
+        QObject::connect(&a, static_cast<void (AeroL::*)(QByteArray &, QString &)>(&AeroL::Voicesignal),
+                         [&](QByteArray &d, QString &) { sink.write(QByteArray("#V ") + d.toHex() + "\n"); });
         a.setSettings(getd("fb", 10500), geti("burst", 0) != 0);
         int group = geti("group", 32);
         // group=0: the groups a burst demodulator emits (burstoqpskdemodulator.cpp:546-585): a start-of-burst marker (negative) is one

@@ -140,6 +140,21 @@ def aerol():
         print("aerol", fb, soft.shape, rows.shape, "crc ok", int(rows[:, 11].sum()))
 
 
+def aerol_c():
+    """Aero-L C channel (SURVEY 8 row f4, second half): what the UNMODIFIED AeroL::DecodeC hands to Voicesignal(data, hex) per frame
+    and the signal units it prints.  The first frame after start-up is excluded from the voice fixture's last byte: its three low
+    bits come from bytes of JConvolutionalCodec::decoded that libcorrect never wrote (jconvolutionalcodec.cpp:165-169, first call)."""
+    assert O.have_ref()
+    from jaero_amd import aerol_frames as AF
+    frames, soft = AF.c_channel_case(8401, 7, 24.0, inv=(True, False))
+    voice, sus, dcd, _ = O.run_ref_aerol_c(soft, 32)
+    np.savez_compressed(os.path.join(HERE, "aerol_c_8400_a.npz"), soft=soft, group=32, voice=voice,
+                        sus=np.array([list(b) for b in sus], dtype=np.uint8).reshape(-1, 10),
+                        voice_in=np.stack([f[0] for f in frames]),
+                        sus_in=np.array([[list(p) for p in f[1]] for f in frames], dtype=np.uint8))
+    print("aerol_c", soft.shape, voice.shape, len(sus), dcd)
+
+
 def rt_case(seed, sigma, inv=(False, False), cut=False):
     """A burst-demodulator soft-bit stream with R and T packets (see aerol_frames.rt_burst_stream)."""
     from jaero_amd import aerol_frames as AF
@@ -222,8 +237,11 @@ if __name__ == "__main__":
         burst()
     elif len(sys.argv) > 1 and sys.argv[1] == "aerol":
         aerol()
+    elif len(sys.argv) > 1 and sys.argv[1] == "aerolc":
+        aerol_c()
     else:
         main()
         burst()
         aerol()
         aerol_burst()
+        aerol_c()
