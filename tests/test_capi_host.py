@@ -46,6 +46,19 @@ def test_no_cpu_fallback():
     assert L.jaero_strerror(rc) == b"no usable HIP device"
 
 
+def test_ingest_and_aerol_argument_checks_need_no_device():
+    """Null / out-of-range arguments are refused before any HIP call (codes and messages as the header documents)."""
+    L = capi.lib()
+    h = C.c_void_p()
+    assert L.jaero_ingest_create(None, 4096, 0, C.byref(h)) == capi.E_INVAL and not h.value
+    assert L.jaero_ingest_push(None, 0, b"", 0, 48000) == capi.E_INVAL
+    assert L.jaero_ingest_queued(None, 0) == capi.E_INVAL
+    assert L.jaero_ingest_pump(None, 0, None, None) == capi.E_INVAL
+    assert L.jaero_ingest_stats(None, None) == capi.E_INVAL
+    assert b"jaero_ingest" in L.jaero_last_error()
+    assert L.jaero_write(None, None, 0, 0, 0, None) == capi.E_INVAL
+
+
 def _oracle_triggers(O, kind, cpu_reduce, writes):
     d = O.Demod(O.oqpsk_settings() if kind == "oqpsk" else O.msk_settings(), cpu_reduce=cpu_reduce)
     trig, base = [], 0
