@@ -95,7 +95,7 @@ typedef struct jaero_settings
     int coarsefreqest_fft_power; /* 2^power point coarse-frequency FFT (13 or 14)  */
     double freq_center;          /* Hz                                             */
     double lockingbw;            /* Hz                                             */
-    double fb;                   /* bit rate: 10500 (OQPSK), 600 / 1200 (MSK)      */
+    double fb;                   /* bit rate: 10500 or 8400 (OQPSK; 8400: continuous kind, fft power 14), 600 / 1200 (MSK) */
     double Fs;                   /* sample rate, 48000                             */
     double signalthreshold;      /* mse threshold                                  */
 } jaero_settings;

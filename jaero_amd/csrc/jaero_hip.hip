@@ -20,6 +20,7 @@
 #include "jaero_device.h"
 #include "k_oqpsk.h"
 #include "k_msk.h"
+#include "k_pre8400.h"
 #include "k_coarse.h"
 #include "k_coarse2.h"
 #include "k_viterbi.h"
@@ -138,6 +139,11 @@ struct jaero_ctx
     int *d_emitted = nullptr; // burst banks: per-channel count of soft bits already emitted (jaero_softbits_view)
     bool coarse_v2 = false; int coarse3_grid = 256, coarse_ver = 4;
     int msk_ldsn = 0; // MSK: matched-filter inputs kept in LDS (the rest of fir_n in registers)
+    // fb == 8400 (k_pre8400.h): prefilter buffers, samples written so far, size of the previous write
+    bool pre8400 = false;
+    JPre pre{};
+    long long pre_n0 = 0;
+    int pre_nprev = 0;
     int *d_chanlist = nullptr;
     int coarse_grid = 0;
     bool coarse_v1 = false;  // JAERO_COARSE_V1=1 selects the four-step LDS/scratch FFT (kept for A/B validation)
@@ -324,7 +330,11 @@ static int validate_settings(const jaero_settings &s)
     if (s.kind < JAERO_KIND_MSK || s.kind > JAERO_KIND_BURST_OQPSK) return fail(JAERO_ENOTSUP, "kind %d not implemented", s.kind);
     if (s.Fs != 48000) return fail(JAERO_ENOTSUP, "only Fs=48000 is implemented (got %g)", s.Fs);
     const bool oq = s.kind == JAERO_KIND_OQPSK || s.kind == JAERO_KIND_BURST_OQPSK;
-    if (oq && s.fb != 10500) return fail(JAERO_ENOTSUP, "OQPSK: only fb=10500 is implemented (8400 C-channel: SURVEY 8f4)");
+    // fb = 8400 (C channel): the continuous demodulator with a 2^14-point coarse FFT (k_pre8400.h); JAERO_DISABLE_8400=1 refuses it
+    const char *no84 = getenv("JAERO_DISABLE_8400");
+    const bool allow84 = !(no84 && atoi(no84) != 0) && s.kind == JAERO_KIND_OQPSK && s.coarsefreqest_fft_power == 14;
+    if (oq && s.fb != 10500 && !(s.fb == 8400 && allow84))
+        return fail(JAERO_ENOTSUP, "OQPSK: fb must be 10500, or 8400 for the continuous demodulator with coarsefreqest_fft_power 14");
     if (!oq && s.fb != 600 && s.fb != 1200) return fail(JAERO_ENOTSUP, "MSK: fb must be 600 or 1200");
     const bool burst = s.kind >= JAERO_KIND_BURST_MSK;
     if (!burst && s.coarsefreqest_fft_power != 13 && s.coarsefreqest_fft_power != 14) return fail(JAERO_ENOTSUP, "coarsefreqest_fft_power must be 13 or 14");
@@ -348,6 +358,8 @@ static void init_channel_scalars(const jaero_ctx *c, const jaero_settings &s, st
     SS(S_LOCKINGBW) = s.lockingbw; SS(S_THRESH) = s.signalthreshold;
     if (fresh)
     {
+        SS(S_PRE_PTR) = 0; SS(S_PRE_FSUM) = 0;
+        SS(S_PRE_STEP) = 8000.0 * ((double)JD_WTSIZE) / ((float)(double)(int)s.Fs); // mixer_fir_pre.SetFreq(freq_center, Fs) in the ctor: 8000 Hz
         SS(S_M2_PTR) = 0; SS(S_MC_PTR) = 0; SS(S_ST_PTR) = 0; SS(S_ST_LAST) = 0;
         SS(S_MSE) = (s.kind == JAERO_KIND_OQPSK) ? 100.0 : 10.0;
         SS(S_DIFF_LAST) = -1.0;
@@ -374,6 +386,12 @@ static void fill_geometry(JGeom &g, const jaero_settings &s, int nch, unsigned f
         g.w4 = delay_weight(T / 4.0); g.w8 = delay_weight(T / 8.0);
         g.res_b0 = 0.00032714218939589035; g.res_b1 = 0; g.res_b2 = 0.00032714218939589035;
         g.res_a1 = -0.39005299948210803; g.res_a2 = 0.99934571562120822;
+        if (s.fb == 8400) // the 10 Hz resonator and ee of oqpskdemodulator.cpp:231-251
+        {
+            g.res_b0 = 0.0012845857864470789; g.res_b1 = 0; g.res_b2 = -0.0012845857864470789;
+            g.res_a1 = -0.90681461999279889; g.res_a2 = 0.99743082842710584;
+            g.ee = 0.65;
+        }
         g.lf_b0 = 0.0010275610653672064; g.lf_b1 = 0.0020551221307344128; g.lf_b2 = 0.0010275610653672064;
         g.lf_a1 = -1.9207386815577139; g.lf_a2 = 0.92509247310306331;
         g.stref_freq = s.fb;
@@ -497,6 +515,23 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
     DA(c->p.pm, (size_t)nchp * g.pm_len);
     DA(c->p.msema, (size_t)nchp * g.msema_len);
     DA(c->p.firsave, (size_t)ng * 2 * g.fir_n * 64);
+    if (g.kind == JAERO_KIND_OQPSK && g.fb == 8400)
+    {
+        c->pre8400 = true;
+        int ring = 1;
+        while (ring < max_write_samples + 2 * PRE_L) ring <<= 1;
+        c->pre.ring = ring;
+        DA(c->pre.xring, (size_t)ring * nchp);
+        DA(c->pre.cidx, (size_t)max_write_samples * nchp);
+        DA(c->pre.out, (size_t)max_write_samples * nchp);
+        double *d_pre_taps = nullptr;
+        DA(d_pre_taps, PRE_K);
+        const std::vector<double> pt = rrc_design(0.6, 2048, g.Fs, g.fb / 2); // rrc_pre_imp (oqpskdemodulator.cpp:281)
+        if ((int)pt.size() != PRE_K) { jaero_destroy(c); return fail(JAERO_EHIP, "prefilter design returned %zu taps", pt.size()); }
+        HIPCHK(hipMemcpy(d_pre_taps, pt.data(), sizeof(double) * PRE_K, hipMemcpyHostToDevice));
+        c->pre.taps = d_pre_taps;
+        HIPCHK(hipFuncSetAttribute((const void *)k_coarse4_w8400, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 257 * (int)sizeof(double)));
+    }
     if (g.kind == JAERO_KIND_MSK) { DA(c->p.dly, (size_t)ng * (g.sps + 1) * 64); DA(c->p.dly8, (size_t)ng * (g.sps2 + 1) * 64); }
     DA(c->p.soft, (size_t)nchp * g.soft_cap);
     if (g.sym_cap) DA(c->p.sym, (size_t)nchp * g.sym_cap * 3);
@@ -535,7 +570,7 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         for (int i = 0; i < g.nfft; i++) { double a = -2.0 * M_PI * ((double)i) / ((double)g.nfft); tw[i].x = cos(a); tw[i].y = sin(a); }
         HIPCHK(hipMemcpy(c->d_tw, tw.data(), sizeof(double2) * g.nfft, hipMemcpyHostToDevice));
         std::vector<double> taps;
-        if (g.kind == JAERO_KIND_OQPSK) taps = rrc_design(1.0, 55, g.Fs, g.fb / 2);
+        if (g.kind == JAERO_KIND_OQPSK) taps = rrc_design(g.fb == 8400 ? 0.6 : 1.0, 55, g.Fs, g.fb / 2);
         else
         {
             taps.resize(g.fir_n);
@@ -758,7 +793,7 @@ extern "C" int jaero_profile_read(jaero_ctx *c, int which, double *total_ms, int
 }
 
 // ------------------------------------------------------------------------------------------ write
-static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int n, int skipA, int onlyA, hipStream_t st)
+static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int n, int skipA, int onlyA, hipStream_t st, int pos)
 {
     const JGeom &g = c->g;
     const bool eb = (c->flags & JAERO_FLAG_EBNO) != 0, cs = (c->flags & JAERO_FLAG_CAPTURE_SYMBOLS) != 0;
@@ -768,7 +803,11 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
         const int lds = (2 * OQ_LDSN * 64 + 64) * (int)sizeof(double); // rings + this wavefront's copy of the 55 taps
         const int fs = (int)(c->m.nB_total % OQ_LDSN);
 #define LO(E, C) hipLaunchKernelGGL((k_oqpsk_samples<55, OQ_LDSN, E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs)
-        if (eb && cs) LO(true, true); else if (eb) LO(true, false); else if (cs) LO(false, true); else LO(false, false);
+#define LO84(E, C) hipLaunchKernelGGL((k_oqpsk_samples_8400<55, OQ_LDSN, E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs, \
+                                      (const double2 *)(c->pre.out + (size_t)pos * g.nchp))
+        if (c->pre8400) { if (eb && cs) LO84(true, true); else if (eb) LO84(true, false); else if (cs) LO84(false, true); else LO84(false, false); }
+        else if (eb && cs) LO(true, true); else if (eb) LO(true, false); else if (cs) LO(false, true); else LO(false, false);
+#undef LO84
 #undef LO
     }
     else
@@ -793,8 +832,12 @@ static void launch_coarse(jaero_ctx *c, const int *d_list, int nlist, hipStream_
         if (c->g.nfft_log2 == 14 && c->coarse_ver == 4)
         {
             // 2^14 = 16 x 16 x 16 x 4, 16-point register FFTs only (k_coarse4); one padded plane of 64*257 doubles in LDS
-            hipLaunchKernelGGL(k_coarse4, dim3(nlist < c->coarse3_grid ? nlist : c->coarse3_grid), dim3(C2_THREADS), 64 * 257 * (int)sizeof(double), st, c->g, c->p,
-                               d_list, nlist, c->d_tw);
+            if (c->pre8400)
+                hipLaunchKernelGGL(k_coarse4_w8400, dim3(nlist < c->coarse3_grid ? nlist : c->coarse3_grid), dim3(C2_THREADS), 64 * 257 * (int)sizeof(double), st,
+                                   c->g, c->p, d_list, nlist, c->d_tw);
+            else
+                hipLaunchKernelGGL(k_coarse4, dim3(nlist < c->coarse3_grid ? nlist : c->coarse3_grid), dim3(C2_THREADS), 64 * 257 * (int)sizeof(double), st, c->g, c->p,
+                                   d_list, nlist, c->d_tw);
         }
         else if (c->g.nfft_log2 == 14 && !c->coarse_v2)
         {
@@ -845,6 +888,15 @@ extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int l
         frames = c->d_pcm_frames; stride = nchp;
     }
 
+    if (c->pre8400)
+    {
+        // the whole write is prefiltered first (oqpskdemodulator.cpp:343-381); its oscillator takes the mean of mixer2's frequency over
+        // the previous write (:607-608)
+        hipLaunchKernelGGL(k_pre8400_mix, dim3(g.ngroups), dim3(64), 0, st, g, c->p, c->pre, frames, stride, nsamples, c->pre_n0, c->pre_nprev);
+        hipLaunchKernelGGL(k_pre8400_fir, dim3(g.ngroups, (nsamples + 4 * PRE_R - 1) / (4 * PRE_R)), dim3(256), 0, st, g, c->p, c->pre, nsamples, c->pre_n0);
+        c->pre_n0 += nsamples;
+        c->pre_nprev = nsamples;
+    }
     int pos = 0;
     while (pos < nsamples)
     {
@@ -856,7 +908,7 @@ extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int l
             const long long nb_after = c->m.nB_total;
             c->m.nB_total = nb_before; // ring slots are those at the START of the segment
             const int pi = prof_begin(c, 0, st);
-            launch_samples(c, frames + (size_t)pos * stride, stride, n, skip_a, only_a, st);
+            launch_samples(c, frames + (size_t)pos * stride, stride, n, skip_a, only_a, st, pos);
             prof_end(c, pi, st);
             c->m.nB_total = nb_after;
         }

@@ -877,8 +877,10 @@ __device__ __forceinline__ void c4_fft(CV<32> &d, double *xch, const double2 *__
 // Measured (MI355X, 65536 estimates per launch): 20.2 ms (k_coarse3 24.7, k_coarse2<14> 28.5); 64 bytes of scratch per thread
 // instead of ~500, i.e. the ~48 GB of spill traffic per launch are gone.  Then 14.9 ms with no scratch at all, once no load is
 // waited for where it is issued (pass-3 twiddles as literals, table values and y[] requested ahead).
-__global__ __launch_bounds__(C2_THREADS) void k_coarse4(const JGeom g, const JPtrs p, const int *__restrict__ chan_list,
-                                                           int nlist, const double2 *__restrict__ tw)
+// W8400 (fb == 8400, k_pre8400.h): the band limit is the centre-weighted window of coarsefreqestimate.cpp:61-74,100
+// instead of the boxcar of :99.
+template <bool W8400>
+__device__ __forceinline__ void coarse4_body(const JGeom g, const JPtrs p, const int *__restrict__ chan_list, int nlist, const double2 *__restrict__ tw)
 {
     constexpr int N = 1 << 14;
     constexpr int E = 32;
@@ -921,9 +923,22 @@ __global__ __launch_bounds__(C2_THREADS) void k_coarse4(const JGeom g, const JPt
         for (int s = 0; s < E; s++)
         {
             const int k = s * C2_THREADS + t;
-            const bool z = (k >= startbin) && (k <= stopbin);
-            const double re = z ? 0.0 : d.r[s], im = z ? 0.0 : d.i[s];
-            d.r[s] = im; d.i[s] = re;
+            if constexpr (!W8400)
+            {
+                const bool z = (k >= startbin) && (k <= stopbin);
+                const double re = z ? 0.0 : d.r[s], im = z ? 0.0 : d.i[s];
+                d.r[s] = im; d.i[s] = re;
+            }
+            else
+            {
+                // window[0] = 1, window[i] = window[N - i] = cos^2(pi/2 * i / startbin) for 1 <= i <= startbin, 0 elsewhere
+                const int i = (k <= N / 2) ? k : N - k;
+                double w = 0.0;
+                if (i <= startbin) { const double c = cos(M_PI_2 * ((double)i) / ((double)startbin)); w = c * c; }
+                if (k == 0) w = 1.0;
+                const double re = d.r[s] * w, im = d.i[s] * w;
+                d.r[s] = im; d.i[s] = re;
+            }
         }
         c4_fft(d, xch, tw, t);
         // swap back (x N / N = 1), square
@@ -1016,6 +1031,17 @@ __global__ __launch_bounds__(C2_THREADS) void k_coarse4(const JGeom g, const JPt
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(C2_THREADS) void k_coarse4(const JGeom g, const JPtrs p, const int *__restrict__ chan_list,
+                                                           int nlist, const double2 *__restrict__ tw)
+{
+    coarse4_body<false>(g, p, chan_list, nlist, tw);
+}
+__global__ __launch_bounds__(C2_THREADS) void k_coarse4_w8400(const JGeom g, const JPtrs p, const int *__restrict__ chan_list,
+                                                                 int nlist, const double2 *__restrict__ tw)
+{
+    coarse4_body<true>(g, p, chan_list, nlist, tw);
 }
 
 

@@ -18,9 +18,13 @@
 // wavefronts (one per SIMD) fit a CU's 160 KiB.  The filter output for sample n+1 depends only on inputs up to sample n
 // (FIR::FIRUpdateAndProcess excludes the newest sample, DSP.cpp:292-304), so it is evaluated one iteration ahead of the
 // serial AGC/timing/carrier chain and overlaps with it.
-template <int FIRN, int LDSN, bool EBNO, bool CAPSYM>
-__global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs p, const int16_t *__restrict__ pcm,
-                                                      int pcm_stride, int n, int skip_a_first, int only_a_last, int fir_slot0)
+// PRE8400 (fb == 8400, see k_pre8400.h): the sample is the prefiltered complex value of k_pre8400_fir mixed with
+// mixer2 instead of PCM x mixer2 through the 55-tap filter (oqpskdemodulator.cpp:434-448), the carrier loop takes the <= 8400 branch
+// (:526-532) and mixer2's frequency is summed over the write for the prefilter's oscillator (:447,607).  Every difference is under
+// `if constexpr`, so the other instantiations compile to what they were.
+template <int FIRN, int LDSN, bool EBNO, bool CAPSYM, bool PRE8400>
+__device__ __forceinline__ void oqpsk_samples_body(const JGeom g, const JPtrs p, const int16_t *__restrict__ pcm, int pcm_stride, int n,
+                                                   int skip_a_first, int only_a_last, int fir_slot0, const double2 *__restrict__ prefilt)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *lre = lds;              // [LDSN][64]
@@ -90,8 +94,11 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
     double *ltap = lds + 2 * LDSN * 64; // [FIRN] this wavefront's copy of the taps
     if (lane < FIRN) ltap[lane] = taps[lane];
     auto fir_eval = [&](double &ore, double &oim) { jd_fir_eval<FIRN, LDSN, 8>(lre, lim, ltap, tre, tim, fir_slot, lane, ore, oim); };
-    double ycur_re, ycur_im;
-    fir_eval(ycur_re, ycur_im);
+    double ycur_re = 0, ycur_im = 0;
+    if constexpr (!PRE8400) fir_eval(ycur_re, ycur_im);
+    double m2fsum = 0; // PRE8400: mixer2_freq_sum of this launch
+    double2 nx_pf = make_double2(0.0, 0.0);
+    if constexpr (PRE8400) nx_pf = prefilt[ch];
 
     const double w4 = g.w4, w4c = 1.0 - g.w4, w8 = g.w8, w8c = 1.0 - g.w8;
     const double agc_len_d = (double)g.agc_len, eb_len_d = (double)g.ebno_len;
@@ -141,6 +148,15 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
         // ---- K2 mix + K6 matched filter (:453-456, DSP.cpp:292-304) ----
         // this sample's filter output was evaluated one iteration ago; push x[n] and evaluate the next one now
         double sre = ycur_re, sim = ycur_im;
+        if constexpr (PRE8400)
+        {
+            // sig2 = mixer2.WTCISValue() * cval_prefiltered[i]
+            const double2 pf = nx_pf;
+            sre = c_m2.x * pf.x - c_m2.y * pf.y;
+            sim = c_m2.x * pf.y + c_m2.y * pf.x;
+            m2fsum += m2_freq;
+            if (i + 1 < n) nx_pf = prefilt[(size_t)(i + 1) * nchp + ch];
+        }
 
         // ---- K7 EbNo (DSP.cpp:729-744) ----
         const double dabval = sqrt(sre * sre + sim * sim);
@@ -261,17 +277,30 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
                 double ct_ec = ct_xt_d - ct_xt;
                 if (ct_ec > M_PI) ct_ec = M_PI;
                 if (ct_ec < -M_PI) ct_ec = -M_PI;
+                if constexpr (!PRE8400)
                 {
+                    {
+                        double y = 0;
+                        y += lf_x2 * g.lf_b2; y += lf_x1 * g.lf_b1; y += ct_ec * g.lf_b0;
+                        y -= lf_y2 * g.lf_a2; y -= lf_y1 * g.lf_a1;
+                        lf_x2 = lf_x1; lf_x1 = ct_ec; lf_y2 = lf_y1; lf_y1 = y;
+                        ct_ec = y;
+                    }
+                    if (ct_ec > M_PI_2) ct_ec = M_PI_2;
+                    if (ct_ec < -M_PI_2) ct_ec = -M_PI_2;
+                    jd_wt_inc_phase_deg(m2_ptr, 1.0 * ct_ec);
+                    jd_wt_setfreq(m2_freq, m2_step, (0.01 * ct_ec) + m2_freq, samplerate);
+                }
+                else
+                {
+                    // 8400 works better with faster phase agility (:526-532): the raw error moves the phase, the filtered one the frequency
                     double y = 0;
                     y += lf_x2 * g.lf_b2; y += lf_x1 * g.lf_b1; y += ct_ec * g.lf_b0;
                     y -= lf_y2 * g.lf_a2; y -= lf_y1 * g.lf_a1;
                     lf_x2 = lf_x1; lf_x1 = ct_ec; lf_y2 = lf_y1; lf_y1 = y;
-                    ct_ec = y;
+                    jd_wt_inc_phase_deg(m2_ptr, 1.0 * ct_ec);
+                    jd_wt_setfreq(m2_freq, m2_step, (0.5 * 0.01 * y) + m2_freq, samplerate);
                 }
-                if (ct_ec > M_PI_2) ct_ec = M_PI_2;
-                if (ct_ec < -M_PI_2) ct_ec = -M_PI_2;
-                jd_wt_inc_phase_deg(m2_ptr, 1.0 * ct_ec);
-                jd_wt_setfreq(m2_freq, m2_step, (0.01 * ct_ec) + m2_freq, samplerate);
 
                 // marg->UpdateSigned(ct_ec)
                 {
@@ -347,6 +376,7 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
         }
 
         // ---- push x[n] (mixed with the carrier phase this sample started with) and evaluate the filter for n+1 ----
+        if constexpr (!PRE8400)
         {
             const double cre = c_m2.x * dval, cim = c_m2.y * dval;
 #pragma unroll
@@ -383,6 +413,7 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
     LDF(S_LF_X1) = lf_x1; LDF(S_LF_X2) = lf_x2; LDF(S_LF_Y1) = lf_y1; LDF(S_LF_Y2) = lf_y2;
     LDF(S_SIG2L_RE) = sig2l_re; LDF(S_SIG2L_IM) = sig2l_im; LDF(S_PTD_RE) = ptd_re; LDF(S_PTD_IM) = ptd_im;
     LDF(S_MARG_SUM) = marg_sum; LDF(S_PM_SUM) = pm_sum; LDF(S_MSEMA_SUM) = msema_sum; LDF(S_MSE) = mse;
+    if constexpr (PRE8400) LDF(S_PRE_FSUM) = LDF(S_PRE_FSUM) + m2fsum;
     LDI(I_AGC_POS) = agc_pos; LDI(I_EB_POS) = eb_pos; LDI(I_BB_PTR) = bb_ptr; LDI(I_COARSE_CNT) = coarse_cnt;
     LDI(I_MARG_POS) = marg_pos; LDI(I_DT_POS) = dt_pos; LDI(I_PM_POS) = pm_pos; LDI(I_MSEMA_POS) = msema_pos;
     LDI(I_YUI) = yui; LDI(I_SIG2L_INIT) = sig2l_init;
@@ -402,3 +433,19 @@ __global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs
         }
     }
 }
+
+template <int FIRN, int LDSN, bool EBNO, bool CAPSYM>
+__global__ __launch_bounds__(64) void k_oqpsk_samples(const JGeom g, const JPtrs p, const int16_t *__restrict__ pcm,
+                                                      int pcm_stride, int n, int skip_a_first, int only_a_last, int fir_slot0)
+{
+    oqpsk_samples_body<FIRN, LDSN, EBNO, CAPSYM, false>(g, p, pcm, pcm_stride, n, skip_a_first, only_a_last, fir_slot0, nullptr);
+}
+
+// fb == 8400: `prefilt` = this segment's rows of JPre::out
+template <int FIRN, int LDSN, bool EBNO, bool CAPSYM>
+__global__ __launch_bounds__(64) void k_oqpsk_samples_8400(const JGeom g, const JPtrs p, const int16_t *__restrict__ pcm, int pcm_stride, int n,
+                                                           int skip_a_first, int only_a_last, int fir_slot0, const double2 *__restrict__ prefilt)
+{
+    oqpsk_samples_body<FIRN, LDSN, EBNO, CAPSYM, true>(g, p, pcm, pcm_stride, n, skip_a_first, only_a_last, fir_slot0, prefilt);
+}
+

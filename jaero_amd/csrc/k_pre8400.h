@@ -1,0 +1,130 @@
+// k_pre8400.h -- prefilter of the 8400 bps C-channel branch of OqpskDemodulator::writeData.
+//
+// Written from the oracle restatement (oracle/jaero_oracle.c, fb == 8400); on an MI355X it reproduces the two reference goldens
+// (every soft byte, estimate frequencies to 5e-12) and, in banks of 5 and 67 channels, the oracle (tests/test_gpu_parity.py).  Not
+// measured or tuned yet: the prefilter costs about as much as the rest of the path, and k_coarse4_w8400 spills.
+//
+// Reference (JAERO/oqpskdemodulator.cpp:343-381): for the whole write, PCM is mixed down with mixer_fir_pre, filtered with
+// JFastFir (kernel RRC alpha 0.6, 2049 taps, nfft 4096: out[m] = sum_k h[k] x[m - L - k], L = nfft - K + 1 = 2048, the behaviour
+// JAERO/tests/jfastfir_tests.cpp pins), and mixed up again with the conjugate of the same oscillator restarted from the phase it
+// had before the write.  At the end of every write the oscillator's frequency becomes the mean of mixer2's over that write
+// (:607-608).  Here:
+//   k_pre8400_mix  one lane per channel, sequential over the write (the oscillator phase is a running sum): down-mixed samples go
+//                  into a per-channel history ring xring[slot][channel], the up-mix table index of every sample into cidx
+//   k_pre8400_fir  time-parallel direct-form FIR on the ring (taps folded by symmetry: 1024 pairs + the centre), then the up-mix;
+//                  NOT bit-identical to the FFT overlap-add of the reference (same sum, other order): the soft-symbol tolerance
+//                  of the north star applies, as for the Hilbert filter of the burst path
+#pragma once
+#include "jaero_device.h"
+
+#define PRE_K 2049                 // taps
+#define PRE_L 2048                 // JFastFir latency nfft - K + 1
+#define PRE_R 8                    // outputs per lane and tile
+#define PRE_U 8                    // tap pairs per step
+
+struct JPre
+{
+    double2 *xring;        // [ring][nchp] down-mixed history, slot = absolute sample index & (ring - 1)
+    unsigned short *cidx;  // [max_write][nchp] table index of the up-mix oscillator for every sample of the current write
+    double2 *out;          // [max_write][nchp] prefiltered samples of the current write (cval_prefiltered)
+    const double *taps;    // [PRE_K]
+    int ring;              // power of two >= max_write + 2 * PRE_L
+};
+
+// fields of JPtrs::S used by the prefilter (appended to the state enum in jaero_device.h): S_PRE_PTR, S_PRE_STEP, S_PRE_FSUM
+
+__global__ __launch_bounds__(64) void k_pre8400_mix(const JGeom g, const JPtrs p, const JPre q, const int16_t *__restrict__ pcm, int pcm_stride,
+                                                    int n, long long n0, int nprev)
+{
+    const int lane = threadIdx.x, ch = blockIdx.x * 64 + lane, nchp = g.nchp;
+    const bool live = ch < g.nch;
+    double ptr = p.S[(size_t)S_PRE_PTR * nchp + ch], step = p.S[(size_t)S_PRE_STEP * nchp + ch];
+    if (nprev > 0)
+    {
+        // mixer_fir_pre.SetFreq(mixer2_freq_sum / i) at the end of the previous write (WaveTable::SetFreq(double), DSP.cpp:151-156)
+        double freq = p.S[(size_t)S_PRE_FSUM * nchp + ch] / ((double)nprev);
+        if (freq < 0) freq = 0;
+        step = (freq) * ((double)JD_WTSIZE) / 48000.0;
+        p.S[(size_t)S_PRE_FSUM * nchp + ch] = 0.0;
+    }
+    const double2 *__restrict__ cis = p.cis;
+    const int rmask = q.ring - 1;
+    // down (:354-364)
+    const double savedphase = (360.0 * ptr / ((double)JD_WTSIZE)); // GetPhaseDeg
+    double pd = ptr, sd = step;
+    for (int i = 0; i < n; i++)
+    {
+        const short s = live ? pcm[(size_t)i * pcm_stride + ch] : (short)0;
+        const double dval = ((double)s) / 32768.0;
+        const double2 c = cis[jd_cisidx(pd)];
+        q.xring[(size_t)((int)((n0 + i) & rmask)) * nchp + ch] = make_double2(c.x * dval, c.y * dval);
+        jd_wt_next(pd, sd);
+    }
+    // up (:371-379): SetPhaseDeg(savedphase), then the same number of frames
+    double phase = fmod(savedphase, 360.0);
+    while (phase < 0) phase += 360.0;
+    double pu = (phase / 360.0) * ((double)JD_WTSIZE), su = step;
+    for (int i = 0; i < n; i++)
+    {
+        q.cidx[(size_t)i * nchp + ch] = (unsigned short)jd_cisidx(pu);
+        jd_wt_next(pu, su);
+    }
+    p.S[(size_t)S_PRE_PTR * nchp + ch] = pu;
+    p.S[(size_t)S_PRE_STEP * nchp + ch] = su;
+}
+
+// grid (nchp / 64, ceil(n / (4 * PRE_R))), 256 threads: wavefront w of a block handles outputs i0 .. i0 + PRE_R - 1 of 64 channels
+__global__ __launch_bounds__(256) void k_pre8400_fir(const JGeom g, const JPtrs p, const JPre q, int n, long long n0)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ch = blockIdx.x * 64 + lane, nchp = g.nchp;
+    const int i0 = (blockIdx.y * 4 + wv) * PRE_R;
+    if (i0 >= n) return;
+    const int rmask = q.ring - 1;
+    const double2 *__restrict__ xr = q.xring + ch;
+    const double *__restrict__ taps = q.taps;
+    // out[m] = h[1024] x[m-3072] + sum_{k<1024} h[k] (x[m-2048-k] + x[m-4096+k]),  m = n0 + i0 + r
+    const long long m0 = n0 + i0;
+    double are[PRE_R], aim[PRE_R];
+#pragma unroll
+    for (int r = 0; r < PRE_R; r++) { are[r] = 0.0; aim[r] = 0.0; }
+    constexpr int WN = PRE_R + PRE_U - 1;
+    for (int j0 = 0; j0 < 1024; j0 += PRE_U)
+    {
+        // window a: x[m0 - 2048 - j0 - (U-1) + w], w = r - u + (U-1);  window b: x[m0 - 4096 + j0 + w], w = r + u
+        double2 wa[WN], wb[WN];
+        const long long ba = m0 - PRE_L - j0 - (PRE_U - 1), bb = m0 - 2 * PRE_L + j0;
+#pragma unroll
+        for (int w = 0; w < WN; w++)
+        {
+            wa[w] = xr[(size_t)((int)((ba + w) & rmask)) * nchp];
+            wb[w] = xr[(size_t)((int)((bb + w) & rmask)) * nchp];
+        }
+#pragma unroll
+        for (int u = 0; u < PRE_U; u++)
+        {
+            const double tp = taps[j0 + u];
+#pragma unroll
+            for (int r = 0; r < PRE_R; r++)
+            {
+                const double2 a = wa[r - u + (PRE_U - 1)], b = wb[r + u];
+                are[r] = fma(tp, a.x + b.x, are[r]);
+                aim[r] = fma(tp, a.y + b.y, aim[r]);
+            }
+        }
+    }
+    const double tc = taps[1024];
+#pragma unroll
+    for (int r = 0; r < PRE_R; r++)
+    {
+        if (i0 + r < n)
+        {
+            const double2 c = xr[(size_t)((int)((m0 + r - 3 * 1024) & rmask)) * nchp];
+            const double yr = fma(tc, c.x, are[r]), yi = fma(tc, c.y, aim[r]);
+            // cval_prefiltered[i] *= mixer_fir_pre.WTCISValue_conj()
+            const double2 cj = p.cis[q.cidx[(size_t)(i0 + r) * nchp + ch]];
+            const double bre = cj.x, bim = -cj.y;
+            q.out[(size_t)(i0 + r) * nchp + ch] = make_double2(yr * bre - yi * bim, yr * bim + yi * bre);
+        }
+    }
+}

@@ -46,7 +46,8 @@ def bank_settings(kind, opts):
 
     if kind == "oqpsk":
         return OqpskSettings(freq_center=opts.get("freq_center", 8000.0), lockingbw=opts.get("lockingbw", 10500.0),
-                             coarsefreqest_fft_power=opts.get("power", 14), signalthreshold=opts.get("threshold", 0.65))
+                             fb=float(opts.get("fb", 10500.0)), coarsefreqest_fft_power=opts.get("power", 14),
+                             signalthreshold=opts.get("threshold", 0.65))
     return MskSettings(freq_center=opts.get("freq_center", 1000.0), lockingbw=opts.get("lockingbw", 1800.0),
                        fb=opts.get("fb", 1200.0), coarsefreqest_fft_power=opts.get("power", 13),
                        signalthreshold=opts.get("threshold", 0.5))

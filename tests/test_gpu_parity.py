@@ -3,6 +3,8 @@
 Contract (BASELINE.json north_star): hard decisions of the soft-bit stream bit-exact, soft symbols within 1e-5.
 In practice the soft bytes themselves are compared with |diff| <= 1 (rounding edges of qRound when the fp64 value
 differs in the last bits because device libm != glibc) and the hard decisions exactly."""
+import os
+
 import numpy as np
 import pytest
 
@@ -98,6 +100,29 @@ def test_alternative_kernels_against_reference_golden(B, monkeypatch, name, env)
     bank.close()
 
 
+@pytest.mark.parametrize("name", ["oqpsk_8400_default", "oqpsk_8400_afc_chunk1500_dcd"])
+def test_8400_against_reference_golden(B, name):
+    """SURVEY 8 row f4, demodulator half: the 8400 bps branch (direct-form prefilter instead of the reference's FFT overlap-add, so
+    soft bytes may differ by one at rounding edges; hard decisions, estimate count and frequencies must agree)."""
+    g = load_golden(name)
+    opts = g["opts"]
+    pcm = g["pcm"].reshape(1, -1)
+    from jaero_amd.demodulator import OqpskSettings
+    st = OqpskSettings(freq_center=8000.0, lockingbw=float(opts["lockingbw"]), fb=float(opts["fb"]), coarsefreqest_fft_power=14, signalthreshold=0.65)
+    bank = B.DemodulatorBank(st, 1, ebno=True, status_log=True, max_write_samples=8192, softbit_capacity=pcm.shape[1])
+    bank.set_flags(afc=bool(opts.get("afc", 0)), cpu_reduce=bool(opts.get("cpureduce", 0)))
+    feed(bank, pcm, opts.get("chunk", 4096), dcd_at=opts.get("dcd_at", -1))
+    soft, log = bank.read_softbits(0), bank.read_status_log(0)
+    n = len(g["soft"])
+    assert n <= len(soft) < n + 32
+    assert np.array_equal(soft[:n] >= 128, g["soft"] >= 128)
+    assert np.max(np.abs(soft[:n].astype(int) - g["soft"].astype(int)), initial=0) <= 1
+    assert log.shape == g["status"].shape
+    assert np.array_equal(log[:, [0, 5]], g["status"][:, [0, 5]])
+    assert np.max(np.abs(log[:, 1:4] - g["status"][:, 1:4])) < 1e-6
+    bank.close()
+
+
 @pytest.mark.parametrize("kind,nch,nsamp,chunk", [("oqpsk", 5, 96000, 4096), ("oqpsk", 67, 40000, 3000),
                                                   ("msk", 3, 96000, 5000), ("msk", 65, 30000, 4096)])
 def test_bank_vs_oracle(B, oracle_mod, kind, nch, nsamp, chunk):
@@ -113,6 +138,25 @@ def test_bank_vs_oracle(B, oracle_mod, kind, nch, nsamp, chunk):
     check = range(nch) if nch <= 8 else sorted({0, 1, 31, 63, 64, nch - 1})
     for c in check:
         ref = O.run_demod(oracle_settings(O, kind, opts), pcm[c], chunk=chunk, capture_symbols=True)
+        compare(bank.read_softbits(c), bank.read_symbols(c), bank.read_status_log(c), ref)
+    bank.close()
+
+
+@pytest.mark.parametrize("nch,nsamp,chunk", [(5, 110000, 4096), (67, 60000, 3000)])
+def test_8400_bank_vs_oracle(B, oracle_mod, nch, nsamp, chunk):
+    """Several 8400 bps channels with different carriers in one bank: every channel against its own oracle run (symbols within the
+    north star's 1e-5; the prefilter is a direct-form sum here and an FFT overlap-add there)."""
+    from jaero_amd import signalgen as G
+
+    O = oracle_mod
+    pcm, _, _ = G.channel_bank("oqpsk", nch, nsamp, ebno_db=11.0, seed0=G.SEED_BASE + 8400, fb=8400.0)
+    opts = {"fb": 8400.0, "lockingbw": 8400.0}
+    bank = B.DemodulatorBank([bank_settings("oqpsk", opts) for _ in range(nch)], ebno=True, status_log=True, capture_symbols=True,
+                             max_write_samples=chunk, softbit_capacity=nsamp)
+    feed(bank, pcm, chunk)
+    check = range(nch) if nch <= 8 else sorted({0, 1, 31, 63, 64, nch - 1})
+    for c in check:
+        ref = O.run_demod(oracle_settings(O, "oqpsk", opts), pcm[c], chunk=chunk, capture_symbols=True)
         compare(bank.read_softbits(c), bank.read_symbols(c), bank.read_status_log(c), ref)
     bank.close()
 
