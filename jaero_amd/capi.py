@@ -27,7 +27,7 @@ EXPORTS = [
     "jaero_num_channels", "jaero_strerror", "jaero_last_error", "jaero_profile_enable", "jaero_profile_read",
     "jaero_debug_schedule", "jaero_read_events",
     "jaero_aerol_create", "jaero_aerol_create_burst", "jaero_aerol_read_packets", "jaero_aerol_destroy", "jaero_aerol_write", "jaero_aerol_read_sus", "jaero_aerol_read_events",
-    "jaero_aerol_tick_dcd", "jaero_aerol_profile_enable", "jaero_aerol_profile_read",
+    "jaero_aerol_tick_dcd", "jaero_aerol_profile_enable", "jaero_aerol_profile_read", "jaero_aerol_read_voice",
     "jaero_ingest_create", "jaero_ingest_destroy", "jaero_ingest_push", "jaero_ingest_queued", "jaero_ingest_pump",
     "jaero_ingest_stats",
 ]
@@ -115,6 +115,7 @@ def lib():
     L.jaero_aerol_create.argtypes = [ip, ip, ip, ip, ip, C.POINTER(vp)]
     L.jaero_aerol_create_burst.argtypes = [ip, ip, ip, ip, ip, C.POINTER(vp)]
     L.jaero_aerol_read_packets.argtypes = [vp, ip, vp, ip, C.POINTER(ip)]
+    L.jaero_aerol_read_voice.argtypes = [vp, ip, vp, ip, C.POINTER(ip)]
     L.jaero_aerol_destroy.argtypes = [vp]
     L.jaero_aerol_destroy.restype = None
     L.jaero_aerol_write.argtypes = [vp, vp, vp, ip, ip, ip, vp]

@@ -16,6 +16,7 @@ struct jaero_aerol_ctx
     int prof_n[3] = {0, 0, 0};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     std::vector<int> ev_which;
+    void *cmode = nullptr; // fb = 8400: C-channel state (aerolc_state, aerolc.h); g / p above stay unused
 };
 
 static void aprof_begin(jaero_aerol_ctx *c, int which, hipStream_t st)
@@ -78,6 +79,7 @@ static int aalloc(jaero_aerol_ctx *c, T **ptr, size_t count)
     return 0;
 }
 
+static void aerolc_free(jaero_aerol_ctx *c);
 extern "C" void jaero_aerol_destroy(jaero_aerol_ctx *c)
 {
     if (!c) return;
@@ -85,20 +87,39 @@ extern "C" void jaero_aerol_destroy(jaero_aerol_ctx *c)
     hipDeviceSynchronize();
     for (void *q : c->allocs) hipFree(q);
     for (auto &e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    aerolc_free(c);
     delete c;
 }
+
+#include "aerolc.h"
+static void aerolc_free(jaero_aerol_ctx *c) { delete (aerolc_state *)c->cmode; c->cmode = nullptr; }
 
 static int aerol_create(int device, int nchannels, int fb, int max_softbits_per_write, int su_capacity, int burst, jaero_aerol_ctx **out)
 {
     if (!out || nchannels <= 0 || max_softbits_per_write <= 0) return fail(JAERO_EINVAL, "jaero_aerol_create: bad arguments");
     *out = nullptr;
-    if (fb != 600 && fb != 1200 && fb != 10500) return fail(JAERO_ENOTSUP, "jaero_aerol_create: fb must be 600, 1200 or 10500 (8400 C-channel: SURVEY 8f4)");
+    const char *xc = getenv("JAERO_EXPERIMENTAL_AEROLC");
+    const bool cmode = fb == 8400 && !burst && xc && atoi(xc) != 0;
+    if (fb != 600 && fb != 1200 && fb != 10500 && !cmode)
+        return fail(JAERO_ENOTSUP, "jaero_aerol_create: fb must be 600, 1200 or 10500 (8400 C channel: written, not yet validated on a GPU; JAERO_EXPERIMENTAL_AEROLC=1 enables it)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(JAERO_ENODEV, "no HIP device available (this library has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(JAERO_ENODEV, "device %d out of range", device);
     HIPCHK(hipSetDevice(device));
     jaero_aerol_ctx *c = new jaero_aerol_ctx();
     c->device = device;
+    if (cmode)
+    {
+        int rc = aerolc_create(c, nchannels, su_capacity);
+        if (!rc) rc = aalloc(c, &c->d_soft, (size_t)nchannels * max_softbits_per_write);
+        if (!rc) rc = aalloc(c, &c->d_counts, (size_t)(nchannels + 63) / 64 * 64);
+        if (rc) { jaero_aerol_destroy(c); return rc; }
+        c->stage_stride = max_softbits_per_write;
+        c->g.nch = nchannels; c->g.nchp = (nchannels + 63) / 64 * 64; c->g.fb = fb;
+        HIPCHK(hipDeviceSynchronize());
+        *out = c;
+        return 0;
+    }
     AGeom &g = c->g;
     g.nch = nchannels; g.nchp = (nchannels + 63) / 64 * 64; g.fb = fb;
     // AeroL::setSettings (JAERO/aerol.cpp:990-1072), burstmode = false
@@ -220,6 +241,7 @@ extern "C" int jaero_aerol_write(jaero_aerol_ctx *c, const int16_t *soft, const 
         dsoft = c->d_soft; dcounts = c->d_counts;
     }
     if (max_count == 0) return 0;
+    if (c->cmode) return aerolc_write(c, dsoft, dcounts, stride, max_count, st);
     if (g.burst)
     {
         // R/T packet search: a round per trial length a channel can reach in this write (every 192 soft bits, plus 128 and 320)
@@ -305,6 +327,7 @@ static int aerol_read_rows(jaero_aerol_ctx *c, int ch, void *rows, int caprows, 
 }
 extern "C" int jaero_aerol_read_sus(jaero_aerol_ctx *c, int ch, int32_t *rows, int caprows, int *nrows)
 {
+    if (c && c->cmode) { aerolc_state *cs = (aerolc_state *)c->cmode; return aerolc_read(c, ch, rows, caprows, nrows, CI_SU_CNT, cs->p.sus, cs->g.su_cap, 16 * sizeof(int32_t)); }
     if (c && c->g.burst) return fail(JAERO_ENOTSUP, "jaero_aerol_read_sus: burst-mode bank (use jaero_aerol_read_packets)");
     return aerol_read_rows(c, ch, rows, caprows, nrows, AI_SU_CNT, c ? c->p.sus : nullptr, c ? c->g.su_cap : 0, 16 * sizeof(int32_t), 1);
 }
@@ -315,6 +338,7 @@ extern "C" int jaero_aerol_read_packets(jaero_aerol_ctx *c, int ch, int32_t *row
 }
 extern "C" int jaero_aerol_read_events(jaero_aerol_ctx *c, int ch, long long *rows, int caprows, int *nrows)
 {
+    if (c && c->cmode) { aerolc_state *cs = (aerolc_state *)c->cmode; return aerolc_read(c, ch, rows, caprows, nrows, CI_EV_CNT, cs->p.events, cs->g.ev_cap, 3 * sizeof(long long)); }
     return aerol_read_rows(c, ch, rows, caprows, nrows, AI_EV_CNT, c ? c->p.events : nullptr, c ? c->g.ev_cap : 0, 3 * sizeof(long long), 2);
 }
 // = AeroL::updateDCD (aerol.cpp:1109-1122), which the reference drives from a 1 s wall-clock QTimer: the caller ticks it once per
@@ -339,6 +363,18 @@ extern "C" int jaero_aerol_tick_dcd(jaero_aerol_ctx *c, int *dcd_out_host)
 {
     if (!c) return fail(JAERO_EINVAL, "null ctx");
     HIPCHK(hipSetDevice(c->device));
+    if (c->cmode)
+    {
+        aerolc_state *cs = (aerolc_state *)c->cmode;
+        hipLaunchKernelGGL(k_aerolc_tick_dcd, dim3(cs->g.nchp / 64), dim3(64), 0, c->last_stream, cs->g, cs->p, dcd_out_host ? c->d_counts : nullptr);
+        if (dcd_out_host)
+        {
+            HIPCHK(hipMemcpyAsync(dcd_out_host, c->d_counts, sizeof(int) * cs->g.nch, hipMemcpyDeviceToHost, c->last_stream));
+            HIPCHK(hipStreamSynchronize(c->last_stream));
+        }
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(k_aerol_tick_dcd, dim3(c->g.nchp / 64), dim3(64), 0, c->last_stream, c->g, c->p, dcd_out_host ? c->d_counts : nullptr);
     if (dcd_out_host)
     {

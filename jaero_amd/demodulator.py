@@ -474,6 +474,14 @@ class AeroLBank:
         capi.check(self.L.jaero_aerol_read_sus(self.h, channel, buf.ctypes.data, caprows, C.byref(n)))
         return buf[: n.value].copy()
 
+    def read_voice(self, channel: int, caprows: int = 256):
+        """C channel (fb 8400): (frame numbers uint32[n], voice bytes uint8[n, 300]), what AeroL::DecodeC hands to Voicesignal."""
+        buf = np.empty((caprows, 304), dtype=np.uint8)
+        n = C.c_int(0)
+        capi.check(self.L.jaero_aerol_read_voice(self.h, channel, buf.ctypes.data, caprows, C.byref(n)))
+        rows = buf[: n.value]
+        return rows[:, :4].copy().view(np.uint32).reshape(-1), rows[:, 4:].copy()
+
     def read_packets(self, channel: int, caprows: int = 4096):
         """burst mode: [(type, bytes)] with type 1 = R packet, 2 = T packet (header 6 bytes, then 12 per signal unit)."""
         buf = np.empty((caprows, 16), dtype=np.int32)
