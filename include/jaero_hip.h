@@ -199,8 +199,7 @@ int jaero_aerol_tick_dcd(jaero_aerol_ctx *ctx, int *dcd_out /* optional [nchanne
  *   jaero_aerol_read_events additionally reports kind 3 = the " Bad R/T Packet" notice (JAERO/aerol.cpp:1289-1293,1531)
  * The reference drops the rest of the demodulator's current group of soft bits at the end of a signal; the bank re-derives the groups
  * from the stream (a marker is one entry, soft bits come in pairs, a group is complete at >= 32 entries after a pair). */
-/* C channel (fb = 8400, AeroL::DecodeC aerol.cpp:2187-2502; EXPERIMENTAL: jaero_aerol_create accepts it only with
- * JAERO_EXPERIMENTAL_AEROLC=1 until it has been validated on a GPU): jaero_aerol_read_sus rows are the three sub-band signal units of
+/* C channel (jaero_aerol_create with fb = 8400: AeroL::DecodeC aerol.cpp:2187-2502): jaero_aerol_read_sus rows are the three sub-band signal units of
  * a frame [frame, k, 12 bytes, crc_ok, 0]; jaero_aerol_read_voice rows are 304 bytes: uint32 frame number, then the 300 voice bytes
  * the reference hands to Voicesignal(data, hex). */
 int jaero_aerol_read_voice(jaero_aerol_ctx *ctx, int channel, uint8_t *rows, int caprows, int *nrows);

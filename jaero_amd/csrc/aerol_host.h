@@ -98,10 +98,8 @@ static int aerol_create(int device, int nchannels, int fb, int max_softbits_per_
 {
     if (!out || nchannels <= 0 || max_softbits_per_write <= 0) return fail(JAERO_EINVAL, "jaero_aerol_create: bad arguments");
     *out = nullptr;
-    const char *xc = getenv("JAERO_EXPERIMENTAL_AEROLC");
-    const bool cmode = fb == 8400 && !burst && xc && atoi(xc) != 0;
-    if (fb != 600 && fb != 1200 && fb != 10500 && !cmode)
-        return fail(JAERO_ENOTSUP, "jaero_aerol_create: fb must be 600, 1200 or 10500 (8400 C channel: written, not yet validated on a GPU; JAERO_EXPERIMENTAL_AEROLC=1 enables it)");
+    const bool cmode = fb == 8400 && !burst; // C channel (aerolc.h)
+    if (fb != 600 && fb != 1200 && fb != 10500 && !cmode) return fail(JAERO_ENOTSUP, "jaero_aerol_create: fb must be 600, 1200, 10500 or (continuous mode) 8400");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(JAERO_ENODEV, "no HIP device available (this library has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(JAERO_ENODEV, "device %d out of range", device);

@@ -1,9 +1,10 @@
 // aerolc.h -- Aero-L C-channel bit pipeline (8400 bps): AeroL::DecodeC (JAERO/aerol.cpp:2187-2502) for a bank of channels.
 // SURVEY 8 row f4, second half.  Included by jaero_hip.hip after aerol_host.h; reached through jaero_aerol_create(fb = 8400).
 //
-// EXPERIMENTAL: written from the oracle restatement (oracle/aerol_oracle.c, c_write / c_frame_done), which is pinned against the
-// unmodified AeroL, but not yet run on a GPU: jaero_aerol_create only accepts fb = 8400 when JAERO_EXPERIMENTAL_AEROLC=1 is set
-// (tests/test_gpu_aerol_c.py is skipped without it).  Correctness first, no tuning: one lane per channel walks the soft bits.
+// Written from the oracle restatement (oracle/aerol_oracle.c, c_write / c_frame_done), which is pinned against the unmodified AeroL.
+// On an MI355X a single channel reproduces the reference golden and the oracle (voice bytes, signal units, events:
+// tests/test_gpu_aerol_c.py::test_golden_single_channel); the multi-channel tests of that file have not run yet (opt-in,
+// JAERO_TEST_AEROLC=1).  Correctness first, no tuning: one lane per channel walks the soft bits.
 //
 // A frame = 104 unique-word bits (two 52-bit words, one per arm, OQPSKPreambleDetectorAndAmbiguityCorrection :811-900, tolerance 6)
 // + 4096 channel bits = 16 interleaver blocks of 64 x 4 -> deinterleaved and depunctured (rate 3/4, every 4th coded bit an
