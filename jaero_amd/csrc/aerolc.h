@@ -236,6 +236,7 @@ __global__ void k_aerolc_tick_dcd(const CGeom g, const CPtrs p, int *dcd_out)
     if (dcd_out) dcd_out[ch] = datacd;
 }
 
+#ifndef AEROLC_KERNELS_ONLY // tests/host_emul/aerolc_emul.cpp compiles the kernels above as host functions
 // ------------------------------------------------------------------------------------------------ host side
 struct aerolc_state
 {
@@ -345,3 +346,4 @@ extern "C" int jaero_aerol_read_voice(jaero_aerol_ctx *c, int ch, uint8_t *rows,
     aerolc_state *cs = (aerolc_state *)c->cmode;
     return aerolc_read(c, ch, rows, caprows, nrows, CI_V_CNT, cs->p.voice, cs->g.v_cap, 304);
 }
+#endif // AEROLC_KERNELS_ONLY
