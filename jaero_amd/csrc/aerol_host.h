@@ -234,6 +234,8 @@ extern "C" int jaero_aerol_write(jaero_aerol_ctx *c, const int16_t *soft, const 
     if (!is_device_ptr)
     {
         if (stride > c->stage_stride) return fail(JAERO_EINVAL, "jaero_aerol_write: stride %d exceeds max_softbits_per_write %d", stride, c->stage_stride);
+        for (int ch = 0; ch < g.nch; ch++) // a count above max_count would be cut short by the round budget, one above stride read past the row
+            if (counts[ch] < 0 || counts[ch] > max_count) return fail(JAERO_EINVAL, "jaero_aerol_write: counts[%d] = %d outside [0, max_count = %d]", ch, counts[ch], max_count);
         HIPCHK(hipMemcpyAsync(c->d_soft, soft, sizeof(int16_t) * (size_t)g.nch * stride, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(c->d_counts, counts, sizeof(int) * g.nch, hipMemcpyHostToDevice, st));
         dsoft = c->d_soft; dcounts = c->d_counts;
@@ -325,7 +327,7 @@ static int aerol_read_rows(jaero_aerol_ctx *c, int ch, void *rows, int caprows, 
 }
 extern "C" int jaero_aerol_read_sus(jaero_aerol_ctx *c, int ch, int32_t *rows, int caprows, int *nrows)
 {
-    if (c && c->cmode) { aerolc_state *cs = (aerolc_state *)c->cmode; return aerolc_read(c, ch, rows, caprows, nrows, CI_SU_CNT, cs->p.sus, cs->g.su_cap, 16 * sizeof(int32_t)); }
+    if (c && c->cmode) { aerolc_state *cs = (aerolc_state *)c->cmode; return aerolc_read(c, ch, rows, caprows, nrows, CI_SU_CNT, cs->p.sus, cs->g.su_cap, 16 * sizeof(int32_t), 1); }
     if (c && c->g.burst) return fail(JAERO_ENOTSUP, "jaero_aerol_read_sus: burst-mode bank (use jaero_aerol_read_packets)");
     return aerol_read_rows(c, ch, rows, caprows, nrows, AI_SU_CNT, c ? c->p.sus : nullptr, c ? c->g.su_cap : 0, 16 * sizeof(int32_t), 1);
 }
@@ -336,7 +338,7 @@ extern "C" int jaero_aerol_read_packets(jaero_aerol_ctx *c, int ch, int32_t *row
 }
 extern "C" int jaero_aerol_read_events(jaero_aerol_ctx *c, int ch, long long *rows, int caprows, int *nrows)
 {
-    if (c && c->cmode) { aerolc_state *cs = (aerolc_state *)c->cmode; return aerolc_read(c, ch, rows, caprows, nrows, CI_EV_CNT, cs->p.events, cs->g.ev_cap, 3 * sizeof(long long)); }
+    if (c && c->cmode) { aerolc_state *cs = (aerolc_state *)c->cmode; return aerolc_read(c, ch, rows, caprows, nrows, CI_EV_CNT, cs->p.events, cs->g.ev_cap, 3 * sizeof(long long), 2); }
     return aerol_read_rows(c, ch, rows, caprows, nrows, AI_EV_CNT, c ? c->p.events : nullptr, c ? c->g.ev_cap : 0, 3 * sizeof(long long), 2);
 }
 // = AeroL::updateDCD (aerol.cpp:1109-1122), which the reference drives from a 1 s wall-clock QTimer: the caller ticks it once per

@@ -298,7 +298,10 @@ static int aerolc_write(jaero_aerol_ctx *c, const int16_t *dsoft, const int *dco
 {
     aerolc_state *cs = (aerolc_state *)c->cmode;
     const CGeom &g = cs->g;
-    const int rounds = max_count / (CC_FRAME + 104) + 2;
+    // a round finishes at most one frame per channel.  Frame ends are at least 4098 soft bits apart: the detector window reopens at
+    // cntr > CC_FRAME - 112, so a (false or real) unique word can fire two bits after a completed frame and the next frame ends
+    // CC_FRAME bits after that -- not CC_FRAME + 104 as in a clean stream.
+    const int rounds = max_count / (CC_FRAME + 1) + 2;
     const int *valid = cs->p.I + (size_t)CI_HAS_BLOCK * g.nchp;
     const dim3 grid(g.nchp / 64), block(64);
     for (int r = 0; r < rounds; r++)
@@ -315,7 +318,7 @@ static int aerolc_write(jaero_aerol_ctx *c, const int16_t *dsoft, const int *dco
 }
 
 // drains rows of one channel: copies min(count, caprows) rows, keeps the rest (as aerol_read_rows does for the other modes)
-static int aerolc_read(jaero_aerol_ctx *c, int ch, void *rows, int caprows, int *nrows, int cnt_field, const void *base, int cap, size_t rowbytes)
+static int aerolc_read(jaero_aerol_ctx *c, int ch, void *rows, int caprows, int *nrows, int cnt_field, const void *base, int cap, size_t rowbytes, int ovbit)
 {
     aerolc_state *cs = (aerolc_state *)c->cmode;
     const CGeom &g = cs->g;
@@ -337,6 +340,17 @@ static int aerolc_read(jaero_aerol_ctx *c, int ch, void *rows, int caprows, int 
     }
     HIPCHK(hipMemcpy(dcnt, &left, sizeof(int), hipMemcpyHostToDevice));
     *nrows = take;
+    // rows the kernels had to drop because the caller fell behind (CI_OVERFLOW: 1 signal units, 2 events, 4 voice frames):
+    // reported once, then cleared, as aerol_read_rows does for the P and R/T banks
+    int ov = 0;
+    int *dov = cs->p.I + (size_t)CI_OVERFLOW * g.nchp + ch;
+    HIPCHK(hipMemcpy(&ov, dov, sizeof(int), hipMemcpyDeviceToHost));
+    if (ov & ovbit)
+    {
+        const int z = ov & ~ovbit;
+        HIPCHK(hipMemcpy(dov, &z, sizeof(int), hipMemcpyHostToDevice));
+        return fail(JAERO_EOVERFLOW, "Aero-L C-channel %d overflowed an output buffer (flag %d); rows were dropped", ch, ovbit);
+    }
     return 0;
 }
 
@@ -344,6 +358,6 @@ extern "C" int jaero_aerol_read_voice(jaero_aerol_ctx *c, int ch, uint8_t *rows,
 {
     if (!c || !c->cmode) return fail(JAERO_EINVAL, "jaero_aerol_read_voice: not a C-channel (fb = 8400) bank");
     aerolc_state *cs = (aerolc_state *)c->cmode;
-    return aerolc_read(c, ch, rows, caprows, nrows, CI_V_CNT, cs->p.voice, cs->g.v_cap, 304);
+    return aerolc_read(c, ch, rows, caprows, nrows, CI_V_CNT, cs->p.voice, cs->g.v_cap, 304, 4);
 }
 #endif // AEROLC_KERNELS_ONLY

@@ -168,11 +168,11 @@ __device__ __forceinline__ int jd_softbit(double v)
 // anyone can read after the launch differs from the every-sample evaluation by < 1e-16.
 #define JD_EBNO_TAIL 192
 
-// Matched-filter taps in the constant address space: a uniform read of them compiles to scalar loads (s_load through the scalar
-// cache, SGPR operands of v_fma_f64).  Through the JPtrs pointer the compiler could not prove them invariant and fetched them with
-// per-lane vector loads inside the filter loop (exposed L2 latency five times per sample).  One table per kind/rate: the values are
-// functions of (kind, fb, Fs) only, so banks of one process never disagree about them.
-__constant__ double c_taps_oqpsk[64];     // RRC alpha=1, 55 taps @ 48 kHz / 5250 sym/s (continuous and burst OQPSK)
+// Matched-filter taps: every sample kernel copies its bank's own taps (JPtrs::taps2 / BPtrs::taps2, uploaded by *_create) into LDS
+// once per launch and reads them from there (jd_fir_eval).  The one kernel that still reads taps inside its loop (burst MSK) takes them
+// from the constant address space, where a uniform read compiles to scalar loads; that table is keyed by fb and its values depend on
+// (fb, Fs) only with Fs fixed at 48 kHz (validate_settings), so banks alive at the same time never disagree about a slot.  The OQPSK
+// taps depend on fb as well (alpha 1.0 at 10500, 0.6 at 8400) and are NOT kept in a process-global symbol.
 __constant__ double c_taps_msk[2][160];   // half-sine, [0] = 1200 bps (80 taps), [1] = 600 bps (160 taps)
 
 // Matched-filter evaluation for one sample of 64 channels (one per lane): sum over i of taps[i] * x[n-FIRN+i], oldest first,

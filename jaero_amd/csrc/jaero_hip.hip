@@ -205,7 +205,8 @@ __global__ void k_center_freq(const JGeom g, const JPtrs p, int ch_first, int nc
     {
         double fc = freq_center_in;
         const double fb = g.fb, Fs = g.Fs;
-        if (g.kind == 1)
+        if (g.kind == 1 && g.fb == 8400) {} // no clamp at 8400 bps (oqpskdemodulator.cpp:293: `if(fb!=8400)`)
+        else if (g.kind == 1)
         {
             if (fc < (0.5 * fb)) fc = 0.5 * fb;
             if (fc > (Fs / 2.0 - 0.5 * fb)) fc = Fs / 2.0 - 0.5 * fb;
@@ -580,8 +581,7 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         std::vector<double> t2(2 * g.fir_n);
         for (int i = 0; i < 2 * g.fir_n; i++) t2[i] = taps[i % g.fir_n];
         HIPCHK(hipMemcpy(d_taps, t2.data(), sizeof(double) * t2.size(), hipMemcpyHostToDevice));
-        if (g.kind == JAERO_KIND_OQPSK) HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_taps_oqpsk), taps.data(), sizeof(double) * taps.size()));
-        else HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_taps_msk), taps.data(), sizeof(double) * taps.size(), (g.fb >= 1200 ? 0 : 1) * 160 * sizeof(double)));
+        if (g.kind != JAERO_KIND_OQPSK) HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_taps_msk), taps.data(), sizeof(double) * taps.size(), (g.fb >= 1200 ? 0 : 1) * 160 * sizeof(double)));
     }
     // scalar state
     {

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
     double tre[TAILN], tim[TAILN];
     const int lane = threadIdx.x, grp = blockIdx.x, ch = grp * 64 + lane, nchp = g.nchp;
     const double2 *__restrict__ cis = p.cis;
-    const double *taps = c_taps_oqpsk;
+    const double *__restrict__ taps = p.taps2; // this bank's own taps, read once into LDS
     const double SPS = g.SPS, samplerate = g.Fs;
 
     double m2_ptr = BLDF(BS_M2_PTR), m2_step = BLDF(BS_M2_STEP), m2_freq = BLDF(BS_M2_FREQ);

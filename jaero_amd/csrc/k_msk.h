@@ -33,7 +33,7 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
     const int nchp = g.nchp;
     const bool live = ch < g.nch;
     const double2 *__restrict__ cis = p.cis;
-    const double *taps = c_taps_msk[FIRN == 80 ? 0 : 1];
+    const double *__restrict__ taps = p.taps2; // this bank's own taps, read once into LDS
 
     double m2_ptr = LDF(S_M2_PTR), m2_step = LDF(S_M2_STEP), m2_freq = LDF(S_M2_FREQ);
     double mc_ptr = LDF(S_MC_PTR), mc_step = LDF(S_MC_STEP);

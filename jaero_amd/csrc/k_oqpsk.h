@@ -38,7 +38,7 @@ __device__ __forceinline__ void oqpsk_samples_body(const JGeom g, const JPtrs p,
     const int nchp = g.nchp;
     const bool live = ch < g.nch;
     const double2 *__restrict__ cis = p.cis;
-    const double *taps = c_taps_oqpsk;
+    const double *__restrict__ taps = p.taps2; // this bank's own taps (they depend on fb: alpha 1.0 at 10500, 0.6 at 8400), read once into LDS
 
     // ---- load state ----
     double m2_ptr = LDF(S_M2_PTR), m2_step = LDF(S_M2_STEP), m2_freq = LDF(S_M2_FREQ);

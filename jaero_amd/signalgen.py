@@ -288,10 +288,12 @@ def oqpsk_torch(nch: int, nsamples: int, device, *, fb: float = 10500.0, Fs: flo
 
 def burst_oqpsk_torch(nch: int, nsamples: int, device, *, period: int = 48000, ndata_sym: int = 3040, fb: float = 10500.0,
                       Fs: float = 48000.0, fc_center: float = 8000.0, fc_spread: float = 100.0, ebno_db: float | None = 15.0,
-                      peak: float = 0.3, seed: int = SEED_BASE, block: int = 2048):
+                      peak: float = 0.3, seed: int = SEED_BASE, block: int = 2048, max_offset_sym: int | None = None):
     """SURVEY.md 8(d) config 4 on a torch device: every channel sends one burst per `period` samples (128 symbols of
     carrier, 128 symbols of alternating preamble, `ndata_sym` random symbols per arm = <= 6080 bits), at a per-channel
-    random offset inside the period, noise in the gaps.  Returns (pcm int16 [nsamples, nch], carriers, offsets)."""
+    random offset inside the period (limited to `max_offset_sym` symbols when given: all channels' bursts then start within that
+    window, so their acquisition events crowd into the same segments), noise in the gaps.
+    Returns (pcm int16 [nsamples, nch], carriers, offsets)."""
     import torch
 
     gen = torch.Generator(device=device)
@@ -301,7 +303,7 @@ def burst_oqpsk_torch(nch: int, nsamples: int, device, *, period: int = 48000, n
     psym = int(round(period / T))
     blen = 256 + ndata_sym
     assert blen < psym
-    off = torch.randint(0, psym - blen, (nch,), generator=gen, device=device)
+    off = torch.randint(0, psym - blen if max_offset_sym is None else min(psym - blen, max_offset_sym), (nch,), generator=gen, device=device)
     k = torch.arange(nsym, device=device)[None, :]
     rel = torch.remainder(k - off[:, None], psym)  # symbol index inside the channel's period
     inb = rel < blen

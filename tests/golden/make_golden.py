@@ -230,6 +230,23 @@ def aerol_burst():
         print("aerol burst", fb, x.shape, [(int(r[0]), int(r[1])) for r in rows], "bad", bad, "dcd", len(dcd))
 
 
+
+def recordings():
+    """Inputs of the two bundled recordings (samples/1200bps_burst_sample{1,2}.wav, mono int16 @ 48 kHz) as test fixtures, so that the
+    GPU box (which has no /root/reference) can run the WHOLE files through the burst-MSK and continuous-MSK banks against the
+    `_burstmsk` / `_contmsk` outputs above.  Data vectors, not reference source; the crc stored in the `_contmsk` golden is checked."""
+    import wave
+    for f in ("1200bps_burst_sample1", "1200bps_burst_sample2"):
+        w = wave.open("/root/reference/samples/" + f + ".wav")
+        assert w.getnchannels() == 1 and w.getframerate() == 48000 and w.getsampwidth() == 2
+        x = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+        g = np.load(os.path.join(HERE, f + "_contmsk.npz"))
+        crc = np.uint32(np.bitwise_xor.reduce(x.astype(np.uint16).astype(np.uint32) * np.arange(1, len(x) + 1, dtype=np.uint32)))
+        assert int(g["nsamples"]) == len(x) and int(g["crc"]) == int(crc)
+        np.savez_compressed(os.path.join(HERE, f + "_pcm.npz"), pcm=x, source=np.array("samples/" + f + ".wav"))
+        print(f, len(x), os.path.getsize(os.path.join(HERE, f + "_pcm.npz")))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "aerolburst":
         aerol_burst()
@@ -239,9 +256,12 @@ if __name__ == "__main__":
         aerol()
     elif len(sys.argv) > 1 and sys.argv[1] == "aerolc":
         aerol_c()
+    elif len(sys.argv) > 1 and sys.argv[1] == "recordings":
+        recordings()
     else:
         main()
         burst()
         aerol()
         aerol_burst()
         aerol_c()
+        recordings()

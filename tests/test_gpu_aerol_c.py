@@ -1,7 +1,5 @@
 """GPU (-m gpu): the Aero-L C-channel bit pipeline (AeroL::DecodeC) through the C ABI against the oracle and the
-reference golden.  The single-channel golden test has run green on an MI355X; the multi-channel tests were written after the
-round's GPU minutes were spent and stay opt-in (JAERO_TEST_AEROLC=1) until they have run once."""
-import os
+reference golden: a single channel, banks of 5 and 70 channels with ragged writes, and the overflow report."""
 
 import numpy as np
 import pytest
@@ -10,7 +8,6 @@ from conftest import load_golden
 from jaero_amd import aerol_frames as AF
 
 pytestmark = pytest.mark.gpu
-not_yet_run = pytest.mark.skipif(os.environ.get("JAERO_TEST_AEROLC") != "1", reason="not yet run on a GPU: JAERO_TEST_AEROLC=1 runs it")
 
 
 @pytest.fixture()
@@ -53,7 +50,6 @@ def test_golden_single_channel(D, oracle_mod):
     bank.close()
 
 
-@not_yet_run
 @pytest.mark.parametrize("nch,write", [(5, 3000), (70, 5000)])
 def test_bank_vs_oracle(D, oracle_mod, nch, write):
     """Channels at different frame phases, inversions and noise levels, ragged writes: every channel equals its own oracle run."""
@@ -79,4 +75,22 @@ def test_bank_vs_oracle(D, oracle_mod, nch, write):
         assert np.array_equal(fn, ofn) and np.array_equal(voice, ovoice), c
         assert np.array_equal(bank.read_sus(c), osus), c
         assert np.array_equal(bank.read_events(c), oev), c
+    bank.close()
+
+
+def test_overflow_is_reported(D):
+    """A caller that falls behind: with room for 3 signal units (= 1 voice frame) per channel the second frame's rows are dropped, and
+    the next read says so once (JAERO_EOVERFLOW), as the P and R/T banks do."""
+    from jaero_amd import capi
+
+    frames, soft = AF.c_channel_case(6001, 4, 30.0, inv=(False, False), lead=100)
+    bank = D.AeroLBank(1, 8400, max_softbits_per_write=4096, su_capacity=3)
+    for s in range(0, len(soft), 4096):
+        bank.write(soft[s:s + 4096].reshape(1, -1))
+    with pytest.raises(capi.JaeroError) as e:
+        bank.read_sus(0)
+    assert e.value.code == capi.E_OVERFLOW
+    assert len(bank.read_sus(0)) == 0  # reported once; the three rows of the first frame were handed over by the failing call's copy
+    with pytest.raises(capi.JaeroError):
+        bank.read_voice(0)
     bank.close()

@@ -1,0 +1,227 @@
+"""GPU (-m gpu): parity at the bank sizes BASELINE.json names -- 4096-channel continuous OQPSK (configs[2]), 256-channel 1200 bps MSK
+(configs[1]; plus 1024 channels so the persistent coarse kernel runs several estimates per workgroup), 4096-channel burst OQPSK
+(configs[3]) -- and the two bundled recordings from their first to their last sample.
+
+With more channels than the chip has CUs the coarse-frequency kernels (k_coarse4, k_coarse2<13>) and k_trident run as persistent
+workgroups that each take several estimates from the list and consume the ring / y[] rows they prefetched for the NEXT estimate; the
+banks of at most 70 channels in the other test files never reach that code.  Channels are compared with their own oracle run
+(O.run_demod / O.run_burst, exactly as test_gpu_parity.compare does) at indices spread over the bank: lanes 0 and 63 of a wavefront,
+neighbouring wavefronts, workgroup iterations 1, 2, 3, ... of the persistent kernels, the last channel.  Every channel has its own
+carrier, bits and noise and -- for the continuous kinds -- its own freq_center / lockingbw, so a mixed-up channel index cannot hide."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from test_gpu_parity import compare
+
+pytestmark = pytest.mark.gpu
+SYM_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def B():
+    from jaero_amd import capi
+    from jaero_amd import demodulator as D
+
+    capi.lib()  # fail loudly if the extension is missing
+    return D
+
+
+def spread(nch, extra=()):
+    """Channel indices spread over a bank: wave edges, neighbouring waves, multiples of the CU count, the end."""
+    want = [0, 1, 63, 64, 127, 255, 256, 257, 300, 511, 512, 767, 1023, 1024, 2047, 2048, 2500, 3071, 3333, 4094, 4095, *extra]
+    return sorted({c for c in want if c < nch} | {nch - 1})
+
+
+def feed_frames(bank, pcm, chunk):
+    """pcm: torch int16 [nsamples, nch] on the device (frame-major), written `chunk` samples at a time."""
+    from jaero_amd import capi
+
+    for s in range(0, pcm.shape[0], chunk):
+        bank.write(pcm[s:s + chunk], layout=capi.PCM_FRAME_MAJOR)
+
+
+@pytest.mark.parametrize("capture,chunk", [(False, 4096), (True, 3000)])
+def test_oqpsk_4096_channels(B, oracle_mod, capture, chunk):
+    """BASELINE configs[2]: 4096-channel synthetic 48 kHz 10.5 kbps OQPSK.  62 000 samples = 15 coarse estimates per channel, each
+    k_coarse4 launch takes 4096 estimates on 256 workgroups (16 persistent iterations each).  capture=False is the instantiation
+    bench.py times (EbNo meters on, no symbol capture); capture=True adds the soft-symbol comparison and ragged 3000-sample writes
+    (the estimate then falls in the middle of a write)."""
+    import torch
+
+    from jaero_amd import signalgen as G
+
+    O = oracle_mod
+    nch, nsamp = 4096, 62000
+    dev = torch.device("cuda", 0)
+    pcm, _, _ = G.oqpsk_torch(nch, nsamp, dev, ebno_db=10.0, seed=G.SEED_BASE + 4096)
+    fcs = [8000.0 + 5.0 * ((c * 7) % 11 - 5) for c in range(nch)]
+    lbw = [10500.0 - 500.0 * (c % 3) for c in range(nch)]
+    setts = [B.OqpskSettings(freq_center=fcs[c], lockingbw=lbw[c]) for c in range(nch)]
+    bank = B.DemodulatorBank(setts, ebno=True, status_log=True, capture_symbols=capture, max_write_samples=chunk,
+                             softbit_capacity=int(nsamp * 10500 / 48000) + 64)
+    feed_frames(bank, pcm, chunk)
+    nsoft = 0
+    for c in spread(nch):
+        x = pcm[:, c].cpu().numpy()
+        ref = O.run_demod(O.oqpsk_settings(freq_center=fcs[c], lockingbw=lbw[c]), x, chunk=chunk, capture_symbols=capture)
+        assert ref["status"].shape[0] == 15
+        sym = bank.read_symbols(c) if capture else None
+        compare(bank.read_softbits(c), sym, bank.read_status_log(c), ref)
+        nsoft += len(ref["soft"])
+    assert nsoft > 20 * 5000  # the channels did lock: soft bits were compared, not just empty streams
+    bank.close()
+
+
+@pytest.mark.parametrize("nch,nsamp", [(256, 50000), (1024, 30000)])
+def test_msk_1200_banks(B, oracle_mod, nch, nsamp):
+    """BASELINE configs[1]: 256-channel synthetic 48 kHz 1200 bps MSK (one estimate per workgroup and launch), and 1024 channels
+    (four persistent iterations of k_coarse2<13> per workgroup); an estimate every 2048 samples."""
+    from jaero_amd import signalgen as G
+
+    O = oracle_mod
+    pcm, _, _ = G.channel_bank("msk", nch, nsamp, ebno_db=10.0, seed0=G.SEED_BASE + 256 + nch, fb=1200.0)
+    fcs = [1000.0 + 3.0 * ((c * 5) % 9 - 4) for c in range(nch)]
+    lbw = [1800.0 - 100.0 * (c % 3) for c in range(nch)]
+    setts = [B.MskSettings(fb=1200.0, freq_center=fcs[c], lockingbw=lbw[c]) for c in range(nch)]
+    chunk = 4096
+    bank = B.DemodulatorBank(setts, ebno=True, status_log=True, capture_symbols=True, max_write_samples=chunk, softbit_capacity=nsamp)
+    for s in range(0, nsamp, chunk):
+        bank.write(pcm[:, s:s + chunk])
+    for c in spread(nch):
+        ref = O.run_demod(O.msk_settings(freq_center=fcs[c], lockingbw=lbw[c], fb=1200.0), pcm[c], chunk=chunk, capture_symbols=True)
+        assert ref["status"].shape[0] == nsamp // 2048
+        compare(bank.read_softbits(c), bank.read_symbols(c), bank.read_status_log(c), ref)
+    bank.close()
+
+
+def test_burst_oqpsk_4096_channels(B, oracle_mod):
+    """BASELINE configs[3]: 4096-channel 10.5 kbps burst OQPSK, one burst per second and channel.  All bursts start within 600 symbols
+    of each other, so the preamble ("trident") checks of the whole bank crowd into two or three segments: k_trident's persistent
+    workgroups then take ~8 events each from the device-side list."""
+    import torch
+
+    from jaero_amd import signalgen as G
+    from test_gpu_burst import check_events, check_soft
+
+    O = oracle_mod
+    nch, nsamp, chunk = 4096, 110000, 4096
+    dev = torch.device("cuda", 0)
+    pcm, _, _ = G.burst_oqpsk_torch(nch, nsamp, dev, ndata_sym=1500, ebno_db=15.0, seed=G.SEED_BASE + 40960, max_offset_sym=600)
+    bank = B.DemodulatorBank(B.BurstOqpskSettings(), nch, capture_symbols=True, trace=True, max_write_samples=chunk, softbit_capacity=30000)
+    feed_frames(bank, pcm, chunk)
+    nacc = 0
+    for c in spread(nch):
+        x = pcm[:, c].cpu().numpy()
+        ref = O.run_burst(O.burst_oqpsk_settings(), x, chunk=chunk, capture_symbols=True, trace=True)
+        check_soft(bank.read_softbits(c), ref["soft"], f"channel {c}")
+        check_events(bank.read_events(c), ref["events"])
+        sym = bank.read_symbols(c)
+        assert sym.shape == ref["symbols"].shape
+        assert np.max(np.abs(sym - ref["symbols"]), initial=0.0) < SYM_TOL
+        nacc += int((ref["soft"] == -1).sum())
+    assert nacc >= 30  # two whole bursts per channel in view (the first one while the detector's averages are still filling)
+    bank.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the bundled recordings, whole (north_star: "bit-exact on the decoded differential bitstream for the bundled sample files")
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["1200bps_burst_sample1", "1200bps_burst_sample2"])
+def test_recording_through_burst_msk(B, name):
+    """samples/1200bps_burst_sample{1,2}.wav through a burst MSK bank = what the unmodified BurstMskDemodulator emitted
+    (tests/golden/*_burstmsk.npz, made by oracle/_ref): every soft bit, every start-of-burst marker, every emission."""
+    from test_gpu_burst import check_events, check_soft
+
+    pcm = load_golden(name + "_pcm")["pcm"]
+    g = load_golden(name + "_burstmsk")
+    assert len(pcm) == int(g["nsamples"])
+    chunk = 4096
+    bank = B.DemodulatorBank(B.BurstMskSettings(freq_center=1000.0, fb=1200.0), 1, max_write_samples=chunk, softbit_capacity=60000)
+    for s in range(0, len(pcm), chunk):
+        bank.write(pcm[None, s:s + chunk])
+    soft = bank.read_softbits(0)
+    check_soft(soft, g["soft"])
+    assert np.array_equal(soft, g["soft"])  # not just the hard decisions: these recordings reproduce byte for byte
+    ev = bank.read_events(0)
+    ev[:, 0] = np.floor(ev[:, 0] / chunk) * chunk  # the reference driver stamps emissions with their write's first sample
+    check_events(ev, g["events"])
+    assert int((soft == -1).sum()) >= 3
+    bank.close()
+
+
+@pytest.mark.parametrize("name", ["1200bps_burst_sample1", "1200bps_burst_sample2"])
+def test_recording_through_continuous_msk(B, name):
+    """The same recordings through the continuous 1200 bps MSK demodulator (BASELINE configs[0] stand-in) = what the
+    unmodified MskDemodulator emitted (tests/golden/*_contmsk.npz): ~250 coarse estimates, ~13 000 soft bits."""
+    pcm = load_golden(name + "_pcm")["pcm"]
+    g = load_golden(name + "_contmsk")
+    assert len(pcm) == int(g["nsamples"])
+    chunk = 4096
+    bank = B.DemodulatorBank(B.MskSettings(fb=1200.0, lockingbw=1800.0, freq_center=1000.0), 1, ebno=True, status_log=True,
+                             max_write_samples=chunk, softbit_capacity=len(pcm))
+    for s in range(0, len(pcm), chunk):
+        bank.write(pcm[None, s:s + chunk])
+    soft, log = bank.read_softbits(0), bank.read_status_log(0)
+    n = len(g["soft"])
+    assert n <= len(soft) < n + 12
+    assert np.array_equal(soft[:n] >= 128, g["soft"] >= 128)
+    assert np.max(np.abs(soft[:n].astype(int) - g["soft"].astype(int)), initial=0) <= 1
+    assert log.shape == g["status"].shape
+    assert np.array_equal(log[:, [0, 5]], g["status"][:, [0, 5]])
+    assert np.max(np.abs(log[:, 1:4] - g["status"][:, 1:4])) < 1e-6
+    bank.close()
+
+
+def test_recordings_side_by_side_in_one_bank(B):
+    """Both recordings as channels 0 and 65 of one 66-channel burst MSK bank (the rest silence / the other recording delayed):
+    the per-lane burst gates of neighbouring channels open at different times."""
+    from test_gpu_burst import check_soft
+
+    a = load_golden("1200bps_burst_sample1_pcm")["pcm"]
+    b = load_golden("1200bps_burst_sample2_pcm")["pcm"]
+    n = min(len(a), len(b))
+    n -= n % 4096
+    nch = 66
+    pcm = np.zeros((nch, n), np.int16)
+    pcm[0], pcm[65] = a[:n], b[:n]
+    pcm[1, 30000:] = b[:n - 30000]
+    pcm[64, 77777:] = a[:n - 77777]
+    bank = B.DemodulatorBank(B.BurstMskSettings(freq_center=1000.0, fb=1200.0), nch, max_write_samples=4096, softbit_capacity=60000)
+    for s in range(0, n, 4096):
+        bank.write(pcm[:, s:s + 4096])
+    ga, gb = load_golden("1200bps_burst_sample1_burstmsk")["soft"], load_golden("1200bps_burst_sample2_burstmsk")["soft"]
+    sa, sb = bank.read_softbits(0), bank.read_softbits(65)
+    # the files were cut to a common length: what was emitted is a prefix of the whole-file golden
+    assert len(sa) > 0.9 * len(ga) and len(sb) > 0.9 * len(gb)
+    check_soft(sa, ga[:len(sa)])
+    check_soft(sb, gb[:len(sb)])
+    assert len(bank.read_softbits(2)) == 0  # silence never opens the gate
+    bank.close()
+
+
+def test_10500_and_8400_banks_alive_together(B, oracle_mod):
+    """Two OQPSK banks with different matched filters (RRC alpha 1.0 at 10500 bps, 0.6 at 8400 bps) live in one process and are fed
+    alternately: each keeps its own taps (they used to share one process-global constant symbol, so the bank created last
+    silently changed the other's filter)."""
+    from jaero_amd import signalgen as G
+
+    O = oracle_mod
+    nsamp, chunk = 60000, 4096
+    p105, _ = G.oqpsk(nsamp, fc=8030.0, ebno_db=11.0, seed=G.SEED_BASE + 1)
+    p84, _ = G.oqpsk(nsamp, fb=8400.0, fc=7975.0, ebno_db=11.0, seed=G.SEED_BASE + 2)
+    b105 = B.DemodulatorBank(B.OqpskSettings(), 1, ebno=True, status_log=True, capture_symbols=True, max_write_samples=chunk, softbit_capacity=nsamp)
+    b84 = B.DemodulatorBank(B.OqpskSettings(fb=8400.0, lockingbw=8400.0), 1, ebno=True, status_log=True, capture_symbols=True,
+                            max_write_samples=chunk, softbit_capacity=nsamp)
+    bb = B.DemodulatorBank(B.BurstOqpskSettings(), 1, max_write_samples=chunk, softbit_capacity=nsamp)  # a third user of 55-tap OQPSK filters
+    for s in range(0, nsamp, chunk):
+        b105.write(p105[None, s:s + chunk])
+        b84.write(p84[None, s:s + chunk])
+        bb.write(p105[None, s:s + chunk])
+    r105 = O.run_demod(O.oqpsk_settings(), p105, chunk=chunk, capture_symbols=True)
+    r84 = O.run_demod(O.oqpsk_settings(fb=8400.0, lockingbw=8400.0), p84, chunk=chunk, capture_symbols=True)
+    compare(b105.read_softbits(0), b105.read_symbols(0), b105.read_status_log(0), r105)
+    compare(b84.read_softbits(0), b84.read_symbols(0), b84.read_status_log(0), r84)
+    assert len(r105["soft"]) > 5000 and len(r84["soft"]) > 4000
+    for b in (b105, b84, bb):
+        b.close()
