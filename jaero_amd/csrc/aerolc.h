@@ -306,11 +306,17 @@ static int aerolc_write(jaero_aerol_ctx *c, const int16_t *dsoft, const int *dco
     const dim3 grid(g.nchp / 64), block(64);
     for (int r = 0; r < rounds; r++)
     {
+        aprof_begin(c, 0, st);
         hipLaunchKernelGGL(k_aerolc_bits, grid, block, 0, st, g, cs->p, dsoft, dcounts, stride);
+        aprof_end(c, st);
+        aprof_begin(c, 1, st);
         hipLaunchKernelGGL(k_viterbi, dim3(g.nch), dim3(64), 0, st, (const uint8_t *)cs->p.dep, CC_NSOFT, (const uint8_t *)cs->p.overlap, 24, cs->p.vbits,
                            CC_NSOFT / 2, 25, CC_NSOFT / 2, g.nch, valid, (const int *)nullptr);
         hipLaunchKernelGGL(k_viterbi_overlap_update, dim3(g.nch), dim3(64), 0, st, (const uint8_t *)cs->p.dep, CC_NSOFT, cs->p.overlap, g.nch, valid, 0);
+        aprof_end(c, st);
+        aprof_begin(c, 2, st);
         hipLaunchKernelGGL(k_aerolc_post, grid, block, 0, st, g, cs->p);
+        aprof_end(c, st);
     }
     hipLaunchKernelGGL(k_aerolc_end_write, grid, block, 0, st, g, cs->p, dcounts);
     HIPCHK(hipGetLastError());

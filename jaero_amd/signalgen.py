@@ -217,13 +217,17 @@ def channel_bank(kind: str, nch: int, nsamples: int, *, ebno_db: float | None = 
 # torch (device-resident) generator for large banks: same waveform family as `oqpsk` above
 # ----------------------------------------------------------------------------------------------------------------------
 def _render_oqpsk_torch(a_i, a_q, carriers, nsamples: int, device, *, fb: float, Fs: float, sigma: float, scale: float, gen,
-                        block: int = 2048):
-    """Passband OQPSK (RRC alpha=1, Q arm delayed T/2) of the +-1/0 symbol arrays a_i, a_q [nch, nsym] -> int16 [nsamples, nch]."""
+                        block: int = 2048, start: int = 0, tphase=None, nphase: int = 1):
+    """Passband OQPSK (RRC alpha=1, Q arm delayed T/2) of the +-1/0 symbol arrays a_i, a_q [nch, nsym] -> int16 [nsamples, nch],
+    samples start .. start+nsamples-1 of the stream.  tphase (int64 [nch], values < nphase) delays channel c's symbol clock by
+    tphase[c]/nphase of TWO symbol periods (so both the symbol instants and the demodulator's odd/even symbol alternation are
+    spread): real channels are not symbol-synchronous with each other."""
     import torch
 
     nch, nsym = a_i.shape
     T = Fs / (fb / 2.0)
     out = torch.empty((nsamples, nch), dtype=torch.int16, device=device)
+    taus = torch.arange(nphase, device=device, dtype=torch.float64) * (2.0 * T / nphase)  # [nphase] timing offsets in samples
 
     def pulse(t):  # alpha = 1
         x = 4.0 * t / T
@@ -237,20 +241,32 @@ def _render_oqpsk_torch(a_i, a_q, carriers, nsamples: int, device, *, fb: float,
         return torch.where(t.abs() < 1e-9, torch.full_like(t, centre), r)
 
     def shape(a, n, delay):
-        t = n - delay
+        if tphase is None:
+            t = n - delay
+            k0 = torch.floor(t / T).to(torch.int64)
+            acc = torch.zeros((nch, n.shape[0]), dtype=torch.float32, device=device)
+            for j in range(-6, 8):
+                k = k0 + j
+                ok = (k >= 0) & (k < nsym)
+                kk = k.clamp(0, nsym - 1)
+                h = pulse((t - k.to(torch.float64) * T)).to(torch.float32) * ok.to(torch.float32)
+                acc += a[:, kk].to(torch.float32) * h[None, :]
+            return acc
+        # per-channel timing phase: the pulse samples are shared by the channels of one phase ([nphase, block] tables, gathered)
+        t = n[None, :] - delay - taus[:, None]                       # [nphase, block]
         k0 = torch.floor(t / T).to(torch.int64)
         acc = torch.zeros((nch, n.shape[0]), dtype=torch.float32, device=device)
         for j in range(-6, 8):
             k = k0 + j
             ok = (k >= 0) & (k < nsym)
-            kk = k.clamp(0, nsym - 1)
-            h = pulse((t - k.to(torch.float64) * T)).to(torch.float32) * ok.to(torch.float32)
-            acc += a[:, kk].to(torch.float32) * h[None, :]
+            h = pulse((t - k.to(torch.float64) * T)).to(torch.float32) * ok.to(torch.float32)  # [nphase, block]
+            kk = k.clamp(0, nsym - 1)[tphase]                        # [nch, block]
+            acc += torch.gather(a, 1, kk).to(torch.float32) * h[tphase]
         return acc
 
     for s in range(0, nsamples, block):
         e = min(nsamples, s + block)
-        n = torch.arange(s, e, device=device, dtype=torch.float64)
+        n = torch.arange(start + s, start + e, device=device, dtype=torch.float64)
         i_t = shape(a_i, n, 0.0)
         q_t = shape(a_q, n, T / 2.0)
         ph = (2.0 * np.pi / Fs) * carriers[:, None] * n[None, :]
@@ -260,6 +276,50 @@ def _render_oqpsk_torch(a_i, a_q, carriers, nsamples: int, device, *, fb: float,
             x = x + torch.randn(x.shape, generator=gen, device=device, dtype=torch.float32) * sigma
         out[s:e] = torch.clamp(torch.round(x * scale), -32768, 32767).to(torch.int16).t()
     return out
+
+
+class OqpskTorchStream:
+    """A bank of continuous 10.5k-style OQPSK channels on a torch device, rendered piece by piece: render(start, n) -> int16 [n, nch]
+    (frame-major).  Channel c: carrier fc_center + U(-fc_spread, fc_spread), random bits, AWGN at Eb/N0,
+    and -- with nphase > 1 -- its own symbol-clock phase (one of `nphase` offsets over two symbol periods, drawn at random): channels
+    of different satellites / transponders are not symbol-synchronous, and a demodulator bank's per-symbol work must not be timed on
+    the special case where every channel of a wavefront reaches its symbol instant at the same sample."""
+
+    def __init__(self, nch: int, total_samples: int, device, *, fb: float = 10500.0, Fs: float = 48000.0, fc_center: float = 8000.0,
+                 fc_spread: float = 100.0, ebno_db: float | None = 10.0, peak: float = 0.3, seed: int = SEED_BASE, nphase: int = 32):
+        import torch
+
+        self.nch, self.total, self.device, self.fb, self.Fs, self.nphase = nch, total_samples, device, fb, Fs, nphase
+        gen = torch.Generator(device=device)
+        gen.manual_seed(seed)
+        T = Fs / (fb / 2.0)
+        nsym = int(np.ceil(total_samples / T)) + 16
+        # +-1 symbols of the two arms (bit 2k of channel c on I, bit 2k+1 on Q); the bits themselves are rebuilt on demand (bits_of)
+        self.a_i = torch.randint(0, 2, (nch, nsym), generator=gen, device=device, dtype=torch.int8) * 2 - 1
+        self.a_q = torch.randint(0, 2, (nch, nsym), generator=gen, device=device, dtype=torch.int8) * 2 - 1
+        self.carriers = fc_center + (torch.rand(nch, generator=gen, device=device, dtype=torch.float64) * 2 - 1) * fc_spread
+        self.tphase = torch.randint(0, nphase, (nch,), generator=gen, device=device) if nphase > 1 else None
+        P = 1.0 / T  # signal power of unit-symbol OQPSK with a unit-energy RRC pulse
+        self.sigma = float(np.sqrt(P * Fs / (2.0 * fb * 10.0 ** (ebno_db / 10.0)))) if ebno_db is not None else 0.0
+        self.scale = peak / (3.0 * np.sqrt(P)) * 32768.0
+        self.gen = gen
+
+    def render(self, start: int, n: int, block: int = 1024):
+        return _render_oqpsk_torch(self.a_i, self.a_q, self.carriers, n, self.device, fb=self.fb, Fs=self.Fs, sigma=self.sigma, scale=self.scale,
+                                   gen=self.gen, block=block, start=start, tphase=self.tphase, nphase=self.nphase)
+
+    def bits_of(self, c: int) -> np.ndarray:
+        """Transmitted bits of channel c (uint8, even indices = I arm, odd = Q arm)."""
+        i = ((self.a_i[c] + 1) // 2).to("cpu").numpy().astype(np.uint8)
+        q = ((self.a_q[c] + 1) // 2).to("cpu").numpy().astype(np.uint8)
+        out = np.empty(2 * len(i), np.uint8)
+        out[0::2], out[1::2] = i, q
+        return out
+
+    def timing_offsets(self):
+        """Per-channel symbol-clock delay in samples."""
+        T = self.Fs / (self.fb / 2.0)
+        return None if self.tphase is None else self.tphase.to("cpu").numpy() * (2.0 * T / self.nphase)
 
 
 def oqpsk_torch(nch: int, nsamples: int, device, *, fb: float = 10500.0, Fs: float = 48000.0, fc_center: float = 8000.0,
