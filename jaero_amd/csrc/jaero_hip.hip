@@ -19,6 +19,7 @@
 #include "../../include/jaero_hip.h"
 #include "jaero_device.h"
 #include "k_oqpsk.h"
+#include "k_oqpsk_fb.h"
 #include "k_msk.h"
 #include "k_pre8400.h"
 #include "k_coarse.h"
@@ -139,6 +140,8 @@ struct jaero_ctx
     int *d_emitted = nullptr; // burst banks: per-channel count of soft bits already emitted (jaero_softbits_view)
     bool coarse_v2 = false; int coarse3_grid = 256, coarse_ver = 4;
     int msk_ldsn = 0; // MSK: matched-filter inputs kept in LDS (the rest of fir_n in registers)
+    int oq_pairs = 0; // 10.5 kbps OQPSK: front/back pairs per workgroup of k_oqpsk_fb (0 = the single-wavefront kernel k_oqpsk_samples)
+    int oq_ldsn = OQ_LDSN;
     // fb == 8400 (k_pre8400.h): prefilter buffers, samples written so far, size of the previous write
     bool pre8400 = false;
     JPre pre{};
@@ -619,6 +622,22 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         if (g.fir_n == 80) MSK_ATTR(80, MSK_LDSN_1200) else MSK_ATTR(160, MSK_LDSN_600)
 #undef MSK_ATTR
     }
+    if (g.kind == JAERO_KIND_OQPSK && !c->pre8400)
+    {
+        // 10.5 kbps: front / back pairs (k_oqpsk_fb.h).  Four pairs per workgroup put one front and one back wavefront on every SIMD of a
+        // CU -- worth it once there are more channel groups than two per CU; smaller banks get one pair per workgroup (two SIMDs per
+        // 64 channels).  JAERO_OQPSK_KERNEL=single keeps the single-wavefront kernel (k_oqpsk.h) for A/B comparison.
+        const char *e = getenv("JAERO_OQPSK_KERNEL");
+        const int ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        c->oq_pairs = (e && !strcmp(e, "single")) ? 0 : ((e && !strcmp(e, "pairs1")) ? 1 : ((e && !strcmp(e, "pairs4")) ? 4 : (g.ngroups > 2 * ncu ? 4 : 1)));
+        if (c->oq_pairs)
+        {
+#define FBA(E, C, PP) HIPCHK(hipFuncSetAttribute((const void *)k_oqpsk_fb<55, FB_LDSN, E, C, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, PP * fb_pair_doubles<FB_LDSN>() * (int)sizeof(double)))
+            FBA(false, false, 1); FBA(false, true, 1); FBA(true, false, 1); FBA(true, true, 1);
+            FBA(false, false, 4); FBA(false, true, 4); FBA(true, false, 4); FBA(true, true, 4);
+#undef FBA
+        }
+    }
     if (g.nfft_log2 == 14)
     {
         HIPCHK(hipFuncSetAttribute((const void *)k_coarse2<14>, hipFuncAttributeMaxDynamicSharedMemorySize, c->coarse2_lds));
@@ -800,6 +819,20 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
     const dim3 grid(g.ngroups), block(64);
     if (g.kind == JAERO_KIND_OQPSK)
     {
+        if (c->oq_pairs)
+        {
+            // front / back wavefront pairs (k_oqpsk_fb.h): PAIRS pairs per workgroup
+            const int fsb = (int)(c->m.nB_total % FB_LDSN);
+            const int P = c->oq_pairs;
+            const dim3 gridp((g.ngroups + P - 1) / P), blockp(P * 128);
+            const int ldsp = P * fb_pair_doubles<FB_LDSN>() * (int)sizeof(double);
+#define LFB(E, C, PP) hipLaunchKernelGGL((k_oqpsk_fb<55, FB_LDSN, E, C, PP>), gridp, blockp, ldsp, st, g, c->p, frames, stride, n, skipA, onlyA, fsb)
+#define LFBP(E, C) { if (P == 4) LFB(E, C, 4); else LFB(E, C, 1); }
+            if (eb && cs) LFBP(true, true) else if (eb) LFBP(true, false) else if (cs) LFBP(false, true) else LFBP(false, false)
+#undef LFBP
+#undef LFB
+            return;
+        }
         const int lds = (2 * OQ_LDSN * 64 + 64) * (int)sizeof(double); // rings + this wavefront's copy of the 55 taps
         const int fs = (int)(c->m.nB_total % OQ_LDSN);
 #define LO(E, C) hipLaunchKernelGGL((k_oqpsk_samples<55, OQ_LDSN, E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs)

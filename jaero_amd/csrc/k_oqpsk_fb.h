@@ -1,0 +1,512 @@
+// k_oqpsk_fb.h -- sample-loop kernel for the continuous 10.5 kbps OQPSK demodulator, front / back wavefront pairs.
+//
+// Same arithmetic as k_oqpsk.h (OqpskDemodulator::writeData's per-sample loop, JAERO/oqpskdemodulator.cpp:388-605, fb > 8400), one
+// channel per lane, but the per-sample work of 64 channels is shared by TWO wavefronts that run concurrently:
+//
+//   F ("front"):  K1 PCM -> double, K3 coarse ring fill (mixer_center), K2 mix with the carrier NCO value the back half hands over,
+//                 K6 RRC matched filter (history in LDS + registers), K7 EbNo meter, K8 AGC + clip.   Owns every HBM stream
+//                 (PCM, AGC / EbNo window rows, coarse ring) and the filter history; needs few registers besides the filter's.
+//   B ("back"):   K9 symbol timing (delays, resonator, atan2, symbol NCO), K10 sample instant + interpolation, K11 carrier loop,
+//                 K12 residual rotation, K13 MSE, K14 soft bits, the carrier NCO.   Owns the symbol-rate rings and the outputs;
+//                 needs registers and no LDS.
+//
+// Why this split works: the matched filter's output for sample n+1 does not contain x[n+1] (FIR::FIRUpdateAndProcess excludes the
+// newest sample, DSP.cpp:292-304), and x[n] = mixer2(n) * pcm[n] is known as soon as the back half has finished sample n-1.  So while
+// B runs sample n, F forms x[n], pushes it and produces the AGC'd, clipped sample n+1.  One s_barrier per sample, two mailboxes in
+// LDS (double buffered): B -> F the carrier table index of the next sample, F -> B {sre, sim, |.|} of the next sample.
+//
+// Why it pays: a wavefront issues one instruction every ~4 cycles; the single-wavefront kernel is ~1700 instructions per sample, of which
+// fewer than half are fp64 VALU work.  It fills a SIMD's register file (512) and 40 KiB of LDS, so nothing else can run beside it.
+// Split, each half fits 256 registers, only F needs LDS, and a 512-thread workgroup (four pairs) puts one F and one B wavefront on
+// every SIMD (waves w and w+4 of a workgroup share a SIMD): the halves' instruction streams interleave, and the serial chain of
+// a channel is spread over two instruction streams.  Small banks use one pair per workgroup (two SIMDs per 64 channels).
+//
+// Second change against k_oqpsk.h: the OUTPUT half of the symbol block (averages, residual rotation, MSE, soft bits -- nothing
+// of it feeds back into the signal path) is queued per lane and run for all lanes together every FB_DEFER samples: with channels
+// that are not symbol-synchronous some lane is at a symbol instant in nearly every sample, and the whole block used to run each
+// time for ~5 % of the lanes.  The feedback half (tanh detector, loop filter, carrier NCO) still runs at the instant.
+// Third: divisions by constants are done with the constant's reciprocal and two fma corrections (jd_div_const), bit-identical to
+// the IEEE quotient; fmod(x, 360) takes the exact shortcut for |x| < 720.
+#pragma once
+#include "jaero_device.h"
+
+#define FB_DEFER 16
+#define FB_LDSN 35 // filter history slots in LDS: 35 KiB + taps + mailboxes = 39 936 B per pair, four pairs per CU
+
+// x / d for a positive constant d with rd = 1.0 / d (correctly rounded): q = x*rd is within an ulp, two Newton corrections through exact
+// fma residuals give the correctly rounded quotient (Markstein); the sign of a zero result is x's.  Checked against x / d on 2e9
+// random, near-multiple and near-midpoint operands per constant (scripts/div_const_check.c): no difference.
+__device__ __forceinline__ double jd_div_const(double x, double d, double rd)
+{
+    double q = x * rd;
+    double r = fma(-d, q, x);
+    q = fma(r, rd, q);
+    r = fma(-d, q, x);
+    q = fma(r, rd, q);
+    return copysign(q, x);
+}
+// WaveTable::SetFreq(double) with the division by the (constant) sample rate done by jd_div_const
+__device__ __forceinline__ void fb_wt_setfreq(double &freq, double &step, double f, double samplerate, double r_samplerate)
+{
+    freq = f;
+    if (freq < 0) freq = 0;
+    step = jd_div_const((freq) * ((double)JD_WTSIZE), samplerate, r_samplerate);
+}
+// fmod(x, 360.0): exact by definition, so any exact evaluation gives the same bits; |x| < 720 covers every value the carrier loop
+// produces (360 * ptr / 19999 + a clamped error), the general case falls back to the library
+__device__ __forceinline__ double fb_fmod360(double x)
+{
+    const double ax = fabs(x);
+    if (ax < 360.0) return x;
+    if (ax < 720.0) return copysign(ax - 360.0, x);
+    return fmod(x, 360.0);
+}
+
+struct FbLds
+{
+    double *lre, *lim, *ltap; // [LDSN][64], [LDSN][64], [64]
+    double *data;             // [2][3][64]  F -> B: sre, sim, abval of a sample
+    int *idx;                 // [2][64]     B -> F: table index of mixer2 for a sample
+};
+template <int LDSN>
+constexpr int fb_pair_doubles() { return 2 * LDSN * 64 + 64 + 2 * 3 * 64 + 64; }
+
+__device__ __forceinline__ void fb_barrier()
+{
+    // LDS traffic of this wavefront done, then the workgroup barrier.  NOT __syncthreads(): that also drains vmcnt, i.e. every
+    // HBM row requested ahead for the next sample.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------------------------------ front half
+template <int FIRN, int LDSN, bool EBNO>
+__device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const FbLds &L, const int16_t *__restrict__ pcm, int pcm_stride, int n,
+                                         int skip_a_first, int only_a_last, int fir_slot0, int grp, int lane)
+{
+    constexpr int TAILN = FIRN - LDSN;
+    double tre[TAILN], tim[TAILN]; // tre[j] = x_re[n-LDSN-j] once x[n] has been pushed
+    const int ch = grp * 64 + lane;
+    const int nchp = g.nchp;
+    const bool live = ch < g.nch;
+    const double2 *__restrict__ cis = p.cis;
+    const int nB = n - (only_a_last ? 1 : 0); // samples whose B-part runs in this launch
+
+    double mc_ptr = LDF(S_MC_PTR), mc_step = LDF(S_MC_STEP);
+    double agc_sum = LDF(S_AGC_SUM);
+    double eb_esum = LDF(S_EB_ESUM), eb_e2sum = LDF(S_EB_E2SUM), eb_ebno = LDF(S_EB_EBNO);
+    int agc_pos = LDI(I_AGC_POS), eb_pos = LDI(I_EB_POS), bb_ptr = LDI(I_BB_PTR), coarse_cnt = LDI(I_COARSE_CNT);
+    const int flags = LDI(I_FLAGS);
+    const int nfft_mask = g.nfft - 1;
+    double2 *__restrict__ bbring = p.bbring + (size_t)ch * g.nfft;
+    double *__restrict__ agc_ring = p.agc_ring + (size_t)grp * g.agc_len * 64 + lane;
+    double *__restrict__ ebe_ring = p.eb_e + (size_t)grp * g.ebno_len * 64 + lane;
+    double *__restrict__ ebe2_ring = p.eb_e2 + (size_t)grp * g.ebno_len * 64 + lane;
+
+    double *lre = L.lre, *lim = L.lim, *ltap = L.ltap;
+    {
+        const double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
+        for (int k = 0; k < LDSN; k++)
+        {
+            lre[k * 64 + lane] = fs[(size_t)k * 64];
+            lim[k * 64 + lane] = fs[(size_t)(FIRN + k) * 64];
+        }
+#pragma unroll
+        for (int j = 0; j < TAILN; j++)
+        {
+            tre[j] = fs[(size_t)(LDSN + j) * 64];
+            tim[j] = fs[(size_t)(FIRN + LDSN + j) * 64];
+        }
+        if (lane < FIRN) ltap[lane] = p.taps2[lane];
+    }
+    int fir_slot = fir_slot0; // wave-uniform: LDS slot holding the oldest LDS entry, overwritten by the next input
+    auto fir_eval = [&](double &ore, double &oim) { jd_fir_eval<FIRN, LDSN, 8>(lre, lim, ltap, tre, tim, fir_slot, lane, ore, oim); };
+
+    const double agc_len_d = (double)g.agc_len, eb_len_d = (double)g.ebno_len;
+    const double r_agc_len = 1.0 / agc_len_d, r_eb_len = 1.0 / eb_len_d;
+
+    // K7 + K8 for one sample: EbNo meter, AGC, clip; hands {sre, sim, abval} to the back half through mailbox `buf`
+    // (oqpskdemodulator.cpp:458-470, DSP.cpp:729-744, :370-379); agc_old / e_old / e2_old = the rows leaving the windows
+    auto front_sample = [&](double sre, double sim, double agc_old, double e_old, double e2_old, int j, int buf) {
+        const double dabval = sqrt(sre * sre + sim * sim);
+        if (EBNO)
+        {
+            const double sq = dabval * dabval;
+            double *e2p = ebe2_ring + (size_t)eb_pos * 64;
+            double *ep = ebe_ring + (size_t)eb_pos * 64;
+            eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq); *e2p = fabs(sq);
+            eb_esum = eb_esum - e_old; eb_esum = eb_esum + fabs(dabval); *ep = fabs(dabval);
+            eb_pos++; if (eb_pos >= g.ebno_len) eb_pos = 0;
+            if (j >= n - JD_EBNO_TAIL) // wave-uniform; see JD_EBNO_TAIL
+            {
+                const double e2val = jd_div_const(eb_e2sum, eb_len_d, r_eb_len), mean = jd_div_const(eb_esum, eb_len_d, r_eb_len);
+                const double meansq = mean * mean;
+                double var = e2val - (mean * mean);
+                var -= (0.024709 * meansq);
+                double mvr = (((g.Fs * meansq / (2.0 * g.fb * var))) * 0.13743);
+                if (mvr < 0.000000001) mvr = 0.000000001;
+                double tebno = 10.0 * log10(mvr);
+                if (isnan(tebno)) tebno = 50;
+                if (tebno > 50.0) tebno = 50;
+                if (tebno < 0.0) tebno = 0;
+                eb_ebno = eb_ebno * 0.8 + 0.2 * tebno;
+            }
+        }
+        {
+            double *ap = agc_ring + (size_t)agc_pos * 64;
+            agc_sum = agc_sum - agc_old;
+            agc_sum = agc_sum + fabs(dabval);
+            *ap = fabs(dabval);
+            agc_pos++; if (agc_pos >= g.agc_len) agc_pos = 0;
+        }
+        double gain = 1.414213562 / fmax(jd_div_const(agc_sum, agc_len_d, r_agc_len), 0.000001);
+        gain = fmax(gain, 0.000001);
+        sre *= gain; sim *= gain;
+        const double abval = hypot(sre, sim);
+        if (abval > 2.84) { const double k = (2.84 / abval); sre = k * sre; sim = k * sim; }
+        double *d = L.data + buf * 3 * 64 + lane;
+        d[0] = sre; d[64] = sim; d[128] = abval;
+    };
+
+    // rows leaving the AGC / EbNo windows at the next sample to be fronted, requested one step ahead
+    double nx_agc = agc_ring[(size_t)agc_pos * 64];
+    double nx_e = 0, nx_e2 = 0;
+    if (EBNO) { nx_e = ebe_ring[(size_t)eb_pos * 64]; nx_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
+    short nx_pcm = (live && n > 0) ? pcm[ch] : (short)0;
+    double2 nx_cc = cis[jd_cisidx(mc_ptr)];
+
+    // prologue: sample 0's filter output comes from the saved history
+    if (nB > 0)
+    {
+        double y_re, y_im;
+        fir_eval(y_re, y_im);
+        const double a0 = nx_agc, e0 = nx_e, e20 = nx_e2;
+        front_sample(y_re, y_im, a0, e0, e20, 0, 0);
+        nx_agc = agc_ring[(size_t)agc_pos * 64];
+        if (EBNO) { nx_e = ebe_ring[(size_t)eb_pos * 64]; nx_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
+    }
+    fb_barrier();
+
+    for (int i = 0; i < nB; i++)
+    {
+        // the carrier NCO's table value for sample i (index handed over by the back half) -- an L2 hit, covered by the ring fill
+        const int m2i = L.idx[(i & 1) * 64 + lane];
+        const double2 c_m2 = cis[m2i];
+        const short s = nx_pcm;
+        const double dval = ((double)s) / 32768.0;
+        const double2 cc = nx_cc;
+        // ---- K3: coarse-frequency ring fill (oqpskdemodulator.cpp:410-415) ----
+        const bool do_fill = !(i == 0 && skip_a_first) && ((coarse_cnt >= g.Fs_int) || !(flags & JF_CPUREDUCE));
+        if (do_fill)
+        {
+            bbring[bb_ptr] = make_double2(cc.x * dval, cc.y * dval);
+            bb_ptr = (bb_ptr + 1) & nfft_mask;
+        }
+        coarse_cnt++; // :431
+        jd_wt_next(mc_ptr, mc_step);
+        if (i + 1 < n)
+        {
+            nx_pcm = live ? pcm[(size_t)(i + 1) * pcm_stride + ch] : (short)0;
+            nx_cc = cis[jd_cisidx(mc_ptr)];
+        }
+        // ---- K2: x[i] = mixer2 * dval, pushed into the matched filter (:453-456) ----
+        {
+            const double cre = c_m2.x * dval, cim = c_m2.y * dval;
+#pragma unroll
+            for (int j = TAILN - 1; j > 0; j--) { tre[j] = tre[j - 1]; tim[j] = tim[j - 1]; }
+            tre[0] = lre[fir_slot * 64 + lane];
+            tim[0] = lim[fir_slot * 64 + lane];
+            lre[fir_slot * 64 + lane] = cre;
+            lim[fir_slot * 64 + lane] = cim;
+            fir_slot++;
+            if (fir_slot >= LDSN) fir_slot = 0;
+        }
+        // ---- K6..K8 for sample i+1 (if its B-part runs in this launch) ----
+        if (i + 1 < nB)
+        {
+            double y_re, y_im;
+            fir_eval(y_re, y_im);
+            const double a0 = nx_agc, e0 = nx_e, e20 = nx_e2;
+            front_sample(y_re, y_im, a0, e0, e20, i + 1, (i + 1) & 1);
+            nx_agc = agc_ring[(size_t)agc_pos * 64];
+            if (EBNO) { nx_e = ebe_ring[(size_t)eb_pos * 64]; nx_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
+        }
+        fb_barrier();
+    }
+    if (only_a_last) // the coarse estimate runs now; the next launch resumes with this sample's B-part
+    {
+        const double dval = ((double)nx_pcm) / 32768.0;
+        const bool do_fill = !(nB == 0 && skip_a_first) && ((coarse_cnt >= g.Fs_int) || !(flags & JF_CPUREDUCE));
+        if (do_fill)
+        {
+            bbring[bb_ptr] = make_double2(nx_cc.x * dval, nx_cc.y * dval);
+            bb_ptr = (bb_ptr + 1) & nfft_mask;
+        }
+    }
+
+    LDF(S_MC_PTR) = mc_ptr; LDF(S_MC_STEP) = mc_step;
+    LDF(S_AGC_SUM) = agc_sum;
+    LDF(S_EB_ESUM) = eb_esum; LDF(S_EB_E2SUM) = eb_e2sum; LDF(S_EB_EBNO) = eb_ebno;
+    LDI(I_AGC_POS) = agc_pos; LDI(I_EB_POS) = eb_pos; LDI(I_BB_PTR) = bb_ptr; LDI(I_COARSE_CNT) = coarse_cnt;
+    {
+        double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
+        for (int k = 0; k < LDSN; k++)
+        {
+            fs[(size_t)k * 64] = lre[k * 64 + lane];
+            fs[(size_t)(FIRN + k) * 64] = lim[k * 64 + lane];
+        }
+#pragma unroll
+        for (int j = 0; j < TAILN; j++)
+        {
+            fs[(size_t)(LDSN + j) * 64] = tre[j];
+            fs[(size_t)(FIRN + LDSN + j) * 64] = tim[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------- back half
+template <bool CAPSYM>
+__device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, const FbLds &L, int n, int only_a_last, int grp, int lane)
+{
+    const int ch = grp * 64 + lane;
+    const int nchp = g.nchp;
+    const double2 *__restrict__ cis = p.cis;
+    const int nB = n - (only_a_last ? 1 : 0);
+
+    double m2_ptr = LDF(S_M2_PTR), m2_step = LDF(S_M2_STEP), m2_freq = LDF(S_M2_FREQ);
+    double st_ptr = LDF(S_ST_PTR), st_step = LDF(S_ST_STEP), st_freq = LDF(S_ST_FREQ), st_last = LDF(S_ST_LAST);
+    double d1 = LDF(S_D1);
+    double d41_1 = LDF(S_D41_1), d41_2 = LDF(S_D41_2), d41_3 = LDF(S_D41_3);
+    double d42_1 = LDF(S_D42_1), d42_2 = LDF(S_D42_2), d42_3 = LDF(S_D42_3);
+    double d8_1 = LDF(S_D8_1), d8_2 = LDF(S_D8_2);
+    double res_x1 = LDF(S_RES_X1), res_x2 = LDF(S_RES_X2), res_y1 = LDF(S_RES_Y1), res_y2 = LDF(S_RES_Y2);
+    double lf_x1 = LDF(S_LF_X1), lf_x2 = LDF(S_LF_X2), lf_y1 = LDF(S_LF_Y1), lf_y2 = LDF(S_LF_Y2);
+    double sig2l_re = LDF(S_SIG2L_RE), sig2l_im = LDF(S_SIG2L_IM), ptd_re = LDF(S_PTD_RE), ptd_im = LDF(S_PTD_IM);
+    double marg_sum = LDF(S_MARG_SUM), pm_sum = LDF(S_PM_SUM), msema_sum = LDF(S_MSEMA_SUM), mse = LDF(S_MSE);
+    const double thresh = LDF(S_THRESH);
+    int marg_pos = LDI(I_MARG_POS), dt_pos = LDI(I_DT_POS), pm_pos = LDI(I_PM_POS), msema_pos = LDI(I_MSEMA_POS);
+    int yui = LDI(I_YUI), sig2l_init = LDI(I_SIG2L_INIT);
+    int soft_cnt = LDI(I_SOFT_CNT), sym_cnt = LDI(I_SYM_CNT), overflow = LDI(I_OVERFLOW);
+
+    const double samplerate = g.Fs; // WaveTable::samplerate after SetFreq(freq,(int)Fs)
+    const double r_samplerate = 1.0 / samplerate;
+    const double wtsize_d = (double)JD_WTSIZE, r_wtsize = 1.0 / wtsize_d, r_360 = 1.0 / 360.0;
+    const double marg_len_d = (double)g.marg_len, pm_len_d = (double)g.pm_len, msema_len_d = (double)g.msema_len;
+    const double r_marg_len = 1.0 / marg_len_d, r_pm_len = 1.0 / pm_len_d, r_msema_len = 1.0 / msema_len_d;
+    double *__restrict__ marg_ring = p.marg + (size_t)ch * g.marg_len;
+    double2 *__restrict__ dt_ring = p.dt + (size_t)ch * g.dt_len;
+    double *__restrict__ pm_ring = p.pm + (size_t)ch * g.pm_len;
+    double *__restrict__ msema_ring = p.msema + (size_t)ch * g.msema_len;
+    const double w4 = g.w4, w4c = 1.0 - g.w4, w8 = g.w8, w8c = 1.0 - g.w8;
+
+    // the output half of a symbol, queued at the instant: marg->UpdateSigned(ct_ec) .. soft bits (oqpskdemodulator.cpp:534-595).
+    // pd_* = what it needs from the instant; px_* = the ring entries leaving the four windows, requested when the symbol is queued.
+    bool pend = false;
+    double pd_ec = 0, pd_re = 0, pd_im = 0;
+    double px_marg = 0, px_pm = 0, px_ms = 0;
+    double2 px_dt = make_double2(0.0, 0.0);
+    auto queue_symbol = [&](double ct_ec, double q_re, double q_im) {
+        pend = true; pd_ec = ct_ec; pd_re = q_re; pd_im = q_im;
+        px_marg = marg_ring[marg_pos];
+        int dn = dt_pos + 1; if (dn >= g.dt_len) dn = 0;
+        px_dt = dt_ring[dn]; // = what dt.update returns: the slot after the one being written (dt_len > 1)
+        px_pm = pm_ring[pm_pos];
+        px_ms = msema_ring[msema_pos];
+    };
+    auto output_half = [&]() {
+        const double ct_ec = pd_ec;
+        double q_re = pd_re, q_im = pd_im;
+        // marg->UpdateSigned(ct_ec)
+        {
+            double *mp = marg_ring + marg_pos;
+            marg_sum = marg_sum - px_marg; marg_sum = marg_sum + ct_ec; *mp = ct_ec;
+            marg_pos++; if (marg_pos >= g.marg_len) marg_pos = 0;
+        }
+        const double marg_val = jd_div_const(marg_sum, marg_len_d, r_marg_len);
+        // dt.update(pt_qpsk)
+        {
+            dt_ring[dt_pos] = make_double2(q_re, q_im);
+            dt_pos++; if (dt_pos >= g.dt_len) dt_pos = 0;
+            q_re = px_dt.x; q_im = px_dt.y;
+        }
+        {
+            const double cr = cos(marg_val), sr = sin(marg_val);
+            const double nr = q_re * cr - q_im * sr;
+            const double ni = q_re * sr + q_im * cr;
+            q_re = nr; q_im = ni;
+        }
+        // MSEcalc::Update (DSP.cpp:451-463)
+        {
+            const double av = hypot(q_re, q_im);
+            double *pp = pm_ring + pm_pos;
+            pm_sum = pm_sum - px_pm; pm_sum = pm_sum + fabs(av); *pp = fabs(av);
+            pm_pos++; if (pm_pos >= g.pm_len) pm_pos = 0;
+            double mu = jd_div_const(pm_sum, pm_len_d, r_pm_len);
+            if (mu < 0.000001) mu = 0.000001;
+            const double s2 = sqrt(2.0);
+            const double t_re = (s2 * q_re) / mu, t_im = (s2 * q_im) / mu;
+            const double tda = (fabs(t_re) - 1.0), tdb = (fabs(t_im) - 1.0);
+            const double e = (tda * tda) + (tdb * tdb);
+            double *ep = msema_ring + msema_pos;
+            msema_sum = msema_sum - px_ms; msema_sum = msema_sum + fabs(e); *ep = fabs(e);
+            msema_pos++; if (msema_pos >= g.msema_len) msema_pos = 0;
+            mse = jd_div_const(msema_sum, msema_len_d, r_msema_len);
+        }
+        if (CAPSYM)
+        {
+            if (sym_cnt < g.sym_cap)
+            {
+                double *sp = p.sym + ((size_t)ch * g.sym_cap + sym_cnt) * 3;
+                sp[0] = q_re; sp[1] = q_im; sp[2] = mse;
+                sym_cnt++;
+            }
+            else overflow |= 2;
+        }
+        if (mse < thresh)
+        {
+            const int b0 = jd_softbit(0.75 * q_im * 127.0 + 128.0);
+            const int b1 = jd_softbit(0.75 * q_re * 127.0 + 128.0);
+            if (soft_cnt + 2 <= g.soft_cap)
+            {
+                int16_t *sp = p.soft + (size_t)ch * g.soft_cap + soft_cnt;
+                sp[0] = (int16_t)b0;
+                sp[1] = (int16_t)b1;
+                soft_cnt += 2;
+            }
+            else overflow |= 1;
+        }
+        pend = false;
+    };
+
+    // mailbox: the table index of mixer2 for sample 0
+    L.idx[lane] = jd_cisidx(m2_ptr);
+    fb_barrier();
+
+    for (int i = 0; i < nB; i++)
+    {
+        const double2 c_st = cis[jd_cisidx(st_ptr)]; // an L2 hit, needed after the resonator
+        const double *d = L.data + (i & 1) * 3 * 64 + lane;
+        double sre = d[0], sim = d[64];
+        const double abval = d[128];
+
+        // ---- K9 symbol timing (:473-484) ----
+        const double ab2 = abval * abval;
+        const double st_diff = d1 - ab2; d1 = ab2;
+        const double st_d1out = w4 * d41_2 + w4c * d41_3; d41_3 = d41_2; d41_2 = d41_1; d41_1 = st_diff;
+        const double st_d2out = w4 * d42_2 + w4c * d42_3; d42_3 = d42_2; d42_2 = d42_1; d42_1 = st_d1out;
+        double st_eta = (st_d2out - st_diff) * st_d1out;
+        {
+            double y = 0;
+            y += res_x2 * g.res_b2; y += res_x1 * g.res_b1; y += st_eta * g.res_b0;
+            y -= res_y2 * g.res_a2; y -= res_y1 * g.res_a1;
+            res_x2 = res_x1; res_x1 = st_eta; res_y2 = res_y1; res_y1 = y;
+            st_eta = y;
+        }
+        const double d8out = w8 * d8_1 + w8c * d8_2; d8_2 = d8_1; d8_1 = st_eta;
+        {
+            const double2 so = c_st;
+            const double m_re = st_eta, m_im = -d8out;
+            const double o_re = so.x * m_re - so.y * m_im;
+            const double o_im = so.x * m_im + so.y * m_re;
+            const double st_angle_error = atan2(o_im, o_re);
+            fb_wt_setfreq(st_freq, st_step, (-st_angle_error * 0.00000001) + st_freq, samplerate, r_samplerate);
+            jd_wt_advance_fraction(st_ptr, jd_div_const(-st_angle_error * 0.01, 360.0, r_360));
+            if (st_freq < (g.stref_freq - 0.1)) fb_wt_setfreq(st_freq, st_step, (g.stref_freq - 0.1), samplerate, r_samplerate);
+            if (st_freq > (g.stref_freq + 0.1)) fb_wt_setfreq(st_freq, st_step, (g.stref_freq + 0.1), samplerate, r_samplerate);
+        }
+
+        // ---- K10..K14 at symbol instants (:487-595) ----
+        if (!sig2l_init) { sig2l_re = sre; sig2l_im = sim; sig2l_init = 1; }
+        double frac;
+        const bool inst = jd_wt_passed(st_last, st_ptr, st_step, g.ee, frac);
+        const bool full = inst && (yui == 0); // yui flips to 1 at this instant: the instant that closes a symbol pair
+        // queued output halves: all lanes together every FB_DEFER samples; a lane about to queue a second one goes first
+        if (pend && (full || (i & (FB_DEFER - 1)) == 0)) output_half();
+        if (inst)
+        {
+            const double pt_last = frac, pt_this = 1.0 - pt_last;
+            const double pt_re = pt_this * sre + pt_last * sig2l_re;
+            const double pt_im = pt_this * sim + pt_last * sig2l_im;
+            yui++; yui %= 2;
+            if (!yui) { ptd_re = pt_re; ptd_im = pt_im; }
+            else
+            {
+                const double ct_xt = tanh(pt_im) * pt_re;
+                const double ct_xt_d = tanh(ptd_re) * ptd_im;
+                double ct_ec = ct_xt_d - ct_xt;
+                if (ct_ec > M_PI) ct_ec = M_PI;
+                if (ct_ec < -M_PI) ct_ec = -M_PI;
+                {
+                    double y = 0;
+                    y += lf_x2 * g.lf_b2; y += lf_x1 * g.lf_b1; y += ct_ec * g.lf_b0;
+                    y -= lf_y2 * g.lf_a2; y -= lf_y1 * g.lf_a1;
+                    lf_x2 = lf_x1; lf_x1 = ct_ec; lf_y2 = lf_y1; lf_y1 = y;
+                    ct_ec = y;
+                }
+                if (ct_ec > M_PI_2) ct_ec = M_PI_2;
+                if (ct_ec < -M_PI_2) ct_ec = -M_PI_2;
+                // mixer2.IncresePhaseDeg(1.0*ct_ec) (DSP.cpp:169-180)
+                {
+                    double phase_deg = 1.0 * ct_ec;
+                    phase_deg += jd_div_const(360.0 * m2_ptr, wtsize_d, r_wtsize);
+                    phase_deg = fb_fmod360(phase_deg);
+                    while (phase_deg < 0) phase_deg += 360.0;
+                    m2_ptr = jd_div_const(phase_deg, 360.0, r_360) * wtsize_d;
+                }
+                fb_wt_setfreq(m2_freq, m2_step, (0.01 * ct_ec) + m2_freq, samplerate, r_samplerate);
+                queue_symbol(ct_ec, pt_re, ptd_im);
+            }
+        }
+        sig2l_re = sre; sig2l_im = sim;
+
+        // ---- advance the NCOs (:600-603) and hand the next sample's carrier table index to the front half ----
+        jd_wt_next(m2_ptr, m2_step);
+        L.idx[((i + 1) & 1) * 64 + lane] = jd_cisidx(m2_ptr);
+        if (st_step < 0) st_step = 0;
+        st_last = st_ptr;
+        st_ptr += st_step;
+        while (((int)st_ptr) >= JD_WTSIZE) st_ptr -= JD_WTSIZE;
+        fb_barrier();
+    }
+    if (pend) output_half();
+
+    LDF(S_M2_PTR) = m2_ptr; LDF(S_M2_STEP) = m2_step; LDF(S_M2_FREQ) = m2_freq;
+    LDF(S_ST_PTR) = st_ptr; LDF(S_ST_STEP) = st_step; LDF(S_ST_FREQ) = st_freq; LDF(S_ST_LAST) = st_last;
+    LDF(S_D1) = d1;
+    LDF(S_D41_1) = d41_1; LDF(S_D41_2) = d41_2; LDF(S_D41_3) = d41_3;
+    LDF(S_D42_1) = d42_1; LDF(S_D42_2) = d42_2; LDF(S_D42_3) = d42_3;
+    LDF(S_D8_1) = d8_1; LDF(S_D8_2) = d8_2;
+    LDF(S_RES_X1) = res_x1; LDF(S_RES_X2) = res_x2; LDF(S_RES_Y1) = res_y1; LDF(S_RES_Y2) = res_y2;
+    LDF(S_LF_X1) = lf_x1; LDF(S_LF_X2) = lf_x2; LDF(S_LF_Y1) = lf_y1; LDF(S_LF_Y2) = lf_y2;
+    LDF(S_SIG2L_RE) = sig2l_re; LDF(S_SIG2L_IM) = sig2l_im; LDF(S_PTD_RE) = ptd_re; LDF(S_PTD_IM) = ptd_im;
+    LDF(S_MARG_SUM) = marg_sum; LDF(S_PM_SUM) = pm_sum; LDF(S_MSEMA_SUM) = msema_sum; LDF(S_MSE) = mse;
+    LDI(I_MARG_POS) = marg_pos; LDI(I_DT_POS) = dt_pos; LDI(I_PM_POS) = pm_pos; LDI(I_MSEMA_POS) = msema_pos;
+    LDI(I_YUI) = yui; LDI(I_SIG2L_INIT) = sig2l_init;
+    LDI(I_SOFT_CNT) = soft_cnt; LDI(I_SYM_CNT) = sym_cnt; LDI(I_OVERFLOW) = overflow;
+}
+
+// PAIRS front/back pairs per workgroup: waves 0..PAIRS-1 are the front halves of channel groups blockIdx.x*PAIRS + w, waves
+// PAIRS..2*PAIRS-1 the back halves of the same groups.  A pair whose group lies beyond the bank only keeps the barrier count.
+template <int FIRN, int LDSN, bool EBNO, bool CAPSYM, int PAIRS>
+__global__ __launch_bounds__(PAIRS * 128) void k_oqpsk_fb(const JGeom g, const JPtrs p, const int16_t *__restrict__ pcm, int pcm_stride, int n,
+                                                          int skip_a_first, int only_a_last, int fir_slot0)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const bool back = wave >= PAIRS;
+    const int pair = back ? wave - PAIRS : wave;
+    const int grp = blockIdx.x * PAIRS + pair;
+    double *base = lds + (size_t)pair * fb_pair_doubles<LDSN>();
+    FbLds L;
+    L.lre = base; L.lim = base + LDSN * 64; L.ltap = base + 2 * LDSN * 64;
+    L.data = L.ltap + 64;
+    L.idx = (int *)(L.data + 2 * 3 * 64);
+    if (grp >= g.ngroups)
+    {
+        const int nB = n - (only_a_last ? 1 : 0);
+        for (int i = 0; i <= nB; i++) fb_barrier();
+        return;
+    }
+    if (back) fb_back<CAPSYM>(g, p, L, n, only_a_last, grp, lane);
+    else fb_front<FIRN, LDSN, EBNO>(g, p, L, pcm, pcm_stride, n, skip_a_first, only_a_last, fir_slot0, grp, lane);
+}

@@ -5,7 +5,7 @@ set -u
 TAG=${1:-r2b}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-( timeout 1500 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -40 ) > "$OUT/pytest_gpu.log"
+timeout 1500 python -m pytest tests -m gpu -q --durations=8 --tb=short > "$OUT/pytest_gpu_full.log" 2>&1; tail -40 "$OUT/pytest_gpu_full.log" > "$OUT/pytest_gpu.log"; grep -n "^E  " "$OUT/pytest_gpu_full.log" | head -40
 tail -4 "$OUT/pytest_gpu.log"
 ( timeout 900 python bench.py --steps 20 --warmup 5 2> "$OUT/bench.err" | tail -1 ) > "$OUT/bench_line.json"
 cat "$OUT/bench_line.json"; tail -3 "$OUT/bench.err"

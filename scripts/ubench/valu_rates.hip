@@ -39,6 +39,17 @@ KERNEL(k_perm, "v_perm_b32 %0, %0, %4, %1\n v_perm_b32 %1, %1, %4, %2\n v_perm_b
 KERNEL64(k_fma_f64, "v_fma_f64 %0, %0, %4, %4\n v_fma_f64 %1, %1, %4, %4\n v_fma_f64 %2, %2, %4, %4\n v_fma_f64 %3, %3, %4, %4")
 KERNEL64(k_add_f64, "v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4")
 KERNEL64(k_mul_f64, "v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4")
+KERNEL64(k_rcp_f64, "v_rcp_f64 %0, %0\n v_rcp_f64 %1, %1\n v_rcp_f64 %2, %2\n v_rcp_f64 %3, %3")
+KERNEL64(k_sqrt_f64, "v_sqrt_f64 %0, %0\n v_sqrt_f64 %1, %1\n v_sqrt_f64 %2, %2\n v_sqrt_f64 %3, %3")
+KERNEL64(k_ldexp_f64, "v_ldexp_f64 %0, %0, 1\n v_ldexp_f64 %1, %1, 1\n v_ldexp_f64 %2, %2, 1\n v_ldexp_f64 %3, %3, 1")
+KERNEL64(k_divfix_f64, "v_div_fixup_f64 %0, %0, %4, %4\n v_div_fixup_f64 %1, %1, %4, %4\n v_div_fixup_f64 %2, %2, %4, %4\n v_div_fixup_f64 %3, %3, %4, %4")
+KERNEL64(k_cmp_f64, "v_cmp_lt_f64 vcc, %0, %4\n v_cmp_lt_f64 vcc, %1, %4\n v_cmp_lt_f64 vcc, %2, %4\n v_cmp_lt_f64 vcc, %3, %4")
+KERNEL64(k_mov_b64, "v_mov_b64 %0, %1\n v_mov_b64 %1, %2\n v_mov_b64 %2, %3\n v_mov_b64 %3, %4")
+KERNEL64(k_max_f64, "v_max_f64 %0, %0, %4\n v_max_f64 %1, %1, %4\n v_max_f64 %2, %2, %4\n v_max_f64 %3, %3, %4")
+KERNEL64(k_dep1_f64, "v_fma_f64 %0, %0, %4, %4\n v_fma_f64 %0, %0, %4, %4\n v_fma_f64 %0, %0, %4, %4\n v_fma_f64 %0, %0, %4, %4")
+KERNEL64(k_dep2_f64, "v_fma_f64 %0, %0, %4, %4\n v_fma_f64 %1, %1, %4, %4\n v_fma_f64 %0, %0, %4, %4\n v_fma_f64 %1, %1, %4, %4")
+KERNEL64(k_fma_salu, "v_fma_f64 %0, %0, %4, %4\n s_add_u32 s20, s20, 1\n v_fma_f64 %1, %1, %4, %4\n s_add_u32 s21, s21, 1")
+KERNEL64(k_fma_mov32, "v_fma_f64 %0, %0, %4, %4\n v_mov_b32 v200, v201\n v_fma_f64 %1, %1, %4, %4\n v_mov_b32 v202, v203")
 KERNEL64(k_dep_f64, "v_fma_f64 %0, %0, %4, %1\n v_add_f64 %0, %0, %2\n v_mul_f64 %0, %0, %4\n v_fma_f64 %0, %0, %4, %3")
 
 template <class K> static void run(const char *name, K kern, unsigned *d, int waves)
@@ -60,9 +71,9 @@ template <class K> static void run(const char *name, K kern, unsigned *d, int wa
 int main()
 {
     unsigned *d;
-    hipMalloc(&d, 4096 * 64 * 4);
-    hipMemset(d, 0, 4096 * 64 * 4);
-    for (int waves : {1024, 2048})
+    hipMalloc(&d, 8192 * 64 * 4);
+    hipMemset(d, 0, 8192 * 64 * 4);
+    for (int waves : {1024, 2048, 4096})
     {
         run("v_add_u32", k_add_u32, d, waves);
         run("v_pk_add_u16", k_pk_add_u16, d, waves);
@@ -81,6 +92,17 @@ int main()
         run("v_fma_f64", k_fma_f64, d, waves);
         run("v_add_f64", k_add_f64, d, waves);
         run("v_mul_f64", k_mul_f64, d, waves);
+        run("v_rcp_f64", k_rcp_f64, d, waves);
+        run("v_sqrt_f64", k_sqrt_f64, d, waves);
+        run("v_ldexp_f64", k_ldexp_f64, d, waves);
+        run("v_div_fixup_f64", k_divfix_f64, d, waves);
+        run("v_cmp_lt_f64", k_cmp_f64, d, waves);
+        run("v_mov_b64", k_mov_b64, d, waves);
+        run("v_max_f64", k_max_f64, d, waves);
+        run("dep1 fma_f64", k_dep1_f64, d, waves);
+        run("dep2 fma_f64", k_dep2_f64, d, waves);
+        run("fma+salu", k_fma_salu, d, waves);
+        run("fma+mov32", k_fma_mov32, d, waves);
         run("dep chain f64", k_dep_f64, d, waves);
     }
     return 0;
