@@ -220,3 +220,123 @@ __device__ __forceinline__ void jd_fir_eval(const double *lre, const double *lim
     }
     ore = are; oim = aim;
 }
+
+// The 55 root-raised-cosine taps are bitwise symmetric (t[i] == t[54 - i]; checked by jaero_create): 28 distinct values, handed to the
+// kernel by value so that they live in SGPRs and are scalar operands of the filter's fmas -- no tap reads from LDS at all.
+struct JTaps28 { double t[28]; };
+
+// jd_fir_eval with the taps as scalar operands (FIRN must be 55) and NO address arithmetic: the LDS ring position is wave-uniform
+// (and the same for every wavefront of a launch, give or take a few samples), so the newest-LDSN part of the sum exists in LDSN
+// versions, one per ring position, each with compile-time LDS offsets; a switch picks one.  All wavefronts of a CU are in the same one
+// or two versions at any time, so the instruction cache sees little of the ~30 KiB this unrolls to.
+typedef __attribute__((address_space(3))) const double jd_lds_cdouble;
+template <int FIRN, int LDSN, int D, int S, int TAP0>
+__device__ __forceinline__ void jd_fir_lds_part(jd_lds_cdouble *lre_l, jd_lds_cdouble *lim_l, const JTaps28 &tp, double &are, double &aim)
+{
+    constexpr int TAILN = TAP0; // tap index that meets the oldest LDS entry
+    double pr[D], pi[D];
+#pragma unroll
+    for (int q = 0; q < D; q++) { pr[q] = lre_l[((S + q) % LDSN) * 64]; pi[q] = lim_l[((S + q) % LDSN) * 64]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < LDSN; q++)
+    {
+        const int s = TAILN + q;
+        const double tap = tp.t[s <= 27 ? s : 54 - s];
+        are = fma(tap, pr[q % D], are);
+        aim = fma(tap, pi[q % D], aim);
+        // keep the software pipeline as written (see jd_fir_eval)
+        asm volatile("" : "+v"(are), "+v"(aim));
+        if (q + D < LDSN) { pr[q % D] = lre_l[((S + q + D) % LDSN) * 64]; pi[q % D] = lim_l[((S + q + D) % LDSN) * 64]; }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// the same sum with run-time ring addresses (one call per launch: the first sample's output from the saved history)
+template <int FIRN, int LDSN, int D, int TAILA>
+__device__ __forceinline__ void jd_fir_eval_sym(const double *lre, const double *lim, const JTaps28 &tp, const double (&tre)[TAILA],
+                                                const double (&tim)[TAILA], int fir_slot, int lane, double &ore, double &oim)
+{
+    static_assert(FIRN == 55, "symmetric-tap filter is the 55-tap RRC");
+    constexpr int TAILN = FIRN - LDSN;
+    double are = 0, aim = 0;
+#pragma unroll
+    for (int s = 0; s < TAILN; s++)
+    {
+        const double tap = tp.t[s <= 27 ? s : 54 - s];
+        are = fma(tap, tre[TAILN - 1 - s], are);
+        aim = fma(tap, tim[TAILN - 1 - s], aim);
+    }
+    int slot = fir_slot;
+#pragma unroll 1
+    for (int q = 0; q < LDSN; q++)
+    {
+        const int s = TAILN + q;
+        const double tap = tp.t[s <= 27 ? s : 54 - s]; // a scalar load per step: this is the once-per-launch path
+        are = fma(tap, lre[slot * 64 + lane], are);
+        aim = fma(tap, lim[slot * 64 + lane], aim);
+        slot++;
+        if (slot >= LDSN) slot = 0;
+    }
+    ore = are; oim = aim;
+}
+template <int FIRN, int LDSN, int D, int TAILA>
+__device__ __forceinline__ void jd_fir_eval_sym_static(const double *lre, const double *lim, const JTaps28 &tp, const double (&tre)[TAILA],
+                                                       const double (&tim)[TAILA], int fir_slot, int lane, double &ore, double &oim)
+{
+    static_assert(FIRN == 55 && LDSN <= 40, "symmetric-tap filter is the 55-tap RRC; the switch below has 40 cases");
+    constexpr int TAILN = FIRN - LDSN;
+    jd_lds_cdouble *lre_l = (jd_lds_cdouble *)lre + lane, *lim_l = (jd_lds_cdouble *)lim + lane;
+    double are = 0, aim = 0;
+#pragma unroll
+    for (int s = 0; s < TAILN; s++)
+    {
+        const double tap = tp.t[s <= 27 ? s : 54 - s];
+        are = fma(tap, tre[TAILN - 1 - s], are);
+        aim = fma(tap, tim[TAILN - 1 - s], aim);
+    }
+#define JD_FIR_CASE(S) case S: if constexpr (S < LDSN) jd_fir_lds_part<FIRN, LDSN, D, (S < LDSN ? S : 0), FIRN - LDSN>(lre_l, lim_l, tp, are, aim); break;
+    switch (fir_slot)
+    {
+        JD_FIR_CASE(0) JD_FIR_CASE(1) JD_FIR_CASE(2) JD_FIR_CASE(3) JD_FIR_CASE(4) JD_FIR_CASE(5) JD_FIR_CASE(6) JD_FIR_CASE(7)
+        JD_FIR_CASE(8) JD_FIR_CASE(9) JD_FIR_CASE(10) JD_FIR_CASE(11) JD_FIR_CASE(12) JD_FIR_CASE(13) JD_FIR_CASE(14) JD_FIR_CASE(15)
+        JD_FIR_CASE(16) JD_FIR_CASE(17) JD_FIR_CASE(18) JD_FIR_CASE(19) JD_FIR_CASE(20) JD_FIR_CASE(21) JD_FIR_CASE(22) JD_FIR_CASE(23)
+        JD_FIR_CASE(24) JD_FIR_CASE(25) JD_FIR_CASE(26) JD_FIR_CASE(27) JD_FIR_CASE(28) JD_FIR_CASE(29) JD_FIR_CASE(30) JD_FIR_CASE(31)
+        JD_FIR_CASE(32) JD_FIR_CASE(33) JD_FIR_CASE(34) JD_FIR_CASE(35) JD_FIR_CASE(36) JD_FIR_CASE(37) JD_FIR_CASE(38) JD_FIR_CASE(39)
+    default: break;
+    }
+#undef JD_FIR_CASE
+    ore = are; oim = aim;
+}
+
+// The first 54 terms of the NEXT output, from the history as it stands before the newest input is pushed: y[n+1] = sum_{s<54} t[s]
+// x[n-54+s] + t[54] x[n].  The caller adds the last term once x[n] exists -- it arrives through a table gather whose latency this sum
+// covers.  History: LDS holds x[n-LDSN .. n-1] (oldest at fir_slot), the register tail x[n-LDSN-1-j]; the oldest tail entry
+// (x[n-55]) is not part of this output.
+template <int FIRN, int LDSN, int D, int TAILA>
+__device__ __forceinline__ void jd_fir_partial_static(const double *lre, const double *lim, const JTaps28 &tp, const double (&tre)[TAILA],
+                                                      const double (&tim)[TAILA], int fir_slot, int lane, double &ore, double &oim)
+{
+    static_assert(FIRN == 55 && LDSN <= 40, "symmetric-tap filter is the 55-tap RRC; the switch below has 40 cases");
+    constexpr int TAILN = FIRN - LDSN;
+    jd_lds_cdouble *lre_l = (jd_lds_cdouble *)lre + lane, *lim_l = (jd_lds_cdouble *)lim + lane;
+    double are = 0, aim = 0;
+#pragma unroll
+    for (int s = 0; s < TAILN - 1; s++) // x[n-54+s] = tail[TAILN-2-s]
+    {
+        const double tap = tp.t[s <= 27 ? s : 54 - s];
+        are = fma(tap, tre[TAILN - 2 - s], are);
+        aim = fma(tap, tim[TAILN - 2 - s], aim);
+    }
+#define JD_FIR_CASE(S) case S: if constexpr (S < LDSN) jd_fir_lds_part<FIRN, LDSN, D, (S < LDSN ? S : 0), FIRN - LDSN - 1>(lre_l, lim_l, tp, are, aim); break;
+    switch (fir_slot)
+    {
+        JD_FIR_CASE(0) JD_FIR_CASE(1) JD_FIR_CASE(2) JD_FIR_CASE(3) JD_FIR_CASE(4) JD_FIR_CASE(5) JD_FIR_CASE(6) JD_FIR_CASE(7)
+        JD_FIR_CASE(8) JD_FIR_CASE(9) JD_FIR_CASE(10) JD_FIR_CASE(11) JD_FIR_CASE(12) JD_FIR_CASE(13) JD_FIR_CASE(14) JD_FIR_CASE(15)
+        JD_FIR_CASE(16) JD_FIR_CASE(17) JD_FIR_CASE(18) JD_FIR_CASE(19) JD_FIR_CASE(20) JD_FIR_CASE(21) JD_FIR_CASE(22) JD_FIR_CASE(23)
+        JD_FIR_CASE(24) JD_FIR_CASE(25) JD_FIR_CASE(26) JD_FIR_CASE(27) JD_FIR_CASE(28) JD_FIR_CASE(29) JD_FIR_CASE(30) JD_FIR_CASE(31)
+        JD_FIR_CASE(32) JD_FIR_CASE(33) JD_FIR_CASE(34) JD_FIR_CASE(35) JD_FIR_CASE(36) JD_FIR_CASE(37) JD_FIR_CASE(38) JD_FIR_CASE(39)
+    default: break;
+    }
+#undef JD_FIR_CASE
+    ore = are; oim = aim;
+}

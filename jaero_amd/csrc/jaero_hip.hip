@@ -142,6 +142,7 @@ struct jaero_ctx
     int msk_ldsn = 0; // MSK: matched-filter inputs kept in LDS (the rest of fir_n in registers)
     int oq_pairs = 0; // 10.5 kbps OQPSK: front/back pairs per workgroup of k_oqpsk_fb (0 = the single-wavefront kernel k_oqpsk_samples)
     int oq_ldsn = OQ_LDSN;
+    JTaps28 oq_taps{}; // the 28 distinct values of the (bitwise symmetric) 55-tap RRC, scalar operands of k_oqpsk_fb's filter
     // fb == 8400 (k_pre8400.h): prefilter buffers, samples written so far, size of the previous write
     bool pre8400 = false;
     JPre pre{};
@@ -584,6 +585,13 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         std::vector<double> t2(2 * g.fir_n);
         for (int i = 0; i < 2 * g.fir_n; i++) t2[i] = taps[i % g.fir_n];
         HIPCHK(hipMemcpy(d_taps, t2.data(), sizeof(double) * t2.size(), hipMemcpyHostToDevice));
+        if (g.kind == JAERO_KIND_OQPSK && g.fir_n == 55)
+        {
+            bool sym = true;
+            for (int i = 0; i < 55; i++) sym = sym && memcmp(&taps[i], &taps[54 - i], sizeof(double)) == 0;
+            c->oq_pairs = (sym && g.fb != 8400) ? -1 : 0; // -1: front/back pairs allowed (decided below); 0: asymmetric taps -> the single-wavefront kernel reads them from LDS
+            for (int i = 0; i < 28; i++) c->oq_taps.t[i] = taps[i];
+        }
         if (g.kind != JAERO_KIND_OQPSK) HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_taps_msk), taps.data(), sizeof(double) * taps.size(), (g.fb >= 1200 ? 0 : 1) * 160 * sizeof(double)));
     }
     // scalar state
@@ -629,7 +637,7 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         // 64 channels).  JAERO_OQPSK_KERNEL=single keeps the single-wavefront kernel (k_oqpsk.h) for A/B comparison.
         const char *e = getenv("JAERO_OQPSK_KERNEL");
         const int ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        c->oq_pairs = (e && !strcmp(e, "single")) ? 0 : ((e && !strcmp(e, "pairs1")) ? 1 : ((e && !strcmp(e, "pairs4")) ? 4 : (g.ngroups > 2 * ncu ? 4 : 1)));
+        if (c->oq_pairs) c->oq_pairs = (e && !strcmp(e, "single")) ? 0 : ((e && !strcmp(e, "pairs1")) ? 1 : ((e && !strcmp(e, "pairs4")) ? 4 : (g.ngroups > 2 * ncu ? 4 : 1)));
         if (c->oq_pairs)
         {
 #define FBA(E, C, PP) HIPCHK(hipFuncSetAttribute((const void *)k_oqpsk_fb<55, FB_LDSN, E, C, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, PP * fb_pair_doubles<FB_LDSN>() * (int)sizeof(double)))
@@ -823,10 +831,11 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
         {
             // front / back wavefront pairs (k_oqpsk_fb.h): PAIRS pairs per workgroup
             const int fsb = (int)(c->m.nB_total % FB_LDSN);
+
             const int P = c->oq_pairs;
             const dim3 gridp((g.ngroups + P - 1) / P), blockp(P * 128);
             const int ldsp = P * fb_pair_doubles<FB_LDSN>() * (int)sizeof(double);
-#define LFB(E, C, PP) hipLaunchKernelGGL((k_oqpsk_fb<55, FB_LDSN, E, C, PP>), gridp, blockp, ldsp, st, g, c->p, frames, stride, n, skipA, onlyA, fsb)
+#define LFB(E, C, PP) hipLaunchKernelGGL((k_oqpsk_fb<55, FB_LDSN, E, C, PP>), gridp, blockp, ldsp, st, g, c->p, frames, stride, n, skipA, onlyA, fsb, c->oq_taps)
 #define LFBP(E, C) { if (P == 4) LFB(E, C, 4); else LFB(E, C, 1); }
             if (eb && cs) LFBP(true, true) else if (eb) LFBP(true, false) else if (cs) LFBP(false, true) else LFBP(false, false)
 #undef LFBP

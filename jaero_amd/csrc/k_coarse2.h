@@ -879,6 +879,13 @@ __device__ __forceinline__ void c4_fft(CV<32> &d, double *xch, const double2 *__
 // waited for where it is issued (pass-3 twiddles as literals, table values and y[] requested ahead).
 // W8400 (fb == 8400, k_pre8400.h): the band limit is the centre-weighted window of coarsefreqestimate.cpp:61-74,100
 // instead of the boxcar of :99.
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits for every global load and STORE in
+// flight: behind the y[] update that is 32 stores per thread on their way to HBM, behind the ring prefetch 32 loads -- the prefetch
+// was issued early precisely so that the peak search would run under it.
+__device__ __forceinline__ void c4_lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 template <bool W8400>
 __device__ __forceinline__ void coarse4_body(const JGeom g, const JPtrs p, const int *__restrict__ chan_list, int nlist, const double2 *__restrict__ tw)
 {
@@ -950,7 +957,7 @@ __device__ __forceinline__ void coarse4_body(const JGeom g, const JPtrs p, const
             d.i[s] = re * im + im * re;
         }
         c4_fft(d, xch, tw, t);
-        __syncthreads(); // the exchange buffer is free: it receives a copy of y for the fold below
+        c4_lds_barrier(); // the exchange buffer is free: it receives a copy of y for the fold below
         // smooth with fftshift: y[i] = y[i]*0.9 + 0.1*10*log10(fmax(abs(out[i]),1)), out[i] = X[i ^ N/2]
         // all 32 old y values are requested before the log10s (64 registers, free once only |X|^2 is kept of d): written as one
         // load-compute-store per element, every element waited out a full HBM round trip (vmcnt counts the stores too)
@@ -974,7 +981,7 @@ __device__ __forceinline__ void coarse4_body(const JGeom g, const JPtrs p, const
                 (xch + ib)[t] = yn;
             }
         }
-        __syncthreads();
+        c4_lds_barrier(); // the fold reads the LDS copy; the stores to y[] drain in the background
         {
             const int ln = li + (int)gridDim.x;
             if (ln < nlist)
@@ -1007,29 +1014,40 @@ __device__ __forceinline__ void coarse4_body(const JGeom g, const JPtrs p, const
             }
             if (val > best) { best = val; besti = i; }
         }
-        red_val[t] = best;
-        red_idx[t] = besti;
-        __syncthreads();
-        for (int s = C2_THREADS / 2; s > 0; s >>= 1)
+        // first maximum over the workgroup (ties: the lower bin, as the reference's ascending scan keeps the first): wavefront
+        // reduction through DPP-free shuffles, then one LDS round for the eight wavefront results -- no barrier drains the ring
+        // prefetch that is in flight
         {
-            if (t < s)
+            double bv = best;
+            int bi = besti;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
             {
-                const double ov = red_val[t + s];
-                const int oi = red_idx[t + s];
-                const double mv = red_val[t];
-                const int mi = red_idx[t];
-                if (oi >= 0 && (mi < 0 || ov > mv || (ov == mv && oi < mi))) { red_val[t] = ov; red_idx[t] = oi; }
+                const double ov = __shfl_xor(bv, off, 64);
+                const int oi = __shfl_xor(bi, off, 64);
+                if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
             }
-            __syncthreads();
+            if ((t & 63) == 0) { red_val[t >> 6] = bv; red_idx[t >> 6] = bi; }
+            c4_lds_barrier();
+            if (t == 0)
+            {
+                for (int w = 1; w < C2_THREADS / 64; w++)
+                {
+                    const double ov = red_val[w];
+                    const int oi = red_idx[w];
+                    if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+                }
+                red_idx[0] = bi;
+            }
         }
         if (t == 0) sh_bigchange = coarse_slot(g, p, ch, (red_idx[0] >= 0) ? red_idx[0] : (N / 2), N, hzperbin, lockingbw);
-        __syncthreads();
+        c4_lds_barrier();
         if (sh_bigchange)
         {
             double2 *ringw = p.bbring + (size_t)ch * N;
             for (int i = t; i < N; i += C2_THREADS) { y[i] = 20; ringw[i] = make_double2(0.0, 0.0); }
         }
-        __syncthreads();
+        c4_lds_barrier(); // LDS reuse only: the next estimate is another channel, and its ring rows are already on their way
     }
 }
 

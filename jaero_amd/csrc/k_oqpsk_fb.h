@@ -31,7 +31,7 @@
 #include "jaero_device.h"
 
 #define FB_DEFER 16
-#define FB_LDSN 35 // filter history slots in LDS: 35 KiB + taps + mailboxes = 39 936 B per pair, four pairs per CU
+#define FB_LDSN 36 // filter history slots in LDS: 36 KiB + mailboxes (+ a spare 512 B) = 40 448 B per pair, four pairs per CU (161 792 of 163 840 B)
 
 // x / d for a positive constant d with rd = 1.0 / d (correctly rounded): q = x*rd is within an ulp, two Newton corrections through exact
 // fma residuals give the correctly rounded quotient (Markstein); the sign of a zero result is x's.  Checked against x / d on 2e9
@@ -81,7 +81,7 @@ __device__ __forceinline__ void fb_barrier()
 // ------------------------------------------------------------------------------------------------------------------ front half
 template <int FIRN, int LDSN, bool EBNO>
 __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const FbLds &L, const int16_t *__restrict__ pcm, int pcm_stride, int n,
-                                         int skip_a_first, int only_a_last, int fir_slot0, int grp, int lane)
+                                         int skip_a_first, int only_a_last, int fir_slot0, int grp, int lane, const JTaps28 &tp)
 {
     constexpr int TAILN = FIRN - LDSN;
     double tre[TAILN], tim[TAILN]; // tre[j] = x_re[n-LDSN-j] once x[n] has been pushed
@@ -119,14 +119,13 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const F
         if (lane < FIRN) ltap[lane] = p.taps2[lane];
     }
     int fir_slot = fir_slot0; // wave-uniform: LDS slot holding the oldest LDS entry, overwritten by the next input
-    auto fir_eval = [&](double &ore, double &oim) { jd_fir_eval<FIRN, LDSN, 8>(lre, lim, ltap, tre, tim, fir_slot, lane, ore, oim); };
 
     const double agc_len_d = (double)g.agc_len, eb_len_d = (double)g.ebno_len;
     const double r_agc_len = 1.0 / agc_len_d, r_eb_len = 1.0 / eb_len_d;
 
     // K7 + K8 for one sample: EbNo meter, AGC, clip; hands {sre, sim, abval} to the back half through mailbox `buf`
     // (oqpskdemodulator.cpp:458-470, DSP.cpp:729-744, :370-379); agc_old / e_old / e2_old = the rows leaving the windows
-    auto front_sample = [&](double sre, double sim, double agc_old, double e_old, double e2_old, int j, int buf) {
+    auto front_sample = [&](double sre, double sim, double agc_old, double e_old, double e2_old, int j, int buf) __attribute__((always_inline)) {
         const double dabval = sqrt(sre * sre + sim * sim);
         if (EBNO)
         {
@@ -167,10 +166,13 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const F
         d[0] = sre; d[64] = sim; d[128] = abval;
     };
 
-    // rows leaving the AGC / EbNo windows at the next sample to be fronted, requested one step ahead
-    double nx_agc = agc_ring[(size_t)agc_pos * 64];
-    double nx_e = 0, nx_e2 = 0;
-    if (EBNO) { nx_e = ebe_ring[(size_t)eb_pos * 64]; nx_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
+    // Memory order matters here: vmcnt retires in order, so the wait for the carrier table value (an L2 hit, needed at once) also
+    // waits for every older request.  All slow requests of a step -- the HBM rows leaving the AGC / EbNo windows TWO samples on, the
+    // next PCM value, the coarse ring store -- are therefore issued right behind that wait, a whole step before the next one.
+    auto ring_pos_next = [](int pos, int len) { pos++; return pos >= len ? 0 : pos; };
+    double r1_agc = agc_ring[(size_t)agc_pos * 64]; // rows for the next sample to be fronted
+    double r1_e = 0, r1_e2 = 0;
+    if (EBNO) { r1_e = ebe_ring[(size_t)eb_pos * 64]; r1_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
     short nx_pcm = (live && n > 0) ? pcm[ch] : (short)0;
     double2 nx_cc = cis[jd_cisidx(mc_ptr)];
 
@@ -178,24 +180,40 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const F
     if (nB > 0)
     {
         double y_re, y_im;
-        fir_eval(y_re, y_im);
-        const double a0 = nx_agc, e0 = nx_e, e20 = nx_e2;
-        front_sample(y_re, y_im, a0, e0, e20, 0, 0);
-        nx_agc = agc_ring[(size_t)agc_pos * 64];
-        if (EBNO) { nx_e = ebe_ring[(size_t)eb_pos * 64]; nx_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
+        jd_fir_eval_sym<FIRN, LDSN, 6>(lre, lim, tp, tre, tim, fir_slot, lane, y_re, y_im);
+        front_sample(y_re, y_im, r1_agc, r1_e, r1_e2, 0, 0);
+        r1_agc = agc_ring[(size_t)agc_pos * 64];
+        if (EBNO) { r1_e = ebe_ring[(size_t)eb_pos * 64]; r1_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
     }
     fb_barrier();
 
     for (int i = 0; i < nB; i++)
     {
-        // the carrier NCO's table value for sample i (index handed over by the back half) -- an L2 hit, covered by the ring fill
+        // the carrier NCO's table value for sample i (index handed over by the back half): an L2 hit a few hundred ns away; the
+        // register half of the history shifts meanwhile.  (Summing 54 of the 55 filter terms of the next output under that latency
+        // -- jd_fir_partial_static -- was measured and is SLOWER, 15.3 against 13.7 ms per step: on the shared SIMD the front half's wait
+        // is where the back half gets the VALU, and a front half that computes through it only collides with the back half's densest
+        // stretch.)
         const int m2i = L.idx[(i & 1) * 64 + lane];
         const double2 c_m2 = cis[m2i];
+#pragma unroll
+        for (int j = TAILN - 1; j > 0; j--) { tre[j] = tre[j - 1]; tim[j] = tim[j - 1]; }
+        double *hre = lre + fir_slot * 64 + lane, *him = lim + fir_slot * 64 + lane;
+        tre[0] = *hre;
+        tim[0] = *him;
         const short s = nx_pcm;
         const double dval = ((double)s) / 32768.0;
         const double2 cc = nx_cc;
-        // ---- K3: coarse-frequency ring fill (oqpskdemodulator.cpp:410-415) ----
         const bool do_fill = !(i == 0 && skip_a_first) && ((coarse_cnt >= g.Fs_int) || !(flags & JF_CPUREDUCE));
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const double cre = c_m2.x * dval, cim = c_m2.y * dval;
+            *hre = cre;
+            *him = cim;
+            fir_slot++;
+            if (fir_slot >= LDSN) fir_slot = 0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (do_fill)
         {
             bbring[bb_ptr] = make_double2(cc.x * dval, cc.y * dval);
@@ -208,27 +226,24 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const F
             nx_pcm = live ? pcm[(size_t)(i + 1) * pcm_stride + ch] : (short)0;
             nx_cc = cis[jd_cisidx(mc_ptr)];
         }
-        // ---- K2: x[i] = mixer2 * dval, pushed into the matched filter (:453-456) ----
+        double r2_agc = 0, r2_e = 0, r2_e2 = 0;
+        if (i + 2 < nB)
         {
-            const double cre = c_m2.x * dval, cim = c_m2.y * dval;
-#pragma unroll
-            for (int j = TAILN - 1; j > 0; j--) { tre[j] = tre[j - 1]; tim[j] = tim[j - 1]; }
-            tre[0] = lre[fir_slot * 64 + lane];
-            tim[0] = lim[fir_slot * 64 + lane];
-            lre[fir_slot * 64 + lane] = cre;
-            lim[fir_slot * 64 + lane] = cim;
-            fir_slot++;
-            if (fir_slot >= LDSN) fir_slot = 0;
+            r2_agc = agc_ring[(size_t)ring_pos_next(agc_pos, g.agc_len) * 64];
+            if (EBNO)
+            {
+                const int ep = ring_pos_next(eb_pos, g.ebno_len);
+                r2_e = ebe_ring[(size_t)ep * 64];
+                r2_e2 = ebe2_ring[(size_t)ep * 64];
+            }
         }
-        // ---- K6..K8 for sample i+1 (if its B-part runs in this launch) ----
+        __builtin_amdgcn_sched_barrier(0);
         if (i + 1 < nB)
         {
             double y_re, y_im;
-            fir_eval(y_re, y_im);
-            const double a0 = nx_agc, e0 = nx_e, e20 = nx_e2;
-            front_sample(y_re, y_im, a0, e0, e20, i + 1, (i + 1) & 1);
-            nx_agc = agc_ring[(size_t)agc_pos * 64];
-            if (EBNO) { nx_e = ebe_ring[(size_t)eb_pos * 64]; nx_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
+            jd_fir_eval_sym_static<FIRN, LDSN, 6>(lre, lim, tp, tre, tim, fir_slot, lane, y_re, y_im);
+            front_sample(y_re, y_im, r1_agc, r1_e, r1_e2, i + 1, (i + 1) & 1);
+            r1_agc = r2_agc; r1_e = r2_e; r1_e2 = r2_e2;
         }
         fb_barrier();
     }
@@ -300,17 +315,22 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, const Fb
 
     // the output half of a symbol, queued at the instant: marg->UpdateSigned(ct_ec) .. soft bits (oqpskdemodulator.cpp:534-595).
     // pd_* = what it needs from the instant; px_* = the ring entries leaving the four windows, requested when the symbol is queued.
-    bool pend = false;
+    // The ring entries are HBM misses; they are requested at the top of the NEXT sample, right behind the wait for the symbol
+    // NCO's table value (vmcnt retires in order: requested at the instant they would sit in front of that wait one sample later).
+    bool pend = false, need_px = false;
     double pd_ec = 0, pd_re = 0, pd_im = 0;
     double px_marg = 0, px_pm = 0, px_ms = 0;
     double2 px_dt = make_double2(0.0, 0.0);
     auto queue_symbol = [&](double ct_ec, double q_re, double q_im) {
-        pend = true; pd_ec = ct_ec; pd_re = q_re; pd_im = q_im;
+        pend = true; need_px = true; pd_ec = ct_ec; pd_re = q_re; pd_im = q_im;
+    };
+    auto request_px = [&]() {
         px_marg = marg_ring[marg_pos];
         int dn = dt_pos + 1; if (dn >= g.dt_len) dn = 0;
         px_dt = dt_ring[dn]; // = what dt.update returns: the slot after the one being written (dt_len > 1)
         px_pm = pm_ring[pm_pos];
         px_ms = msema_ring[msema_pos];
+        need_px = false;
     };
     auto output_half = [&]() {
         const double ct_ec = pd_ec;
@@ -379,11 +399,12 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, const Fb
 
     // mailbox: the table index of mixer2 for sample 0
     L.idx[lane] = jd_cisidx(m2_ptr);
+    double2 nx_cst = cis[jd_cisidx(st_ptr)];
     fb_barrier();
 
     for (int i = 0; i < nB; i++)
     {
-        const double2 c_st = cis[jd_cisidx(st_ptr)]; // an L2 hit, needed after the resonator
+        const double2 c_st = nx_cst; // requested at the end of the previous sample
         const double *d = L.data + (i & 1) * 3 * 64 + lane;
         double sre = d[0], sim = d[64];
         const double abval = d[128];
@@ -413,6 +434,7 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, const Fb
             if (st_freq < (g.stref_freq - 0.1)) fb_wt_setfreq(st_freq, st_step, (g.stref_freq - 0.1), samplerate, r_samplerate);
             if (st_freq > (g.stref_freq + 0.1)) fb_wt_setfreq(st_freq, st_step, (g.stref_freq + 0.1), samplerate, r_samplerate);
         }
+        if (need_px) request_px(); // for the symbol queued in the previous sample
 
         // ---- K10..K14 at symbol instants (:487-595) ----
         if (!sig2l_init) { sig2l_re = sre; sig2l_im = sim; sig2l_init = 1; }
@@ -465,8 +487,10 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, const Fb
         st_last = st_ptr;
         st_ptr += st_step;
         while (((int)st_ptr) >= JD_WTSIZE) st_ptr -= JD_WTSIZE;
+        nx_cst = cis[jd_cisidx(st_ptr)]; // the symbol NCO's table value for the next sample: in flight across the barrier
         fb_barrier();
     }
+    if (need_px) request_px();
     if (pend) output_half();
 
     LDF(S_M2_PTR) = m2_ptr; LDF(S_M2_STEP) = m2_step; LDF(S_M2_FREQ) = m2_freq;
@@ -488,7 +512,7 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, const Fb
 // PAIRS..2*PAIRS-1 the back halves of the same groups.  A pair whose group lies beyond the bank only keeps the barrier count.
 template <int FIRN, int LDSN, bool EBNO, bool CAPSYM, int PAIRS>
 __global__ __launch_bounds__(PAIRS * 128) void k_oqpsk_fb(const JGeom g, const JPtrs p, const int16_t *__restrict__ pcm, int pcm_stride, int n,
-                                                          int skip_a_first, int only_a_last, int fir_slot0)
+                                                          int skip_a_first, int only_a_last, int fir_slot0, const JTaps28 tp)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -508,5 +532,5 @@ __global__ __launch_bounds__(PAIRS * 128) void k_oqpsk_fb(const JGeom g, const J
         return;
     }
     if (back) fb_back<CAPSYM>(g, p, L, n, only_a_last, grp, lane);
-    else fb_front<FIRN, LDSN, EBNO>(g, p, L, pcm, pcm_stride, n, skip_a_first, only_a_last, fir_slot0, grp, lane);
+    else fb_front<FIRN, LDSN, EBNO>(g, p, L, pcm, pcm_stride, n, skip_a_first, only_a_last, fir_slot0, grp, lane, tp);
 }

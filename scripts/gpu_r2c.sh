@@ -9,7 +9,7 @@ for mode in pairs4 pairs1; do
   JAERO_OQPSK_KERNEL=$mode timeout 900 python -m pytest $T -m gpu -q --tb=short -x > "$OUT/pytest_$mode.log" 2>&1
   tail -3 "$OUT/pytest_$mode.log"; grep -n "^E  " "$OUT/pytest_$mode.log" | head -20
 done
-for mode in auto single; do
+for mode in auto; do
   ( JAERO_OQPSK_KERNEL=$mode timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --as-written 0 2> "$OUT/bench_$mode.err" | tail -1 ) > "$OUT/bench_$mode.json"
   python - "$OUT/bench_$mode.json" <<'PY'
 import json,sys
