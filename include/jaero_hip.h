@@ -235,6 +235,11 @@ int jaero_ingest_stats(const jaero_ingest *ing, long long *three);
 int jaero_debug_schedule(int fft_power, int Fs, int cpu_reduce, const int *write_sizes, int nwrites,
                          long long *trigger_samples, int cap, int *segments_out);
 
+/* Test hook: the 8400 bps prefilter kernel alone.  n complex samples (re, im interleaved, host pointers) through the kernel
+ * RRC(alpha, 2049 taps, 48 kHz, fsym symbols/s) with JFastFir's latency for nfft = 4096 (out[m] = sum_k h[k] x[m - 2048 - k]):
+ * JFastFir::SetKernel + update as JAERO/oqpskdemodulator.cpp:278-283,366-368 use it and JAERO/tests/jfastfir_tests.cpp:31-58 pins it. */
+int jaero_debug_prefilter(int device, const double *in_reim, int n, double alpha, double fsym, double *out_reim);
+
 /* introspection */
 int jaero_abi_version(void);
 int jaero_num_channels(const jaero_ctx *ctx);

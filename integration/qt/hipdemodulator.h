@@ -1,0 +1,157 @@
+// hipdemodulator.h -- QIODevice adaptors that put libjaero_hip.so under JAERO's existing wiring.
+//
+// HipOqpskDemodulator / HipMskDemodulator have the member functions, slots and signals MainWindow uses on
+// OqpskDemodulator / MskDemodulator (JAERO/oqpskdemodulator.h:15-152, JAERO/mskdemodulator.h:17-160), so the connect() lines of
+// JAERO/mainwindow.cpp:198-202,234-237 keep working: each object is a one-channel bank of include/jaero_hip.h.
+// Add to JAERO.pro: HEADERS += hipdemodulator.h, INCLUDEPATH += <repo>/include, LIBS += -L<repo>/jaero_amd -ljaero_hip.
+// Compiled (moc + g++ against Qt 5.9.7) and driven by the unmodified AeroL in integration/qt/adaptor_demo.cpp /
+// tests/test_qt_adaptor.py.
+#pragma once
+#include <QIODevice>
+#include <QVector>
+#include <QByteArray>
+#include <vector>
+extern "C" {
+#include "jaero_hip.h"
+}
+
+class HipDemodulatorBase : public QIODevice
+{
+    Q_OBJECT
+public:
+    explicit HipDemodulatorBase(QObject *parent, int kind_, int group_) : QIODevice(parent), kind(kind_), group(group_) {}
+    ~HipDemodulatorBase() override { if (ctx) jaero_destroy(ctx); }
+    void setAFC(bool v) { afc = v; pushFlags(); }             // oqpskdemodulator.cpp:149-152
+    void setSQL(bool v) { sql = v; pushFlags(); }             // :154-157
+    void setCPUReduce(bool v) { cpuReduce = v; pushFlags(); } // :159-163
+    void start() { open(QIODevice::WriteOnly); }              // :312-315
+    void stop() { close(); }
+    double getCurrentFreq()
+    {
+        jaero_status st;
+        return (ctx && jaero_read_status(ctx, 0, &st) == JAERO_OK) ? st.freq_center : freq_center;
+    }
+    qint64 readData(char *, qint64) override { return 0; }
+    // = writeData of the reference (oqpskdemodulator.cpp:334-627, mskdemodulator.cpp:313-488): len bytes of little-endian int16 mono
+    qint64 writeData(const char *data, qint64 len) override
+    {
+        if (!ctx || len < 2) return len;
+        const int16_t *pcm = reinterpret_cast<const int16_t *>(data);
+        qint64 n = len / 2;
+        for (qint64 s = 0; s < n; s += maxWrite)
+        {
+            const int m = int(n - s < maxWrite ? n - s : maxWrite);
+            if (jaero_write(ctx, pcm + s, m, JAERO_PCM_CHANNEL_MAJOR, /*host pointer*/ 0, nullptr) != JAERO_OK)
+            {
+                emit WarningTextSignal(QString("libjaero_hip: %1").arg(jaero_last_error()));
+                return len;
+            }
+            drain();
+        }
+        return len;
+    }
+signals:
+    void processDemodulatedSoftBits(const QVector<short> &soft_bits);
+    void Plottables(double freq_est, double freq_center, double bandwidth);
+    void MSESignal(double mse);
+    void SignalStatus(bool gotasignal);
+    void EbNoMeasurmentSignal(double EbNo);
+    void SampleRateChanged(double Fs);
+    void BitRateChanged(double fb, bool burstmode);
+    void WarningTextSignal(QString str);
+public slots:
+    void CenterFreqChangedSlot(double f) { if (ctx) jaero_center_freq_changed(ctx, 0, f); }          // :291-310
+    void DCDstatSlot(bool d) { dcd = d; if (ctx) jaero_set_dcd(ctx, -1, d); }                       // :679-684
+    void dataReceived(const QByteArray &audio, quint32) { writeData(audio.constData(), audio.length()); } // :686-693
+protected:
+    void applySettings(const jaero_settings &js)
+    {
+        if (!ctx)
+        {
+            if (jaero_create(0, 1, &js, 0, JAERO_FLAG_EBNO | JAERO_FLAG_STATUS_LOG, maxWrite, 0, &ctx) != JAERO_OK)
+            {
+                emit WarningTextSignal(QString("libjaero_hip: %1").arg(jaero_last_error()));
+                ctx = nullptr;
+                return;
+            }
+            pushFlags();
+            jaero_set_dcd(ctx, -1, dcd);
+        }
+        else if (jaero_set_settings(ctx, 0, &js) != JAERO_OK)
+            emit WarningTextSignal(QString("libjaero_hip: %1").arg(jaero_last_error()));
+        if (js.Fs != Fs) { Fs = js.Fs; emit SampleRateChanged(Fs); }
+        if (js.fb != fb) { fb = js.fb; emit BitRateChanged(fb, false); }
+        lockingbw = js.lockingbw;
+        freq_center = js.freq_center;
+    }
+private:
+    void pushFlags() { if (ctx) jaero_set_flags(ctx, -1, afc, sql, cpuReduce); }
+    void drain()
+    {
+        // soft bits in the reference's groups (32 for OQPSK :583-591, 12 for MSK mskdemodulator.cpp:472-477); what does not fill a
+        // group yet waits for the next write, as RxDataBits does
+        int n = 0;
+        buf.resize(1 << 16);
+        if (jaero_read_softbits(ctx, 0, buf.data(), int(buf.size()), &n) != JAERO_OK) n = 0;
+        for (int i = 0; i < n; i++)
+        {
+            pending.push_back(buf[i]);
+            if (pending.size() >= group) { emit processDemodulatedSoftBits(pending); pending.clear(); }
+        }
+        // one status row per FreqOffsetEstimateSlot call: [n, freq_est, freq_center, mse, ebno, signal] (:670-675)
+        double rows[64 * 6];
+        int nr = 0;
+        if (jaero_read_status_log(ctx, 0, rows, 64, &nr) != JAERO_OK) nr = 0;
+        for (int r = 0; r < nr; r++)
+        {
+            const double *q = rows + 6 * r;
+            emit Plottables(q[1], q[2], lockingbw);
+            emit EbNoMeasurmentSignal(q[4]);
+            emit MSESignal(q[3]);
+            emit SignalStatus(q[5] != 0);
+        }
+    }
+    jaero_ctx *ctx = nullptr;
+    const int kind, group;
+    const int maxWrite = 1 << 16;
+    bool afc = false, sql = false, cpuReduce = false, dcd = false;
+    double Fs = 0, fb = 0, lockingbw = 0, freq_center = 0;
+    QVector<short> pending;
+    std::vector<int16_t> buf;
+};
+
+class HipOqpskDemodulator : public HipDemodulatorBase
+{
+    Q_OBJECT
+public:
+    struct Settings // == OqpskDemodulator::Settings (JAERO/oqpskdemodulator.h:20-39)
+    {
+        int coarsefreqest_fft_power = 14;
+        double freq_center = 8000, lockingbw = 10500, fb = 10500, Fs = 48000, signalthreshold = 0.65;
+        bool zmqAudio = false;
+    };
+    explicit HipOqpskDemodulator(QObject *parent = nullptr) : HipDemodulatorBase(parent, JAERO_KIND_OQPSK, 32) {}
+    void setSettings(Settings s) // oqpskdemodulator.cpp:175-289
+    {
+        jaero_settings js{JAERO_KIND_OQPSK, s.coarsefreqest_fft_power, s.freq_center, s.lockingbw, s.fb, s.Fs, s.signalthreshold};
+        applySettings(js);
+    }
+};
+
+class HipMskDemodulator : public HipDemodulatorBase
+{
+    Q_OBJECT
+public:
+    struct Settings // == MskDemodulator::Settings (JAERO/mskdemodulator.h:24-45)
+    {
+        int coarsefreqest_fft_power = 13;
+        double freq_center = 1000, lockingbw = 900, fb = 600, Fs = 48000, signalthreshold = 0.5;
+        bool zmqAudio = false;
+    };
+    explicit HipMskDemodulator(QObject *parent = nullptr) : HipDemodulatorBase(parent, JAERO_KIND_MSK, 12) {}
+    void setSettings(Settings s) // mskdemodulator.cpp:135-263
+    {
+        jaero_settings js{JAERO_KIND_MSK, s.coarsefreqest_fft_power, s.freq_center, s.lockingbw, s.fb, s.Fs, s.signalthreshold};
+        applySettings(js);
+    }
+};

@@ -140,6 +140,7 @@ struct jaero_ctx
     int *d_emitted = nullptr; // burst banks: per-channel count of soft bits already emitted (jaero_softbits_view)
     bool coarse_v2 = false; int coarse3_grid = 256, coarse_ver = 4;
     int msk_ldsn = 0; // MSK: matched-filter inputs kept in LDS (the rest of fir_n in registers)
+    std::vector<int> dly_t0; // MSK: shared delay-line slot at which each channel's delayedsmpl pointer last restarted (jaero_set_settings)
     int oq_pairs = 0; // 10.5 kbps OQPSK: front/back pairs per workgroup of k_oqpsk_fb (0 = the single-wavefront kernel k_oqpsk_samples)
     int oq_ldsn = OQ_LDSN;
     JTaps28 oq_taps{}; // the 28 distinct values of the (bitwise symmetric) 55-tap RRC, scalar operands of k_oqpsk_fb's filter
@@ -663,9 +664,10 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
 }
 
 // ------------------------------------------------------------------------------------------ control surface
-static int upload_flags(jaero_ctx *c)
+static int upload_flags(jaero_ctx *c, int lo, int hi)
 {
-    HIPCHK(hipMemcpy(c->o_flags, c->m.flags.data(), sizeof(int) * c->o_nchp, hipMemcpyHostToDevice));
+    // ordered on the stream of the last write (as the write that follows will be); the host copy lives as long as the bank
+    HIPCHK(hipMemcpyAsync(c->o_flags + lo, c->m.flags.data() + lo, sizeof(int) * (hi - lo), hipMemcpyHostToDevice, c->last_stream));
     return 0;
 }
 
@@ -673,7 +675,6 @@ extern "C" int jaero_set_flags(jaero_ctx *c, int channel, int afc, int sql, int 
 {
     if (!c || channel < -1 || channel >= c->o_nch) return fail(JAERO_EINVAL, "jaero_set_flags: bad channel");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipDeviceSynchronize());
     const int lo = channel < 0 ? 0 : channel, hi = channel < 0 ? c->o_nchp : channel + 1;
     for (int ch = lo; ch < hi; ch++)
     {
@@ -683,17 +684,16 @@ extern "C" int jaero_set_flags(jaero_ctx *c, int channel, int afc, int sql, int 
         if (cpu_reduce) f |= JF_CPUREDUCE;
         c->m.flags[ch] = f;
     }
-    return upload_flags(c);
+    return upload_flags(c, lo, hi);
 }
 
 extern "C" int jaero_set_dcd(jaero_ctx *c, int channel, int dcd)
 {
     if (!c || channel < -1 || channel >= c->o_nch) return fail(JAERO_EINVAL, "jaero_set_dcd: bad channel");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipDeviceSynchronize());
     const int lo = channel < 0 ? 0 : channel, hi = channel < 0 ? c->o_nchp : channel + 1;
     for (int ch = lo; ch < hi; ch++) c->m.flags[ch] = (c->m.flags[ch] & ~JF_DCD) | (dcd ? JF_DCD : 0);
-    return upload_flags(c);
+    return upload_flags(c, lo, hi);
 }
 
 extern "C" int jaero_center_freq_changed(jaero_ctx *c, int channel, double hz)
@@ -712,18 +712,57 @@ extern "C" int jaero_center_freq_changed(jaero_ctx *c, int channel, double hz)
     return 0;
 }
 
-// zero one channel's column of a [group][slot][lane] ring (group_stride = elements per group)
-template <class T>
-static hipError_t zero_column(T *base, size_t group_stride, int len, int ch)
+// setSettings on live channels [ch_lo, ch_hi): the scalar fields it rewrites, the counters it restarts and the rings it recreates
+// (= zeroes), for those channels' columns only.  blockIdx.x = channel - ch_lo, blockIdx.y strides over ring slots.
+struct JSetVals
 {
-    const int grp = ch / 64, lane = ch % 64;
-    return hipMemset2D((void *)(base + (size_t)grp * group_stride + lane), sizeof(T) * 64, 0, sizeof(T), (size_t)len);
+    int nS, nI;
+    int fS[40]; double vS[40];   // S[fS[k]][ch] = vS[k]
+    int fI[16]; int vI[16];      // I[fI[k]][ch] = vI[k]
+    int zero_eb, zero_msk;       // MSK also recreates the EbNo meter, marg and the quadrature delay line
+    int dly_rot;                 // MSK: slots by which the channel's delayedsmpl column is rotated (see below)
+};
+__global__ void k_apply_settings(const JGeom g, const JPtrs p, int ch_lo, const JSetVals v)
+{
+    const int ch = ch_lo + blockIdx.x, nchp = g.nchp;
+    const int grp = ch >> 6, lane = ch & 63;
+    if (blockIdx.y == 0)
+    {
+        for (int k = threadIdx.x; k < v.nS; k += blockDim.x) p.S[(size_t)v.fS[k] * nchp + ch] = v.vS[k];
+        for (int k = threadIdx.x; k < v.nI; k += blockDim.x) p.I[(size_t)v.fI[k] * nchp + ch] = v.vI[k];
+    }
+    const int tid = blockIdx.y * blockDim.x + threadIdx.x, nth = gridDim.y * blockDim.x;
+    for (int s = tid; s < g.agc_len; s += nth) p.agc_ring[((size_t)grp * g.agc_len + s) * 64 + lane] = 0.0;
+    for (int s = tid; s < 2 * g.fir_n; s += nth) p.firsave[((size_t)grp * 2 * g.fir_n + s) * 64 + lane] = 0.0;
+    if (v.zero_eb && p.eb_e)
+        for (int s = tid; s < g.ebno_len; s += nth)
+        {
+            p.eb_e[((size_t)grp * g.ebno_len + s) * 64 + lane] = 0.0;
+            p.eb_e2[((size_t)grp * g.ebno_len + s) * 64 + lane] = 0.0;
+        }
+    if (v.zero_msk)
+    {
+        for (int s = tid; s < g.marg_len; s += nth) p.marg[(size_t)ch * g.marg_len + s] = 0.0;
+        for (int s = tid; s < g.sps2 + 1; s += nth) p.dly8[((size_t)grp * (g.sps2 + 1) + s) * 64 + lane] = 0.0;
+        // delayedsmpl.setLength(SPS) keeps the buffer's contents and restarts its pointer at 0 (DSP.h:446-453).  Here the ring slot is
+        // shared by the 64 channels of a wavefront (slot = samples so far mod SPS+1), so restarting ONE channel's pointer means
+        // rotating that channel's column by the distance between the shared slot now and the slot its pointer last restarted at.
+        if (tid == 0 && v.dly_rot > 0)
+        {
+            const int L = g.sps + 1; // 41 or 81
+            double2 tmp[96];
+            for (int s = 0; s < L; s++) tmp[s] = p.dly[((size_t)grp * L + s) * 64 + lane];
+            for (int s = 0; s < L; s++) p.dly[((size_t)grp * L + (s + v.dly_rot) % L) * 64 + lane] = tmp[s];
+        }
+    }
 }
 
 extern "C" int jaero_set_settings(jaero_ctx *c, int channel, const jaero_settings *s)
 {
     // setSettings on a live object (oqpskdemodulator.cpp:175-289, mskdemodulator.cpp:135-263): retunes the mixers
     // (phase kept), recreates AGC / matched filters / timing delays / resonator, restarts the coarse ring pointer.
+    // Only the addressed channels' columns are touched, by one small kernel on the stream of the last jaero_write: no device
+    // synchronisation, no copy of the bank's state.
     if (!c || !s || channel < -1 || channel >= c->o_nch) return fail(JAERO_EINVAL, "jaero_set_settings: bad arguments");
     if (c->burst) return fail(JAERO_ENOTSUP, "jaero_set_settings on a live burst bank is not implemented; create a new bank");
     int rc = validate_settings(*s);
@@ -732,39 +771,51 @@ extern "C" int jaero_set_settings(jaero_ctx *c, int channel, const jaero_setting
     if (s->kind != g.kind || s->fb != g.fb || s->Fs != g.Fs || s->coarsefreqest_fft_power != g.nfft_log2)
         return fail(JAERO_EINVAL, "jaero_set_settings: kind/fb/Fs/fft_power are fixed per bank; create a new bank to change them");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipDeviceSynchronize());
     const int nchp = g.nchp;
-    std::vector<double> S((size_t)S_NFIELDS * nchp);
-    std::vector<int> I((size_t)I_NFIELDS * nchp);
-    HIPCHK(hipMemcpy(S.data(), c->p.S, S.size() * sizeof(double), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(I.data(), c->p.I, I.size() * sizeof(int), hipMemcpyDeviceToHost));
     const int lo = channel < 0 ? 0 : channel, hi = channel < 0 ? g.nch : channel + 1;
-    static const int zero_fields_oqpsk[] = {S_AGC_SUM, S_D1, S_D41_1, S_D41_2, S_D41_3, S_D42_1, S_D42_2, S_D42_3, S_D8_1, S_D8_2,
-                                            S_RES_X1, S_RES_X2, S_RES_Y1, S_RES_Y2};
-    static const int zero_fields_msk[] = {S_AGC_SUM, S_RES_X1, S_RES_X2, S_RES_Y1, S_RES_Y2, S_EB_ESUM, S_EB_E2SUM, S_EB_EBNO, S_MARG_SUM};
+    // what init_channel_scalars(fresh = false) writes, computed once (the same for every addressed channel) on a one-column scratch
+    std::vector<double> S((size_t)S_NFIELDS * nchp, 0.0);
+    std::vector<int> I((size_t)I_NFIELDS * nchp, 0);
+    init_channel_scalars(c, *s, S, I, lo, false);
+    JSetVals v{};
+    auto setS = [&](int f, double x) { v.fS[v.nS] = f; v.vS[v.nS] = x; v.nS++; };
+    auto setI = [&](int f, int x) { v.fI[v.nI] = f; v.vI[v.nI] = x; v.nI++; };
+    for (int f : {S_M2_FREQ, S_M2_STEP, S_MC_FREQ, S_MC_STEP, S_ST_FREQ, S_ST_STEP, S_LOCKINGBW, S_THRESH}) setS(f, S[(size_t)f * nchp + lo]);
+    if (g.kind == JAERO_KIND_OQPSK)
+        for (int f : {S_AGC_SUM, S_D1, S_D41_1, S_D41_2, S_D41_3, S_D42_1, S_D42_2, S_D42_3, S_D8_1, S_D8_2, S_RES_X1, S_RES_X2, S_RES_Y1, S_RES_Y2}) setS(f, 0.0);
+    else
+    {
+        setS(S_MSE, 10.0); // setSettings resets mse (mskdemodulator.cpp:180)
+        for (int f : {S_AGC_SUM, S_RES_X1, S_RES_X2, S_RES_Y1, S_RES_Y2, S_EB_ESUM, S_EB_E2SUM, S_EB_EBNO, S_MARG_SUM}) setS(f, 0.0);
+        setI(I_MARG_POS, 0); setI(I_DT_POS, 0);
+        if (c->p.eb_e) setI(I_EB_POS, 0);
+        v.zero_eb = 1; v.zero_msk = 1;
+    }
+    setI(I_BB_PTR, 0); setI(I_COARSE_CNT, 0); setI(I_AGC_POS, 0);
     for (int ch = lo; ch < hi; ch++)
     {
         c->settings[ch] = *s;
-        init_channel_scalars(c, *s, S, I, ch, false);
-        if (g.kind == JAERO_KIND_OQPSK) for (int f : zero_fields_oqpsk) S[(size_t)f * nchp + ch] = 0;
-        else for (int f : zero_fields_msk) S[(size_t)f * nchp + ch] = 0;
-        I[(size_t)I_BB_PTR * nchp + ch] = 0; I[(size_t)I_COARSE_CNT * nchp + ch] = 0; I[(size_t)I_AGC_POS * nchp + ch] = 0;
         c->m.bbptr[ch] = 0; c->m.cnt[ch] = 0;
-        HIPCHK(zero_column(c->p.agc_ring, (size_t)g.agc_len * 64, g.agc_len, ch));
-        HIPCHK(zero_column(c->p.firsave, (size_t)2 * g.fir_n * 64, 2 * g.fir_n, ch)); // both arms
-        if (g.kind == JAERO_KIND_MSK)
+    }
+    const int ny = (hi - lo) >= 256 ? 4 : 64; // one channel: 64 blocks share its 192 000-slot AGC column; the whole bank: four per channel
+    if (g.kind == JAERO_KIND_MSK)
+    {
+        // runs of channels whose delayedsmpl pointer last restarted at the same shared slot get one launch each (normally: one run)
+        const int L = g.sps + 1;
+        const int now = (int)(c->m.nB_total % L);
+        if (c->dly_t0.empty()) c->dly_t0.assign(nchp, 0);
+        for (int a = lo; a < hi;)
         {
-            if (c->p.eb_e) { HIPCHK(zero_column(c->p.eb_e, (size_t)g.ebno_len * 64, g.ebno_len, ch)); HIPCHK(zero_column(c->p.eb_e2, (size_t)g.ebno_len * 64, g.ebno_len, ch)); I[(size_t)I_EB_POS * nchp + ch] = 0; }
-            HIPCHK(hipMemset(c->p.marg + (size_t)ch * g.marg_len, 0, sizeof(double) * g.marg_len));
-            I[(size_t)I_MARG_POS * nchp + ch] = 0; I[(size_t)I_DT_POS * nchp + ch] = 0;
-            HIPCHK(zero_column(c->p.dly8, (size_t)(g.sps2 + 1) * 64, g.sps2 + 1, ch));
-            // delayedsmpl.setLength keeps its contents but restarts at slot 0; with the shared ring slot the contents
-            // are cleared instead (deviation only visible for SPS samples after a live setSettings)
-            HIPCHK(zero_column(c->p.dly, (size_t)(g.sps + 1) * 64, g.sps + 1, ch));
+            int b = a + 1;
+            while (b < hi && c->dly_t0[b] == c->dly_t0[a]) b++;
+            v.dly_rot = ((now - c->dly_t0[a]) % L + L) % L;
+            hipLaunchKernelGGL(k_apply_settings, dim3(b - a, ny), dim3(256), 0, c->last_stream, g, c->p, a, v);
+            for (int ch = a; ch < b; ch++) c->dly_t0[ch] = now;
+            a = b;
         }
     }
-    HIPCHK(hipMemcpy(c->p.S, S.data(), S.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c->p.I, I.data(), I.size() * sizeof(int), hipMemcpyHostToDevice));
+    else hipLaunchKernelGGL(k_apply_settings, dim3(hi - lo, ny), dim3(256), 0, c->last_stream, g, c->p, lo, v);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -1000,6 +1051,43 @@ extern "C" int jaero_debug_schedule(int fft_power, int Fs, int cpu_reduce, const
     }
     if (segments_out) *segments_out = nseg;
     return ntrig;
+}
+
+// Test hook: k_pre8400_fir alone (one channel, unity up-mix) on n complex samples, kernel RRC(alpha, 2048 taps + 1, 48 kHz, fsym):
+// out[m] = sum_k h[k] x[m - 2048 - k], what JFastFir::update returns for SetKernel(points, 4096) -- the operation the reference's
+// own test vectors pin (JAERO/tests/jfastfir_tests.cpp:31-58, tests/test_jfastfir_vectors.py).
+extern "C" int jaero_debug_prefilter(int device, const double *in_reim, int n, double alpha, double fsym, double *out_reim)
+{
+    if (!in_reim || !out_reim || n <= 0) return fail(JAERO_EINVAL, "jaero_debug_prefilter: bad arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(JAERO_ENODEV, "no HIP device available");
+    HIPCHK(hipSetDevice(device));
+    const std::vector<double> taps = rrc_design(alpha, 2048, 48000.0, fsym);
+    if ((int)taps.size() != PRE_K) return fail(JAERO_EINVAL, "prefilter design returned %zu taps", taps.size());
+    JGeom g{}; g.nch = 1; g.nchp = 64; g.ngroups = 1;
+    JPtrs p{};
+    JPre q{};
+    int ring = 1;
+    while (ring < n + 2 * PRE_L + 64) ring <<= 1;
+    q.ring = ring;
+    double2 *d_cis = nullptr; double *d_taps = nullptr;
+    HIPCHK(hipMalloc((void **)&q.xring, sizeof(double2) * (size_t)ring * 64));
+    HIPCHK(hipMalloc((void **)&q.cidx, sizeof(unsigned short) * (size_t)n * 64));
+    HIPCHK(hipMalloc((void **)&q.out, sizeof(double2) * (size_t)n * 64));
+    HIPCHK(hipMalloc((void **)&d_cis, sizeof(double2) * 4));
+    HIPCHK(hipMalloc((void **)&d_taps, sizeof(double) * PRE_K));
+    HIPCHK(hipMemset(q.xring, 0, sizeof(double2) * (size_t)ring * 64));
+    HIPCHK(hipMemset(q.cidx, 0, sizeof(unsigned short) * (size_t)n * 64));
+    const double2 one[4] = {{1.0, 0.0}, {1.0, 0.0}, {1.0, 0.0}, {1.0, 0.0}}; // table entry 0 = cis(0): the up-mix multiplies by its conjugate
+    HIPCHK(hipMemcpy(d_cis, one, sizeof one, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_taps, taps.data(), sizeof(double) * PRE_K, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy2D(q.xring, sizeof(double2) * 64, in_reim, sizeof(double2), sizeof(double2), (size_t)n, hipMemcpyHostToDevice)); // channel 0 of every slot
+    p.cis = d_cis; q.taps = d_taps;
+    hipLaunchKernelGGL(k_pre8400_fir, dim3(1, (n + 4 * PRE_R - 1) / (4 * PRE_R)), dim3(256), 0, 0, g, p, q, n, 0LL);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy2D(out_reim, sizeof(double2), q.out, sizeof(double2) * 64, sizeof(double2), (size_t)n, hipMemcpyDeviceToHost));
+    hipFree(q.xring); hipFree(q.cidx); hipFree(q.out); hipFree(d_cis); hipFree(d_taps);
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------ outputs

@@ -926,24 +926,42 @@ __device__ __forceinline__ void coarse4_body(const JGeom g, const JPtrs p, const
         }
         c4_fft(d, xch, tw, t);
         // band limit (fb != 8400 boxcar, coarsefreqestimate.cpp:99) then inverse transform = forward on swapped planes
-#pragma unroll
-        for (int s = 0; s < E; s++)
+        if constexpr (W8400)
         {
-            const int k = s * C2_THREADS + t;
-            if constexpr (!W8400)
+            // window[0] = 1, window[i] = window[N - i] = cos^2(pi/2 * i / startbin) for 1 <= i <= startbin, 0 elsewhere (:61-74).  The
+            // startbin + 1 distinct values are made once per estimate in the (idle) exchange buffer, ~6 cosines per thread; evaluated
+            // per element it was 32 per thread, most of them for bins the window zeroes, and the kernel spilled.
+            c4_lds_barrier();
+            for (int i = t; i <= startbin; i += C2_THREADS)
             {
-                const bool z = (k >= startbin) && (k <= stopbin);
-                const double re = z ? 0.0 : d.r[s], im = z ? 0.0 : d.i[s];
+                const double c = cos(M_PI_2 * ((double)i) / ((double)startbin));
+                xch[i] = (i == 0) ? 1.0 : c * c;
+            }
+            c4_lds_barrier();
+            double w[E];
+#pragma unroll
+            for (int s = 0; s < E; s++)
+            {
+                const int k = s * C2_THREADS + t;
+                const int i = (k <= N / 2) ? k : N - k;
+                w[s] = (i <= startbin) ? xch[i] : 0.0;
+            }
+            c4_lds_barrier(); // the next transform's exchanges reuse the buffer
+#pragma unroll
+            for (int s = 0; s < E; s++)
+            {
+                const double re = d.r[s] * w[s], im = d.i[s] * w[s];
                 d.r[s] = im; d.i[s] = re;
             }
-            else
+        }
+        else
+        {
+#pragma unroll
+            for (int s = 0; s < E; s++)
             {
-                // window[0] = 1, window[i] = window[N - i] = cos^2(pi/2 * i / startbin) for 1 <= i <= startbin, 0 elsewhere
-                const int i = (k <= N / 2) ? k : N - k;
-                double w = 0.0;
-                if (i <= startbin) { const double c = cos(M_PI_2 * ((double)i) / ((double)startbin)); w = c * c; }
-                if (k == 0) w = 1.0;
-                const double re = d.r[s] * w, im = d.i[s] * w;
+                const int k = s * C2_THREADS + t;
+                const bool z = (k >= startbin) && (k <= stopbin);
+                const double re = z ? 0.0 : d.r[s], im = z ? 0.0 : d.i[s];
                 d.r[s] = im; d.i[s] = re;
             }
         }

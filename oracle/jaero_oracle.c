@@ -1206,5 +1206,22 @@ double jo_demod_get_mse(jo_demod *d) { return d->mse; }
 double jo_demod_get_freq_est(jo_demod *d) { return d->mixer2.freq; }
 double jo_demod_get_freq_center(jo_demod *d) { return d->mixer_center.freq; }
 
+/* JFastFir::SetKernel(rrc(alpha, K, Fs, fsym), nfft) + update(x) on n complex samples (re, im interleaved): the operation
+ * JAERO/tests/jfastfir_tests.cpp:31-58 checks against the recorded output of JAERO v1.0.4.11 */
+void jo_fastfir_run(const double *in, long n, double alpha, int K, int nfft, double Fs, double fsym, double *out)
+{
+    double *pts = (double *)malloc(sizeof(double) * (size_t)(K + 8));
+    const int np = jo_rrc_design(alpha, K, Fs, fsym, pts);
+    fastfir_t f;
+    memset(&f, 0, sizeof f);
+    fastfir_set_kernel_real(&f, pts, np, nfft);
+    cpx *x = (cpx *)malloc(sizeof(cpx) * (size_t)n);
+    for (long i = 0; i < n; i++) { x[i].re = in[2 * i]; x[i].im = in[2 * i + 1]; }
+    fastfir_update(&f, x, n);
+    for (long i = 0; i < n; i++) { out[2 * i] = x[i].re; out[2 * i + 1] = x[i].im; }
+    free(x); free(pts);
+    fastfir_free(&f);
+}
+
 /* burst demodulators: same translation unit (shares the static primitives above) */
 #include "jaero_oracle_burst.c"

@@ -101,4 +101,5 @@ void jo_hilbert_update(jo_hilbert *h, const int16_t *pcm, long n, double *out_re
 #ifdef __cplusplus
 }
 #endif
+void jo_fastfir_run(const double *in, long n, double alpha, int K, int nfft, double Fs, double fsym, double *out);
 #endif

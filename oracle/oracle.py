@@ -323,6 +323,17 @@ def run_burst(settings: Settings, pcm: np.ndarray, chunk: int = 4096, afc=False,
     return out
 
 
+def fastfir(x: np.ndarray, alpha=0.6, K=2048, nfft=4096, Fs=48000.0, fsym=5250.0) -> np.ndarray:
+    """JFastFir with the RRC kernel of JAERO/tests/jfastfir_tests.cpp (restated overlap-add), complex128 in -> complex128 out."""
+    L = lib()
+    L.jo_fastfir_run.argtypes = [C.c_void_p, C.c_long, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p]
+    L.jo_fastfir_run.restype = None
+    a = np.ascontiguousarray(x, dtype=np.complex128)
+    out = np.empty_like(a)
+    L.jo_fastfir_run(a.ctypes.data, len(a), alpha, K, nfft, Fs, fsym, out.ctypes.data)
+    return out
+
+
 def hilbert_kernel(N=2048) -> np.ndarray:
     out = np.zeros(N, dtype=np.complex128)
     lib().jo_hilbert_kernel(N, out.ctypes.data)

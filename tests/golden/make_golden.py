@@ -231,6 +231,28 @@ def aerol_burst():
 
 
 
+def jfastfir():
+    """The reference's own JFastFir test vectors (JAERO/tests/jfastfir_data_{input,expected_output}.cpp: the input and what JAERO
+    v1.0.4.11 produced for it, checked by JAERO/tests/jfastfir_tests.cpp:31-58 from sample 4096 on at 1e-5) as a binary fixture, after
+    confirming that the JFFT stand-in behind oracle/_ref reproduces them."""
+    import re
+
+    def parse(path):
+        txt = open(path).read()
+        v = re.findall(r"cpx_type\(([-+0-9.eE]+),([-+0-9.eE]+)\)", txt)
+        return np.array([complex(float(a), float(b)) for a, b in v], dtype=np.complex128)
+
+    x = parse("/root/reference/JAERO/tests/jfastfir_data_input.cpp")
+    want = parse("/root/reference/JAERO/tests/jfastfir_data_expected_output.cpp")
+    assert len(x) == len(want) and len(x) > 4096
+    got = O.ref_tool("fastfir", x, np.complex128, alpha=0.6, K=2048, nfft=4096, Fs=48000, fsym=5250)
+    err = float(np.max(np.abs(got[4096:] - want[4096:])))
+    assert err < 1e-5, err
+    np.savez_compressed(os.path.join(HERE, "jfastfir.npz"), input=x, expected_output=want,
+                        source=np.array("JAERO/tests/jfastfir_data_input.cpp, jfastfir_data_expected_output.cpp (v1.0.4.11 of JAERO)"))
+    print("jfastfir", len(x), "shim max |err| from 4096 on:", err)
+
+
 def recordings():
     """Inputs of the two bundled recordings (samples/1200bps_burst_sample{1,2}.wav, mono int16 @ 48 kHz) as test fixtures, so that the
     GPU box (which has no /root/reference) can run the WHOLE files through the burst-MSK and continuous-MSK banks against the
@@ -258,6 +280,8 @@ if __name__ == "__main__":
         aerol_c()
     elif len(sys.argv) > 1 and sys.argv[1] == "recordings":
         recordings()
+    elif len(sys.argv) > 1 and sys.argv[1] == "jfastfir":
+        jfastfir()
     else:
         main()
         burst()
@@ -265,3 +289,4 @@ if __name__ == "__main__":
         aerol_burst()
         aerol_c()
         recordings()
+        jfastfir()

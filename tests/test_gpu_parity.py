@@ -266,3 +266,38 @@ def test_single_channel_mirror_emits_like_reference(B, oracle_mod):
     assert len(flat) == len(g["soft"])
     assert np.array_equal(flat >= 128, g["soft"] >= 128)
     assert len(status) == len(g["status"])
+
+
+def test_msk_live_set_settings(B, oracle_mod):
+    """MskDemodulator::setSettings on an open object (mskdemodulator.cpp:135-263): the AGC, the EbNo meter, marg and the timing delay are
+    recreated, the matched filters rebuilt, delayedsmpl keeps its contents but restarts its pointer -- for ONE channel of a bank whose
+    other channels carry on (the delay-line slot is shared by the wavefront, so that channel's column is rotated).  Twice, at
+    different distances, and once for the whole bank."""
+    from jaero_amd import signalgen as G
+
+    O = oracle_mod
+    nch, nsamp = 3, 60000
+    pcm, _, _ = G.channel_bank("msk", nch, nsamp, ebno_db=12.0, seed0=G.SEED_BASE + 900, fb=1200.0)
+    st = B.MskSettings(fb=1200.0, lockingbw=1800.0, freq_center=1000.0)
+    bank = B.DemodulatorBank([st] * nch, ebno=True, status_log=True, capture_symbols=True, max_write_samples=8192, softbit_capacity=nsamp)
+    new1 = B.MskSettings(fb=1200.0, lockingbw=1500.0, freq_center=1010.0)
+    new2 = B.MskSettings(fb=1200.0, lockingbw=1800.0, freq_center=995.0, signalthreshold=0.6)
+    cuts = [0, 12345, 30001, 47000, nsamp]
+    events = {12345: (1, new1), 30001: (1, new2), 47000: (-1, new1)}
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if a in events:
+            ch, ns = events[a]
+            bank.set_settings(ns, channel=ch)
+        for s in range(a, b, 4000):
+            bank.write(pcm[:, s:min(s + 4000, b)])
+    for c in range(nch):
+        d = O.Demod(O.msk_settings(fb=1200.0, lockingbw=1800.0, freq_center=1000.0), capture_symbols=True)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if a in events and events[a][0] in (-1, c):
+                ns = events[a][1]
+                d.set_settings(O.msk_settings(fb=1200.0, lockingbw=ns.lockingbw, freq_center=ns.freq_center, threshold=ns.signalthreshold))
+            for s in range(a, b, 4000):
+                d.write(pcm[c, s:min(s + 4000, b)])
+        ref = {"soft": d.take_soft(), "status": d.take_status(), "symbols": d.take_symbols(), "pending": d.pending}
+        compare(bank.read_softbits(c), bank.read_symbols(c), bank.read_status_log(c), ref)
+    bank.close()

@@ -1,0 +1,83 @@
+"""The Qt adaptors of integration/qt/hipdemodulator.h (HipOqpskDemodulator / HipMskDemodulator: QIODevice subclasses over the C ABI)
+compiled with moc against Qt 5.9.7 and wired, as MainWindow wires the reference's own classes, to the UNMODIFIED AeroL:
+what AeroL prints (signal units, DCD changes) must be the same text with either demodulator in front of it.
+
+oracle/_ref/adaptor_demo is built by `make -C oracle adaptor` (it links reference objects, so only where /root/reference exists; the
+binary travels to the GPU box like oracle/_ref/jaero_ref).  The CPU test checks that it exists, runs its reference side and exports
+the expected surface; the GPU test runs both sides."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from jaero_amd import aerol_frames as AF
+from jaero_amd import signalgen as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "oracle", "_ref", "adaptor_demo")
+have_demo = pytest.mark.skipif(not os.path.exists(DEMO), reason="oracle/_ref/adaptor_demo not built (needs /root/reference + Qt: make -C oracle adaptor)")
+
+
+def p_channel_pcm(nfr=8, fc=8011.0, seed=5):
+    pay = AF.random_payloads(nfr, 10500, seed=seed)
+    bits, _ = AF.p_channel_bits(pay, 10500)
+    n = int(len(bits) / 2 * 48000 / 5250) + 2000
+    pcm, _ = G.oqpsk(n, fc=fc, ebno_db=13.0, seed=seed + 20, bits=np.concatenate([bits, np.zeros(64, np.uint8)]))
+    return pcm, pay
+
+
+def run_demo(impl, kind, pcm, **kv):
+    env = dict(os.environ, QT_QPA_PLATFORM="offscreen")
+    with tempfile.TemporaryDirectory() as td:
+        inp, outp = os.path.join(td, "in.s16"), os.path.join(td, "out.txt")
+        np.ascontiguousarray(pcm, dtype=np.int16).tofile(inp)
+        subprocess.check_call([DEMO, impl, kind, inp, outp] + [f"{k}={v}" for k, v in kv.items()], env=env, stdout=subprocess.DEVNULL)
+        return open(outp, "rb").read().decode("latin1")
+
+
+@have_demo
+def test_reference_side_decodes_the_frames():
+    """Sanity of the driver itself: the all-reference chain prints the transmitted signal units."""
+    import re
+
+    pcm, pay = p_channel_pcm(nfr=14)
+    txt = run_demo("ref", "oqpsk", pcm)
+    assert "#DCD 1" in txt
+    sent = {"".join("%02X" % b for b in p) for fr in pay for p in fr}
+    good = [ln for ln in txt.split("\n") if re.match(r"^. 0x", ln) and "Bad CRC" not in ln]  # the first frames arrive while the AGC settles
+    got = ["".join(re.findall(r"0x([0-9A-F]{2})", ln)) for ln in good]
+    assert len(got) >= 26 * 6 and all(g in sent for g in got)
+
+
+def test_adaptor_header_mirrors_the_reference_surface():
+    """Every member MainWindow uses on the reference classes exists in the adaptor header (names as in oqpskdemodulator.h:41-67)."""
+    src = open(os.path.join(ROOT, "integration", "qt", "hipdemodulator.h")).read()
+    for name in ("setSettings", "setAFC", "setSQL", "setCPUReduce", "start", "stop", "getCurrentFreq", "writeData", "readData",
+                 "processDemodulatedSoftBits", "Plottables", "MSESignal", "SignalStatus", "EbNoMeasurmentSignal", "SampleRateChanged",
+                 "BitRateChanged", "CenterFreqChangedSlot", "DCDstatSlot", "dataReceived", "WarningTextSignal"):
+        assert name in src, name
+
+
+@pytest.mark.gpu
+@have_demo
+def test_hip_adaptor_under_unmodified_aerol_oqpsk():
+    pcm, _ = p_channel_pcm(nfr=14)
+    ref = run_demo("ref", "oqpsk", pcm)
+    hip = run_demo("hip", "oqpsk", pcm)
+    assert ref.count("#DCD 1") >= 1 and len(ref) > 2000
+    assert hip == ref
+
+
+@pytest.mark.gpu
+@have_demo
+def test_hip_adaptor_under_unmodified_aerol_msk():
+    pay = AF.random_payloads(8, 1200, seed=9)
+    bits, _ = AF.p_channel_bits(pay, 1200)
+    n = int(len(bits) * 48000 / 1200) + 4000
+    pcm, _ = G.msk(n, fb=1200.0, fc=1007.0, ebno_db=16.0, seed=31, bits=np.concatenate([bits, np.zeros(16, np.uint8)]))
+    ref = run_demo("ref", "msk", pcm, fb=1200)
+    hip = run_demo("hip", "msk", pcm, fb=1200)
+    assert len(ref) > 500
+    assert hip == ref
