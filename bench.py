@@ -38,6 +38,17 @@ ALG_BYTES_WHOLE_PATH_BURST = 187.0
 HBM_PEAK_GBS = 8000.0                                         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 
 
+def child_env():
+    """Environment for the CPU-baseline child processes: a profiler wrapped around bench.py (rocprofv3) preloads its tool library into
+    every child, and that library needs a newer libstdc++ than the Qt build the reference binary runs against."""
+    env = dict(os.environ)
+    for k in list(env):
+        if k == "LD_PRELOAD" or k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS")):
+            env.pop(k)
+    env.setdefault("QT_QPA_PLATFORM", "offscreen")
+    return env
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,7 +90,7 @@ def cpu_baseline(chunk: int):
     use_ref = O.have_ref()
     if use_ref:
         try:
-            subprocess.check_output([O.REF_BIN, "fft", "/dev/null", "/dev/null", "n=1"], stderr=subprocess.STDOUT)
+            subprocess.check_output([O.REF_BIN, "fft", "/dev/null", "/dev/null", "n=1"], stderr=subprocess.STDOUT, env=child_env())
         except Exception:
             use_ref = False
     with tempfile.TemporaryDirectory() as td:
@@ -88,7 +99,7 @@ def cpu_baseline(chunk: int):
         t0 = time.time()
         if use_ref:
             kind = "reference"
-            procs = [subprocess.Popen([O.REF_BIN, "time", refkind, path, f"chunk={chunk}"], stdout=subprocess.PIPE) for _ in range(ncores)]
+            procs = [subprocess.Popen([O.REF_BIN, "time", refkind, path, f"chunk={chunk}"], stdout=subprocess.PIPE, env=child_env()) for _ in range(ncores)]
             outs = [p.communicate()[0] for p in procs]
             inner = [float(o.split()[0]) for o in outs]
         else:
@@ -96,7 +107,7 @@ def cpu_baseline(chunk: int):
             code = ("import sys,time,numpy as np; sys.path.insert(0,%r); from oracle import oracle as O; "
                     "x=np.fromfile(%r,dtype=np.int16); d=%s; t=time.time(); "
                     "[d.write(x[s:s+%d]) for s in range(0,len(x),%d)]; print(time.time()-t)") % (ROOT, path, mk, chunk, chunk)
-            procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE) for _ in range(ncores)]
+            procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, env=child_env()) for _ in range(ncores)]
             outs = [p.communicate()[0] for p in procs]
             inner = [float(o.split()[0]) for o in outs]
         wall = time.time() - t0
@@ -291,7 +302,7 @@ def aerol_bench():
                     path = os.path.join(td, "in.s16")
                     x.tofile(path)
                     t1 = time.time()
-                    procs = [subprocess.Popen([O.REF_BIN, "aerol", path, os.path.join(td, f"o{i}.txt"), "fb=10500", "group=32"], stdout=subprocess.PIPE)
+                    procs = [subprocess.Popen([O.REF_BIN, "aerol", path, os.path.join(td, f"o{i}.txt"), "fb=10500", "group=32"], stdout=subprocess.PIPE, env=child_env())
                              for i in range(ncores)]
                     inner = [float(pp.communicate()[0].split()[0]) for pp in procs]
                     wall = time.time() - t1
@@ -400,7 +411,7 @@ def aerol_c_bench():
                     path = os.path.join(td, "in.s16")
                     x.tofile(path)
                     t1 = time.time()
-                    procs = [subprocess.Popen([O.REF_BIN, "aerol", path, os.path.join(td, f"o{i}.txt"), "fb=8400", "group=32"], stdout=subprocess.PIPE)
+                    procs = [subprocess.Popen([O.REF_BIN, "aerol", path, os.path.join(td, f"o{i}.txt"), "fb=8400", "group=32"], stdout=subprocess.PIPE, env=child_env())
                              for i in range(logical)]
                     inner = [float(pp.communicate()[0].split()[0]) for pp in procs]
                     wall = time.time() - t1
@@ -520,7 +531,7 @@ def msk_bench():
                     path = os.path.join(td, "in.s16")
                     x.tofile(path)
                     t1 = time.time()
-                    procs = [subprocess.Popen([O.REF_BIN, "time", "msk", path, f"chunk={chunk}", "fb=1200", "lockingbw=1800", "freq_center=1000"], stdout=subprocess.PIPE)
+                    procs = [subprocess.Popen([O.REF_BIN, "time", "msk", path, f"chunk={chunk}", "fb=1200", "lockingbw=1800", "freq_center=1000"], stdout=subprocess.PIPE, env=child_env())
                              for _ in range(ncores)]
                     inner = [float(pp.communicate()[0].split()[0]) for pp in procs]
                     wall = time.time() - t1
@@ -624,7 +635,7 @@ def aerol_burst_bench():
                     x.tofile(path)
                     t1 = time.time()
                     procs = [subprocess.Popen([O.REF_BIN, "aerol", path, os.path.join(td, f"o{i}.txt"), "fb=10500", "group=0", "burst=1"],
-                                              stdout=subprocess.PIPE) for i in range(ncores)]
+                                              stdout=subprocess.PIPE, env=child_env()) for i in range(ncores)]
                     inner = [float(pp.communicate()[0].split()[0]) for pp in procs]
                     wall = time.time() - t1
                 line["cpu_baseline"] = {"value": round(sum(len(x) / t for t in inner) / 1e6, 3), "unit": "Msoftbits/s", "cores": ncores, "kind": "reference",
@@ -678,7 +689,7 @@ def cpu_baseline_continuous(chunk: int, fb: float):
     use_ref = O.have_ref()
     if use_ref:
         try:
-            subprocess.check_output([O.REF_BIN, "fft", "/dev/null", "/dev/null", "n=1"], stderr=subprocess.STDOUT)
+            subprocess.check_output([O.REF_BIN, "fft", "/dev/null", "/dev/null", "n=1"], stderr=subprocess.STDOUT, env=child_env())
         except Exception:
             use_ref = False
     kv = [f"chunk={chunk}"] + ([f"fb={int(fb)}", f"lockingbw={int(fb)}"] if fb != 10500 else [])
@@ -689,12 +700,12 @@ def cpu_baseline_continuous(chunk: int, fb: float):
         def run(nproc):
             t0 = time.time()
             if use_ref:
-                procs = [subprocess.Popen([O.REF_BIN, "time", "oqpsk", path] + kv, stdout=subprocess.PIPE) for _ in range(nproc)]
+                procs = [subprocess.Popen([O.REF_BIN, "time", "oqpsk", path] + kv, stdout=subprocess.PIPE, env=child_env()) for _ in range(nproc)]
             else:
                 code = ("import sys,time,numpy as np; sys.path.insert(0,%r); from oracle import oracle as O; "
                         "x=np.fromfile(%r,dtype=np.int16); d=O.Demod(O.oqpsk_settings(fb=%r,lockingbw=%r)); t=time.time(); "
                         "[d.write(x[s:s+%d]) for s in range(0,len(x),%d)]; print(time.time()-t)") % (ROOT, path, fb, fb, chunk, chunk)
-                procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE) for _ in range(nproc)]
+                procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, env=child_env()) for _ in range(nproc)]
             inner = [float(p.communicate()[0].split()[0]) for p in procs]
             return sum(n / t for t in inner) / 1e6, time.time() - t0
 

@@ -112,6 +112,7 @@ def lib():
     L.jaero_profile_enable.argtypes = [vp, ip]
     L.jaero_profile_read.argtypes = [vp, ip, C.POINTER(dp), C.POINTER(ip), ip]
     L.jaero_debug_schedule.argtypes = [ip, ip, ip, vp, ip, vp, ip, C.POINTER(ip)]
+    L.jaero_debug_prefilter.argtypes = [ip, vp, ip, dp, dp, vp]
     L.jaero_aerol_create.argtypes = [ip, ip, ip, ip, ip, C.POINTER(vp)]
     L.jaero_aerol_create_burst.argtypes = [ip, ip, ip, ip, ip, C.POINTER(vp)]
     L.jaero_aerol_read_packets.argtypes = [vp, ip, vp, ip, C.POINTER(ip)]

@@ -242,6 +242,7 @@ struct aerolc_state
 {
     CGeom g{};
     CPtrs p{};
+    unsigned long long *d_vhist = nullptr; // k_viterbi_lanes history scratch (banks large enough for the lane layout)
 };
 
 static int aerolc_create(jaero_aerol_ctx *c, int nchannels, int su_capacity)
@@ -264,6 +265,7 @@ static int aerolc_create(jaero_aerol_ctx *c, int nchannels, int su_capacity)
     CA(cs->p.sus, (size_t)g.nchp * g.su_cap * 16);
     CA(cs->p.voice, (size_t)g.nchp * g.v_cap * 304);
     CA(cs->p.events, (size_t)g.nchp * g.ev_cap * 3);
+    if (viterbi_use_lanes(g.nch, CC_NSOFT, 24)) CA(cs->d_vhist, viterbi_hist_bytes(g.nch) / sizeof(unsigned long long));
     uint8_t *d_scr = nullptr;
     CA(d_scr, 5000);
 #undef CA
@@ -310,8 +312,9 @@ static int aerolc_write(jaero_aerol_ctx *c, const int16_t *dsoft, const int *dco
         hipLaunchKernelGGL(k_aerolc_bits, grid, block, 0, st, g, cs->p, dsoft, dcounts, stride);
         aprof_end(c, st);
         aprof_begin(c, 1, st);
-        hipLaunchKernelGGL(k_viterbi, dim3(g.nch), dim3(64), 0, st, (const uint8_t *)cs->p.dep, CC_NSOFT, (const uint8_t *)cs->p.overlap, 24, cs->p.vbits,
-                           CC_NSOFT / 2, 25, CC_NSOFT / 2, g.nch, valid, (const int *)nullptr);
+        // one block per wavefront for small banks, one per lane (k_viterbi_lanes) from 16 384 channels on, as the P-channel pipeline
+        viterbi_launch(st, (const uint8_t *)cs->p.dep, CC_NSOFT, (const uint8_t *)cs->p.overlap, 24, cs->p.vbits, CC_NSOFT / 2, 25, CC_NSOFT / 2, g.nch, valid,
+                       cs->d_vhist);
         hipLaunchKernelGGL(k_viterbi_overlap_update, dim3(g.nch), dim3(64), 0, st, (const uint8_t *)cs->p.dep, CC_NSOFT, cs->p.overlap, g.nch, valid, 0);
         aprof_end(c, st);
         aprof_begin(c, 2, st);

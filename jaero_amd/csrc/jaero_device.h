@@ -96,7 +96,9 @@ struct JPtrs
     double *slog;        // [nchp][log_cap][6]
     const double2 *cis;  // [19999]
     const double *taps2; // [2*fir_n] taps repeated twice
+    double *symrec;      // k_oqpsk_fb: [nchp][JD_SYMREC_LEN][8] one 64-byte record per symbol pair (see fb_back)
 };
+#define JD_SYMREC_LEN 800
 
 __device__ __forceinline__ int jd_cisidx(double wtptr)
 {
@@ -295,39 +297,6 @@ __device__ __forceinline__ void jd_fir_eval_sym_static(const double *lre, const 
         aim = fma(tap, tim[TAILN - 1 - s], aim);
     }
 #define JD_FIR_CASE(S) case S: if constexpr (S < LDSN) jd_fir_lds_part<FIRN, LDSN, D, (S < LDSN ? S : 0), FIRN - LDSN>(lre_l, lim_l, tp, are, aim); break;
-    switch (fir_slot)
-    {
-        JD_FIR_CASE(0) JD_FIR_CASE(1) JD_FIR_CASE(2) JD_FIR_CASE(3) JD_FIR_CASE(4) JD_FIR_CASE(5) JD_FIR_CASE(6) JD_FIR_CASE(7)
-        JD_FIR_CASE(8) JD_FIR_CASE(9) JD_FIR_CASE(10) JD_FIR_CASE(11) JD_FIR_CASE(12) JD_FIR_CASE(13) JD_FIR_CASE(14) JD_FIR_CASE(15)
-        JD_FIR_CASE(16) JD_FIR_CASE(17) JD_FIR_CASE(18) JD_FIR_CASE(19) JD_FIR_CASE(20) JD_FIR_CASE(21) JD_FIR_CASE(22) JD_FIR_CASE(23)
-        JD_FIR_CASE(24) JD_FIR_CASE(25) JD_FIR_CASE(26) JD_FIR_CASE(27) JD_FIR_CASE(28) JD_FIR_CASE(29) JD_FIR_CASE(30) JD_FIR_CASE(31)
-        JD_FIR_CASE(32) JD_FIR_CASE(33) JD_FIR_CASE(34) JD_FIR_CASE(35) JD_FIR_CASE(36) JD_FIR_CASE(37) JD_FIR_CASE(38) JD_FIR_CASE(39)
-    default: break;
-    }
-#undef JD_FIR_CASE
-    ore = are; oim = aim;
-}
-
-// The first 54 terms of the NEXT output, from the history as it stands before the newest input is pushed: y[n+1] = sum_{s<54} t[s]
-// x[n-54+s] + t[54] x[n].  The caller adds the last term once x[n] exists -- it arrives through a table gather whose latency this sum
-// covers.  History: LDS holds x[n-LDSN .. n-1] (oldest at fir_slot), the register tail x[n-LDSN-1-j]; the oldest tail entry
-// (x[n-55]) is not part of this output.
-template <int FIRN, int LDSN, int D, int TAILA>
-__device__ __forceinline__ void jd_fir_partial_static(const double *lre, const double *lim, const JTaps28 &tp, const double (&tre)[TAILA],
-                                                      const double (&tim)[TAILA], int fir_slot, int lane, double &ore, double &oim)
-{
-    static_assert(FIRN == 55 && LDSN <= 40, "symmetric-tap filter is the 55-tap RRC; the switch below has 40 cases");
-    constexpr int TAILN = FIRN - LDSN;
-    jd_lds_cdouble *lre_l = (jd_lds_cdouble *)lre + lane, *lim_l = (jd_lds_cdouble *)lim + lane;
-    double are = 0, aim = 0;
-#pragma unroll
-    for (int s = 0; s < TAILN - 1; s++) // x[n-54+s] = tail[TAILN-2-s]
-    {
-        const double tap = tp.t[s <= 27 ? s : 54 - s];
-        are = fma(tap, tre[TAILN - 2 - s], are);
-        aim = fma(tap, tim[TAILN - 2 - s], aim);
-    }
-#define JD_FIR_CASE(S) case S: if constexpr (S < LDSN) jd_fir_lds_part<FIRN, LDSN, D, (S < LDSN ? S : 0), FIRN - LDSN - 1>(lre_l, lim_l, tp, are, aim); break;
     switch (fir_slot)
     {
         JD_FIR_CASE(0) JD_FIR_CASE(1) JD_FIR_CASE(2) JD_FIR_CASE(3) JD_FIR_CASE(4) JD_FIR_CASE(5) JD_FIR_CASE(6) JD_FIR_CASE(7)

@@ -135,10 +135,8 @@ struct jaero_ctx
     // device helpers
     int16_t *d_pcm_frames = nullptr; // [max_write][nchp] staging for channel-major / host input
     int16_t *d_pcm_raw = nullptr;    // [nch*max_write] staging for host input
-    double2 *d_scratch = nullptr;
     double2 *d_tw = nullptr;
     int *d_emitted = nullptr; // burst banks: per-channel count of soft bits already emitted (jaero_softbits_view)
-    bool coarse_v2 = false; int coarse3_grid = 256, coarse_ver = 4;
     int msk_ldsn = 0; // MSK: matched-filter inputs kept in LDS (the rest of fir_n in registers)
     std::vector<int> dly_t0; // MSK: shared delay-line slot at which each channel's delayedsmpl pointer last restarted (jaero_set_settings)
     int oq_pairs = 0; // 10.5 kbps OQPSK: front/back pairs per workgroup of k_oqpsk_fb (0 = the single-wavefront kernel k_oqpsk_samples)
@@ -150,8 +148,6 @@ struct jaero_ctx
     long long pre_n0 = 0;
     int pre_nprev = 0;
     int *d_chanlist = nullptr;
-    int coarse_grid = 0;
-    bool coarse_v1 = false;  // JAERO_COARSE_V1=1 selects the four-step LDS/scratch FFT (kept for A/B validation)
     int coarse2_grid = 0, coarse2_lds = 0;
     jaero_status *d_status = nullptr;
     int16_t *d_pack = nullptr; size_t pack_elems = 0;
@@ -546,9 +542,6 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
     DA(c->d_pcm_raw, (size_t)max_write_samples * nchannels);
     DA(c->d_chanlist, nchp);
     DA(c->d_status, nchp);
-    c->coarse_v1 = getenv("JAERO_COARSE_V1") && atoi(getenv("JAERO_COARSE_V1")) != 0;
-    c->coarse_grid = nchannels < 512 ? nchannels : 512;
-    if (c->coarse_v1) DA(c->d_scratch, (size_t)c->coarse_grid * 2 * g.nfft);
     {
         const int E = g.nfft / C2_THREADS;
         const int a = E * 528, b = C2_THREADS * (E + 1);
@@ -639,24 +632,18 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         const char *e = getenv("JAERO_OQPSK_KERNEL");
         const int ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (c->oq_pairs) c->oq_pairs = (e && !strcmp(e, "single")) ? 0 : ((e && !strcmp(e, "pairs1")) ? 1 : ((e && !strcmp(e, "pairs4")) ? 4 : (g.ngroups > 2 * ncu ? 4 : 1)));
+        if (c->oq_pairs && !(g.marg_len == JD_SYMREC_LEN && g.dt_len == JD_SYMREC_LEN / 2 + 1 && g.pm_len == JD_SYMREC_LEN / 2 && g.msema_len == JD_SYMREC_LEN / 2))
+            c->oq_pairs = 0; // the combined symbol-record ring of k_oqpsk_fb assumes the reference's window lengths (800 / 400 / 400 / 400)
         if (c->oq_pairs)
         {
+            if ((rc = dalloc(c, &c->p.symrec, (size_t)nchp * JD_SYMREC_LEN * 8))) { jaero_destroy(c); return rc; }
 #define FBA(E, C, PP) HIPCHK(hipFuncSetAttribute((const void *)k_oqpsk_fb<55, FB_LDSN, E, C, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, PP * fb_pair_doubles<FB_LDSN>() * (int)sizeof(double)))
             FBA(false, false, 1); FBA(false, true, 1); FBA(true, false, 1); FBA(true, true, 1);
             FBA(false, false, 4); FBA(false, true, 4); FBA(true, false, 4); FBA(true, true, 4);
 #undef FBA
         }
     }
-    if (g.nfft_log2 == 14)
-    {
-        HIPCHK(hipFuncSetAttribute((const void *)k_coarse2<14>, hipFuncAttributeMaxDynamicSharedMemorySize, c->coarse2_lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_coarse3, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 34 * (int)sizeof(double)));
-        const char *e = getenv("JAERO_COARSE_KERNEL"); // "2" = the single 2^14-point transform (k_coarse2<14>), for comparison
-        c->coarse_v2 = e && !strcmp(e, "2");
-        c->coarse_ver = (e && !strcmp(e, "3")) ? 3 : (c->coarse_v2 ? 2 : 4); // "3" = pairs of 2^13-point transforms (k_coarse3)
-        HIPCHK(hipFuncSetAttribute((const void *)k_coarse4, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 257 * (int)sizeof(double)));
-        c->coarse3_grid = c->coarse2_grid;
-    }
+    if (g.nfft_log2 == 14) HIPCHK(hipFuncSetAttribute((const void *)k_coarse4, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 257 * (int)sizeof(double)));
     else HIPCHK(hipFuncSetAttribute((const void *)k_coarse2<13>, hipFuncAttributeMaxDynamicSharedMemorySize, c->coarse2_lds));
     HIPCHK(hipDeviceSynchronize());
     *out = c;
@@ -918,37 +905,17 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
 
 static void launch_coarse(jaero_ctx *c, const int *d_list, int nlist, hipStream_t st)
 {
-    if (!c->coarse_v1)
-    {
-        // register-resident FFT: one workgroup per CU (512-VGPR budget, ~140 KB LDS), persistent over the list
-        const int grid2 = nlist < c->coarse2_grid ? nlist : c->coarse2_grid;
-        if (c->g.nfft_log2 == 14 && c->coarse_ver == 4)
-        {
-            // 2^14 = 16 x 16 x 16 x 4, 16-point register FFTs only (k_coarse4); one padded plane of 64*257 doubles in LDS
-            if (c->pre8400)
-                hipLaunchKernelGGL(k_coarse4_w8400, dim3(nlist < c->coarse3_grid ? nlist : c->coarse3_grid), dim3(C2_THREADS), 64 * 257 * (int)sizeof(double), st,
-                                   c->g, c->p, d_list, nlist, c->d_tw);
-            else
-                hipLaunchKernelGGL(k_coarse4, dim3(nlist < c->coarse3_grid ? nlist : c->coarse3_grid), dim3(C2_THREADS), 64 * 257 * (int)sizeof(double), st, c->g, c->p,
-                                   d_list, nlist, c->d_tw);
-        }
-        else if (c->g.nfft_log2 == 14 && !c->coarse_v2)
-        {
-            // 2^14 as pairs of 2^13-point transforms run together (k_coarse3, wg_fft13x2); two 68 KiB exchange buffers in LDS
-            const int lds3 = 512 * 34 * (int)sizeof(double);
-            hipLaunchKernelGGL(k_coarse3, dim3(nlist < c->coarse3_grid ? nlist : c->coarse3_grid), dim3(C2_THREADS), lds3, st, c->g, c->p, d_list, nlist, c->d_tw);
-        }
-        else if (c->g.nfft_log2 == 14)
-            hipLaunchKernelGGL((k_coarse2<14>), dim3(grid2), dim3(C2_THREADS), c->coarse2_lds, st, c->g, c->p, d_list, nlist, c->d_tw);
-        else
-            hipLaunchKernelGGL((k_coarse2<13>), dim3(grid2), dim3(C2_THREADS), c->coarse2_lds, st, c->g, c->p, d_list, nlist, c->d_tw);
-        return;
-    }
-    const int grid = nlist < c->coarse_grid ? nlist : c->coarse_grid;
+    // register-resident FFTs: one 512-thread workgroup per CU (the whole register file, ~130 KiB of LDS), persistent over the list
+    const int grid = nlist < c->coarse2_grid ? nlist : c->coarse2_grid;
     if (c->g.nfft_log2 == 14)
-        hipLaunchKernelGGL((k_coarse<14>), dim3(grid), dim3(CO_THREADS), 0, st, c->g, c->p, d_list, nlist, c->d_scratch, c->d_tw);
-    else
-        hipLaunchKernelGGL((k_coarse<13>), dim3(grid), dim3(CO_THREADS), 0, st, c->g, c->p, d_list, nlist, c->d_scratch, c->d_tw);
+    {
+        // 2^14 = 16 x 16 x 16 x 4, 16-point register FFTs only (k_coarse4); one padded plane of 64*257 doubles in LDS
+        if (c->pre8400)
+            hipLaunchKernelGGL(k_coarse4_w8400, dim3(grid), dim3(C2_THREADS), 64 * 257 * (int)sizeof(double), st, c->g, c->p, d_list, nlist, c->d_tw);
+        else
+            hipLaunchKernelGGL(k_coarse4, dim3(grid), dim3(C2_THREADS), 64 * 257 * (int)sizeof(double), st, c->g, c->p, d_list, nlist, c->d_tw);
+    }
+    else hipLaunchKernelGGL((k_coarse2<13>), dim3(grid), dim3(C2_THREADS), c->coarse2_lds, st, c->g, c->p, d_list, nlist, c->d_tw);
 }
 
 extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layout, int is_device_ptr, void *stream)

@@ -414,305 +414,6 @@ __global__ __launch_bounds__(C2_THREADS) void k_coarse2(const JGeom g, const JPt
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// N = 2^14 as pairs of 2^13-point transforms.  wg_fft<14> keeps 32 complex points per thread and the compiler runs out of
-// registers (it hoists ~100 per-thread twiddle factors out of the passes and reloads them from scratch: 54 of the 88 GB this
-// kernel moved per launch were that); wg_fft<13> keeps 16 and has no scratch traffic.  So every 2^14-point transform is split once
-// by hand, alternating the two textbook forms so that no redistribution is needed in between:
-//   decimation in frequency: natural-order input  x[n], n = s*512 + t          ->  X[2m], X[2m+1], m = s*512 + t
-//       X[2m] = FFT8192(x[n] + x[n+8192])[m],   X[2m+1] = FFT8192((x[n] - x[n+8192]) W^n)[m],   W = exp(-2 pi i / 16384)
-//   decimation in time: input x[2m], x[2m+1] held like that                    ->  natural-order output
-//       A = FFT8192(x[2m]), B = FFT8192(x[2m+1]):   Y[q] = A[q] + W^q B[q],   Y[q+8192] = A[q] - W^q B[q]
-// FFT (DIF) -> band limit -> IFFT (DIT, planes swapped) -> square -> FFT (DIF) -> |.|^2 -> dB smoothing; thread t ends up with the
-// bin pairs (2m, 2m+1), which it folds into y[] as 16-byte accesses.  W^(s*512+t) = W^t * W_32^s: one table value per thread and
-// sixteen compile-time constants.
-// Measured (MI355X, 65536 estimates per launch): k_coarse2<14> 28.5 ms -> k_coarse3 24.7 ms (opaque thread index per estimate: -1.6 ms,
-// fold from an LDS copy of y instead of L2: -1.8 ms; running the two half transforms together instead of one after the other made
-// no difference by itself).  Still ~30 spill stores + reloads per thread in each middle pass (32 points in, 32 out, 256 registers).
-struct C2Half
-{
-    CV<16> a, b; // natural order: a = points s*512+t (s < 16), b = points (s+16)*512+t; split order: a = even bins/samples, b = odd
-};
-__device__ __forceinline__ double2 c2_w32(int s) // W_32^s, s < 16
-{
-    return make_double2(jd_w64r(2 * s), jd_w64i(2 * s));
-}
-// natural (a = low half, b = high half) -> DIF inputs (a = sum, b = twiddled difference)
-__device__ __forceinline__ void c2_dif_split(C2Half &h, const double2 base)
-{
-#pragma clang fp contract(fast)
-#pragma unroll
-    for (int s = 0; s < 16; s++)
-    {
-        const double2 w = (s == 0) ? base : cmul2(base, c2_w32(s));
-        const double sr = h.a.r[s] + h.b.r[s], si = h.a.i[s] + h.b.i[s];
-        const double dr = h.a.r[s] - h.b.r[s], di = h.a.i[s] - h.b.i[s];
-        h.a.r[s] = sr; h.a.i[s] = si;
-        h.b.r[s] = dr * w.x - di * w.y;
-        h.b.i[s] = dr * w.y + di * w.x;
-    }
-}
-// DIT outputs: (a = A, b = B) -> natural (a = Y[q], b = Y[q+8192])
-__device__ __forceinline__ void c2_dit_merge(C2Half &h, const double2 base)
-{
-#pragma clang fp contract(fast)
-#pragma unroll
-    for (int s = 0; s < 16; s++)
-    {
-        const double2 w = (s == 0) ? base : cmul2(base, c2_w32(s));
-        const double br = h.b.r[s] * w.x - h.b.i[s] * w.y, bi = h.b.r[s] * w.y + h.b.i[s] * w.x;
-        const double ar = h.a.r[s], ai = h.a.i[s];
-        h.a.r[s] = ar + br; h.a.i[s] = ai + bi;
-        h.b.r[s] = ar - br; h.b.i[s] = ai - bi;
-    }
-}
-
-// one 2^13-point transform; the thread index is laundered so that nothing derived from it inside (twiddle powers, LDS addresses:
-// ~100 registers' worth) can be hoisted out of the estimate loop or shared between the six calls -- kept live across the loop they
-// are what the compiler spills
-// TWO 2^13-point transforms at once (the pair every split 2^14-point transform consists of).  wg_fft<13> is 16 x 32 x 16: its middle
-// pass is 256 32-point FFTs, i.e. half of the 512 threads idle (and the other transform's 16 points per thread sit in registers
-// meanwhile).  Here threads 0..255 run the middle pass of transform a while threads 256..511 run that of transform b; passes 1 and 3
-// (16-point FFTs, one per thread and transform) are done for both.  One barrier schedule serves both transforms.  LDS: two exchange
-// buffers of 512*17 doubles.  tw = W_16384^k (stride 2 = W_8192).
-__device__ __forceinline__ void wg_fft13x2(CV<16> &da, CV<16> &db, double *xch, const double2 *__restrict__ tw, int t)
-{
-#pragma clang fp contract(fast)
-    constexpr int N = 1 << 13, E = 16, S1 = 528, S2 = E + 1, XB = C2_THREADS * 17; // XB: offset of transform b's buffer
-    const int n3 = t & 15, n2 = t >> 4;
-    // ---- pass 1 (both): 16-point FFT over n1, twiddle W_N^(16*n2*k1) ----
-    {
-        double2 B[4], A[8];
-        twiddle_powers<E>(make_double2(1.0, 0.0), tw[((16 * n2) & (N - 1)) * 2], B, A);
-        CV<E> f;
-        regfft<E>(da, f);
-#pragma unroll
-        for (int k1 = 0; k1 < E; k1++)
-        {
-            const double2 w = (k1 < 4) ? B[k1 & 3] : cmul2(A[k1 >> 2], B[k1 & 3]);
-            da.r[k1] = f.r[k1] * w.x - f.i[k1] * w.y;
-            da.i[k1] = f.r[k1] * w.y + f.i[k1] * w.x;
-        }
-        regfft<E>(db, f);
-#pragma unroll
-        for (int k1 = 0; k1 < E; k1++)
-        {
-            const double2 w = (k1 < 4) ? B[k1 & 3] : cmul2(A[k1 >> 2], B[k1 & 3]);
-            db.r[k1] = f.r[k1] * w.x - f.i[k1] * w.y;
-            db.i[k1] = f.r[k1] * w.y + f.i[k1] * w.x;
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- exchange 1: L1[k1][n2][n3]; middle-pass thread u = t mod 256 of transform (t >= 256): n3 = u & 15, k1 = u >> 4 ----
-    const int u = t & 255, k1u = u >> 4, n3u = u & 15;
-    double *mine = xch + ((t >= 256) ? XB : 0);
-    CV<32> m;
-    {
-        __syncthreads();
-#pragma unroll
-        for (int k1 = 0; k1 < E; k1++) { xch[k1 * S1 + t] = da.r[k1]; xch[XB + k1 * S1 + t] = db.r[k1]; }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 32; q++) m.r[q] = mine[k1u * S1 + q * 16 + n3u];
-        __syncthreads();
-#pragma unroll
-        for (int k1 = 0; k1 < E; k1++) { xch[k1 * S1 + t] = da.i[k1]; xch[XB + k1 * S1 + t] = db.i[k1]; }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 32; q++) m.i[q] = mine[k1u * S1 + q * 16 + n3u];
-    }
-    // ---- pass 2: 32-point FFT over n2, twiddle W_N^(n3*(k1 + E*k2)) ----
-    {
-        CV<32> c;
-        __builtin_amdgcn_sched_barrier(0);
-        regfft32_seq(m, c);
-        double2 B[4], A[8];
-        twiddle_powers<E>(tw[((n3u * k1u) & (N - 1)) * 2], tw[((n3u * E) & (N - 1)) * 2], B, A);
-#pragma unroll
-        for (int k2 = 0; k2 < 32; k2++)
-        {
-            const double2 w = (k2 < 4) ? B[k2 & 3] : cmul2(A[k2 >> 2], B[k2 & 3]);
-            m.r[k2] = c.r[k2] * w.x - c.i[k2] * w.y;
-            m.i[k2] = c.r[k2] * w.y + c.i[k2] * w.x;
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- exchange 2: M[(k2*16 + n3)][k1]; pass-3 thread v: k1 = v & 15, k2 = v >> 4 (both transforms) ----
-    {
-        const int k1v = t & (E - 1), k2b = t >> 4;
-        CV<16> ca, cb;
-        __syncthreads();
-#pragma unroll
-        for (int k2 = 0; k2 < 32; k2++) mine[(k2 * 16 + n3u) * S2 + k1u] = m.r[k2];
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 16; q++) { ca.r[q] = xch[(k2b * 16 + q) * S2 + k1v]; cb.r[q] = xch[XB + (k2b * 16 + q) * S2 + k1v]; }
-        __syncthreads();
-#pragma unroll
-        for (int k2 = 0; k2 < 32; k2++) mine[(k2 * 16 + n3u) * S2 + k1u] = m.i[k2];
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 16; q++) { ca.i[q] = xch[(k2b * 16 + q) * S2 + k1v]; cb.i[q] = xch[XB + (k2b * 16 + q) * S2 + k1v]; }
-        // ---- pass 3: 16-point FFT over n3; X[k1 + 16*k2 + 512*k3] -> slot k3 ----
-        regfft<16>(ca, da);
-        regfft<16>(cb, db);
-    }
-}
-
-// the thread index is laundered per call so that nothing derived from it inside (twiddle powers, LDS addresses) is hoisted out of the
-// estimate loop or shared between the three calls and then kept live -- and spilled -- across everything else
-__device__ __forceinline__ void c3_fft2(C2Half &h, double *xch, const double2 *__restrict__ tw, int t)
-{
-    int tt = t;
-    asm volatile("" : "+v"(tt));
-    wg_fft13x2(h.a, h.b, xch, tw, tt);
-}
-
-__global__ __launch_bounds__(C2_THREADS) void k_coarse3(const JGeom g, const JPtrs p, const int *__restrict__ chan_list, int nlist,
-                                                         const double2 *__restrict__ tw /* W_16384^k */)
-{
-    constexpr int N = 1 << 14;
-    extern __shared__ __attribute__((aligned(16))) double xch[]; // two exchange buffers of 512*17 doubles (wg_fft13x2)
-    __shared__ double red_val[C2_THREADS];
-    __shared__ int red_idx[C2_THREADS];
-    __shared__ int sh_bigchange;
-    const int t0 = threadIdx.x;
-    const int nchp = g.nchp;
-
-    C2Half h;
-    for (int li = blockIdx.x; li < nlist; li += gridDim.x)
-    {
-        // The thread index is made opaque once per estimate: every per-thread offset, mask bound and twiddle below is one or two
-        // instructions from it, but hoisted out of this loop (they are all loop invariant) they add up to ~100 live registers that
-        // the compiler then spills and reloads from scratch -- 0.9 MB of HBM traffic per estimate, more than the estimate's data.
-        int t = t0;
-        asm volatile("" : "+v"(t));
-        double2 base = tw[t];
-        const int ch = chan_list ? chan_list[li] : li;
-        const double2 *__restrict__ ring = p.bbring + (size_t)ch * N;
-        const int bb_ptr = p.I[(size_t)I_BB_PTR * nchp + ch];
-        const double lockingbw = p.S[(size_t)S_LOCKINGBW * nchp + ch];
-        const double hzperbin = g.Fs / ((double)N);
-        const int startbin = (int)fmax(round(lockingbw / hzperbin), 1.0);
-        const int stopbin = N - startbin;
-        const int expectedpeakbin = (int)round(g.fb / (2.0 * hzperbin));
-        double *__restrict__ y = p.y + (size_t)ch * N;
-
-        if (li == (int)blockIdx.x)
-        {
-#pragma unroll
-            for (int s = 0; s < 16; s++)
-            {
-                const double2 v = ring[(bb_ptr + s * C2_THREADS + t) & (N - 1)];
-                const double2 u = ring[(bb_ptr + (s + 16) * C2_THREADS + t) & (N - 1)];
-                h.a.r[s] = v.x; h.a.i[s] = v.y; h.b.r[s] = u.x; h.b.i[s] = u.y;
-            }
-        }
-        // keep the per-thread twiddle chain inside this iteration (hoisted out of the loop it costs 64 registers for good)
-        asm volatile("" : "+v"(base.x), "+v"(base.y));
-        c2_dif_split(h, base);
-        c3_fft2(h, xch, tw, t);
-        // band limit (fb != 8400 boxcar, coarsefreqestimate.cpp:99); inverse transform = forward on swapped planes
-#pragma unroll
-        for (int s = 0; s < 16; s++)
-        {
-            const int k0 = 2 * (s * C2_THREADS + t), k1 = k0 + 1;
-            const bool z0 = (k0 >= startbin) && (k0 <= stopbin), z1 = (k1 >= startbin) && (k1 <= stopbin);
-            const double ar = z0 ? 0.0 : h.a.r[s], ai = z0 ? 0.0 : h.a.i[s];
-            const double br = z1 ? 0.0 : h.b.r[s], bi = z1 ? 0.0 : h.b.i[s];
-            h.a.r[s] = ai; h.a.i[s] = ar; h.b.r[s] = bi; h.b.i[s] = br;
-        }
-        c3_fft2(h, xch, tw, t);
-        asm volatile("" : "+v"(base.x), "+v"(base.y));
-        c2_dit_merge(h, base);
-        // swap back (x N / N = 1), square
-#pragma unroll
-        for (int s = 0; s < 16; s++)
-        {
-            double re = h.a.i[s], im = h.a.r[s];
-            h.a.r[s] = re * re - im * im; h.a.i[s] = re * im + im * re;
-            re = h.b.i[s]; im = h.b.r[s];
-            h.b.r[s] = re * re - im * im; h.b.i[s] = re * im + im * re;
-        }
-        asm volatile("" : "+v"(base.x), "+v"(base.y));
-        c2_dif_split(h, base);
-        c3_fft2(h, xch, tw, t);
-        __syncthreads(); // every thread has read its pass-3 inputs from the exchange buffers, which now receive the copy of y
-        // smooth with fftshift: y[i] = y[i]*0.9 + 0.1*10*log10(fmax(abs(out[i]),1)), out[i] = X[i ^ N/2]; bins 2m, 2m+1 together
-#pragma unroll
-        for (int s = 0; s < 16; s++)
-        {
-            const int k0 = 2 * (s * C2_THREADS + t);
-            double2 *yp = (double2 *)(y + (k0 ^ (N / 2)));
-            double2 yv = *yp;
-            yv.x = yv.x * 0.9 + 5.0 * c2_log10(fmax(h.a.r[s] * h.a.r[s] + h.a.i[s] * h.a.i[s], 1.0));
-            yv.y = yv.y * 0.9 + 5.0 * c2_log10(fmax(h.b.r[s] * h.b.r[s] + h.b.i[s] * h.b.i[s], 1.0));
-            *yp = yv;
-            // a copy in LDS (the exchange buffers are idle now; 16384 doubles fit): the fold below reads six neighbours per candidate
-            // bin, which from L2 was ~14 serial round trips per estimate
-            *(double2 *)(xch + (k0 ^ (N / 2))) = yv;
-        }
-        __syncthreads();
-        {
-            const int ln = li + (int)gridDim.x;
-            if (ln < nlist)
-            {
-                const int chn = chan_list ? chan_list[ln] : ln;
-                const double2 *__restrict__ ringn = p.bbring + (size_t)chn * N;
-                const int bpn = p.I[(size_t)I_BB_PTR * nchp + chn];
-#pragma unroll
-                for (int s = 0; s < 16; s++)
-                {
-                    const double2 v = ringn[(bpn + s * C2_THREADS + t) & (N - 1)];
-                    const double2 u = ringn[(bpn + (s + 16) * C2_THREADS + t) & (N - 1)];
-                    h.a.r[s] = v.x; h.a.i[s] = v.y; h.b.r[s] = u.x; h.b.i[s] = u.y;
-                }
-            }
-        }
-
-        // fold + peak search (:116-131)
-        const int i0 = (int)round((-lockingbw / hzperbin) + ((double)(N / 2)));
-        const int i1 = (int)round((lockingbw / hzperbin) + ((double)(N / 2)));
-        double best = 0;
-        int besti = -1;
-        for (int i = i0 + t; i < i1; i += C2_THREADS)
-        {
-            if ((i < 0) || (i >= N)) continue;
-            double val = 0;
-            for (int j = -1; j <= 1; j++)
-            {
-                if (((i - expectedpeakbin - j) < 0) || ((i + expectedpeakbin + j) >= N)) continue;
-                val += (xch[i - expectedpeakbin - j] + xch[i + expectedpeakbin + j]);
-            }
-            if (val > best) { best = val; besti = i; }
-        }
-        red_val[t] = best;
-        red_idx[t] = besti;
-        __syncthreads();
-        for (int s = C2_THREADS / 2; s > 0; s >>= 1)
-        {
-            if (t < s)
-            {
-                const double ov = red_val[t + s];
-                const int oi = red_idx[t + s];
-                const double mv = red_val[t];
-                const int mi = red_idx[t];
-                if (oi >= 0 && (mi < 0 || ov > mv || (ov == mv && oi < mi))) { red_val[t] = ov; red_idx[t] = oi; }
-            }
-            __syncthreads();
-        }
-        if (t == 0) sh_bigchange = coarse_slot(g, p, ch, (red_idx[0] >= 0) ? red_idx[0] : (N / 2), N, hzperbin, lockingbw);
-        __syncthreads();
-        if (sh_bigchange)
-        {
-            double2 *ringw = p.bbring + (size_t)ch * N;
-            for (int i = t; i < N; i += C2_THREADS) { y[i] = 20; ringw[i] = make_double2(0.0, 0.0); }
-        }
-        __syncthreads();
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------------
 // 2^14-point transform out of 16-point pieces only: 16384 = 16 x 16 x 16 x 4, four passes, natural order in AND out, all 512
 // threads busy in every pass, never more than one 16-point FFT's worth of temporaries on top of the 32 points a thread holds
 // (wg_fft<14> and the middle pass of wg_fft<13> run 32-point FFTs in registers -- 32 in, 32 out, 256 VGPRs -- and spill).
@@ -901,7 +602,7 @@ __device__ __forceinline__ void coarse4_body(const JGeom g, const JPtrs p, const
     CV<E> d;
     for (int li = blockIdx.x; li < nlist; li += gridDim.x)
     {
-        int t = t0; // opaque once per estimate: see k_coarse3
+        int t = t0; // opaque once per estimate: what derives from it is 1-2 instructions, but hoisted out of the persistent loop ~100 live registers
         asm volatile("" : "+v"(t));
         const int ch = chan_list ? chan_list[li] : li;
         const double2 *__restrict__ ring = p.bbring + (size_t)ch * N;

@@ -102,6 +102,37 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const F
     double *__restrict__ ebe_ring = p.eb_e + (size_t)grp * g.ebno_len * 64 + lane;
     double *__restrict__ ebe2_ring = p.eb_e2 + (size_t)grp * g.ebno_len * 64 + lane;
 
+    // Coarse ring fill, four entries at a time: a 16-byte store into the per-channel ring is a quarter of a 64-byte sector; issued one per
+    // sample (3.5 us apart) every one of them cost the L2 a sector fill from HBM plus a sector write (measured: 23 GB written and
+    // 15 GB of extra reads per 4096-sample launch for 4.3 GB of ring entries).  The last three entries wait in registers and go out with
+    // the fourth, back to back, as one complete sector; what is left at the end of the launch (at most three) goes out singly.
+    double2 cq1 = make_double2(0.0, 0.0), cq2 = cq1, cq3 = cq1;
+    int cq_n = 0; // entries waiting (they are the ring positions just below bb_ptr)
+    auto ring_fill = [&](const double2 v) __attribute__((always_inline)) {
+        if ((bb_ptr & 3) == 3)
+        {
+            double2 *dst = bbring + bb_ptr;
+            if (cq_n >= 3) dst[-3] = cq3;
+            if (cq_n >= 2) dst[-2] = cq2;
+            if (cq_n >= 1) dst[-1] = cq1;
+            dst[0] = v;
+            cq_n = 0;
+        }
+        else
+        {
+            cq3 = cq2; cq2 = cq1; cq1 = v;
+            cq_n++;
+        }
+        bb_ptr = (bb_ptr + 1) & nfft_mask;
+    };
+    auto ring_flush = [&]() __attribute__((always_inline)) {
+        double2 *dst = bbring + bb_ptr;
+        if (cq_n >= 3) dst[-3] = cq3;
+        if (cq_n >= 2) dst[-2] = cq2;
+        if (cq_n >= 1) dst[-1] = cq1;
+        cq_n = 0;
+    };
+
     double *lre = L.lre, *lim = L.lim, *ltap = L.ltap;
     {
         const double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
@@ -214,11 +245,7 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const F
             if (fir_slot >= LDSN) fir_slot = 0;
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (do_fill)
-        {
-            bbring[bb_ptr] = make_double2(cc.x * dval, cc.y * dval);
-            bb_ptr = (bb_ptr + 1) & nfft_mask;
-        }
+        if (do_fill) ring_fill(make_double2(cc.x * dval, cc.y * dval));
         coarse_cnt++; // :431
         jd_wt_next(mc_ptr, mc_step);
         if (i + 1 < n)
@@ -251,12 +278,9 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const F
     {
         const double dval = ((double)nx_pcm) / 32768.0;
         const bool do_fill = !(nB == 0 && skip_a_first) && ((coarse_cnt >= g.Fs_int) || !(flags & JF_CPUREDUCE));
-        if (do_fill)
-        {
-            bbring[bb_ptr] = make_double2(nx_cc.x * dval, nx_cc.y * dval);
-            bb_ptr = (bb_ptr + 1) & nfft_mask;
-        }
+        if (do_fill) ring_fill(make_double2(nx_cc.x * dval, nx_cc.y * dval));
     }
+    ring_flush();
 
     LDF(S_MC_PTR) = mc_ptr; LDF(S_MC_STEP) = mc_step;
     LDF(S_AGC_SUM) = agc_sum;
@@ -307,10 +331,12 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, const Fb
     const double wtsize_d = (double)JD_WTSIZE, r_wtsize = 1.0 / wtsize_d, r_360 = 1.0 / 360.0;
     const double marg_len_d = (double)g.marg_len, pm_len_d = (double)g.pm_len, msema_len_d = (double)g.msema_len;
     const double r_marg_len = 1.0 / marg_len_d, r_pm_len = 1.0 / pm_len_d, r_msema_len = 1.0 / msema_len_d;
-    double *__restrict__ marg_ring = p.marg + (size_t)ch * g.marg_len;
-    double2 *__restrict__ dt_ring = p.dt + (size_t)ch * g.dt_len;
-    double *__restrict__ pm_ring = p.pm + (size_t)ch * g.pm_len;
-    double *__restrict__ msema_ring = p.msema + (size_t)ch * g.msema_len;
+    // Symbol-rate windows: marg (MovingAverage(800)), dt (DelayThing(400)), pointmean and msema (MovingAverage(400) each) all advance
+    // once per symbol pair from the same start, so ONE ring of 800 records {ct_ec, q_re, q_im, |q|, e} serves the four: the entry
+    // leaving marg's window is in the record about to be overwritten, those leaving the other three in the record written 400 symbols
+    // ago.  A symbol then costs two 64-byte record reads and one full-sector write; as four per-channel arrays of 8-byte entries it
+    // was four sector fills and four partial writes (measured: ~15 GB of reads and ~4 GB of writes per launch for 0.6 GB of entries).
+    double *__restrict__ symrec = p.symrec + (size_t)ch * JD_SYMREC_LEN * 8;
     const double w4 = g.w4, w4c = 1.0 - g.w4, w8 = g.w8, w8c = 1.0 - g.w8;
 
     // the output half of a symbol, queued at the instant: marg->UpdateSigned(ct_ec) .. soft bits (oqpskdemodulator.cpp:534-595).
@@ -325,29 +351,24 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, const Fb
         pend = true; need_px = true; pd_ec = ct_ec; pd_re = q_re; pd_im = q_im;
     };
     auto request_px = [&]() {
-        px_marg = marg_ring[marg_pos];
-        int dn = dt_pos + 1; if (dn >= g.dt_len) dn = 0;
-        px_dt = dt_ring[dn]; // = what dt.update returns: the slot after the one being written (dt_len > 1)
-        px_pm = pm_ring[pm_pos];
-        px_ms = msema_ring[msema_pos];
+        px_marg = symrec[marg_pos * 8]; // written 800 symbols ago
+        int o = marg_pos + JD_SYMREC_LEN / 2; if (o >= JD_SYMREC_LEN) o -= JD_SYMREC_LEN;
+        const double2 *r = (const double2 *)(symrec + o * 8); // written 400 symbols ago: {ct_ec, q_re}, {q_im, |q|}, {e, -}
+        const double2 r0 = r[0], r1 = r[1], r2 = r[2];
+        px_dt = make_double2(r0.y, r1.x); // = what dt.update returns
+        px_pm = r1.y;
+        px_ms = r2.x;
         need_px = false;
     };
     auto output_half = [&]() {
         const double ct_ec = pd_ec;
         double q_re = pd_re, q_im = pd_im;
         // marg->UpdateSigned(ct_ec)
-        {
-            double *mp = marg_ring + marg_pos;
-            marg_sum = marg_sum - px_marg; marg_sum = marg_sum + ct_ec; *mp = ct_ec;
-            marg_pos++; if (marg_pos >= g.marg_len) marg_pos = 0;
-        }
+        marg_sum = marg_sum - px_marg; marg_sum = marg_sum + ct_ec;
         const double marg_val = jd_div_const(marg_sum, marg_len_d, r_marg_len);
         // dt.update(pt_qpsk)
-        {
-            dt_ring[dt_pos] = make_double2(q_re, q_im);
-            dt_pos++; if (dt_pos >= g.dt_len) dt_pos = 0;
-            q_re = px_dt.x; q_im = px_dt.y;
-        }
+        const double in_re = q_re, in_im = q_im;
+        q_re = px_dt.x; q_im = px_dt.y;
         {
             const double cr = cos(marg_val), sr = sin(marg_val);
             const double nr = q_re * cr - q_im * sr;
@@ -355,21 +376,27 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, const Fb
             q_re = nr; q_im = ni;
         }
         // MSEcalc::Update (DSP.cpp:451-463)
+        double av_w, e_w;
         {
             const double av = hypot(q_re, q_im);
-            double *pp = pm_ring + pm_pos;
-            pm_sum = pm_sum - px_pm; pm_sum = pm_sum + fabs(av); *pp = fabs(av);
-            pm_pos++; if (pm_pos >= g.pm_len) pm_pos = 0;
+            pm_sum = pm_sum - px_pm; pm_sum = pm_sum + fabs(av); av_w = fabs(av);
             double mu = jd_div_const(pm_sum, pm_len_d, r_pm_len);
             if (mu < 0.000001) mu = 0.000001;
             const double s2 = sqrt(2.0);
             const double t_re = (s2 * q_re) / mu, t_im = (s2 * q_im) / mu;
             const double tda = (fabs(t_re) - 1.0), tdb = (fabs(t_im) - 1.0);
             const double e = (tda * tda) + (tdb * tdb);
-            double *ep = msema_ring + msema_pos;
-            msema_sum = msema_sum - px_ms; msema_sum = msema_sum + fabs(e); *ep = fabs(e);
-            msema_pos++; if (msema_pos >= g.msema_len) msema_pos = 0;
+            msema_sum = msema_sum - px_ms; msema_sum = msema_sum + fabs(e); e_w = fabs(e);
             mse = jd_div_const(msema_sum, msema_len_d, r_msema_len);
+        }
+        // this symbol's record: one complete 64-byte sector
+        {
+            double2 *w = (double2 *)(symrec + marg_pos * 8);
+            w[0] = make_double2(ct_ec, in_re);
+            w[1] = make_double2(in_im, av_w);
+            w[2] = make_double2(e_w, 0.0);
+            w[3] = make_double2(0.0, 0.0);
+            marg_pos++; if (marg_pos >= JD_SYMREC_LEN) marg_pos = 0;
         }
         if (CAPSYM)
         {

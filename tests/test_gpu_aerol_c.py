@@ -50,9 +50,11 @@ def test_golden_single_channel(D, oracle_mod):
     bank.close()
 
 
-@pytest.mark.parametrize("nch,write", [(5, 3000), (70, 5000)])
-def test_bank_vs_oracle(D, oracle_mod, nch, write):
-    """Channels at different frame phases, inversions and noise levels, ragged writes: every channel equals its own oracle run."""
+@pytest.mark.parametrize("nch,write,layout", [(5, 3000, "wave"), (70, 5000, "wave"), (70, 5000, "lanes")])
+def test_bank_vs_oracle(D, oracle_mod, monkeypatch, nch, write, layout):
+    """Channels at different frame phases, inversions and noise levels, ragged writes: every channel equals its own oracle run.  Both
+    Viterbi layouts (one block per wavefront; one per lane, what banks of 16 384 channels and more use)."""
+    monkeypatch.setenv("JAERO_VITERBI_LAYOUT", layout)
     rng = np.random.default_rng(77 + nch)
     streams = []
     for c in range(nch):

@@ -76,30 +76,6 @@ def test_against_reference_golden(B, name):
     bank.close()
 
 
-@pytest.mark.parametrize("name,env", [("oqpsk_10k5_default", {"JAERO_COARSE_KERNEL": "2"}), ("oqpsk_10k5_default", {"JAERO_COARSE_KERNEL": "3"}),
-                                      ("oqpsk_10k5_default", {"JAERO_COARSE_V1": "1"}), ("msk_1200_default", {"JAERO_COARSE_V1": "1"})])
-def test_alternative_kernels_against_reference_golden(B, monkeypatch, name, env):
-    """The kernels kept for A/B measurements (the earlier coarse-frequency kernels) produce the
-    same stream as the defaults: same golden, selected by the environment variables jaero_create reads."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    g = load_golden(name)
-    opts = g["opts"]
-    pcm = g["pcm"].reshape(1, -1)
-    bank = B.DemodulatorBank(bank_settings(g["kind"], opts), 1, ebno=True, status_log=True, max_write_samples=8192, softbit_capacity=pcm.shape[1])
-    bank.set_flags(afc=bool(opts.get("afc", 0)), cpu_reduce=bool(opts.get("cpureduce", 0)))
-    feed(bank, pcm, opts.get("chunk", 4096), dcd_at=opts.get("dcd_at", -1))
-    soft, log = bank.read_softbits(0), bank.read_status_log(0)
-    n = len(g["soft"])
-    assert n <= len(soft) < n + 32
-    assert np.array_equal(soft[:n] >= 128, g["soft"] >= 128)
-    assert np.max(np.abs(soft[:n].astype(int) - g["soft"].astype(int)), initial=0) <= 1
-    assert log.shape == g["status"].shape
-    assert np.array_equal(log[:, [0, 5]], g["status"][:, [0, 5]])
-    assert np.max(np.abs(log[:, 1:4] - g["status"][:, 1:4])) < 1e-6
-    bank.close()
-
-
 @pytest.mark.parametrize("name", ["oqpsk_8400_default", "oqpsk_8400_afc_chunk1500_dcd"])
 def test_8400_against_reference_golden(B, name):
     """SURVEY 8 row f4, demodulator half: the 8400 bps branch (direct-form prefilter instead of the reference's FFT overlap-add, so
