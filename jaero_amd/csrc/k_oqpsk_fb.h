@@ -52,6 +52,19 @@ __device__ __forceinline__ void fb_wt_setfreq(double &freq, double &step, double
     if (freq < 0) freq = 0;
     step = jd_div_const((freq) * ((double)JD_WTSIZE), samplerate, r_samplerate);
 }
+// WaveTable::WTnextFrame (DSP.cpp:70-77): one step of an oscillator.  ptr < WTSIZE before, step < WTSIZE (a frequency below the sample
+// rate), so the reference's `while ((int)ptr >= WTSIZE) ptr -= WTSIZE` runs at most once; written as a select plus a loop that is
+// never entered it costs a handful of instructions instead of a divergent loop (same result for any ptr, step).
+__device__ __forceinline__ void fb_wt_next(double &ptr, double &step)
+{
+    if (step < 0) step = 0;
+    ptr += step;
+    if (((int)ptr) >= JD_WTSIZE)
+    {
+        ptr -= JD_WTSIZE;
+        while (((int)ptr) >= JD_WTSIZE) ptr -= JD_WTSIZE;
+    }
+}
 // fmod(x, 360.0): exact by definition, so any exact evaluation gives the same bits; |x| < 720 covers every value the carrier loop
 // produces (360 * ptr / 19999 + a clamped error), the general case falls back to the library
 __device__ __forceinline__ double fb_fmod360(double x)
@@ -247,7 +260,7 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const F
         __builtin_amdgcn_sched_barrier(0);
         if (do_fill) ring_fill(make_double2(cc.x * dval, cc.y * dval));
         coarse_cnt++; // :431
-        jd_wt_next(mc_ptr, mc_step);
+        fb_wt_next(mc_ptr, mc_step);
         if (i + 1 < n)
         {
             nx_pcm = live ? pcm[(size_t)(i + 1) * pcm_stride + ch] : (short)0;
@@ -479,8 +492,8 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, const Fb
             if (!yui) { ptd_re = pt_re; ptd_im = pt_im; }
             else
             {
-                const double ct_xt = tanh(pt_im) * pt_re;
-                const double ct_xt_d = tanh(ptd_re) * ptd_im;
+                const double ct_xt = jd_tanh(pt_im) * pt_re;
+                const double ct_xt_d = jd_tanh(ptd_re) * ptd_im;
                 double ct_ec = ct_xt_d - ct_xt;
                 if (ct_ec > M_PI) ct_ec = M_PI;
                 if (ct_ec < -M_PI) ct_ec = -M_PI;
@@ -508,12 +521,16 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, const Fb
         sig2l_re = sre; sig2l_im = sim;
 
         // ---- advance the NCOs (:600-603) and hand the next sample's carrier table index to the front half ----
-        jd_wt_next(m2_ptr, m2_step);
+        fb_wt_next(m2_ptr, m2_step);
         L.idx[((i + 1) & 1) * 64 + lane] = jd_cisidx(m2_ptr);
         if (st_step < 0) st_step = 0;
         st_last = st_ptr;
         st_ptr += st_step;
-        while (((int)st_ptr) >= JD_WTSIZE) st_ptr -= JD_WTSIZE;
+        if (((int)st_ptr) >= JD_WTSIZE)
+        {
+            st_ptr -= JD_WTSIZE;
+            while (((int)st_ptr) >= JD_WTSIZE) st_ptr -= JD_WTSIZE;
+        }
         nx_cst = cis[jd_cisidx(st_ptr)]; // the symbol NCO's table value for the next sample: in flight across the barrier
         fb_barrier();
     }
