@@ -239,6 +239,9 @@ int jaero_debug_schedule(int fft_power, int Fs, int cpu_reduce, const int *write
  * RRC(alpha, 2049 taps, 48 kHz, fsym symbols/s) with JFastFir's latency for nfft = 4096 (out[m] = sum_k h[k] x[m - 2048 - k]):
  * JFastFir::SetKernel + update as JAERO/oqpskdemodulator.cpp:278-283,366-368 use it and JAERO/tests/jfastfir_tests.cpp:31-58 pins it. */
 int jaero_debug_prefilter(int device, const double *in_reim, int n, double alpha, double fsym, double *out_reim);
+/* Test hook: the first n prefiltered complex samples (re, im pairs) of the last jaero_write of an 8400 bps bank, channel ch
+ * (cval_prefiltered, JAERO/oqpskdemodulator.cpp:343-381). */
+int jaero_debug_read_prefiltered(jaero_ctx *ctx, int channel, double *out_reim, int n);
 
 /* introspection */
 int jaero_abi_version(void);

@@ -143,7 +143,7 @@ struct jaero_ctx
     int oq_ldsn = OQ_LDSN;
     JTaps28 oq_taps{}; // the 28 distinct values of the (bitwise symmetric) 55-tap RRC, scalar operands of k_oqpsk_fb's filter
     // fb == 8400 (k_pre8400.h): prefilter buffers, samples written so far, size of the previous write
-    bool pre8400 = false;
+    bool pre8400 = false, pre_direct = false;
     JPre pre{};
     long long pre_n0 = 0;
     int pre_nprev = 0;
@@ -454,6 +454,34 @@ extern "C" void jaero_destroy(jaero_ctx *c)
     delete c;
 }
 
+// Tables of k_pre8400_fft: H = DFT_4096(taps, zero-padded) / 4096 and exp(-2 pi i k / 4096), summed in long double on the host.
+static int pre8400_tables(const std::vector<double> &taps, double2 **d_H, double2 **d_tw)
+{
+    const int N = 2 * PRE_L;
+    std::vector<long double> cr(N), ci(N);
+    for (int k = 0; k < N; k++) { const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)N; cr[k] = cosl(a); ci[k] = sinl(a); }
+    std::vector<double2> H(N), tw(N);
+    for (int k = 0; k < N; k++)
+    {
+        long double sr = 0, si = 0;
+        for (int j = 0; j < PRE_K; j++) { const int e = (int)(((long long)k * j) & (N - 1)); sr += (long double)taps[j] * cr[e]; si += (long double)taps[j] * ci[e]; }
+        H[k].x = (double)(sr / N); H[k].y = (double)(si / N);
+        tw[k].x = (double)cr[k]; tw[k].y = (double)ci[k];
+    }
+    HIPCHK(hipMalloc((void **)d_H, sizeof(double2) * N));
+    HIPCHK(hipMalloc((void **)d_tw, sizeof(double2) * N));
+    HIPCHK(hipMemcpy(*d_H, H.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(*d_tw, tw.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
+    HIPCHK(hipFuncSetAttribute((const void *)k_pre8400_fft, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * PRE_L * (int)sizeof(double)));
+    return 0;
+}
+
+static void launch_pre8400_filter(const JGeom &g, const JPtrs &p, const JPre &q, int n, long long n0, bool direct, hipStream_t st)
+{
+    if (direct) hipLaunchKernelGGL(k_pre8400_fir, dim3(g.ngroups, (n + 4 * PRE_R - 1) / (4 * PRE_R)), dim3(256), 0, st, g, p, q, n, n0);
+    else hipLaunchKernelGGL(k_pre8400_fft, dim3(g.nchp / 4, (int)(((n0 + n - 1) >> 11) - (n0 >> 11) + 1)), dim3(PF_THREADS), 4 * 2 * PRE_L * (int)sizeof(double), st, g, p, q, n, n0);
+}
+
 extern "C" int jaero_create(int device, int nchannels, const jaero_settings *settings, int per_channel_stride, unsigned flags,
                             int max_write_samples, int softbit_capacity, jaero_ctx **out)
 {
@@ -521,7 +549,8 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
     {
         c->pre8400 = true;
         int ring = 1;
-        while (ring < max_write_samples + 2 * PRE_L) ring <<= 1;
+        // a write's first transform block starts up to 2047 samples before the write and looks 4096 samples further back
+        while (ring < max_write_samples + 3 * PRE_L) ring <<= 1;
         c->pre.ring = ring;
         DA(c->pre.xring, (size_t)ring * nchp);
         DA(c->pre.cidx, (size_t)max_write_samples * nchp);
@@ -532,6 +561,14 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         if ((int)pt.size() != PRE_K) { jaero_destroy(c); return fail(JAERO_EHIP, "prefilter design returned %zu taps", pt.size()); }
         HIPCHK(hipMemcpy(d_pre_taps, pt.data(), sizeof(double) * PRE_K, hipMemcpyHostToDevice));
         c->pre.taps = d_pre_taps;
+        {
+            double2 *dH = nullptr, *dtw = nullptr;
+            if ((rc = pre8400_tables(pt, &dH, &dtw))) { jaero_destroy(c); return rc; }
+            c->pre.H = dH; c->pre.tw = dtw;
+            c->allocs.push_back(dH); c->allocs.push_back(dtw);
+            const char *e = getenv("JAERO_PRE8400"); // "direct": the time-domain form (k_pre8400_fir), kept for A/B measurements
+            c->pre_direct = e && !strcmp(e, "direct");
+        }
         HIPCHK(hipFuncSetAttribute((const void *)k_coarse4_w8400, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 257 * (int)sizeof(double)));
     }
     if (g.kind == JAERO_KIND_MSK) { DA(c->p.dly, (size_t)ng * (g.sps + 1) * 64); DA(c->p.dly8, (size_t)ng * (g.sps2 + 1) * 64); }
@@ -953,7 +990,7 @@ extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int l
         // the whole write is prefiltered first (oqpskdemodulator.cpp:343-381); its oscillator takes the mean of mixer2's frequency over
         // the previous write (:607-608)
         hipLaunchKernelGGL(k_pre8400_mix, dim3(g.ngroups), dim3(64), 0, st, g, c->p, c->pre, frames, stride, nsamples, c->pre_n0, c->pre_nprev);
-        hipLaunchKernelGGL(k_pre8400_fir, dim3(g.ngroups, (nsamples + 4 * PRE_R - 1) / (4 * PRE_R)), dim3(256), 0, st, g, c->p, c->pre, nsamples, c->pre_n0);
+        launch_pre8400_filter(g, c->p, c->pre, nsamples, c->pre_n0, c->pre_direct, st);
         c->pre_n0 += nsamples;
         c->pre_nprev = nsamples;
     }
@@ -1035,7 +1072,7 @@ extern "C" int jaero_debug_prefilter(int device, const double *in_reim, int n, d
     JPtrs p{};
     JPre q{};
     int ring = 1;
-    while (ring < n + 2 * PRE_L + 64) ring <<= 1;
+    while (ring < n + 3 * PRE_L + 64) ring <<= 1;
     q.ring = ring;
     double2 *d_cis = nullptr; double *d_taps = nullptr;
     HIPCHK(hipMalloc((void **)&q.xring, sizeof(double2) * (size_t)ring * 64));
@@ -1050,10 +1087,28 @@ extern "C" int jaero_debug_prefilter(int device, const double *in_reim, int n, d
     HIPCHK(hipMemcpy(d_taps, taps.data(), sizeof(double) * PRE_K, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy2D(q.xring, sizeof(double2) * 64, in_reim, sizeof(double2), sizeof(double2), (size_t)n, hipMemcpyHostToDevice)); // channel 0 of every slot
     p.cis = d_cis; q.taps = d_taps;
-    hipLaunchKernelGGL(k_pre8400_fir, dim3(1, (n + 4 * PRE_R - 1) / (4 * PRE_R)), dim3(256), 0, 0, g, p, q, n, 0LL);
-    HIPCHK(hipGetLastError());
+    {
+        const char *e = getenv("JAERO_PRE8400");
+        double2 *dH = nullptr, *dtw = nullptr;
+        int rc = pre8400_tables(taps, &dH, &dtw);
+        if (rc) return rc;
+        q.H = dH; q.tw = dtw;
+        launch_pre8400_filter(g, p, q, n, 0LL, e && !strcmp(e, "direct"), 0);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipDeviceSynchronize());
+        hipFree(dH); hipFree(dtw);
+    }
     HIPCHK(hipMemcpy2D(out_reim, sizeof(double2), q.out, sizeof(double2) * 64, sizeof(double2), (size_t)n, hipMemcpyDeviceToHost));
     hipFree(q.xring); hipFree(q.cidx); hipFree(q.out); hipFree(d_cis); hipFree(d_taps);
+    return 0;
+}
+
+// Test hook: the prefiltered samples of the last write of an 8400 bps bank (cval_prefiltered, oqpskdemodulator.cpp:343-381), channel ch.
+extern "C" int jaero_debug_read_prefiltered(jaero_ctx *c, int ch, double *out_reim, int n)
+{
+    if (!c || !out_reim || !c->pre8400 || ch < 0 || ch >= c->g.nch || n <= 0 || n > c->pre_nprev) return fail(JAERO_EINVAL, "jaero_debug_read_prefiltered: bad arguments");
+    HIPCHK(hipStreamSynchronize(c->last_stream));
+    HIPCHK(hipMemcpy2D(out_reim, sizeof(double2), c->pre.out + ch, sizeof(double2) * c->g.nchp, sizeof(double2), (size_t)n, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -16,6 +16,7 @@
 //                  of the north star applies, as for the Hilbert filter of the burst path
 #pragma once
 #include "jaero_device.h"
+#include "k_coarse2.h" // CV<>, regfft<16>, c4_twiddle16, c4_lds_barrier
 
 #define PRE_K 2049                 // taps
 #define PRE_L 2048                 // JFastFir latency nfft - K + 1
@@ -28,7 +29,9 @@ struct JPre
     unsigned short *cidx;  // [max_write][nchp] table index of the up-mix oscillator for every sample of the current write
     double2 *out;          // [max_write][nchp] prefiltered samples of the current write (cval_prefiltered)
     const double *taps;    // [PRE_K]
-    int ring;              // power of two >= max_write + 2 * PRE_L
+    int ring;              // power of two >= max_write + 3 * PRE_L
+    const double2 *H;      // [4096] DFT of the taps (zero-padded to 4096) / 4096, natural order        (k_pre8400_fft)
+    const double2 *tw;     // [4096] exp(-2 pi i k / 4096)                                               (k_pre8400_fft)
 };
 
 // fields of JPtrs::S used by the prefilter (appended to the state enum in jaero_device.h): S_PRE_PTR, S_PRE_STEP, S_PRE_FSUM
@@ -125,6 +128,119 @@ __global__ __launch_bounds__(256) void k_pre8400_fir(const JGeom g, const JPtrs 
             const double2 cj = p.cis[q.cidx[(size_t)(i0 + r) * nchp + ch]];
             const double bre = cj.x, bim = -cj.y;
             q.out[(size_t)(i0 + r) * nchp + ch] = make_double2(yr * bre - yi * bim, yr * bim + yi * bre);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_pre8400_fft: the same filter as k_pre8400_fir by overlap-save, i.e. the way the reference's JFastFir computes it (nfft 4096, 2049
+// taps, 2048 fresh outputs per transform pair) -- 4 x 4096-point transforms per channel and 4096-sample write instead of 2049 multiply-
+// adds per output (k_pre8400_fir: 127 ms per 65 536-channel step, four times the rest of the path).
+//
+//   grid (nchp / 4, 2048-sample blocks the write touches), 1024 threads = 4 channels x 256 threads, 128 KiB LDS.  Thread (c = tid & 3, T = tid >> 2): the
+//   four lanes c of a T touch the four channels' 16-byte entries of one ring slot / output row = one complete 64-byte sector.
+//   Block b: window x[m0 - 4096 .. m0 - 1], m0 = 2048 (floor(n0 / 2048) + b); its circular convolution with h is the linear one at window indices
+//   2048 .. 4095, which are out[m0 .. m0 + 2047] (latency 2048 = nfft - K + 1 as in JFastFir).
+//   4096 = 16 x 16 x 16, 16 points per thread, thread T holds index T + 256 s in slot s on entry AND on exit of a transform:
+//     pass 1  n = 256 n1 + n2 (n2 = T): 16-point DFT over n1 -> k1, times W_4096^(n2 k1)
+//     exch 1  L = k1 * 256 + 16 m1 + m2          writer T = 16 m1 + m2 slot k1 -> reader T = 16 k1 + m2 slot m1
+//     pass 2  16-point DFT over m1 -> q1, times W_256^(m2 q1)
+//     exch 2  L = (q1 * 16 + m2) * 16 + (k1 ^ m2) writer T = 16 k1 + m2 slot q1 -> reader T = k1 + 16 q1 slot m2
+//     pass 3  16-point DFT over m2 -> q2: X[k1 + 16 q1 + 256 q2] = X[T + 256 s]
+//   LDS address = 4 L + c: a wavefront (16 T x 4 c) touches 64 consecutive doubles in every access but the writes of exchange 2, where
+//   the swizzle k1 ^ m2 spreads each half wavefront over all banks.  Planes (re, im) go through the buffer one after the other.
+//   The inverse transform is the forward one on the conjugate (1 / 4096 is folded into H).
+//   Not bit-identical to the reference's FFT (JFFT is not vendored; other butterfly order): differences ~1e-16 of the signal peak, as
+//   with the direct form; the soft-symbol tolerance applies.
+#define PF_THREADS 1024
+
+__device__ __forceinline__ void pf_exchange1(double (&v)[16], double *xch, int T, int c)
+{
+    const int wb = T * 4 + c, rb = ((T >> 4) * 256 + (T & 15)) * 4 + c;
+#pragma unroll
+    for (int s = 0; s < 16; s++) xch[wb + s * 1024] = v[s];
+    c4_lds_barrier();
+#pragma unroll
+    for (int s = 0; s < 16; s++) v[s] = xch[rb + s * 64];
+    c4_lds_barrier();
+}
+
+__device__ __forceinline__ void pf_exchange2(double (&v)[16], double *xch, int T, int c)
+{
+    const int hi = T >> 4, lo = T & 15;
+    // writer: k1 = hi, m2 = lo, slot q1; reader: q1 = hi, k1 = lo, slot m2
+    const int wb = (lo * 16 + (hi ^ lo)) * 4 + c;
+#pragma unroll
+    for (int s = 0; s < 16; s++) xch[wb + s * 1024] = v[s];
+    c4_lds_barrier();
+#pragma unroll
+    for (int s = 0; s < 16; s++) v[s] = xch[((hi * 16 + s) * 16 + (lo ^ s)) * 4 + c];
+    c4_lds_barrier();
+}
+
+__device__ __forceinline__ void pf_fft4096(CV<16> &d, double *xch, const double2 *__restrict__ tw, int T, int c)
+{
+#pragma clang fp contract(fast)
+    const double2 st1 = tw[T], st2 = tw[16 * (T & 15)];
+    CV<16> o;
+    regfft<16>(d, o);
+    c4_twiddle16(o, st1);
+    pf_exchange1(o.r, xch, T, c);
+    pf_exchange1(o.i, xch, T, c);
+    regfft<16>(o, d);
+    c4_twiddle16(d, st2);
+    pf_exchange2(d.r, xch, T, c);
+    pf_exchange2(d.i, xch, T, c);
+    regfft<16>(d, o);
+#pragma unroll
+    for (int s = 0; s < 16; s++) { d.r[s] = o.r[s]; d.i[s] = o.i[s]; }
+}
+
+__global__ __launch_bounds__(PF_THREADS) void k_pre8400_fft(const JGeom g, const JPtrs p, const JPre q, int n, long long n0)
+{
+    extern __shared__ double pf_xch[]; // 4 channels x 4096 doubles
+    const int tid = threadIdx.x, c = tid & 3, T = tid >> 2;
+    const int nchp = g.nchp, ch = blockIdx.x * 4 + c;
+    // transform blocks sit at absolute multiples of 2048 samples, as JFastFir's do whatever the write sizes are: an output is an exact
+    // zero here exactly where it is one there (both of the 2048-sample input blocks behind it all zero -- the first 2048 outputs of a
+    // stream, digital silence); round-off in place of those zeros is what the AGC behind the filter would amplify to full scale
+    const long long m0 = ((n0 >> 11) + blockIdx.y) << 11;
+    const int i0 = (int)(m0 - n0); // may be negative: the part of the block that belonged to the previous write is not stored
+    const int rmask = q.ring - 1;
+    CV<16> d;
+    {
+        const double2 *__restrict__ xr = q.xring + ch;
+        const long long b = m0 - 2 * PRE_L + T;
+#pragma unroll
+        for (int s = 0; s < 16; s++)
+        {
+            const double2 v = xr[(size_t)((int)((b + 256 * s) & rmask)) * nchp];
+            d.r[s] = v.x; d.i[s] = v.y;
+        }
+    }
+    pf_fft4096(d, pf_xch, q.tw, T, c);
+    {
+        const double2 *__restrict__ H = q.H + T;
+#pragma unroll
+        for (int s = 0; s < 16; s++)
+        {
+            const double2 h = H[256 * s];
+            const double yr = d.r[s] * h.x - d.i[s] * h.y, yi = d.r[s] * h.y + d.i[s] * h.x;
+            d.r[s] = yr; d.i[s] = -yi;
+        }
+    }
+    pf_fft4096(d, pf_xch, q.tw, T, c);
+#pragma unroll
+    for (int s = 8; s < 16; s++)
+    {
+        const int i = i0 + T + 256 * (s - 8);
+        if (i >= 0 && i < n)
+        {
+            const double yr = d.r[s], yi = -d.i[s];
+            // cval_prefiltered[i] *= mixer_fir_pre.WTCISValue_conj()
+            const double2 cj = p.cis[q.cidx[(size_t)i * nchp + ch]];
+            const double bre = cj.x, bim = -cj.y;
+            q.out[(size_t)i * nchp + ch] = make_double2(yr * bre - yi * bim, yr * bim + yi * bre);
         }
     }
 }

@@ -45,7 +45,8 @@ def compare(got_soft, got_sym, got_log, ref, check_ebno=True):
     assert np.max(np.abs(got_soft[:n].astype(int) - ref["soft"].astype(int)), initial=0) <= 1
     if "symbols" in ref:
         assert got_sym.shape == ref["symbols"].shape
-        assert np.max(np.abs(got_sym - ref["symbols"]), initial=0.0) < SYM_TOL
+        d = np.abs(got_sym - ref["symbols"])
+        assert np.max(d, initial=0.0) < SYM_TOL, f"symbol {np.unravel_index(d.argmax(), d.shape)}: {got_sym[d.argmax() // d.shape[1]]} vs {ref['symbols'][d.argmax() // d.shape[1]]}"
     assert got_log.shape == ref["status"].shape
     if len(got_log):
         assert np.array_equal(got_log[:, [0, 5]], ref["status"][:, [0, 5]])
@@ -78,8 +79,8 @@ def test_against_reference_golden(B, name):
 
 @pytest.mark.parametrize("name", ["oqpsk_8400_default", "oqpsk_8400_afc_chunk1500_dcd"])
 def test_8400_against_reference_golden(B, name):
-    """SURVEY 8 row f4, demodulator half: the 8400 bps branch (direct-form prefilter instead of the reference's FFT overlap-add, so
-    soft bytes may differ by one at rounding edges; hard decisions, estimate count and frequencies must agree)."""
+    """SURVEY 8 row f4, demodulator half: the 8400 bps branch (the prefilter is an overlap-save FFT filter as in the reference, but not
+    the reference's FFT, so soft bytes may differ by one at rounding edges; hard decisions, estimate count and frequencies must agree)."""
     g = load_golden(name)
     opts = g["opts"]
     pcm = g["pcm"].reshape(1, -1)
@@ -121,7 +122,7 @@ def test_bank_vs_oracle(B, oracle_mod, kind, nch, nsamp, chunk):
 @pytest.mark.parametrize("nch,nsamp,chunk", [(5, 110000, 4096), (67, 60000, 3000)])
 def test_8400_bank_vs_oracle(B, oracle_mod, nch, nsamp, chunk):
     """Several 8400 bps channels with different carriers in one bank: every channel against its own oracle run (symbols within the
-    north star's 1e-5; the prefilter is a direct-form sum here and an FFT overlap-add there)."""
+    north star's 1e-5; the prefilter's transforms are not the reference's FFT)."""
     from jaero_amd import signalgen as G
 
     O = oracle_mod
@@ -135,6 +136,51 @@ def test_8400_bank_vs_oracle(B, oracle_mod, nch, nsamp, chunk):
         ref = O.run_demod(oracle_settings(O, "oqpsk", opts), pcm[c], chunk=chunk, capture_symbols=True)
         compare(bank.read_softbits(c), bank.read_symbols(c), bank.read_status_log(c), ref)
     bank.close()
+
+
+@pytest.mark.parametrize("chunk", [1024, 1500, 2047, [700, 3100, 4096, 50, 2048]])
+def test_8400_small_writes_and_digital_silence(B, oracle_mod, chunk):
+    """The 8400 bps prefilter is an overlap-save FFT filter (k_pre8400_fft) whose transform blocks sit where JFastFir's do -- at absolute
+    multiples of 2048 samples -- whatever the write sizes, so that its outputs are exact zeros exactly where the reference's are (the
+    first 2048 samples of a stream, digital silence): round-off in their place is amplified to full scale by the AGC behind the filter
+    and the loops then settle elsewhere.  Writes shorter than a block, and 15 000 samples of exact zeros in the middle."""
+    from jaero_amd import signalgen as G
+
+    O = oracle_mod
+    pcm, _ = G.oqpsk(90000, fb=8400.0, fc=7985.0, ebno_db=10.0, seed=G.SEED_BASE + 8411)
+    pcm = pcm.copy()
+    pcm[40000:55000] = 0
+    opts = {"fb": 8400.0, "lockingbw": 8400.0}
+    bank = B.DemodulatorBank([bank_settings("oqpsk", opts)], ebno=True, status_log=True, capture_symbols=True, max_write_samples=4096,
+                             softbit_capacity=len(pcm))
+    sizes = chunk if isinstance(chunk, list) else [chunk]
+    s = k = 0
+    while s < len(pcm):
+        m = min(sizes[k % len(sizes)], len(pcm) - s)
+        bank.write(pcm[None, s:s + m])
+        s += m
+        k += 1
+    ref = O.run_demod(oracle_settings(O, "oqpsk", opts), pcm, chunk=(chunk if not isinstance(chunk, list) else [sizes[i % len(sizes)] for i in range(200)]),
+                      capture_symbols=True)
+    soft, sym, log = bank.read_softbits(0), bank.read_symbols(0), bank.read_status_log(0)
+    bank.close()
+    # hard decisions and soft bytes: the whole stream
+    n = len(ref["soft"])
+    assert len(soft) == n + ref["pending"]
+    assert np.array_equal(soft[:n] >= 128, ref["soft"] >= 128), "hard decisions differ"
+    assert np.max(np.abs(soft[:n].astype(int) - ref["soft"].astype(int)), initial=0) <= 1
+    assert sym.shape == ref["symbols"].shape and log.shape == ref["status"].shape
+    assert np.array_equal(log[:, [0, 5]], ref["status"][:, [0, 5]])
+    # soft symbols and status: the north star's 1e-5 up to the end of the silence (symbol 4812 = sample 55 000).  Behind it the loops
+    # re-acquire with the AGC's window full of zeros, and that amplifies the ~1e-13 the device libm differs from glibc by: measured
+    # 1e-3 on single symbols for ~300 of the next 3000 (scripts/diag/pre8400_silence.py; the same with the direct-form prefilter, and
+    # 3e-8 over the whole stream without the silence)
+    d = np.abs(sym - ref["symbols"]).max(axis=1)
+    assert np.max(d[:4700]) < SYM_TOL, f"symbol {d[:4700].argmax()}"
+    assert np.max(d) < 5e-3, f"symbol {d.argmax()}"
+    dl = np.abs(log[:, 1:4] - ref["status"][:, 1:4]).max(axis=1)
+    k = int(np.searchsorted(log[:, 0], 55000 // 4096))
+    assert np.max(dl[:k], initial=0.0) < 1e-6 and np.max(dl) < 1e-4
 
 
 def test_chunking_and_layout_invariance(B):

@@ -1,8 +1,9 @@
 """The third of the reference's golden-vector tests for the JFFT stand-in: JAERO/tests/jfastfir_tests.cpp:31-58 feeds a
 recorded input through JFastFir with the kernel RRC(0.6, 2049 taps, 48 kHz, 5250 sym/s), nfft 4096, and requires the output recorded
 from JAERO v1.0.4.11 from sample 4096 on, at 1e-5.  Same vectors (tests/golden/jfastfir.npz, made by make_golden.py jfastfir), same
-bar, for: the unmodified JFastFir over the stand-in (oracle/_ref), the oracle's restatement, and the GPU's direct-form prefilter kernel
-k_pre8400_fir (the 8400 bps C-channel path, which uses exactly this filter at alpha 0.6)."""
+bar, for: the unmodified JFastFir over the stand-in (oracle/_ref), the oracle's restatement, and the GPU's prefilter kernels -- the
+overlap-save FFT form k_pre8400_fft the 8400 bps C-channel path runs (exactly this filter at alpha 0.6) and the direct form
+k_pre8400_fir kept beside it."""
 import numpy as np
 import pytest
 
@@ -32,9 +33,11 @@ def test_unmodified_jfastfir_over_the_shim(oracle_mod):
 
 
 @pytest.mark.gpu
-def test_gpu_prefilter_kernel():
+@pytest.mark.parametrize("form", ["fft", "direct"])
+def test_gpu_prefilter_kernel(form, monkeypatch):
     from jaero_amd import capi
 
+    monkeypatch.setenv("JAERO_PRE8400", form)
     g = load_golden("jfastfir")
     x = np.ascontiguousarray(g["input"], dtype=np.complex128)
     out = np.empty_like(x)
