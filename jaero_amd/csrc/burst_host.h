@@ -256,6 +256,7 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
             hipLaunchKernelGGL(k_hist_push_frames, dim3((nchp + 255) / 256, nsamples), dim3(256), 0, st, dsrc, nch, nch, p.pcmhist, nchp, g.hist_len, slot0, nsamples);
         else
             hipLaunchKernelGGL(k_hist_push_chmajor, dim3(nchp / 64, (nsamples + 63) / 64), dim3(256), 0, st, dsrc, nch, nsamples, p.pcmhist, nchp, g.hist_len, slot0);
+        LAUNCHCHK("the burst history push");
         prof_end(c, pi, st);
     }
     const bool cs = (c->flags & JAERO_FLAG_CAPTURE_SYMBOLS) != 0;
@@ -279,12 +280,15 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
             default: hipLaunchKernelGGL(k_hilbert<3>, hgrid, dim3(256), 0, st, g, p, n, n0); break;
             }
         }
+        LAUNCHCHK("k_hilbert");
         prof_end(c, pi, st);
         pi = prof_begin(c, 4, st);
         hipLaunchKernelGGL(k_burst_front, dim3(g.ngroups), dim3(64), 0, st, g, p, n, n0);
+        LAUNCHCHK("k_burst_front");
         prof_end(c, pi, st);
         pi = prof_begin(c, 1, st);
         hipLaunchKernelGGL(k_trident, dim3(c->tri_grid), dim3(C2_THREADS), c->tri_lds, st, g, p, c->d_tri_scratch, n0);
+        LAUNCHCHK("k_trident");
         prof_end(c, pi, st);
         pi = prof_begin(c, 0, st);
         if (g.kind == JAERO_KIND_BURST_OQPSK)
@@ -297,6 +301,7 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
             if (cs) hipLaunchKernelGGL((k_burst_msk_demod<true>), dim3(g.ngroups), dim3(64), lds, st, g, p, n, n0, first);
             else hipLaunchKernelGGL((k_burst_msk_demod<false>), dim3(g.ngroups), dim3(64), lds, st, g, p, n, n0, first);
         }
+        LAUNCHCHK("the burst demodulator");
         prof_end(c, pi, st);
         first = 0;
         c->nsamples_total += n;

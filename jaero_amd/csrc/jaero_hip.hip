@@ -49,6 +49,14 @@ static int fail(int code, const char *fmt, ...)
         if (_e != hipSuccess) return fail(JAERO_EHIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
+// right behind a kernel launch inside jaero_write: a launch that was refused (bad configuration, missing LDS attribute) is reported by
+// name at the launch that failed, not as a stale error at the end of the call
+#define LAUNCHCHK(what)                                                                                  \
+    do {                                                                                                 \
+        hipError_t _e = hipGetLastError();                                                               \
+        if (_e != hipSuccess) return fail(JAERO_EHIP, "launch of %s failed: %s (%s:%d)", what, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
 #define OQ_LDSN 39 // matched-filter history slots kept in LDS (rest in VGPRs) + the taps: 39.5 KiB per wavefront -> 4 wavefronts per CU
 #define MSK_LDSN_1200 39 // of 80 taps: four wavefronts per CU (rings + the wavefront's copy of the taps: 39.6 KiB)
 #define MSK_LDSN_600 78  // of 160 taps: two wavefronts per CU (79.3 KiB)
@@ -981,6 +989,7 @@ extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int l
     {
         const int pi = prof_begin(c, 2, st);
         hipLaunchKernelGGL(k_transpose_pcm, dim3(nchp / 64, (nsamples + 63) / 64), dim3(256), 0, st, dsrc, c->d_pcm_frames, nch, nchp, nsamples);
+        LAUNCHCHK("k_transpose_pcm");
         prof_end(c, pi, st);
         frames = c->d_pcm_frames; stride = nchp;
     }
@@ -990,7 +999,9 @@ extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int l
         // the whole write is prefiltered first (oqpskdemodulator.cpp:343-381); its oscillator takes the mean of mixer2's frequency over
         // the previous write (:607-608)
         hipLaunchKernelGGL(k_pre8400_mix, dim3(g.ngroups), dim3(64), 0, st, g, c->p, c->pre, frames, stride, nsamples, c->pre_n0, c->pre_nprev);
+        LAUNCHCHK("k_pre8400_mix");
         launch_pre8400_filter(g, c->p, c->pre, nsamples, c->pre_n0, c->pre_direct, st);
+        LAUNCHCHK("the 8400 bps prefilter");
         c->pre_n0 += nsamples;
         c->pre_nprev = nsamples;
     }
@@ -1006,6 +1017,7 @@ extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int l
             c->m.nB_total = nb_before; // ring slots are those at the START of the segment
             const int pi = prof_begin(c, 0, st);
             launch_samples(c, frames + (size_t)pos * stride, stride, n, skip_a, only_a, st, pos);
+            LAUNCHCHK("the sample loop");
             prof_end(c, pi, st);
             c->m.nB_total = nb_after;
         }
@@ -1020,6 +1032,7 @@ extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int l
             }
             const int pi = prof_begin(c, 1, st);
             launch_coarse(c, dl, nlist, st);
+            LAUNCHCHK("the coarse-frequency estimate");
             prof_end(c, pi, st);
         }
         pos = next;
