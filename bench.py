@@ -930,26 +930,29 @@ def main():
         # the two edge operations of the path (north_star: "RCCL over xGMI used only to fan out shared IQ and gather decoded bits"),
         # once, untimed for the metric: rank 0 scatters one step of frames for ALL ranks' channels, rank 0 gathers every channel's
         # soft bits of the run
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        frames = None
-        if rank == 0:
-            frames = pcm[:chunk].repeat(1, world) if world * nch * chunk * 2 < (8 << 30) else pcm[:chunk // 8].repeat(1, world)
-        ns = chunk if world * nch * chunk * 2 < (8 << 30) else chunk // 8
-        torch.cuda.synchronize(); dist.barrier()
-        ev[0].record()
-        mine = jd.fan_out_pcm(frames, nch * world, ns, src=0, device=dev)
-        ev[1].record()
-        cap = 256
-        sp, cp, scap = bank.softbits_view()
-        soft_t = torch.zeros((nch, cap), dtype=torch.int16, device=dev)
-        cnt_t = torch.full((nch,), cap, dtype=torch.int32, device=dev)
-        ev[2].record()
-        sa, ca = jd.gather_softbits(soft_t, cnt_t, nch * world, dst=0)
-        ev[3].record()
-        torch.cuda.synchronize()
-        edge = {"fan_out_pcm_ms": round(ev[0].elapsed_time(ev[1]), 3), "fan_out_bytes": int(ns * nch * (world - 1) * 2),
-                "gather_softbits_ms": round(ev[2].elapsed_time(ev[3]), 3), "gather_bytes": int(nch * (world - 1) * (cap * 2 + 4)),
-                "backend": "nccl (RCCL), point-to-point send/recv", "shape_ok": bool(mine.shape == (ns, nch))}
+        try:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            frames = None
+            if rank == 0:
+                frames = pcm[:chunk].repeat(1, world) if world * nch * chunk * 2 < (8 << 30) else pcm[:chunk // 8].repeat(1, world)
+            ns = chunk if world * nch * chunk * 2 < (8 << 30) else chunk // 8
+            torch.cuda.synchronize(); dist.barrier()
+            ev[0].record()
+            mine = jd.fan_out_pcm(frames, nch * world, ns, src=0, device=dev)
+            ev[1].record()
+            cap = 256
+            sp, cp, scap = bank.softbits_view()
+            soft_t = torch.zeros((nch, cap), dtype=torch.int16, device=dev)
+            cnt_t = torch.full((nch,), cap, dtype=torch.int32, device=dev)
+            ev[2].record()
+            sa, ca = jd.gather_softbits(soft_t, cnt_t, nch * world, dst=0)
+            ev[3].record()
+            torch.cuda.synchronize()
+            edge = {"fan_out_pcm_ms": round(ev[0].elapsed_time(ev[1]), 3), "fan_out_bytes": int(ns * nch * (world - 1) * 2),
+                    "gather_softbits_ms": round(ev[2].elapsed_time(ev[3]), 3), "gather_bytes": int(nch * (world - 1) * (cap * 2 + 4)),
+                    "backend": "nccl (RCCL), point-to-point send/recv", "shape_ok": bool(mine.shape == (ns, nch))}
+        except Exception as e:  # an edge operation that fails must not take the measured line with it
+            edge = {"error": f"{type(e).__name__}: {e}"[:300]}
         dist.barrier()
     bank.close()
     del pcm

@@ -1,7 +1,10 @@
 // adaptor_demo -- TEST DRIVER.  Wires a demodulator to the UNMODIFIED AeroL exactly as MainWindow does
 // (JAERO/mainwindow.cpp:198-202,234-237) and writes what AeroL prints to its console device:
 //
-//   adaptor_demo ref|hip oqpsk|msk <in.s16> <out.txt> [fb=10500] [lockingbw=..] [freq_center=..] [chunk=4096]
+//   adaptor_demo ref|hip oqpsk|msk <in.s16> <out.txt> [fb=10500] [lockingbw=..] [freq_center=..] [chunk=4096] [prefb=..]
+//
+// prefb: setSettings is first called with that bit rate, 20 000 samples of the input are written, then setSettings with the real one
+// (a user changing the rate in the settings dialog): the rest must decode as if nothing had happened before.
 //
 // "ref" = the reference's own OqpskDemodulator / MskDemodulator; "hip" = HipOqpskDemodulator / HipMskDemodulator
 // (integration/qt/hipdemodulator.h over libjaero_hip.so).  tests/test_qt_adaptor.py requires the two outputs to be equal.
@@ -63,6 +66,14 @@ int main(int argc, char **argv)
         {
             OqpskDemodulator d(0);
             OqpskDemodulator::Settings s;
+            if (kv.contains("prefb"))
+            {
+                s.fb = getd("prefb", 8400); s.lockingbw = s.fb;
+                d.setSettings(s);
+                d.start();
+                d.write(pcm.constData(), 40000);
+                d.stop();
+            }
             s.fb = fb; s.lockingbw = getd("lockingbw", fb); s.freq_center = getd("freq_center", 8000);
             d.setSettings(s);
             run(d, *ap, pcm, chunk);
@@ -71,6 +82,14 @@ int main(int argc, char **argv)
         {
             HipOqpskDemodulator d(0);
             HipOqpskDemodulator::Settings s;
+            if (kv.contains("prefb"))
+            {
+                s.fb = getd("prefb", 8400); s.lockingbw = s.fb;
+                d.setSettings(s);
+                d.start();
+                d.write(pcm.constData(), 40000);
+                d.stop();
+            }
             s.fb = fb; s.lockingbw = getd("lockingbw", fb); s.freq_center = getd("freq_center", 8000);
             d.setSettings(s);
             run(d, *ap, pcm, chunk);

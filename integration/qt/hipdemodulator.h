@@ -77,14 +77,26 @@ protected:
             pushFlags();
             jaero_set_dcd(ctx, -1, dcd);
         }
+        else if (js.kind != cur.kind || js.fb != cur.fb || js.Fs != cur.Fs || js.coarsefreqest_fft_power != cur.coarsefreqest_fft_power)
+        {
+            // a change of rate / kind / FFT size: the reference's setSettings rebuilds every filter, delay line and window, i.e. starts a new
+            // demodulator in the old object; a bank fixes those per bank, so the one-channel bank is replaced.  Soft bits that did not fill
+            // a group yet stay in `pending`, as RxDataBits survives setSettings there.
+            jaero_destroy(ctx);
+            ctx = nullptr;
+            applySettings(js);
+            return;
+        }
         else if (jaero_set_settings(ctx, 0, &js) != JAERO_OK)
             emit WarningTextSignal(QString("libjaero_hip: %1").arg(jaero_last_error()));
+        cur = js;
         if (js.Fs != Fs) { Fs = js.Fs; emit SampleRateChanged(Fs); }
         if (js.fb != fb) { fb = js.fb; emit BitRateChanged(fb, false); }
         lockingbw = js.lockingbw;
         freq_center = js.freq_center;
     }
 private:
+    jaero_settings cur{};
     void pushFlags() { if (ctx) jaero_set_flags(ctx, -1, afc, sql, cpuReduce); }
     void drain()
     {

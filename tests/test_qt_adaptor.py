@@ -72,6 +72,29 @@ def test_hip_adaptor_under_unmodified_aerol_oqpsk():
 
 @pytest.mark.gpu
 @have_demo
+def test_hip_adaptor_rate_change_replaces_the_bank():
+    """A user changing the bit rate: setSettings(8400) + some input, then setSettings(10500).  A bank fixes rate / kind / FFT size, so the
+    adaptor replaces its one-channel bank: the channel restarts as a fresh demodulator.  (The reference rebuilds AGC, filters, delays and
+    windows in the old object but keeps its oscillator phases and symbol-rate window contents, which here lets it decode the first
+    frames a little earlier: 260 against 234 CRC-clean lines on this input -- that head start is not reproduced.)  Required: after the
+    change the adaptor prints exactly what it prints without the episode, and every line is a transmitted signal unit."""
+    import re
+
+    pcm, pay = p_channel_pcm(nfr=14)
+    fresh = run_demo("hip", "oqpsk", pcm)
+    hip = run_demo("hip", "oqpsk", pcm, prefb=8400)
+
+    def good(txt):
+        return [ln for ln in txt.split("\n") if re.match(r"^. 0x", ln) and "Bad CRC" not in ln]
+
+    sent = {"".join("%02X" % b for b in p) for fr in pay for p in fr}
+    got = ["".join(re.findall(r"0x([0-9A-F]{2})", ln)) for ln in good(hip)]
+    assert len(got) >= 26 * 6 and all(g in sent for g in got)
+    assert good(hip) == good(fresh)
+
+
+@pytest.mark.gpu
+@have_demo
 def test_hip_adaptor_under_unmodified_aerol_msk():
     pay = AF.random_payloads(8, 1200, seed=9)
     bits, _ = AF.p_channel_bits(pay, 1200)
