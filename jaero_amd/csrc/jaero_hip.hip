@@ -577,7 +577,7 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
             const char *e = getenv("JAERO_PRE8400"); // "direct": the time-domain form (k_pre8400_fir), kept for A/B measurements
             c->pre_direct = e && !strcmp(e, "direct");
         }
-        HIPCHK(hipFuncSetAttribute((const void *)k_coarse4_w8400, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 257 * (int)sizeof(double)));
+        HIPCHK(hipFuncSetAttribute((const void *)k_coarse4_w8400, hipFuncAttributeMaxDynamicSharedMemorySize, (64 * 257 + C4_TABN) * (int)sizeof(double)));
     }
     if (g.kind == JAERO_KIND_MSK) { DA(c->p.dly, (size_t)ng * (g.sps + 1) * 64); DA(c->p.dly8, (size_t)ng * (g.sps2 + 1) * 64); }
     DA(c->p.soft, (size_t)nchp * g.soft_cap);
@@ -956,7 +956,7 @@ static void launch_coarse(jaero_ctx *c, const int *d_list, int nlist, hipStream_
     {
         // 2^14 = 16 x 16 x 16 x 4, 16-point register FFTs only (k_coarse4); one padded plane of 64*257 doubles in LDS
         if (c->pre8400)
-            hipLaunchKernelGGL(k_coarse4_w8400, dim3(grid), dim3(C2_THREADS), 64 * 257 * (int)sizeof(double), st, c->g, c->p, d_list, nlist, c->d_tw);
+            hipLaunchKernelGGL(k_coarse4_w8400, dim3(grid), dim3(C2_THREADS), (64 * 257 + C4_TABN) * (int)sizeof(double), st, c->g, c->p, d_list, nlist, c->d_tw);
         else
             hipLaunchKernelGGL(k_coarse4, dim3(grid), dim3(C2_THREADS), 64 * 257 * (int)sizeof(double), st, c->g, c->p, d_list, nlist, c->d_tw);
     }

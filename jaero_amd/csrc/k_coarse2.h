@@ -277,11 +277,12 @@ __global__ __launch_bounds__(C2_THREADS) void k_coarse2(const JGeom g, const JPt
     constexpr int N = 1 << LOG2N;
     constexpr int E = N / C2_THREADS;
     extern __shared__ __attribute__((aligned(16))) double xch[];
-    __shared__ double red_val[C2_THREADS];
-    __shared__ int red_idx[C2_THREADS];
+    __shared__ double red_val[C2_THREADS / 64]; // one entry per wavefront
+    __shared__ int red_idx[C2_THREADS / 64];
     __shared__ int sh_bigchange;
     const int t0 = threadIdx.x;
     const int nchp = g.nchp;
+    int tab_startbin = -1; // W8400: the startbin the window table behind the exchange buffer was made for
 
     CV<E> d;
     for (int li = blockIdx.x; li < nlist; li += gridDim.x)
@@ -580,6 +581,7 @@ __device__ __forceinline__ void c4_fft(CV<32> &d, double *xch, const double2 *__
 // waited for where it is issued (pass-3 twiddles as literals, table values and y[] requested ahead).
 // W8400 (fb == 8400, k_pre8400.h): the band limit is the centre-weighted window of coarsefreqestimate.cpp:61-74,100
 // instead of the boxcar of :99.
+#define C4_TABN 3584 // W8400: window table entries kept in LDS behind the exchange buffer (28 KiB): lockingbw < 10.49 kHz
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits for every global load and STORE in
 // flight: behind the y[] update that is 32 stores per thread on their way to HBM, behind the ring prefetch 32 loads -- the prefetch
 // was issued early precisely so that the peak search would run under it.
@@ -593,11 +595,12 @@ __device__ __forceinline__ void coarse4_body(const JGeom g, const JPtrs p, const
     constexpr int N = 1 << 14;
     constexpr int E = 32;
     extern __shared__ __attribute__((aligned(16))) double xch[];
-    __shared__ double red_val[C2_THREADS];
-    __shared__ int red_idx[C2_THREADS];
+    __shared__ double red_val[C2_THREADS / 64]; // one entry per wavefront
+    __shared__ int red_idx[C2_THREADS / 64];
     __shared__ int sh_bigchange;
     const int t0 = threadIdx.x;
     const int nchp = g.nchp;
+    int tab_startbin = -1; // W8400: the startbin the window table behind the exchange buffer was made for
 
     CV<E> d;
     for (int li = blockIdx.x; li < nlist; li += gridDim.x)
@@ -629,31 +632,42 @@ __device__ __forceinline__ void coarse4_body(const JGeom g, const JPtrs p, const
         // band limit (fb != 8400 boxcar, coarsefreqestimate.cpp:99) then inverse transform = forward on swapped planes
         if constexpr (W8400)
         {
-            // window[0] = 1, window[i] = window[N - i] = cos^2(pi/2 * i / startbin) for 1 <= i <= startbin, 0 elsewhere (:61-74).  The
-            // startbin + 1 distinct values are made once per estimate in the (idle) exchange buffer, ~6 cosines per thread; evaluated
-            // per element it was 32 per thread, most of them for bins the window zeroes, and the kernel spilled.
-            c4_lds_barrier();
-            for (int i = t; i <= startbin; i += C2_THREADS)
+            // window[0] = 1, window[i] = window[N - i] = cos^2(pi/2 * i / startbin) for 1 <= i <= startbin, 0 elsewhere (:61-74).  Its
+            // startbin + 1 distinct values come from a table in LDS: entry startbin + 1 = 0 stands for every bin the window zeroes.  The
+            // table sits behind the exchange buffer and is rebuilt only when startbin changes (a persistent workgroup serves ~256
+            // estimates, normally all with one locking bandwidth); a window wider than that space (lockingbw >= 10.49 kHz) is made per
+            // estimate in the idle exchange buffer.  (Round 1 evaluated 32 cosines per thread and estimate and spilled; one table per
+            // estimate cost 6 cosines per thread and three barriers: 17.9 ms per 65 536 estimates against 14.8 for the boxcar.)
+            const bool persistent = startbin < C4_TABN - 1;
+            double *wt = persistent ? xch + 64 * 257 : xch;
+            if (!persistent || startbin != tab_startbin)
             {
-                const double c = cos(M_PI_2 * ((double)i) / ((double)startbin));
-                xch[i] = (i == 0) ? 1.0 : c * c;
+                c4_lds_barrier();
+                for (int i = t; i <= startbin + 1; i += C2_THREADS)
+                {
+                    const double c = cos(M_PI_2 * ((double)i) / ((double)startbin));
+                    wt[i] = (i == 0) ? 1.0 : ((i <= startbin) ? c * c : 0.0);
+                }
+                c4_lds_barrier();
+                if (persistent) tab_startbin = startbin;
             }
-            c4_lds_barrier();
-            double w[E];
+            // applied eight at a time as they are read: all 32 weights in registers beside the 32 points spill (and without the fence the
+            // scheduler hoists all 32 LDS reads to the top, which is the same thing)
 #pragma unroll
-            for (int s = 0; s < E; s++)
+            for (int s0 = 0; s0 < E; s0 += 8)
             {
-                const int k = s * C2_THREADS + t;
-                const int i = (k <= N / 2) ? k : N - k;
-                w[s] = (i <= startbin) ? xch[i] : 0.0;
-            }
-            c4_lds_barrier(); // the next transform's exchanges reuse the buffer
 #pragma unroll
-            for (int s = 0; s < E; s++)
-            {
-                const double re = d.r[s] * w[s], im = d.i[s] * w[s];
-                d.r[s] = im; d.i[s] = re;
+                for (int s = s0; s < s0 + 8; s++)
+                {
+                    const int k = s * C2_THREADS + t;
+                    const int i = (k <= N / 2) ? k : N - k;
+                    const double w = wt[i <= startbin ? i : startbin + 1];
+                    const double re = d.r[s] * w, im = d.i[s] * w;
+                    d.r[s] = im; d.i[s] = re;
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if (!persistent) c4_lds_barrier(); // the next transform's exchanges reuse the buffer
         }
         else
         {
