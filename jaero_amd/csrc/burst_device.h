@@ -107,4 +107,6 @@ struct BPtrs
     const double2 *cis; const double *taps2; const double *hil_taps; // hil_taps[j] = imag(kernel[2j+1]), j < ntaps/4
     const double2 *tw14;         // W_8192^k (twiddle table of the 2^13-point transforms in k_trident)
     const double2 *tw15;         // W_32768^n, n < 16384 (pre-twiddle of the odd-bin half transforms in k_trident)
+    const double2 *hilH;         // [4096] DFT of the Hilbert kernel's imaginary taps (zero-padded) / 4096      (k_hilbert_fft)
+    const double2 *tw12;         // [4096] exp(-2 pi i k / 4096)                                                  (k_hilbert_fft)
 };

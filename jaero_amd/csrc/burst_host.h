@@ -96,7 +96,9 @@ static void burst_fill_geometry(BGeom &g, const jaero_settings &s, int nch, unsi
     if (g.maxseg > max_write) g.maxseg = (max_write + 15) / 16 * 16;
     g.bt_len = 2 * g.PL + 1;
     g.cv_len = g.D1 + (g.D2 > g.tri_sz ? g.D2 : g.tri_sz) + g.maxseg + 64;
-    g.hist_len = (g.hil_lat + g.hil_ntaps + max_write + 64 + 3) & ~3; // whole cells of four samples (k_hilbert)
+    // whole cells of four samples (k_hilbert); k_hilbert_fft's first block starts up to 2047 samples before the segment and looks
+    // hil_lat + 2048 samples further back
+    g.hist_len = (g.hil_lat + 2 * g.hil_ntaps + max_write + 64 + 3) & ~3;
 }
 
 static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, const hipDeviceProp_t &prop, int softbit_capacity)
@@ -183,6 +185,15 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
             hil[j] = (2.0 / ((double)N)) / (tan(M_PI * (((double)i) / ((double)N) - 0.5)));
         }
         HIPCHK(hipMemcpy(d_hil, hil.data(), sizeof(double) * hil.size(), hipMemcpyHostToDevice));
+        // the same taps at their positions k = 1, 3, ... 2047 for the overlap-save form (k_hilbert_fft)
+        std::vector<double> gk(N, 0.0);
+        for (int k = 1; k < N; k += 2) gk[k] = (2.0 / ((double)N)) / (tan(M_PI * (((double)k) / ((double)N) - 0.5)));
+        double2 *dH = nullptr, *dtw = nullptr;
+        if ((rc = fft4096_tables(gk, &dH, &dtw, (const void *)k_hilbert_fft))) return rc;
+        c->allocs.push_back(dH); c->allocs.push_back(dtw);
+        p.hilH = dH; p.tw12 = dtw;
+        const char *e = getenv("JAERO_HILBERT"); // "direct": the time-domain form (k_hilbert), kept for A/B measurements
+        c->hil_direct = (e && !strcmp(e, "direct")) || g.hil_ntaps != 2048;
     }
     // scalar state
     {
@@ -268,6 +279,9 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
         const long long n0 = c->nsamples_total;
         HIPCHK(hipMemsetAsync(p.ev_count, 0, sizeof(int), st));
         int pi = prof_begin(c, 3, st);
+        if (!c->hil_direct)
+            hipLaunchKernelGGL(k_hilbert_fft, dim3(g.nchp / 8, (int)(((n0 + n - 1) >> 11) - (n0 >> 11) + 1)), dim3(PF_THREADS), 4 * 2 * PRE_L * (int)sizeof(double), st, g, p, n, n0);
+        else
         {
             // every window of this launch starts at the same offset inside a four-sample cell of the history ring
             const int ph = (int)(((n0 - g.hil_lat + 1) % 4 + 4) % 4);

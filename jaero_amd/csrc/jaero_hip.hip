@@ -152,6 +152,7 @@ struct jaero_ctx
     JTaps28 oq_taps{}; // the 28 distinct values of the (bitwise symmetric) 55-tap RRC, scalar operands of k_oqpsk_fb's filter
     // fb == 8400 (k_pre8400.h): prefilter buffers, samples written so far, size of the previous write
     bool pre8400 = false, pre_direct = false;
+    bool hil_direct = false; // burst banks: JAERO_HILBERT=direct selects the time-domain Hilbert kernel
     JPre pre{};
     long long pre_n0 = 0;
     int pre_nprev = 0;
@@ -431,6 +432,29 @@ static void fill_geometry(JGeom &g, const jaero_settings &s, int nch, unsigned f
     }
 }
 
+// Tables of the overlap-save filters (k_pre8400_fft, k_hilbert_fft): H = DFT_4096(taps, zero-padded) / 4096 and exp(-2 pi i k / 4096),
+// summed in long double on the host.  kernel_fn = the kernel whose dynamic LDS limit is raised to the 128 KiB exchange buffer.
+static int fft4096_tables(const std::vector<double> &taps, double2 **d_H, double2 **d_tw, const void *kernel_fn)
+{
+    const int N = 2 * PRE_L;
+    std::vector<long double> cr(N), ci(N);
+    for (int k = 0; k < N; k++) { const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)N; cr[k] = cosl(a); ci[k] = sinl(a); }
+    std::vector<double2> H(N), tw(N);
+    for (int k = 0; k < N; k++)
+    {
+        long double sr = 0, si = 0;
+        for (int j = 0; j < (int)taps.size(); j++) { const int e = (int)(((long long)k * j) & (N - 1)); sr += (long double)taps[j] * cr[e]; si += (long double)taps[j] * ci[e]; }
+        H[k].x = (double)(sr / N); H[k].y = (double)(si / N);
+        tw[k].x = (double)cr[k]; tw[k].y = (double)ci[k];
+    }
+    HIPCHK(hipMalloc((void **)d_H, sizeof(double2) * N));
+    HIPCHK(hipMalloc((void **)d_tw, sizeof(double2) * N));
+    HIPCHK(hipMemcpy(*d_H, H.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(*d_tw, tw.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
+    HIPCHK(hipFuncSetAttribute(kernel_fn, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * PRE_L * (int)sizeof(double)));
+    return 0;
+}
+
 #include "burst_host.h"
 
 // ------------------------------------------------------------------------------------------ create / destroy
@@ -460,28 +484,6 @@ extern "C" void jaero_destroy(jaero_ctx *c)
     for (void *q : c->allocs) hipFree(q);
     for (auto &e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete c;
-}
-
-// Tables of k_pre8400_fft: H = DFT_4096(taps, zero-padded) / 4096 and exp(-2 pi i k / 4096), summed in long double on the host.
-static int pre8400_tables(const std::vector<double> &taps, double2 **d_H, double2 **d_tw)
-{
-    const int N = 2 * PRE_L;
-    std::vector<long double> cr(N), ci(N);
-    for (int k = 0; k < N; k++) { const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)N; cr[k] = cosl(a); ci[k] = sinl(a); }
-    std::vector<double2> H(N), tw(N);
-    for (int k = 0; k < N; k++)
-    {
-        long double sr = 0, si = 0;
-        for (int j = 0; j < PRE_K; j++) { const int e = (int)(((long long)k * j) & (N - 1)); sr += (long double)taps[j] * cr[e]; si += (long double)taps[j] * ci[e]; }
-        H[k].x = (double)(sr / N); H[k].y = (double)(si / N);
-        tw[k].x = (double)cr[k]; tw[k].y = (double)ci[k];
-    }
-    HIPCHK(hipMalloc((void **)d_H, sizeof(double2) * N));
-    HIPCHK(hipMalloc((void **)d_tw, sizeof(double2) * N));
-    HIPCHK(hipMemcpy(*d_H, H.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(*d_tw, tw.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
-    HIPCHK(hipFuncSetAttribute((const void *)k_pre8400_fft, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * PRE_L * (int)sizeof(double)));
-    return 0;
 }
 
 static void launch_pre8400_filter(const JGeom &g, const JPtrs &p, const JPre &q, int n, long long n0, bool direct, hipStream_t st)
@@ -571,7 +573,7 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         c->pre.taps = d_pre_taps;
         {
             double2 *dH = nullptr, *dtw = nullptr;
-            if ((rc = pre8400_tables(pt, &dH, &dtw))) { jaero_destroy(c); return rc; }
+            if ((rc = fft4096_tables(pt, &dH, &dtw, (const void *)k_pre8400_fft))) { jaero_destroy(c); return rc; }
             c->pre.H = dH; c->pre.tw = dtw;
             c->allocs.push_back(dH); c->allocs.push_back(dtw);
             const char *e = getenv("JAERO_PRE8400"); // "direct": the time-domain form (k_pre8400_fir), kept for A/B measurements
@@ -1103,7 +1105,7 @@ extern "C" int jaero_debug_prefilter(int device, const double *in_reim, int n, d
     {
         const char *e = getenv("JAERO_PRE8400");
         double2 *dH = nullptr, *dtw = nullptr;
-        int rc = pre8400_tables(taps, &dH, &dtw);
+        int rc = fft4096_tables(taps, &dH, &dtw, (const void *)k_pre8400_fft);
         if (rc) return rc;
         q.H = dH; q.tw = dtw;
         launch_pre8400_filter(g, p, q, n, 0LL, e && !strcmp(e, "direct"), 0);

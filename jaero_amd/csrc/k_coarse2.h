@@ -277,12 +277,11 @@ __global__ __launch_bounds__(C2_THREADS) void k_coarse2(const JGeom g, const JPt
     constexpr int N = 1 << LOG2N;
     constexpr int E = N / C2_THREADS;
     extern __shared__ __attribute__((aligned(16))) double xch[];
-    __shared__ double red_val[C2_THREADS / 64]; // one entry per wavefront
-    __shared__ int red_idx[C2_THREADS / 64];
+    __shared__ double red_val[C2_THREADS];
+    __shared__ int red_idx[C2_THREADS];
     __shared__ int sh_bigchange;
     const int t0 = threadIdx.x;
     const int nchp = g.nchp;
-    int tab_startbin = -1; // W8400: the startbin the window table behind the exchange buffer was made for
 
     CV<E> d;
     for (int li = blockIdx.x; li < nlist; li += gridDim.x)
