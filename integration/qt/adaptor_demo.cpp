@@ -1,7 +1,7 @@
 // adaptor_demo -- TEST DRIVER.  Wires a demodulator to the UNMODIFIED AeroL exactly as MainWindow does
 // (JAERO/mainwindow.cpp:198-202,234-237) and writes what AeroL prints to its console device:
 //
-//   adaptor_demo ref|hip oqpsk|msk <in.s16> <out.txt> [fb=10500] [lockingbw=..] [freq_center=..] [chunk=4096] [prefb=..]
+//   adaptor_demo ref|hip oqpsk|msk|burstoqpsk|burstmsk <in.s16> <out.txt> [fb=10500] [lockingbw=..] [freq_center=..] [chunk=4096] [prefb=..] [dump=1]
 //
 // prefb: setSettings is first called with that bit rate, 20 000 samples of the input are written, then setSettings with the real one
 // (a user changing the rate in the settings dialog): the rest must decode as if nothing had happened before.
@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include "oqpskdemodulator.h"
 #include "mskdemodulator.h"
+#include "burstoqpskdemodulator.h"
+#include "burstmskdemodulator.h"
 #include "aerol.h"
 #include "hipdemodulator.h"
 
@@ -29,6 +31,40 @@ struct AeroLZ : public AeroL // realimag, muw, lastframeinfo are never initialis
     static void *operator new(size_t n) { return calloc(1, n); }
     static void operator delete(void *p) { free(p); }
 };
+
+// The burst classes leave members uninitialised (BurstOqpskDemodulator::rotator_freq is read on the first sample,
+// JAERO/burstoqpskdemodulator.h:186, burstoqpskdemodulator.cpp:572): constructed in zeroed storage so that a run is deterministic.
+struct BurstOqpskZ : public BurstOqpskDemodulator
+{
+    BurstOqpskZ() : BurstOqpskDemodulator(0) {}
+    void DCDstatSlot(bool) {} // the burst OQPSK demodulator has no DCD input
+    static void *operator new(size_t n) { return calloc(1, n); }
+    static void operator delete(void *p) { free(p); }
+};
+struct BurstMskZ : public BurstMskDemodulator
+{
+    BurstMskZ() : BurstMskDemodulator(0) {}
+    static void *operator new(size_t n) { return calloc(1, n); }
+    static void operator delete(void *p) { free(p); }
+};
+
+static QIODevice *g_sink = nullptr;
+template <class DEMOD>
+static void run_burst(DEMOD &d, AeroL &a, const QByteArray &pcm, int chunk)
+{
+    QObject::connect(&d, &DEMOD::processDemodulatedSoftBits, &a, &AeroL::processDemodulatedSoftBits);
+    if (kv.contains("dump")) // the groups themselves, as AeroL receives them: "G <n>: v v v ..."
+        QObject::connect(&d, &DEMOD::processDemodulatedSoftBits, [](const QVector<short> &v) {
+            QString ln = QString("G %1:").arg(v.size());
+            for (int i = 0; i < v.size(); i++) ln += QString(" %1").arg(v[i]);
+            g_sink->write((ln + "\n").toLatin1());
+        });
+    d.start();
+    const char *p = pcm.constData();
+    const long nb = pcm.size();
+    for (long s = 0; s < nb; s += 2L * chunk) d.write(p + s, (nb - s < 2L * chunk) ? nb - s : 2L * chunk);
+    d.stop();
+}
 
 template <class DEMOD>
 static void run(DEMOD &d, AeroL &a, const QByteArray &pcm, int chunk)
@@ -56,6 +92,7 @@ int main(int argc, char **argv)
     AeroLZ *ap = new AeroLZ();
     QBuffer sink;
     sink.open(QIODevice::ReadWrite);
+    g_sink = &sink;
     ap->ConnectSinkDevice(&sink);
     QObject::connect(ap, &AeroL::DataCarrierDetect, [&](bool d) { sink.write(QString("#DCD %1\n").arg(d ? 1 : 0).toLatin1()); });
     if (kind == "oqpsk")
@@ -93,6 +130,62 @@ int main(int argc, char **argv)
             s.fb = fb; s.lockingbw = getd("lockingbw", fb); s.freq_center = getd("freq_center", 8000);
             d.setSettings(s);
             run(d, *ap, pcm, chunk);
+        }
+    }
+    else if (kind == "burstoqpsk")
+    {
+        const double fb = getd("fb", 10500);
+        ap->setSettings(fb, true);
+        if (impl == "ref")
+        {
+            BurstOqpskZ *d = new BurstOqpskZ();
+            BurstOqpskDemodulator::Settings s;
+            s.fb = fb; s.lockingbw = getd("lockingbw", fb); s.freq_center = getd("freq_center", 8000); s.Fs = 48000; s.signalthreshold = 0.6;
+            s.coarsefreqest_fft_power = 13; s.channel_stereo = false; s.zmqAudio = false;
+            d->setAFC(false); d->setSQL(false); d->setCPUReduce(false);
+            d->setScatterPointType(BurstOqpskDemodulator::SPT_None);
+            d->setSettings(s);
+            run_burst<BurstOqpskDemodulator>(*d, *ap, pcm, chunk);
+        }
+        else
+        {
+            HipBurstOqpskDemodulator d(0);
+            HipBurstOqpskDemodulator::Settings s;
+            s.fb = fb; s.lockingbw = getd("lockingbw", fb); s.freq_center = getd("freq_center", 8000);
+            d.setAFC(false); d.setSQL(false); d.setCPUReduce(false);
+            d.setScatterPointType(HipBurstOqpskDemodulator::SPT_None);
+            d.setSettings(s);
+            run_burst(d, *ap, pcm, chunk);
+        }
+    }
+    else if (kind == "burstmsk")
+    {
+        const double fb = getd("fb", 1200);
+        ap->setSettings(fb, true);
+        if (impl == "ref")
+        {
+            BurstMskZ *d = new BurstMskZ();
+            BurstMskDemodulator::Settings s;
+            s.fb = fb; s.lockingbw = getd("lockingbw", 1.5 * fb); s.freq_center = getd("freq_center", 1000); s.Fs = 48000; s.signalthreshold = 0.6;
+            s.coarsefreqest_fft_power = 13; s.symbolspercycle = 16; s.zmqAudio = false;
+            d->setAFC(false); d->setSQL(false); d->setCPUReduce(false);
+            d->setScatterPointType(BurstMskDemodulator::SPT_None);
+            d->DCDstatSlot(false);
+            d->setSettings(s);
+            QObject::connect(ap, &AeroL::DataCarrierDetect, d, &BurstMskDemodulator::DCDstatSlot); // only the MSK burst class has the input
+            run_burst<BurstMskDemodulator>(*d, *ap, pcm, chunk);
+        }
+        else
+        {
+            HipBurstMskDemodulator d(0);
+            HipBurstMskDemodulator::Settings s;
+            s.fb = fb; s.lockingbw = getd("lockingbw", 1.5 * fb); s.freq_center = getd("freq_center", 1000);
+            d.setAFC(false); d.setSQL(false); d.setCPUReduce(false);
+            d.setScatterPointType(HipBurstMskDemodulator::SPT_None);
+            d.DCDstatSlot(false);
+            d.setSettings(s);
+            QObject::connect(ap, &AeroL::DataCarrierDetect, &d, &HipBurstMskDemodulator::DCDstatSlot);
+            run_burst(d, *ap, pcm, chunk);
         }
     }
     else

@@ -3,6 +3,9 @@
 // HipOqpskDemodulator / HipMskDemodulator have the member functions, slots and signals MainWindow uses on
 // OqpskDemodulator / MskDemodulator (JAERO/oqpskdemodulator.h:15-152, JAERO/mskdemodulator.h:17-160), so the connect() lines of
 // JAERO/mainwindow.cpp:198-202,234-237 keep working: each object is a one-channel bank of include/jaero_hip.h.
+// HipBurstOqpskDemodulator / HipBurstMskDemodulator do the same for BurstOqpskDemodulator / BurstMskDemodulator
+// (JAERO/burstoqpskdemodulator.h:15-232, JAERO/burstmskdemodulator.h:22-220): soft bits in the reference's groups with the -1
+// start-of-burst marker, SignalStatus / EbNoMeasurmentSignal / Plottables from the bank's event log.
 // Add to JAERO.pro: HEADERS += hipdemodulator.h, INCLUDEPATH += <repo>/include, LIBS += -L<repo>/jaero_amd -ljaero_hip.
 // Compiled (moc + g++ against Qt 5.9.7) and driven by the unmodified AeroL in integration/qt/adaptor_demo.cpp /
 // tests/test_qt_adaptor.py.
@@ -164,6 +167,156 @@ public:
     void setSettings(Settings s) // mskdemodulator.cpp:135-263
     {
         jaero_settings js{JAERO_KIND_MSK, s.coarsefreqest_fft_power, s.freq_center, s.lockingbw, s.fb, s.Fs, s.signalthreshold};
+        applySettings(js);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ burst kinds
+class HipBurstDemodulatorBase : public QIODevice
+{
+    Q_OBJECT
+public:
+    enum ScatterPointType { SPT_constellation, SPT_phaseoffseterror, SPT_phaseoffsetest, SPT_None };
+    explicit HipBurstDemodulatorBase(QObject *parent, int kind_, int group_) : QIODevice(parent), kind(kind_), group(group_) {}
+    ~HipBurstDemodulatorBase() override { if (ctx) jaero_destroy(ctx); }
+    void setAFC(bool v) { afc = v; pushFlags(); }
+    void setSQL(bool v) { sql = v; pushFlags(); }
+    void setCPUReduce(bool v) { cpuReduce = v; pushFlags(); }
+    void setScatterPointType(ScatterPointType) {} // GUI only: the library produces no scatter points
+    void invalidatesettings() { Fs = -1; fb = -1; }
+    void start() { open(QIODevice::WriteOnly); }
+    void stop() { close(); }
+    double getCurrentFreq() { return freq_est; }
+    qint64 readData(char *, qint64) override { return 0; }
+    // = writeData / writeDataSlot of the reference (burstoqpskdemodulator.cpp:300-737, burstmskdemodulator.cpp:371-754), mono int16
+    qint64 writeData(const char *data, qint64 len) override
+    {
+        if (!ctx || len < 2) return len;
+        const int16_t *pcm = reinterpret_cast<const int16_t *>(data);
+        const qint64 n = len / 2;
+        for (qint64 s = 0; s < n; s += maxWrite)
+        {
+            const int m = int(n - s < maxWrite ? n - s : maxWrite);
+            if (jaero_write(ctx, pcm + s, m, JAERO_PCM_CHANNEL_MAJOR, /*host pointer*/ 0, nullptr) != JAERO_OK)
+            {
+                emit WarningTextSignal(QString("libjaero_hip: %1").arg(jaero_last_error()));
+                return len;
+            }
+            drain();
+        }
+        return len;
+    }
+signals:
+    void processDemodulatedSoftBits(const QVector<short> &soft_bits);
+    void Plottables(double freq_est, double freq_center, double bandwidth);
+    void MSESignal(double mse);
+    void SignalStatus(bool gotasignal);
+    void EbNoMeasurmentSignal(double EbNo);
+    void SampleRateChanged(double Fs);
+    void BitRateChanged(double fb, bool burstmode);
+    void WarningTextSignal(const QString &str);
+public slots:
+    void CenterFreqChangedSlot(double f) { if (ctx && jaero_center_freq_changed(ctx, 0, f) == JAERO_OK) freq_center = f; }
+    void DCDstatSlot(bool d) { dcd = d; if (ctx) jaero_set_dcd(ctx, -1, d); }
+    void dataReceived(const QByteArray &audio, quint32) { writeData(audio.constData(), audio.length()); }
+protected:
+    void applySettings(const jaero_settings &js)
+    {
+        // a burst bank has no live setSettings (JAERO_ENOTSUP): the one-channel bank is replaced, the channel restarts as a new demodulator
+        if (ctx) { jaero_destroy(ctx); ctx = nullptr; }
+        if (jaero_create(0, 1, &js, 0, 0, maxWrite, 0, &ctx) != JAERO_OK)
+        {
+            emit WarningTextSignal(QString("libjaero_hip: %1").arg(jaero_last_error()));
+            ctx = nullptr;
+            return;
+        }
+        pushFlags();
+        jaero_set_dcd(ctx, -1, dcd);
+        pending.clear();
+        if (js.Fs != Fs) { Fs = js.Fs; emit SampleRateChanged(Fs); }
+        if (js.fb != fb) { fb = js.fb; emit BitRateChanged(fb, true); }
+        lockingbw = js.lockingbw;
+        freq_center = js.freq_center;
+        drainEvents(); // the Plottables emission at the end of setSettings
+    }
+private:
+    void pushFlags() { if (ctx) jaero_set_flags(ctx, -1, afc, sql, cpuReduce); }
+    void drainEvents()
+    {
+        double rows[256 * 3];
+        int nr = 0;
+        if (jaero_read_events(ctx, 0, rows, 256, &nr) != JAERO_OK) nr = 0;
+        for (int r = 0; r < nr; r++)
+        {
+            const int k = int(rows[3 * r + 1]);
+            const double v = rows[3 * r + 2];
+            if (k == JAERO_EV_SIGNAL) emit SignalStatus(v != 0);
+            else if (k == JAERO_EV_EBNO) emit EbNoMeasurmentSignal(v);
+            else if (k == JAERO_EV_FREQ) { freq_est = v; emit Plottables(v, freq_center, lockingbw); }
+        }
+    }
+    void drain()
+    {
+        // The bank hands over the emitted groups back to back (what has not filled a group yet stays on the device, as RxDataBits
+        // does); the groups are cut as the reference cuts them: the start-of-burst marker (-1) is one entry, soft bits come in
+        // pairs, a group goes out once it holds >= `group` entries after a pair (burstoqpskdemodulator.cpp:546-585 with 32,
+        // burstmskdemodulator.cpp with 12).  AeroL's burst mode depends on these boundaries (it drops the rest of a group at signal end).
+        int n = 0;
+        buf.resize(1 << 16);
+        if (jaero_read_softbits(ctx, 0, buf.data(), int(buf.size()), &n) != JAERO_OK) n = 0;
+        int i = 0;
+        while (i < n)
+        {
+            if (buf[i] < 0) { pending.push_back(buf[i++]); continue; }
+            pending.push_back(buf[i++]);
+            if (i < n) pending.push_back(buf[i++]);
+            if (pending.size() >= group) { emit processDemodulatedSoftBits(pending); pending.clear(); }
+        }
+        drainEvents();
+    }
+    jaero_ctx *ctx = nullptr;
+    const int kind, group;
+    const int maxWrite = 1 << 16;
+    bool afc = false, sql = false, cpuReduce = false, dcd = false;
+    double Fs = 0, fb = 0, lockingbw = 0, freq_center = 0, freq_est = 0;
+    QVector<short> pending;
+    std::vector<int16_t> buf;
+};
+
+class HipBurstOqpskDemodulator : public HipBurstDemodulatorBase
+{
+    Q_OBJECT
+public:
+    struct Settings // == BurstOqpskDemodulator::Settings (JAERO/burstoqpskdemodulator.h:24-45)
+    {
+        int coarsefreqest_fft_power = 13;
+        double freq_center = 8000, lockingbw = 10500, fb = 10500, Fs = 48000, signalthreshold = 0.6;
+        bool channel_stereo = false, zmqAudio = false;
+    };
+    explicit HipBurstOqpskDemodulator(QObject *parent = nullptr) : HipBurstDemodulatorBase(parent, JAERO_KIND_BURST_OQPSK, 32) {}
+    void setSettings(Settings s) // burstoqpskdemodulator.cpp:202-277
+    {
+        jaero_settings js{JAERO_KIND_BURST_OQPSK, s.coarsefreqest_fft_power, s.freq_center, s.lockingbw, s.fb, s.Fs, s.signalthreshold};
+        applySettings(js);
+    }
+};
+
+class HipBurstMskDemodulator : public HipBurstDemodulatorBase
+{
+    Q_OBJECT
+public:
+    struct Settings // == BurstMskDemodulator::Settings (JAERO/burstmskdemodulator.h:29-50)
+    {
+        int coarsefreqest_fft_power = 13;
+        double freq_center = 1000, lockingbw = 1800, fb = 1200, Fs = 48000;
+        int symbolspercycle = 16;
+        double signalthreshold = 0.6;
+        bool zmqAudio = false;
+    };
+    explicit HipBurstMskDemodulator(QObject *parent = nullptr) : HipBurstDemodulatorBase(parent, JAERO_KIND_BURST_MSK, 12) {}
+    void setSettings(Settings s) // burstmskdemodulator.cpp:150-325
+    {
+        jaero_settings js{JAERO_KIND_BURST_MSK, s.coarsefreqest_fft_power, s.freq_center, s.lockingbw, s.fb, s.Fs, s.signalthreshold};
         applySettings(js);
     }
 };

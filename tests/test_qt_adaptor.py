@@ -54,6 +54,8 @@ def test_reference_side_decodes_the_frames():
 def test_adaptor_header_mirrors_the_reference_surface():
     """Every member MainWindow uses on the reference classes exists in the adaptor header (names as in oqpskdemodulator.h:41-67)."""
     src = open(os.path.join(ROOT, "integration", "qt", "hipdemodulator.h")).read()
+    for name in ("HipBurstOqpskDemodulator", "HipBurstMskDemodulator", "setScatterPointType", "invalidatesettings"):
+        assert name in src, name
     for name in ("setSettings", "setAFC", "setSQL", "setCPUReduce", "start", "stop", "getCurrentFreq", "writeData", "readData",
                  "processDemodulatedSoftBits", "Plottables", "MSESignal", "SignalStatus", "EbNoMeasurmentSignal", "SampleRateChanged",
                  "BitRateChanged", "CenterFreqChangedSlot", "DCDstatSlot", "dataReceived", "WarningTextSignal"):
@@ -103,4 +105,50 @@ def test_hip_adaptor_under_unmodified_aerol_msk():
     ref = run_demo("ref", "msk", pcm, fb=1200)
     hip = run_demo("hip", "msk", pcm, fb=1200)
     assert len(ref) > 500
+    assert hip == ref
+
+
+def rt_burst_pcm():
+    """Three R / T packets as 10.5 kbps burst OQPSK passband PCM (as tests/test_gpu_aerol_burst.py builds them)."""
+    n = 48000 * 5
+    rng = np.random.default_rng(21)
+    rb = lambda k: bytes(rng.integers(0, 256, k, dtype=np.uint8))
+    uw = np.repeat(np.array([(AF.UW >> (31 - k)) & 1 for k in range(32)], dtype=np.uint8), 2)
+    pk = [("R", rb(17)), ("T", (rb(4), [rb(10) for _ in range(4)])), ("R", rb(17))]
+    data = [np.concatenate([uw, AF.rt_packet_bits(k, p)]) for k, p in pk]
+    pcm, _ = G.burst_oqpsk(n, burst_starts=[40000, 100000, 185000], ndata_sym=900, fc=8015.0, ebno_db=16.0, seed=G.SEED_BASE + 300, data=data)
+    return pcm
+
+
+@have_demo
+def test_reference_side_decodes_the_bursts():
+    """Sanity of the burst half of the driver: BurstOqpskDemodulator -> AeroL (burst mode), all reference, prints R / T packets."""
+    txt = run_demo("ref", "burstoqpsk", rt_burst_pcm())
+    assert "T Packet from AES" in txt and "R_channel" in txt and "#DCD 1" in txt
+
+
+@pytest.mark.gpu
+@have_demo
+def test_hip_burst_adaptor_under_unmodified_aerol_oqpsk():
+    """HipBurstOqpskDemodulator (soft-bit groups cut as the reference cuts them, -1 start-of-burst marker) under the unmodified AeroL in
+    burst mode: the same text as the all-reference chain."""
+    pcm = rt_burst_pcm()
+    ref = run_demo("ref", "burstoqpsk", pcm)
+    hip = run_demo("hip", "burstoqpsk", pcm)
+    assert len(ref) > 100
+    assert hip == ref
+
+
+@pytest.mark.gpu
+@have_demo
+@pytest.mark.parametrize("fb", [1200, 600])
+def test_hip_burst_adaptor_groups_msk(fb):
+    """HipBurstMskDemodulator: the soft-bit groups it hands to AeroL (dumped by the driver: sizes 12 / 13 with the -1 marker, values)
+    are the groups BurstMskDemodulator hands over, and AeroL prints the same lines (DCD changes feed back through DCDstatSlot)."""
+    pcm, bursts = G.burst_msk(48000 * 6 if fb == 1200 else 48000 * 9, burst_starts=[30000, 150000] if fb == 1200 else [30000, 230000],
+                              ndata=400, fb=float(fb), fc=1007.0, ebno_db=18.0, seed=G.SEED_BASE + 77 + fb)
+    ref = run_demo("ref", "burstmsk", pcm, fb=fb, dump=1)
+    hip = run_demo("hip", "burstmsk", pcm, fb=fb, dump=1)
+    groups = [ln for ln in ref.split("\n") if ln.startswith("G ")]
+    assert len(groups) >= 40 and any(" -1" in ln for ln in groups)
     assert hip == ref
