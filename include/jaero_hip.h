@@ -96,7 +96,7 @@ typedef struct jaero_settings
     double freq_center;          /* Hz                                             */
     double lockingbw;            /* Hz                                             */
     double fb;                   /* bit rate: 10500 or 8400 (OQPSK; 8400: continuous kind, fft power 14), 600 / 1200 (MSK) */
-    double Fs;                   /* sample rate, 48000                             */
+    double Fs;                   /* sample rate: 48000; MSK kind also 24000, 12000 */
     double signalthreshold;      /* mse threshold                                  */
 } jaero_settings;
 

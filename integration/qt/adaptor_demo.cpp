@@ -1,7 +1,7 @@
 // adaptor_demo -- TEST DRIVER.  Wires a demodulator to the UNMODIFIED AeroL exactly as MainWindow does
 // (JAERO/mainwindow.cpp:198-202,234-237) and writes what AeroL prints to its console device:
 //
-//   adaptor_demo ref|hip oqpsk|msk|burstoqpsk|burstmsk <in.s16> <out.txt> [fb=10500] [lockingbw=..] [freq_center=..] [chunk=4096] [prefb=..] [dump=1]
+//   adaptor_demo ref|hip oqpsk|msk|burstoqpsk|burstmsk <in.s16> <out.txt> [fb=10500] [lockingbw=..] [freq_center=..] [chunk=4096] [prefb=..] [dump=1] [datarate=..]
 //
 // prefb: setSettings is first called with that bit rate, 20 000 samples of the input are written, then setSettings with the real one
 // (a user changing the rate in the settings dialog): the rest must decode as if nothing had happened before.
@@ -75,7 +75,10 @@ static void run(DEMOD &d, AeroL &a, const QByteArray &pcm, int chunk)
     d.start();
     const char *p = pcm.constData();
     const long nb = pcm.size();
-    for (long s = 0; s < nb; s += 2L * chunk) d.write(p + s, (nb - s < 2L * chunk) ? nb - s : 2L * chunk);
+    if (kv.contains("datarate")) // through dataReceived(audio, sampleRate), the ZMQ path: the MSK classes follow the incoming rate
+        for (long s = 0; s < nb; s += 2L * chunk) d.dataReceived(QByteArray(p + s, int((nb - s < 2L * chunk) ? nb - s : 2L * chunk)), quint32(getd("datarate", 48000)));
+    else
+        for (long s = 0; s < nb; s += 2L * chunk) d.write(p + s, (nb - s < 2L * chunk) ? nb - s : 2L * chunk);
     d.stop();
 }
 

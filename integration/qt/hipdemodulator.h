@@ -65,7 +65,18 @@ signals:
 public slots:
     void CenterFreqChangedSlot(double f) { if (ctx) jaero_center_freq_changed(ctx, 0, f); }          // :291-310
     void DCDstatSlot(bool d) { dcd = d; if (ctx) jaero_set_dcd(ctx, -1, d); }                       // :679-684
-    void dataReceived(const QByteArray &audio, quint32) { writeData(audio.constData(), audio.length()); } // :686-693
+    // OqpskDemodulator::dataReceived only warns about another rate (:686-693); MskDemodulator::dataReceived re-applies its last settings with
+    // the incoming rate (mskdemodulator.cpp:528-537) -- here: a new one-channel bank at that rate (applySettings)
+    void dataReceived(const QByteArray &audio, quint32 sampleRate)
+    {
+        if (double(sampleRate) != Fs && kind == JAERO_KIND_MSK && ctx)
+        {
+            jaero_settings js = cur;
+            js.Fs = double(sampleRate);
+            applySettings(js);
+        }
+        writeData(audio.constData(), audio.length());
+    }
 protected:
     void applySettings(const jaero_settings &js)
     {

@@ -60,6 +60,8 @@ static int fail(int code, const char *fmt, ...)
 #define OQ_LDSN 39 // matched-filter history slots kept in LDS (rest in VGPRs) + the taps: 39.5 KiB per wavefront -> 4 wavefronts per CU
 #define MSK_LDSN_1200 39 // of 80 taps: four wavefronts per CU (rings + the wavefront's copy of the taps: 39.6 KiB)
 #define MSK_LDSN_600 78  // of 160 taps: two wavefronts per CU (79.3 KiB)
+#define MSK_LDSN_40 24   // of 40 taps (1200 bps at 24 kHz, 600 bps at 12 kHz)
+#define MSK_LDSN_20 12   // of 20 taps (1200 bps at 12 kHz)
 
 struct ProfSlot { double ms = 0; int launches = 0; };
 
@@ -339,8 +341,11 @@ static double delay_weight(double fractdelay)
 static int validate_settings(const jaero_settings &s)
 {
     if (s.kind < JAERO_KIND_MSK || s.kind > JAERO_KIND_BURST_OQPSK) return fail(JAERO_ENOTSUP, "kind %d not implemented", s.kind);
-    if (s.Fs != 48000) return fail(JAERO_ENOTSUP, "only Fs=48000 is implemented (got %g)", s.Fs);
     const bool oq = s.kind == JAERO_KIND_OQPSK || s.kind == JAERO_KIND_BURST_OQPSK;
+    // the continuous MSK demodulator also runs at 24 and 12 kHz (MskDemodulator::dataReceived re-applies its settings with the sample rate
+    // of the incoming audio, JAERO/mskdemodulator.cpp:528-537): matched filters of 2 Fs / fb = 20, 40, 80 or 160 taps
+    const bool fs_ok = s.Fs == 48000 || (s.kind == JAERO_KIND_MSK && (s.Fs == 24000 || s.Fs == 12000));
+    if (!fs_ok) return fail(JAERO_ENOTSUP, "Fs = %g is not implemented (48000; continuous MSK also 24000 and 12000)", s.Fs);
     // fb = 8400 (C channel): the continuous demodulator with a 2^14-point coarse FFT (k_pre8400.h); JAERO_DISABLE_8400=1 refuses it
     const char *no84 = getenv("JAERO_DISABLE_8400");
     const bool allow84 = !(no84 && atoi(no84) != 0) && s.kind == JAERO_KIND_OQPSK && s.coarsefreqest_fft_power == 14;
@@ -414,12 +419,14 @@ static void fill_geometry(JGeom &g, const jaero_settings &s, int nch, unsigned f
         g.fir_n = 2 * g.sps;
         g.agc_len = (int)round(1 * s.Fs);
         g.marg_len = g.sps; g.dt_len = g.sps / 2 + 1; g.pm_len = 1; g.msema_len = 600;
+        // resonator and sampling-point offset: mskdemodulator.cpp:196-233 (one resonator for every rate other than 48 kHz)
         if (s.fb >= 1200)
         {
             g.correctionfactor = 0.6;
             g.res_a1 = -1.993312819378528; g.res_a2 = 0.999476538254407;
             g.res_b0 = 2.617308727964618e-04; g.res_b1 = 0; g.res_b2 = -2.617308727964618e-04;
             g.ee = 0.025;
+            if (s.Fs != 48000) g.ee = 0.05;
         }
         else
         {
@@ -427,6 +434,12 @@ static void fill_geometry(JGeom &g, const jaero_settings &s, int nch, unsigned f
             g.res_a1 = -1.998196509168551; g.res_a2 = 0.999738234875681;
             g.res_b0 = 1.308825621597620e-04; g.res_b1 = 0; g.res_b2 = -1.308825621597620e-04;
             g.ee = 0.025;
+            if (s.Fs != 48000) g.ee = 0.0125;
+        }
+        if (s.Fs != 48000)
+        {
+            g.res_a1 = -1.974342917561558; g.res_a2 = 0.998953350377616;
+            g.res_b0 = 5.233248111921052e-04; g.res_b1 = 0; g.res_b2 = -5.233248111921052e-04;
         }
         g.stref_freq = s.fb / 2;
     }
@@ -658,7 +671,8 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
     // dynamic LDS for the matched-filter rings
     if (g.kind == JAERO_KIND_MSK)
     {
-        if (g.fir_n != 80 && g.fir_n != 160) return fail(JAERO_ENOTSUP, "MSK matched filter of %d taps (fb %g) has no kernel", g.fir_n, g.fb);
+        if (g.fir_n != 20 && g.fir_n != 40 && g.fir_n != 80 && g.fir_n != 160)
+            return fail(JAERO_ENOTSUP, "MSK matched filter of %d taps (fb %g at Fs %g) has no kernel", g.fir_n, g.fb, g.Fs);
 #define MSK_ATTR(F, L) \
     { \
         const int lds_bytes = (2 * (L) * 64 + (F)) * (int)sizeof(double); \
@@ -667,8 +681,9 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<F, L, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
         HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<F, L, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
     }
-        c->msk_ldsn = g.fir_n == 80 ? MSK_LDSN_1200 : MSK_LDSN_600;
-        if (g.fir_n == 80) MSK_ATTR(80, MSK_LDSN_1200) else MSK_ATTR(160, MSK_LDSN_600)
+        c->msk_ldsn = g.fir_n == 160 ? MSK_LDSN_600 : (g.fir_n == 80 ? MSK_LDSN_1200 : (g.fir_n == 40 ? MSK_LDSN_40 : MSK_LDSN_20));
+        if (g.fir_n == 80) MSK_ATTR(80, MSK_LDSN_1200) else if (g.fir_n == 160) MSK_ATTR(160, MSK_LDSN_600)
+        else if (g.fir_n == 40) MSK_ATTR(40, MSK_LDSN_40) else MSK_ATTR(20, MSK_LDSN_20)
 #undef MSK_ATTR
     }
     if (g.kind == JAERO_KIND_OQPSK && !c->pre8400)
@@ -944,7 +959,8 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
         const int fs = (int)(c->m.nB_total % ldsn), ds = (int)(c->m.nB_total % (g.sps + 1)), d8 = (int)(c->m.nB_total % (g.sps2 + 1));
 #define LM(F, L, E, C) hipLaunchKernelGGL((k_msk_samples<F, L, E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs, ds, d8)
 #define LMS(F, L) { if (eb && cs) LM(F, L, true, true); else if (eb) LM(F, L, true, false); else if (cs) LM(F, L, false, true); else LM(F, L, false, false); }
-        if (g.fir_n == 80) LMS(80, MSK_LDSN_1200) else LMS(160, MSK_LDSN_600)
+        if (g.fir_n == 80) LMS(80, MSK_LDSN_1200) else if (g.fir_n == 160) LMS(160, MSK_LDSN_600)
+        else if (g.fir_n == 40) LMS(40, MSK_LDSN_40) else LMS(20, MSK_LDSN_20)
 #undef LMS
 #undef LM
     }

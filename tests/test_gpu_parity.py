@@ -183,6 +183,26 @@ def test_8400_small_writes_and_digital_silence(B, oracle_mod, chunk):
     assert np.max(dl[:k], initial=0.0) < 1e-6 and np.max(dl) < 1e-4
 
 
+@pytest.mark.parametrize("Fs,fb", [(24000.0, 1200.0), (24000.0, 600.0), (12000.0, 1200.0), (12000.0, 600.0)])
+def test_msk_at_other_sample_rates(B, oracle_mod, Fs, fb):
+    """MskDemodulator::dataReceived re-applies its settings with the sample rate of the incoming audio (mskdemodulator.cpp:528-537);
+    a bank fixes Fs, and continuous MSK banks exist for 24 and 12 kHz as well (matched filters of 2 Fs / fb = 80, 40, 20 taps).  Three
+    channels with different carriers against their oracle runs (the oracle equals the unmodified reference at these rates too:
+    tests/test_oracle_vs_ref.py)."""
+    from jaero_amd import signalgen as G
+
+    O = oracle_mod
+    nch, nsamp, chunk = 3, int(Fs * 5), 3000
+    pcm = np.stack([G.msk(nsamp, fb=fb, Fs=Fs, fc=1000.0 + 9.0 * c, ebno_db=12.0, seed=G.SEED_BASE + 500 + c)[0] for c in range(nch)])
+    bank = B.DemodulatorBank([B.MskSettings(fb=fb, lockingbw=1.5 * fb, freq_center=1000.0, Fs=Fs) for _ in range(nch)], ebno=True,
+                             status_log=True, capture_symbols=True, max_write_samples=chunk, softbit_capacity=nsamp)
+    feed(bank, pcm, chunk)
+    for c in range(nch):
+        ref = O.run_demod(O.msk_settings(lockingbw=1.5 * fb, fb=fb, Fs=Fs), pcm[c], chunk=chunk, capture_symbols=True)
+        compare(bank.read_softbits(c), bank.read_symbols(c), bank.read_status_log(c), ref)
+    bank.close()
+
+
 def test_chunking_and_layout_invariance(B):
     """Same stream fed as 4096-sample channel-major writes, odd-sized writes, and frame-major device tensors."""
     import torch

@@ -48,6 +48,14 @@ def test_msk_random(O, fb, seed):
          O.run_demod(O.msk_settings(fb=fb, lockingbw=bw), pcm, dcd_at=20000))
 
 
+@pytest.mark.parametrize("Fs,fb", [(24000, 1200), (24000, 600), (12000, 1200), (12000, 600)])
+def test_msk_other_sample_rates(O, Fs, fb):
+    """What MskDemodulator::dataReceived does when audio arrives at another rate (mskdemodulator.cpp:528-537): setSettings with that Fs."""
+    pcm, _ = G.msk(int(Fs * 6), fb=float(fb), Fs=float(Fs), fc=1004.0, ebno_db=11.0, seed=40 + fb // 600 + Fs // 12000)
+    _cmp(O.run_ref("msk", pcm, fb=fb, lockingbw=1.5 * fb, Fs=Fs, chunk=3000),
+         O.run_demod(O.msk_settings(fb=float(fb), lockingbw=1.5 * fb, Fs=float(Fs)), pcm, chunk=3000))
+
+
 def test_noise_only_and_center_change(O):
     rng = np.random.default_rng(3)
     noise = rng.normal(0, 2500, 60000).astype(np.int16)

@@ -152,3 +152,18 @@ def test_hip_burst_adaptor_groups_msk(fb):
     groups = [ln for ln in ref.split("\n") if ln.startswith("G ")]
     assert len(groups) >= 40 and any(" -1" in ln for ln in groups)
     assert hip == ref
+
+
+@pytest.mark.gpu
+@have_demo
+def test_hip_msk_adaptor_follows_the_incoming_sample_rate():
+    """Audio arriving through dataReceived at 24 kHz while the demodulator was set up for 48 kHz: MskDemodulator re-applies its settings
+    with that rate (mskdemodulator.cpp:528-537), the adaptor replaces its bank; AeroL prints the same signal units."""
+    pay = AF.random_payloads(8, 1200, seed=11)
+    bits, _ = AF.p_channel_bits(pay, 1200)
+    n = int(len(bits) * 24000 / 1200) + 2000
+    pcm, _ = G.msk(n, fb=1200.0, Fs=24000.0, fc=1007.0, ebno_db=16.0, seed=33, bits=np.concatenate([bits, np.zeros(16, np.uint8)]))
+    ref = run_demo("ref", "msk", pcm, fb=1200, datarate=24000)
+    hip = run_demo("hip", "msk", pcm, fb=1200, datarate=24000)
+    assert len(ref) > 500
+    assert hip == ref
