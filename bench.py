@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--timing-phases", type=int, default=32, help="continuous OQPSK workloads: number of distinct symbol-clock phases drawn per channel (1 = all channels symbol-synchronous)")
     ap.add_argument("--check-channels", type=int, default=16, help="channels (spread over the bank) compared with the oracle on the same PCM after the timed region; 0 = none")
     ap.add_argument("--as-written", type=int, default=1, help="also time BASELINE configs[2] / configs[1] at their literal sizes (N = 1)")
-    ap.add_argument("--workload", default="oqpsk", choices=["oqpsk", "oqpsk8400", "msk", "burst_oqpsk", "aerol", "aerol_burst", "aerol_c"],
+    ap.add_argument("--workload", default="oqpsk", choices=["oqpsk", "oqpsk8400", "msk", "burst_oqpsk", "burst_msk", "aerol", "aerol_burst", "aerol_c"],
                     help="oqpsk = BASELINE configs[2] (continuous, the headline); msk = configs[1] shape (1200 bps MSK) scaled to a bank that fills the chip; burst_oqpsk = configs[3] (one burst per second per "
                          "channel); aerol = the 10.5 kbps P-channel bit pipeline behind the demodulator (SURVEY 8 row f1), one frame per step; "
                          "aerol_burst = the R/T channel packet search behind a burst demodulator (row f2), one burst per channel and step")
@@ -80,9 +80,12 @@ def cpu_baseline(chunk: int):
 
     ncores = os.cpu_count() or 1
     n = ARGS.cpu_samples
-    burst = ARGS.workload == "burst_oqpsk"
-    refkind = "burstoqpsk" if burst else "oqpsk"
-    if burst:
+    burst = ARGS.workload in ("burst_oqpsk", "burst_msk")
+    bmsk = ARGS.workload == "burst_msk"
+    refkind = "burstmsk" if bmsk else ("burstoqpsk" if burst else "oqpsk")
+    if bmsk:
+        pcm, _ = G.burst_msk(n, burst_starts=list(range(20000, n - 60000, 72000)), ndata=1000, fb=1200.0, fc=1010.0, ebno_db=18.0, seed=G.SEED_BASE + 77)
+    elif burst:
         pcm, _ = G.burst_oqpsk(n, burst_starts=list(range(20000, n - 40000, 48000)), ndata_sym=3040, fc=8037.5, ebno_db=15.0, seed=G.SEED_BASE + 77)
     else:
         pcm, _ = G.oqpsk(n, fc=8037.5, ebno_db=ARGS.ebno_db, seed=G.SEED_BASE + 77)
@@ -99,11 +102,12 @@ def cpu_baseline(chunk: int):
         t0 = time.time()
         if use_ref:
             kind = "reference"
-            procs = [subprocess.Popen([O.REF_BIN, "time", refkind, path, f"chunk={chunk}"], stdout=subprocess.PIPE, env=child_env()) for _ in range(ncores)]
+            extra = ["fb=1200", "lockingbw=1800", "freq_center=1000"] if bmsk else []
+            procs = [subprocess.Popen([O.REF_BIN, "time", refkind, path, f"chunk={chunk}"] + extra, stdout=subprocess.PIPE, env=child_env()) for _ in range(ncores)]
             outs = [p.communicate()[0] for p in procs]
             inner = [float(o.split()[0]) for o in outs]
         else:
-            mk = "O.BurstDemod(O.burst_oqpsk_settings())" if burst else "O.Demod(O.oqpsk_settings())"
+            mk = "O.BurstDemod(O.burst_msk_settings())" if bmsk else ("O.BurstDemod(O.burst_oqpsk_settings())" if burst else "O.Demod(O.oqpsk_settings())")
             code = ("import sys,time,numpy as np; sys.path.insert(0,%r); from oracle import oracle as O; "
                     "x=np.fromfile(%r,dtype=np.int16); d=%s; t=time.time(); "
                     "[d.write(x[s:s+%d]) for s in range(0,len(x),%d)]; print(time.time()-t)") % (ROOT, path, mk, chunk, chunk)
@@ -114,7 +118,7 @@ def cpu_baseline(chunk: int):
     # aggregate over cores: every core did n samples in `inner[i]` seconds of writeData time, concurrently
     value = sum(n / t for t in inner) / 1e6
     return {"value": round(value, 3), "unit": "Msamples/s", "cores": ncores, "kind": kind,
-            "sample": f"{n} samples of 48 kHz 10.5k {'burst ' if burst else ''}OQPSK per core, {chunk}-sample writes, cpuReduce=false, "
+            "sample": f"{n} samples of 48 kHz {'1200 bps burst MSK' if bmsk else ('10.5k burst OQPSK' if burst else '10.5k OQPSK')} per core, {chunk}-sample writes, cpuReduce=false, "
                       f"one process per core ({wall:.1f} s wall)",
             "per_core_msps": round(value / ncores, 3),
             "note": "FFT inside the reference build is the JFFT stand-in (oracle/ref/shim/jfft.h), not JFFT"}
@@ -146,7 +150,7 @@ def ber_check(bank, bits, nch_check: int, tail: int = 3000):
     return worst, locked
 
 
-def burst_line(bank, rank, world, nch, chunk, K, W, dt, value):
+def burst_line(bank, rank, world, nch, chunk, K, W, dt, value, msk=False):
     """JSON line for the burst OQPSK workload (BASELINE configs[3]); kernel classes: tracking chain, trident check, history
     push, Hilbert FIR, front end (jaero_profile_read which = 0..4)."""
     from jaero_amd import capi
@@ -168,13 +172,17 @@ def burst_line(bank, rank, world, nch, chunk, K, W, dt, value):
     units = K * chunk * nch / launches
     achieved = per_sample * units / (avg_ms * 1e-3) / 1e9
     line = {
-        "metric": "Msamples/s of real 48 kHz PCM through the 10.5 kbps burst OQPSK demodulator hot path",
+        "metric": ("Msamples/s of real 48 kHz PCM through the 1200 bps burst MSK demodulator hot path" if msk else
+                   "Msamples/s of real 48 kHz PCM through the 10.5 kbps burst OQPSK demodulator hot path"),
         "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{nch}-channel-per-GPU synthetic 48 kHz 10.5 kbps burst OQPSK (BASELINE configs[3] shape): one burst per "
-                               f"second per channel (128 symbols carrier + 128 symbols preamble + 3040 symbols data) at a random offset, noise "
-                               f"between bursts, Eb/N0 15 dB, {chunk}-sample writes",
+        "config": {"workload": (f"{nch}-channel-per-GPU synthetic 48 kHz 1200 bps burst MSK (R/T-channel style): one burst per 1.5 s per channel "
+                                f"(120 bit periods carrier + 100 preamble + 1000 data bits), 32 distinct streams with their bursts at different "
+                                f"offsets replicated over the channels, noise between bursts, Eb/N0 18 dB, {chunk}-sample writes" if msk else
+                                f"{nch}-channel-per-GPU synthetic 48 kHz 10.5 kbps burst OQPSK (BASELINE configs[3] shape): one burst per "
+                                f"second per channel (128 symbols carrier + 128 symbols preamble + 3040 symbols data) at a random offset, noise "
+                                f"between bursts, Eb/N0 15 dB, {chunk}-sample writes"),
                    "channels_per_gpu": nch, "total_channels": nch * world, "chunk": chunk,
                    "realtime_channel_equivalents": int(value / 0.048),
                    "bursts_accepted_in_first_channels": acc, "channels_checked": min(8, nch),
@@ -854,6 +862,45 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         burst_line(bank, rank, world, nch, chunk, K, W, dt, float(K) * chunk * nch * world / dt / 1e6)
+        bank.close()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    if ARGS.workload == "burst_msk":
+        from jaero_amd.demodulator import BurstMskSettings
+
+        nsamp = (K + W) * chunk
+        nuniq = 32
+        rng = np.random.default_rng(signalgen.SEED_BASE + 900 + lo)
+        uniq = np.stack([signalgen.burst_msk(nsamp, burst_starts=list(range(int(rng.integers(2000, 70000)), nsamp - 1000, 72000)), ndata=1000, fb=1200.0,
+                                             fc=1000.0 + float(rng.uniform(-8, 8)), ebno_db=18.0, seed=signalgen.SEED_BASE + 900 + lo + u)[0] for u in range(nuniq)])
+        ut = torch.from_numpy(uniq).to(dev)                                  # [nuniq][nsamp]
+        idx = torch.arange(nch, device=dev) % nuniq
+        pcm = ut.t().contiguous()[:, idx].contiguous()                       # frame-major [nsamp][nch]
+        bank = DemodulatorBank(BurstMskSettings(freq_center=1000.0, fb=1200.0), nch, device=local, max_write_samples=chunk,
+                               softbit_capacity=int(nsamp * 1200 / 48000) + 64)
+        bank.set_flags(afc=False, sql=False, cpu_reduce=False)
+        for i in range(W):
+            bank.write(pcm[i * chunk:(i + 1) * chunk], layout=capi.PCM_FRAME_MAJOR, stream=stream)
+        torch.cuda.synchronize()
+        bank.profile_enable(True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(W, W + K):
+            bank.write(pcm[i * chunk:(i + 1) * chunk], layout=capi.PCM_FRAME_MAJOR, stream=stream)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        burst_line(bank, rank, world, nch, chunk, K, W, dt, float(K) * chunk * nch * world / dt / 1e6, msk=True)
         bank.close()
         if world > 1:
             dist.barrier()

@@ -232,7 +232,8 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
     c->o_nrx = p.I + (size_t)BI_NRX * nchp;
     c->m.nch = nch; c->m.nchp = nchp;
     c->m.flags.assign(nchp, 0);
-    const int lds = (oq ? 2 * 39 * 64 + 64 : 2 * g.fir_n * 64) * (int)sizeof(double); // burst OQPSK: 39 of its 55 history slots + the taps in LDS
+    // burst OQPSK: 39 of its 55 history slots + the taps in LDS; burst MSK: 39 of 80 (1200 bps) or all 160 (600 bps) slots
+    const int lds = (oq ? 2 * 39 * 64 + 64 : 2 * (g.fir_n == 80 ? BMSK_LDSN_1200 : g.fir_n) * 64) * (int)sizeof(double);
     if (oq)
     {
         HIPCHK(hipFuncSetAttribute((const void *)k_burst_oqpsk_demod<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -240,8 +241,11 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
     }
     else
     {
-        HIPCHK(hipFuncSetAttribute((const void *)k_burst_msk_demod<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_burst_msk_demod<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if (g.fir_n != 80 && g.fir_n != 160) return fail(JAERO_ENOTSUP, "burst MSK matched filter of %d taps has no kernel", g.fir_n);
+        HIPCHK(hipFuncSetAttribute((const void *)k_burst_msk_demod<false, 80, BMSK_LDSN_1200>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_burst_msk_demod<true, 80, BMSK_LDSN_1200>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_burst_msk_demod<false, 160, 160>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_burst_msk_demod<true, 160, 160>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
     HIPCHK(hipFuncSetAttribute((const void *)k_trident, hipFuncAttributeMaxDynamicSharedMemorySize, c->tri_lds));
     HIPCHK(hipDeviceSynchronize());
@@ -271,7 +275,7 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
         prof_end(c, pi, st);
     }
     const bool cs = (c->flags & JAERO_FLAG_CAPTURE_SYMBOLS) != 0;
-    const int lds = (g.kind == JAERO_KIND_BURST_OQPSK ? 2 * 39 * 64 + 64 : 2 * g.fir_n * 64) * (int)sizeof(double);
+    const int lds = (g.kind == JAERO_KIND_BURST_OQPSK ? 2 * 39 * 64 + 64 : 2 * (g.fir_n == 80 ? BMSK_LDSN_1200 : g.fir_n) * 64) * (int)sizeof(double);
     int first = 1;
     for (int pos = 0; pos < nsamples;)
     {
@@ -312,8 +316,16 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
         }
         else
         {
-            if (cs) hipLaunchKernelGGL((k_burst_msk_demod<true>), dim3(g.ngroups), dim3(64), lds, st, g, p, n, n0, first);
-            else hipLaunchKernelGGL((k_burst_msk_demod<false>), dim3(g.ngroups), dim3(64), lds, st, g, p, n, n0, first);
+            if (g.fir_n == 80)
+            {
+                if (cs) hipLaunchKernelGGL((k_burst_msk_demod<true, 80, BMSK_LDSN_1200>), dim3(g.ngroups), dim3(64), lds, st, g, p, n, n0, first);
+                else hipLaunchKernelGGL((k_burst_msk_demod<false, 80, BMSK_LDSN_1200>), dim3(g.ngroups), dim3(64), lds, st, g, p, n, n0, first);
+            }
+            else
+            {
+                if (cs) hipLaunchKernelGGL((k_burst_msk_demod<true, 160, 160>), dim3(g.ngroups), dim3(64), lds, st, g, p, n, n0, first);
+                else hipLaunchKernelGGL((k_burst_msk_demod<false, 160, 160>), dim3(g.ngroups), dim3(64), lds, st, g, p, n, n0, first);
+            }
         }
         LAUNCHCHK("the burst demodulator");
         prof_end(c, pi, st);

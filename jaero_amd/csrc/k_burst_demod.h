@@ -345,12 +345,24 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
 // Everything after the sample counters runs only while (startstop > 0 || mse < signalthreshold) (:601), so the matched
 // filter, agc2, EbNo, delayedsmpl and delayt8 rings advance per channel: their positions are per-lane state and the rings are
 // per-channel arrays; the matched-filter ring lives in LDS for the launch ([slot][lane], per-lane slot, conflict-free).
-template <bool CAPSYM>
+// Round 2: (i) the matched filter reads eight history entries ahead of the sixteen fmas that consume them (it was one LDS round trip per
+// tap: 80 or 160 dependent waits per sample); (ii) the entries leaving the per-channel windows (EbNo, agc2, the two delay lines) are
+// requested at the top of a sample -- their addresses are known there -- instead of where they are consumed, one HBM / L2 round trip
+// each, one after the other; (iii) the EbNo meter's divide / sqrt / two log10 run only where its value can be observed (the
+// JD_EBNO_TAIL samples before the end of a launch, before its one emission per burst, and before the gate closes), as in the burst OQPSK
+// kernel.  78 -> 43 ms per 4096-sample launch of 65 536 channels.
+// LDSN < FIRN keeps only the LDSN newest history entries of each arm in LDS (per-lane ring position) and the older ones in registers
+// (the shift runs under the gate's exec mask).  Tried for 1200 bps to get four wavefronts per CU instead of two (40 instead of 80 KiB each,
+// so that the 1024 wavefronts of a 65 536-channel bank are resident at once instead of in two rounds): the kernel already holds 380
+// registers, the 164 of the tail spill (39 slots: 50 ms per launch, 52 slots: 51 ms, against 43 ms with everything in LDS).  So LDSN = FIRN.
+#define BMSK_LDSN_1200 80
+template <bool CAPSYM, int FIRN, int LDSN>
 __global__ __launch_bounds__(64) void k_burst_msk_demod(const BGeom g, const BPtrs p, int n, long long n0, int first_of_write)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int FIRN = g.fir_n;
-    double *lre = lds, *lim = lds + FIRN * 64;
+    double *lre = lds, *lim = lds + LDSN * 64;
+    constexpr int TAILN = FIRN - LDSN, TAILA = TAILN > 0 ? TAILN : 1;
+    double tre[TAILA], tim[TAILA]; // tre[j] = x_re[newest - LDSN - j]
     const int lane = threadIdx.x, grp = blockIdx.x, ch = grp * 64 + lane, nchp = g.nchp;
     const double2 *__restrict__ cis = p.cis;
     const double *taps = c_taps_msk[g.fb >= 1200 ? 0 : 1];
@@ -384,8 +396,10 @@ __global__ __launch_bounds__(64) void k_burst_msk_demod(const BGeom g, const BPt
     double *msema_ring = p.msema + (size_t)ch * g.msema_len;
     int16_t *__restrict__ soft = p.soft + (size_t)ch * g.soft_cap;
     {
-        const double *fs = p.firsave + (size_t)ch * 2 * FIRN;
-        for (int k = 0; k < FIRN; k++) { lre[k * 64 + lane] = fs[k]; lim[k * 64 + lane] = fs[FIRN + k]; }
+        const double *fs = p.firsave + (size_t)ch * 2 * FIRN; // [0, LDSN): the LDS ring's slots, [LDSN, FIRN): the register tail
+        for (int k = 0; k < LDSN; k++) { lre[k * 64 + lane] = fs[k]; lim[k * 64 + lane] = fs[FIRN + k]; }
+#pragma unroll
+        for (int j = 0; j < TAILN; j++) { tre[j] = fs[LDSN + j]; tim[j] = fs[FIRN + LDSN + j]; }
     }
     int s_val = (int)((n0 - g.D1 - g.D2 + 8LL * g.cv_len) % g.cv_len);
     const double agc2_len_d = (double)g.agc2_len, eb_len_d = (double)g.eb_len;
@@ -450,19 +464,73 @@ __global__ __launch_bounds__(64) void k_burst_msk_demod(const BGeom g, const BPt
         if (startstop > 0 || mse < thresh)
         {
             const double2 c2 = cis[jd_cisidx(m2_ptr)];
+            // window entries this sample replaces / reads: requested now, consumed behind the filter
+            const double e2_old = ebe2_ring[eb_pos], e_old = ebe_ring[eb_pos], agc2_old = agc2_ring[agc2_pos];
+            const int dly_nx = (dly_pos + 1 >= g.dly_len) ? 0 : dly_pos + 1;
+            const int d8_nx = (d8_pos + 1 >= g.d8_len) ? 0 : d8_pos + 1, d8_nx2 = (d8_nx + 1 >= g.d8_len) ? 0 : d8_nx + 1;
+            const double2 ptd_pre = dly_ring[dly_nx];
+            const double d8_a = d8_ring[d8_nx2], d8_b = d8_ring[d8_nx];
+            const double st_ptr_top = st_ptr;
+            const double2 so_pre = cis[jd_cisidx(st_ptr)]; // the symbol oscillator's table entry: valid unless the preamble block below moves st_ptr
             const double cre = (c2.x * val) * vol_gain, cim = (c2.y * val) * vol_gain;
             double sre = 0, sim = 0;
             {
-                int slot = fir_pos;
-                for (int t = 0; t < FIRN; t++)
+                // output from x[n-FIRN .. n-1], taps[t] <-> x[n-FIRN+t], oldest first: the register tail, then the LDS ring from its oldest slot
+#pragma unroll
+                for (int t = 0; t < TAILN; t++)
                 {
                     const double tp = taps[t];
-                    sre = fma(tp, lre[slot * 64 + lane], sre);
-                    sim = fma(tp, lim[slot * 64 + lane], sim);
-                    slot++; if (slot >= FIRN) slot = 0;
+                    sre = fma(tp, tre[TAILN - 1 - t], sre);
+                    sim = fma(tp, tim[TAILN - 1 - t], sim);
+                }
+                int slot = fir_pos;
+                constexpr int NB = LDSN / 8, REM = LDSN % 8;
+#pragma unroll 1
+                for (int b = 0; b < NB; b++)
+                {
+                    double xr[8], xi[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                    {
+                        xr[u] = lre[slot * 64 + lane];
+                        xi[u] = lim[slot * 64 + lane];
+                        slot++; if (slot >= LDSN) slot = 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                    {
+                        const double tp = taps[TAILN + 8 * b + u];
+                        sre = fma(tp, xr[u], sre);
+                        sim = fma(tp, xi[u], sim);
+                    }
+                }
+                if constexpr (REM > 0)
+                {
+                    double xr[REM], xi[REM];
+#pragma unroll
+                    for (int u = 0; u < REM; u++)
+                    {
+                        xr[u] = lre[slot * 64 + lane];
+                        xi[u] = lim[slot * 64 + lane];
+                        slot++; if (slot >= LDSN) slot = 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < REM; u++)
+                    {
+                        const double tp = taps[TAILN + 8 * NB + u];
+                        sre = fma(tp, xr[u], sre);
+                        sim = fma(tp, xi[u], sim);
+                    }
+                }
+                // push x[n]: the oldest LDS entry moves into the register tail (this block runs under the gate's exec mask)
+                if constexpr (TAILN > 0)
+                {
+#pragma unroll
+                    for (int j = TAILN - 1; j > 0; j--) { tre[j] = tre[j - 1]; tim[j] = tim[j - 1]; }
+                    tre[0] = lre[fir_pos * 64 + lane]; tim[0] = lim[fir_pos * 64 + lane];
                 }
                 lre[fir_pos * 64 + lane] = cre; lim[fir_pos * 64 + lane] = cim;
-                fir_pos++; if (fir_pos >= FIRN) fir_pos = 0;
+                fir_pos++; if (fir_pos >= LDSN) fir_pos = 0;
             }
             if (cntr > (g.startProcessing * SPS) && cntr < g.endRotation)
             {
@@ -499,21 +567,27 @@ __global__ __launch_bounds__(64) void k_burst_msk_demod(const BGeom g, const BPt
             {
                 const double sq = sabs * sabs;
                 double *e2p = ebe2_ring + eb_pos, *ep = ebe_ring + eb_pos;
-                eb_e2sum = eb_e2sum - *e2p; eb_e2sum = eb_e2sum + fabs(sq); *e2p = fabs(sq);
-                eb_esum = eb_esum - *ep; eb_esum = eb_esum + fabs(sabs); *ep = fabs(sabs);
+                eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq); *e2p = fabs(sq);
+                eb_esum = eb_esum - e_old; eb_esum = eb_esum + fabs(sabs); *ep = fabs(sabs);
                 eb_pos++; if (eb_pos >= g.eb_len) eb_pos = 0;
-                const double e2val = eb_e2sum / eb_len_d, mean = eb_esum / eb_len_d;
-                const double var = e2val - (mean * mean);
-                const double alpha = sqrt(2.0) / mean;
-                double tebno = 10.0 * (log10(2.0) - log10(((var * alpha * alpha) - 0.0085))) - 5.0;
-                if (isnan(tebno)) tebno = 50;
-                if (tebno > 50.0) tebno = 50;
-                eb_ebno = eb_ebno * 0.8 + 0.2 * tebno;
+                // the value is observable once per burst (the emission below), at the end of a launch (status) and where the gate closes;
+                // its IIR forgets a term after k samples as 0.8^k, so the arithmetic runs only in the JD_EBNO_TAIL samples before those
+                const int to_emit = (g.endRotation + (int)(200 * SPS)) - cntr;
+                if (i >= n - JD_EBNO_TAIL || (to_emit >= 0 && to_emit < JD_EBNO_TAIL) || startstop <= JD_EBNO_TAIL)
+                {
+                    const double e2val = eb_e2sum / eb_len_d, mean = eb_esum / eb_len_d;
+                    const double var = e2val - (mean * mean);
+                    const double alpha = sqrt(2.0) / mean;
+                    double tebno = 10.0 * (log10(2.0) - log10(((var * alpha * alpha) - 0.0085))) - 5.0;
+                    if (isnan(tebno)) tebno = 50;
+                    if (tebno > 50.0) tebno = 50;
+                    eb_ebno = eb_ebno * 0.8 + 0.2 * tebno;
+                }
             }
             if (cntr == g.endRotation + (200 * SPS)) bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_EBNO, eb_ebno);
             {
                 double *ap = agc2_ring + agc2_pos;
-                agc2_sum = agc2_sum - *ap; agc2_sum = agc2_sum + fabs(sabs); *ap = fabs(sabs);
+                agc2_sum = agc2_sum - agc2_old; agc2_sum = agc2_sum + fabs(sabs); *ap = fabs(sabs);
                 agc2_pos++; if (agc2_pos >= g.agc2_len) agc2_pos = 0;
                 double gain = 1.414213562 / fmax(agc2_sum / agc2_len_d, 0.000001);
                 gain = fmax(gain, 0.000001);
@@ -523,8 +597,8 @@ __global__ __launch_bounds__(64) void k_burst_msk_demod(const BGeom g, const BPt
             if (abval > 2.84) { const double k = (2.84 / abval); sre = k * sre; sim = k * sim; }
             // delayedsmpl.update_dont_touch(sig2)
             dly_ring[dly_pos] = make_double2(sre, sim);
-            dly_pos++; if (dly_pos >= g.dly_len) dly_pos = 0;
-            const double2 ptd = dly_ring[dly_pos];
+            dly_pos = dly_nx;
+            const double2 ptd = ptd_pre; // = dly_ring[dly_pos]: the oldest entry, not the one just written (dly_len >= 2)
             const double pm_re = sre, pm_im = ptd.y;
             double st_eta = hypot(pm_re, pm_im);
             {
@@ -536,10 +610,11 @@ __global__ __launch_bounds__(64) void k_burst_msk_demod(const BGeom g, const BPt
             }
             // delayt8.update(st_eta): integer delay SPS/2
             d8_ring[d8_pos] = st_eta;
-            d8_pos++; if (d8_pos >= g.d8_len) d8_pos = 0;
-            const double d8out = 0.0 * d8_ring[(d8_pos + 1 >= g.d8_len) ? 0 : d8_pos + 1] + 1.0 * d8_ring[d8_pos];
+            d8_pos = d8_nx;
+            const double d8out = 0.0 * d8_a + 1.0 * d8_b; // d8_ring[d8_pos + 1] and d8_ring[d8_pos]: older than the entry just written (d8_len >= 3)
             {
-                const double2 so = cis[jd_cisidx(st_ptr)];
+                double2 so = so_pre;
+                if (st_ptr != st_ptr_top) so = cis[jd_cisidx(st_ptr)];
                 const double m_re = st_eta, m_im = -d8out;
                 const double o_re = so.x * m_re - so.y * m_im, o_im = so.x * m_im + so.y * m_re;
                 const double st_angle_error = atan2(o_im, o_re);
@@ -617,6 +692,8 @@ __global__ __launch_bounds__(64) void k_burst_msk_demod(const BGeom g, const BPt
     BLDI(BI_SOFT_CNT) = soft_cnt; BLDI(BI_SYM_CNT) = sym_cnt; BLDI(BI_EV_CNT) = ev_cnt; BLDI(BI_OVERFLOW) = overflow;
     {
         double *fs = p.firsave + (size_t)ch * 2 * FIRN;
-        for (int k = 0; k < FIRN; k++) { fs[k] = lre[k * 64 + lane]; fs[FIRN + k] = lim[k * 64 + lane]; }
+        for (int k = 0; k < LDSN; k++) { fs[k] = lre[k * 64 + lane]; fs[FIRN + k] = lim[k * 64 + lane]; }
+#pragma unroll
+        for (int j = 0; j < TAILN; j++) { fs[LDSN + j] = tre[j]; fs[FIRN + LDSN + j] = tim[j]; }
     }
 }
