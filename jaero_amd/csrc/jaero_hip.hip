@@ -643,7 +643,7 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         {
             bool sym = true;
             for (int i = 0; i < 55; i++) sym = sym && memcmp(&taps[i], &taps[54 - i], sizeof(double)) == 0;
-            c->oq_pairs = (sym && g.fb != 8400) ? -1 : 0; // -1: front/back pairs allowed (decided below); 0: asymmetric taps -> the single-wavefront kernel reads them from LDS
+            c->oq_pairs = sym ? -1 : 0; // -1: front/back pairs allowed (decided below); 0: asymmetric taps -> the single-wavefront kernel reads them from LDS
             for (int i = 0; i < 28; i++) c->oq_taps.t[i] = taps[i];
         }
         if (g.kind != JAERO_KIND_OQPSK) HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_taps_msk), taps.data(), sizeof(double) * taps.size(), (g.fb >= 1200 ? 0 : 1) * 160 * sizeof(double)));
@@ -686,9 +686,9 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         else if (g.fir_n == 40) MSK_ATTR(40, MSK_LDSN_40) else MSK_ATTR(20, MSK_LDSN_20)
 #undef MSK_ATTR
     }
-    if (g.kind == JAERO_KIND_OQPSK && !c->pre8400)
+    if (g.kind == JAERO_KIND_OQPSK)
     {
-        // 10.5 kbps: front / back pairs (k_oqpsk_fb.h).  Four pairs per workgroup put one front and one back wavefront on every SIMD of a
+        // front / back pairs (k_oqpsk_fb.h; at 8400 bps the two halves take turns, see there).  Four pairs per workgroup put one front and one back wavefront on every SIMD of a
         // CU -- worth it once there are more channel groups than two per CU; smaller banks get one pair per workgroup (two SIMDs per
         // 64 channels).  JAERO_OQPSK_KERNEL=single keeps the single-wavefront kernel (k_oqpsk.h) for A/B comparison.
         const char *e = getenv("JAERO_OQPSK_KERNEL");
@@ -699,9 +699,17 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         if (c->oq_pairs)
         {
             if ((rc = dalloc(c, &c->p.symrec, (size_t)nchp * JD_SYMREC_LEN * 8))) { jaero_destroy(c); return rc; }
-#define FBA(E, C, PP) HIPCHK(hipFuncSetAttribute((const void *)k_oqpsk_fb<55, FB_LDSN, E, C, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, PP * fb_pair_doubles<FB_LDSN>() * (int)sizeof(double)))
-            FBA(false, false, 1); FBA(false, true, 1); FBA(true, false, 1); FBA(true, true, 1);
-            FBA(false, false, 4); FBA(false, true, 4); FBA(true, false, 4); FBA(true, true, 4);
+#define FBA(E, C, PP, X) HIPCHK(hipFuncSetAttribute((const void *)k_oqpsk_fb<55, FB_LDSN, E, C, PP, X>, hipFuncAttributeMaxDynamicSharedMemorySize, PP * fb_pair_doubles<FB_LDSN>() * (int)sizeof(double)))
+            if (c->pre8400)
+            {
+                FBA(false, false, 1, true); FBA(false, true, 1, true); FBA(true, false, 1, true); FBA(true, true, 1, true);
+                FBA(false, false, 4, true); FBA(false, true, 4, true); FBA(true, false, 4, true); FBA(true, true, 4, true);
+            }
+            else
+            {
+                FBA(false, false, 1, false); FBA(false, true, 1, false); FBA(true, false, 1, false); FBA(true, true, 1, false);
+                FBA(false, false, 4, false); FBA(false, true, 4, false); FBA(true, false, 4, false); FBA(true, true, 4, false);
+            }
 #undef FBA
         }
     }
@@ -935,8 +943,9 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
             const int P = c->oq_pairs;
             const dim3 gridp((g.ngroups + P - 1) / P), blockp(P * 128);
             const int ldsp = P * fb_pair_doubles<FB_LDSN>() * (int)sizeof(double);
-#define LFB(E, C, PP) hipLaunchKernelGGL((k_oqpsk_fb<55, FB_LDSN, E, C, PP>), gridp, blockp, ldsp, st, g, c->p, frames, stride, n, skipA, onlyA, fsb, c->oq_taps)
-#define LFBP(E, C) { if (P == 4) LFB(E, C, 4); else LFB(E, C, 1); }
+            const double2 *pf = c->pre8400 ? (const double2 *)(c->pre.out + (size_t)pos * g.nchp) : nullptr;
+#define LFB(E, C, PP, X) hipLaunchKernelGGL((k_oqpsk_fb<55, FB_LDSN, E, C, PP, X>), gridp, blockp, ldsp, st, g, c->p, frames, stride, n, skipA, onlyA, fsb, c->oq_taps, pf)
+#define LFBP(E, C) { if (c->pre8400) { if (P == 4) LFB(E, C, 4, true); else LFB(E, C, 1, true); } else { if (P == 4) LFB(E, C, 4, false); else LFB(E, C, 1, false); } }
             if (eb && cs) LFBP(true, true) else if (eb) LFBP(true, false) else if (cs) LFBP(false, true) else LFBP(false, false)
 #undef LFBP
 #undef LFB

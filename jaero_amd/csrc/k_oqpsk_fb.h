@@ -1,4 +1,4 @@
-// k_oqpsk_fb.h -- sample-loop kernel for the continuous 10.5 kbps OQPSK demodulator, front / back wavefront pairs.
+// k_oqpsk_fb.h -- sample-loop kernel for the continuous OQPSK demodulator (10.5 kbps; 8400 bps with PRE8400), front / back wavefront pairs.
 //
 // Same arithmetic as k_oqpsk.h (OqpskDemodulator::writeData's per-sample loop, JAERO/oqpskdemodulator.cpp:388-605, fb > 8400), one
 // channel per lane, but the per-sample work of 64 channels is shared by TWO wavefronts that run concurrently:
@@ -92,9 +92,14 @@ __device__ __forceinline__ void fb_barrier()
 }
 
 // ------------------------------------------------------------------------------------------------------------------ front half
-template <int FIRN, int LDSN, bool EBNO>
+// PRE8400 (fb == 8400, k_pre8400.h): there is no matched filter in the loop -- the sample is the prefiltered complex value times the
+// carrier NCO's value OF THE SAME SAMPLE (oqpskdemodulator.cpp:436-448), so the front half cannot run ahead of the back half: the two
+// take turns (two barriers per sample).  What the split still buys there: the back half's code (queued output half, exact rewrites)
+// instead of the single-wavefront kernel's, and the A-part of a sample (coarse ring fill, next inputs) under the back half's work.
+template <int FIRN, int LDSN, bool EBNO, bool PRE8400>
 __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const FbLds &L, const int16_t *__restrict__ pcm, int pcm_stride, int n,
-                                         int skip_a_first, int only_a_last, int fir_slot0, int grp, int lane, const JTaps28 &tp)
+                                         int skip_a_first, int only_a_last, int fir_slot0, int grp, int lane, const JTaps28 &tp,
+                                         const double2 *__restrict__ prefilt)
 {
     constexpr int TAILN = FIRN - LDSN;
     double tre[TAILN], tim[TAILN]; // tre[j] = x_re[n-LDSN-j] once x[n] has been pushed
@@ -147,6 +152,7 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const F
     };
 
     double *lre = L.lre, *lim = L.lim, *ltap = L.ltap;
+    if constexpr (!PRE8400)
     {
         const double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
         for (int k = 0; k < LDSN; k++)
@@ -220,6 +226,42 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const F
     short nx_pcm = (live && n > 0) ? pcm[ch] : (short)0;
     double2 nx_cc = cis[jd_cisidx(mc_ptr)];
 
+    if constexpr (PRE8400)
+    {
+        double2 nx_pf = (nB > 0) ? prefilt[ch] : make_double2(0.0, 0.0);
+        fb_barrier(); // the back half has published the carrier table index of sample 0
+        for (int i = 0; i < nB; i++)
+        {
+            // sig2 = mixer2.WTCISValue() * cval_prefiltered[i], then EbNo, AGC, clip -> mailbox: the back half waits for this
+            const int m2i = L.idx[(i & 1) * 64 + lane];
+            const double2 c_m2 = cis[m2i];
+            const double2 pf = nx_pf;
+            const double sre = c_m2.x * pf.x - c_m2.y * pf.y, sim = c_m2.x * pf.y + c_m2.y * pf.x;
+            front_sample(sre, sim, r1_agc, r1_e, r1_e2, i, i & 1);
+            fb_barrier();
+            // under the back half's sample i: this sample's coarse ring entry (K3, :410-415) and the next sample's inputs
+            const double dval = ((double)nx_pcm) / 32768.0;
+            const double2 cc = nx_cc;
+            const bool do_fill = !(i == 0 && skip_a_first) && ((coarse_cnt >= g.Fs_int) || !(flags & JF_CPUREDUCE));
+            if (do_fill) ring_fill(make_double2(cc.x * dval, cc.y * dval));
+            coarse_cnt++; // :431
+            fb_wt_next(mc_ptr, mc_step);
+            if (i + 1 < n)
+            {
+                nx_pcm = live ? pcm[(size_t)(i + 1) * pcm_stride + ch] : (short)0;
+                nx_cc = cis[jd_cisidx(mc_ptr)];
+                nx_pf = prefilt[(size_t)(i + 1) * nchp + ch];
+            }
+            if (i + 1 < nB)
+            {
+                r1_agc = agc_ring[(size_t)agc_pos * 64];
+                if (EBNO) { r1_e = ebe_ring[(size_t)eb_pos * 64]; r1_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
+            }
+            fb_barrier(); // the back half has published the carrier table index of sample i + 1
+        }
+    }
+    else
+    {
     // prologue: sample 0's filter output comes from the saved history
     if (nB > 0)
     {
@@ -287,6 +329,7 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const F
         }
         fb_barrier();
     }
+    } // !PRE8400
     if (only_a_last) // the coarse estimate runs now; the next launch resumes with this sample's B-part
     {
         const double dval = ((double)nx_pcm) / 32768.0;
@@ -299,6 +342,7 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const F
     LDF(S_AGC_SUM) = agc_sum;
     LDF(S_EB_ESUM) = eb_esum; LDF(S_EB_E2SUM) = eb_e2sum; LDF(S_EB_EBNO) = eb_ebno;
     LDI(I_AGC_POS) = agc_pos; LDI(I_EB_POS) = eb_pos; LDI(I_BB_PTR) = bb_ptr; LDI(I_COARSE_CNT) = coarse_cnt;
+    if constexpr (!PRE8400)
     {
         double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
         for (int k = 0; k < LDSN; k++)
@@ -316,7 +360,7 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const F
 }
 
 // ------------------------------------------------------------------------------------------------------------------- back half
-template <bool CAPSYM>
+template <bool CAPSYM, bool PRE8400>
 __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, const FbLds &L, int n, int only_a_last, int grp, int lane)
 {
     const int ch = grp * 64 + lane;
@@ -442,8 +486,14 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, const Fb
     double2 nx_cst = cis[jd_cisidx(st_ptr)];
     fb_barrier();
 
+    double m2fsum = 0; // PRE8400: mixer2_freq_sum of this launch (:447,607)
     for (int i = 0; i < nB; i++)
     {
+        if constexpr (PRE8400)
+        {
+            fb_barrier(); // the front half has formed this sample with the table index published one barrier ago
+            m2fsum += m2_freq;
+        }
         const double2 c_st = nx_cst; // requested at the end of the previous sample
         const double *d = L.data + (i & 1) * 3 * 64 + lane;
         double sre = d[0], sim = d[64];
@@ -497,15 +547,21 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, const Fb
                 double ct_ec = ct_xt_d - ct_xt;
                 if (ct_ec > M_PI) ct_ec = M_PI;
                 if (ct_ec < -M_PI) ct_ec = -M_PI;
+                double lf_y;
                 {
                     double y = 0;
                     y += lf_x2 * g.lf_b2; y += lf_x1 * g.lf_b1; y += ct_ec * g.lf_b0;
                     y -= lf_y2 * g.lf_a2; y -= lf_y1 * g.lf_a1;
                     lf_x2 = lf_x1; lf_x1 = ct_ec; lf_y2 = lf_y1; lf_y1 = y;
-                    ct_ec = y;
+                    lf_y = y;
                 }
-                if (ct_ec > M_PI_2) ct_ec = M_PI_2;
-                if (ct_ec < -M_PI_2) ct_ec = -M_PI_2;
+                if constexpr (!PRE8400)
+                {
+                    ct_ec = lf_y;
+                    if (ct_ec > M_PI_2) ct_ec = M_PI_2;
+                    if (ct_ec < -M_PI_2) ct_ec = -M_PI_2;
+                }
+                // 8400 "works better with faster phase agility" (:526-532): the raw error moves the phase, the filtered one the frequency
                 // mixer2.IncresePhaseDeg(1.0*ct_ec) (DSP.cpp:169-180)
                 {
                     double phase_deg = 1.0 * ct_ec;
@@ -514,7 +570,8 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, const Fb
                     while (phase_deg < 0) phase_deg += 360.0;
                     m2_ptr = jd_div_const(phase_deg, 360.0, r_360) * wtsize_d;
                 }
-                fb_wt_setfreq(m2_freq, m2_step, (0.01 * ct_ec) + m2_freq, samplerate, r_samplerate);
+                if constexpr (PRE8400) fb_wt_setfreq(m2_freq, m2_step, (0.5 * 0.01 * lf_y) + m2_freq, samplerate, r_samplerate);
+                else fb_wt_setfreq(m2_freq, m2_step, (0.01 * ct_ec) + m2_freq, samplerate, r_samplerate);
                 queue_symbol(ct_ec, pt_re, ptd_im);
             }
         }
@@ -550,13 +607,15 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, const Fb
     LDI(I_MARG_POS) = marg_pos; LDI(I_DT_POS) = dt_pos; LDI(I_PM_POS) = pm_pos; LDI(I_MSEMA_POS) = msema_pos;
     LDI(I_YUI) = yui; LDI(I_SIG2L_INIT) = sig2l_init;
     LDI(I_SOFT_CNT) = soft_cnt; LDI(I_SYM_CNT) = sym_cnt; LDI(I_OVERFLOW) = overflow;
+    if constexpr (PRE8400) LDF(S_PRE_FSUM) = LDF(S_PRE_FSUM) + m2fsum;
 }
 
 // PAIRS front/back pairs per workgroup: waves 0..PAIRS-1 are the front halves of channel groups blockIdx.x*PAIRS + w, waves
 // PAIRS..2*PAIRS-1 the back halves of the same groups.  A pair whose group lies beyond the bank only keeps the barrier count.
-template <int FIRN, int LDSN, bool EBNO, bool CAPSYM, int PAIRS>
+template <int FIRN, int LDSN, bool EBNO, bool CAPSYM, int PAIRS, bool PRE8400 = false>
 __global__ __launch_bounds__(PAIRS * 128) void k_oqpsk_fb(const JGeom g, const JPtrs p, const int16_t *__restrict__ pcm, int pcm_stride, int n,
-                                                          int skip_a_first, int only_a_last, int fir_slot0, const JTaps28 tp)
+                                                          int skip_a_first, int only_a_last, int fir_slot0, const JTaps28 tp,
+                                                          const double2 *__restrict__ prefilt)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -572,9 +631,10 @@ __global__ __launch_bounds__(PAIRS * 128) void k_oqpsk_fb(const JGeom g, const J
     if (grp >= g.ngroups)
     {
         const int nB = n - (only_a_last ? 1 : 0);
-        for (int i = 0; i <= nB; i++) fb_barrier();
+        const int nbar = PRE8400 ? 2 * nB + 1 : nB + 1;
+        for (int i = 0; i < nbar; i++) fb_barrier();
         return;
     }
-    if (back) fb_back<CAPSYM>(g, p, L, n, only_a_last, grp, lane);
-    else fb_front<FIRN, LDSN, EBNO>(g, p, L, pcm, pcm_stride, n, skip_a_first, only_a_last, fir_slot0, grp, lane, tp);
+    if (back) fb_back<CAPSYM, PRE8400>(g, p, L, n, only_a_last, grp, lane);
+    else fb_front<FIRN, LDSN, EBNO, PRE8400>(g, p, L, pcm, pcm_stride, n, skip_a_first, only_a_last, fir_slot0, grp, lane, tp, prefilt);
 }
