@@ -52,24 +52,23 @@ __global__ __launch_bounds__(64) void k_pre8400_mix(const JGeom g, const JPtrs p
     }
     const double2 *__restrict__ cis = p.cis;
     const int rmask = q.ring - 1;
-    // down (:354-364)
+    // down (:354-364) and up (:371-379: SetPhaseDeg(savedphase), then the same number of frames): two independent oscillators with
+    // the same step, advanced in one loop (as two loops each waited for its own table gathers and stores: 3.6 ms per step)
     const double savedphase = (360.0 * ptr / ((double)JD_WTSIZE)); // GetPhaseDeg
-    double pd = ptr, sd = step;
-    for (int i = 0; i < n; i++)
-    {
-        const short s = live ? pcm[(size_t)i * pcm_stride + ch] : (short)0;
-        const double dval = ((double)s) / 32768.0;
-        const double2 c = cis[jd_cisidx(pd)];
-        q.xring[(size_t)((int)((n0 + i) & rmask)) * nchp + ch] = make_double2(c.x * dval, c.y * dval);
-        jd_wt_next(pd, sd);
-    }
-    // up (:371-379): SetPhaseDeg(savedphase), then the same number of frames
     double phase = fmod(savedphase, 360.0);
     while (phase < 0) phase += 360.0;
+    double pd = ptr, sd = step;
     double pu = (phase / 360.0) * ((double)JD_WTSIZE), su = step;
+    short nx = (live && n > 0) ? pcm[ch] : (short)0;
     for (int i = 0; i < n; i++)
     {
+        const short s = nx;
+        if (i + 1 < n) nx = live ? pcm[(size_t)(i + 1) * pcm_stride + ch] : (short)0;
+        const double dval = ((double)s) / 32768.0;
+        const double2 c = cis[jd_cisidx(pd)];
         q.cidx[(size_t)i * nchp + ch] = (unsigned short)jd_cisidx(pu);
+        q.xring[(size_t)((int)((n0 + i) & rmask)) * nchp + ch] = make_double2(c.x * dval, c.y * dval);
+        jd_wt_next(pd, sd);
         jd_wt_next(pu, su);
     }
     p.S[(size_t)S_PRE_PTR * nchp + ch] = pu;
