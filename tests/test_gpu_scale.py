@@ -73,6 +73,45 @@ def test_oqpsk_4096_channels(B, oracle_mod, capture, chunk):
     bank.close()
 
 
+@pytest.mark.parametrize("fb", [10500.0, 8400.0])
+def test_oqpsk_65536_channels(B, oracle_mod, fb):
+    """The bank bench.py times: 65 536 channels (four front / back pairs per workgroup, 256 persistent coarse estimates per workgroup and
+    launch), per-channel carriers, bits, noise and symbol-clock phases, at 10.5 kbps and at 8400 bps (prefilter + pair kernel with the
+    halves taking turns).  28 672 samples = 7 estimates per channel; 20 channels spread over the bank against their oracle runs: soft
+    bits, status rows (freq_est, freq_center, mse, EbNo)."""
+    import torch
+
+    from jaero_amd import capi
+    from jaero_amd import signalgen as G
+
+    free, _ = torch.cuda.mem_get_info(0)
+    if free < 250 * (1 << 30):
+        pytest.skip("needs ~250 GB of free HBM")
+    O = oracle_mod
+    nch, chunk, nsteps = 65536, 4096, 7
+    dev = torch.device("cuda", 0)
+    gen = G.OqpskTorchStream(nch, nsteps * chunk, dev, fb=fb, ebno_db=11.0, seed=G.SEED_BASE + 65536, nphase=32)
+    st = B.OqpskSettings(fb=fb, lockingbw=fb, coarsefreqest_fft_power=14)
+    bank = B.DemodulatorBank(st, nch, ebno=True, status_log=True, max_write_samples=chunk, softbit_capacity=int(nsteps * chunk * fb / 48000) + 64)
+    check = sorted({0, 63, 64, 255, 256, 257, 511, 1023, 4095, 4096, 16383, 16384, 16385, 30000, 32767, 32768, 50001, 65471, 65472, 65535})
+    cidx = torch.tensor(check, dtype=torch.long, device=dev)
+    host = []
+    for i in range(nsteps):
+        blk = gen.render(i * chunk, chunk)
+        host.append(blk[:, cidx].cpu().numpy())
+        bank.write(blk, layout=capi.PCM_FRAME_MAJOR)
+        del blk
+    x = np.concatenate(host)  # [nsamples][len(check)]
+    nsoft = 0
+    for k, c in enumerate(check):
+        ref = O.run_demod(O.oqpsk_settings(fb=fb, lockingbw=fb), np.ascontiguousarray(x[:, k]), chunk=chunk)
+        assert ref["status"].shape[0] == nsteps
+        compare(bank.read_softbits(c), None, bank.read_status_log(c), ref)
+        nsoft += len(ref["soft"])
+    assert nsoft > len(check) * 1000
+    bank.close()
+
+
 @pytest.mark.parametrize("nch,nsamp", [(256, 50000), (1024, 30000)])
 def test_msk_1200_banks(B, oracle_mod, nch, nsamp):
     """BASELINE configs[1]: 256-channel synthetic 48 kHz 1200 bps MSK (one estimate per workgroup and launch), and 1024 channels
