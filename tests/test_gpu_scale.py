@@ -112,6 +112,43 @@ def test_oqpsk_65536_channels(B, oracle_mod, fb):
     bank.close()
 
 
+def test_msk_65536_channels(B, oracle_mod):
+    """The bank `bench.py --workload msk` times: 65 536 channels of 1200 bps MSK (four k_msk_samples wavefronts per CU, k_coarse2<13> with
+    256 persistent estimates per workgroup and launch, two launches per 4096-sample write).  37 distinct signals, channel c carries
+    signal (5 c) mod 37 (so that neighbouring lanes, wavefronts and workgroup iterations all differ); 20 spread channels against the
+    oracle run of their signal."""
+    import torch
+
+    from jaero_amd import capi
+    from jaero_amd import signalgen as G
+
+    free, _ = torch.cuda.mem_get_info(0)
+    if free < 200 * (1 << 30):
+        pytest.skip("needs ~200 GB of free HBM")
+    O = oracle_mod
+    nch, chunk, nsteps, nuniq = 65536, 4096, 7, 37
+    dev = torch.device("cuda", 0)
+    nsamp = nsteps * chunk
+    uniq = np.stack([G.msk(nsamp, fb=1200.0, fc=1000.0 + 4.0 * (u % 9 - 4), ebno_db=11.0, seed=G.SEED_BASE + 650 + u)[0] for u in range(nuniq)])
+    idx = (torch.arange(nch, device=dev) * 5) % nuniq
+    pcm = torch.from_numpy(np.ascontiguousarray(uniq.T)).to(dev)[:, idx].contiguous()  # frame-major [nsamp, nch]
+    bank = B.DemodulatorBank(B.MskSettings(fb=1200.0, lockingbw=1800.0, freq_center=1000.0), nch, ebno=True, status_log=True,
+                             max_write_samples=chunk, softbit_capacity=int(nsamp * 1200 / 48000) + 64)
+    for s0 in range(0, nsamp, chunk):
+        bank.write(pcm[s0:s0 + chunk], layout=capi.PCM_FRAME_MAJOR)
+    check = sorted({0, 63, 64, 255, 256, 257, 511, 1023, 4095, 4096, 16383, 16384, 16385, 30000, 32767, 32768, 50001, 65471, 65472, 65535})
+    refs = {}
+    nsoft = 0
+    for c in check:
+        u = (c * 5) % nuniq
+        if u not in refs:
+            refs[u] = O.run_demod(O.msk_settings(fb=1200.0, lockingbw=1800.0), uniq[u], chunk=chunk)
+        compare(bank.read_softbits(c), None, bank.read_status_log(c), refs[u])
+        nsoft += len(refs[u]["soft"])
+    assert nsoft > len(check) * 300
+    bank.close()
+
+
 @pytest.mark.parametrize("nch,nsamp", [(256, 50000), (1024, 30000)])
 def test_msk_1200_banks(B, oracle_mod, nch, nsamp):
     """BASELINE configs[1]: 256-channel synthetic 48 kHz 1200 bps MSK (one estimate per workgroup and launch), and 1024 channels
