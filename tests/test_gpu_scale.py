@@ -187,9 +187,9 @@ def test_burst_oqpsk_4096_channels(B, oracle_mod):
     # Digital silence for the first half second (it swallows every channel's first burst).  Where the reference's Hilbert filter --
     # an FFT overlap-add (JFastFir) -- should output exact zeros (before the first signal sample has travelled through its 6145-sample
     # latency) it emits round-off of the block that holds the signal's start, ~1e-12 of full scale, which the AGC at its gain cap of
-    # 1.4e6 turns into "symbols" of ~1e-4 if a burst gate happens to be open then; the direct-form filter here gives exact zeros.
-    # With silence first no gate is open in that stretch, and that artefact of the FFT library (JFFT there, a stand-in in the oracle)
-    # stays out of the comparison.
+    # 1.4e6 turns into "symbols" of ~1e-4 if a burst gate happens to be open then; the filter here (overlap-save too, but with its own
+    # 4096-point blocks) gives exact zeros or its own round-off there.  With silence first no gate is open in that stretch, and that
+    # artefact of the FFT library (JFFT there, a stand-in in the oracle) stays out of the comparison.
     pcm[:24000] = 0
     bank = B.DemodulatorBank(B.BurstOqpskSettings(), nch, capture_symbols=True, trace=True, max_write_samples=chunk, softbit_capacity=30000)
     feed_frames(bank, pcm, chunk)
@@ -207,6 +207,37 @@ def test_burst_oqpsk_4096_channels(B, oracle_mod):
         assert np.max(np.abs(sym - ref["symbols"])[~noise_only], initial=0.0) < SYM_TOL
         nacc += int((ref["soft"] == -1).sum())
     assert nacc >= 5  # one whole burst per channel in view (right behind half a second of silence: not every one is accepted)
+    bank.close()
+
+
+def test_burst_oqpsk_65536_channels(B, oracle_mod):
+    """The bank `bench.py --workload burst_oqpsk` times: 65 536 channels, one burst per second and channel at random offsets
+    (k_hilbert_fft with 8192 workgroups x 2 blocks per segment, k_trident's persistent workgroups with thousands of events per segment).
+    20 spread channels against their oracle runs: soft bits (with the -1 markers) and events."""
+    import torch
+
+    from jaero_amd import signalgen as G
+    from test_gpu_burst import check_events, check_soft
+
+    free, _ = torch.cuda.mem_get_info(0)
+    if free < 200 * (1 << 30):
+        pytest.skip("needs ~200 GB of free HBM")
+    O = oracle_mod
+    nch, nsamp, chunk = 65536, 26 * 4096, 4096
+    dev = torch.device("cuda", 0)
+    pcm, _, _ = G.burst_oqpsk_torch(nch, nsamp, dev, ndata_sym=1500, ebno_db=15.0, seed=G.SEED_BASE + 65537)
+    pcm[:24000] = 0  # as in test_burst_oqpsk_4096_channels
+    bank = B.DemodulatorBank(B.BurstOqpskSettings(), nch, max_write_samples=chunk, softbit_capacity=30000)
+    feed_frames(bank, pcm, chunk)
+    check = sorted({0, 63, 64, 255, 256, 257, 511, 1023, 4095, 4096, 16383, 16384, 16385, 30000, 32767, 32768, 50001, 65471, 65472, 65535})
+    nacc = 0
+    for c in check:
+        x = pcm[:, c].cpu().numpy()
+        ref = O.run_burst(O.burst_oqpsk_settings(), x, chunk=chunk)
+        check_soft(bank.read_softbits(c), ref["soft"], f"channel {c}")
+        check_events(bank.read_events(c), ref["events"])
+        nacc += int((ref["soft"] == -1).sum())
+    assert nacc >= 10
     bank.close()
 
 
