@@ -203,6 +203,18 @@ def test_msk_at_other_sample_rates(B, oracle_mod, Fs, fb):
     bank.close()
 
 
+def test_unsupported_rates_are_refused(B):
+    """What a bank cannot be is refused at creation with JAERO_ENOTSUP (not silently run at another rate): OQPSK away from 48 kHz, MSK
+    at a rate without a kernel, bit rates the reference's GUI does not offer."""
+    from jaero_amd import capi
+
+    for st in (B.OqpskSettings(Fs=24000.0), B.MskSettings(fb=1200.0, lockingbw=1800.0, Fs=44100.0), B.MskSettings(fb=2400.0, lockingbw=3600.0),
+               B.OqpskSettings(fb=9600.0)):
+        with pytest.raises(capi.JaeroError) as e:
+            B.DemodulatorBank(st, 1)
+        assert e.value.code == capi.E_NOTSUP, st
+
+
 def test_chunking_and_layout_invariance(B):
     """Same stream fed as 4096-sample channel-major writes, odd-sized writes, and frame-major device tensors."""
     import torch
