@@ -7,12 +7,13 @@
 #include "burst_device.h"
 #include "jaero_device.h"
 #include "k_burst_front.h"
+#include "k_oqpsk_fb.h" // jd_div_const, fb_wt_setfreq, fb_fmod360: exact rewrites (bit-identical results, fewer instructions)
 
 __device__ __forceinline__ void bd_set_phase_deg(double &ptr, double phase_deg) // WaveTable::SetPhaseDeg (DSP.cpp:175-180)
 {
-    phase_deg = fmod(phase_deg, 360.0);
+    phase_deg = fb_fmod360(phase_deg);
     while (phase_deg < 0) phase_deg += 360.0;
-    ptr = (phase_deg / 360.0) * ((double)JD_WTSIZE);
+    ptr = jd_div_const(phase_deg, 360.0, 1.0 / 360.0) * ((double)JD_WTSIZE);
 }
 __device__ __forceinline__ void bd_event(const BGeom &g, const BPtrs &p, int ch, int &ev_cnt, int &overflow, long long sample, int kind, double value)
 {
@@ -84,6 +85,9 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
     int s_val = (int)((n0 - g.D1 - g.D2 + 8LL * g.cv_len) % g.cv_len);
     const double w4 = g.w4, w4c = 1.0 - g.w4, w8 = g.w8, w8c = 1.0 - g.w8, a1w = g.a1_w, a1wc = 1.0 - g.a1_w;
     const double agc2_len_d = (double)g.agc2_len, eb_len_d = (double)g.eb_len;
+    // divisions by these constants: reciprocal + two fma corrections (jd_div_const, bit-identical to the quotient)
+    const double r_agc2_len = 1.0 / agc2_len_d, r_samplerate = 1.0 / samplerate, r_360 = 1.0 / 360.0, wtsize_d = (double)JD_WTSIZE, r_wtsize = 1.0 / wtsize_d;
+    const double msema_len_d = (double)g.msema_len, r_msema_len = 1.0 / msema_len_d;
 
     // ring entries of sample i+1 are requested at the top of iteration i (all slots are wave-uniform and data independent)
     double nx_val = cvre[(size_t)s_val * 64], nx_agc2 = agc2_ring[(size_t)s_agc2 * 64];
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
             double t_re = sre, t_im = sim;
             bd_cmul(t_re, t_im, str_re, str_im);
             bd_cmul(t_re, t_im, 0.0, 1.0);
-            const double er = tanh(t_im) * (t_re);
+            const double er = jd_tanh(t_im) * (t_re);
             double sn, cs;
             sincos(er * 0.01, &sn, &cs);
             bd_cmul(str_re, str_im, cs, sn);
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
             double st_err = atan2(e_im, e_re);
             st_err *= 1.5 * (1.0 - progress * progress);
             jd_wt_advance_fraction(stq_ptr, -(1.0 / (2.0 * M_PI)) * st_err * 0.1);
-            bd_set_phase_deg(st_ptr, (360.0 * stq_ptr / ((double)JD_WTSIZE)) * 4.0 + (360.0 * g.ee));
+            bd_set_phase_deg(st_ptr, jd_div_const(360.0 * stq_ptr, wtsize_d, r_wtsize) * 4.0 + (360.0 * g.ee));
         }
         // ---- carrier phase correction, EbNo, AGC, clip (:570-590) ----
         bd_cmul(sre, sim, sav_re, sav_im);
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
             double *ap = agc2_ring + (size_t)s_agc2 * 64;
             agc2_sum = agc2_sum - agc2_old; agc2_sum = agc2_sum + fabs(sig2abs); *ap = fabs(sig2abs);
             s_agc2++; if (s_agc2 >= g.agc2_len) s_agc2 = 0;
-            double gain = 1.414213562 / fmax(agc2_sum / agc2_len_d, 0.000001);
+            double gain = 1.414213562 / fmax(jd_div_const(agc2_sum, agc2_len_d, r_agc2_len), 0.000001);
             gain = fmax(gain, 0.000001);
             sre *= gain; sim *= gain;
         }
@@ -243,11 +247,11 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
             const double st_angle_error = atan2(o_im, o_re);
             if (cntr > SPS * (128 + 64))
             {
-                jd_wt_setfreq(st_freq, st_step, (-st_angle_error * 0.00000001) + st_freq, samplerate);
-                jd_wt_advance_fraction(st_ptr, -st_angle_error * 0.01 / 360.0);
+                fb_wt_setfreq(st_freq, st_step, (-st_angle_error * 0.00000001) + st_freq, samplerate, r_samplerate);
+                jd_wt_advance_fraction(st_ptr, jd_div_const(-st_angle_error * 0.01, 360.0, r_360));
             }
-            if (st_freq < (g.stref_freq - 0.1)) jd_wt_setfreq(st_freq, st_step, (g.stref_freq - 0.1), samplerate);
-            if (st_freq > (g.stref_freq + 0.1)) jd_wt_setfreq(st_freq, st_step, (g.stref_freq + 0.1), samplerate);
+            if (st_freq < (g.stref_freq - 0.1)) fb_wt_setfreq(st_freq, st_step, (g.stref_freq - 0.1), samplerate, r_samplerate);
+            if (st_freq > (g.stref_freq + 0.1)) fb_wt_setfreq(st_freq, st_step, (g.stref_freq + 0.1), samplerate, r_samplerate);
         }
         // ---- sample times (:615-724) ----
         double frac;
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
         {
             const double pt_last = frac, pt_this = 1.0 - pt_last;
             const double pt_re = pt_this * sre + pt_last * sig2l_re, pt_im = pt_this * sim + pt_last * sig2l_im;
-            const double twospeed = -4.0 * ((fmod((360.0 * stq_ptr / ((double)JD_WTSIZE)) * 2.0 + (360.0 * g.ee * 0.5), 360.0) / 360.0) - (0.34046 + 0.4111 * g.ee));
+            const double twospeed = -4.0 * (jd_div_const(fb_fmod360(jd_div_const(360.0 * stq_ptr, wtsize_d, r_wtsize) * 2.0 + (360.0 * g.ee * 0.5)), 360.0, r_360) - (0.34046 + 0.4111 * g.ee));
             const bool even = !(twospeed < 0);
             yui++; yui %= 2;
             if (cntr < ((128 + 128) * SPS))
@@ -266,8 +270,8 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
             else
             {
                 const double q_re = pt_re, q_im = ptd_im;
-                const double ct_xt = tanh(pt_im) * pt_re;
-                const double ct_xt_d = tanh(ptd_re) * ptd_im;
+                const double ct_xt = jd_tanh(pt_im) * pt_re;
+                const double ct_xt_d = jd_tanh(ptd_re) * ptd_im;
                 double ct_ec = ct_xt_d - ct_xt;
                 if (ct_ec > M_PI) ct_ec = M_PI;
                 if (ct_ec < -M_PI) ct_ec = -M_PI;
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
                     double *mp = msema_ring + msema_pos;
                     msema_sum = msema_sum - *mp; msema_sum = msema_sum + fabs(e); *mp = fabs(e);
                     msema_pos++; if (msema_pos >= g.msema_len) msema_pos = 0;
-                    mse = msema_sum / ((double)g.msema_len);
+                    mse = jd_div_const(msema_sum, msema_len_d, r_msema_len);
                 }
                 if (startstop > 0)
                 {
@@ -537,7 +541,7 @@ __global__ __launch_bounds__(64) void k_burst_msk_demod(const BGeom g, const BPt
                 double t_re = sre, t_im = sim;
                 bd_cmul(t_re, t_im, str_re, str_im);
                 bd_cmul(t_re, t_im, 0.0, 1.0);
-                const double er = tanh(t_im) * (t_re);
+                const double er = jd_tanh(t_im) * (t_re);
                 double sn, cs;
                 sincos(er * 0.5, &sn, &cs);
                 bd_cmul(str_re, str_im, cs, sn);
@@ -623,8 +627,8 @@ __global__ __launch_bounds__(64) void k_burst_msk_demod(const BGeom g, const BPt
             double frac;
             if (jd_wt_passed(st_last, st_ptr, st_step, g.ee, frac))
             {
-                const double ct_xt = tanh(sim) * sre;
-                const double ct_xt_d = tanh(ptd.x) * ptd.y;
+                const double ct_xt = jd_tanh(sim) * sre;
+                const double ct_xt_d = jd_tanh(ptd.x) * ptd.y;
                 double ct_ec = ct_xt_d - ct_xt;
                 if (ct_ec > M_PI) ct_ec = M_PI;
                 if (ct_ec < -M_PI) ct_ec = -M_PI;
