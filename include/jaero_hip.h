@@ -122,7 +122,9 @@ int jaero_create(int device, int nchannels, const jaero_settings *settings, int 
                  unsigned flags, int max_write_samples, int softbit_capacity, jaero_ctx **out);
 void jaero_destroy(jaero_ctx *ctx);
 
-/* channel = -1 applies to every channel */
+/* setSettings on a live channel (channel = -1: every channel), enqueued on the stream of the bank's last jaero_write: the channel's state
+ * becomes what the reference's setSettings leaves behind.  kind, fb, Fs and the FFT power are fixed per bank (JAERO_EINVAL if they differ);
+ * burst banks and 8400 bps banks take no live setSettings (JAERO_ENOTSUP): create a new bank (the Qt adaptors of integration/qt do). */
 int jaero_set_settings(jaero_ctx *ctx, int channel, const jaero_settings *s);
 int jaero_set_flags(jaero_ctx *ctx, int channel, int afc, int sql, int cpu_reduce);
 int jaero_set_dcd(jaero_ctx *ctx, int channel, int dcd);

@@ -102,7 +102,13 @@ protected:
             return;
         }
         else if (jaero_set_settings(ctx, 0, &js) != JAERO_OK)
-            emit WarningTextSignal(QString("libjaero_hip: %1").arg(jaero_last_error()));
+        {
+            // what a live bank cannot take (8400 bps: the prefilter would have to restart for one channel): replace the bank
+            jaero_destroy(ctx);
+            ctx = nullptr;
+            applySettings(js);
+            return;
+        }
         cur = js;
         if (js.Fs != Fs) { Fs = js.Fs; emit SampleRateChanged(Fs); }
         if (js.fb != fb) { fb = js.fb; emit BitRateChanged(fb, false); }

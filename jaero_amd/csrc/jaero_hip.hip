@@ -822,6 +822,9 @@ extern "C" int jaero_set_settings(jaero_ctx *c, int channel, const jaero_setting
     // synchronisation, no copy of the bank's state.
     if (!c || !s || channel < -1 || channel >= c->o_nch) return fail(JAERO_EINVAL, "jaero_set_settings: bad arguments");
     if (c->burst) return fail(JAERO_ENOTSUP, "jaero_set_settings on a live burst bank is not implemented; create a new bank");
+    // fb = 8400: the reference's setSettings also re-creates the prefilter (JFastFir::SetKernel: empty history, 2048 zeros of latency, transform
+    // blocks re-aligned to that moment), which k_pre8400_fft's bank-wide block alignment cannot do for one channel
+    if (c->pre8400) return fail(JAERO_ENOTSUP, "jaero_set_settings on a live 8400 bps bank is not implemented; create a new bank");
     int rc = validate_settings(*s);
     if (rc) return rc;
     const JGeom &g = c->g;

@@ -213,6 +213,13 @@ def test_unsupported_rates_are_refused(B):
         with pytest.raises(capi.JaeroError) as e:
             B.DemodulatorBank(st, 1)
         assert e.value.code == capi.E_NOTSUP, st
+    # and what a live bank cannot take: setSettings at 8400 bps (the prefilter would have to restart for one channel)
+    st = B.OqpskSettings(fb=8400.0, lockingbw=8400.0, coarsefreqest_fft_power=14)
+    bank = B.DemodulatorBank(st, 2)
+    with pytest.raises(capi.JaeroError) as e:
+        bank.set_settings(st, channel=0)
+    assert e.value.code == capi.E_NOTSUP
+    bank.close()
 
 
 def test_chunking_and_layout_invariance(B):
