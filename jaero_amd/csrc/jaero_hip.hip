@@ -21,6 +21,7 @@
 #include "k_oqpsk.h"
 #include "k_oqpsk_fb.h"
 #include "k_msk.h"
+#include "k_msk_fb.h"
 #include "k_pre8400.h"
 #include "k_coarse.h"
 #include "k_coarse2.h"
@@ -149,6 +150,7 @@ struct jaero_ctx
     int *d_emitted = nullptr; // burst banks: per-channel count of soft bits already emitted (jaero_softbits_view)
     int msk_ldsn = 0; // MSK: matched-filter inputs kept in LDS (the rest of fir_n in registers)
     std::vector<int> dly_t0; // MSK: shared delay-line slot at which each channel's delayedsmpl pointer last restarted (jaero_set_settings)
+    int msk_pairs = 0; // MSK with an 80-tap filter: front/back pairs per workgroup of k_msk_fb (0 = k_msk_samples)
     int oq_pairs = 0; // 10.5 kbps OQPSK: front/back pairs per workgroup of k_oqpsk_fb (0 = the single-wavefront kernel k_oqpsk_samples)
     int oq_ldsn = OQ_LDSN;
     JTaps28 oq_taps{}; // the 28 distinct values of the (bitwise symmetric) 55-tap RRC, scalar operands of k_oqpsk_fb's filter
@@ -685,6 +687,24 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         if (g.fir_n == 80) MSK_ATTR(80, MSK_LDSN_1200) else if (g.fir_n == 160) MSK_ATTR(160, MSK_LDSN_600)
         else if (g.fir_n == 40) MSK_ATTR(40, MSK_LDSN_40) else MSK_ATTR(20, MSK_LDSN_20)
 #undef MSK_ATTR
+        if (g.fir_n == 80)
+        {
+            // front / back pairs (k_msk_fb.h) for banks of at most two channel groups per CU: one pair per workgroup, the two halves on
+            // different SIMDs (256 channels: 82 -> 113 Msamples/s, 16 384: 4.07 -> 4.94 G).  Larger banks keep k_msk_samples: the front
+            // half's 44-deep register tail does not fit the 256 registers a wavefront has at two per SIMD (four pairs per workgroup:
+            // 458 spilled registers, 6.6 against 9.25 Gsamples/s at 65 536 channels).  JAERO_MSK_KERNEL=single|pairs1|pairs4 forces one.
+            const char *e = getenv("JAERO_MSK_KERNEL");
+            const int ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            c->msk_pairs = (e && !strcmp(e, "single")) ? 0 : ((e && !strcmp(e, "pairs1")) ? 1 : ((e && !strcmp(e, "pairs4")) ? 4 : (g.ngroups > 2 * ncu ? 0 : 1)));
+            if (c->msk_pairs)
+            {
+                c->msk_ldsn = MFB_LDSN;
+#define MFA(E, C, PP) HIPCHK(hipFuncSetAttribute((const void *)k_msk_fb<80, MFB_LDSN, E, C, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, PP * mfb_pair_doubles<80, MFB_LDSN>() * (int)sizeof(double)))
+                MFA(false, false, 1); MFA(false, true, 1); MFA(true, false, 1); MFA(true, true, 1);
+                MFA(false, false, 4); MFA(false, true, 4); MFA(true, false, 4); MFA(true, true, 4);
+#undef MFA
+            }
+        }
     }
     if (g.kind == JAERO_KIND_OQPSK)
     {
@@ -969,6 +989,18 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
         const int ldsn = c->msk_ldsn;
         const int lds = (2 * ldsn * 64 + g.fir_n) * (int)sizeof(double); // rings + this wavefront's copy of the taps
         const int fs = (int)(c->m.nB_total % ldsn), ds = (int)(c->m.nB_total % (g.sps + 1)), d8 = (int)(c->m.nB_total % (g.sps2 + 1));
+        if (c->msk_pairs)
+        {
+            const int P = c->msk_pairs;
+            const dim3 gridp((g.ngroups + P - 1) / P), blockp(P * 128);
+            const int ldsp = P * mfb_pair_doubles<80, MFB_LDSN>() * (int)sizeof(double);
+#define LMF(E, C, PP) hipLaunchKernelGGL((k_msk_fb<80, MFB_LDSN, E, C, PP>), gridp, blockp, ldsp, st, g, c->p, frames, stride, n, skipA, onlyA, fs, ds, d8)
+#define LMFP(E, C) { if (P == 4) LMF(E, C, 4); else LMF(E, C, 1); }
+            if (eb && cs) LMFP(true, true) else if (eb) LMFP(true, false) else if (cs) LMFP(false, true) else LMFP(false, false)
+#undef LMFP
+#undef LMF
+            return;
+        }
 #define LM(F, L, E, C) hipLaunchKernelGGL((k_msk_samples<F, L, E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs, ds, d8)
 #define LMS(F, L) { if (eb && cs) LM(F, L, true, true); else if (eb) LM(F, L, true, false); else if (cs) LM(F, L, false, true); else LM(F, L, false, false); }
         if (g.fir_n == 80) LMS(80, MSK_LDSN_1200) else if (g.fir_n == 160) LMS(160, MSK_LDSN_600)

@@ -1,0 +1,461 @@
+// k_msk_fb.h -- sample-loop kernel for the continuous MSK demodulator with an 80-tap matched filter (1200 bps at 48 kHz, 600 bps at
+// 24 kHz), front / back wavefront pairs.
+//
+// Same arithmetic as k_msk.h (MskDemodulator::writeData's per-sample loop, JAERO/mskdemodulator.cpp:319-485), one channel per lane, the
+// per-sample work of 64 channels shared by two wavefronts exactly as in k_oqpsk_fb.h:
+//
+//   F ("front"):  PCM -> double, coarse ring fill (mixer_center), mix with the carrier NCO value the back half hands over, half-sine
+//                 matched filter (history in LDS + registers), MSKEbNoMeasure, AGC + clip.  Owns the PCM / AGC / EbNo / coarse-ring
+//                 streams and the filter history.
+//   B ("back"):   the SPS-sample delayed arm, |pt_msk| -> resonator -> quadrature delay -> symbol PLL weighted by 1 - |tanh(err)|, and at
+//                 symbol instants the carrier loop, residual rotation, MSE, soft differential decode, soft bits; the carrier NCO.  Owns
+//                 the two delay lines, the symbol-rate windows and the outputs.
+//
+// The matched filter's output for sample n+1 does not contain x[n+1] (FIR::FIRUpdateAndProcess excludes the newest sample,
+// DSP.cpp:292-304) and x[n] = mixer2(n) * pcm[n] is known once the back half has finished sample n-1: while B runs sample n, F forms
+// x[n], pushes it and produces the AGC'd, clipped sample n+1.  One LDS-only barrier per sample, double-buffered mailboxes.
+// Only the front half needs LDS: 36 of the 80 history entries of each arm + the taps + the mailboxes = 40 064 B per pair, so four pairs
+// per workgroup would fit a CU (160 256 B) -- but the other 44 entries of each arm live in the front half's registers (176 of them), which
+// fits the 512 registers of a wavefront alone on its SIMD and not the 256 it has at two per SIMD.  Used, therefore, for banks of at
+// most two channel groups per CU with ONE pair per workgroup (the halves on different SIMDs): measured on an MI355X, 256 channels
+// 82 -> 113 Msamples/s, 16 384 channels 4.07 -> 4.94 Gsamples/s; with four pairs per workgroup at 65 536 channels 458 registers spill
+// and it is slower than k_msk_samples (6.6 against 9.25 Gsamples/s), which larger banks keep.  The 160-tap filter (600 bps at 48 kHz)
+// keeps k_msk_samples too.
+#pragma once
+#include "jaero_device.h"
+#include "k_oqpsk_fb.h" // fb_barrier, fb_wt_next, jd_div_const
+
+#define MFB_LDSN 36
+
+struct MfbLds
+{
+    double *lre, *lim, *ltap; // [LDSN][64], [LDSN][64], [FIRN]
+    double *data;             // [2][2][64]  F -> B: sre, sim of a sample
+    int *idx;                 // [2][64]     B -> F: table index of mixer2 for a sample
+};
+template <int FIRN, int LDSN>
+constexpr int mfb_pair_doubles() { return 2 * LDSN * 64 + FIRN + 2 * 2 * 64 + 64; }
+
+// ------------------------------------------------------------------------------------------------------------------ front half
+template <int FIRN, int LDSN, bool EBNO>
+__device__ __forceinline__ void mfb_front(const JGeom &g, const JPtrs &p, const MfbLds &L, const int16_t *__restrict__ pcm, int pcm_stride, int n,
+                                          int skip_a_first, int only_a_last, int fir_slot0, int grp, int lane)
+{
+    constexpr int TAILN = FIRN - LDSN;
+    double tre[TAILN], tim[TAILN]; // tre[j] = x_re[n-LDSN-j] once x[n] has been pushed
+    const int ch = grp * 64 + lane;
+    const int nchp = g.nchp;
+    const bool live = ch < g.nch;
+    const double2 *__restrict__ cis = p.cis;
+    const int nB = n - (only_a_last ? 1 : 0); // samples whose B-part runs in this launch
+
+    double mc_ptr = LDF(S_MC_PTR), mc_step = LDF(S_MC_STEP);
+    double agc_sum = LDF(S_AGC_SUM);
+    double eb_esum = LDF(S_EB_ESUM), eb_e2sum = LDF(S_EB_E2SUM), eb_ebno = LDF(S_EB_EBNO);
+    int agc_pos = LDI(I_AGC_POS), eb_pos = LDI(I_EB_POS), bb_ptr = LDI(I_BB_PTR), coarse_cnt = LDI(I_COARSE_CNT);
+    const int flags = LDI(I_FLAGS);
+    const int nfft_mask = g.nfft - 1;
+    double2 *__restrict__ bbring = p.bbring + (size_t)ch * g.nfft;
+    double *__restrict__ agc_ring = p.agc_ring + (size_t)grp * g.agc_len * 64 + lane;
+    double *__restrict__ ebe_ring = p.eb_e + (size_t)grp * g.ebno_len * 64 + lane;
+    double *__restrict__ ebe2_ring = p.eb_e2 + (size_t)grp * g.ebno_len * 64 + lane;
+
+    // coarse ring fill, four entries at a time as one complete 64-byte sector (see k_oqpsk_fb.h)
+    double2 cq1 = make_double2(0.0, 0.0), cq2 = cq1, cq3 = cq1;
+    int cq_n = 0;
+    auto ring_fill = [&](const double2 v) __attribute__((always_inline)) {
+        if ((bb_ptr & 3) == 3)
+        {
+            double2 *dst = bbring + bb_ptr;
+            if (cq_n >= 3) dst[-3] = cq3;
+            if (cq_n >= 2) dst[-2] = cq2;
+            if (cq_n >= 1) dst[-1] = cq1;
+            dst[0] = v;
+            cq_n = 0;
+        }
+        else
+        {
+            cq3 = cq2; cq2 = cq1; cq1 = v;
+            cq_n++;
+        }
+        bb_ptr = (bb_ptr + 1) & nfft_mask;
+    };
+    auto ring_flush = [&]() __attribute__((always_inline)) {
+        double2 *dst = bbring + bb_ptr;
+        if (cq_n >= 3) dst[-3] = cq3;
+        if (cq_n >= 2) dst[-2] = cq2;
+        if (cq_n >= 1) dst[-1] = cq1;
+        cq_n = 0;
+    };
+
+    double *lre = L.lre, *lim = L.lim, *ltap = L.ltap;
+    {
+        const double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
+        for (int k = 0; k < LDSN; k++)
+        {
+            lre[k * 64 + lane] = fs[(size_t)k * 64];
+            lim[k * 64 + lane] = fs[(size_t)(FIRN + k) * 64];
+        }
+#pragma unroll
+        for (int j = 0; j < TAILN; j++)
+        {
+            tre[j] = fs[(size_t)(LDSN + j) * 64];
+            tim[j] = fs[(size_t)(FIRN + LDSN + j) * 64];
+        }
+        for (int k = lane; k < FIRN; k += 64) ltap[k] = p.taps2[k];
+    }
+    int fir_slot = fir_slot0; // wave-uniform: LDS slot holding the oldest LDS entry, overwritten by the next input
+    auto fir_eval = [&](double &ore, double &oim) __attribute__((always_inline)) { jd_fir_eval<FIRN, LDSN, 8>(lre, lim, ltap, tre, tim, fir_slot, lane, ore, oim); };
+
+    const double agc_len_d = (double)g.agc_len, eb_len_d = (double)g.ebno_len;
+
+    // MSKEbNoMeasure::Update (DSP.cpp:493-505), AGC + clip (mskdemodulator.cpp:378-382) for one sample; hands {sre, sim} to the back half
+    auto front_sample = [&](double sre, double sim, double agc_old, double e_old, double e2_old, int j, int buf) __attribute__((always_inline)) {
+        const double dabval = sqrt(sre * sre + sim * sim);
+        if (EBNO)
+        {
+            const double sq = dabval * dabval;
+            double *e2p = ebe2_ring + (size_t)eb_pos * 64;
+            double *ep = ebe_ring + (size_t)eb_pos * 64;
+            eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq); *e2p = fabs(sq);
+            eb_esum = eb_esum - e_old; eb_esum = eb_esum + fabs(dabval); *ep = fabs(dabval);
+            eb_pos++; if (eb_pos >= g.ebno_len) eb_pos = 0;
+            if (j >= n - JD_EBNO_TAIL) // wave-uniform; see JD_EBNO_TAIL
+            {
+                const double e2val = eb_e2sum / eb_len_d, mean = eb_esum / eb_len_d;
+                const double var = e2val - (mean * mean);
+                const double alpha = sqrt(2.0) / mean;
+                double tebno = 10.0 * (log10(2.0) - log10(((var * alpha * alpha) - 0.0085))) - 5.0;
+                if (isnan(tebno)) tebno = 50;
+                if (tebno > 50.0) tebno = 50;
+                eb_ebno = eb_ebno * 0.8 + 0.2 * tebno;
+            }
+        }
+        {
+            double *ap = agc_ring + (size_t)agc_pos * 64;
+            agc_sum = agc_sum - agc_old;
+            agc_sum = agc_sum + fabs(dabval);
+            *ap = fabs(dabval);
+            agc_pos++; if (agc_pos >= g.agc_len) agc_pos = 0;
+        }
+        double gain = 1.414213562 / fmax(agc_sum / agc_len_d, 0.000001);
+        gain = fmax(gain, 0.000001);
+        sre *= gain; sim *= gain;
+        const double abval = sqrt(sre * sre + sim * sim);
+        if (abval > 2.84) { const double k = (2.84 / abval); sre = k * sre; sim = k * sim; }
+        double *d = L.data + buf * 2 * 64 + lane;
+        d[0] = sre; d[64] = sim;
+    };
+
+    auto ring_pos_next = [](int pos, int len) { pos++; return pos >= len ? 0 : pos; };
+    double r1_agc = agc_ring[(size_t)agc_pos * 64]; // rows for the next sample to be fronted
+    double r1_e = 0, r1_e2 = 0;
+    if (EBNO) { r1_e = ebe_ring[(size_t)eb_pos * 64]; r1_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
+    short nx_pcm = (live && n > 0) ? pcm[ch] : (short)0;
+    double2 nx_cc = cis[jd_cisidx(mc_ptr)];
+
+    // prologue: sample 0's filter output comes from the saved history
+    if (nB > 0)
+    {
+        double y_re, y_im;
+        fir_eval(y_re, y_im);
+        front_sample(y_re, y_im, r1_agc, r1_e, r1_e2, 0, 0);
+        r1_agc = agc_ring[(size_t)agc_pos * 64];
+        if (EBNO) { r1_e = ebe_ring[(size_t)eb_pos * 64]; r1_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
+    }
+    fb_barrier();
+
+    for (int i = 0; i < nB; i++)
+    {
+        // the carrier NCO's table value for sample i (index handed over by the back half): an L2 hit; the register half of the history
+        // shifts meanwhile
+        const int m2i = L.idx[(i & 1) * 64 + lane];
+        const double2 c_m2 = cis[m2i];
+#pragma unroll
+        for (int j = TAILN - 1; j > 0; j--) { tre[j] = tre[j - 1]; tim[j] = tim[j - 1]; }
+        double *hre = lre + fir_slot * 64 + lane, *him = lim + fir_slot * 64 + lane;
+        tre[0] = *hre;
+        tim[0] = *him;
+        const short s = nx_pcm;
+        const double dval = ((double)s) / 32768.0;
+        const double2 cc = nx_cc;
+        const bool do_fill = !(i == 0 && skip_a_first) && ((coarse_cnt >= g.Fs_int) || !(flags & JF_CPUREDUCE));
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const double cre = c_m2.x * dval, cim = c_m2.y * dval; // x[n], mixed with the carrier phase this sample started with
+            *hre = cre;
+            *him = cim;
+            fir_slot++;
+            if (fir_slot >= LDSN) fir_slot = 0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_fill) ring_fill(make_double2(cc.x * dval, cc.y * dval)); // :350-355
+        coarse_cnt++;                                                   // :368
+        fb_wt_next(mc_ptr, mc_step);
+        if (i + 1 < n)
+        {
+            nx_pcm = live ? pcm[(size_t)(i + 1) * pcm_stride + ch] : (short)0;
+            nx_cc = cis[jd_cisidx(mc_ptr)];
+        }
+        double r2_agc = 0, r2_e = 0, r2_e2 = 0;
+        if (i + 2 < nB)
+        {
+            r2_agc = agc_ring[(size_t)ring_pos_next(agc_pos, g.agc_len) * 64];
+            if (EBNO)
+            {
+                const int ep = ring_pos_next(eb_pos, g.ebno_len);
+                r2_e = ebe_ring[(size_t)ep * 64];
+                r2_e2 = ebe2_ring[(size_t)ep * 64];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 < nB)
+        {
+            double y_re, y_im;
+            fir_eval(y_re, y_im);
+            front_sample(y_re, y_im, r1_agc, r1_e, r1_e2, i + 1, (i + 1) & 1);
+            r1_agc = r2_agc; r1_e = r2_e; r1_e2 = r2_e2;
+        }
+        fb_barrier();
+    }
+    if (only_a_last) // the coarse estimate runs now; the next launch resumes with this sample's B-part
+    {
+        const double dval = ((double)nx_pcm) / 32768.0;
+        const bool do_fill = !(nB == 0 && skip_a_first) && ((coarse_cnt >= g.Fs_int) || !(flags & JF_CPUREDUCE));
+        if (do_fill) ring_fill(make_double2(nx_cc.x * dval, nx_cc.y * dval));
+    }
+    ring_flush();
+
+    LDF(S_MC_PTR) = mc_ptr; LDF(S_MC_STEP) = mc_step;
+    LDF(S_AGC_SUM) = agc_sum;
+    LDF(S_EB_ESUM) = eb_esum; LDF(S_EB_E2SUM) = eb_e2sum; LDF(S_EB_EBNO) = eb_ebno;
+    LDI(I_AGC_POS) = agc_pos; LDI(I_EB_POS) = eb_pos; LDI(I_BB_PTR) = bb_ptr; LDI(I_COARSE_CNT) = coarse_cnt;
+    {
+        double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
+        for (int k = 0; k < LDSN; k++)
+        {
+            fs[(size_t)k * 64] = lre[k * 64 + lane];
+            fs[(size_t)(FIRN + k) * 64] = lim[k * 64 + lane];
+        }
+#pragma unroll
+        for (int j = 0; j < TAILN; j++)
+        {
+            fs[(size_t)(LDSN + j) * 64] = tre[j];
+            fs[(size_t)(FIRN + LDSN + j) * 64] = tim[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------- back half
+template <bool CAPSYM>
+__device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const MfbLds &L, int n, int only_a_last, int dly_slot0, int d8_slot0,
+                                         int grp, int lane)
+{
+    const int ch = grp * 64 + lane;
+    const int nchp = g.nchp;
+    const double2 *__restrict__ cis = p.cis;
+    const int nB = n - (only_a_last ? 1 : 0);
+
+    double m2_ptr = LDF(S_M2_PTR), m2_step = LDF(S_M2_STEP), m2_freq = LDF(S_M2_FREQ);
+    double st_ptr = LDF(S_ST_PTR), st_step = LDF(S_ST_STEP), st_last = LDF(S_ST_LAST);
+    double res_x1 = LDF(S_RES_X1), res_x2 = LDF(S_RES_X2), res_y1 = LDF(S_RES_Y1), res_y2 = LDF(S_RES_Y2);
+    double marg_sum = LDF(S_MARG_SUM), msema_sum = LDF(S_MSEMA_SUM), mse = LDF(S_MSE);
+    double diff_last = LDF(S_DIFF_LAST);
+    int marg_pos = LDI(I_MARG_POS), dt_pos = LDI(I_DT_POS), msema_pos = LDI(I_MSEMA_POS);
+    const int flags = LDI(I_FLAGS);
+    const bool dcd = flags & JF_DCD;
+    int soft_cnt = LDI(I_SOFT_CNT), sym_cnt = LDI(I_SYM_CNT), overflow = LDI(I_OVERFLOW);
+
+    const double samplerate = g.Fs;
+    double *__restrict__ marg_ring = p.marg + (size_t)ch * g.marg_len;
+    double2 *__restrict__ dt_ring = p.dt + (size_t)ch * g.dt_len;
+    double *__restrict__ msema_ring = p.msema + (size_t)ch * g.msema_len;
+    int16_t *__restrict__ soft = p.soft + (size_t)ch * g.soft_cap;
+    const int dly_len = g.sps + 1, d8_len = g.sps2 + 1;
+    double2 *__restrict__ dly_ring = p.dly + (size_t)grp * dly_len * 64 + lane;
+    double *__restrict__ d8_ring = p.dly8 + (size_t)grp * d8_len * 64 + lane;
+    int dly_slot = dly_slot0, d8_slot = d8_slot0; // wave-uniform ring phases
+
+    auto ring_next = [](int pos, int len) { pos++; return pos >= len ? 0 : pos; };
+    // mailbox: the table index of mixer2 for sample 0
+    L.idx[lane] = jd_cisidx(m2_ptr);
+    double2 nx_cst = cis[jd_cisidx(st_ptr)];
+    double2 nx_ptd = dly_ring[(size_t)ring_next(dly_slot, dly_len) * 64]; // slot read after this sample's write to dly_slot
+    double nx_d8 = d8_ring[(size_t)ring_next(d8_slot, d8_len) * 64];
+    fb_barrier();
+
+    for (int i = 0; i < nB; i++)
+    {
+        const double2 c_st = nx_cst;
+        const double2 ptd = nx_ptd;
+        const double d8out = nx_d8;
+        const double *d = L.data + (i & 1) * 2 * 64 + lane;
+        const double sre = d[0], sim = d[64];
+        if (i + 1 < nB)
+        {
+            nx_ptd = dly_ring[(size_t)ring_next(ring_next(dly_slot, dly_len), dly_len) * 64]; // dly_len, d8_len >= 3
+            nx_d8 = d8_ring[(size_t)ring_next(ring_next(d8_slot, d8_len), d8_len) * 64];
+        }
+
+        // pt_d = delayedsmpl.update_dont_touch(sig2) (:384): SPS-sample delay on a ring of SPS+1
+        {
+            dly_ring[(size_t)dly_slot * 64] = make_double2(sre, sim);
+            dly_slot++; if (dly_slot >= dly_len) dly_slot = 0; // ptd = the entry at the new dly_slot, requested one iteration ago
+        }
+        double q_re = sre, q_im = ptd.y; // pt_msk
+
+        // symbol timing (:387-405)
+        double st_eta;
+        {
+            const double x0 = hypot(q_re, q_im);
+            double y = 0;
+            y += res_x2 * g.res_b2; y += res_x1 * g.res_b1; y += x0 * g.res_b0;
+            y -= res_y2 * g.res_a2; y -= res_y1 * g.res_a1;
+            res_x2 = res_x1; res_x1 = x0; res_y2 = res_y1; res_y1 = y;
+            st_eta = y;
+        }
+        {
+            // Delay<double>(SPS/2): integer delay, weighting 0 -> returns x[n-SPS/2] (d8out, requested one iteration ago)
+            d8_ring[(size_t)d8_slot * 64] = st_eta;
+            d8_slot++; if (d8_slot >= d8_len) d8_slot = 0;
+        }
+        {
+            const double2 so = c_st;
+            const double m_re = st_eta, m_im = -d8out;
+            const double o_re = so.x * m_re - so.y * m_im;
+            const double o_im = so.x * m_im + so.y * m_re;
+            const double st_angle_error = atan2(o_im, o_re);
+            const double weighting = fabs(tanh(st_angle_error));
+            if (!dcd) jd_wt_advance_fraction(st_ptr, -(1.0 - weighting) * st_angle_error * (0.05 / 360.0));
+            else jd_wt_advance_fraction(st_ptr, -(1.0 - weighting) * st_angle_error * (0.003 / 360.0));
+        }
+
+        double frac;
+        if (jd_wt_passed(st_last, st_ptr, st_step, g.ee, frac))
+        {
+            // entries leaving the three symbol-rate windows (per-channel arrays in HBM), requested together ahead of their use
+            const double marg_old = marg_ring[marg_pos];
+            int dn = dt_pos + 1; if (dn >= g.dt_len) dn = 0;
+            const double2 dt_old = dt_ring[dn]; // dt_len = SPS/2 + 1 > 1
+            const double ms_old = msema_ring[msema_pos];
+            // carrier tracking (:411-426)
+            const double ct_xt = tanh(sim) * sre;
+            const double ct_xt_d = tanh(ptd.x) * ptd.y;
+            double ct_ec = ct_xt_d - ct_xt;
+            if (ct_ec > M_PI) ct_ec = M_PI;
+            if (ct_ec < -M_PI) ct_ec = -M_PI;
+            if (ct_ec > M_PI_2) ct_ec = M_PI_2;
+            if (ct_ec < -M_PI_2) ct_ec = -M_PI_2;
+            double carrier_aggression = 12.0 * g.correctionfactor;
+            if (dcd) carrier_aggression = 8.0 * g.correctionfactor;
+            jd_wt_inc_phase_deg(m2_ptr, carrier_aggression * 1.0 * ct_ec);
+            jd_wt_setfreq(m2_freq, m2_step, (carrier_aggression * 0.01 * ct_ec) + m2_freq, samplerate);
+
+            {
+                const double v = ct_ec / 2.0;
+                double *mp = marg_ring + marg_pos;
+                marg_sum = marg_sum - marg_old; marg_sum = marg_sum + v; *mp = v;
+                marg_pos++; if (marg_pos >= g.marg_len) marg_pos = 0;
+            }
+            const double marg_val = marg_sum / ((double)g.marg_len);
+            {
+                dt_ring[dt_pos] = make_double2(q_re, q_im);
+                dt_pos++; if (dt_pos >= g.dt_len) dt_pos = 0;
+                q_re = dt_old.x; q_im = dt_old.y;
+            }
+            {
+                const double cr = cos(marg_val), sr = sin(marg_val);
+                const double nr = q_re * cr - q_im * sr;
+                const double ni = q_re * sr + q_im * cr;
+                q_re = nr; q_im = ni;
+            }
+            {
+                const double tda = (fabs(q_re * 0.75) - 1.0), tdb = (fabs(q_im * 0.75) - 1.0);
+                const double e = (tda * tda) + (tdb * tdb);
+                double *ep = msema_ring + msema_pos;
+                msema_sum = msema_sum - ms_old; msema_sum = msema_sum + fabs(e); *ep = fabs(e);
+                msema_pos++; if (msema_pos >= g.msema_len) msema_pos = 0;
+                mse = msema_sum / ((double)g.msema_len);
+            }
+            if (CAPSYM)
+            {
+                if (sym_cnt < g.sym_cap)
+                {
+                    double *sp = p.sym + ((size_t)ch * g.sym_cap + sym_cnt) * 3;
+                    sp[0] = q_re; sp[1] = q_im; sp[2] = mse;
+                    sym_cnt++;
+                }
+                else overflow |= 2;
+            }
+            // soft differential decode + demap (:450-469, DSP.cpp:531-563)
+            int b0, b1;
+            {
+                double soft_in = q_im, r;
+                if (soft_in < 0 && diff_last < 0) r = diff_last;
+                else if (soft_in > 0 && diff_last > 0) r = -diff_last;
+                else r = fabs(diff_last);
+                diff_last = soft_in;
+                b0 = jd_softbit((r) * 127.0 + 128.0);
+                soft_in = q_re;
+                if (soft_in < 0 && diff_last < 0) r = diff_last;
+                else if (soft_in > 0 && diff_last > 0) r = -diff_last;
+                else r = fabs(diff_last);
+                diff_last = soft_in;
+                r = -r;
+                b1 = jd_softbit((r) * 127.0 + 128.0);
+            }
+            if (soft_cnt + 2 <= g.soft_cap)
+            {
+                soft[soft_cnt] = (int16_t)b0;
+                soft[soft_cnt + 1] = (int16_t)b1;
+                soft_cnt += 2;
+            }
+            else overflow |= 1;
+        }
+
+        // advance the NCOs (:480-483) and hand the next sample's carrier table index to the front half
+        jd_wt_next(m2_ptr, m2_step);
+        L.idx[((i + 1) & 1) * 64 + lane] = jd_cisidx(m2_ptr);
+        if (st_step < 0) st_step = 0;
+        st_last = st_ptr;
+        st_ptr += st_step;
+        while (((int)st_ptr) >= JD_WTSIZE) st_ptr -= JD_WTSIZE;
+        nx_cst = cis[jd_cisidx(st_ptr)]; // the symbol NCO's table value for the next sample: in flight across the barrier
+        fb_barrier();
+    }
+
+    LDF(S_M2_PTR) = m2_ptr; LDF(S_M2_STEP) = m2_step; LDF(S_M2_FREQ) = m2_freq;
+    LDF(S_ST_PTR) = st_ptr; LDF(S_ST_STEP) = st_step; LDF(S_ST_LAST) = st_last;
+    LDF(S_RES_X1) = res_x1; LDF(S_RES_X2) = res_x2; LDF(S_RES_Y1) = res_y1; LDF(S_RES_Y2) = res_y2;
+    LDF(S_MARG_SUM) = marg_sum; LDF(S_MSEMA_SUM) = msema_sum; LDF(S_MSE) = mse;
+    LDF(S_DIFF_LAST) = diff_last;
+    LDI(I_MARG_POS) = marg_pos; LDI(I_DT_POS) = dt_pos; LDI(I_MSEMA_POS) = msema_pos;
+    LDI(I_SOFT_CNT) = soft_cnt; LDI(I_SYM_CNT) = sym_cnt; LDI(I_OVERFLOW) = overflow;
+}
+
+// PAIRS front/back pairs per workgroup: waves 0..PAIRS-1 are the front halves of channel groups blockIdx.x*PAIRS + w, waves
+// PAIRS..2*PAIRS-1 the back halves of the same groups.  A pair whose group lies beyond the bank only keeps the barrier count.
+template <int FIRN, int LDSN, bool EBNO, bool CAPSYM, int PAIRS>
+__global__ __launch_bounds__(PAIRS * 128) void k_msk_fb(const JGeom g, const JPtrs p, const int16_t *__restrict__ pcm, int pcm_stride, int n,
+                                                        int skip_a_first, int only_a_last, int fir_slot0, int dly_slot0, int d8_slot0)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const bool back = wave >= PAIRS;
+    const int pair = back ? wave - PAIRS : wave;
+    const int grp = blockIdx.x * PAIRS + pair;
+    double *base = lds + (size_t)pair * mfb_pair_doubles<FIRN, LDSN>();
+    MfbLds L;
+    L.lre = base; L.lim = base + LDSN * 64; L.ltap = base + 2 * LDSN * 64;
+    L.data = L.ltap + FIRN;
+    L.idx = (int *)(L.data + 2 * 2 * 64);
+    if (grp >= g.ngroups)
+    {
+        const int nB = n - (only_a_last ? 1 : 0);
+        for (int i = 0; i <= nB; i++) fb_barrier();
+        return;
+    }
+    if (back) mfb_back<CAPSYM>(g, p, L, n, only_a_last, dly_slot0, d8_slot0, grp, lane);
+    else mfb_front<FIRN, LDSN, EBNO>(g, p, L, pcm, pcm_stride, n, skip_a_first, only_a_last, fir_slot0, grp, lane);
+}
