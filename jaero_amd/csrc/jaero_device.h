@@ -37,6 +37,7 @@ enum
     S_MARG_SUM, S_PM_SUM, S_MSEMA_SUM, S_MSE,
     S_DIFF_LAST,
     S_LOCKINGBW, S_THRESH,
+    S_MFB_A0_RE, S_MFB_A0_IM,          // k_msk_fb with four pairs: the back half's partial filter sum for the next launch's first sample
     S_PRE_PTR, S_PRE_STEP, S_PRE_FSUM, // fb == 8400: mixer_fir_pre phase / step, sum of mixer2's frequency over the current write
     S_NFIELDS
 };

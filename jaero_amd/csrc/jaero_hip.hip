@@ -689,19 +689,25 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
 #undef MSK_ATTR
         if (g.fir_n == 80)
         {
-            // front / back pairs (k_msk_fb.h) for banks of at most two channel groups per CU: one pair per workgroup, the two halves on
-            // different SIMDs (256 channels: 82 -> 113 Msamples/s, 16 384: 4.07 -> 4.94 G).  Larger banks keep k_msk_samples: the front
-            // half's 44-deep register tail does not fit the 256 registers a wavefront has at two per SIMD (four pairs per workgroup:
-            // 458 spilled registers, 6.6 against 9.25 Gsamples/s at 65 536 channels).  JAERO_MSK_KERNEL=single|pairs1|pairs4 forces one.
+            // front / back pairs (k_msk_fb.h).  Banks of at most two channel groups per CU: one pair per workgroup, the halves on different
+            // SIMDs, 36 history entries per arm in LDS and 44 in the front half's registers (256 channels: 82 -> 113 Msamples/s).  Larger
+            // banks: four pairs per workgroup, each pair on one SIMD, 32 entries in LDS, 26 in the front half's and the 22 oldest in the
+            // back half's registers (65 536 channels: 9.2 -> 10.6 Gsamples/s).  JAERO_MSK_KERNEL=single|pairs1|pairs4 forces one.
             const char *e = getenv("JAERO_MSK_KERNEL");
             const int ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-            c->msk_pairs = (e && !strcmp(e, "single")) ? 0 : ((e && !strcmp(e, "pairs1")) ? 1 : ((e && !strcmp(e, "pairs4")) ? 4 : (g.ngroups > 2 * ncu ? 0 : 1)));
-            if (c->msk_pairs)
+            c->msk_pairs = (e && !strcmp(e, "single")) ? 0 : ((e && !strcmp(e, "pairs1")) ? 1 : ((e && !strcmp(e, "pairs4")) ? 4 : (g.ngroups > 2 * ncu ? 4 : 1)));
+            if (c->msk_pairs == 1)
             {
                 c->msk_ldsn = MFB_LDSN;
-#define MFA(E, C, PP) HIPCHK(hipFuncSetAttribute((const void *)k_msk_fb<80, MFB_LDSN, E, C, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, PP * mfb_pair_doubles<80, MFB_LDSN>() * (int)sizeof(double)))
-                MFA(false, false, 1); MFA(false, true, 1); MFA(true, false, 1); MFA(true, true, 1);
-                MFA(false, false, 4); MFA(false, true, 4); MFA(true, false, 4); MFA(true, true, 4);
+#define MFA(E, C) HIPCHK(hipFuncSetAttribute((const void *)k_msk_fb<80, MFB_LDSN, E, C, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, mfb_pair_doubles<80, MFB_LDSN, 0>() * (int)sizeof(double)))
+                MFA(false, false); MFA(false, true); MFA(true, false); MFA(true, true);
+#undef MFA
+            }
+            else if (c->msk_pairs == 4)
+            {
+                c->msk_ldsn = MFB4_LDSN;
+#define MFA(E, C) HIPCHK(hipFuncSetAttribute((const void *)k_msk_fb<80, MFB4_LDSN, E, C, 4, MFB4_TB>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * mfb_pair_doubles<80, MFB4_LDSN, MFB4_TB>() * (int)sizeof(double)))
+                MFA(false, false); MFA(false, true); MFA(true, false); MFA(true, true);
 #undef MFA
             }
         }
@@ -866,7 +872,7 @@ extern "C" int jaero_set_settings(jaero_ctx *c, int channel, const jaero_setting
     else
     {
         setS(S_MSE, 10.0); // setSettings resets mse (mskdemodulator.cpp:180)
-        for (int f : {S_AGC_SUM, S_RES_X1, S_RES_X2, S_RES_Y1, S_RES_Y2, S_EB_ESUM, S_EB_E2SUM, S_EB_EBNO, S_MARG_SUM}) setS(f, 0.0);
+        for (int f : {S_AGC_SUM, S_RES_X1, S_RES_X2, S_RES_Y1, S_RES_Y2, S_EB_ESUM, S_EB_E2SUM, S_EB_EBNO, S_MARG_SUM, S_MFB_A0_RE, S_MFB_A0_IM}) setS(f, 0.0);
         setI(I_MARG_POS, 0); setI(I_DT_POS, 0);
         if (c->p.eb_e) setI(I_EB_POS, 0);
         v.zero_eb = 1; v.zero_msk = 1;
@@ -993,9 +999,9 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
         {
             const int P = c->msk_pairs;
             const dim3 gridp((g.ngroups + P - 1) / P), blockp(P * 128);
-            const int ldsp = P * mfb_pair_doubles<80, MFB_LDSN>() * (int)sizeof(double);
-#define LMF(E, C, PP) hipLaunchKernelGGL((k_msk_fb<80, MFB_LDSN, E, C, PP>), gridp, blockp, ldsp, st, g, c->p, frames, stride, n, skipA, onlyA, fs, ds, d8)
-#define LMFP(E, C) { if (P == 4) LMF(E, C, 4); else LMF(E, C, 1); }
+            const int ldsp = (P == 4 ? 4 * mfb_pair_doubles<80, MFB4_LDSN, MFB4_TB>() : mfb_pair_doubles<80, MFB_LDSN, 0>()) * (int)sizeof(double);
+#define LMF(E, C, PP, LL, TT) hipLaunchKernelGGL((k_msk_fb<80, LL, E, C, PP, TT>), gridp, blockp, ldsp, st, g, c->p, frames, stride, n, skipA, onlyA, fs, ds, d8)
+#define LMFP(E, C) { if (P == 4) LMF(E, C, 4, MFB4_LDSN, MFB4_TB); else LMF(E, C, 1, MFB_LDSN, 0); }
             if (eb && cs) LMFP(true, true) else if (eb) LMFP(true, false) else if (cs) LMFP(false, true) else LMFP(false, false)
 #undef LMFP
 #undef LMF

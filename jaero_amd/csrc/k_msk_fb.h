@@ -14,34 +14,80 @@
 // The matched filter's output for sample n+1 does not contain x[n+1] (FIR::FIRUpdateAndProcess excludes the newest sample,
 // DSP.cpp:292-304) and x[n] = mixer2(n) * pcm[n] is known once the back half has finished sample n-1: while B runs sample n, F forms
 // x[n], pushes it and produces the AGC'd, clipped sample n+1.  One LDS-only barrier per sample, double-buffered mailboxes.
-// Only the front half needs LDS: 36 of the 80 history entries of each arm + the taps + the mailboxes = 40 064 B per pair, so four pairs
-// per workgroup would fit a CU (160 256 B) -- but the other 44 entries of each arm live in the front half's registers (176 of them), which
-// fits the 512 registers of a wavefront alone on its SIMD and not the 256 it has at two per SIMD.  Used, therefore, for banks of at
-// most two channel groups per CU with ONE pair per workgroup (the halves on different SIMDs): measured on an MI355X, 256 channels
-// 82 -> 113 Msamples/s, 16 384 channels 4.07 -> 4.94 Gsamples/s; with four pairs per workgroup at 65 536 channels 458 registers spill
-// and it is slower than k_msk_samples (6.6 against 9.25 Gsamples/s), which larger banks keep.  The 160-tap filter (600 bps at 48 kHz)
-// keeps k_msk_samples too.
+// Only the front half needs LDS.  Banks of at most two channel groups per CU run ONE pair per workgroup (the halves on different SIMDs,
+// 512 registers each): 36 of the 80 history entries of each arm in LDS, 44 in the front half's registers.  Full banks run FOUR pairs per
+// workgroup (a pair shares a SIMD, 256 registers per wavefront, 40 064 B of LDS per pair = 160 256 B per CU); there the front half's
+// 44-deep tail does not fit, so the history is split three ways (MFB4_*, below).  Measured on an MI355X: 256 channels 82 -> 113
+// Msamples/s, 16 384 channels 4.07 -> 4.94 Gsamples/s, 65 536 channels 9.2 -> 10.6 Gsamples/s (sample loop 15.9 -> 12.1 ms per step); the
+// first four-pair version, with the whole tail in the front half, spilled 458 registers and ran at 6.6.  The 160-tap filter (600 bps
+// at 48 kHz) keeps k_msk_samples.
 #pragma once
 #include "jaero_device.h"
 #include "k_oqpsk_fb.h" // fb_barrier, fb_wt_next, jd_div_const
 
-#define MFB_LDSN 36
+#define MFB_LDSN 36  // one pair per workgroup (small banks): 36 history entries of each arm in LDS, 44 in the front half's registers
+// Four pairs per workgroup (full banks): a wavefront has 256 registers at two per SIMD, the front half's 44-deep tail (176 registers)
+// does not fit.  Then the OLDEST 22 entries of each arm live in the BACK half's registers (it has room), which starts every filter
+// output -- the sum runs oldest first -- and hands the partial sum to the front half; the front half keeps 26 entries in registers
+// and 32 in LDS and continues the same sum.  Same operations in the same order as the single accumulator chain.
+#define MFB4_LDSN 32
+#define MFB4_TB 22
 
 struct MfbLds
 {
     double *lre, *lim, *ltap; // [LDSN][64], [LDSN][64], [FIRN]
     double *data;             // [2][2][64]  F -> B: sre, sim of a sample
     int *idx;                 // [2][64]     B -> F: table index of mixer2 for a sample
+    double *oldx;             // [2][2][64]  F -> B (TB > 0): the history entry that reaches the back half's tail two samples on
+    double *acc;              // [2][2][64]  B -> F (TB > 0): the filter sum over the back half's entries for a sample
 };
-template <int FIRN, int LDSN>
-constexpr int mfb_pair_doubles() { return 2 * LDSN * 64 + FIRN + 2 * 2 * 64 + 64; }
+template <int FIRN, int LDSN, int TB>
+constexpr int mfb_pair_doubles() { return 2 * LDSN * 64 + FIRN + 2 * 2 * 64 + 64 + (TB > 0 ? 2 * 2 * 2 * 64 : 0); }
+
+// jd_fir_eval (jaero_device.h) continuing a sum: taps T0 .. FIRN-1 over the TAILN register entries (oldest first) and the LDSN LDS
+// entries, starting from (are0, aim0) = the sum over taps 0 .. T0-1
+template <int FIRN, int LDSN, int D, int T0, int TAILA>
+__device__ __forceinline__ void mfb_fir_continue(const double *lre, const double *lim, const double *ltap, const double (&tre)[TAILA],
+                                                 const double (&tim)[TAILA], int fir_slot, int lane, double are0, double aim0, double &ore, double &oim)
+{
+    constexpr int NT = FIRN - T0, TAILN = NT - LDSN;
+    double pr[D], pi[D], pt[D];
+    int slot = fir_slot;
+    auto fetch = [&](int s, int q) {
+        pt[q] = ltap[T0 + s];
+        if (s >= TAILN)
+        {
+            pr[q] = lre[slot * 64 + lane];
+            pi[q] = lim[slot * 64 + lane];
+            slot++;
+            if (slot >= LDSN) slot = 0;
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < D; s++) fetch(s, s);
+    __builtin_amdgcn_sched_barrier(0);
+    double are = are0, aim = aim0;
+#pragma unroll
+    for (int s = 0; s < NT; s++)
+    {
+        const int q = s % D;
+        const double xr = (s < TAILN) ? tre[(TAILN - 1 - s) < 0 ? 0 : (TAILN - 1 - s)] : pr[q];
+        const double xi = (s < TAILN) ? tim[(TAILN - 1 - s) < 0 ? 0 : (TAILN - 1 - s)] : pi[q];
+        are = fma(pt[q], xr, are);
+        aim = fma(pt[q], xi, aim);
+        asm volatile("" : "+v"(are), "+v"(aim)); // keeps the software pipeline as written (see jd_fir_eval)
+        if (s + D < NT) fetch(s + D, q);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    ore = are; oim = aim;
+}
 
 // ------------------------------------------------------------------------------------------------------------------ front half
-template <int FIRN, int LDSN, bool EBNO>
+template <int FIRN, int LDSN, bool EBNO, int TB>
 __device__ __forceinline__ void mfb_front(const JGeom &g, const JPtrs &p, const MfbLds &L, const int16_t *__restrict__ pcm, int pcm_stride, int n,
                                           int skip_a_first, int only_a_last, int fir_slot0, int grp, int lane)
 {
-    constexpr int TAILN = FIRN - LDSN;
+    constexpr int TAILN = FIRN - LDSN - TB; // this half's register tail; the TB oldest entries are the back half's
     double tre[TAILN], tim[TAILN]; // tre[j] = x_re[n-LDSN-j] once x[n] has been pushed
     const int ch = grp * 64 + lane;
     const int nchp = g.nchp;
@@ -105,7 +151,15 @@ __device__ __forceinline__ void mfb_front(const JGeom &g, const JPtrs &p, const 
         for (int k = lane; k < FIRN; k += 64) ltap[k] = p.taps2[k];
     }
     int fir_slot = fir_slot0; // wave-uniform: LDS slot holding the oldest LDS entry, overwritten by the next input
-    auto fir_eval = [&](double &ore, double &oim) __attribute__((always_inline)) { jd_fir_eval<FIRN, LDSN, 8>(lre, lim, ltap, tre, tim, fir_slot, lane, ore, oim); };
+    // rel = index of the sample (within this launch) whose output is formed: its partial sum from the back half sits in acc[rel & 1]
+    auto fir_eval = [&](int rel, double &ore, double &oim) __attribute__((always_inline)) {
+        if constexpr (TB > 0)
+        {
+            const double *a = L.acc + (rel & 1) * 2 * 64 + lane;
+            mfb_fir_continue<FIRN, LDSN, 8, TB>(lre, lim, ltap, tre, tim, fir_slot, lane, a[0], a[64], ore, oim);
+        }
+        else jd_fir_eval<FIRN, LDSN, 8>(lre, lim, ltap, tre, tim, fir_slot, lane, ore, oim);
+    };
 
     const double agc_len_d = (double)g.agc_len, eb_len_d = (double)g.ebno_len;
 
@@ -154,11 +208,12 @@ __device__ __forceinline__ void mfb_front(const JGeom &g, const JPtrs &p, const 
     short nx_pcm = (live && n > 0) ? pcm[ch] : (short)0;
     double2 nx_cc = cis[jd_cisidx(mc_ptr)];
 
+    if constexpr (TB > 0) fb_barrier(); // the back half has published its partial sums for samples 0 and 1
     // prologue: sample 0's filter output comes from the saved history
     if (nB > 0)
     {
         double y_re, y_im;
-        fir_eval(y_re, y_im);
+        fir_eval(0, y_re, y_im);
         front_sample(y_re, y_im, r1_agc, r1_e, r1_e2, 0, 0);
         r1_agc = agc_ring[(size_t)agc_pos * 64];
         if (EBNO) { r1_e = ebe_ring[(size_t)eb_pos * 64]; r1_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
@@ -188,6 +243,12 @@ __device__ __forceinline__ void mfb_front(const JGeom &g, const JPtrs &p, const 
             fir_slot++;
             if (fir_slot >= LDSN) fir_slot = 0;
         }
+        if constexpr (TB > 0)
+        {
+            // the entry that leaves this tail two samples on is the newest one of the partial sum the back half forms during the next sample
+            double *o = L.oldx + ((i + 1) & 1) * 2 * 64 + lane;
+            o[0] = tre[TAILN - 2]; o[64] = tim[TAILN - 2];
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (do_fill) ring_fill(make_double2(cc.x * dval, cc.y * dval)); // :350-355
         coarse_cnt++;                                                   // :368
@@ -212,7 +273,7 @@ __device__ __forceinline__ void mfb_front(const JGeom &g, const JPtrs &p, const 
         if (i + 1 < nB)
         {
             double y_re, y_im;
-            fir_eval(y_re, y_im);
+            fir_eval(i + 1, y_re, y_im);
             front_sample(y_re, y_im, r1_agc, r1_e, r1_e2, i + 1, (i + 1) & 1);
             r1_agc = r2_agc; r1_e = r2_e; r1_e2 = r2_e2;
         }
@@ -247,10 +308,13 @@ __device__ __forceinline__ void mfb_front(const JGeom &g, const JPtrs &p, const 
 }
 
 // ------------------------------------------------------------------------------------------------------------------- back half
-template <bool CAPSYM>
+template <bool CAPSYM, int FIRN, int LDSN, int TB>
 __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const MfbLds &L, int n, int only_a_last, int dly_slot0, int d8_slot0,
                                          int grp, int lane)
 {
+    constexpr int TBA = TB > 0 ? TB : 1, TF = FIRN - LDSN - TB;
+    double tbr[TBA], tbi[TBA]; // TB > 0: the TB oldest history entries of each arm, tbr[0] the newest of them
+    double acc_prev_re = 0, acc_prev_im = 0, acc_last_re = 0, acc_last_im = 0, xin_re = 0, xin_im = 0;
     const int ch = grp * 64 + lane;
     const int nchp = g.nchp;
     const double2 *__restrict__ cis = p.cis;
@@ -277,11 +341,50 @@ __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const M
     int dly_slot = dly_slot0, d8_slot = d8_slot0; // wave-uniform ring phases
 
     auto ring_next = [](int pos, int len) { pos++; return pos >= len ? 0 : pos; };
+    // sum over this half's entries, oldest first: taps[t] <-> tb[TB - 1 - t]
+    auto tail_sum = [&](double &ore, double &oim) __attribute__((always_inline)) {
+        double are = 0, aim = 0;
+#pragma unroll
+        for (int t = 0; t < TB; t++)
+        {
+            const double tp = L.ltap[t];
+            are = fma(tp, tbr[TB - 1 - t], are);
+            aim = fma(tp, tbi[TB - 1 - t], aim);
+        }
+        ore = are; oim = aim;
+    };
+    if constexpr (TB > 0)
+    {
+        // saved history of the group: [0, LDSN) the LDS ring, [LDSN, LDSN + TF) the front half's tail, [LDSN + TF, FIRN) this tail; the
+        // partial sum for sample 0 was formed two samples ago (the launch before): kept in the state; the one for sample 1 is the sum
+        // over the tail as saved; the entry arriving during sample 0 is what the front half would have handed over: its tail entry TF - 2
+        const double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < TB; j++) { tbr[j] = fs[(size_t)(LDSN + TF + j) * 64]; tbi[j] = fs[(size_t)(FIRN + LDSN + TF + j) * 64]; }
+        xin_re = fs[(size_t)(LDSN + TF - 2) * 64]; xin_im = fs[(size_t)(FIRN + LDSN + TF - 2) * 64];
+        acc_prev_re = LDF(S_MFB_A0_RE); acc_prev_im = LDF(S_MFB_A0_IM);
+        // the front half fills its LDS copy of the taps before its first barrier, this half reads them behind it: use the bank's table here
+        {
+            double are = 0, aim = 0;
+#pragma unroll
+            for (int t = 0; t < TB; t++)
+            {
+                const double tp = p.taps2[t];
+                are = fma(tp, tbr[TB - 1 - t], are);
+                aim = fma(tp, tbi[TB - 1 - t], aim);
+            }
+            acc_last_re = are; acc_last_im = aim;
+        }
+        double *a = L.acc + lane;
+        a[0] = acc_prev_re; a[64] = acc_prev_im;             // sample 0
+        a[128] = acc_last_re; a[128 + 64] = acc_last_im;     // sample 1
+    }
     // mailbox: the table index of mixer2 for sample 0
     L.idx[lane] = jd_cisidx(m2_ptr);
     double2 nx_cst = cis[jd_cisidx(st_ptr)];
     double2 nx_ptd = dly_ring[(size_t)ring_next(dly_slot, dly_len) * 64]; // slot read after this sample's write to dly_slot
     double nx_d8 = d8_ring[(size_t)ring_next(d8_slot, d8_len) * 64];
+    if constexpr (TB > 0) fb_barrier(); // partial sums of samples 0 and 1 published; the front half forms sample 0 now
     fb_barrier();
 
     for (int i = 0; i < nB; i++)
@@ -291,6 +394,19 @@ __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const M
         const double d8out = nx_d8;
         const double *d = L.data + (i & 1) * 2 * 64 + lane;
         const double sre = d[0], sim = d[64];
+        if constexpr (TB > 0)
+        {
+            // the entry the front half announced during the previous sample joins this tail; the sum over it is what the front half
+            // starts from when it forms sample i + 2 (during sample i + 1)
+            if (i > 0) { const double *o = L.oldx + (i & 1) * 2 * 64 + lane; xin_re = o[0]; xin_im = o[64]; }
+#pragma unroll
+            for (int j = TB - 1; j > 0; j--) { tbr[j] = tbr[j - 1]; tbi[j] = tbi[j - 1]; }
+            tbr[0] = xin_re; tbi[0] = xin_im;
+            acc_prev_re = acc_last_re; acc_prev_im = acc_last_im;
+            tail_sum(acc_last_re, acc_last_im);
+            double *a = L.acc + (i & 1) * 2 * 64 + lane; // (i + 2) & 1
+            a[0] = acc_last_re; a[64] = acc_last_im;
+        }
         if (i + 1 < nB)
         {
             nx_ptd = dly_ring[(size_t)ring_next(ring_next(dly_slot, dly_len), dly_len) * 64]; // dly_len, d8_len >= 3
@@ -431,11 +547,19 @@ __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const M
     LDF(S_DIFF_LAST) = diff_last;
     LDI(I_MARG_POS) = marg_pos; LDI(I_DT_POS) = dt_pos; LDI(I_MSEMA_POS) = msema_pos;
     LDI(I_SOFT_CNT) = soft_cnt; LDI(I_SYM_CNT) = sym_cnt; LDI(I_OVERFLOW) = overflow;
+    if constexpr (TB > 0)
+    {
+        // next launch: its sample 0 starts from the sum formed for sample nB (acc_prev after nB steps), its tail is this one
+        LDF(S_MFB_A0_RE) = acc_prev_re; LDF(S_MFB_A0_IM) = acc_prev_im;
+        double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < TB; j++) { fs[(size_t)(LDSN + TF + j) * 64] = tbr[j]; fs[(size_t)(FIRN + LDSN + TF + j) * 64] = tbi[j]; }
+    }
 }
 
 // PAIRS front/back pairs per workgroup: waves 0..PAIRS-1 are the front halves of channel groups blockIdx.x*PAIRS + w, waves
 // PAIRS..2*PAIRS-1 the back halves of the same groups.  A pair whose group lies beyond the bank only keeps the barrier count.
-template <int FIRN, int LDSN, bool EBNO, bool CAPSYM, int PAIRS>
+template <int FIRN, int LDSN, bool EBNO, bool CAPSYM, int PAIRS, int TB = 0>
 __global__ __launch_bounds__(PAIRS * 128) void k_msk_fb(const JGeom g, const JPtrs p, const int16_t *__restrict__ pcm, int pcm_stride, int n,
                                                         int skip_a_first, int only_a_last, int fir_slot0, int dly_slot0, int d8_slot0)
 {
@@ -445,17 +569,19 @@ __global__ __launch_bounds__(PAIRS * 128) void k_msk_fb(const JGeom g, const JPt
     const bool back = wave >= PAIRS;
     const int pair = back ? wave - PAIRS : wave;
     const int grp = blockIdx.x * PAIRS + pair;
-    double *base = lds + (size_t)pair * mfb_pair_doubles<FIRN, LDSN>();
+    double *base = lds + (size_t)pair * mfb_pair_doubles<FIRN, LDSN, TB>();
     MfbLds L;
     L.lre = base; L.lim = base + LDSN * 64; L.ltap = base + 2 * LDSN * 64;
     L.data = L.ltap + FIRN;
     L.idx = (int *)(L.data + 2 * 2 * 64);
+    L.oldx = L.data + 2 * 2 * 64 + 64;
+    L.acc = L.oldx + 2 * 2 * 64;
     if (grp >= g.ngroups)
     {
         const int nB = n - (only_a_last ? 1 : 0);
-        for (int i = 0; i <= nB; i++) fb_barrier();
+        for (int i = 0; i <= nB + (TB > 0 ? 1 : 0); i++) fb_barrier();
         return;
     }
-    if (back) mfb_back<CAPSYM>(g, p, L, n, only_a_last, dly_slot0, d8_slot0, grp, lane);
-    else mfb_front<FIRN, LDSN, EBNO>(g, p, L, pcm, pcm_stride, n, skip_a_first, only_a_last, fir_slot0, grp, lane);
+    if (back) mfb_back<CAPSYM, FIRN, LDSN, TB>(g, p, L, n, only_a_last, dly_slot0, d8_slot0, grp, lane);
+    else mfb_front<FIRN, LDSN, EBNO, TB>(g, p, L, pcm, pcm_stride, n, skip_a_first, only_a_last, fir_slot0, grp, lane);
 }
