@@ -175,7 +175,6 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
         std::vector<double> t2(2 * g.fir_n);
         for (int i = 0; i < 2 * g.fir_n; i++) t2[i] = taps[i % g.fir_n];
         HIPCHK(hipMemcpy(d_taps, t2.data(), sizeof(double) * t2.size(), hipMemcpyHostToDevice));
-        if (!oq) HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_taps_msk), taps.data(), sizeof(double) * taps.size(), (g.fb >= 1200 ? 0 : 1) * 160 * sizeof(double)));
         // QJHilbertFilter::setSize (JAERO/DSP.cpp:760-787): imaginary part of the odd taps
         const int N = g.hil_ntaps;
         std::vector<double> hil(N / 4);

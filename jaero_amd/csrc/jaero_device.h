@@ -171,12 +171,10 @@ __device__ __forceinline__ int jd_softbit(double v)
 // anyone can read after the launch differs from the every-sample evaluation by < 1e-16.
 #define JD_EBNO_TAIL 192
 
-// Matched-filter taps: every sample kernel copies its bank's own taps (JPtrs::taps2 / BPtrs::taps2, uploaded by *_create) into LDS
-// once per launch and reads them from there (jd_fir_eval).  The one kernel that still reads taps inside its loop (burst MSK) takes them
-// from the constant address space, where a uniform read compiles to scalar loads; that table is keyed by fb and its values depend on
-// (fb, Fs) only with Fs fixed at 48 kHz (validate_settings), so banks alive at the same time never disagree about a slot.  The OQPSK
-// taps depend on fb as well (alpha 1.0 at 10500, 0.6 at 8400) and are NOT kept in a process-global symbol.
-__constant__ double c_taps_msk[2][160];   // half-sine, [0] = 1200 bps (80 taps), [1] = 600 bps (160 taps)
+// Matched-filter taps: every kernel reads its bank's own taps (JPtrs::taps2 / BPtrs::taps2, uploaded by *_create): the sample kernels
+// copy them into LDS once per launch (jd_fir_eval) or take them as scalar kernel arguments (JTaps28); the burst MSK kernel reads
+// p.taps2 inside its loop with a wave-uniform index (scalar loads).  There is NO process-global tap table: the values depend on
+// (kind, fb, Fs) and banks of different (fb, Fs) are alive together (tests/test_gpu_scale.py::test_msk_family_banks_alive_together).
 
 // Matched-filter evaluation for one sample of 64 channels (one per lane): sum over i of taps[i] * x[n-FIRN+i], oldest first,
 // re and im chains, one fma per tap and chain (the order and the fusing of DSP.cpp's FIR::FIRUpdateAndProcess).

@@ -648,7 +648,6 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
             c->oq_pairs = sym ? -1 : 0; // -1: front/back pairs allowed (decided below); 0: asymmetric taps -> the single-wavefront kernel reads them from LDS
             for (int i = 0; i < 28; i++) c->oq_taps.t[i] = taps[i];
         }
-        if (g.kind != JAERO_KIND_OQPSK) HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_taps_msk), taps.data(), sizeof(double) * taps.size(), (g.fb >= 1200 ? 0 : 1) * 160 * sizeof(double)));
     }
     // scalar state
     {

@@ -342,3 +342,133 @@ def test_10500_and_8400_banks_alive_together(B, oracle_mod):
     assert len(r105["soft"]) > 5000 and len(r84["soft"]) > 4000
     for b in (b105, b84, bb):
         b.close()
+
+
+def test_msk_family_banks_alive_together(B, oracle_mod):
+    """Every MSK-family kernel reads its bank's own half-sine taps (the burst MSK loop used to read a process-global constant table
+    keyed by fb, which every continuous MSK create overwrote -- with 20 / 40 taps at 24 / 12 kHz).  A burst MSK 1200 bank (80 taps) and
+    a burst MSK 600 bank (160 taps) stay alive and are fed while continuous MSK banks at (24 kHz, 1200: 40 taps), (24 kHz, 600: 80
+    taps) and (12 kHz, 1200: 20 taps) are created and run between their writes; all five equal their oracle runs."""
+    from jaero_amd import signalgen as G
+    from test_gpu_burst import check_events, check_soft
+
+    O = oracle_mod
+    rng = np.random.default_rng(77)
+    burst, bpcm, bopts = {}, {}, {}
+    for fb in (1200, 600):
+        n = int(48000 * 4 * (1200 / fb))
+        bpcm[fb] = G.burst_msk(n, burst_starts=[int(n * 0.2)], fb=float(fb), fc=1900.0 + 40.0 * (fb == 600), ncw=130, ebno_db=18.0,
+                               seed=G.SEED_BASE + 770 + fb)[0]
+        bopts[fb] = dict(freq_center=1000.0, fb=float(fb), lockingbw=1.5 * fb)
+        burst[fb] = B.DemodulatorBank(B.BurstMskSettings(**bopts[fb]), 1, capture_symbols=True, max_write_samples=4096, softbit_capacity=30000)
+    cont = [(24000.0, 1200.0), (24000.0, 600.0), (12000.0, 1200.0)]
+    cbank, cpcm = {}, {}
+    pos = {1200: 0, 600: 0}
+
+    def feed_bursts(frac):
+        for fb in (1200, 600):
+            end = int(len(bpcm[fb]) * frac)
+            while pos[fb] < end:
+                m = min(4096, end - pos[fb])
+                burst[fb].write(bpcm[fb][None, pos[fb]:pos[fb] + m])
+                pos[fb] += m
+
+    feed_bursts(0.1)
+    for k, (Fs, fb) in enumerate(cont):
+        nsamp = int(Fs * 4)
+        cpcm[(Fs, fb)] = G.msk(nsamp, fb=fb, Fs=Fs, fc=1000.0 + 6.0 * k, ebno_db=12.0, seed=G.SEED_BASE + 780 + k)[0]
+        # created while the burst banks are alive and mid-stream: must not touch their filters
+        cbank[(Fs, fb)] = B.DemodulatorBank(B.MskSettings(fb=fb, lockingbw=1.5 * fb, freq_center=1000.0, Fs=Fs), 1, ebno=True, status_log=True,
+                                            capture_symbols=True, max_write_samples=3000, softbit_capacity=nsamp)
+        x = cpcm[(Fs, fb)]
+        for s in range(0, nsamp, 3000):
+            cbank[(Fs, fb)].write(x[None, s:s + 3000])
+        feed_bursts(0.1 + 0.3 * (k + 1))
+    feed_bursts(1.0)
+    nacc = 0
+    for fb in (1200, 600):
+        ref = O.run_burst(O.burst_msk_settings(**bopts[fb]), bpcm[fb], chunk=4096, capture_symbols=True)
+        check_soft(burst[fb].read_softbits(0), ref["soft"], f"burst MSK {fb}")
+        check_events(burst[fb].read_events(0), ref["events"])
+        sym = burst[fb].read_symbols(0)
+        assert sym.shape == ref["symbols"].shape and np.max(np.abs(sym - ref["symbols"]), initial=0.0) < SYM_TOL
+        nacc += int((ref["soft"] == -1).sum())
+        assert len(ref["soft"]) > 300
+    assert nacc == 2
+    for (Fs, fb), bank in cbank.items():
+        ref = O.run_demod(O.msk_settings(lockingbw=1.5 * fb, fb=fb, Fs=Fs), cpcm[(Fs, fb)], chunk=3000, capture_symbols=True)
+        compare(bank.read_softbits(0), bank.read_symbols(0), bank.read_status_log(0), ref)
+    for b in list(burst.values()) + list(cbank.values()):
+        b.close()
+
+
+def test_burst_msk_65536_channels(B, oracle_mod):
+    """The bank `bench.py --workload burst_msk` times: 65 536 channels of 1200 bps burst MSK (k_burst_msk_demod in two residency rounds,
+    per-lane ring positions, k_trident's persistent workgroups).  37 distinct streams with their bursts at different offsets, channel c
+    carries stream (5 c) mod 37; 20 spread channels against the oracle run of their stream: soft bits with markers, events."""
+    import torch
+
+    from jaero_amd import capi
+    from jaero_amd import signalgen as G
+    from test_gpu_burst import check_events, check_soft
+
+    free, _ = torch.cuda.mem_get_info(0)
+    if free < 200 * (1 << 30):
+        pytest.skip("needs ~200 GB of free HBM")
+    O = oracle_mod
+    nch, chunk, nsteps, nuniq = 65536, 4096, 30, 37
+    nsamp = nsteps * chunk
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(G.SEED_BASE + 6553)
+    uniq = np.stack([G.burst_msk(nsamp, burst_starts=list(range(int(rng.integers(2000, 60000)), nsamp - 1000, 72000)), ndata=700, fb=1200.0,
+                                 fc=1000.0 + float(rng.uniform(-8, 8)), ebno_db=18.0, seed=G.SEED_BASE + 6600 + u)[0] for u in range(nuniq)])
+    idx = (torch.arange(nch, device=dev) * 5) % nuniq
+    pcm = torch.from_numpy(np.ascontiguousarray(uniq.T)).to(dev)[:, idx].contiguous()  # frame-major [nsamp, nch]
+    opts = dict(freq_center=1000.0, fb=1200.0)
+    bank = B.DemodulatorBank(B.BurstMskSettings(**opts), nch, max_write_samples=chunk, softbit_capacity=int(nsamp * 1200 / 48000) + 64)
+    for s0 in range(0, nsamp, chunk):
+        bank.write(pcm[s0:s0 + chunk], layout=capi.PCM_FRAME_MAJOR)
+    check = sorted({0, 63, 64, 255, 256, 257, 511, 1023, 4095, 4096, 16383, 16384, 16385, 30000, 32767, 32768, 50001, 65471, 65472, 65535})
+    refs, nacc = {}, 0
+    for c in check:
+        u = (c * 5) % nuniq
+        if u not in refs:
+            refs[u] = O.run_burst(O.burst_msk_settings(**opts), uniq[u], chunk=chunk)
+        check_soft(bank.read_softbits(c), refs[u]["soft"], f"channel {c}")
+        check_events(bank.read_events(c), refs[u]["events"])
+        nacc += int((refs[u]["soft"] == -1).sum())
+    assert nacc >= len(check)
+    bank.close()
+
+
+@pytest.mark.parametrize("nch", [4096])
+def test_msk_600_bank(B, oracle_mod, nch):
+    """600 bps MSK at 48 kHz (the 160-tap loop k_msk_samples<160,78>) in a bank: 4096 channels = 16 persistent iterations of k_coarse2<13>
+    per workgroup and launch, 32 estimates per channel (one every 2048 samples); every channel its own lockingbw; 29 distinct signals,
+    channel c carries signal (3 c) mod 29."""
+    import torch
+
+    from jaero_amd import capi
+    from jaero_amd import signalgen as G
+
+    O = oracle_mod
+    chunk, nuniq = 4096, 29
+    nsamp = 16 * chunk
+    dev = torch.device("cuda", 0)
+    uniq = np.stack([G.msk(nsamp, fb=600.0, fc=1000.0 + 3.0 * (u % 7 - 3), ebno_db=11.0, seed=G.SEED_BASE + 6000 + u)[0] for u in range(nuniq)])
+    idx = (torch.arange(nch, device=dev) * 3) % nuniq
+    pcm = torch.from_numpy(np.ascontiguousarray(uniq.T)).to(dev)[:, idx].contiguous()
+    lbw = [900.0 - 50.0 * (c % 3) for c in range(nch)]
+    setts = [B.MskSettings(fb=600.0, lockingbw=lbw[c], freq_center=1000.0) for c in range(nch)]
+    bank = B.DemodulatorBank(setts, ebno=True, status_log=True, max_write_samples=chunk, softbit_capacity=int(nsamp * 600 / 48000) + 64)
+    for s0 in range(0, nsamp, chunk):
+        bank.write(pcm[s0:s0 + chunk], layout=capi.PCM_FRAME_MAJOR)
+    nsoft = 0
+    for c in spread(nch):
+        u = (c * 3) % nuniq
+        ref = O.run_demod(O.msk_settings(fb=600.0, lockingbw=lbw[c]), uniq[u], chunk=chunk)
+        assert ref["status"].shape[0] >= 3
+        compare(bank.read_softbits(c), None, bank.read_status_log(c), ref)
+        nsoft += len(ref["soft"])
+    assert nsoft > 20 * 400
+    bank.close()
