@@ -25,6 +25,7 @@
 #include "k_pre8400.h"
 #include "k_coarse.h"
 #include "k_coarse2.h"
+#include "k_coarse5.h"
 #include "k_viterbi.h"
 #include "k_viterbi_lanes.h"
 #include "burst_device.h"
@@ -594,7 +595,7 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
             const char *e = getenv("JAERO_PRE8400"); // "direct": the time-domain form (k_pre8400_fir), kept for A/B measurements
             c->pre_direct = e && !strcmp(e, "direct");
         }
-        HIPCHK(hipFuncSetAttribute((const void *)k_coarse4_w8400, hipFuncAttributeMaxDynamicSharedMemorySize, (64 * 257 + C4_TABN) * (int)sizeof(double)));
+        HIPCHK(hipFuncSetAttribute((const void *)k_coarse5_w8400, hipFuncAttributeMaxDynamicSharedMemorySize, (C5_XCH + C4_TABN) * (int)sizeof(double)));
     }
     if (g.kind == JAERO_KIND_MSK) { DA(c->p.dly, (size_t)ng * (g.sps + 1) * 64); DA(c->p.dly8, (size_t)ng * (g.sps2 + 1) * 64); }
     DA(c->p.soft, (size_t)nchp * g.soft_cap);
@@ -738,7 +739,7 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
 #undef FBA
         }
     }
-    if (g.nfft_log2 == 14) HIPCHK(hipFuncSetAttribute((const void *)k_coarse4, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 257 * (int)sizeof(double)));
+    if (g.nfft_log2 == 14) HIPCHK(hipFuncSetAttribute((const void *)k_coarse5, hipFuncAttributeMaxDynamicSharedMemorySize, C5_XCH * (int)sizeof(double)));
     else HIPCHK(hipFuncSetAttribute((const void *)k_coarse2<13>, hipFuncAttributeMaxDynamicSharedMemorySize, c->coarse2_lds));
     HIPCHK(hipDeviceSynchronize());
     *out = c;
@@ -1021,11 +1022,11 @@ static void launch_coarse(jaero_ctx *c, const int *d_list, int nlist, hipStream_
     const int grid = nlist < c->coarse2_grid ? nlist : c->coarse2_grid;
     if (c->g.nfft_log2 == 14)
     {
-        // 2^14 = 16 x 16 x 16 x 4, 16-point register FFTs only (k_coarse4); one padded plane of 64*257 doubles in LDS
+        // 2^14 = 16 x 16 x 16 x 4, 16-point register FFTs only, two streams per thread (k_coarse5.h); both planes of one stream in LDS
         if (c->pre8400)
-            hipLaunchKernelGGL(k_coarse4_w8400, dim3(grid), dim3(C2_THREADS), (64 * 257 + C4_TABN) * (int)sizeof(double), st, c->g, c->p, d_list, nlist, c->d_tw);
+            hipLaunchKernelGGL(k_coarse5_w8400, dim3(grid), dim3(C2_THREADS), (C5_XCH + C4_TABN) * (int)sizeof(double), st, c->g, c->p, d_list, nlist, c->d_tw);
         else
-            hipLaunchKernelGGL(k_coarse4, dim3(grid), dim3(C2_THREADS), 64 * 257 * (int)sizeof(double), st, c->g, c->p, d_list, nlist, c->d_tw);
+            hipLaunchKernelGGL(k_coarse5, dim3(grid), dim3(C2_THREADS), C5_XCH * (int)sizeof(double), st, c->g, c->p, d_list, nlist, c->d_tw);
     }
     else hipLaunchKernelGGL((k_coarse2<13>), dim3(grid), dim3(C2_THREADS), c->coarse2_lds, st, c->g, c->p, d_list, nlist, c->d_tw);
 }

@@ -6,9 +6,30 @@
 #include "jaero_device.h"
 
 // Thread-0 epilogue of one estimate: emptyingcountdown (coarsefreqestimate.cpp:133-135), FreqOffsetEstimateSlot
-// (oqpskdemodulator.cpp:629-677 / mskdemodulator.cpp:490-519), coarseCounter reset, status row.  Returns 1 when the
-// AFC recentre fired (caller then performs bigchange(): y[i]=20 and zeroes the ring).
-__device__ __forceinline__ int coarse_slot(const JGeom &g, const JPtrs &p, int ch, int zmaxloc, int N, double hzperbin, double lockingbw)
+// (oqpskdemodulator.cpp:629-677 / mskdemodulator.cpp:490-519), coarseCounter reset, status row.  In two halves so that the kernel can
+// request the channel's state (thirteen global loads, one round trip) BEFORE its peak search and use it behind it: with load and use
+// together the whole workgroup stood at the barrier behind this epilogue for that round trip, once per estimate.
+struct CoarseSlotState
+{
+    int emptying, flags, countdown, countdown2, nest, log_cnt;
+    double mse, thr, m2_freq, m2_step, mc_freq, mc_step, ebno;
+};
+__device__ __forceinline__ CoarseSlotState coarse_slot_load(const JGeom &g, const JPtrs &p, int ch)
+{
+    const int nchp = g.nchp;
+    const int *I = p.I + ch;
+    const double *S = p.S + ch;
+    CoarseSlotState c;
+    c.emptying = I[(size_t)I_EMPTYING * nchp]; c.flags = I[(size_t)I_FLAGS * nchp]; c.countdown = I[(size_t)I_COUNTDOWN * nchp];
+    c.countdown2 = I[(size_t)I_COUNTDOWN2 * nchp]; c.nest = I[(size_t)I_NEST * nchp]; c.log_cnt = I[(size_t)I_LOG_CNT * nchp];
+    c.mse = S[(size_t)S_MSE * nchp]; c.thr = S[(size_t)S_THRESH * nchp];
+    c.m2_freq = S[(size_t)S_M2_FREQ * nchp]; c.m2_step = S[(size_t)S_M2_STEP * nchp];
+    c.mc_freq = S[(size_t)S_MC_FREQ * nchp]; c.mc_step = S[(size_t)S_MC_STEP * nchp];
+    c.ebno = S[(size_t)S_EB_EBNO * nchp];
+    return c;
+}
+// Returns 1 when the AFC recentre fired (caller then performs bigchange(): y[i]=20 and zeroes the ring).
+__device__ __forceinline__ int coarse_slot_apply(const JGeom &g, const JPtrs &p, int ch, const CoarseSlotState &c, int zmaxloc, int N, double hzperbin, double lockingbw)
 {
     const int nchp = g.nchp;
     int *I = p.I + ch;
@@ -16,20 +37,18 @@ __device__ __forceinline__ int coarse_slot(const JGeom &g, const JPtrs &p, int c
 #define CI(f) I[(size_t)(f) * nchp]
 #define CS(f) S[(size_t)(f) * nchp]
     double freq_offset_est = -((double)(zmaxloc - N / 2)) * hzperbin * 0.5;
-    int emptying = CI(I_EMPTYING);
+    int emptying = c.emptying;
     if (emptying > 0) { emptying--; freq_offset_est = 0; }
-    CI(I_EMPTYING) = emptying;
 
-    const int flags = CI(I_FLAGS);
-    const bool afc = flags & JF_AFC, dcd = flags & JF_DCD;
-    const double mse = CS(S_MSE), thr = CS(S_THRESH);
-    double m2_freq = CS(S_M2_FREQ), m2_step = CS(S_M2_STEP);
-    double mc_freq = CS(S_MC_FREQ), mc_step = CS(S_MC_STEP);
-    int countdown = CI(I_COUNTDOWN);
+    const bool afc = c.flags & JF_AFC, dcd = c.flags & JF_DCD;
+    const double mse = c.mse, thr = c.thr;
+    double m2_freq = c.m2_freq, m2_step = c.m2_step;
+    double mc_freq = c.mc_freq, mc_step = c.mc_step;
+    int countdown = c.countdown;
     bool big = false;
     if (g.kind == 1) // OQPSK
     {
-        int countdown2 = CI(I_COUNTDOWN2);
+        int countdown2 = c.countdown2;
         if ((mse < thr) && (!dcd))
         {
             if (countdown2 > 0) countdown2--;
@@ -63,20 +82,21 @@ __device__ __forceinline__ int coarse_slot(const JGeom &g, const JPtrs &p, int c
         jd_wt_setfreq(mc_freq, mc_step, m2_freq, g.Fs);
         if (mc_freq < lbw / 2.0) jd_wt_setfreq(mc_freq, mc_step, lbw / 2.0, g.Fs);
         if (mc_freq > (g.Fs / 2.0 - lbw / 2.0)) jd_wt_setfreq(mc_freq, mc_step, g.Fs / 2.0 - lbw / 2.0, g.Fs);
-        CI(I_EMPTYING) = 4; // coarsefreqestimate->bigchange()
+        emptying = 4; // coarsefreqestimate->bigchange()
     }
+    CI(I_EMPTYING) = emptying;
     CI(I_COUNTDOWN) = countdown;
     CS(S_M2_FREQ) = m2_freq; CS(S_M2_STEP) = m2_step;
     CS(S_MC_FREQ) = mc_freq; CS(S_MC_STEP) = mc_step;
     CI(I_COARSE_CNT) = 0; // :426 coarseCounter = 0
-    const int nest = CI(I_NEST);
+    const int nest = c.nest;
     if (g.flags & 2u)
     {
-        const int lc = CI(I_LOG_CNT);
+        const int lc = c.log_cnt;
         if (lc < g.log_cap)
         {
             double *row = p.slog + ((size_t)ch * g.log_cap + lc) * 6;
-            row[0] = (double)nest; row[1] = m2_freq; row[2] = mc_freq; row[3] = mse; row[4] = CS(S_EB_EBNO);
+            row[0] = (double)nest; row[1] = m2_freq; row[2] = mc_freq; row[3] = mse; row[4] = c.ebno;
             row[5] = (mse > thr) ? 0.0 : 1.0;
             CI(I_LOG_CNT) = lc + 1;
         }
@@ -86,4 +106,9 @@ __device__ __forceinline__ int coarse_slot(const JGeom &g, const JPtrs &p, int c
 #undef CI
 #undef CS
     return big ? 1 : 0;
+}
+__device__ __forceinline__ int coarse_slot(const JGeom &g, const JPtrs &p, int ch, int zmaxloc, int N, double hzperbin, double lockingbw)
+{
+    const CoarseSlotState c = coarse_slot_load(g, p, ch);
+    return coarse_slot_apply(g, p, ch, c, zmaxloc, N, hzperbin, lockingbw);
 }
