@@ -72,6 +72,144 @@ def parse():
     return ap.parse_args()
 
 
+def maybe_spawn():
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks here (one per GPU, torch.distributed.run on
+    127.0.0.1) and exit with their status.  Under a launcher (WORLD_SIZE set) this is a no-op."""
+    if ARGS.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ARGS.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+def setup_ranks():
+    """(rank, world, local rank, torch device, ranks_share_a_device).  world must be what --gpus says: no silent single-rank run."""
+    import torch
+
+    from jaero_amd import dist as jd
+
+    rank, world, local = jd.init_from_env()
+    if world != ARGS.gpus:
+        raise SystemExit(f"bench.py: --gpus {ARGS.gpus} but WORLD_SIZE = {world} (launch with torch.distributed.run --nproc-per-node {ARGS.gpus}, or without a launcher)")
+    shared = jd.ranks_share_a_device()
+    di = jd.device_index(local)
+    torch.cuda.set_device(di)
+    return rank, world, local, torch.device("cuda", di), shared
+
+
+def run_timed(step, W, K, world, dev, before_timed=None):
+    """W untimed warm-up steps, then exactly K steps between barrier + device synchronisation on both sides.  Returns (max over ranks of the
+    wall time between the barriers, every rank's time for its own K steps)."""
+    import torch
+    import torch.distributed as dist
+
+    sync = torch.cuda.synchronize if torch.cuda.is_available() else (lambda: None)  # (no GPU: the gloo plumbing test of tests/test_dist_gloo.py)
+    for i in range(W):
+        step(i)
+    sync()
+    if before_timed is not None:
+        before_timed()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        step(i)
+    sync()
+    own = time.perf_counter() - t0      # this rank's own K steps (before it waits for the others)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    dts = [own]
+    if world > 1:
+        t = torch.tensor([dt, own], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        lst = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(lst, t)
+        dt = max(float(x[0].item()) for x in lst)
+        dts = [float(x[1].item()) for x in lst]
+    return dt, dts
+
+
+def rank_fields(world, shared, dts, units_per_rank, scale=1e6):
+    """config entries every multi-rank line carries: per-rank rate, whether ranks really had a GPU each."""
+    return {"ranks": world, "per_rank_rate": [round(units_per_rank / t / scale, 2) for t in dts],
+            "ranks_share_a_device": bool(shared),
+            "control_plane": "none (single rank)" if world == 1 else ("gloo (ranks share a device: RCCL refuses that; throughput figure NOT a scaling point)" if shared else "nccl (RCCL)")}
+
+
+def finish(world):
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+SIMDS, CLOCK_HZ = 1024, 2.4e9   # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
+
+
+def issue_roofline(kernel_ms_per_step: dict, names: dict, nch: int):
+    """The roof that binds these kernels: every VALU instruction of a wavefront holds its SIMD's issue port for 4
+    cycles (fp64; 32-bit operations finish sooner, so the floor is generous), so a launch cannot take less than
+    valu_insts x 4 / (1024 SIMDs x 2.4 GHz).  Instruction counts come from the SQ counter summary of the same workload
+    (profiles/sq_summary*.json, scripts/pmc_sq.sh) and are only used when they were taken on the kernel that ran here."""
+    path = os.path.join(ROOT, "profiles", "sq_summary.json")
+    out = {"cycles_per_inst": 4, "simds": SIMDS, "clock_hz": CLOCK_HZ, "source": None, "per_kernel": {}, "step": None}
+    if not os.path.exists(path):
+        out["reason"] = "profiles/sq_summary.json missing (run scripts/gpu_round.sh)"
+        return out
+    try:
+        sq = json.load(open(path))
+    except Exception as e:
+        out["reason"] = f"unreadable: {e}"
+        return out
+    out["source"] = f"profiles/sq_summary.json@{sq.get('tag', 'untagged')} (rocprofv3 --pmc SQ_INSTS_VALU pass of this workload, not this run)"
+    scale = nch / float(sq.get("channels_per_gpu", nch))
+    tot_floor = tot_ms = 0.0
+    for cls, ms in kernel_ms_per_step.items():
+        want = names.get(cls, "")
+        ent = next((v for k, v in sq.items() if isinstance(v, dict) and want and want.rstrip("<") in k), None)
+        if ent is None or "SQ_INSTS_VALU" not in ent:
+            out["per_kernel"][cls] = {"valu_insts_per_step": None, "reason": f"no counters for the kernel that ran ({want!r})"}
+            continue
+        insts = ent["SQ_INSTS_VALU"] * scale * float(ent.get("full_launches_per_step", 1))
+        floor = insts * 4.0 / (SIMDS * CLOCK_HZ) * 1e3
+        out["per_kernel"][cls] = {"kernel": want, "valu_insts_per_step": round(insts), "floor_ms": round(floor, 3), "ms": round(ms, 3),
+                                  "frac": round(floor / ms, 4) if ms else None, "wait_any_frac_of_wave_cycles": (round(ent["SQ_WAIT_ANY"] / ent["SQ_WAVE_CYCLES"], 3)
+                                  if "SQ_WAIT_ANY" in ent and ent.get("SQ_WAVE_CYCLES") else None)}
+        tot_floor += floor
+        tot_ms += ms
+    if tot_ms:
+        out["step"] = {"floor_ms": round(tot_floor, 3), "ms": round(tot_ms, 3), "frac": round(tot_floor / tot_ms, 4)}
+    return out
+
+
+def measured_traffic(pmc_file: str, cls: str, kernel_that_ran: str, nch: int):
+    """(traffic bytes per launch or None, where it came from / why it is null).  The counter summary is a committed file: it is used only
+    if it names the kernel that ran here."""
+    path = os.path.join(ROOT, "profiles", pmc_file)
+    if not os.path.exists(path):
+        return None, f"profiles/{pmc_file} missing"
+    try:
+        pj = json.load(open(path))
+        ent = pj.get(cls)
+        if not ent or ent.get("hbm_bytes_per_launch") is None:
+            return None, f"profiles/{pmc_file} has no entry for {cls}"
+        if not kernel_that_ran or kernel_that_ran.rstrip("<") not in str(ent.get("kernel", "")):
+            return None, (f"STALE: profiles/{pmc_file}@{pj.get('tag', 'untagged')} was taken on {ent.get('kernel')!r}, this run launched {kernel_that_ran!r}: "
+                          f"redo the --pmc passes (scripts/gpu_round.sh)")
+        t = ent["hbm_bytes_per_launch"] * nch / float(pj.get("channels_per_gpu", nch))
+        return t, f"profiles/{pmc_file}@{pj.get('tag', 'untagged')} (rocprofv3 --pmc passes of this command, not this run; kernel name checked)"
+    except Exception as e:
+        return None, f"profiles/{pmc_file} unreadable: {e}"
+
+
 def cpu_baseline(chunk: int):
     """The reference's own CPU path timed on this box's host cores: one process per core (function-local statics
     make instances unshareable), each demodulating `n` samples of the same kind of synthetic signal."""
@@ -150,7 +288,7 @@ def ber_check(bank, bits, nch_check: int, tail: int = 3000):
     return worst, locked
 
 
-def burst_line(bank, rank, world, nch, chunk, K, W, dt, value, msk=False):
+def burst_line(bank, rank, world, nch, chunk, K, W, dt, value, msk=False, extra=None):
     """JSON line for the burst OQPSK workload (BASELINE configs[3]); kernel classes: tracking chain, trident check, history
     push, Hilbert FIR, front end (jaero_profile_read which = 0..4)."""
     from jaero_amd import capi
@@ -188,10 +326,15 @@ def burst_line(bank, rank, world, nch, chunk, K, W, dt, value, msk=False):
                    "bursts_accepted_in_first_channels": acc, "channels_checked": min(8, nch),
                    "whole_path_hbm_frac_at_187B_per_sample": round(value * 1e6 * ALG_BYTES_WHOLE_PATH_BURST / 1e9 / (HBM_PEAK_GBS * world), 5),
                    "kernel_ms_total": {k: round(v, 3) for k, v in ms.items()}, "kernel_launches": nl},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "alg_bytes_per_sample": per_sample,
-                     "samples_per_launch": units, "avg_launch_ms": round(avg_ms, 4)},
+        "roofline": {"bound": "hbm", "kernel": dom, "kernel_name": bank.profile_kernel(names.index(dom)), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_from": "no --pmc pass of this workload committed",
+                     "alg_bytes_per_sample": per_sample, "samples_per_launch": units, "avg_launch_ms": round(avg_ms, 4)},
     }
+    tr, tr_from = measured_traffic("pmc_summary_burst_msk.json" if msk else "pmc_summary_burst_oqpsk.json", dom, bank.profile_kernel(names.index(dom)), nch)
+    if tr is not None or "STALE" in tr_from:
+        line["roofline"]["traffic"], line["roofline"]["traffic_from"] = tr, tr_from
+    if extra:
+        line["config"].update(extra)
     if world == 1 and not ARGS.no_cpu_baseline:
         try:
             line["cpu_baseline"] = cpu_baseline(chunk)
@@ -214,9 +357,8 @@ def aerol_bench():
     from jaero_amd.demodulator import AeroLBank
 
     capi.lib()
-    rank, world, local = jd.init_from_env()
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    rank, world, local, dev, shared = setup_ranks()
+    local = dev.index
     nch, K, W = ARGS.channels, ARGS.steps, ARGS.warmup
     fb, flen = 10500, 5250
     nuniq = 64
@@ -249,24 +391,7 @@ def aerol_bench():
     def step(i):
         bank.write_device(frames[i].data_ptr(), counts.data_ptr(), pitch, flen, stream)
 
-    for i in range(W):
-        step(i)
-    torch.cuda.synchronize()
-    bank.profile_enable(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(W, W + K):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, dts = run_timed(step, W, K, world, dev, before_timed=lambda: bank.profile_enable(True))
     names = ["bits", "viterbi", "post"]
     alg = {"bits": 3.0, "viterbi": 1.5, "post": 1.5}
     ms, nl = {}, {}
@@ -300,6 +425,7 @@ def aerol_bench():
                                  "one wavefront per SIMD issuing one instruction per ~2.2 ns (scripts/ubench/valu_rates.hip); "
                                  "the HBM figure is reported because the contract asks for it"},
         }
+        line["config"].update(rank_fields(world, shared, dts, value * 1e6 * dt / world))
         if world == 1 and not ARGS.no_cpu_baseline:
             from oracle import oracle as O  # cpu_baseline leg only
             x = np.tile(host[0], max(1, int(2_000_000 / host.shape[1]) + 1))[:2_000_000]
@@ -326,9 +452,7 @@ def aerol_bench():
                                         "sample": f"{len(x)} soft bits through oracle/aerol_oracle.c (AeroL::Decode restated), 32-bit groups, one thread"}
         print(json.dumps(line), flush=True)
     bank.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish(world)
 
 
 def aerol_c_bench():
@@ -344,9 +468,8 @@ def aerol_c_bench():
     from jaero_amd.demodulator import AeroLBank
 
     capi.lib()
-    rank, world, local = jd.init_from_env()
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    rank, world, local, dev, shared = setup_ranks()
+    local = dev.index
     nch, K, W = ARGS.channels, ARGS.steps, ARGS.warmup
     flen, nuniq = 4200, 16
     streams = []
@@ -366,24 +489,7 @@ def aerol_c_bench():
     def step(i):
         bank.write_device(frames_t[i].data_ptr(), counts.data_ptr(), flen, flen, stream)
 
-    for i in range(W):
-        step(i)
-    torch.cuda.synchronize()
-    bank.profile_enable(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(W, W + K):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, dts = run_timed(step, W, K, world, dev, before_timed=lambda: bank.profile_enable(True))
     names = ["bits", "viterbi", "post"]
     ms, nl = {}, {}
     for w, nm in enumerate(names):
@@ -410,6 +516,7 @@ def aerol_c_bench():
                          "alg_bytes_per_softbit": alg,
                          "note": "integer work bound by VALU issue and per-lane byte accesses (one lane walks a channel's soft bits), two orders below the HBM roof"},
         }
+        line["config"].update(rank_fields(world, shared, dts, value * 1e6 * dt / world))
         if world == 1 and not ARGS.no_cpu_baseline:
             from oracle import oracle as O  # cpu_baseline leg only
             x = np.tile(host[0], max(1, int(1_000_000 / host.shape[1]) + 1))[:1_000_000]
@@ -437,9 +544,7 @@ def aerol_c_bench():
                                         "sample": f"{len(x)} soft bits through oracle/aerol_oracle.c (DecodeC restated), 32-bit groups, one thread"}
         print(json.dumps(line), flush=True)
     bank.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish(world)
 
 
 def msk_bench():
@@ -454,9 +559,8 @@ def msk_bench():
     from jaero_amd.demodulator import DemodulatorBank, MskSettings
 
     capi.lib()
-    rank, world, local = jd.init_from_env()
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    rank, world, local, dev, shared = setup_ranks()
+    local = dev.index
     nch, chunk, K, W = ARGS.channels, ARGS.chunk, ARGS.steps, ARGS.warmup
     nsamp, nuniq = (K + W) * chunk, 32
     uniq = np.stack([signalgen.msk(nsamp, fb=1200.0, fc=1000.0 + 7.0 * u, ebno_db=ARGS.ebno_db, seed=signalgen.SEED_BASE + 900 + u + 100 * rank)[0]
@@ -472,24 +576,7 @@ def msk_bench():
     def step(i):
         bank.write(pcm[i * chunk:(i + 1) * chunk], layout=capi.PCM_FRAME_MAJOR, stream=stream)
 
-    for i in range(W):
-        step(i)
-    torch.cuda.synchronize()
-    bank.profile_enable(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(W, W + K):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, dts = run_timed(step, W, K, world, dev, before_timed=lambda: bank.profile_enable(True))
     samp_ms, samp_n = bank.profile_read(0)
     coarse_ms, coarse_n = bank.profile_read(1)
     st = [bank.read_status(c) for c in range(min(8, nch))]
@@ -504,16 +591,8 @@ def msk_bench():
         avg_ms = dom_ms / max(launches, 1)
         units = K * chunk * nch / max(launches, 1)
         achieved = per_sample * units / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary_msk.json")  # PMC pass of this workload (scripts/gpu_round.sh <tag> --workload msk)
-        if os.path.exists(pmc):
-            try:
-                pj = json.load(open(pmc))
-                traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
-                if traffic is not None:
-                    traffic = traffic * nch / float(pj.get("channels_per_gpu", nch))
-            except Exception:
-                traffic = None
+        knames = {"sample_loop": bank.profile_kernel(0), "coarse_freq": bank.profile_kernel(1)}
+        traffic, traffic_from = measured_traffic("pmc_summary_msk.json", dom, knames[dom], nch)
         line = {
             "metric": "Msamples/s of real 48 kHz PCM through the 1200 bps MSK demodulator hot path", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
@@ -526,9 +605,37 @@ def msk_bench():
                        "kernel_ms_total": {"sample_loop": round(samp_ms, 3), "coarse_freq": round(coarse_ms, 3)},
                        "kernel_launches": {"sample_loop": samp_n, "coarse_freq": coarse_n}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "alg_bytes_per_sample": per_sample,
-                         "samples_per_launch": units, "avg_launch_ms": round(avg_ms, 4)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_from": traffic_from, "kernel_name": knames[dom],
+                         "alg_bytes_per_sample": per_sample, "samples_per_launch": units, "avg_launch_ms": round(avg_ms, 4)},
         }
+        line["config"].update(rank_fields(world, shared, dts, float(K) * chunk * nch))
+        line["config"]["kernels"] = knames
+        if ARGS.check_channels > 0:
+            from oracle import oracle as O  # checker only, after the clock has stopped
+            try:
+                O.build()
+                oc = {"channels": [], "hard_bits_equal": True, "max_soft_byte_diff": 0, "bits_compared": 0}
+                refs = {}
+                for c in spread_channels(nch, ARGS.check_channels):
+                    u = c % nuniq
+                    if u not in refs:
+                        refs[u] = O.run_demod(O.msk_settings(fb=1200.0, lockingbw=1800.0, freq_center=1000.0), uniq[u], chunk=chunk)
+                    ref, got = refs[u], bank.read_softbits(c, cap=1 << 20)
+                    n = len(ref["soft"])
+                    ok = len(got) == n + ref["pending"] and bool(np.array_equal(got[:n] >= 128, ref["soft"] >= 128))
+                    oc["hard_bits_equal"] &= ok
+                    if ok and n:
+                        oc["max_soft_byte_diff"] = max(oc["max_soft_byte_diff"], int(np.max(np.abs(got[:n].astype(int) - ref["soft"].astype(int)))))
+                    oc["channels"].append(int(c))
+                    oc["bits_compared"] += n
+                line["config"]["oracle_check"] = oc
+                if not oc["hard_bits_equal"]:
+                    print(json.dumps(line), flush=True)
+                    raise SystemExit("bench.py: hard decisions of a sampled MSK channel differ from the oracle's on the same PCM")
+            except SystemExit:
+                raise
+            except Exception as e:
+                line["config"]["oracle_check"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not ARGS.no_cpu_baseline:
             from oracle import oracle as O  # cpu_baseline leg only
             ncores = os.cpu_count() or 1
@@ -548,9 +655,7 @@ def msk_bench():
                                                   f"one process per core ({wall:.1f} s wall)"}
         print(json.dumps(line), flush=True)
     bank.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish(world)
 
 
 def aerol_burst_bench():
@@ -566,9 +671,8 @@ def aerol_burst_bench():
     from jaero_amd.demodulator import AeroLBank
 
     capi.lib()
-    rank, world, local = jd.init_from_env()
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    rank, world, local, dev, shared = setup_ranks()
+    local = dev.index
     nch, K, W = ARGS.channels, ARGS.steps, ARGS.warmup
     per, nuniq = 5248, 32  # the reference ignores a unique word for NumberOfBits-68 = 4924 soft bits after the previous one
     rng = np.random.default_rng(5 + rank)
@@ -595,23 +699,7 @@ def aerol_burst_bench():
     def step(i):
         bank.write_device(frames[i].data_ptr(), counts.data_ptr(), per, per, stream)
 
-    for i in range(W):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(W, W + K):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, dts = run_timed(step, W, K, world, dev)
     npk = sum(len(bank.read_packets(c)) for c in range(min(4, nch)))
     if rank == 0:
         value = float(K) * per * nch * world / dt / 1e6
@@ -633,6 +721,7 @@ def aerol_burst_bench():
                          "note": "whole-step figure (the step is launch- and latency-bound: 31 rounds of 4 small kernels); the Viterbi trials "
                                  "are integer-VALU work, see the aerol workload"},
         }
+        line["config"].update(rank_fields(world, shared, dts, value * 1e6 * dt / world))
         if world == 1 and not ARGS.no_cpu_baseline:
             from oracle import oracle as O  # cpu_baseline leg only
             x = np.tile(host[0], max(1, int(1_000_000 / host.shape[1]) + 1))[:1_000_000]
@@ -657,9 +746,7 @@ def aerol_burst_bench():
                                         "sample": f"{len(x)} soft bits through oracle/aerol_oracle.c in burst mode, one thread"}
         print(json.dumps(line), flush=True)
     bank.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish(world)
 
 
 def host_cores():
@@ -787,7 +874,7 @@ def oracle_check(O, fb, pcm_by_ch, n_pre, soft_by_ch, bits_by_ch, chunk):
     return res
 
 
-def small_bank_run(kind: str, nch: int, chunk: int, K: int, W: int, dev, local):
+def small_bank_run(kind: str, nch: int, chunk: int, K: int, W: int, dev, local, seed_offset: int = 0):
     """BASELINE configs as written (4096-channel OQPSK = configs[2], 256-channel 1200 bps MSK = configs[1]): Msamples/s of a short
     timed run (same clock discipline, inputs resident)."""
     import torch
@@ -797,7 +884,7 @@ def small_bank_run(kind: str, nch: int, chunk: int, K: int, W: int, dev, local):
 
     nsamp = (K + W) * chunk
     if kind == "oqpsk":
-        st = signalgen.OqpskTorchStream(nch, nsamp, dev, ebno_db=ARGS.ebno_db, seed=signalgen.SEED_BASE + 31, nphase=ARGS.timing_phases)
+        st = signalgen.OqpskTorchStream(nch, nsamp, dev, ebno_db=ARGS.ebno_db, seed=signalgen.SEED_BASE + 31 + seed_offset, nphase=ARGS.timing_phases)
         pcm = st.render(0, nsamp)
         bank = DemodulatorBank(OqpskSettings(), nch, device=local, ebno=bool(ARGS.ebno), max_write_samples=chunk, softbit_capacity=int(nsamp * 10500 / 48000) + 64)
     else:
@@ -820,58 +907,42 @@ def small_bank_run(kind: str, nch: int, chunk: int, K: int, W: int, dev, local):
     return {"channels": nch, "msamples_per_s": round(v, 2), "ms_per_step": round(dt / K * 1e3, 4), "realtime_channel_equivalents": int(v / 0.048)}
 
 
-def main():
+def burst_oracle_check(O, kind: str, pcm_by_ch: dict, soft_by_ch: dict, chunk: int):
+    """Sampled channels of a burst bank against the oracle on the same PCM: the whole soft-bit stream (start-of-burst markers at the same
+    places, equal hard decisions, bytes within 1)."""
+    res = {"channels": [], "streams_equal": True, "max_soft_byte_diff": 0, "softbits_compared": 0, "bursts": 0}
+    sett = O.burst_msk_settings(freq_center=1000.0, fb=1200.0) if kind == "burstmsk" else O.burst_oqpsk_settings()
+    cache = {}
+    for c, x in pcm_by_ch.items():
+        key = x.tobytes()[:4096] + bytes(str(len(x)), "ascii")
+        if key not in cache:
+            cache[key] = O.run_burst(sett, x, chunk=chunk)["soft"]
+        ref, got = cache[key], soft_by_ch[c]
+        ok = len(got) == len(ref) and bool(np.array_equal(got == -1, ref == -1)) and bool(np.array_equal(got >= 128, ref >= 128))
+        res["streams_equal"] &= ok
+        if ok and len(ref):
+            res["max_soft_byte_diff"] = max(res["max_soft_byte_diff"], int(np.max(np.abs(got.astype(int) - ref.astype(int)))))
+        res["channels"].append(int(c))
+        res["softbits_compared"] += int(len(ref))
+        res["bursts"] += int((ref == -1).sum())
+    return res
+
+
+def burst_bench(msk: bool):
+    """BASELINE configs[3] (burst OQPSK) / its MSK sibling: a step = one 4096-sample write of every channel of a burst bank."""
     import torch
-    import torch.distributed as dist
 
     from jaero_amd import capi, signalgen
     from jaero_amd import dist as jd
-    from jaero_amd.demodulator import BurstOqpskSettings, DemodulatorBank, OqpskSettings
+    from jaero_amd.demodulator import BurstMskSettings, BurstOqpskSettings, DemodulatorBank
 
-    capi.lib()  # fail loudly if the HIP extension is missing
-    rank, world, local = jd.init_from_env()
-    assert world == ARGS.gpus or world == 1, (world, ARGS.gpus)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    capi.lib()
+    rank, world, local, dev, shared = setup_ranks()
     nch, chunk, K, W = ARGS.channels, ARGS.chunk, ARGS.steps, ARGS.warmup
     lo, _ = jd.shard_range(nch * world, rank, world)
     stream = torch.cuda.current_stream().cuda_stream
-
-    if ARGS.workload == "burst_oqpsk":
-        nsamp = (K + W) * chunk
-        soft_cap = int(nsamp * 10500 / 48000) + 64
-        pcm, _, _ = signalgen.burst_oqpsk_torch(nch, nsamp, dev, ebno_db=15.0, seed=signalgen.SEED_BASE + lo)
-        bank = DemodulatorBank(BurstOqpskSettings(), nch, device=local, max_write_samples=chunk, softbit_capacity=soft_cap)
-        bank.set_flags(afc=False, sql=False, cpu_reduce=False)
-        for i in range(W):
-            bank.write(pcm[i * chunk:(i + 1) * chunk], layout=capi.PCM_FRAME_MAJOR, stream=stream)
-        torch.cuda.synchronize()
-        bank.profile_enable(True)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(W, W + K):
-            bank.write(pcm[i * chunk:(i + 1) * chunk], layout=capi.PCM_FRAME_MAJOR, stream=stream)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        burst_line(bank, rank, world, nch, chunk, K, W, dt, float(K) * chunk * nch * world / dt / 1e6)
-        bank.close()
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-
-    if ARGS.workload == "burst_msk":
-        from jaero_amd.demodulator import BurstMskSettings
-
-        nsamp = (K + W) * chunk
+    nsamp = (K + W) * chunk
+    if msk:
         nuniq = 32
         rng = np.random.default_rng(signalgen.SEED_BASE + 900 + lo)
         uniq = np.stack([signalgen.burst_msk(nsamp, burst_starts=list(range(int(rng.integers(2000, 70000)), nsamp - 1000, 72000)), ndata=1000, fb=1200.0,
@@ -879,35 +950,55 @@ def main():
         ut = torch.from_numpy(uniq).to(dev)                                  # [nuniq][nsamp]
         idx = torch.arange(nch, device=dev) % nuniq
         pcm = ut.t().contiguous()[:, idx].contiguous()                       # frame-major [nsamp][nch]
-        bank = DemodulatorBank(BurstMskSettings(freq_center=1000.0, fb=1200.0), nch, device=local, max_write_samples=chunk,
+        bank = DemodulatorBank(BurstMskSettings(freq_center=1000.0, fb=1200.0), nch, device=dev.index, max_write_samples=chunk,
                                softbit_capacity=int(nsamp * 1200 / 48000) + 64)
-        bank.set_flags(afc=False, sql=False, cpu_reduce=False)
-        for i in range(W):
-            bank.write(pcm[i * chunk:(i + 1) * chunk], layout=capi.PCM_FRAME_MAJOR, stream=stream)
-        torch.cuda.synchronize()
-        bank.profile_enable(True)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(W, W + K):
-            bank.write(pcm[i * chunk:(i + 1) * chunk], layout=capi.PCM_FRAME_MAJOR, stream=stream)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        burst_line(bank, rank, world, nch, chunk, K, W, dt, float(K) * chunk * nch * world / dt / 1e6, msk=True)
-        bank.close()
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+    else:
+        pcm, _, _ = signalgen.burst_oqpsk_torch(nch, nsamp, dev, ebno_db=15.0, seed=signalgen.SEED_BASE + lo)
+        bank = DemodulatorBank(BurstOqpskSettings(), nch, device=dev.index, max_write_samples=chunk, softbit_capacity=int(nsamp * 10500 / 48000) + 64)
+    bank.set_flags(afc=False, sql=False, cpu_reduce=False)
 
-    # ---------------------------------------------------------------- continuous OQPSK: 10.5 kbps (headline) or 8400 bps (row f4)
+    def step(i):
+        bank.write(pcm[i * chunk:(i + 1) * chunk], layout=capi.PCM_FRAME_MAJOR, stream=stream)
+
+    dt, dts = run_timed(step, W, K, world, dev, before_timed=lambda: bank.profile_enable(True))
+    extra = rank_fields(world, shared, dts, float(K) * chunk * nch)
+    if rank == 0 and ARGS.check_channels > 0:
+        from oracle import oracle as O  # checker only, after the clock has stopped
+        try:
+            O.build()
+            check = spread_channels(nch, ARGS.check_channels)
+            pcm_by_ch = {c: pcm[:, c].cpu().numpy() for c in check}
+            soft_by_ch = {c: bank.read_softbits(c, cap=1 << 20) for c in check}
+            oc = burst_oracle_check(O, "burstmsk" if msk else "burstoqpsk", pcm_by_ch, soft_by_ch, chunk)
+            extra["oracle_check"] = oc
+            if not oc["streams_equal"]:
+                extra["oracle_check"]["FAILED"] = True
+        except Exception as e:
+            extra["oracle_check"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    burst_line(bank, rank, world, nch, chunk, K, W, dt, float(K) * chunk * nch * world / dt / 1e6, msk=msk, extra=extra)
+    failed = bool(extra.get("oracle_check", {}).get("FAILED"))
+    bank.close()
+    finish(world)
+    if failed:
+        raise SystemExit("bench.py: a sampled channel's soft-bit stream differs from the oracle's on the same PCM")
+
+
+def main():
+    """Continuous OQPSK: 10.5 kbps (the headline, BASELINE configs[2] shape; at N > 1 configs[4]) or 8400 bps (row f4)."""
+    import torch
+    import torch.distributed as dist
+
+    from jaero_amd import capi, signalgen
+    from jaero_amd import dist as jd
+    from jaero_amd.demodulator import DemodulatorBank, OqpskSettings
+
+    capi.lib()  # fail loudly if the HIP extension is missing
+    rank, world, local, dev, shared = setup_ranks()
+    local = dev.index
+    nch, chunk, K, W = ARGS.channels, ARGS.chunk, ARGS.steps, ARGS.warmup
+    lo, _ = jd.shard_range(nch * world, rank, world)
+    stream = torch.cuda.current_stream().cuda_stream
+
     fb = 8400.0 if ARGS.workload == "oqpsk8400" else 10500.0
     # Untimed pre-roll (part of preparing the resident state, like the W warm-up steps): the reference's AGC averages over 4 s and
     # its BER settles once that window has filled (SURVEY 8(d): "score BER after t = 4 s"), so the bank is run to t >= 4 s before
@@ -926,8 +1017,11 @@ def main():
                 host_pcm[c].append(cols[j])
 
     soft_cap = int((W + K) * chunk * fb / 48000) + 64
+    free0, hbm_total = torch.cuda.mem_get_info(dev.index)
     bank = DemodulatorBank(OqpskSettings(fb=fb, lockingbw=fb, coarsefreqest_fft_power=int(os.environ.get('JAERO_BENCH_FFT_POWER', '14'))), nch, device=local,
                            ebno=bool(ARGS.ebno), max_write_samples=chunk, softbit_capacity=soft_cap)
+    free1, _ = torch.cuda.mem_get_info(dev.index)
+    bytes_per_channel = max(free0 - free1, 1) / float(nch)
     bank.set_flags(afc=False, sql=False, cpu_reduce=False)
     PB = 8  # pre-roll rendered and consumed 8 steps at a time (the PCM of the whole pre-roll would not fit beside a 65536-channel bank)
     for b in range(0, pre, PB):
@@ -946,34 +1040,20 @@ def main():
     def step(i):
         bank.write(pcm[i * chunk:(i + 1) * chunk], layout=capi.PCM_FRAME_MAJOR, stream=stream)
 
-    for i in range(W):
-        step(i)
-    torch.cuda.synchronize()
-    bank.profile_enable(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(W, W + K):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, dts = run_timed(step, W, K, world, dev, before_timed=lambda: bank.profile_enable(True))
 
     samp_ms, samp_n = bank.profile_read(0)
     coarse_ms, coarse_n = bank.profile_read(1)
+    kernel_names = {"sample_loop": bank.profile_kernel(0), "coarse_freq": bank.profile_kernel(1)}
     total_samples = float(K) * chunk * nch * world
     value = total_samples / dt / 1e6
     soft_by_ch = {c: bank.read_softbits(c, cap=1 << 22) for c in check}
     locked = sum(int(bank.read_status(c).signal) for c in check)
 
     edge = None
-    if world > 1:
+    if world > 1 and shared:
+        edge = {"skipped": "ranks share a device: the control plane is gloo, the RCCL edge operations need one GPU per rank"}
+    elif world > 1:
         # the two edge operations of the path (north_star: "RCCL over xGMI used only to fan out shared IQ and gather decoded bits"),
         # once, untimed for the metric: rank 0 scatters one step of frames for ALL ranks' channels, rank 0 gathers every channel's
         # soft bits of the run
@@ -988,7 +1068,6 @@ def main():
             mine = jd.fan_out_pcm(frames, nch * world, ns, src=0, device=dev)
             ev[1].record()
             cap = 256
-            sp, cp, scap = bank.softbits_view()
             soft_t = torch.zeros((nch, cap), dtype=torch.int16, device=dev)
             cnt_t = torch.full((nch,), cap, dtype=torch.int32, device=dev)
             ev[2].record()
@@ -1004,6 +1083,26 @@ def main():
     bank.close()
     del pcm
 
+    # BASELINE configs as written: configs[2] / configs[1] at N = 1, configs[4] (32768 channels over 8 GPUs = 4096 per GPU) at N > 1
+    as_written = None
+    if ARGS.as_written and fb == 10500:
+        try:
+            if world == 1:
+                as_written = {"configs[2] 4096-channel 10.5 kbps OQPSK": small_bank_run("oqpsk", 4096, chunk, K, W, dev, local),
+                              "configs[1] 256-channel 1200 bps MSK": small_bank_run("msk", 256, chunk, K, W, dev, local),
+                              "note": "the banks as BASELINE.json words them: 64 (4) wavefronts on 1024 SIMDs -- lane-per-channel kernels are latency bound there"}
+            else:
+                r = small_bank_run("oqpsk", 4096, chunk, K, W, dev, local, seed_offset=lo)
+                t = torch.tensor([r["ms_per_step"]], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                v = 4096.0 * world * chunk / (float(t.item()) * 1e-3) / 1e6
+                as_written = {f"configs[4] {4096 * world}-channel 10.5 kbps OQPSK sharded over {world} GPUs (4096 per GPU)":
+                              {"channels": 4096 * world, "msamples_per_s": round(v, 2), "ms_per_step_slowest_rank": round(float(t.item()), 4),
+                               "realtime_channel_equivalents": int(v / 0.048)},
+                              "note": "BASELINE configs[4] as written (32768 channels over 8 GPUs): 64 wavefronts per GPU on 1024 SIMDs, the small-bank rate"}
+        except Exception as e:
+            as_written = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     if rank == 0:
         with_eb = bool(ARGS.ebno)
         b_samp = ALG_BYTES_SAMPLE_KERNEL + (ALG_BYTES_SAMPLE_KERNEL_EBNO if with_eb else 0.0)
@@ -1015,17 +1114,7 @@ def main():
         ms_per_step = dom_ms / K                       # this kernel's time per step (HIP events on the launch stream inside jaero_write)
         samples_per_step = float(chunk) * nch           # what its launches of one step process together (this rank)
         achieved = per_sample * samples_per_step / (ms_per_step * 1e-3) / 1e9
-        traffic, traffic_from = None, None
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json" if fb != 8400 else "pmc_summary_8400.json")
-        if os.path.exists(pmc):
-            try:
-                pj = json.load(open(pmc))
-                traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
-                if traffic is not None:  # measured at pj["channels_per_gpu"] channels per full-step launch: scale to this run's bank
-                    traffic = traffic * nch / float(pj.get("channels_per_gpu", nch))
-                    traffic_from = f"profiles/{os.path.basename(pmc)}@{pj.get('tag', 'untagged')} (rocprofv3 --pmc passes of this command, not this run)"
-            except Exception:
-                traffic = None
+        traffic, traffic_from = measured_traffic("pmc_summary.json" if fb != 8400 else "pmc_summary_8400.json", dom, kernel_names[dom], nch)
         # fp64 side roof: the reference's arithmetic is ~350 fp64 flops per sample in the sample loop and 3 x 5 N log2 N
         # per estimate (N = 2^14, one estimate per 4096 samples and channel) = 840 per sample; 78.6 TFLOP/s fp64 vector peak
         fl_samp, fl_coarse = 350.0, 3.0 * 5.0 * 16384 * 14 / 4096.0
@@ -1034,16 +1123,17 @@ def main():
                 "flops_per_sample": {"sample_loop": fl_samp, "coarse_freq": fl_coarse},
                 "per_kernel_frac": {"sample_loop": round(fl_samp * samples_per_step / (samp_ms / K * 1e-3) / 78.6e12, 5),
                                     "coarse_freq": round(fl_coarse * samples_per_step / (coarse_ms / K * 1e-3) / 78.6e12, 5) if coarse_ms else None},
-                "note": "algorithmic flops of the reference's arithmetic (FMA = 2), not issued instructions: the sample loop issues ~3x as many fp64 "
-                        "wave instructions as that (correctly rounded divides, atan2/tanh/sin/cos/log10/hypot expansions, selects) -- see DESIGN 9"}
+                "note": "ALGORITHMIC flops of the reference's arithmetic (FMA = 2), not issued instructions -- the issued-instruction roof is roofline_fp64_issue"}
+        issue = issue_roofline({"sample_loop": samp_ms / K, "coarse_freq": coarse_ms / K}, kernel_names, nch)
         name = "10.5 kbps" if fb == 10500 else "8400 bps (C channel)"
+        cfg_name = ("BASELINE configs[2] shape" if world == 1 else f"BASELINE configs[4] shape: {nch * world} channels sharded over {world} GPUs")
         line = {
             "metric": f"Msamples/s of real 48 kHz PCM through the {name} OQPSK demodulator hot path",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{nch}-channel-per-GPU synthetic 48 kHz {name} OQPSK continuous (BASELINE configs[2] shape, "
-                                   f"scaled to {nch} channels so every SIMD of the 256 CUs holds a wavefront of 64 channels), "
+            "config": {"workload": f"{nch}-channel-per-GPU synthetic 48 kHz {name} OQPSK continuous ({cfg_name}, "
+                                   f"scaled to {nch} channels per GPU so every SIMD of the 256 CUs holds a wavefront of 64 channels), "
                                    f"{chunk}-sample writes, coarse 2^14 FFT every 4096 samples, AFC off, EbNo meters {'on' if with_eb else 'off'}, "
                                    f"Eb/N0 {ARGS.ebno_db} dB, every channel its own carrier (8000 +- 100 Hz), bits, noise and symbol-clock phase "
                                    f"({ARGS.timing_phases} phases over two symbol periods), {pre} untimed pre-roll steps so the timed steps start at "
@@ -1051,21 +1141,29 @@ def main():
                        "channels_per_gpu": nch, "total_channels": nch * world, "chunk": chunk, "ebno_meters": with_eb,
                        "preroll_steps": pre, "timing_phases": ARGS.timing_phases,
                        "realtime_channel_equivalents": int(value / 0.048),
+                       "realtime_channel_equivalents_note": "throughput / 48 kS/s: a bank of channels_per_gpu resident channels run that many times faster than "
+                                                            "real time, NOT that many channels resident at once (see resident_channels_max)",
+                       "hbm_bytes_per_resident_channel": int(bytes_per_channel),
+                       "resident_channels_max": int(hbm_total / bytes_per_channel),
                        "whole_path_hbm_frac_at_163B_per_sample": round(value * 1e6 * ALG_BYTES_WHOLE_PATH / 1e9 / (HBM_PEAK_GBS * world), 5),
                        "kernel_ms_per_step": {"sample_loop": round(samp_ms / K, 4), "coarse_freq": round(coarse_ms / K, 4)},
                        "kernel_ms_total": {"sample_loop": round(samp_ms, 3), "coarse_freq": round(coarse_ms, 3)},
-                       "kernel_launches": {"sample_loop": samp_n, "coarse_freq": coarse_n},
+                       "kernel_launches": {"sample_loop": samp_n, "coarse_freq": coarse_n}, "kernels": kernel_names,
                        "locked_of_checked": locked, "channels_checked": len(check)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": dom, "kernel_name": kernel_names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_from": traffic_from,
                          "alg_bytes_per_sample": per_sample, "samples_per_step": samples_per_step, "kernel_ms_per_step": round(ms_per_step, 4),
                          "launches_per_step": round((samp_n if dom == "sample_loop" else coarse_n) / float(K), 2),
                          "note": "achieved = alg_bytes_per_sample x samples_per_step / kernel_ms_per_step; a step's sample-loop work is one full "
                                  "launch plus a one-sample launch behind the coarse estimate (the reference runs the estimate inside that sample)"},
             "roofline_fp64": fp64,
+            "roofline_fp64_issue": issue,
         }
+        line["config"].update(rank_fields(world, shared, dts, float(K) * chunk * nch))
         if edge:
             line["config"]["edge_collectives"] = edge
+        if as_written:
+            line["config"]["as_written"] = as_written
         if check:
             from oracle import oracle as O  # checker only, after the clock has stopped
             try:
@@ -1080,28 +1178,21 @@ def main():
                 raise
             except Exception as e:
                 line["config"]["oracle_check"] = {"error": str(e)}
-        if world == 1 and ARGS.as_written and fb == 10500:
-            try:
-                line["config"]["as_written"] = {
-                    "configs[2] 4096-channel 10.5 kbps OQPSK": small_bank_run("oqpsk", 4096, chunk, K, W, dev, local),
-                    "configs[1] 256-channel 1200 bps MSK": small_bank_run("msk", 256, chunk, K, W, dev, local),
-                    "note": "the banks as BASELINE.json words them: 64 (4) wavefronts on 1024 SIMDs -- lane-per-channel kernels are latency bound there"}
-            except Exception as e:
-                line["config"]["as_written"] = {"error": str(e)}
         if world == 1 and not ARGS.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline_continuous(chunk, fb)
             except Exception as e:  # never lose the GPU line because the CPU leg failed
                 line["cpu_baseline"] = {"value": None, "error": str(e)}
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish(world)
 
 
 if __name__ == "__main__":
     ARGS = parse()
-    if ARGS.workload == "msk":
+    maybe_spawn()
+    if ARGS.workload in ("burst_oqpsk", "burst_msk"):
+        burst_bench(ARGS.workload == "burst_msk")
+    elif ARGS.workload == "msk":
         pass  # 65536 channels: four wavefronts per CU (40 KiB of LDS each, the older half of the filter history in registers)
         msk_bench()
     elif ARGS.workload == "aerol":

@@ -256,6 +256,9 @@ const char *jaero_last_error(void);
  * 4 = burst front end (burst).  *launches receives the launch count. */
 int jaero_profile_enable(jaero_ctx *ctx, int on);
 int jaero_profile_read(jaero_ctx *ctx, int which, double *total_ms, int *launches, int reset);
+/* The name (up to the template arguments) of the kernel this bank launches for class `which`, as a profiler prints it: lets a harness
+ * check that counter summaries it holds (profiles/pmc_summary*.json) belong to the kernel that actually ran. */
+int jaero_profile_kernel(jaero_ctx *ctx, int which, char *buf, int cap);
 
 #ifdef __cplusplus
 }

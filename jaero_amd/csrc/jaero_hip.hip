@@ -956,6 +956,29 @@ extern "C" int jaero_profile_read(jaero_ctx *c, int which, double *total_ms, int
     return 0;
 }
 
+extern "C" int jaero_profile_kernel(jaero_ctx *c, int which, char *buf, int cap)
+{
+    if (!c || !buf || cap < 2 || which < 0 || which > 4) return fail(JAERO_EINVAL, "jaero_profile_kernel: bad arguments");
+    const JGeom &g = c->g;
+    const char *nm = "";
+    if (c->burst)
+    {
+        static const char *bn[5] = {"k_burst_oqpsk_demod", "k_trident", "k_hist_push", "k_hilbert_fft", "k_burst_front"};
+        nm = bn[which];
+        if (which == 0 && c->bg.kind == JAERO_KIND_BURST_MSK) nm = "k_burst_msk_demod";
+        if (which == 3 && c->hil_direct) nm = "k_hilbert<";
+    }
+    else if (which == 0)
+    {
+        if (g.kind == JAERO_KIND_OQPSK) nm = c->oq_pairs ? "k_oqpsk_fb<" : (c->pre8400 ? "k_oqpsk_samples_8400<" : "k_oqpsk_samples<");
+        else nm = c->msk_pairs ? "k_msk_fb<" : "k_msk_samples<";
+    }
+    else if (which == 1) nm = (g.nfft_log2 == 14) ? (c->pre8400 ? "k_coarse5_w8400" : "k_coarse5") : "k_coarse2<";
+    else if (which == 2) nm = "k_transpose_pcm";
+    snprintf(buf, (size_t)cap, "%s", nm);
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------ write
 static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int n, int skipA, int onlyA, hipStream_t st, int pos)
 {

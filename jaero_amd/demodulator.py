@@ -207,6 +207,12 @@ class DemodulatorBank:
         capi.check(self.L.jaero_profile_read(self.h, which, C.byref(ms), C.byref(n), int(reset)))
         return ms.value, n.value
 
+    def profile_kernel(self, which: int) -> str:
+        """Name (up to its template arguments) of the kernel this bank launches for class `which` (jaero_profile_kernel)."""
+        buf = C.create_string_buffer(96)
+        capi.check(self.L.jaero_profile_kernel(self.h, which, buf, 96))
+        return buf.value.decode()
+
 
 class Ingest:
     """Batched ingest in front of a DemodulatorBank (jaero_ingest_*): dataReceived(audio, sampleRate) per channel

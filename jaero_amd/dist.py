@@ -34,11 +34,29 @@ def init_from_env(backend: Optional[str] = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("JAERO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() and not ranks_share_a_device() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def ranks_share_a_device() -> bool:
+    """True when this node has fewer GPUs than local ranks (a multi-rank run squeezed onto a smaller lease: every rank then takes device
+    local_rank % device_count, and the control plane runs over gloo because RCCL refuses two ranks on one GPU)."""
+    import torch
+
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    return n > 0 and lw > n
+
+
+def device_index(local: int) -> int:
+    """The GPU of local rank `local`: its own one, or local % device_count when ranks share devices."""
+    import torch
+
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    return local % n if n else 0
 
 
 def fan_out_pcm(frames, nch_total: int, nsamples: int, src: int = 0, device=None):
