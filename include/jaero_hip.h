@@ -128,6 +128,9 @@ void jaero_destroy(jaero_ctx *ctx);
 int jaero_set_settings(jaero_ctx *ctx, int channel, const jaero_settings *s);
 int jaero_set_flags(jaero_ctx *ctx, int channel, int afc, int sql, int cpu_reduce);
 int jaero_set_dcd(jaero_ctx *ctx, int channel, int dcd);
+/* CenterFreqChangedSlot: continuous kinds JAERO/oqpskdemodulator.cpp:291-310 / mskdemodulator.cpp:265-282; burst MSK
+ * JAERO/burstmskdemodulator.cpp:327-342 (clamp, mixer2 follows under AFC or is pulled to within lockingbw/2, Plottables emission in the
+ * event log); burst OQPSK: accepted, no effect -- the reference's slot is empty (burstoqpskdemodulator.cpp:284-289). */
 int jaero_center_freq_changed(jaero_ctx *ctx, int channel, double freq_center_hz);
 
 /* = writeData for every channel: nsamples of real int16 PCM per channel.  `pcm` is a host pointer

@@ -188,6 +188,8 @@ struct jaero_ctx
     std::vector<EvUse> ev_used;
     size_t ev_next = 0;
     hipStream_t last_stream = nullptr;
+    hipEvent_t order_ev = nullptr; // a write on another stream than the previous one waits for what was enqueued on that one (setters included)
+    bool poisoned = false;         // a launch inside a write failed: the host's schedule mirror has advanced past the device state
 };
 
 // ------------------------------------------------------------------------------------------ small kernels
@@ -362,9 +364,10 @@ static int validate_settings(const jaero_settings &s)
 }
 
 // per-channel scalar initial state = constructor + setSettings of the reference
-static void init_channel_scalars(const jaero_ctx *c, const jaero_settings &s, std::vector<double> &S, std::vector<int> &I, int ch, bool fresh)
+// stride = the column pitch of S / I (the bank's nchp, or 1 for a one-column scratch with ch = 0: jaero_set_settings)
+static void init_channel_scalars(const jaero_ctx *c, const jaero_settings &s, std::vector<double> &S, std::vector<int> &I, int ch, bool fresh, int stride = 0)
 {
-    const int nchp = c->g.nchp;
+    const int nchp = stride > 0 ? stride : c->g.nchp;
     auto SS = [&](int f) -> double & { return S[(size_t)f * nchp + ch]; };
     auto II = [&](int f) -> int & { return I[(size_t)f * nchp + ch]; };
     double fc = s.freq_center;
@@ -499,6 +502,7 @@ extern "C" void jaero_destroy(jaero_ctx *c)
     hipDeviceSynchronize();
     for (void *q : c->allocs) hipFree(q);
     for (auto &e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    if (c->order_ev) hipEventDestroy(c->order_ev);
     delete c;
 }
 
@@ -747,10 +751,17 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
 }
 
 // ------------------------------------------------------------------------------------------ control surface
-static int upload_flags(jaero_ctx *c, int lo, int hi)
+// flags[ch] = (flags[ch] & ~mask) | bits for ch in [lo, hi): by value, on the stream of the last write (as the write that follows will
+// be, see jaero_write) -- no host buffer is in flight, so a second call right behind the first cannot disturb it
+__global__ void k_set_flag_bits(int *flags, int lo, int hi, int mask, int bits)
 {
-    // ordered on the stream of the last write (as the write that follows will be); the host copy lives as long as the bank
-    HIPCHK(hipMemcpyAsync(c->o_flags + lo, c->m.flags.data() + lo, sizeof(int) * (hi - lo), hipMemcpyHostToDevice, c->last_stream));
+    const int ch = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch < hi) flags[ch] = (flags[ch] & ~mask) | bits;
+}
+static int upload_flags(jaero_ctx *c, int lo, int hi, int mask, int bits)
+{
+    hipLaunchKernelGGL(k_set_flag_bits, dim3((hi - lo + 255) / 256), dim3(256), 0, c->last_stream, c->o_flags, lo, hi, mask, bits);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -759,15 +770,9 @@ extern "C" int jaero_set_flags(jaero_ctx *c, int channel, int afc, int sql, int 
     if (!c || channel < -1 || channel >= c->o_nch) return fail(JAERO_EINVAL, "jaero_set_flags: bad channel");
     HIPCHK(hipSetDevice(c->device));
     const int lo = channel < 0 ? 0 : channel, hi = channel < 0 ? c->o_nchp : channel + 1;
-    for (int ch = lo; ch < hi; ch++)
-    {
-        int f = c->m.flags[ch] & JF_DCD;
-        if (afc) f |= JF_AFC;
-        if (sql) f |= JF_SQL;
-        if (cpu_reduce) f |= JF_CPUREDUCE;
-        c->m.flags[ch] = f;
-    }
-    return upload_flags(c, lo, hi);
+    const int bits = (afc ? JF_AFC : 0) | (sql ? JF_SQL : 0) | (cpu_reduce ? JF_CPUREDUCE : 0);
+    for (int ch = lo; ch < hi; ch++) c->m.flags[ch] = (c->m.flags[ch] & JF_DCD) | bits;
+    return upload_flags(c, lo, hi, JF_AFC | JF_SQL | JF_CPUREDUCE, bits);
 }
 
 extern "C" int jaero_set_dcd(jaero_ctx *c, int channel, int dcd)
@@ -776,7 +781,7 @@ extern "C" int jaero_set_dcd(jaero_ctx *c, int channel, int dcd)
     HIPCHK(hipSetDevice(c->device));
     const int lo = channel < 0 ? 0 : channel, hi = channel < 0 ? c->o_nchp : channel + 1;
     for (int ch = lo; ch < hi; ch++) c->m.flags[ch] = (c->m.flags[ch] & ~JF_DCD) | (dcd ? JF_DCD : 0);
-    return upload_flags(c, lo, hi);
+    return upload_flags(c, lo, hi, JF_DCD, dcd ? JF_DCD : 0);
 }
 
 extern "C" int jaero_center_freq_changed(jaero_ctx *c, int channel, double hz)
@@ -787,7 +792,11 @@ extern "C" int jaero_center_freq_changed(jaero_ctx *c, int channel, double hz)
     {
         // BurstOqpskDemodulator::CenterFreqChangedSlot does nothing (burstoqpskdemodulator.cpp:284-289)
         if (c->bg.kind == JAERO_KIND_BURST_OQPSK) return 0;
-        return fail(JAERO_ENOTSUP, "jaero_center_freq_changed: not implemented for burst MSK banks (the trident check retunes them)");
+        // BurstMskDemodulator::CenterFreqChangedSlot (burstmskdemodulator.cpp:327-342), on the bank's stream like every other call
+        const int lo = channel < 0 ? 0 : channel, n = channel < 0 ? c->o_nch : 1;
+        hipLaunchKernelGGL(k_burst_msk_center_freq, dim3((n + 63) / 64), dim3(64), 0, c->last_stream, c->bg, c->bp, lo, n, hz, (long long)c->nsamples_total);
+        HIPCHK(hipGetLastError());
+        return 0;
     }
     const int lo = channel < 0 ? 0 : channel, n = channel < 0 ? c->g.nch : 1;
     hipLaunchKernelGGL(k_center_freq, dim3(n), dim3(256), 0, c->last_stream, c->g, c->p, lo, n, hz);
@@ -860,13 +869,13 @@ extern "C" int jaero_set_settings(jaero_ctx *c, int channel, const jaero_setting
     const int nchp = g.nchp;
     const int lo = channel < 0 ? 0 : channel, hi = channel < 0 ? g.nch : channel + 1;
     // what init_channel_scalars(fresh = false) writes, computed once (the same for every addressed channel) on a one-column scratch
-    std::vector<double> S((size_t)S_NFIELDS * nchp, 0.0);
-    std::vector<int> I((size_t)I_NFIELDS * nchp, 0);
-    init_channel_scalars(c, *s, S, I, lo, false);
+    std::vector<double> S((size_t)S_NFIELDS, 0.0);
+    std::vector<int> I((size_t)I_NFIELDS, 0);
+    init_channel_scalars(c, *s, S, I, 0, false, 1);
     JSetVals v{};
     auto setS = [&](int f, double x) { v.fS[v.nS] = f; v.vS[v.nS] = x; v.nS++; };
     auto setI = [&](int f, int x) { v.fI[v.nI] = f; v.vI[v.nI] = x; v.nI++; };
-    for (int f : {S_M2_FREQ, S_M2_STEP, S_MC_FREQ, S_MC_STEP, S_ST_FREQ, S_ST_STEP, S_LOCKINGBW, S_THRESH}) setS(f, S[(size_t)f * nchp + lo]);
+    for (int f : {S_M2_FREQ, S_M2_STEP, S_MC_FREQ, S_MC_STEP, S_ST_FREQ, S_ST_STEP, S_LOCKINGBW, S_THRESH}) setS(f, S[(size_t)f]);
     if (g.kind == JAERO_KIND_OQPSK)
         for (int f : {S_AGC_SUM, S_D1, S_D41_1, S_D41_2, S_D41_3, S_D42_1, S_D42_2, S_D42_3, S_D8_1, S_D8_2, S_RES_X1, S_RES_X2, S_RES_Y1, S_RES_Y2}) setS(f, 0.0);
     else
@@ -1060,10 +1069,24 @@ extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int l
     if (nsamples == 0) return 0;
     if (nsamples > c->max_write) return fail(JAERO_EINVAL, "jaero_write: nsamples %d exceeds max_write_samples %d", nsamples, c->max_write);
     if (layout != JAERO_PCM_CHANNEL_MAJOR && layout != JAERO_PCM_FRAME_MAJOR) return fail(JAERO_EINVAL, "jaero_write: bad layout");
+    if (c->poisoned) return fail(JAERO_EHIP, "jaero_write: an earlier write of this bank failed part-way (its schedule mirror is ahead of the device state): destroy the bank and create a new one");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
+    if (st != c->last_stream)
+    {
+        // setters and earlier writes were enqueued on last_stream: this write is ordered behind them
+        if (!c->order_ev) HIPCHK(hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(c->order_ev, c->last_stream));
+        HIPCHK(hipStreamWaitEvent(st, c->order_ev, 0));
+    }
     c->last_stream = st;
-    if (c->burst) return burst_write(c, pcm, nsamples, layout, is_device_ptr, st);
+    c->poisoned = true; // until this write has been enqueued completely
+    if (c->burst)
+    {
+        const int rc = burst_write(c, pcm, nsamples, layout, is_device_ptr, st);
+        if (rc == 0) c->poisoned = false;
+        return rc;
+    }
     const JGeom &g = c->g;
     const int nch = g.nch, nchp = g.nchp;
 
@@ -1129,6 +1152,7 @@ extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int l
         pos = next;
     }
     HIPCHK(hipGetLastError());
+    c->poisoned = false;
     return 0;
 }
 

@@ -25,6 +25,29 @@ __device__ __forceinline__ void bd_event(const BGeom &g, const BPtrs &p, int ch,
     }
     else overflow |= 4;
 }
+// BurstMskDemodulator::CenterFreqChangedSlot (JAERO/burstmskdemodulator.cpp:327-342; wired to the spectrum display, mainwindow.cpp:415)
+// for channels [ch_lo, ch_lo + n): the same lines k_burst_msk_demod runs when a trident verdict retunes it, plus the slot's Plottables
+// emission, stamped with the first sample of the write that follows.
+__global__ void k_burst_msk_center_freq(const BGeom g, const BPtrs p, int ch_lo, int n, double freq_center, long long sample)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, nchp = g.nchp;
+    if (k >= n) return;
+    const int ch = ch_lo + k;
+    double m2_freq = BLDF(BS_M2_FREQ), m2_step = BLDF(BS_M2_STEP);
+    const double lockingbw = BLDF(BS_LOCKINGBW);
+    const bool afc = BLDI(BI_FLAGS) & JF_AFC;
+    int ev_cnt = BLDI(BI_EV_CNT), overflow = BLDI(BI_OVERFLOW);
+    double fc = freq_center;
+    if (fc < (0.75 * g.fb)) fc = 0.75 * g.fb;
+    if (fc > (g.Fs / 2.0 - 0.75 * g.fb)) fc = g.Fs / 2.0 - 0.75 * g.fb;
+    double mc_freq = fc; if (mc_freq < 0) mc_freq = 0; // WaveTable::SetFreq
+    if (afc) jd_wt_setfreq(m2_freq, m2_step, mc_freq, g.Fs);
+    if ((m2_freq - mc_freq) > (lockingbw / 2.0)) jd_wt_setfreq(m2_freq, m2_step, mc_freq + (lockingbw / 2.0), g.Fs);
+    if ((m2_freq - mc_freq) < (-lockingbw / 2.0)) jd_wt_setfreq(m2_freq, m2_step, mc_freq - (lockingbw / 2.0), g.Fs);
+    bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_FREQ, m2_freq);
+    BLDF(BS_MC_FREQ) = mc_freq; BLDF(BS_M2_FREQ) = m2_freq; BLDF(BS_M2_STEP) = m2_step;
+    BLDI(BI_EV_CNT) = ev_cnt; BLDI(BI_OVERFLOW) = overflow;
+}
 __device__ __forceinline__ void bd_cmul(double &ar, double &ai, double br, double bi)
 {
     const double r = ar * br - ai * bi, i = ar * bi + ai * br;

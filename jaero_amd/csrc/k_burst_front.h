@@ -292,7 +292,11 @@ __global__ __launch_bounds__(64) void k_burst_front(const BGeom g, const BPtrs p
             if (tm)
             {
                 const int pos0 = bback(s_bt, twoPL, g.bt_len);
-                const double *__restrict__ btg = p.bt + (size_t)grp * g.bt_len * 64;
+                // the ring this kernel also WRITES (through bt, this iteration's entry included): a plain pointer, and the stores of all
+                // lanes made visible to the wavefront before other lanes' columns are read
+                const double *btg = p.bt + (size_t)grp * g.bt_len * 64;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): this wavefront's own stores have reached memory order before the cross-lane reads
                 while (tm)
                 {
                     const int src = __ffsll((long long)tm) - 1;

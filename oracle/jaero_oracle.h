@@ -77,6 +77,8 @@ void jo_burst_set_flags(jo_burst *d, int afc, int sql, int cpu_reduce);
 void jo_burst_set_dcd(jo_burst *d, int dcd); /* BurstMskDemodulator::DCDstatSlot */
 /* = writeData (mono) */
 long jo_burst_write(jo_burst *d, const int16_t *pcm, long nsamples);
+/* CenterFreqChangedSlot(freq_center): acts on burst MSK (burstmskdemodulator.cpp:327-342), empty for burst OQPSK (burstoqpskdemodulator.cpp:284-289) */
+void jo_burst_center_freq_changed(jo_burst *d, double freq_center);
 /* soft bits as passed to processDemodulatedSoftBits, concatenated; -1 = start-of-burst marker */
 long jo_burst_take_soft(jo_burst *d, int16_t *dst, long cap);
 /* rows of 3 doubles [absolute sample index, kind, value]; kind 0 SignalStatus(value), 1 EbNoMeasurmentSignal(value),

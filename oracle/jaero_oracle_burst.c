@@ -576,6 +576,12 @@ static void bmsk_center_freq_changed(jo_burst *d, double freq_center, long sampl
     if ((d->mixer2.freq - d->mixer_center.freq) < (-d->lockingbw / 2.0)) wt_setfreq(&d->mixer2, d->mixer_center.freq - (d->lockingbw / 2.0));
     burst_event(d, sample, JO_EV_FREQ, d->mixer2.freq);
 }
+/* CenterFreqChangedSlot as a caller reaches it (JAERO/mainwindow.cpp:415 wires the spectrum display to it): BurstMskDemodulator acts
+ * (burstmskdemodulator.cpp:327-342), BurstOqpskDemodulator's slot is empty (burstoqpskdemodulator.cpp:284-289) */
+void jo_burst_center_freq_changed(jo_burst *d, double freq_center)
+{
+    if (d->kind == JO_KIND_BURST_MSK) bmsk_center_freq_changed(d, freq_center, d->nsamples_total);
+}
 static void bmsk_set_settings(jo_burst *d, const jo_settings *s) /* burstmskdemodulator.cpp:150-325 */
 {
     d->Fs = s->Fs; d->lockingbw = s->lockingbw; d->fb = s->fb;

@@ -113,6 +113,8 @@ def lib():
         L.jo_burst_trace.argtypes = [C.c_void_p, C.c_int]
         L.jo_burst_capture_symbols.argtypes = [C.c_void_p, C.c_int]
         L.jo_burst_write.restype = C.c_long
+        L.jo_burst_center_freq_changed.restype = None
+        L.jo_burst_center_freq_changed.argtypes = [C.c_void_p, C.c_double]
         L.jo_burst_write.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         for name in ("jo_burst_take_soft", "jo_burst_take_events", "jo_burst_take_symbols"):
             f = getattr(L, name)
@@ -290,6 +292,9 @@ class BurstDemod:
         pcm = np.ascontiguousarray(pcm, dtype=np.int16)
         self.L.jo_burst_write(self.h, pcm.ctypes.data, pcm.shape[0])
 
+    def center_freq_changed(self, hz: float):
+        self.L.jo_burst_center_freq_changed(self.h, float(hz))
+
     def take_soft(self):
         return _drain(self.L.jo_burst_take_soft, self.h, 1, np.int16, 1 << 16)
 
@@ -312,10 +317,15 @@ class BurstDemod:
         return self.L.jo_burst_get_freq_est(self.h)
 
 
-def run_burst(settings: Settings, pcm: np.ndarray, chunk: int = 4096, afc=False, sql=False, capture_symbols=False, trace=False):
-    """Feed pcm in `chunk`-sample writes; returns dict(soft, events[, symbols], pending, mse, freq_est)."""
+def run_burst(settings: Settings, pcm: np.ndarray, chunk: int = 4096, afc=False, sql=False, capture_symbols=False, trace=False,
+              center_at: int = -1, center_hz: float = 0.0):
+    """Feed pcm in `chunk`-sample writes (CenterFreqChangedSlot(center_hz) in front of the first write at or behind sample `center_at`);
+    returns dict(soft, events[, symbols], pending, mse, freq_est)."""
     d = BurstDemod(settings, afc=afc, sql=sql, capture_symbols=capture_symbols, trace=trace)
     for s in range(0, pcm.shape[0], chunk):
+        if center_at >= 0 and s >= center_at:
+            d.center_freq_changed(center_hz)
+            center_at = -1
         d.write(pcm[s:s + chunk])
     out = {"soft": d.take_soft(), "events": d.take_events(), "pending": d.pending, "mse": d.mse, "freq_est": d.freq_est}
     if capture_symbols:

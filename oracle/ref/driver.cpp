@@ -112,6 +112,7 @@ static double feed(DEMOD &d, const QByteArray &pcm)
     double secs = 0;
     for (long s = 0; s < nsamp;)
     {
+        g_write_start = s; // what a slot called between two writes emits is stamped with the write that follows it
         if (dcd_at >= 0 && s >= dcd_at) { d.DCDstatSlot(true); dcd_at = -1; }
         if (dcd_off_at >= 0 && s >= dcd_off_at) { d.DCDstatSlot(false); dcd_off_at = -1; }
         if (cf_at >= 0 && s >= cf_at) { d.CenterFreqChangedSlot(cf_hz); cf_at = -1; }

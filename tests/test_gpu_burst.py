@@ -171,3 +171,31 @@ def test_single_channel_mirror_groups(B):
     check_soft(flat, g["soft"])
     assert all(len(grp) in (32, 33) for grp in groups)
     assert status.count(True) == int((g["soft"] == -1).sum())
+
+
+@pytest.mark.parametrize("afc,hz", [(False, 2300.0), (True, 1400.0)])
+def test_burst_msk_center_freq_changed(B, oracle_mod, afc, hz):
+    """BurstMskDemodulator::CenterFreqChangedSlot (burstmskdemodulator.cpp:327-342) on ONE channel of a live burst MSK bank between two
+    writes: that channel equals the oracle given the same call at the same sample (the oracle = the unmodified reference there:
+    tests/test_oracle_burst.py), its neighbours equal the oracle without it."""
+    n, chunk, at = 48000 * 5, 4096, 90112
+    pcm = np.stack([G.burst_msk(n, burst_starts=[30000 + 500 * c, 150000 + 300 * c], fb=1200.0, fc=1900.0 + 10 * c, ebno_db=18.0, seed=41 + c)[0]
+                    for c in range(3)])
+    bank = bank_for(B, "burstmsk", dict(fb=1200, lockingbw=1800.0), 3, max_write_samples=chunk, softbit_capacity=30000)
+    bank.set_flags(afc=afc, sql=False, cpu_reduce=False)
+    for s in range(0, n, chunk):
+        if s == at:
+            bank.center_freq_changed(hz, channel=1)
+        bank.write(pcm[:, s:s + chunk])
+    sett = oracle_mod.burst_msk_settings(fb=1200.0, lockingbw=1800.0)
+    for c in range(3):
+        ref = oracle_mod.run_burst(sett, pcm[c], chunk=chunk, afc=afc, center_at=at if c == 1 else -1, center_hz=hz)
+        check_soft(bank.read_softbits(c), ref["soft"], f"channel {c}")
+        check_events(bank.read_events(c), ref["events"])
+        assert (ref["events"][:, 0] == at).any() == (c == 1)
+        assert (ref["soft"] == -1).sum() >= 1
+    bank.close()
+    # the burst OQPSK slot is empty (burstoqpskdemodulator.cpp:284-289): accepted, nothing happens
+    b2 = bank_for(B, "burstoqpsk", {}, 1, max_write_samples=chunk, softbit_capacity=1000)
+    b2.center_freq_changed(7000.0)
+    b2.close()

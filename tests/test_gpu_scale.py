@@ -184,13 +184,6 @@ def test_burst_oqpsk_4096_channels(B, oracle_mod):
     nch, nsamp, chunk = 4096, 110000, 4096
     dev = torch.device("cuda", 0)
     pcm, _, _ = G.burst_oqpsk_torch(nch, nsamp, dev, ndata_sym=1500, ebno_db=15.0, seed=G.SEED_BASE + 40960, max_offset_sym=600)
-    # Digital silence for the first half second (it swallows every channel's first burst).  Where the reference's Hilbert filter --
-    # an FFT overlap-add (JFastFir) -- should output exact zeros (before the first signal sample has travelled through its 6145-sample
-    # latency) it emits round-off of the block that holds the signal's start, ~1e-12 of full scale, which the AGC at its gain cap of
-    # 1.4e6 turns into "symbols" of ~1e-4 if a burst gate happens to be open then; the filter here (overlap-save too, but with its own
-    # 4096-point blocks) gives exact zeros or its own round-off there.  With silence first no gate is open in that stretch, and that
-    # artefact of the FFT library (JFFT there, a stand-in in the oracle) stays out of the comparison.
-    pcm[:24000] = 0
     bank = B.DemodulatorBank(B.BurstOqpskSettings(), nch, capture_symbols=True, trace=True, max_write_samples=chunk, softbit_capacity=30000)
     feed_frames(bank, pcm, chunk)
     nacc = 0
@@ -201,12 +194,20 @@ def test_burst_oqpsk_4096_channels(B, oracle_mod):
         check_events(bank.read_events(c), ref["events"])
         sym = bank.read_symbols(c)
         assert sym.shape == ref["symbols"].shape
-        # rows that are nothing but amplified round-off on both sides (see above) are only required to be that
-        noise_only = (np.abs(ref["symbols"][:, :2]).max(axis=1) < 1e-3) & (np.abs(sym[:, :2]).max(axis=1) < 1e-3)
-        assert noise_only.sum() <= 0.2 * max(len(noise_only), 1)
-        assert np.max(np.abs(sym - ref["symbols"])[~noise_only], initial=0.0) < SYM_TOL
+        # The tracking chain reads the REAL part of the delayed analytic signal, and that part is one tap of the Hilbert kernel (-1 at
+        # k = 1024): minus the input 1024 samples earlier.  A burst that opens its gate within the first L + D1 + D2 + 1024 = 12 537 samples
+        # of a stream (L = 6145 the filter's latency, D1 + D2 = 5368 the two delay lines) is therefore demodulated, for up to 1024 samples =
+        # 112 symbols, from input "before the stream began": exact zeros here (k_hilbert_fft copies the real part), while the reference's
+        # FFT convolution leaves its round-off there (~1e-13 of full scale, whatever FFT library it is linked with), which the AGC at its
+        # gain cap of 1.4e6 turns into "symbols" of 1e-7 .. 1e-4.  Those leading rows carry nothing but the reference's FFT round-off:
+        # they must be exact zeros here, tiny there, at most 112, and nothing else may differ.
+        lead = 0
+        while lead < len(sym) and not sym[lead, :2].any():
+            lead += 1
+        assert lead <= 112 and np.abs(ref["symbols"][:lead, :2]).max(initial=0.0) < 2e-4
+        assert np.max(np.abs(sym - ref["symbols"])[lead:], initial=0.0) < SYM_TOL
         nacc += int((ref["soft"] == -1).sum())
-    assert nacc >= 5  # one whole burst per channel in view (right behind half a second of silence: not every one is accepted)
+    assert nacc >= 5  # one whole burst per channel in view
     bank.close()
 
 
@@ -226,7 +227,6 @@ def test_burst_oqpsk_65536_channels(B, oracle_mod):
     nch, nsamp, chunk = 65536, 26 * 4096, 4096
     dev = torch.device("cuda", 0)
     pcm, _, _ = G.burst_oqpsk_torch(nch, nsamp, dev, ndata_sym=1500, ebno_db=15.0, seed=G.SEED_BASE + 65537)
-    pcm[:24000] = 0  # as in test_burst_oqpsk_4096_channels
     bank = B.DemodulatorBank(B.BurstOqpskSettings(), nch, max_write_samples=chunk, softbit_capacity=30000)
     feed_frames(bank, pcm, chunk)
     check = sorted({0, 63, 64, 255, 256, 257, 511, 1023, 4095, 4096, 16383, 16384, 16385, 30000, 32767, 32768, 50001, 65471, 65472, 65535})

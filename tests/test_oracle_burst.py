@@ -105,6 +105,20 @@ def test_burst_msk_synthetic_vs_ref(R, fb, seed, chunk):
     assert np.array_equal(r["events"], as_write_stamps(o["events"], chunk))
 
 
+@pytest.mark.parametrize("afc,hz", [(False, 2300.0), (True, 1400.0), (False, 100.0)])
+def test_burst_msk_center_freq_changed_vs_ref(R, afc, hz):
+    """BurstMskDemodulator::CenterFreqChangedSlot in the middle of a stream (burstmskdemodulator.cpp:327-342): the clamp to
+    [0.75 fb, Fs/2 - 0.75 fb], mixer2 following under AFC or pulled to within lockingbw/2, the Plottables emission -- the unmodified
+    reference (center_at / center_hz of oracle/ref/driver.cpp) against the restatement."""
+    n = 48000 * 5
+    pcm, _ = G.burst_msk(n, burst_starts=[30000, 150000], fb=1200.0, fc=1900.0, ebno_db=18.0, seed=41)
+    r = R.run_ref("burstmsk", pcm, fb=1200, lockingbw=1800, chunk=4096, center_at=90112, center_hz=hz, afc=int(afc))
+    o = R.run_burst(R.burst_msk_settings(fb=1200.0, lockingbw=1800.0), pcm, chunk=4096, afc=afc, center_at=90112, center_hz=hz)
+    assert np.array_equal(r["soft"], o["soft"])
+    assert np.array_equal(r["events"], as_write_stamps(o["events"], 4096))
+    assert (o["events"][:, 0] == 90112).any()  # the slot's own Plottables emission
+
+
 def test_burst_oqpsk_random_vs_ref(R):
     pcm, _ = G.burst_oqpsk(100000, burst_starts=[30000], ndata_sym=800, fc=7990.0, ebno_db=12.0, seed=77)
     r = R.run_ref("burstoqpsk", pcm, chunk=2000)
