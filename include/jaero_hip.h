@@ -247,6 +247,9 @@ int jaero_debug_prefilter(int device, const double *in_reim, int n, double alpha
 /* Test hook: the first n prefiltered complex samples (re, im pairs) of the last jaero_write of an 8400 bps bank, channel ch
  * (cval_prefiltered, JAERO/oqpskdemodulator.cpp:343-381). */
 int jaero_debug_read_prefiltered(jaero_ctx *ctx, int channel, double *out_reim, int n);
+/* Test hook: the Viterbi decoder picks its layout by size (one block per wavefront below 16 384 blocks, one per lane from there); tests
+ * force one so that both meet the oracle at small sizes.  mode: 0 = by size (default), 1 = wave, 2 = lanes.  Process-wide. */
+int jaero_debug_viterbi_layout(int mode);
 
 /* introspection */
 int jaero_abi_version(void);

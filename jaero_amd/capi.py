@@ -24,7 +24,7 @@ EXPORTS = [
     "jaero_center_freq_changed", "jaero_write", "jaero_read_softbits", "jaero_read_softbits_all",
     "jaero_softbits_view", "jaero_discard_softbits", "jaero_read_status", "jaero_read_status_log",
     "jaero_read_symbols", "jaero_viterbi_decode_soft", "jaero_viterbi_continuous", "jaero_abi_version",
-    "jaero_num_channels", "jaero_strerror", "jaero_last_error", "jaero_profile_enable", "jaero_profile_read", "jaero_profile_kernel",
+    "jaero_num_channels", "jaero_strerror", "jaero_last_error", "jaero_profile_enable", "jaero_profile_read", "jaero_profile_kernel", "jaero_debug_viterbi_layout",
     "jaero_debug_schedule", "jaero_debug_prefilter", "jaero_debug_read_prefiltered", "jaero_read_events",
     "jaero_aerol_create", "jaero_aerol_create_burst", "jaero_aerol_read_packets", "jaero_aerol_destroy", "jaero_aerol_write", "jaero_aerol_read_sus", "jaero_aerol_read_events",
     "jaero_aerol_tick_dcd", "jaero_aerol_profile_enable", "jaero_aerol_profile_read", "jaero_aerol_read_voice",

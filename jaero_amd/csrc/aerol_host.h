@@ -165,8 +165,8 @@ static int aerol_create(int device, int nchannels, int fb, int max_softbits_per_
         g.packed = 1;
         // deinterleaver output: row-major.  The tiled layout ([wavefront][16-byte group][lane][16], k_viterbi_lanes reads 8 x 1 KiB per chunk)
         // was built when cold rows cost the decoder 0.85 ms; with its chunk prefetch it no longer gains anything and the tiled writes cost
-        // 0.14 ms (3.51 vs 3.36 ms per step), so it is only kept behind JAERO_AEROL_TILED for measurements.
-        g.tiled = getenv("JAERO_AEROL_TILED") ? 1 : 0;
+        // 0.14 ms (3.51 vs 3.36 ms per step): not used (its switch left the library in round 3; the kernels keep the code path).
+        g.tiled = 0;
         g.dl2_words = (g.dl2_sz + 31) / 32 + 1;
         AA(c->p.dl2w, (size_t)g.nchp * g.dl2_words);
     }

@@ -191,8 +191,7 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
         if ((rc = fft4096_tables(gk, &dH, &dtw, (const void *)k_hilbert_fft))) return rc;
         c->allocs.push_back(dH); c->allocs.push_back(dtw);
         p.hilH = dH; p.tw12 = dtw;
-        const char *e = getenv("JAERO_HILBERT"); // "direct": the time-domain form (k_hilbert), kept for A/B measurements
-        c->hil_direct = (e && !strcmp(e, "direct")) || g.hil_ntaps != 2048;
+        if (g.hil_ntaps != 2048) return fail(JAERO_ENOTSUP, "the overlap-save Hilbert kernel is built for QJHilbertFilter's 2048 taps");
     }
     // scalar state
     {
@@ -282,22 +281,8 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
         const long long n0 = c->nsamples_total;
         HIPCHK(hipMemsetAsync(p.ev_count, 0, sizeof(int), st));
         int pi = prof_begin(c, 3, st);
-        if (!c->hil_direct)
-            hipLaunchKernelGGL(k_hilbert_fft, dim3(g.nchp / 8, (int)(((n0 + n - 1) >> 11) - (n0 >> 11) + 1)), dim3(PF_THREADS), 4 * 2 * PRE_L * (int)sizeof(double), st, g, p, n, n0);
-        else
-        {
-            // every window of this launch starts at the same offset inside a four-sample cell of the history ring
-            const int ph = (int)(((n0 - g.hil_lat + 1) % 4 + 4) % 4);
-            const dim3 hgrid(g.ngroups, (n + 4 * HB_R - 1) / (4 * HB_R));
-            switch (ph)
-            {
-            case 0: hipLaunchKernelGGL(k_hilbert<0>, hgrid, dim3(256), 0, st, g, p, n, n0); break;
-            case 1: hipLaunchKernelGGL(k_hilbert<1>, hgrid, dim3(256), 0, st, g, p, n, n0); break;
-            case 2: hipLaunchKernelGGL(k_hilbert<2>, hgrid, dim3(256), 0, st, g, p, n, n0); break;
-            default: hipLaunchKernelGGL(k_hilbert<3>, hgrid, dim3(256), 0, st, g, p, n, n0); break;
-            }
-        }
-        LAUNCHCHK("k_hilbert");
+        hipLaunchKernelGGL(k_hilbert_fft, dim3(g.nchp / 8, (int)(((n0 + n - 1) >> 11) - (n0 >> 11) + 1)), dim3(PF_THREADS), 4 * 2 * PRE_L * (int)sizeof(double), st, g, p, n, n0);
+        LAUNCHCHK("k_hilbert_fft");
         prof_end(c, pi, st);
         pi = prof_begin(c, 4, st);
         hipLaunchKernelGGL(k_burst_front, dim3(g.ngroups), dim3(64), 0, st, g, p, n, n0);

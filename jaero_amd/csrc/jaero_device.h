@@ -51,6 +51,10 @@ enum
     I_DLY_POS,   // MSK: shared slot of delayedsmpl / delayt8 rings
     I_NFIELDS
 };
+// state access of the continuous sample kernels (ch, nchp in scope)
+#define LDF(f) (p.S[(size_t)(f) * nchp + ch])
+#define LDI(f) (p.I[(size_t)(f) * nchp + ch])
+
 #define JF_AFC 1
 #define JF_SQL 2
 #define JF_CPUREDUCE 4

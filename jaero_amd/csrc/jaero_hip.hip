@@ -18,7 +18,6 @@
 #include <vector>
 #include "../../include/jaero_hip.h"
 #include "jaero_device.h"
-#include "k_oqpsk.h"
 #include "k_oqpsk_fb.h"
 #include "k_msk.h"
 #include "k_msk_fb.h"
@@ -157,7 +156,6 @@ struct jaero_ctx
     JTaps28 oq_taps{}; // the 28 distinct values of the (bitwise symmetric) 55-tap RRC, scalar operands of k_oqpsk_fb's filter
     // fb == 8400 (k_pre8400.h): prefilter buffers, samples written so far, size of the previous write
     bool pre8400 = false, pre_direct = false;
-    bool hil_direct = false; // burst banks: JAERO_HILBERT=direct selects the time-domain Hilbert kernel
     JPre pre{};
     long long pre_n0 = 0;
     int pre_nprev = 0;
@@ -351,9 +349,8 @@ static int validate_settings(const jaero_settings &s)
     // of the incoming audio, JAERO/mskdemodulator.cpp:528-537): matched filters of 2 Fs / fb = 20, 40, 80 or 160 taps
     const bool fs_ok = s.Fs == 48000 || (s.kind == JAERO_KIND_MSK && (s.Fs == 24000 || s.Fs == 12000));
     if (!fs_ok) return fail(JAERO_ENOTSUP, "Fs = %g is not implemented (48000; continuous MSK also 24000 and 12000)", s.Fs);
-    // fb = 8400 (C channel): the continuous demodulator with a 2^14-point coarse FFT (k_pre8400.h); JAERO_DISABLE_8400=1 refuses it
-    const char *no84 = getenv("JAERO_DISABLE_8400");
-    const bool allow84 = !(no84 && atoi(no84) != 0) && s.kind == JAERO_KIND_OQPSK && s.coarsefreqest_fft_power == 14;
+    // fb = 8400 (C channel): the continuous demodulator with a 2^14-point coarse FFT (k_pre8400.h)
+    const bool allow84 = s.kind == JAERO_KIND_OQPSK && s.coarsefreqest_fft_power == 14;
     if (oq && s.fb != 10500 && !(s.fb == 8400 && allow84))
         return fail(JAERO_ENOTSUP, "OQPSK: fb must be 10500, or 8400 for the continuous demodulator with coarsefreqest_fft_power 14");
     if (!oq && s.fb != 600 && s.fb != 1200) return fail(JAERO_ENOTSUP, "MSK: fb must be 600 or 1200");
@@ -508,8 +505,8 @@ extern "C" void jaero_destroy(jaero_ctx *c)
 
 static void launch_pre8400_filter(const JGeom &g, const JPtrs &p, const JPre &q, int n, long long n0, bool direct, hipStream_t st)
 {
-    if (direct) hipLaunchKernelGGL(k_pre8400_fir, dim3(g.ngroups, (n + 4 * PRE_R - 1) / (4 * PRE_R)), dim3(256), 0, st, g, p, q, n, n0);
-    else hipLaunchKernelGGL(k_pre8400_fft, dim3(g.nchp / 4, (int)(((n0 + n - 1) >> 11) - (n0 >> 11) + 1)), dim3(PF_THREADS), 4 * 2 * PRE_L * (int)sizeof(double), st, g, p, q, n, n0);
+    (void)direct;
+    hipLaunchKernelGGL(k_pre8400_fft, dim3(g.nchp / 4, (int)(((n0 + n - 1) >> 11) - (n0 >> 11) + 1)), dim3(PF_THREADS), 4 * 2 * PRE_L * (int)sizeof(double), st, g, p, q, n, n0);
 }
 
 extern "C" int jaero_create(int device, int nchannels, const jaero_settings *settings, int per_channel_stride, unsigned flags,
@@ -596,8 +593,7 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
             if ((rc = fft4096_tables(pt, &dH, &dtw, (const void *)k_pre8400_fft))) { jaero_destroy(c); return rc; }
             c->pre.H = dH; c->pre.tw = dtw;
             c->allocs.push_back(dH); c->allocs.push_back(dtw);
-            const char *e = getenv("JAERO_PRE8400"); // "direct": the time-domain form (k_pre8400_fir), kept for A/B measurements
-            c->pre_direct = e && !strcmp(e, "direct");
+            c->pre_direct = false; // (the time-domain form k_pre8400_fir and its A/B switch left the library in round 3)
         }
         HIPCHK(hipFuncSetAttribute((const void *)k_coarse5_w8400, hipFuncAttributeMaxDynamicSharedMemorySize, (C5_XCH + C4_TABN) * (int)sizeof(double)));
     }
@@ -688,18 +684,16 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<F, L, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
     }
         c->msk_ldsn = g.fir_n == 160 ? MSK_LDSN_600 : (g.fir_n == 80 ? MSK_LDSN_1200 : (g.fir_n == 40 ? MSK_LDSN_40 : MSK_LDSN_20));
-        if (g.fir_n == 80) MSK_ATTR(80, MSK_LDSN_1200) else if (g.fir_n == 160) MSK_ATTR(160, MSK_LDSN_600)
-        else if (g.fir_n == 40) MSK_ATTR(40, MSK_LDSN_40) else MSK_ATTR(20, MSK_LDSN_20)
+        if (g.fir_n == 160) MSK_ATTR(160, MSK_LDSN_600) else if (g.fir_n == 40) MSK_ATTR(40, MSK_LDSN_40) else if (g.fir_n == 20) MSK_ATTR(20, MSK_LDSN_20) // 80 taps: k_msk_fb below
 #undef MSK_ATTR
         if (g.fir_n == 80)
         {
             // front / back pairs (k_msk_fb.h).  Banks of at most two channel groups per CU: one pair per workgroup, the halves on different
             // SIMDs, 36 history entries per arm in LDS and 44 in the front half's registers (256 channels: 82 -> 113 Msamples/s).  Larger
             // banks: four pairs per workgroup, each pair on one SIMD, 32 entries in LDS, 26 in the front half's and the 22 oldest in the
-            // back half's registers (65 536 channels: 9.2 -> 10.6 Gsamples/s).  JAERO_MSK_KERNEL=single|pairs1|pairs4 forces one.
-            const char *e = getenv("JAERO_MSK_KERNEL");
+            // back half's registers (65 536 channels: 9.2 -> 10.6 Gsamples/s).
             const int ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-            c->msk_pairs = (e && !strcmp(e, "single")) ? 0 : ((e && !strcmp(e, "pairs1")) ? 1 : ((e && !strcmp(e, "pairs4")) ? 4 : (g.ngroups > 2 * ncu ? 4 : 1)));
+            c->msk_pairs = g.ngroups > 2 * ncu ? 4 : 1;
             if (c->msk_pairs == 1)
             {
                 c->msk_ldsn = MFB_LDSN;
@@ -720,12 +714,11 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
     {
         // front / back pairs (k_oqpsk_fb.h; at 8400 bps the two halves take turns, see there).  Four pairs per workgroup put one front and one back wavefront on every SIMD of a
         // CU -- worth it once there are more channel groups than two per CU; smaller banks get one pair per workgroup (two SIMDs per
-        // 64 channels).  JAERO_OQPSK_KERNEL=single keeps the single-wavefront kernel (k_oqpsk.h) for A/B comparison.
-        const char *e = getenv("JAERO_OQPSK_KERNEL");
+        // 64 channels).  (The single-wavefront kernel of round 1 and its A/B switch left the library in round 3.)
         const int ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        if (c->oq_pairs) c->oq_pairs = (e && !strcmp(e, "single")) ? 0 : ((e && !strcmp(e, "pairs1")) ? 1 : ((e && !strcmp(e, "pairs4")) ? 4 : (g.ngroups > 2 * ncu ? 4 : 1)));
-        if (c->oq_pairs && !(g.marg_len == JD_SYMREC_LEN && g.dt_len == JD_SYMREC_LEN / 2 + 1 && g.pm_len == JD_SYMREC_LEN / 2 && g.msema_len == JD_SYMREC_LEN / 2))
-            c->oq_pairs = 0; // the combined symbol-record ring of k_oqpsk_fb assumes the reference's window lengths (800 / 400 / 400 / 400)
+        if (!c->oq_pairs) { jaero_destroy(c); return fail(JAERO_ENOTSUP, "matched-filter taps are not bitwise symmetric: k_oqpsk_fb takes the 28 distinct taps as scalar arguments"); }
+        c->oq_pairs = g.ngroups > 2 * ncu ? 4 : 1;
+        static_assert(JD_SYMREC_LEN == 800, "the combined symbol-record ring of k_oqpsk_fb assumes the reference's window lengths (800 / 400 / 400 / 400)");
         if (c->oq_pairs)
         {
             if ((rc = dalloc(c, &c->p.symrec, (size_t)nchp * JD_SYMREC_LEN * 8))) { jaero_destroy(c); return rc; }
@@ -975,11 +968,10 @@ extern "C" int jaero_profile_kernel(jaero_ctx *c, int which, char *buf, int cap)
         static const char *bn[5] = {"k_burst_oqpsk_demod", "k_trident", "k_hist_push", "k_hilbert_fft", "k_burst_front"};
         nm = bn[which];
         if (which == 0 && c->bg.kind == JAERO_KIND_BURST_MSK) nm = "k_burst_msk_demod";
-        if (which == 3 && c->hil_direct) nm = "k_hilbert<";
     }
     else if (which == 0)
     {
-        if (g.kind == JAERO_KIND_OQPSK) nm = c->oq_pairs ? "k_oqpsk_fb<" : (c->pre8400 ? "k_oqpsk_samples_8400<" : "k_oqpsk_samples<");
+        if (g.kind == JAERO_KIND_OQPSK) nm = "k_oqpsk_fb<";
         else nm = c->msk_pairs ? "k_msk_fb<" : "k_msk_samples<";
     }
     else if (which == 1) nm = (g.nfft_log2 == 14) ? (c->pre8400 ? "k_coarse5_w8400" : "k_coarse5") : "k_coarse2<";
@@ -996,7 +988,6 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
     const dim3 grid(g.ngroups), block(64);
     if (g.kind == JAERO_KIND_OQPSK)
     {
-        if (c->oq_pairs)
         {
             // front / back wavefront pairs (k_oqpsk_fb.h): PAIRS pairs per workgroup
             const int fsb = (int)(c->m.nB_total % FB_LDSN);
@@ -1012,15 +1003,7 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
 #undef LFB
             return;
         }
-        const int lds = (2 * OQ_LDSN * 64 + 64) * (int)sizeof(double); // rings + this wavefront's copy of the 55 taps
-        const int fs = (int)(c->m.nB_total % OQ_LDSN);
-#define LO(E, C) hipLaunchKernelGGL((k_oqpsk_samples<55, OQ_LDSN, E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs)
-#define LO84(E, C) hipLaunchKernelGGL((k_oqpsk_samples_8400<55, OQ_LDSN, E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs, \
-                                      (const double2 *)(c->pre.out + (size_t)pos * g.nchp))
-        if (c->pre8400) { if (eb && cs) LO84(true, true); else if (eb) LO84(true, false); else if (cs) LO84(false, true); else LO84(false, false); }
-        else if (eb && cs) LO(true, true); else if (eb) LO(true, false); else if (cs) LO(false, true); else LO(false, false);
-#undef LO84
-#undef LO
+        return; // (c->oq_pairs is always set: jaero_create refuses a bank it could not serve with k_oqpsk_fb)
     }
     else
     {
@@ -1041,8 +1024,7 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
         }
 #define LM(F, L, E, C) hipLaunchKernelGGL((k_msk_samples<F, L, E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs, ds, d8)
 #define LMS(F, L) { if (eb && cs) LM(F, L, true, true); else if (eb) LM(F, L, true, false); else if (cs) LM(F, L, false, true); else LM(F, L, false, false); }
-        if (g.fir_n == 80) LMS(80, MSK_LDSN_1200) else if (g.fir_n == 160) LMS(160, MSK_LDSN_600)
-        else if (g.fir_n == 40) LMS(40, MSK_LDSN_40) else LMS(20, MSK_LDSN_20)
+        if (g.fir_n == 160) LMS(160, MSK_LDSN_600) else if (g.fir_n == 40) LMS(40, MSK_LDSN_40) else LMS(20, MSK_LDSN_20) // 80 taps never get here (k_msk_fb)
 #undef LMS
 #undef LM
     }
@@ -1185,7 +1167,7 @@ extern "C" int jaero_debug_schedule(int fft_power, int Fs, int cpu_reduce, const
     return ntrig;
 }
 
-// Test hook: k_pre8400_fir alone (one channel, unity up-mix) on n complex samples, kernel RRC(alpha, 2048 taps + 1, 48 kHz, fsym):
+// Test hook: the 8400 bps prefilter kernel (k_pre8400_fft) alone (one channel, unity up-mix) on n complex samples, kernel RRC(alpha, 2048 taps + 1, 48 kHz, fsym):
 // out[m] = sum_k h[k] x[m - 2048 - k], what JFastFir::update returns for SetKernel(points, 4096) -- the operation the reference's
 // own test vectors pin (JAERO/tests/jfastfir_tests.cpp:31-58, tests/test_jfastfir_vectors.py).
 extern "C" int jaero_debug_prefilter(int device, const double *in_reim, int n, double alpha, double fsym, double *out_reim)
@@ -1216,12 +1198,11 @@ extern "C" int jaero_debug_prefilter(int device, const double *in_reim, int n, d
     HIPCHK(hipMemcpy2D(q.xring, sizeof(double2) * 64, in_reim, sizeof(double2), sizeof(double2), (size_t)n, hipMemcpyHostToDevice)); // channel 0 of every slot
     p.cis = d_cis; q.taps = d_taps;
     {
-        const char *e = getenv("JAERO_PRE8400");
         double2 *dH = nullptr, *dtw = nullptr;
         int rc = fft4096_tables(taps, &dH, &dtw, (const void *)k_pre8400_fft);
         if (rc) return rc;
         q.H = dH; q.tw = dtw;
-        launch_pre8400_filter(g, p, q, n, 0LL, e && !strcmp(e, "direct"), 0);
+        launch_pre8400_filter(g, p, q, n, 0LL, false, 0);
         HIPCHK(hipGetLastError());
         HIPCHK(hipDeviceSynchronize());
         hipFree(dH); hipFree(dtw);
@@ -1434,12 +1415,18 @@ extern "C" int jaero_read_events(jaero_ctx *c, int ch, double *rows, int caprows
 // pay off).  The lane layout wins once the per-wavefront layout has more than ~14 waves queued per SIMD.
 #define VL_MIN_BLOCKS 16384
 static inline size_t viterbi_hist_bytes(int nblocks) { return (size_t)((nblocks + 63) / 64) * VT_CAP * 64 * sizeof(unsigned long long); }
+static int g_viterbi_layout = 0; // test hook jaero_debug_viterbi_layout: 0 = by size (the product behaviour), 1 = wave, 2 = lanes
+extern "C" int jaero_debug_viterbi_layout(int mode)
+{
+    if (mode < 0 || mode > 2) return fail(JAERO_EINVAL, "jaero_debug_viterbi_layout: mode must be 0 (by size), 1 (wave) or 2 (lanes)");
+    g_viterbi_layout = mode;
+    return 0;
+}
 static inline bool viterbi_use_lanes(int nblocks, int nsoft, int pad)
 {
     if ((nsoft + pad) / 2 < 4 * VT_ORDER) return false;
-    const char *e = getenv("JAERO_VITERBI_LAYOUT"); // "wave" / "lanes" force one layout (tests run both against the oracle); default: by size
-    if (e && !strcmp(e, "wave")) return false;
-    if (e && !strcmp(e, "lanes")) return true;
+    if (g_viterbi_layout == 1) return false;
+    if (g_viterbi_layout == 2) return true;
     return nblocks >= VL_MIN_BLOCKS;
 }
 static void viterbi_launch(hipStream_t st, const uint8_t *d_soft, int nsoft, const uint8_t *d_ov, int pad, uint8_t *d_out, int out_stride,

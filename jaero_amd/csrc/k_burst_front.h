@@ -14,79 +14,9 @@
 // hfir.update(hfirbuff) (JAERO/burstoqpskdemodulator.cpp:344, JAERO/DSP.cpp:754-794): the 2048-tap kernel is
 //   kernel[1024] = -1, kernel[odd k] = j (2/N)/tan(pi (k/N - 1/2)), everything else 0, and JFastFir delays by L = nfft-K+1.
 // So   re y[n] = -x[n-L-1024],   im y[n] = sum_{j<512} h[2j+1] (x[n-L-(2j+1)] - x[n-L-(2047-2j)])   (h[N-k] = -h[k]).
-// One wavefront = 64 channels (lane = channel) x HB_R consecutive outputs; taps are wave-uniform (scalar loads); the two input
-// windows of a block of HB_U tap pairs are loaded once into registers (static indices after unrolling, no shifting).
 // The PCM history ring is kept in cells of four consecutive samples per channel: int16 index ((slot >> 2) * nchp + ch) * 4 + (slot & 3).
-// A lane fetches four samples with one 8-byte load, a wavefront 512 contiguous bytes: with one 2-byte load per sample (the first
-// version) the kernel was bound by the texture-address unit, 60 load instructions per 256 of arithmetic.  All windows of a launch start
-// at the same offset inside a cell (PH = (n0 - latency + 1) & 3: block and tap offsets are multiples of 16), so PH is a template
-// parameter and every sample sits in a compile-time register and half-word.
-#define HB_R 16
-#define HB_U 8
+// (The time-parallel direct form of this filter, k_hilbert<PH>, 8.9 ms per 2048-sample segment against 1.4 ms, left the library in round 3.)
 __device__ __forceinline__ size_t hb_idx(int slot, int nchp, int ch) { return ((size_t)(slot >> 2) * nchp + ch) * 4 + (slot & 3); }
-template <int PH>
-__global__ __launch_bounds__(256) void k_hilbert(const BGeom g, const BPtrs p, int ns, long long n0)
-{
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int grp = blockIdx.x, ch = grp * 64 + lane;
-    const int i0 = (blockIdx.y * 4 + wv) * HB_R;
-    if (i0 >= ns) return;
-    const int H = g.hist_len, HC = H >> 2, nchp = g.nchp;
-    const uint2 *__restrict__ cells = (const uint2 *)p.pcmhist + ch;
-    const double *__restrict__ taps = p.hil_taps;
-    // index of x feeding tap k = 0 of output r = 0, made non-negative by a multiple of the ring length
-    const long long nb0 = n0 + i0 - g.hil_lat + 4LL * H;
-    double acc[HB_R];
-#pragma unroll
-    for (int r = 0; r < HB_R; r++) acc[r] = 0.0;
-    constexpr int WN = HB_R + 2 * (HB_U - 1);
-    constexpr int NC = (PH + WN - 1) / 4 + 1; // cells a window touches
-    auto sample = [](const uint2 (&c)[NC], int m) -> double { // window sample m: compile-time cell and half-word
-        const int o = PH + m;
-        const unsigned w = (o & 2) ? c[o >> 2].y : c[o >> 2].x;
-        return (double)((o & 1) ? ((int)w >> 16) : (int)(short)(w & 0xFFFFu));
-    };
-    for (int j0 = 0; j0 < 512; j0 += HB_U)
-    {
-        int ca = (int)(((nb0 - 2 * j0 - 1 - 2 * (HB_U - 1)) % H) >> 2);
-        int cb = (int)(((nb0 - 2047 + 2 * j0) % H) >> 2);
-        uint2 wa[NC], wb[NC];
-#pragma unroll
-        for (int q = 0; q < NC; q++)
-        {
-            wa[q] = cells[(size_t)ca * nchp];
-            wb[q] = cells[(size_t)cb * nchp];
-            ca++; if (ca >= HC) ca = 0;
-            cb++; if (cb >= HC) cb = 0;
-        }
-        double ea[WN], eb[WN];
-#pragma unroll
-        for (int m = 0; m < WN; m++) { ea[m] = sample(wa, m); eb[m] = sample(wb, m); }
-#pragma unroll
-        for (int u = 0; u < HB_U; u++)
-        {
-            const double tp = taps[j0 + u];
-#pragma unroll
-            for (int r = 0; r < HB_R; r++) acc[r] = fma(tp, ea[r - 2 * u + 2 * (HB_U - 1)] - eb[r + 2 * u], acc[r]);
-        }
-    }
-    int sr = (int)((nb0 - 1024) % H);
-    const int16_t *__restrict__ hist = p.pcmhist;
-    double *__restrict__ ore = p.hre + ((size_t)grp * g.maxseg + i0) * 64 + lane;
-    double *__restrict__ oim = p.him + ((size_t)grp * g.maxseg + i0) * 64 + lane;
-#pragma unroll
-    for (int r = 0; r < HB_R; r++)
-    {
-        if (i0 + r < ns)
-        {
-            // PCM -> double as the reference does (x/32768.0); the taps carry no scaling, so scale the sums here
-            ore[(size_t)r * 64] = -(((double)hist[hb_idx(sr, nchp, ch)]) / 32768.0);
-            oim[(size_t)r * 64] = acc[r] / 32768.0;
-        }
-        sr++; if (sr >= H) sr = 0;
-    }
-}
-
 // The same filter by overlap-save (the reference's QJHilbertFilter IS a JFastFir): the kernel's real part is a single tap (-1 at
 // k = 1024), so re y is a delayed copy of the input and only the imaginary taps g[k] (odd k, REAL values) need a convolution.  With
 // real taps two real channels share one complex transform pair: z = x_a + j x_b,  g (*) z = (g (*) x_a) + j (g (*) x_b).
@@ -95,7 +25,7 @@ __global__ __launch_bounds__(256) void k_hilbert(const BGeom g, const BPtrs p, i
 //   (8 channels x 4 samples) and write 64 contiguous bytes of hre / him.
 //   Block: outputs m0 .. m0 + 2047 (m0 an absolute multiple of 2048) = window indices 2048 .. 4095 of x[m0 - L - 2048 .. m0 - L + 2047]
 //   convolved with g (2048 taps): im y[m] = sum_k g[k] x[m - L - k].  4096-point transforms: pf_fft4096 (k_pre8400.h).
-// 1.9 ms per 2048-sample segment of 65 536 channels against 8.9 ms for the direct form above (kept: JAERO_HILBERT=direct).  Not
+// 1.4 ms per 2048-sample segment of 65 536 channels against 8.9 ms for the direct form it replaced.  Not
 // bit-identical to the direct form (other summation order: ~1e-15 of full scale), nor to the reference's transform.
 __global__ __launch_bounds__(PF_THREADS) void k_hilbert_fft(const BGeom g, const BPtrs p, int ns, long long n0)
 {

@@ -11,17 +11,15 @@
 // (:607-608).  Here:
 //   k_pre8400_mix  one lane per channel, sequential over the write (the oscillator phase is a running sum): down-mixed samples go
 //                  into a per-channel history ring xring[slot][channel], the up-mix table index of every sample into cidx
-//   k_pre8400_fir  time-parallel direct-form FIR on the ring (taps folded by symmetry: 1024 pairs + the centre), then the up-mix;
-//                  NOT bit-identical to the FFT overlap-add of the reference (same sum, other order): the soft-symbol tolerance
-//                  of the north star applies, as for the Hilbert filter of the burst path
+//   k_pre8400_fft  the filter by overlap-save on that ring, then the up-mix (below); its round-off differs from the reference's FFT
+//                  overlap-add (other transform, other order): the soft-symbol tolerance of the north star applies, as for the Hilbert
+//                  filter of the burst path.  (The direct form k_pre8400_fir, 127 ms per step, left the library in round 3.)
 #pragma once
 #include "jaero_device.h"
 #include "k_coarse2.h" // CV<>, regfft<16>, c4_twiddle16, c4_lds_barrier
 
 #define PRE_K 2049                 // taps
 #define PRE_L 2048                 // JFastFir latency nfft - K + 1
-#define PRE_R 8                    // outputs per lane and tile
-#define PRE_U 8                    // tap pairs per step
 
 struct JPre
 {
@@ -75,64 +73,7 @@ __global__ __launch_bounds__(64) void k_pre8400_mix(const JGeom g, const JPtrs p
     p.S[(size_t)S_PRE_STEP * nchp + ch] = su;
 }
 
-// grid (nchp / 64, ceil(n / (4 * PRE_R))), 256 threads: wavefront w of a block handles outputs i0 .. i0 + PRE_R - 1 of 64 channels
-__global__ __launch_bounds__(256) void k_pre8400_fir(const JGeom g, const JPtrs p, const JPre q, int n, long long n0)
-{
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int ch = blockIdx.x * 64 + lane, nchp = g.nchp;
-    const int i0 = (blockIdx.y * 4 + wv) * PRE_R;
-    if (i0 >= n) return;
-    const int rmask = q.ring - 1;
-    const double2 *__restrict__ xr = q.xring + ch;
-    const double *__restrict__ taps = q.taps;
-    // out[m] = h[1024] x[m-3072] + sum_{k<1024} h[k] (x[m-2048-k] + x[m-4096+k]),  m = n0 + i0 + r
-    const long long m0 = n0 + i0;
-    double are[PRE_R], aim[PRE_R];
-#pragma unroll
-    for (int r = 0; r < PRE_R; r++) { are[r] = 0.0; aim[r] = 0.0; }
-    constexpr int WN = PRE_R + PRE_U - 1;
-    for (int j0 = 0; j0 < 1024; j0 += PRE_U)
-    {
-        // window a: x[m0 - 2048 - j0 - (U-1) + w], w = r - u + (U-1);  window b: x[m0 - 4096 + j0 + w], w = r + u
-        double2 wa[WN], wb[WN];
-        const long long ba = m0 - PRE_L - j0 - (PRE_U - 1), bb = m0 - 2 * PRE_L + j0;
-#pragma unroll
-        for (int w = 0; w < WN; w++)
-        {
-            wa[w] = xr[(size_t)((int)((ba + w) & rmask)) * nchp];
-            wb[w] = xr[(size_t)((int)((bb + w) & rmask)) * nchp];
-        }
-#pragma unroll
-        for (int u = 0; u < PRE_U; u++)
-        {
-            const double tp = taps[j0 + u];
-#pragma unroll
-            for (int r = 0; r < PRE_R; r++)
-            {
-                const double2 a = wa[r - u + (PRE_U - 1)], b = wb[r + u];
-                are[r] = fma(tp, a.x + b.x, are[r]);
-                aim[r] = fma(tp, a.y + b.y, aim[r]);
-            }
-        }
-    }
-    const double tc = taps[1024];
-#pragma unroll
-    for (int r = 0; r < PRE_R; r++)
-    {
-        if (i0 + r < n)
-        {
-            const double2 c = xr[(size_t)((int)((m0 + r - 3 * 1024) & rmask)) * nchp];
-            const double yr = fma(tc, c.x, are[r]), yi = fma(tc, c.y, aim[r]);
-            // cval_prefiltered[i] *= mixer_fir_pre.WTCISValue_conj()
-            const double2 cj = p.cis[q.cidx[(size_t)(i0 + r) * nchp + ch]];
-            const double bre = cj.x, bim = -cj.y;
-            q.out[(size_t)(i0 + r) * nchp + ch] = make_double2(yr * bre - yi * bim, yr * bim + yi * bre);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// k_pre8400_fft: the same filter as k_pre8400_fir by overlap-save, i.e. the way the reference's JFastFir computes it (nfft 4096, 2049
+// k_pre8400_fft: the prefilter by overlap-save, i.e. the way the reference's JFastFir computes it (nfft 4096, 2049
 // taps, 2048 fresh outputs per transform pair) -- 4 x 4096-point transforms per channel and 4096-sample write instead of 2049 multiply-
 // adds per output (k_pre8400_fir: 127 ms per 65 536-channel step, four times the rest of the path).
 //

@@ -51,3 +51,16 @@ def bank_settings(kind, opts):
     return MskSettings(freq_center=opts.get("freq_center", 1000.0), lockingbw=opts.get("lockingbw", 1800.0),
                        fb=opts.get("fb", 1200.0), coarsefreqest_fft_power=opts.get("power", 13),
                        signalthreshold=opts.get("threshold", 0.5))
+
+
+@pytest.fixture
+def force_viterbi_layout():
+    """The Viterbi decoder picks its layout by size; tests force one ("wave" / "lanes" / "auto") through the library's test hook
+    jaero_debug_viterbi_layout so that both layouts meet the oracle at small sizes.  Reset to "by size" afterwards."""
+    from jaero_amd import capi
+
+    def force(name: str):
+        capi.check(capi.lib().jaero_debug_viterbi_layout({"auto": 0, "wave": 1, "lanes": 2}[name]))
+
+    yield force
+    capi.lib().jaero_debug_viterbi_layout(0)

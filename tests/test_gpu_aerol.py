@@ -36,10 +36,10 @@ def test_against_reference_golden(B, fb):
 
 
 @pytest.mark.parametrize("fb,layout", [(10500, "wave"), (1200, "wave"), (10500, "lanes"), (600, "lanes")])
-def test_bank_vs_oracle(B, oracle_mod, monkeypatch, fb, layout):
+def test_bank_vs_oracle(B, oracle_mod, force_viterbi_layout, fb, layout):
     """70 channels (two wave groups), different frames / noise / arm inversions / garbage prefixes per channel, ragged per-channel
     counts in every write."""
-    monkeypatch.setenv("JAERO_VITERBI_LAYOUT", layout)  # large banks decode one block per lane; force it at this size too
+    force_viterbi_layout(layout)  # large banks decode one block per lane; force it at this size too
     nch = 70
     rng = np.random.default_rng(fb)
     streams = []

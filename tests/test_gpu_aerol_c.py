@@ -51,10 +51,10 @@ def test_golden_single_channel(D, oracle_mod):
 
 
 @pytest.mark.parametrize("nch,write,layout", [(5, 3000, "wave"), (70, 5000, "wave"), (70, 5000, "lanes")])
-def test_bank_vs_oracle(D, oracle_mod, monkeypatch, nch, write, layout):
+def test_bank_vs_oracle(D, oracle_mod, force_viterbi_layout, nch, write, layout):
     """Channels at different frame phases, inversions and noise levels, ragged writes: every channel equals its own oracle run.  Both
     Viterbi layouts (one block per wavefront; one per lane, what banks of 16 384 channels and more use)."""
-    monkeypatch.setenv("JAERO_VITERBI_LAYOUT", layout)
+    force_viterbi_layout(layout)
     rng = np.random.default_rng(77 + nch)
     streams = []
     for c in range(nch):

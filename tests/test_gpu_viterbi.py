@@ -1,5 +1,5 @@
 """GPU (-m gpu): the batched Viterbi kernels -- one block per wavefront (k_viterbi) and one block per lane (k_viterbi_lanes, what
-banks of >= 16384 blocks use) -- vs the libcorrect restatement (integer: bit-exact).  JAERO_VITERBI_LAYOUT forces a layout."""
+banks of >= 16384 blocks use) -- vs the libcorrect restatement (integer: bit-exact).  The test hook jaero_debug_viterbi_layout forces a layout."""
 import numpy as np
 import pytest
 
@@ -7,8 +7,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(params=["wave", "lanes"])
-def layout(request, monkeypatch):
-    monkeypatch.setenv("JAERO_VITERBI_LAYOUT", request.param)
+def layout(request, force_viterbi_layout):
+    force_viterbi_layout(request.param)
     return request.param
 
 
@@ -89,7 +89,7 @@ def test_device_pointers_and_roundtrip_property(oracle_mod):
     assert bool((out[:, : want.numel()] == want[None, :]).all())
 
 
-def test_lane_layout_bank_vs_wave_layout(oracle_mod, monkeypatch):
+def test_lane_layout_bank_vs_wave_layout(oracle_mod, force_viterbi_layout):
     """20000 blocks (the size at which the library switches to one block per lane by itself; last wavefront ragged): every decoded bit
     equal to the one-block-per-wavefront kernel's, and a sample of blocks equal to the oracle's."""
     import torch
@@ -106,10 +106,7 @@ def test_lane_layout_bank_vs_wave_layout(oracle_mod, monkeypatch):
     soft[7] = 0
     outs = {}
     for lay in ("wave", "auto"):
-        if lay == "auto":
-            monkeypatch.delenv("JAERO_VITERBI_LAYOUT", raising=False)
-        else:
-            monkeypatch.setenv("JAERO_VITERBI_LAYOUT", lay)
+        force_viterbi_layout(lay)
         out = torch.zeros((nblk, nsoft // 2), dtype=torch.uint8, device="cuda")
         capi.check(L.jaero_viterbi_decode_soft(0, soft.data_ptr(), nblk, nsoft, out.data_ptr(), 1, None))
         torch.cuda.synchronize()

@@ -33,11 +33,9 @@ def test_unmodified_jfastfir_over_the_shim(oracle_mod):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["fft", "direct"])
-def test_gpu_prefilter_kernel(form, monkeypatch):
+def test_gpu_prefilter_kernel():
     from jaero_amd import capi
 
-    monkeypatch.setenv("JAERO_PRE8400", form)
     g = load_golden("jfastfir")
     x = np.ascontiguousarray(g["input"], dtype=np.complex128)
     out = np.empty_like(x)
