@@ -60,7 +60,6 @@ static int fail(int code, const char *fmt, ...)
 
 #define OQ_LDSN 39 // matched-filter history slots kept in LDS (rest in VGPRs) + the taps: 39.5 KiB per wavefront -> 4 wavefronts per CU
 #define MSK_LDSN_1200 39 // of 80 taps: four wavefronts per CU (rings + the wavefront's copy of the taps: 39.6 KiB)
-#define MSK_LDSN_600 78  // of 160 taps: two wavefronts per CU (79.3 KiB)
 #define MSK_LDSN_40 24   // of 40 taps (1200 bps at 24 kHz, 600 bps at 12 kHz)
 #define MSK_LDSN_20 12   // of 20 taps (1200 bps at 12 kHz)
 
@@ -683,9 +682,18 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<F, L, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
         HIPCHK(hipFuncSetAttribute((const void *)k_msk_samples<F, L, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
     }
-        c->msk_ldsn = g.fir_n == 160 ? MSK_LDSN_600 : (g.fir_n == 80 ? MSK_LDSN_1200 : (g.fir_n == 40 ? MSK_LDSN_40 : MSK_LDSN_20));
-        if (g.fir_n == 160) MSK_ATTR(160, MSK_LDSN_600) else if (g.fir_n == 40) MSK_ATTR(40, MSK_LDSN_40) else if (g.fir_n == 20) MSK_ATTR(20, MSK_LDSN_20) // 80 taps: k_msk_fb below
+        c->msk_ldsn = g.fir_n == 40 ? MSK_LDSN_40 : MSK_LDSN_20; // 80 / 160 taps: set with the pair kernel below
+        if (g.fir_n == 40) MSK_ATTR(40, MSK_LDSN_40) else if (g.fir_n == 20) MSK_ATTR(20, MSK_LDSN_20) // 80 and 160 taps: k_msk_fb below
 #undef MSK_ATTR
+        if (g.fir_n == 160)
+        {
+            // 160 taps: two pairs per workgroup, each wavefront alone on a SIMD (k_msk_fb.h, MFB2_*)
+            c->msk_pairs = 2;
+            c->msk_ldsn = MFB2_LDSN;
+#define MFA(E, C) HIPCHK(hipFuncSetAttribute((const void *)k_msk_fb<160, MFB2_LDSN, E, C, 2, MFB2_TB>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * mfb_pair_doubles<160, MFB2_LDSN, MFB2_TB>() * (int)sizeof(double)))
+            MFA(false, false); MFA(false, true); MFA(true, false); MFA(true, true);
+#undef MFA
+        }
         if (g.fir_n == 80)
         {
             // front / back pairs (k_msk_fb.h).  Banks of at most two channel groups per CU: one pair per workgroup, the halves on different
@@ -1014,7 +1022,14 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
         {
             const int P = c->msk_pairs;
             const dim3 gridp((g.ngroups + P - 1) / P), blockp(P * 128);
-            const int ldsp = (P == 4 ? 4 * mfb_pair_doubles<80, MFB4_LDSN, MFB4_TB>() : mfb_pair_doubles<80, MFB_LDSN, 0>()) * (int)sizeof(double);
+            const int ldsp = (P == 4 ? 4 * mfb_pair_doubles<80, MFB4_LDSN, MFB4_TB>() : (P == 2 ? 2 * mfb_pair_doubles<160, MFB2_LDSN, MFB2_TB>() : mfb_pair_doubles<80, MFB_LDSN, 0>())) * (int)sizeof(double);
+#define LMF2(E, C) hipLaunchKernelGGL((k_msk_fb<160, MFB2_LDSN, E, C, 2, MFB2_TB>), gridp, blockp, ldsp, st, g, c->p, frames, stride, n, skipA, onlyA, fs, ds, d8)
+            if (P == 2)
+            {
+                if (eb && cs) LMF2(true, true); else if (eb) LMF2(true, false); else if (cs) LMF2(false, true); else LMF2(false, false);
+                return;
+            }
+#undef LMF2
 #define LMF(E, C, PP, LL, TT) hipLaunchKernelGGL((k_msk_fb<80, LL, E, C, PP, TT>), gridp, blockp, ldsp, st, g, c->p, frames, stride, n, skipA, onlyA, fs, ds, d8)
 #define LMFP(E, C) { if (P == 4) LMF(E, C, 4, MFB4_LDSN, MFB4_TB); else LMF(E, C, 1, MFB_LDSN, 0); }
             if (eb && cs) LMFP(true, true) else if (eb) LMFP(true, false) else if (cs) LMFP(false, true) else LMFP(false, false)
@@ -1024,7 +1039,7 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
         }
 #define LM(F, L, E, C) hipLaunchKernelGGL((k_msk_samples<F, L, E, C>), grid, block, lds, st, g, c->p, frames, stride, n, skipA, onlyA, fs, ds, d8)
 #define LMS(F, L) { if (eb && cs) LM(F, L, true, true); else if (eb) LM(F, L, true, false); else if (cs) LM(F, L, false, true); else LM(F, L, false, false); }
-        if (g.fir_n == 160) LMS(160, MSK_LDSN_600) else if (g.fir_n == 40) LMS(40, MSK_LDSN_40) else LMS(20, MSK_LDSN_20) // 80 taps never get here (k_msk_fb)
+        if (g.fir_n == 40) LMS(40, MSK_LDSN_40) else LMS(20, MSK_LDSN_20) // 80 and 160 taps never get here (k_msk_fb)
 #undef LMS
 #undef LM
     }

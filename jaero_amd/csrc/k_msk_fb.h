@@ -32,6 +32,16 @@
 // and 32 in LDS and continues the same sum.  Same operations in the same order as the single accumulator chain.
 #define MFB4_LDSN 32
 #define MFB4_TB 22
+// 160 taps (600 bps at 48 kHz; round 3): TWO pairs per workgroup, every wavefront alone on its SIMD (512 registers): 72 entries of each arm
+// in LDS (81 664 B per pair, 163 328 B per CU), 36 in the front half's registers, the 52 oldest in the back half's (measured splits 36/44/52/60: 5.87, 6.02, 6.03 Gsamples/s; all still spill 230-300 registers).  k_msk_samples<160,78>
+// (two wavefronts per CU, 82 entries in 256 registers) spilled ~750 registers; one wavefront per CU with the whole history in LDS and no
+// scratch is slower still (3.4 against 2.3 Gsamples/s at 65 536 channels): occupancy, not the scratch traffic, decides there.
+#ifndef MFB2_LDSN
+#define MFB2_LDSN 72
+#endif
+#ifndef MFB2_TB
+#define MFB2_TB 52
+#endif
 
 struct MfbLds
 {

@@ -1,12 +1,14 @@
-"""CPU model of the history hand-over in k_msk_fb with four pairs per workgroup (jaero_amd/csrc/k_msk_fb.h, MFB4_*).
+"""CPU model of the history hand-over in k_msk_fb with a three-way split (jaero_amd/csrc/k_msk_fb.h: MFB4_* for the 80-tap filter with four
+pairs per workgroup, MFB2_* for the 160-tap filter with two).
 
 The 80-entry matched-filter history of an arm is split three ways: the 32 newest entries in LDS and the next 26 in the front half's
-registers, the 22 oldest in the back half's registers.  The back half starts every filter sum (oldest first) two samples ahead and hands
+registers, the 22 oldest in the back half's registers (160 entries: 72 / 36 / 52).  The back half starts every filter sum (oldest first) two samples ahead and hands
 it over; the front half announces, two samples ahead, the entry that will reach the back half's tail.  Across launches the pending sum
 travels in the state (S_MFB_A0_*), the tails in firsave.  The kernel runs on the GPU only (tests/test_gpu_parity.py, test_gpu_scale.py);
 this model replays its schedule -- mailbox slots, barriers as phase boundaries, launches of 0, 1, 2 ... samples -- with integer data
 (so that every order of summation gives the same number) and checks each output against the plain 80-tap sum."""
 import numpy as np
+import pytest
 
 FIRN, L, TB = 80, 32, 22
 TF = FIRN - L - TB
@@ -69,12 +71,16 @@ class Pair:
         return y
 
 
-def test_three_way_history_matches_the_plain_filter():
+@pytest.mark.parametrize("firn,l,tb", [(80, 32, 22), (160, 72, 52)])
+def test_three_way_history_matches_the_plain_filter(firn, l, tb):
+    global FIRN, L, TB, TF
+    FIRN, L, TB = firn, l, tb
+    TF = FIRN - L - TB
     rng = np.random.default_rng(8)
     taps = [int(v) for v in rng.integers(-9, 10, FIRN)]
     p = Pair(taps)
     hist = [0] * FIRN                      # x[n-80 .. n-1], oldest first
-    sizes = [0, 1, 1, 2, 3, 0, 5, 1, 40, 2, 81, 7, 1, 0, 2, 100]
+    sizes = [0, 1, 1, 2, 3, 0, 5, 1, 40, 2, 81, 7, 1, 0, 2, 100, 161, 3, 200]
     for n in sizes:
         x = [int(v) for v in rng.integers(-50, 51, n)]
         y = p.launch(x)
