@@ -75,15 +75,34 @@ __device__ __forceinline__ double fb_fmod360(double x)
     return fmod(x, 360.0);
 }
 
+#ifndef FB_PAIRSYNC
+#define FB_PAIRSYNC 0 // experiment (round 3): the two halves of a pair wait for EACH OTHER through sequence words in LDS instead of for the whole workgroup
+#endif
 struct FbLds
 {
     double *lre, *lim, *ltap; // [LDSN][64], [LDSN][64], [64]
     double *data;             // [2][3][64]  F -> B: sre, sim, abval of a sample
     int *idx;                 // [2][64]     B -> F: table index of mixer2 for a sample
+    volatile int *seq;        // FB_PAIRSYNC: [2] sequence words (front, back)
+    int me, count;            // FB_PAIRSYNC: which word is mine, how many sync points I have passed
 };
 template <int LDSN>
 constexpr int fb_pair_doubles() { return 2 * LDSN * 64 + 64 + 2 * 3 * 64 + 64; }
 
+#if FB_PAIRSYNC
+// pair-local sync point: my LDS traffic done, my sequence word = number of sync points passed, wait until the partner's is as large
+__device__ __forceinline__ void fb_pair_sync(FbLds &L)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    L.count++;
+    if ((threadIdx.x & 63) == 0) L.seq[L.me] = L.count;
+    while (L.seq[L.me ^ 1] < L.count) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+#define FB_SYNC(L) fb_pair_sync(L)
+#else
+#define FB_SYNC(L) fb_barrier()
+#endif
 __device__ __forceinline__ void fb_barrier()
 {
     // LDS traffic of this wavefront done, then the workgroup barrier.  NOT __syncthreads(): that also drains vmcnt, i.e. every
@@ -97,7 +116,7 @@ __device__ __forceinline__ void fb_barrier()
 // take turns (two barriers per sample).  What the split still buys there: the back half's code (queued output half, exact rewrites)
 // instead of the single-wavefront kernel's, and the A-part of a sample (coarse ring fill, next inputs) under the back half's work.
 template <int FIRN, int LDSN, bool EBNO, bool PRE8400>
-__device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const FbLds &L, const int16_t *__restrict__ pcm, int pcm_stride, int n,
+__device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &L, const int16_t *__restrict__ pcm, int pcm_stride, int n,
                                          int skip_a_first, int only_a_last, int fir_slot0, int grp, int lane, const JTaps28 &tp,
                                          const double2 *__restrict__ prefilt)
 {
@@ -229,7 +248,7 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const F
     if constexpr (PRE8400)
     {
         double2 nx_pf = (nB > 0) ? prefilt[ch] : make_double2(0.0, 0.0);
-        fb_barrier(); // the back half has published the carrier table index of sample 0
+        FB_SYNC(L); // the back half has published the carrier table index of sample 0
         for (int i = 0; i < nB; i++)
         {
             // sig2 = mixer2.WTCISValue() * cval_prefiltered[i], then EbNo, AGC, clip -> mailbox: the back half waits for this
@@ -238,7 +257,7 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const F
             const double2 pf = nx_pf;
             const double sre = c_m2.x * pf.x - c_m2.y * pf.y, sim = c_m2.x * pf.y + c_m2.y * pf.x;
             front_sample(sre, sim, r1_agc, r1_e, r1_e2, i, i & 1);
-            fb_barrier();
+            FB_SYNC(L);
             // under the back half's sample i: this sample's coarse ring entry (K3, :410-415) and the next sample's inputs
             const double dval = ((double)nx_pcm) / 32768.0;
             const double2 cc = nx_cc;
@@ -257,7 +276,7 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const F
                 r1_agc = agc_ring[(size_t)agc_pos * 64];
                 if (EBNO) { r1_e = ebe_ring[(size_t)eb_pos * 64]; r1_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
             }
-            fb_barrier(); // the back half has published the carrier table index of sample i + 1
+            FB_SYNC(L); // the back half has published the carrier table index of sample i + 1
         }
     }
     else
@@ -271,7 +290,7 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const F
         r1_agc = agc_ring[(size_t)agc_pos * 64];
         if (EBNO) { r1_e = ebe_ring[(size_t)eb_pos * 64]; r1_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
     }
-    fb_barrier();
+    FB_SYNC(L);
 
     for (int i = 0; i < nB; i++)
     {
@@ -327,7 +346,7 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const F
             front_sample(y_re, y_im, r1_agc, r1_e, r1_e2, i + 1, (i + 1) & 1);
             r1_agc = r2_agc; r1_e = r2_e; r1_e2 = r2_e2;
         }
-        fb_barrier();
+        FB_SYNC(L);
     }
     } // !PRE8400
     if (only_a_last) // the coarse estimate runs now; the next launch resumes with this sample's B-part
@@ -361,7 +380,7 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, const F
 
 // ------------------------------------------------------------------------------------------------------------------- back half
 template <bool CAPSYM, bool PRE8400>
-__device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, const FbLds &L, int n, int only_a_last, int grp, int lane)
+__device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, FbLds &L, int n, int only_a_last, int grp, int lane)
 {
     const int ch = grp * 64 + lane;
     const int nchp = g.nchp;
@@ -484,14 +503,14 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, const Fb
     // mailbox: the table index of mixer2 for sample 0
     L.idx[lane] = jd_cisidx(m2_ptr);
     double2 nx_cst = cis[jd_cisidx(st_ptr)];
-    fb_barrier();
+    FB_SYNC(L);
 
     double m2fsum = 0; // PRE8400: mixer2_freq_sum of this launch (:447,607)
     for (int i = 0; i < nB; i++)
     {
         if constexpr (PRE8400)
         {
-            fb_barrier(); // the front half has formed this sample with the table index published one barrier ago
+            FB_SYNC(L); // the front half has formed this sample with the table index published one barrier ago
             m2fsum += m2_freq;
         }
         const double2 c_st = nx_cst; // requested at the end of the previous sample
@@ -589,7 +608,7 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, const Fb
             while (((int)st_ptr) >= JD_WTSIZE) st_ptr -= JD_WTSIZE;
         }
         nx_cst = cis[jd_cisidx(st_ptr)]; // the symbol NCO's table value for the next sample: in flight across the barrier
-        fb_barrier();
+        FB_SYNC(L);
     }
     if (need_px) request_px();
     if (pend) output_half();
@@ -628,6 +647,14 @@ __global__ __launch_bounds__(PAIRS * 128) void k_oqpsk_fb(const JGeom g, const J
     L.lre = base; L.lim = base + LDSN * 64; L.ltap = base + 2 * LDSN * 64;
     L.data = L.ltap + 64;
     L.idx = (int *)(L.data + 2 * 3 * 64);
+#if FB_PAIRSYNC
+    L.seq = (volatile int *)(L.ltap + 56); // the taps take 55 of the 64 doubles there
+    L.me = back ? 1 : 0; L.count = 0;
+    if (lane == 0) L.seq[L.me] = 0;
+    fb_barrier(); // the one workgroup barrier: every sequence word is zero before anyone waits on one
+    if (grp >= g.ngroups) return;
+#else
+    L.seq = nullptr; L.me = 0; L.count = 0;
     if (grp >= g.ngroups)
     {
         const int nB = n - (only_a_last ? 1 : 0);
@@ -635,6 +662,7 @@ __global__ __launch_bounds__(PAIRS * 128) void k_oqpsk_fb(const JGeom g, const J
         for (int i = 0; i < nbar; i++) fb_barrier();
         return;
     }
+#endif
     if (back) fb_back<CAPSYM, PRE8400>(g, p, L, n, only_a_last, grp, lane);
     else fb_front<FIRN, LDSN, EBNO, PRE8400>(g, p, L, pcm, pcm_stride, n, skip_a_first, only_a_last, fir_slot0, grp, lane, tp, prefilt);
 }
