@@ -14,11 +14,19 @@ struct CoarseSlotState
     int emptying, flags, countdown, countdown2, nest, log_cnt;
     double mse, thr, m2_freq, m2_step, mc_freq, mc_step, ebno;
 };
+// Loads through the CONSTANT address space: with a wave-uniform address they become scalar loads (lgkmcnt), so waiting for them does
+// not wait for the vector loads in flight around them -- as vector loads (vmcnt retires in order) thread 0 stood behind its wavefront's
+// share of the next estimate's ring prefetch, and the workgroup behind thread 0, once per estimate.  Safe here: what is read was written
+// by earlier launches (the scalar cache is invalidated at kernel start) or, for other channels, by this kernel.
+typedef const __attribute__((address_space(4))) int jd_cint;
+typedef const __attribute__((address_space(4))) double jd_cdouble;
+__device__ __forceinline__ int jd_sload(const int *q) { return *(jd_cint *)q; }
+__device__ __forceinline__ double jd_sload(const double *q) { return *(jd_cdouble *)q; }
 __device__ __forceinline__ CoarseSlotState coarse_slot_load(const JGeom &g, const JPtrs &p, int ch)
 {
     const int nchp = g.nchp;
-    const int *I = p.I + ch;
-    const double *S = p.S + ch;
+    jd_cint *I = (jd_cint *)(p.I + ch);
+    jd_cdouble *S = (jd_cdouble *)(p.S + ch);
     CoarseSlotState c;
     c.emptying = I[(size_t)I_EMPTYING * nchp]; c.flags = I[(size_t)I_FLAGS * nchp]; c.countdown = I[(size_t)I_COUNTDOWN * nchp];
     c.countdown2 = I[(size_t)I_COUNTDOWN2 * nchp]; c.nest = I[(size_t)I_NEST * nchp]; c.log_cnt = I[(size_t)I_LOG_CNT * nchp];
@@ -34,6 +42,11 @@ __device__ __forceinline__ int coarse_slot_apply(const JGeom &g, const JPtrs &p,
     const int nchp = g.nchp;
     int *I = p.I + ch;
     double *S = p.S + ch;
+    // the sample rate through an opaque copy: what derives from it (Fs / 2, reciprocals) is a few instructions here, but hoisted out of a
+    // persistent kernel's estimate loop it is kept -- spilled -- across the whole loop, and the reload's wait (vmcnt counts in order) stands
+    // behind every vector load in flight
+    double Fs = g.Fs;
+    asm volatile("" : "+s"(Fs));
 #define CI(f) I[(size_t)(f) * nchp]
 #define CS(f) S[(size_t)(f) * nchp]
     double freq_offset_est = -((double)(zmaxloc - N / 2)) * hzperbin * 0.5;
@@ -52,12 +65,12 @@ __device__ __forceinline__ int coarse_slot_apply(const JGeom &g, const JPtrs &p,
         if ((mse < thr) && (!dcd))
         {
             if (countdown2 > 0) countdown2--;
-            else jd_wt_setfreq(m2_freq, m2_step, mc_freq + freq_offset_est, g.Fs);
+            else jd_wt_setfreq(m2_freq, m2_step, mc_freq + freq_offset_est, Fs);
         }
         else countdown2 = 5;
         CI(I_COUNTDOWN2) = countdown2;
         if ((mse > thr) && (fabs(m2_freq - (mc_freq + freq_offset_est)) > 3.0))
-            jd_wt_setfreq(m2_freq, m2_step, mc_freq + freq_offset_est, g.Fs);
+            jd_wt_setfreq(m2_freq, m2_step, mc_freq + freq_offset_est, Fs);
         if ((afc) && (mse < thr) && (fabs(m2_freq - mc_freq) > 3.0))
         {
             if (countdown > 0) countdown--;
@@ -68,7 +81,7 @@ __device__ __forceinline__ int coarse_slot_apply(const JGeom &g, const JPtrs &p,
     else // MSK
     {
         if ((mse > thr) && (fabs(m2_freq - (mc_freq + freq_offset_est)) > 0.0))
-            jd_wt_setfreq(m2_freq, m2_step, mc_freq + freq_offset_est, g.Fs);
+            jd_wt_setfreq(m2_freq, m2_step, mc_freq + freq_offset_est, Fs);
         if ((afc) && (dcd) && (fabs(m2_freq - mc_freq) > 2.0))
         {
             if (countdown > 0) countdown--;
@@ -79,9 +92,9 @@ __device__ __forceinline__ int coarse_slot_apply(const JGeom &g, const JPtrs &p,
     if (big)
     {
         const double lbw = lockingbw; // demodulator's lockingbw == estimator's (oqpsk passes 2*bw/2)
-        jd_wt_setfreq(mc_freq, mc_step, m2_freq, g.Fs);
-        if (mc_freq < lbw / 2.0) jd_wt_setfreq(mc_freq, mc_step, lbw / 2.0, g.Fs);
-        if (mc_freq > (g.Fs / 2.0 - lbw / 2.0)) jd_wt_setfreq(mc_freq, mc_step, g.Fs / 2.0 - lbw / 2.0, g.Fs);
+        jd_wt_setfreq(mc_freq, mc_step, m2_freq, Fs);
+        if (mc_freq < lbw / 2.0) jd_wt_setfreq(mc_freq, mc_step, lbw / 2.0, Fs);
+        if (mc_freq > (Fs / 2.0 - lbw / 2.0)) jd_wt_setfreq(mc_freq, mc_step, Fs / 2.0 - lbw / 2.0, Fs);
         emptying = 4; // coarsefreqestimate->bigchange()
     }
     CI(I_EMPTYING) = emptying;

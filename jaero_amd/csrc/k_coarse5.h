@@ -22,16 +22,7 @@
 #include "k_coarse2.h"
 
 #ifndef C5_MIX
-#define C5_MIX 1
-#endif
-#ifndef C5_STAGGER
-#define C5_STAGGER 1 // measured: no effect (14.4 - 14.7 ms for 1, 2, 8, 32)
-#endif
-#ifndef C5_EARLY_A
-#define C5_EARLY_A 1
-#endif
-#ifndef C5_CS_EARLY
-#define C5_CS_EARLY 0
+#define C5_MIX 0 // experiment: one LDS instruction after every few VALU instructions (sched_group_barrier) -- measured, no gain
 #endif
 #define C4_TABN 3584 // W8400: window table entries kept in LDS behind the exchange buffer (28 KiB): lockingbw < 10.49 kHz
 #define C5_PLANE 8224                    // doubles per plane buffer (exchange 2 needs 31*257 + 256 = 8223)
@@ -198,17 +189,9 @@ __device__ __forceinline__ void coarse5_body(const JGeom g, const JPtrs p, const
     const int nchp = g.nchp;
     int tab_startbin = -1; // W8400: the startbin the window table behind the exchange buffer was made for
 
-    // Every estimate takes every CU the same time, so the 256 persistent workgroups of a launch stay in step: all of them in their ring /
-    // y phase at the same moment (134 MB wanted at once, then 40 us of nothing).  A one-time delay of (workgroup mod C5_STAGGER) eighths of
-    // an estimate spreads the phases over the estimate's duration.
-    if (C5_STAGGER > 1)
-    {
-        const int k = (int)(blockIdx.x % C5_STAGGER) * (56 / C5_STAGGER); // ~1 us units
-        for (int i = 0; i < k; i++) { __builtin_amdgcn_s_sleep(32); } // 32 x 64 clocks ~ 1 us
-    }
     CV<16> a, b;
-    int ch_next = ((int)blockIdx.x < nlist) ? (chan_list ? chan_list[blockIdx.x] : (int)blockIdx.x) : 0;
-    int bp_next = p.I[(size_t)I_BB_PTR * nchp + ch_next];
+    int ch_next = ((int)blockIdx.x < nlist) ? (chan_list ? jd_sload(chan_list + blockIdx.x) : (int)blockIdx.x) : 0;
+    int bp_next = jd_sload(p.I + (size_t)I_BB_PTR * nchp + ch_next);
     for (int li = blockIdx.x; li < nlist; li += gridDim.x)
     {
         int t = t0; // opaque once per estimate (what derives from it is 1-2 instructions; hoisted out of the persistent loop, ~100 live registers)
@@ -221,11 +204,13 @@ __device__ __forceinline__ void coarse5_body(const JGeom g, const JPtrs p, const
         const bool has_next = ln < nlist;
         if (has_next)
         {
-            ch_next = chan_list ? chan_list[ln] : ln;
-            bp_next = p.I[(size_t)I_BB_PTR * nchp + ch_next];
+            ch_next = chan_list ? jd_sload(chan_list + ln) : ln; // scalar loads (k_coarse.h): no vmcnt wait behind the vector traffic
+            bp_next = jd_sload(p.I + (size_t)I_BB_PTR * nchp + ch_next);
         }
-        const double lockingbw = p.S[(size_t)S_LOCKINGBW * nchp + ch];
-        const double hzperbin = g.Fs / ((double)N);
+        const double lockingbw = jd_sload(p.S + (size_t)S_LOCKINGBW * nchp + ch);
+        double fs_l = g.Fs; // opaque per estimate, as t: hoisted out of the loop Fs / N would be kept (spilled) across it, and a reload's wait
+        asm volatile("" : "+s"(fs_l)); // stands behind every vector load in flight (vmcnt counts in order)
+        const double hzperbin = fs_l * (1.0 / ((double)N)); // N a power of two: the same bits as the reference's quotient
         const int startbin = (int)fmax(round(lockingbw / hzperbin), 1.0);
         const int stopbin = N - startbin;
         const int expectedpeakbin = (int)round(g.fb / (2.0 * hzperbin));
@@ -312,10 +297,12 @@ __device__ __forceinline__ void coarse5_body(const JGeom g, const JPtrs p, const
         c5_bar(); // the exchange buffer is free: it receives a copy of y for the fold below
         // smooth with fftshift: y[i] = y[i]*0.9 + 0.1*10*log10(fmax(abs(out[i]),1)), out[i] = X[i ^ N/2]
         // All 32 old y values are requested before the log10s, into the registers of the imaginary planes (dead once only |X|^2 is kept).
-        // Stream a is finished first (log10, update, stores); its 64 registers then take stream a's half of the NEXT estimate's ring, which
-        // travels under stream b's log10s; stream b's half follows behind the last y stores.
-        const double2 *__restrict__ ringn = p.bbring + (size_t)ch_next * N;
-        CoarseSlotState cs = {};
+        // y[] is this kernel's private state (nothing else reads it; bigchange() sets every entry), so in HBM it is kept in the ORDER THE
+        // THREADS HOLD IT: entry (stream H, slot s, thread t) -- the smoothed value of bin C5_IDX(H, s, t) ^ N/2 -- at (H*16 + s)*512 + t:
+        // every access a whole 512-byte row.  In bin order the two streams of a slot own alternate 16-byte pieces; written one stream after
+        // the other (tried: stream a first, its half of the next ring requested under stream b's log10s, 1.6 % faster) a launch moved 51.7
+        // GB instead of 34.6 (partial-sector writes and their fills), written back to back still 37.8.  The ring keeps the reference's
+        // order (the sample loop fills it): its 32-byte pieces of the two streams are requested back to back.
         {
             double ya[16], yb[16];
             const int toff = ((t >> 1) << 2) | (t & 1);
@@ -325,7 +312,7 @@ __device__ __forceinline__ void coarse5_body(const JGeom g, const JPtrs p, const
             if constexpr (!(ABL & 1))
             {
 #pragma unroll
-                for (int s = 0; s < 16; s++) { ya[s] = (y + ((s ^ 8) << 10))[toff]; yb[s] = (y + (((s ^ 8) << 10) + 2))[toff]; } // uniform base + lane offset
+                for (int s = 0; s < 16; s++) { ya[s] = (y + s * 512)[t]; yb[s] = (y + (16 + s) * 512)[t]; } // uniform base + lane: whole 512-byte rows
             }
             else
             {
@@ -335,50 +322,13 @@ __device__ __forceinline__ void coarse5_body(const JGeom g, const JPtrs p, const
             C5_FENCE; // or the scheduler sinks every load to its use again
             // 10*log10(max(|X|,1)) == 5*log10(max(|X|^2,1)): no hypot; differs from the reference expression by <= 1 ulp
 #pragma unroll
-            for (int s = 0; s < 16; s++) a.r[s] = 5.0 * c2_log10(fmax(a.r[s], 1.0));
+            for (int s = 0; s < 16; s++) { a.r[s] = 5.0 * c2_log10(fmax(a.r[s], 1.0)); b.r[s] = 5.0 * c2_log10(fmax(b.r[s], 1.0)); }
 #pragma unroll
             for (int s = 0; s < 16; s++)
             {
-                const double na = ya[s] * 0.9 + a.r[s];
-                if constexpr (!(ABL & 1)) (y + ((s ^ 8) << 10))[toff] = na;
-                (xch + ((s ^ 8) << 10))[toff] = na;
-            }
-            C5_FENCE;
-#if C5_EARLY_A
-            if constexpr (!(ABL & 1))
-            {
-                if (has_next)
-                {
-#pragma unroll
-                    for (int s = 0; s < 16; s++)
-                    {
-                        const double2 v0 = ringn[(bp_next + C5_IDX(0, s, t)) & (N - 1)];
-                        a.r[s] = v0.x; a.i[s] = v0.y;
-                    }
-                }
-            }
-            else
-            {
-#pragma unroll
-                for (int s = 0; s < 16; s++) { a.r[s] = (double)(t + s); a.i[s] = (double)(t - s); }
-            }
-            C5_FENCE;
-#endif
-#pragma unroll
-            for (int s = 0; s < 16; s++) b.r[s] = 5.0 * c2_log10(fmax(b.r[s], 1.0));
-            C5_FENCE;
-            // the channel's acquisition state for the epilogue (thread 0): requested here, in front of the last y stores and the second half of
-            // the prefetch, so that waiting for it (vmcnt counts in order) waits for neither
-#if C5_CS_EARLY
-            if (t == 0) cs = coarse_slot_load(g, p, ch);
-            C5_FENCE;
-#endif
-#pragma unroll
-            for (int s = 0; s < 16; s++)
-            {
-                const double nb = yb[s] * 0.9 + b.r[s];
-                if constexpr (!(ABL & 1)) (y + (((s ^ 8) << 10) + 2))[toff] = nb;
-                (xch + (((s ^ 8) << 10) + 2))[toff] = nb;
+                const double na = ya[s] * 0.9 + a.r[s], nb = yb[s] * 0.9 + b.r[s];
+                if constexpr (!(ABL & 1)) { (y + s * 512)[t] = na; (y + (16 + s) * 512)[t] = nb; }
+                (xch + ((s ^ 8) << 10))[toff] = na; (xch + (((s ^ 8) << 10) + 2))[toff] = nb;
             }
         }
         c5_bar(); // the fold reads the LDS copy; the stores to y[] drain in the background
@@ -386,22 +336,25 @@ __device__ __forceinline__ void coarse5_body(const JGeom g, const JPtrs p, const
         {
             if (has_next)
             {
+                // laundered: known since the top of the estimate, the 32 ring addresses would otherwise be computed there and kept (spilled)
+                // across the three transforms
+                int bpn = bp_next, chn = ch_next, tp = t;
+                asm volatile("" : "+v"(bpn), "+v"(chn), "+v"(tp));
+                const double2 *__restrict__ ringn = p.bbring + (size_t)chn * N;
+                const int toffp = bpn + (((tp >> 1) << 2) | (tp & 1));
 #pragma unroll
                 for (int s = 0; s < 16; s++)
                 {
-#if !C5_EARLY_A
-                    const double2 v0 = ringn[(bp_next + C5_IDX(0, s, t)) & (N - 1)];
-                    a.r[s] = v0.x; a.i[s] = v0.y;
-#endif
-                    const double2 v1 = ringn[(bp_next + C5_IDX(1, s, t)) & (N - 1)];
-                    b.r[s] = v1.x; b.i[s] = v1.y;
+                    const double2 v0 = ringn[(toffp + (s << 10)) & (N - 1)];
+                    const double2 v1 = ringn[(toffp + (s << 10) + 2) & (N - 1)];
+                    a.r[s] = v0.x; a.i[s] = v0.y; b.r[s] = v1.x; b.i[s] = v1.y;
                 }
             }
         }
         else
         {
 #pragma unroll
-            for (int s = 0; s < 16; s++) { b.r[s] = (double)(t ^ s); b.i[s] = 1.0; }
+            for (int s = 0; s < 16; s++) { a.r[s] = (double)(t + s); a.i[s] = (double)(t - s); b.r[s] = (double)(t ^ s); b.i[s] = 1.0; }
         }
 
         // fold + peak search (:116-131)
@@ -445,10 +398,7 @@ __device__ __forceinline__ void coarse5_body(const JGeom g, const JPtrs p, const
                 red_idx[0] = bi;
             }
         }
-#if !C5_CS_EARLY
-        if (t == 0) cs = coarse_slot_load(g, p, ch);
-#endif
-        if (t == 0) sh_bigchange = coarse_slot_apply(g, p, ch, cs, (red_idx[0] >= 0) ? red_idx[0] : (N / 2), N, hzperbin, lockingbw);
+        if (t == 0) sh_bigchange = coarse_slot(g, p, ch, (red_idx[0] >= 0) ? red_idx[0] : (N / 2), N, hzperbin, lockingbw);
         c5_bar();
         if (sh_bigchange)
         {

@@ -159,7 +159,12 @@ int main(int argc, char **argv)
             // the band-limited signal's square occupies |k| < 2 startbin; the bins beyond hold the transform's round-off (~1e-16 of the
             // lines' power) and are never read by the fold (|k| <= startbin + expectedpeakbin + 1): compared inside the support only
             const int hw = 2 * (int)lround((10500.0 - 500.0 * (c % 3)) / (48000.0 / N)) - 8;
-            for (int i = N / 2 - hw; i <= N / 2 + hw; i++) maxd = fmax(maxd, fabs(y0[i] - y1[i]));
+            // k_coarse5 keeps y[] in the order its threads hold it: bin i = C5_IDX(H, s, t) ^ N/2 lives at (H*16 + s)*512 + t
+            for (int i = N / 2 - hw; i <= N / 2 + hw; i++)
+            {
+                const int k = i ^ (N / 2), H = (k >> 1) & 1, sl = k >> 10, tt = (((k >> 2) & 255) << 1) | (k & 1);
+                maxd = fmax(maxd, fabs(y0[i] - y1[(H * 16 + sl) * 512 + tt]));
+            }
             CK(hipMemcpy(l0.data(), sd[0].slog + (size_t)c * g.log_cap * 6, l0.size() * 8, hipMemcpyDeviceToHost));
             CK(hipMemcpy(l1.data(), sd[1].slog + (size_t)c * g.log_cap * 6, l1.size() * 8, hipMemcpyDeviceToHost));
             for (int r = 0; r < 3; r++) { nrow++; if (l0[r * 6 + 1] != l1[r * 6 + 1] || l0[r * 6 + 0] != l1[r * 6 + 0]) badbin++; }
