@@ -51,6 +51,14 @@ enum
     I_DLY_POS,   // MSK: shared slot of delayedsmpl / delayt8 rings
     I_NFIELDS
 };
+// Read-only data through the CONSTANT address space: with a wave-uniform address such a load is a scalar load (lgkmcnt) that the compiler
+// may also hoist and reuse -- a load through a plain pointer held in a kernel-argument struct is neither (any store may alias it), and as
+// a vector load it queues behind every other vector load in flight (vmcnt retires in order).  Only for memory this kernel does not write.
+typedef const __attribute__((address_space(4))) int jd_cint;
+typedef const __attribute__((address_space(4))) double jd_cdouble;
+__device__ __forceinline__ int jd_sload(const int *q) { return *(jd_cint *)q; }
+__device__ __forceinline__ double jd_sload(const double *q) { return *(jd_cdouble *)q; }
+
 // state access of the continuous sample kernels (ch, nchp in scope)
 #define LDF(f) (p.S[(size_t)(f) * nchp + ch])
 #define LDI(f) (p.I[(size_t)(f) * nchp + ch])

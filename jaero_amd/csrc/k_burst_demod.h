@@ -392,7 +392,8 @@ __global__ __launch_bounds__(64) void k_burst_msk_demod(const BGeom g, const BPt
     double tre[TAILA], tim[TAILA]; // tre[j] = x_re[newest - LDSN - j]
     const int lane = threadIdx.x, grp = blockIdx.x, ch = grp * 64 + lane, nchp = g.nchp;
     const double2 *__restrict__ cis = p.cis;
-    const double *__restrict__ taps = p.taps2; // this bank's own half-sine taps (burst_host.h); wave-uniform index -> scalar loads
+    jd_cdouble *taps = (jd_cdouble *)p.taps2; // this bank's own half-sine taps (burst_host.h) through the constant address space: scalar loads, as from the
+                                              // process-global __constant__ table they replace (through a plain pointer they were vector loads in the filter loop: 4.5 -> 3.6 Gsamples/s)
     const double SPS = g.SPS, samplerate = g.Fs;
 
     double m2_ptr = BLDF(BS_M2_PTR), m2_step = BLDF(BS_M2_STEP), m2_freq = BLDF(BS_M2_FREQ), mc_freq = BLDF(BS_MC_FREQ);

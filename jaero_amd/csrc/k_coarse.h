@@ -18,10 +18,6 @@ struct CoarseSlotState
 // not wait for the vector loads in flight around them -- as vector loads (vmcnt retires in order) thread 0 stood behind its wavefront's
 // share of the next estimate's ring prefetch, and the workgroup behind thread 0, once per estimate.  Safe here: what is read was written
 // by earlier launches (the scalar cache is invalidated at kernel start) or, for other channels, by this kernel.
-typedef const __attribute__((address_space(4))) int jd_cint;
-typedef const __attribute__((address_space(4))) double jd_cdouble;
-__device__ __forceinline__ int jd_sload(const int *q) { return *(jd_cint *)q; }
-__device__ __forceinline__ double jd_sload(const double *q) { return *(jd_cdouble *)q; }
 __device__ __forceinline__ CoarseSlotState coarse_slot_load(const JGeom &g, const JPtrs &p, int ch)
 {
     const int nchp = g.nchp;
