@@ -24,7 +24,7 @@
 #include "k_pre8400.h"
 #include "k_coarse.h"
 #include "k_coarse2.h"
-#include "k_coarse5.h"
+#include "k_coarse6.h"
 #include "k_viterbi.h"
 #include "k_viterbi_lanes.h"
 #include "burst_device.h"
@@ -594,7 +594,7 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
             c->allocs.push_back(dH); c->allocs.push_back(dtw);
             c->pre_direct = false; // (the time-domain form k_pre8400_fir and its A/B switch left the library in round 3)
         }
-        HIPCHK(hipFuncSetAttribute((const void *)k_coarse5_w8400, hipFuncAttributeMaxDynamicSharedMemorySize, (C5_XCH + C4_TABN) * (int)sizeof(double)));
+        HIPCHK(hipFuncSetAttribute((const void *)k_coarse6_w8400, hipFuncAttributeMaxDynamicSharedMemorySize, (C6_XCH + C4_TABN) * (int)sizeof(double)));
     }
     if (g.kind == JAERO_KIND_MSK) { DA(c->p.dly, (size_t)ng * (g.sps + 1) * 64); DA(c->p.dly8, (size_t)ng * (g.sps2 + 1) * 64); }
     DA(c->p.soft, (size_t)nchp * g.soft_cap);
@@ -744,7 +744,7 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
 #undef FBA
         }
     }
-    if (g.nfft_log2 == 14) HIPCHK(hipFuncSetAttribute((const void *)k_coarse5, hipFuncAttributeMaxDynamicSharedMemorySize, C5_XCH * (int)sizeof(double)));
+    if (g.nfft_log2 == 14) HIPCHK(hipFuncSetAttribute((const void *)k_coarse6, hipFuncAttributeMaxDynamicSharedMemorySize, C6_XCH * (int)sizeof(double)));
     else HIPCHK(hipFuncSetAttribute((const void *)k_coarse2<13>, hipFuncAttributeMaxDynamicSharedMemorySize, c->coarse2_lds));
     HIPCHK(hipDeviceSynchronize());
     *out = c;
@@ -982,7 +982,7 @@ extern "C" int jaero_profile_kernel(jaero_ctx *c, int which, char *buf, int cap)
         if (g.kind == JAERO_KIND_OQPSK) nm = "k_oqpsk_fb<";
         else nm = c->msk_pairs ? "k_msk_fb<" : "k_msk_samples<";
     }
-    else if (which == 1) nm = (g.nfft_log2 == 14) ? (c->pre8400 ? "k_coarse5_w8400" : "k_coarse5") : "k_coarse2<";
+    else if (which == 1) nm = (g.nfft_log2 == 14) ? (c->pre8400 ? "k_coarse6_w8400" : "k_coarse6") : "k_coarse2<";
     else if (which == 2) nm = "k_transpose_pcm";
     snprintf(buf, (size_t)cap, "%s", nm);
     return 0;
@@ -1051,11 +1051,11 @@ static void launch_coarse(jaero_ctx *c, const int *d_list, int nlist, hipStream_
     const int grid = nlist < c->coarse2_grid ? nlist : c->coarse2_grid;
     if (c->g.nfft_log2 == 14)
     {
-        // 2^14 = 16 x 16 x 16 x 4, 16-point register FFTs only, two streams per thread (k_coarse5.h); both planes of one stream in LDS
+        // 2^14 = 32 x 32 x 16 in registers, two LDS exchanges per transform, one plane at a time in LDS (k_coarse6.h)
         if (c->pre8400)
-            hipLaunchKernelGGL(k_coarse5_w8400, dim3(grid), dim3(C2_THREADS), (C5_XCH + C4_TABN) * (int)sizeof(double), st, c->g, c->p, d_list, nlist, c->d_tw);
+            hipLaunchKernelGGL(k_coarse6_w8400, dim3(grid), dim3(C2_THREADS), (C6_XCH + C4_TABN) * (int)sizeof(double), st, c->g, c->p, d_list, nlist, c->d_tw);
         else
-            hipLaunchKernelGGL(k_coarse5, dim3(grid), dim3(C2_THREADS), C5_XCH * (int)sizeof(double), st, c->g, c->p, d_list, nlist, c->d_tw);
+            hipLaunchKernelGGL(k_coarse6, dim3(grid), dim3(C2_THREADS), C6_XCH * (int)sizeof(double), st, c->g, c->p, d_list, nlist, c->d_tw);
     }
     else hipLaunchKernelGGL((k_coarse2<13>), dim3(grid), dim3(C2_THREADS), c->coarse2_lds, st, c->g, c->p, d_list, nlist, c->d_tw);
 }

@@ -1,0 +1,368 @@
+// k_coarse6.h -- the 2^14-point coarse frequency estimator with TWO LDS exchanges per transform: 16384 = 32 x 32 x 16 (round 3).
+//
+// Same function as k_coarse5 / k_coarse4 (CoarseFreqEstimate::ProcessBasebandData + FreqOffsetEstimateSlot,
+// JAERO/coarsefreqestimate.cpp:90-137, JAERO/oqpskdemodulator.cpp:629-677).  What round 3 measured: a transform's
+// LDS traffic and its arithmetic do not overlap on this CU however they are arranged, so the only way left to shorten an estimate is to
+// move fewer bytes through LDS.  16 x 16 x 16 x 4 needs three exchanges of all 32 points a thread holds; 32 x 32 x 16 needs two:
+//
+//   n = 512 n1 + 16 n2 + n3        k = k1 + 32 k2 + 1024 k3        (n1, n2, k1, k2 < 32;  n3, k3 < 16)
+//   pass 1: FFT32 over n1, x W_N^(k1 (n mod 512))      exchange 1      pass 2: FFT32 over n2, x W_512^(k2 n3)      exchange 2
+//   pass 3: two FFT16 over n3
+//
+// natural order on entry AND exit (slot = index >> 9, thread = index & 511), so ring / y[] accesses are whole 512-byte rows and the three
+// transforms chain in registers.  The 32-point FFTs that made the first kernel of this shape (k_coarse2<14>) spill 359 registers are done
+// in place: one radix-2 stage, then a 16-point FFT on each half; their outputs stay in SPLIT order (slot j < 16 = X[2j], slot 16 + j =
+// X[2j + 1]), which only changes compile-time addresses of the exchange behind them.  Twiddles: even powers by a chain of products with
+// step^2, each odd power one product more -- two live values instead of a table of 31.  Index maps, twiddles and bank behaviour:
+// tests/test_coarse_fft14_e32_model.py.
+#pragma once
+#include "k_coarse2.h"
+
+#ifndef C4_TABN
+#define C4_TABN 3584 // W8400: window table entries kept in LDS behind the exchange buffer (28 KiB): lockingbw < 10.49 kHz
+#endif
+__device__ __forceinline__ void c6_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#define C6_FENCE __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ double2 c6_sq(const double2 a)
+{
+#pragma clang fp contract(fast)
+    return make_double2(a.x * a.x - a.y * a.y, 2.0 * (a.x * a.y));
+}
+
+#define C6_XCH 16448 // doubles: one plane of the whole transform (exchange 2: 16 rows at stride 513, + 8208 for the upper half of k2)
+
+__device__ __forceinline__ constexpr int c6_k(int s) { return s < 16 ? 2 * s : 2 * (s - 16) + 1; }
+
+// in-place forward 32-point DFT, natural order in, split order out
+__device__ __forceinline__ void c6_fft32(CV<32> &x)
+{
+#pragma clang fp contract(fast)
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+    {
+        const double ar = x.r[j], ai = x.i[j], br = x.r[j + 16], bi = x.i[j + 16];
+        x.r[j] = ar + br; x.i[j] = ai + bi;
+        double dr = ar - br, di = ai - bi;
+        cmul_w64(dr, di, 2 * j); // W_32^j
+        x.r[j + 16] = dr; x.i[j + 16] = di;
+    }
+    C6_FENCE;
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+    {
+        CV<16> in, out;
+#pragma unroll
+        for (int j = 0; j < 16; j++) { in.r[j] = x.r[16 * h + j]; in.i[j] = x.i[16 * h + j]; }
+        regfft<16>(in, out);
+#pragma unroll
+        for (int j = 0; j < 16; j++) { x.r[16 * h + j] = out.r[j]; x.i[16 * h + j] = out.i[j]; }
+        C6_FENCE;
+    }
+}
+
+// x[slot of k] *= p1^k for k = 1 .. 31 (split order): even powers e_j = p1^(2j) by a chain, each odd power one product more; three live
+// values instead of a table of 31.  (Four interleaved chains of depth 5 instead of one of depth 15 measured no faster: 13.34 vs 13.19 ms.)
+__device__ __forceinline__ void c6_twiddle32(CV<32> &x, const double2 p1)
+{
+#pragma clang fp contract(fast)
+    auto app = [&](int slot, const double2 w) __attribute__((always_inline)) {
+        const double r = x.r[slot] * w.x - x.i[slot] * w.y, i = x.r[slot] * w.y + x.i[slot] * w.x;
+        x.r[slot] = r; x.i[slot] = i;
+    };
+    const double2 p2 = c6_sq(p1);
+    double2 e = p2;
+    app(16, p1);
+#pragma unroll
+    for (int j = 1; j < 16; j++)
+    {
+        app(j, e);
+        app(16 + j, cmul2(e, p1));
+        if (j < 15) e = cmul2(e, p2);
+    }
+}
+
+// In-place forward 2^14-point DFT of the workgroup's data, natural distribution in and out.  xch: C6_XCH doubles.
+__device__ __forceinline__ void wg_fft14_e32(CV<32> &d, double *xch, const double2 *__restrict__ tw, int t)
+{
+#pragma clang fp contract(fast)
+    const double2 st1 = tw[t], st2 = tw[32 * (t & 15)]; // W_N^(n mod 512); W_512^n3 -- requested before the first butterfly
+    const int k1u = t >> 4, n3 = t & 15, odd = k1u & 1;
+    const int e1w0 = t, e1w1 = (t + 16) & 511;                  // exchange 1 writer: even / odd k1 rows (odd rows rotated by one n2 row)
+    const int e1r = k1u * 512 + odd * 16 + n3;                  // reader: + 16 m, except the one row that wraps
+    const int e1rw = e1r + 496 - 512 * odd;                     //   m = 31
+    // exchange 2: row stride 513 -- a 64-bit LDS access is served 16 lanes at a time from 16 eight-byte bank pairs, and the 16 lanes of a
+    // writer group differ in n3 only: an ODD stride spreads them over all 16 (514, chosen for a 32-lane rule, measured 403 M conflict cycles
+    // per launch: SQ_LDS_BANK_CONFLICT)
+    const int e2w = k1u + n3 * 513;                             // writer: + (k2 & 15) * 32 + (k2 >> 4) * 8208
+    const int e2r = t;                                          // reader: + n3 * 513 + k2hi * 8208
+
+    // ---- pass 1 ----
+    c6_fft32(d);
+    c6_twiddle32(d, st1);
+    C6_FENCE;
+    // ---- exchange 1, a plane at a time ----
+    c6_bar(); // the buffer is free (previous transform's last reads / the fold)
+#pragma unroll
+    for (int s = 0; s < 32; s++) xch[c6_k(s) * 512 + ((c6_k(s) & 1) ? e1w1 : e1w0)] = d.r[s];
+    c6_bar();
+#pragma unroll
+    for (int m = 0; m < 32; m++) d.r[m] = xch[(m < 31 ? e1r + 16 * m : e1rw)];
+    c6_bar();
+#pragma unroll
+    for (int s = 0; s < 32; s++) xch[c6_k(s) * 512 + ((c6_k(s) & 1) ? e1w1 : e1w0)] = d.i[s];
+    c6_bar();
+#pragma unroll
+    for (int m = 0; m < 32; m++) d.i[m] = xch[(m < 31 ? e1r + 16 * m : e1rw)];
+    C6_FENCE;
+    // ---- pass 2 ----
+    c6_fft32(d);
+    c6_twiddle32(d, st2);
+    C6_FENCE;
+    // ---- exchange 2 ----
+    c6_bar();
+#pragma unroll
+    for (int s = 0; s < 32; s++) xch[e2w + (c6_k(s) & 15) * 32 + (c6_k(s) >> 4) * 8208] = d.r[s];
+    c6_bar();
+#pragma unroll
+    for (int m = 0; m < 32; m++) d.r[m] = xch[e2r + (m & 15) * 513 + (m >> 4) * 8208]; // slot m = n3 + 16 k2hi
+    c6_bar();
+#pragma unroll
+    for (int s = 0; s < 32; s++) xch[e2w + (c6_k(s) & 15) * 32 + (c6_k(s) >> 4) * 8208] = d.i[s];
+    c6_bar();
+#pragma unroll
+    for (int m = 0; m < 32; m++) d.i[m] = xch[e2r + (m & 15) * 513 + (m >> 4) * 8208];
+    C6_FENCE;
+    // ---- pass 3: FFT16 over n3 for k2hi = 0, 1; X[.. + 1024 k3] -> slot 2 k3 + k2hi (= natural: k = slot * 512 + t) ----
+    {
+        CV<16> in, o0, o1;
+#pragma unroll
+        for (int j = 0; j < 16; j++) { in.r[j] = d.r[j]; in.i[j] = d.i[j]; }
+        regfft<16>(in, o0);
+        C6_FENCE;
+#pragma unroll
+        for (int j = 0; j < 16; j++) { in.r[j] = d.r[16 + j]; in.i[j] = d.i[16 + j]; }
+        regfft<16>(in, o1);
+#pragma unroll
+        for (int k3 = 0; k3 < 16; k3++) { d.r[2 * k3] = o0.r[k3]; d.i[2 * k3] = o0.i[k3]; d.r[2 * k3 + 1] = o1.r[k3]; d.i[2 * k3 + 1] = o1.i[k3]; }
+    }
+}
+
+__device__ __forceinline__ void c6_fft(CV<32> &d, double *xch, const double2 *__restrict__ tw, int t)
+{
+    int tt = t; // laundered per call: nothing derived from it inside is shared between the three calls of an estimate and kept live
+    asm volatile("" : "+v"(tt));
+    wg_fft14_e32(d, xch, tw, tt);
+}
+
+template <bool W8400>
+__device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const int *__restrict__ chan_list, int nlist, const double2 *__restrict__ tw)
+{
+    constexpr int N = 1 << 14;
+    constexpr int E = 32;
+    extern __shared__ __attribute__((aligned(16))) double xch[];
+    __shared__ double red_val[C2_THREADS / 64]; // one entry per wavefront
+    __shared__ int red_idx[C2_THREADS / 64];
+    __shared__ int sh_bigchange;
+    const int t0 = threadIdx.x;
+    const int nchp = g.nchp;
+    int tab_startbin = -1; // W8400: the startbin the window table behind the exchange buffer was made for
+
+    CV<E> d;
+    int ch_next = ((int)blockIdx.x < nlist) ? (chan_list ? jd_sload(chan_list + blockIdx.x) : (int)blockIdx.x) : 0;
+    int bp_next = jd_sload(p.I + (size_t)I_BB_PTR * nchp + ch_next);
+    for (int li = blockIdx.x; li < nlist; li += gridDim.x)
+    {
+        int t = t0; // opaque once per estimate (what derives from it is 1-2 instructions; hoisted out of the persistent loop, ~100 live registers)
+        asm volatile("" : "+v"(t));
+        const int ch = ch_next, bb_ptr = bp_next;
+        const double2 *__restrict__ ring = p.bbring + (size_t)ch * N;
+        // the next estimate's channel and ring position: scalar loads (jaero_device.h), requested a whole estimate before the prefetch that
+        // needs them
+        const int ln = li + (int)gridDim.x;
+        const bool has_next = ln < nlist;
+        if (has_next)
+        {
+            ch_next = chan_list ? jd_sload(chan_list + ln) : ln;
+            bp_next = jd_sload(p.I + (size_t)I_BB_PTR * nchp + ch_next);
+        }
+        const double lockingbw = jd_sload(p.S + (size_t)S_LOCKINGBW * nchp + ch);
+        double fs_l = g.Fs; // opaque per estimate, as t: hoisted out of the loop Fs / N would be kept (spilled) across it, and a reload's wait
+        asm volatile("" : "+s"(fs_l)); // stands behind every vector load in flight (vmcnt counts in order)
+        const double hzperbin = fs_l * (1.0 / ((double)N)); // N a power of two: the same bits as the reference's quotient
+        const int startbin = (int)fmax(round(lockingbw / hzperbin), 1.0);
+        const int stopbin = N - startbin;
+        const int expectedpeakbin = (int)round(g.fb / (2.0 * hzperbin));
+        double *__restrict__ y = p.y + (size_t)ch * N;
+
+        // bbtmpbuff[j] = bbcycbuff[(ptr+j)%N] (time order); for every list entry but the first these loads were issued while the
+        // previous estimate was in its peak search / state machine
+        if (li == (int)blockIdx.x)
+        {
+#pragma unroll
+            for (int s = 0; s < E; s++)
+            {
+                const double2 v = ring[(bb_ptr + s * C2_THREADS + t) & (N - 1)];
+                d.r[s] = v.x; d.i[s] = v.y;
+            }
+        }
+        c6_fft(d, xch, tw, t);
+        // band limit (fb != 8400 boxcar, coarsefreqestimate.cpp:99) then inverse transform = forward on swapped planes
+        if constexpr (W8400)
+        {
+            // window[0] = 1, window[i] = window[N - i] = cos^2(pi/2 * i / startbin) for 1 <= i <= startbin, 0 elsewhere (:61-74).  Its
+            // startbin + 1 distinct values come from a table in LDS behind the exchange buffer (entry startbin + 1 = 0 stands for every bin
+            // the window zeroes), rebuilt only when startbin changes; a window wider than that space (lockingbw >= 10.49 kHz) is made per
+            // estimate in the idle exchange buffer.
+            const bool persistent = startbin < C4_TABN - 1;
+            double *wt = persistent ? xch + C6_XCH : xch;
+            if (!persistent || startbin != tab_startbin)
+            {
+                c6_bar();
+                for (int i = t; i <= startbin + 1; i += C2_THREADS)
+                {
+                    const double c = cos(M_PI_2 * ((double)i) / ((double)startbin));
+                    wt[i] = (i == 0) ? 1.0 : ((i <= startbin) ? c * c : 0.0);
+                }
+                c6_bar();
+                if (persistent) tab_startbin = startbin;
+            }
+#pragma unroll
+            for (int s0 = 0; s0 < E; s0 += 8)
+            {
+#pragma unroll
+                for (int s = s0; s < s0 + 8; s++)
+                {
+                    const int k = s * C2_THREADS + t;
+                    const int i = (k <= N / 2) ? k : N - k;
+                    const double w = wt[i <= startbin ? i : startbin + 1];
+                    const double re = d.r[s] * w, im = d.i[s] * w;
+                    d.r[s] = im; d.i[s] = re;
+                }
+                C6_FENCE;
+            }
+            if (!persistent) c6_bar(); // the next transform's exchanges reuse the buffer
+        }
+        else
+        {
+#pragma unroll
+            for (int s = 0; s < E; s++)
+            {
+                const int k = s * C2_THREADS + t;
+                const bool z = (k >= startbin) && (k <= stopbin);
+                const double re = z ? 0.0 : d.r[s], im = z ? 0.0 : d.i[s];
+                d.r[s] = im; d.i[s] = re;
+            }
+        }
+        c6_fft(d, xch, tw, t);
+        // swap back (x N / N = 1), square
+#pragma unroll
+        for (int s = 0; s < E; s++)
+        {
+            const double re = d.i[s], im = d.r[s];
+            d.r[s] = re * re - im * im;
+            d.i[s] = re * im + im * re;
+        }
+        c6_fft(d, xch, tw, t);
+        c6_bar(); // the exchange buffer is free: it receives a copy of y for the fold below
+        // smooth with fftshift: y[i] = y[i]*0.9 + 0.1*10*log10(fmax(abs(out[i]),1)), out[i] = X[i ^ N/2]
+        // all 32 old y values are requested before the log10s (their registers: the imaginary plane, dead once only |X|^2 is kept)
+        {
+            double yv[E];
+#pragma unroll
+            for (int s = 0; s < E; s++) d.r[s] = d.r[s] * d.r[s] + d.i[s] * d.i[s];
+            C6_FENCE; // d.i is dead from here: its registers take the y values
+#pragma unroll
+            for (int s = 0; s < E; s++) yv[s] = (y + ((s * C2_THREADS) ^ (N / 2)))[t]; // (s*512 + t) ^ N/2: uniform base + t
+            C6_FENCE; // or the scheduler sinks every load to its use again
+            // 10*log10(max(|X|,1)) == 5*log10(max(|X|^2,1)): no hypot; differs from the reference expression by <= 1 ulp
+#pragma unroll
+            for (int s = 0; s < E; s++) d.r[s] = 5.0 * c2_log10(fmax(d.r[s], 1.0));
+#pragma unroll
+            for (int s = 0; s < E; s++)
+            {
+                const int ib = (s * C2_THREADS) ^ (N / 2);
+                const double yn = yv[s] * 0.9 + d.r[s];
+                (y + ib)[t] = yn;
+                (xch + ib)[t] = yn;
+            }
+        }
+        c6_bar(); // the fold reads the LDS copy; the stores to y[] drain in the background
+        if (has_next)
+        {
+            // laundered: known since the top of the estimate, the 32 ring addresses would otherwise be computed there and kept (spilled)
+            // across the three transforms -- and every reload waits for all vector loads in flight, which serialises this prefetch
+            int bpn = bp_next, chn = ch_next, tp = t;
+            asm volatile("" : "+v"(bpn), "+v"(chn), "+v"(tp));
+            const double2 *__restrict__ ringn = p.bbring + (size_t)chn * N;
+            const int toffp = bpn + tp;
+#pragma unroll
+            for (int s = 0; s < E; s++)
+            {
+                const double2 v = ringn[(toffp + s * C2_THREADS) & (N - 1)];
+                d.r[s] = v.x; d.i[s] = v.y;
+            }
+        }
+
+        // fold + peak search (:116-131)
+        const int i0 = (int)round((-lockingbw / hzperbin) + ((double)(N / 2)));
+        const int i1 = (int)round((lockingbw / hzperbin) + ((double)(N / 2)));
+        double best = 0;
+        int besti = -1;
+        for (int i = i0 + t; i < i1; i += C2_THREADS)
+        {
+            if ((i < 0) || (i >= N)) continue;
+            double val = 0;
+            for (int j = -1; j <= 1; j++)
+            {
+                if (((i - expectedpeakbin - j) < 0) || ((i + expectedpeakbin + j) >= N)) continue;
+                val += (xch[i - expectedpeakbin - j] + xch[i + expectedpeakbin + j]);
+            }
+            if (val > best) { best = val; besti = i; }
+        }
+        // first maximum over the workgroup (ties: the lower bin, as the reference's ascending scan keeps the first): wavefront
+        // reduction through shuffles, then one LDS round for the eight wavefront results -- no barrier drains the ring prefetch in flight
+        {
+            double bv = best;
+            int bi = besti;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+            {
+                const double ov = __shfl_xor(bv, off, 64);
+                const int oi = __shfl_xor(bi, off, 64);
+                if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+            }
+            if ((t & 63) == 0) { red_val[t >> 6] = bv; red_idx[t >> 6] = bi; }
+            c6_bar();
+            if (t == 0)
+            {
+                for (int w = 1; w < C2_THREADS / 64; w++)
+                {
+                    const double ov = red_val[w];
+                    const int oi = red_idx[w];
+                    if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+                }
+                red_idx[0] = bi;
+            }
+        }
+        if (t == 0) sh_bigchange = coarse_slot(g, p, ch, (red_idx[0] >= 0) ? red_idx[0] : (N / 2), N, hzperbin, lockingbw);
+        c6_bar();
+        if (sh_bigchange)
+        {
+            __syncthreads(); // rare (AFC recentre): this estimate's y stores must have landed before other threads overwrite the same rows
+            double2 *ringw = p.bbring + (size_t)ch * N;
+            for (int i = t; i < N; i += C2_THREADS) { y[i] = 20; ringw[i] = make_double2(0.0, 0.0); }
+        }
+        // no barrier here: the next use of LDS is behind the first barrier of the next estimate's transform
+    }
+}
+
+__global__ __launch_bounds__(C2_THREADS) void k_coarse6(const JGeom g, const JPtrs p, const int *__restrict__ chan_list,
+                                                           int nlist, const double2 *__restrict__ tw)
+{
+    coarse6_body<false>(g, p, chan_list, nlist, tw);
+}
+__global__ __launch_bounds__(C2_THREADS) void k_coarse6_w8400(const JGeom g, const JPtrs p, const int *__restrict__ chan_list,
+                                                                 int nlist, const double2 *__restrict__ tw)
+{
+    coarse6_body<true>(g, p, chan_list, nlist, tw);
+}

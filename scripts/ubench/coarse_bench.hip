@@ -6,8 +6,9 @@
 // Every channel's ring holds cos(2 pi 896 n / N) exp(j 2 pi d n / N) + noise (d per channel): its square has lines at 2d and 2d +- 1792,
 // so the fold has one clear maximum at N/2 + 2d and both kernels must report the same bin; y[] rows are compared to 1e-9 inside the
 // support of the squared signal's spectrum.
-#include "../../jaero_amd/csrc/k_coarse5.h"
+#include "k_coarse5.h"
 #include "k_coarse4.h"
+#include "../../jaero_amd/csrc/k_coarse6.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -52,6 +53,18 @@ __global__ __launch_bounds__(C2_THREADS) void k_fft_test(const double2 *x, doubl
     for (int s = 0; s < 16; s++) { X[C5_IDX(0, s, t)] = make_double2(a.r[s], a.i[s]); X[C5_IDX(1, s, t)] = make_double2(b.r[s], b.i[s]); }
 }
 
+__global__ __launch_bounds__(C2_THREADS) void k_fft_test6(const double2 *x, double2 *X, const double2 *tw)
+{
+    extern __shared__ __attribute__((aligned(16))) double xch[];
+    const int t = threadIdx.x;
+    CV<32> d;
+#pragma unroll
+    for (int s = 0; s < 32; s++) { const double2 v = x[s * 512 + t]; d.r[s] = v.x; d.i[s] = v.y; }
+    c6_fft(d, xch, tw, t);
+#pragma unroll
+    for (int s = 0; s < 32; s++) X[s * 512 + t] = make_double2(d.r[s], d.i[s]);
+}
+
 static void host_fft(std::vector<double> &re, std::vector<double> &im)
 {
     const int n = (int)re.size();
@@ -93,8 +106,8 @@ int main(int argc, char **argv)
         S[(size_t)S_M2_FREQ * nch + c] = 8000.0; S[(size_t)S_MC_FREQ * nch + c] = 8000.0;
         I[(size_t)I_BB_PTR * nch + c] = (c * 977) & (N - 1);
     }
-    Side sd[2];
-    for (int k = 0; k < 2; k++)
+    Side sd[3];
+    for (int k = 0; k < 3; k++)
     {
         CK(hipMalloc(&sd[k].S, S.size() * 8)); CK(hipMalloc(&sd[k].I, I.size() * 4)); CK(hipMalloc(&sd[k].y, (size_t)nch * N * 8));
         CK(hipMalloc(&sd[k].slog, (size_t)nch * g.log_cap * 6 * 8));
@@ -102,7 +115,9 @@ int main(int argc, char **argv)
         CK(hipMemset(sd[k].y, 0, (size_t)nch * N * 8));
     }
     auto ptrs = [&](int k) { JPtrs p = {}; p.S = sd[k].S; p.I = sd[k].I; p.bbring = ring; p.y = sd[k].y; p.slog = sd[k].slog; return p; };
-    const int lds4 = 64 * 257 * 8, lds5 = C5_XCH * 8;
+    const int lds4 = 64 * 257 * 8, lds5 = C5_XCH * 8, lds6 = C6_XCH * 8;
+    CK(hipFuncSetAttribute((const void *)k_coarse6, hipFuncAttributeMaxDynamicSharedMemorySize, lds6));
+    CK(hipFuncSetAttribute((const void *)k_coarse6_w8400, hipFuncAttributeMaxDynamicSharedMemorySize, lds6 + C4_TABN * 8));
     CK(hipFuncSetAttribute((const void *)k_coarse4, hipFuncAttributeMaxDynamicSharedMemorySize, lds4));
     CK(hipFuncSetAttribute((const void *)k_coarse5, hipFuncAttributeMaxDynamicSharedMemorySize, lds5));
     CK(hipFuncSetAttribute((const void *)k5_abl<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds5));
@@ -127,6 +142,13 @@ int main(int argc, char **argv)
         double md = 0; int nbad = 0, firstbad = -1;
         for (int i = 0; i < N; i++) { const double d = fmax(fabs(hX[i].x - re[i]), fabs(hX[i].y - im[i])); md = fmax(md, d); if (d > 1e-9) { nbad++; if (firstbad < 0) firstbad = i; } }
         printf("wg_fft14_2s against a host FFT: max error %.3e, bins off by more than 1e-9: %d (first %d)\n", md, nbad, firstbad);
+        CK(hipFuncSetAttribute((const void *)k_fft_test6, hipFuncAttributeMaxDynamicSharedMemorySize, C6_XCH * 8));
+        hipLaunchKernelGGL(k_fft_test6, dim3(1), dim3(C2_THREADS), C6_XCH * 8, 0, (const double2 *)dx, dX, (const double2 *)tw);
+        CK(hipDeviceSynchronize()); CK(hipGetLastError());
+        CK(hipMemcpy(hX.data(), dX, N * 16, hipMemcpyDeviceToHost));
+        double md6 = 0; int nbad6 = 0;
+        for (int i = 0; i < N; i++) { const double d = fmax(fabs(hX[i].x - re[i]), fabs(hX[i].y - im[i])); md6 = fmax(md6, d); if (d > 1e-9) nbad6++; }
+        printf("wg_fft14_e32 against a host FFT: max error %.3e, bins off by more than 1e-9: %d\n", md6, nbad6);
         if (nbad) { for (int i = 0, k = 0; i < N && k < 24; i++) if (fmax(fabs(hX[i].x - re[i]), fabs(hX[i].y - im[i])) > 1e-9) { printf(" %d", i); k++; } printf("\n"); }
     }
     const int grid = nch < ncu ? nch : ncu;
@@ -146,16 +168,17 @@ int main(int argc, char **argv)
     {
         hipLaunchKernelGGL(k_coarse4, dim3(grid), dim3(C2_THREADS), lds4, 0, g, ptrs(0), (const int *)nullptr, nch, (const double2 *)tw);
         hipLaunchKernelGGL(k_coarse5, dim3(grid), dim3(C2_THREADS), lds5, 0, g, ptrs(1), (const int *)nullptr, nch, (const double2 *)tw);
+        hipLaunchKernelGGL(k_coarse6, dim3(grid), dim3(C2_THREADS), lds6, 0, g, ptrs(2), (const int *)nullptr, nch, (const double2 *)tw);
     }
     CK(hipDeviceSynchronize()); CK(hipGetLastError());
     {
         const int ncheck = nch < 512 ? nch : 512;
-        std::vector<double> y0((size_t)N), y1((size_t)N), l0((size_t)g.log_cap * 6), l1((size_t)g.log_cap * 6);
-        double maxd = 0; int badbin = 0, nrow = 0;
+        std::vector<double> y0((size_t)N), y1((size_t)N), y2((size_t)N), l0((size_t)g.log_cap * 6), l1((size_t)g.log_cap * 6), l2((size_t)g.log_cap * 6);
+        double maxd = 0, maxd6 = 0; int badbin = 0, badbin6 = 0, nrow = 0;
         for (int k = 0; k < ncheck; k++)
         {
             const int c = (int)(((long long)k * (nch - 1)) / (ncheck > 1 ? ncheck - 1 : 1));
-            CK(hipMemcpy(y0.data(), sd[0].y + (size_t)c * N, N * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(y1.data(), sd[1].y + (size_t)c * N, N * 8, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(y0.data(), sd[0].y + (size_t)c * N, N * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(y1.data(), sd[1].y + (size_t)c * N, N * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(y2.data(), sd[2].y + (size_t)c * N, N * 8, hipMemcpyDeviceToHost));
             // the band-limited signal's square occupies |k| < 2 startbin; the bins beyond hold the transform's round-off (~1e-16 of the
             // lines' power) and are never read by the fold (|k| <= startbin + expectedpeakbin + 1): compared inside the support only
             const int hw = 2 * (int)lround((10500.0 - 500.0 * (c % 3)) / (48000.0 / N)) - 8;
@@ -164,17 +187,22 @@ int main(int argc, char **argv)
             {
                 const int k = i ^ (N / 2), H = (k >> 1) & 1, sl = k >> 10, tt = (((k >> 2) & 255) << 1) | (k & 1);
                 maxd = fmax(maxd, fabs(y0[i] - y1[(H * 16 + sl) * 512 + tt]));
+                maxd6 = fmax(maxd6, fabs(y0[i] - y2[i]));
             }
             CK(hipMemcpy(l0.data(), sd[0].slog + (size_t)c * g.log_cap * 6, l0.size() * 8, hipMemcpyDeviceToHost));
             CK(hipMemcpy(l1.data(), sd[1].slog + (size_t)c * g.log_cap * 6, l1.size() * 8, hipMemcpyDeviceToHost));
-            for (int r = 0; r < 3; r++) { nrow++; if (l0[r * 6 + 1] != l1[r * 6 + 1] || l0[r * 6 + 0] != l1[r * 6 + 0]) badbin++; }
+            CK(hipMemcpy(l2.data(), sd[2].slog + (size_t)c * g.log_cap * 6, l2.size() * 8, hipMemcpyDeviceToHost));
+            for (int r = 0; r < 3; r++) { nrow++; if (l0[r * 6 + 1] != l1[r * 6 + 1] || l0[r * 6 + 0] != l1[r * 6 + 0]) badbin++; if (l0[r * 6 + 1] != l2[r * 6 + 1] || l0[r * 6 + 0] != l2[r * 6 + 0]) badbin6++; }
             if (k < 3) printf("  channel %d: estimates (m2_freq) k_coarse4 %.4f %.4f %.4f | k_coarse5 %.4f %.4f %.4f\n", c, l0[1], l0[7], l0[13], l1[1], l1[7], l1[13]);
         }
         printf("parity over %d channels x 3 estimates: max |y4 - y5| inside the signal's support = %.3e, status rows that differ: %d of %d  -> %s\n", ncheck, maxd, badbin, nrow,
                (maxd < 1e-9 && badbin == 0) ? "OK" : "MISMATCH");
+        printf("k_coarse6 against k_coarse4: max |y4 - y6| inside the support = %.3e, status rows that differ: %d of %d  -> %s\n", maxd6, badbin6, nrow, (maxd6 < 1e-9 && badbin6 == 0) ? "OK" : "MISMATCH");
     }
     timeit("k_coarse4", [&] { hipLaunchKernelGGL(k_coarse4, dim3(grid), dim3(C2_THREADS), lds4, 0, g, ptrs(0), (const int *)nullptr, nch, (const double2 *)tw); }, nl);
     timeit("k_coarse5", [&] { hipLaunchKernelGGL(k_coarse5, dim3(grid), dim3(C2_THREADS), lds5, 0, g, ptrs(1), (const int *)nullptr, nch, (const double2 *)tw); }, nl);
+    timeit("k_coarse6 (32 x 32 x 16)", [&] { hipLaunchKernelGGL(k_coarse6, dim3(grid), dim3(C2_THREADS), lds6, 0, g, ptrs(2), (const int *)nullptr, nch, (const double2 *)tw); }, nl);
+    timeit("k_coarse6_w8400", [&] { hipLaunchKernelGGL(k_coarse6_w8400, dim3(grid), dim3(C2_THREADS), lds6 + C4_TABN * 8, 0, g, ptrs(2), (const int *)nullptr, nch, (const double2 *)tw); }, nl);
     timeit("k_coarse5 no ring/y traffic", [&] { hipLaunchKernelGGL(k5_abl<1>, dim3(grid), dim3(C2_THREADS), lds5, 0, g, ptrs(1), (const int *)nullptr, nch, (const double2 *)tw); }, nl);
     timeit("k_coarse5 no transforms", [&] { hipLaunchKernelGGL(k5_abl<2>, dim3(grid), dim3(C2_THREADS), lds5, 0, g, ptrs(1), (const int *)nullptr, nch, (const double2 *)tw); }, nl);
     timeit("k_coarse5 neither (log10, fold, slot)", [&] { hipLaunchKernelGGL(k5_abl<3>, dim3(grid), dim3(C2_THREADS), lds5, 0, g, ptrs(1), (const int *)nullptr, nch, (const double2 *)tw); }, nl);
@@ -184,6 +212,7 @@ int main(int argc, char **argv)
     timeit("k_coarse4_w8400", [&] { hipLaunchKernelGGL(k_coarse4_w8400, dim3(grid), dim3(C2_THREADS), lds4 + C4_TABN * 8, 0, g, ptrs(0), (const int *)nullptr, nch, (const double2 *)tw); }, nl);
     timeit("k_coarse5_w8400", [&] { hipLaunchKernelGGL(k_coarse5_w8400, dim3(grid), dim3(C2_THREADS), lds5 + C4_TABN * 8, 0, g, ptrs(1), (const int *)nullptr, nch, (const double2 *)tw); }, nl);
     timeit("k_coarse4 (again)", [&] { hipLaunchKernelGGL(k_coarse4, dim3(grid), dim3(C2_THREADS), lds4, 0, g, ptrs(0), (const int *)nullptr, nch, (const double2 *)tw); }, nl);
+    timeit("k_coarse6 (again)", [&] { hipLaunchKernelGGL(k_coarse6, dim3(grid), dim3(C2_THREADS), lds6, 0, g, ptrs(2), (const int *)nullptr, nch, (const double2 *)tw); }, nl);
     timeit("k_coarse5 (again)", [&] { hipLaunchKernelGGL(k_coarse5, dim3(grid), dim3(C2_THREADS), lds5, 0, g, ptrs(1), (const int *)nullptr, nch, (const double2 *)tw); }, nl);
     return 0;
 }

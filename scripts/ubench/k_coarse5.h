@@ -19,12 +19,14 @@
 // every 64 B; y: 2 x 16 B of every 32 B), issued back to back.  Index maps, twiddles and LDS bank behaviour are pinned by the CPU model
 // tests/test_coarse_fft14_model.py.
 #pragma once
-#include "k_coarse2.h"
+#include "../../jaero_amd/csrc/k_coarse2.h"
 
 #ifndef C5_MIX
 #define C5_MIX 0 // experiment: one LDS instruction after every few VALU instructions (sched_group_barrier) -- measured, no gain
 #endif
+#ifndef C4_TABN
 #define C4_TABN 3584 // W8400: window table entries kept in LDS behind the exchange buffer (28 KiB): lockingbw < 10.49 kHz
+#endif
 #define C5_PLANE 8224                    // doubles per plane buffer (exchange 2 needs 31*257 + 256 = 8223)
 #define C5_XCH (2 * C5_PLANE)            // 16448 doubles = 131 584 B: r plane of a stream in [0, 8224), i plane behind it
 

@@ -1,0 +1,89 @@
+"""CPU model of the 32 x 32 x 16 workgroup transform of k_coarse6 (jaero_amd/csrc/k_coarse6.h: wg_fft14_e32): two LDS exchanges per
+2^14-point transform instead of three.  n = 512 n1 + 16 n2 + n3, k = k1 + 32 k2 + 1024 k3; natural distribution on entry and exit (slot =
+index >> 9, thread = index & 511).  A 32-point register FFT leaves its outputs in SPLIT order (slot j < 16 holds X[2j], slot 16 + j holds
+X[2j + 1]: one radix-2 stage, then a 16-point FFT on each half in place), which only changes the compile-time addresses of the next
+exchange.  Checked: the maps are permutations, the model equals numpy's FFT, every wavefront access is conflict-free: a 64-bit LDS access
+is served 16 lanes at a time from 16 eight-byte bank pairs, so every group of 16 consecutive lanes must touch 16 addresses that differ
+modulo 16 (the rule SQ_LDS_BANK_CONFLICT confirmed on an MI355X: a first version that only satisfied a 32-lane / 32-bank rule, with row
+stride 514 in exchange 2, counted 403 M conflict cycles per launch)."""
+import numpy as np
+
+N = 16384
+T = np.arange(512)
+TW = np.exp(-2j * np.pi * np.arange(N) / N)
+XLEN = 16448
+
+
+def K(s):
+    """index held by slot s after a split-order 32-point FFT"""
+    return 2 * s if s < 16 else 2 * (s - 16) + 1
+
+
+def fft32_split(d):
+    o = np.fft.fft(d, axis=1)
+    return np.stack([o[:, K(s)] for s in range(32)], axis=1)
+
+
+def ex1_write(s):   # pass-1 thread t = n & 511 = 16 n2 + n3 holds k1 = K(s); odd k1 rows are rotated by one n2 row (16 doubles)
+    k1 = K(s)
+    return k1 * 512 + ((T + 16 * (k1 & 1)) & 511)
+
+
+def ex1_read(m):    # pass-2 thread (k1 = t >> 4, n3 = t & 15) wants slot n2 = m: compile-time offset 16 m from a per-thread base (one wrap)
+    k1, n3 = T >> 4, T & 15
+    return k1 * 512 + ((m + (k1 & 1)) & 31) * 16 + n3
+
+
+def ex2_write(s):   # pass-2 thread (k1, n3) holds k2 = K(s)
+    k1, n3, k2 = T >> 4, T & 15, K(s)
+    return (k2 & 15) * 32 + k1 + n3 * 513 + (k2 >> 4) * 8208
+
+
+def ex2_read(n3, k2hi):   # pass-3 thread t = k & 511 = (k2 & 15) * 32 + k1
+    return T + n3 * 513 + k2hi * 8208
+
+
+def model_fft(x):
+    d = x.reshape(32, 512).T.copy()                               # d[t, slot] = x[slot*512 + t]
+    o = fft32_split(d)
+    o = o * np.stack([TW[T] ** K(s) for s in range(32)], axis=1)  # W_N^(k1 (n mod 512))
+    L = np.full(N, np.nan, complex)
+    for s in range(32):
+        L[ex1_write(s)] = o[:, s]
+    d2 = np.stack([L[ex1_read(m)] for m in range(32)], axis=1)
+    o = fft32_split(d2)
+    o = o * np.stack([TW[32 * (T & 15)] ** K(s) for s in range(32)], axis=1)   # W_512^(k2 n3)
+    L = np.full(XLEN, np.nan, complex)
+    for s in range(32):
+        L[ex2_write(s)] = o[:, s]
+    out = np.zeros((512, 32), complex)
+    for k2hi in range(2):
+        d3 = np.stack([L[ex2_read(n3, k2hi)] for n3 in range(16)], axis=1)
+        o3 = np.fft.fft(d3, axis=1)
+        for k3 in range(16):
+            out[:, 2 * k3 + k2hi] = o3[:, k3]
+    return out.T.reshape(N)                                       # out[t, slot] = X[slot*512 + t]
+
+
+def test_maps_are_permutations():
+    assert sorted(np.concatenate([ex1_write(s) for s in range(32)])) == list(range(N))
+    assert sorted(np.concatenate([ex1_read(m) for m in range(32)])) == list(range(N))
+    w = np.concatenate([ex2_write(s) for s in range(32)])
+    r = np.concatenate([ex2_read(n3, h) for n3 in range(16) for h in range(2)])
+    assert len(set(w.tolist())) == N and sorted(w) == sorted(r) and w.max() < XLEN
+
+
+def test_transform_is_natural_in_natural_out():
+    rng = np.random.default_rng(32)
+    x = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    assert np.max(np.abs(model_fft(x) - np.fft.fft(x))) < 1e-8
+
+
+def test_lds_accesses_are_conflict_free():
+    maps = [(f"ex1_write{s}", ex1_write(s)) for s in range(32)] + [(f"ex1_read{m}", ex1_read(m)) for m in range(32)]
+    maps += [(f"ex2_write{s}", ex2_write(s)) for s in range(32)] + [(f"ex2_read{n3}{h}", ex2_read(n3, h)) for n3 in range(16) for h in range(2)]
+    for name, a in maps:
+        for w in range(8):
+            addr = a[64 * w:64 * w + 64]
+            for q in range(4):
+                assert len(set((addr[16 * q:16 * q + 16] % 16).tolist())) == 16, (name, w, q)

@@ -1,13 +1,13 @@
-"""CPU model of the two-stream 2^14-point workgroup transform of the coarse-frequency kernel (jaero_amd/csrc/k_coarse5.h: wg_fft14_2s).
+"""CPU model of the two-stream 2^14-point workgroup transform of the coarse-frequency kernel (scripts/ubench/k_coarse5.h: wg_fft14_2s).
 
 The kernel only runs on the GPU (every bank test compares its estimates with the oracle's); what can be pinned without one is its index
 arithmetic: 16384 = 16 x 16 x 16 x 4 (decimation in frequency), n = n1*1024 + n2*64 + n3*4 + 2h + q, k = k1 + 16 k2 + 256 k3 + 4096 k4.
 The bit h (bit 1 of the index) is passive in passes 1-3, so the 32 points a thread holds are two independent STREAMS of 16 (h = 0, 1)
-until the last pass; while one stream's values travel through LDS the other stream's 16-point FFT runs (k_coarse5.h).  Distribution D*
+until the last pass; while one stream's values travel through LDS the other stream's 16-point FFT runs (scripts/ubench/k_coarse5.h; the product kernel is k_coarse6.h, modelled in test_coarse_fft14_e32_model.py).  Distribution D*
 (the same on entry and on exit, so three transforms chain register to register): element e sits in stream e1 (bit 1), slot e >> 10,
 thread ((e >> 2) & 255) << 1 | (e & 1).  Checked here: (i) the three exchange maps are permutations of their buffer; (ii) with the
 twiddles of the kernel the model equals numpy's FFT, D* in and D* out; (iii) every LDS access of a wavefront is conflict-free (64-bit
-accesses are served half a wavefront at a time from 32 eight-byte banks) -- most are 64 consecutive doubles."""
+accesses are served 16 lanes at a time from 16 eight-byte bank pairs) -- most are 64 consecutive doubles."""
 import numpy as np
 
 N = 16384
@@ -138,7 +138,7 @@ def test_lds_accesses_are_conflict_free():
             a = fn(s)
             for w in range(8):
                 addr = a[64 * w:64 * w + 64]
-                for half in (addr[:32], addr[32:]):
-                    assert len(set((half % 32).tolist())) == 32, (name, s, w)
+                for q in range(4):  # served 16 lanes at a time from 16 eight-byte bank pairs (SQ_LDS_BANK_CONFLICT agrees: tests/test_coarse_fft14_e32_model.py)
+                    assert len(set((addr[16 * q:16 * q + 16] % 16).tolist())) == 16, (name, s, w, q)
                 if name not in ("ex2_write", "ex1_read"):
                     assert sorted(addr.tolist()) == list(range(addr.min(), addr.min() + 64)), (name, s, w)
