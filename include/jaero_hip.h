@@ -122,9 +122,16 @@ int jaero_create(int device, int nchannels, const jaero_settings *settings, int 
                  unsigned flags, int max_write_samples, int softbit_capacity, jaero_ctx **out);
 void jaero_destroy(jaero_ctx *ctx);
 
-/* setSettings on a live channel (channel = -1: every channel), enqueued on the stream of the bank's last jaero_write: the channel's state
- * becomes what the reference's setSettings leaves behind.  kind, fb, Fs and the FFT power are fixed per bank (JAERO_EINVAL if they differ);
- * burst banks and 8400 bps banks take no live setSettings (JAERO_ENOTSUP): create a new bank (the Qt adaptors of integration/qt do). */
+/* setSettings on a live channel (channel = -1: every channel): the channel's state becomes what the reference's setSettings leaves behind
+ * (JAERO/oqpskdemodulator.cpp:175-289, JAERO/mskdemodulator.cpp:135-263).
+ *   - freq_center / lockingbw / signalthreshold of one or all channels: in place, enqueued on the stream of the bank's last jaero_write.
+ *   - fb, Fs or the FFT power (shared by the channels of a bank), and any setSettings of an 8400 bps bank (its prefilter restarts): whole bank
+ *     only (channel = -1, or a one-channel bank).  The bank is re-created behind the handle and receives what the reference keeps in the old
+ *     object: oscillator phases, loop-filter / rotator / timing states, the symbol-rate windows (MSK: msema, the first entries of dt and
+ *     delayedsmpl in buffer order), the EbNo meter of the OQPSK kind, the coarse ring and the smoothed spectrum, flags, unread outputs.
+ *     Control plane: allocates and synchronises the device; pointers from the *_view calls are stale afterwards.  An OQPSK bank keeps Fs.
+ *   - JAERO_EINVAL: another kind (another class in the reference), or fb / Fs / FFT power for one channel of several;
+ *     JAERO_ENOTSUP: burst banks (create a new bank; the Qt adaptors of integration/qt do), one channel of an 8400 bps bank. */
 int jaero_set_settings(jaero_ctx *ctx, int channel, const jaero_settings *s);
 int jaero_set_flags(jaero_ctx *ctx, int channel, int afc, int sql, int cpu_reduce);
 int jaero_set_dcd(jaero_ctx *ctx, int channel, int dcd);

@@ -91,22 +91,13 @@ protected:
             pushFlags();
             jaero_set_dcd(ctx, -1, dcd);
         }
-        else if (js.kind != cur.kind || js.fb != cur.fb || js.Fs != cur.Fs || js.coarsefreqest_fft_power != cur.coarsefreqest_fft_power)
-        {
-            // a change of rate / kind / FFT size: the reference's setSettings rebuilds every filter, delay line and window, i.e. starts a new
-            // demodulator in the old object; a bank fixes those per bank, so the one-channel bank is replaced.  Soft bits that did not fill
-            // a group yet stay in `pending`, as RxDataBits survives setSettings there.
-            jaero_destroy(ctx);
-            ctx = nullptr;
-            applySettings(js);
-            return;
-        }
         else if (jaero_set_settings(ctx, 0, &js) != JAERO_OK)
         {
-            // what a live bank cannot take (8400 bps: the prefilter would have to restart for one channel): replace the bank
-            jaero_destroy(ctx);
-            ctx = nullptr;
-            applySettings(js);
+            // A change of rate / sample rate / FFT size (and any setSettings at 8400 bps) re-creates the one-channel bank behind the handle
+            // with what the reference's setSettings keeps in the old object -- oscillator phases, loop states, symbol-rate windows, coarse
+            // ring and spectrum (jaero_hip.h).  Soft bits that did not fill a group yet stay in `pending`, as RxDataBits survives there.
+            // What is left to fail: bad settings, out of memory.
+            emit WarningTextSignal(QString("libjaero_hip: %1").arg(jaero_last_error()));
             return;
         }
         cur = js;

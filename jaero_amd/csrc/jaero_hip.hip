@@ -141,6 +141,7 @@ struct jaero_ctx
     JPtrs p{};
     unsigned flags = 0;
     int max_write = 0;
+    int soft_cap_req = 0; // softbit_capacity as given to jaero_create (0 = default for the rate): a re-created bank asks for the same
     std::vector<void *> allocs;
     // device helpers
     int16_t *d_pcm_frames = nullptr; // [max_write][nchp] staging for channel-major / host input
@@ -540,6 +541,7 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
     c->device = device;
     c->flags = flags;
     c->max_write = max_write_samples;
+    c->soft_cap_req = softbit_capacity;
     if (s0.kind >= JAERO_KIND_BURST_MSK)
     {
         std::vector<jaero_settings> all(nchannels);
@@ -850,25 +852,13 @@ __global__ void k_apply_settings(const JGeom g, const JPtrs p, int ch_lo, const 
     }
 }
 
-extern "C" int jaero_set_settings(jaero_ctx *c, int channel, const jaero_settings *s)
+// setSettings on the channels [lo, hi) of a bank whose kind, rates and FFT size stay what they are: only those channels' columns are touched,
+// by one small kernel on the stream of the last jaero_write (no device synchronisation, no copy of the bank's state)
+static int apply_live_settings(jaero_ctx *c, int lo, int hi, const jaero_settings *s)
 {
-    // setSettings on a live object (oqpskdemodulator.cpp:175-289, mskdemodulator.cpp:135-263): retunes the mixers
-    // (phase kept), recreates AGC / matched filters / timing delays / resonator, restarts the coarse ring pointer.
-    // Only the addressed channels' columns are touched, by one small kernel on the stream of the last jaero_write: no device
-    // synchronisation, no copy of the bank's state.
-    if (!c || !s || channel < -1 || channel >= c->o_nch) return fail(JAERO_EINVAL, "jaero_set_settings: bad arguments");
-    if (c->burst) return fail(JAERO_ENOTSUP, "jaero_set_settings on a live burst bank is not implemented; create a new bank");
-    // fb = 8400: the reference's setSettings also re-creates the prefilter (JFastFir::SetKernel: empty history, 2048 zeros of latency, transform
-    // blocks re-aligned to that moment), which k_pre8400_fft's bank-wide block alignment cannot do for one channel
-    if (c->pre8400) return fail(JAERO_ENOTSUP, "jaero_set_settings on a live 8400 bps bank is not implemented; create a new bank");
-    int rc = validate_settings(*s);
-    if (rc) return rc;
     const JGeom &g = c->g;
-    if (s->kind != g.kind || s->fb != g.fb || s->Fs != g.Fs || s->coarsefreqest_fft_power != g.nfft_log2)
-        return fail(JAERO_EINVAL, "jaero_set_settings: kind/fb/Fs/fft_power are fixed per bank; create a new bank to change them");
     HIPCHK(hipSetDevice(c->device));
     const int nchp = g.nchp;
-    const int lo = channel < 0 ? 0 : channel, hi = channel < 0 ? g.nch : channel + 1;
     // what init_channel_scalars(fresh = false) writes, computed once (the same for every addressed channel) on a one-column scratch
     std::vector<double> S((size_t)S_NFIELDS, 0.0);
     std::vector<int> I((size_t)I_NFIELDS, 0);
@@ -913,6 +903,133 @@ extern "C" int jaero_set_settings(jaero_ctx *c, int channel, const jaero_setting
     else hipLaunchKernelGGL(k_apply_settings, dim3(hi - lo, ny), dim3(256), 0, c->last_stream, g, c->p, lo, v);
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+// k_carry_dly: MSK delayedsmpl.setLength(SamplesPerSymbol) keeps the buffer's first min(old, new) entries IN BUFFER ORDER and restarts the
+// pointer at 0 (DSP.h:446-453).  Buffer index j of channel ch lives in the old bank's shared slot (t0[ch] + j) mod Lo (t0 = the shared slot at
+// which the channel's pointer last restarted) and in slot j of the new bank, whose shared slot counter starts at 0.
+__global__ void k_carry_dly(const double2 *__restrict__ od, int Lo, const int *__restrict__ t0, double2 *__restrict__ nd, int Ln, int nchp)
+{
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= nchp) return;
+    const int grp = ch >> 6, lane = ch & 63, keep = Lo < Ln ? Lo : Ln, s0 = t0[ch];
+    for (int j = 0; j < keep; j++) nd[((size_t)grp * Ln + j) * 64 + lane] = od[((size_t)grp * Lo + (s0 + j) % Lo) * 64 + lane];
+}
+
+// setSettings that changes what a bank fixes (bit rate, sample rate, FFT size; any setSettings of an 8400 bps bank, whose prefilter restarts):
+// the reference rebuilds AGC, matched filters, delays, resonator (and at 8400 bps the prefilter) INSIDE the old object, which keeps its oscillator
+// phases, loop-filter and rotator states, moving-average windows, the coarse ring's contents and the smoothed spectrum (oqpskdemodulator.cpp:
+// 175-289, mskdemodulator.cpp:135-263).  Here: a sibling bank is created for the new settings, those survivors are copied into it, the same
+// in-place setSettings as above runs on it, and it takes the place of the old bank behind the handle.  Whole banks only; control plane (it
+// allocates and synchronises).  Outputs not read yet move along; device pointers obtained from the views are stale.
+static int rebank_with_carry_over(jaero_ctx *c, const jaero_settings *s)
+{
+    const JGeom og = c->g;
+    if (og.kind == JAERO_KIND_OQPSK && s->Fs != og.Fs) return fail(JAERO_ENOTSUP, "jaero_set_settings: an OQPSK bank keeps its sample rate");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->last_stream));
+    jaero_ctx *n = nullptr;
+    int rc = jaero_create(c->device, og.nch, s, 0, c->flags, c->max_write, c->soft_cap_req, &n);
+    if (rc) return rc;
+    const JGeom &ng = n->g;
+    const int nchp = og.nchp;
+    auto fin = [&](int code) { jaero_destroy(n); return code; };
+#define CP(dst, src, bytes) do { if (hipMemcpy((dst), (src), (bytes), hipMemcpyDeviceToDevice) != hipSuccess) return fin(fail(JAERO_EHIP, "jaero_set_settings: carry-over copy failed")); } while (0)
+#define CP2(dst, dpitch, src, spitch, width, rows) do { if (hipMemcpy2D((dst), (dpitch), (src), (spitch), (width), (rows), hipMemcpyDeviceToDevice) != hipSuccess) return fin(fail(JAERO_EHIP, "jaero_set_settings: carry-over copy failed")); } while (0)
+    CP(n->p.S, c->p.S, sizeof(double) * (size_t)S_NFIELDS * nchp);
+    CP(n->p.I, c->p.I, sizeof(int) * (size_t)I_NFIELDS * nchp);
+    {
+        // outputs not read yet (soft bits, captured symbols, status rows) move to the new bank's buffers; its capacities follow the new rate
+        std::vector<int> cnt(3 * (size_t)nchp);
+        static_assert(I_SYM_CNT == I_SOFT_CNT + 1 && I_LOG_CNT == I_SOFT_CNT + 2, "output counters are consecutive columns");
+        if (hipMemcpy(cnt.data(), c->p.I + (size_t)I_SOFT_CNT * nchp, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost) != hipSuccess) return fin(fail(JAERO_EHIP, "jaero_set_settings: reading the output counters failed"));
+        int mx[3] = {0, 0, 0};
+        for (int k = 0; k < 3; k++) for (int ch = 0; ch < og.nch; ch++) mx[k] = cnt[(size_t)k * nchp + ch] > mx[k] ? cnt[(size_t)k * nchp + ch] : mx[k];
+        if (mx[0] > ng.soft_cap || mx[1] > ng.sym_cap || mx[2] > ng.log_cap)
+            return fin(fail(JAERO_EINVAL, "jaero_set_settings: unread outputs (%d soft bits, %d symbols, %d status rows) exceed the new bank's buffers; read them first", mx[0], mx[1], mx[2]));
+        if (mx[0]) CP2(n->p.soft, sizeof(int16_t) * ng.soft_cap, c->p.soft, sizeof(int16_t) * og.soft_cap, sizeof(int16_t) * mx[0], (size_t)nchp);
+        if (mx[1]) CP2(n->p.sym, sizeof(double) * 3 * ng.sym_cap, c->p.sym, sizeof(double) * 3 * og.sym_cap, sizeof(double) * 3 * mx[1], (size_t)nchp);
+        if (mx[2]) CP2(n->p.slog, sizeof(double) * 6 * ng.log_cap, c->p.slog, sizeof(double) * 6 * og.log_cap, sizeof(double) * 6 * mx[2], (size_t)nchp);
+    }
+    // windows that survive: msema (both kinds); marg / dt / pm of the OQPSK demodulator (MSK: marg is new, dt keeps a prefix, below)
+    CP(n->p.msema, c->p.msema, sizeof(double) * (size_t)nchp * og.msema_len);
+    if (og.kind == JAERO_KIND_OQPSK)
+    {
+        CP(n->p.marg, c->p.marg, sizeof(double) * (size_t)nchp * og.marg_len);
+        CP(n->p.dt, c->p.dt, sizeof(double2) * (size_t)nchp * og.dt_len);
+        CP(n->p.pm, c->p.pm, sizeof(double) * (size_t)nchp * og.pm_len);
+        if (c->p.symrec && n->p.symrec) CP(n->p.symrec, c->p.symrec, sizeof(double) * (size_t)nchp * JD_SYMREC_LEN * 8); // k_oqpsk_fb keeps the four windows in one record ring
+        if (c->p.eb_e && n->p.eb_e) // the OQPSK EbNo meter is only told the new rates (setup_update, DSP.cpp:723-727)
+        {
+            CP(n->p.eb_e, c->p.eb_e, sizeof(double) * (size_t)og.ngroups * og.ebno_len * 64);
+            CP(n->p.eb_e2, c->p.eb_e2, sizeof(double) * (size_t)og.ngroups * og.ebno_len * 64);
+        }
+    }
+    else
+    {
+        const int keep = og.dt_len < ng.dt_len ? og.dt_len : ng.dt_len; // dt.setLength: DelayThing keeps the first entries (DSP.h:446-453)
+        CP2(n->p.dt, sizeof(double2) * ng.dt_len, c->p.dt, sizeof(double2) * og.dt_len, sizeof(double2) * keep, (size_t)nchp);
+        CP(n->p.pm, c->p.pm, sizeof(double) * (size_t)nchp * (og.pm_len < ng.pm_len ? og.pm_len : ng.pm_len));
+        int *d_t0 = nullptr;
+        if (c->dly_t0.empty()) c->dly_t0.assign(nchp, 0);
+        if (hipMalloc(&d_t0, sizeof(int) * nchp) != hipSuccess) return fin(fail(JAERO_ENOMEM, "jaero_set_settings: out of device memory"));
+        hipMemcpy(d_t0, c->dly_t0.data(), sizeof(int) * nchp, hipMemcpyHostToDevice);
+        // the old bank's shared slot counter stands at nB_total: a channel whose pointer restarted at slot t0 has its buffer index 0 there
+        hipLaunchKernelGGL(k_carry_dly, dim3((nchp + 255) / 256), dim3(256), 0, 0, (const double2 *)c->p.dly, og.sps + 1, (const int *)d_t0, (double2 *)n->p.dly, ng.sps + 1, nchp);
+        hipDeviceSynchronize();
+        hipFree(d_t0);
+    }
+    {
+        // bbcycbuff.resize / y.resize: same size = untouched, otherwise the first entries stay (new ones are zero)
+        const int keep = og.nfft < ng.nfft ? og.nfft : ng.nfft;
+        CP2(n->p.bbring, sizeof(double2) * ng.nfft, c->p.bbring, sizeof(double2) * og.nfft, sizeof(double2) * keep, (size_t)nchp);
+        CP2(n->p.y, sizeof(double) * ng.nfft, c->p.y, sizeof(double) * og.nfft, sizeof(double) * keep, (size_t)nchp);
+    }
+    if (og.kind == JAERO_KIND_OQPSK)
+    {
+        // mixer_fir_pre is not touched by setSettings: its phase stays.  Its frequency is set at the end of every write to mixer2_freq_sum / i
+        // (oqpskdemodulator.cpp:607-608; applied here by k_pre8400_mix at the start of the next write from S_PRE_FSUM / nprev), and that sum
+        // only grows in the 8400 bps branch (:447): after a write at another rate the reference's prefilter oscillator stands at 0 Hz, which
+        // is what its first 8400 bps write then mixes with.  Same here: sum 0 over the length of the last write.
+        n->pre_nprev = c->pre_nprev;
+        if (!c->pre8400 && hipMemset(n->p.S + (size_t)S_PRE_FSUM * nchp, 0, sizeof(double) * (size_t)nchp) != hipSuccess) return fin(fail(JAERO_EHIP, "memset"));
+    }
+#undef CP
+#undef CP2
+    n->m.flags = c->m.flags;
+    n->prof = c->prof;
+    if ((rc = apply_live_settings(n, 0, ng.nchp, s))) return fin(rc); // the padding lanes too: their window positions came over with I and must fit the new lengths
+    if (hipDeviceSynchronize() != hipSuccess) return fin(fail(JAERO_EHIP, "jaero_set_settings: carry-over failed"));
+    std::swap(*c, *n);
+    jaero_destroy(n); // the old bank
+    return 0;
+}
+
+extern "C" int jaero_set_settings(jaero_ctx *c, int channel, const jaero_settings *s)
+{
+    // setSettings on a live object (oqpskdemodulator.cpp:175-289, mskdemodulator.cpp:135-263): retunes the mixers
+    // (phase kept), recreates AGC / matched filters / timing delays / resonator, restarts the coarse ring pointer.
+    if (!c || !s || channel < -1 || channel >= c->o_nch) return fail(JAERO_EINVAL, "jaero_set_settings: bad arguments");
+    if (c->burst) return fail(JAERO_ENOTSUP, "jaero_set_settings on a live burst bank is not implemented; create a new bank");
+    int rc = validate_settings(*s);
+    if (rc) return rc;
+    const JGeom &g = c->g;
+    if (s->kind != g.kind) return fail(JAERO_EINVAL, "jaero_set_settings: the kind of a bank is fixed (another demodulator class in the reference); create a new bank");
+    const bool whole = channel < 0 || g.nch == 1;
+    if (s->fb != g.fb || s->Fs != g.Fs || s->coarsefreqest_fft_power != g.nfft_log2)
+    {
+        if (!whole) return fail(JAERO_EINVAL, "jaero_set_settings: fb/Fs/fft_power are shared by the channels of a bank; change them for the whole bank (channel = -1)");
+        return rebank_with_carry_over(c, s);
+    }
+    if (c->pre8400)
+    {
+        // fb = 8400: setSettings also re-creates the prefilter (JFastFir::SetKernel: empty history, 2048 zeros of latency, transform blocks
+        // re-aligned to that moment), which k_pre8400_fft's bank-wide block alignment cannot do for one channel of several
+        if (!whole) return fail(JAERO_ENOTSUP, "jaero_set_settings on one channel of a live 8400 bps bank is not implemented (the prefilter restarts bank-wide): use channel = -1");
+        return rebank_with_carry_over(c, s);
+    }
+    HIPCHK(hipSetDevice(c->device));
+    return apply_live_settings(c, channel < 0 ? 0 : channel, channel < 0 ? g.nch : channel + 1, s);
 }
 
 // ------------------------------------------------------------------------------------------ profiling helpers
@@ -1114,8 +1231,8 @@ extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int l
         launch_pre8400_filter(g, c->p, c->pre, nsamples, c->pre_n0, c->pre_direct, st);
         LAUNCHCHK("the 8400 bps prefilter");
         c->pre_n0 += nsamples;
-        c->pre_nprev = nsamples;
     }
+    if (g.kind == JAERO_KIND_OQPSK) c->pre_nprev = nsamples; // (at every rate: a bank re-created for 8400 bps needs the length of the last write, rebank_with_carry_over)
     int pos = 0;
     while (pos < nsamples)
     {

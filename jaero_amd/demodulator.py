@@ -122,8 +122,12 @@ class DemodulatorBank:
 
     # ---- control surface (channel=-1: all) ----
     def set_settings(self, settings, channel: int = -1):
+        """setSettings on live channels.  A change of fb / Fs / FFT power (whole bank only) re-creates the bank behind the handle with the
+        state the reference's setSettings keeps (jaero_hip.h)."""
         s = settings.to_c()
         capi.check(self.L.jaero_set_settings(self.h, channel, C.byref(s)))
+        if channel < 0 or self.nch == 1:
+            self.fb, self.Fs = s.fb, s.Fs
 
     def set_flags(self, afc=False, sql=False, cpu_reduce=False, channel: int = -1):
         capi.check(self.L.jaero_set_flags(self.h, channel, int(afc), int(sql), int(cpu_reduce)))

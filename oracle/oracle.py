@@ -231,9 +231,11 @@ class Demod:
 
 
 def run_demod(settings: Settings, pcm: np.ndarray, chunk=4096, afc=False, cpu_reduce=False,
-              dcd_at: int = -1, capture_symbols=False, center_at: int = -1, center_hz: float = 0.0):
+              dcd_at: int = -1, capture_symbols=False, center_at: int = -1, center_hz: float = 0.0,
+              set_at: int = -1, set_settings: Settings = None):
     """Convenience: feed pcm in `chunk`-sample writes (an int, or the list of successive write sizes),
-    return dict(soft, status[, symbols])."""
+    return dict(soft, status[, symbols]).  set_at / set_settings: setSettings on the live object before the write that starts at or
+    after that sample."""
     d = Demod(settings, afc=afc, cpu_reduce=cpu_reduce, capture_symbols=capture_symbols)
     n = pcm.shape[0]
     s = 0
@@ -249,6 +251,9 @@ def run_demod(settings: Settings, pcm: np.ndarray, chunk=4096, afc=False, cpu_re
         if center_at >= 0 and s >= center_at:
             d.center_freq_changed(center_hz)
             center_at = -1
+        if set_at >= 0 and s >= set_at:
+            d.set_settings(set_settings)
+            set_at = -1
         m = min(chunk, n - s)
         d.write(pcm[s:s + m])
         s += m

@@ -23,6 +23,7 @@
 //       FFTWrapper / FFTrWrapper transform (golden-vector pinning of the JFFT shim)
 //   jaero_ref fastfir <in.c128> <out.c128> alpha=0.6 K=2048 nfft=4096 Fs=48000 fsym=5250
 //   jaero_ref time oqpsk|msk <in.s16> [key=value ...]    -> prints seconds spent inside writeData
+#include <functional>
 #include <QCoreApplication>
 #include <QVector>
 #include <QByteArray>
@@ -99,9 +100,14 @@ static void hook_burst(DEMOD &d, Capture &c)
         c.status.push_back((double)g_write_start); c.status.push_back(0.0); c.status.push_back(s ? 1.0 : 0.0); });
 }
 
+// set_at=N [set_fb= set_Fs= set_lockingbw= set_freq_center= set_power=]: setSettings on the live object before the write that starts at or
+// after sample N (a user changing the rate in the settings dialog; MskDemodulator::dataReceived on audio at another rate)
+static std::function<void()> g_set_again;
+
 template <class DEMOD>
 static double feed(DEMOD &d, const QByteArray &pcm)
 {
+    long set_at = (long)getd("set_at", -1);
     int chunk = geti("chunk", 4096);
     long dcd_at = (long)getd("dcd_at", -1);         // sample index at which DCDstatSlot(true) is called (chunk aligned)
     long dcd_off_at = (long)getd("dcd_off_at", -1);
@@ -116,6 +122,7 @@ static double feed(DEMOD &d, const QByteArray &pcm)
         if (dcd_at >= 0 && s >= dcd_at) { d.DCDstatSlot(true); dcd_at = -1; }
         if (dcd_off_at >= 0 && s >= dcd_off_at) { d.DCDstatSlot(false); dcd_off_at = -1; }
         if (cf_at >= 0 && s >= cf_at) { d.CenterFreqChangedSlot(cf_hz); cf_at = -1; }
+        if (set_at >= 0 && s >= set_at) { if (g_set_again) g_set_again(); set_at = -1; }
         long n = chunk;
         if (s + n > nsamp) n = nsamp - s;
         g_write_start = s;
@@ -139,7 +146,14 @@ static double run_oqpsk(const QByteArray &pcm, Capture &c)
     d.DCDstatSlot(false);
     d.setSettings(s);
     d.start();
-    return feed(d, pcm);
+    g_set_again = [&d, s]() mutable {
+        s.fb = getd("set_fb", s.fb); s.Fs = getd("set_Fs", s.Fs); s.freq_center = getd("set_freq_center", s.freq_center);
+        s.lockingbw = getd("set_lockingbw", s.lockingbw); s.coarsefreqest_fft_power = geti("set_power", s.coarsefreqest_fft_power);
+        d.setSettings(s);
+    };
+    const double secs = feed(d, pcm);
+    g_set_again = nullptr;
+    return secs;
 }
 
 static double run_msk(const QByteArray &pcm, Capture &c)
@@ -154,7 +168,14 @@ static double run_msk(const QByteArray &pcm, Capture &c)
     d.DCDstatSlot(false);
     d.setSettings(s);
     d.start();
-    return feed(d, pcm);
+    g_set_again = [&d, s]() mutable {
+        s.fb = getd("set_fb", s.fb); s.Fs = getd("set_Fs", s.Fs); s.freq_center = getd("set_freq_center", s.freq_center);
+        s.lockingbw = getd("set_lockingbw", s.lockingbw); s.coarsefreqest_fft_power = geti("set_power", s.coarsefreqest_fft_power);
+        d.setSettings(s);
+    };
+    const double secs = feed(d, pcm);
+    g_set_again = nullptr;
+    return secs;
 }
 
 // The burst classes leave members uninitialised (BurstOqpskDemodulator::rotator_freq is read on the first sample,

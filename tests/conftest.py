@@ -38,7 +38,8 @@ def oracle_settings(O, kind, opts):
         return O.oqpsk_settings(freq_center=opts.get("freq_center", 8000.0), lockingbw=opts.get("lockingbw", 10500.0),
                                 fb=opts.get("fb", 10500.0), power=opts.get("power", 14), threshold=opts.get("threshold", 0.65))
     return O.msk_settings(freq_center=opts.get("freq_center", 1000.0), lockingbw=opts.get("lockingbw", 1800.0),
-                          fb=opts.get("fb", 1200.0), power=opts.get("power", 13), threshold=opts.get("threshold", 0.5))
+                          fb=opts.get("fb", 1200.0), power=opts.get("power", 13), threshold=opts.get("threshold", 0.5),
+                          Fs=float(opts.get("Fs", 48000.0)))
 
 
 def bank_settings(kind, opts):
@@ -50,7 +51,7 @@ def bank_settings(kind, opts):
                              signalthreshold=opts.get("threshold", 0.65))
     return MskSettings(freq_center=opts.get("freq_center", 1000.0), lockingbw=opts.get("lockingbw", 1800.0),
                        fb=opts.get("fb", 1200.0), coarsefreqest_fft_power=opts.get("power", 13),
-                       signalthreshold=opts.get("threshold", 0.5))
+                       signalthreshold=opts.get("threshold", 0.5), Fs=float(opts.get("Fs", 48000.0)))
 
 
 @pytest.fixture

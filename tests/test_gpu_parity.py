@@ -362,3 +362,61 @@ def test_msk_live_set_settings(B, oracle_mod):
         ref = {"soft": d.take_soft(), "status": d.take_status(), "symbols": d.take_symbols(), "pending": d.pending}
         compare(bank.read_softbits(c), bank.read_symbols(c), bank.read_status_log(c), ref)
     bank.close()
+
+
+@pytest.mark.parametrize("fb0,fb1,nch", [(8400, 10500, 3), (8400, 8400, 1), (10500, 8400, 2)])
+def test_oqpsk_live_rate_change_carries_state_over(B, oracle_mod, fb0, fb1, nch):
+    """setSettings with another bit rate on a running bank: the reference rebuilds AGC, filters, delays, resonator and
+    the 8400 bps prefilter inside the old object and KEEPS oscillator phases, loop states, the symbol-rate windows, the coarse ring and the
+    smoothed spectrum (oqpskdemodulator.cpp:175-289).  The bank is re-created behind the handle with those survivors copied
+    (rebank_with_carry_over); every channel against an oracle run that got the same call between the same two writes -- the oracle's own
+    live rate change is pinned to the reference in tests/test_oracle_vs_ref.py::test_oqpsk_live_rate_change.  Towards 8400 bps the
+    prefilter's mixer starts from the mean of mixer2's frequency over the last 10.5 kbps write, as in the reference (:607-608): the sample
+    loop keeps that sum at every rate."""
+    from jaero_amd import signalgen as G
+
+    O = oracle_mod
+    nsamp, set_at, chunk = 90000, 20480, 4096
+    pcm, _, _ = G.channel_bank("oqpsk", nch, nsamp, ebno_db=12.0, seed0=G.SEED_BASE + 7100 + fb0 // 100, fb=float(fb1))
+    o0, o1 = {"fb": float(fb0), "lockingbw": float(fb0)}, {"fb": float(fb1), "lockingbw": float(fb1), "freq_center": 8005.0}
+    bank = B.DemodulatorBank([bank_settings("oqpsk", o0) for _ in range(nch)], ebno=True, status_log=True, capture_symbols=True,
+                             max_write_samples=chunk, softbit_capacity=nsamp)
+    feed(bank, pcm[:, :set_at], chunk)
+    bank.set_settings(bank_settings("oqpsk", o1), channel=-1 if nch > 1 else 0)  # nothing was read yet: the outputs so far move to the new bank
+    feed(bank, pcm[:, set_at:], chunk)
+    for c in range(nch):
+        ref = O.run_demod(oracle_settings(O, "oqpsk", o0), pcm[c], chunk=chunk, capture_symbols=True, set_at=set_at,
+                          set_settings=oracle_settings(O, "oqpsk", o1))
+        soft, sym, log = bank.read_softbits(c), bank.read_symbols(c), bank.read_status_log(c)
+        compare(soft, sym, log, ref)
+    # what stays refused: one channel of several, another kind
+    if nch > 1:
+        from jaero_amd import capi
+        with pytest.raises(capi.JaeroError):
+            bank.set_settings(bank_settings("oqpsk", o0), channel=0)
+    bank.close()
+
+
+@pytest.mark.parametrize("Fs0,fb0,Fs1,fb1", [(48000, 600, 48000, 1200), (48000, 1200, 24000, 1200), (24000, 600, 48000, 600)])
+def test_msk_live_rate_change_carries_state_over(B, oracle_mod, Fs0, fb0, Fs1, fb1):
+    """MskDemodulator::setSettings with another bit / sample rate (mskdemodulator.cpp:135-263; what dataReceived does when audio arrives at
+    another rate, :528-537): oscillator phases, loop states, msema, the first entries of delayedsmpl and dt in buffer order, the coarse
+    ring and the smoothed spectrum survive.  Oracle side pinned to the reference in test_oracle_vs_ref.py::test_msk_live_rate_change."""
+    from jaero_amd import signalgen as G
+
+    O = oracle_mod
+    nch, set_at, chunk = 3, 9000, 3000
+    nsamp = int(Fs1 * 3)
+    pcm, _, _ = G.channel_bank("msk", nch, nsamp, ebno_db=12.0, seed0=G.SEED_BASE + 7700 + fb0 // 100 + Fs0 // 12000, fb=float(fb1), Fs=float(Fs1))
+    o0 = {"fb": float(fb0), "lockingbw": 1.5 * fb0, "Fs": float(Fs0)}
+    o1 = {"fb": float(fb1), "lockingbw": 1.5 * fb1, "Fs": float(Fs1)}
+    bank = B.DemodulatorBank([bank_settings("msk", o0) for _ in range(nch)], ebno=True, status_log=True, capture_symbols=True,
+                             max_write_samples=chunk, softbit_capacity=nsamp)
+    feed(bank, pcm[:, :set_at], chunk)
+    bank.set_settings(bank_settings("msk", o1), channel=-1)
+    feed(bank, pcm[:, set_at:], chunk)
+    for c in range(nch):
+        ref = O.run_demod(oracle_settings(O, "msk", o0), pcm[c], chunk=chunk, capture_symbols=True, set_at=set_at,
+                          set_settings=oracle_settings(O, "msk", o1))
+        compare(bank.read_softbits(c), bank.read_symbols(c), bank.read_status_log(c), ref)
+    bank.close()

@@ -70,3 +70,25 @@ def test_fft_shim_matches_restatement(O):
     z = x.astype(np.complex128).copy()
     O.lib().jo_fft(z.ctypes.data, 256, 0)
     assert np.array_equal(y, z)
+
+
+@pytest.mark.parametrize("fb0,fb1,set_at", [(8400, 10500, 20480), (10500, 8400, 24576), (8400, 8400, 20480)])
+def test_oqpsk_live_rate_change(O, fb0, fb1, set_at):
+    """OqpskDemodulator::setSettings on a running object with another bit rate (oqpskdemodulator.cpp:175-289: AGC, filters, delays and
+    resonator are rebuilt, oscillator phases, moving averages, the smoothed spectrum and the loop filter stay): the restatement against
+    the reference, which received the same call between the same two writes."""
+    pcm, _ = G.oqpsk(90000, fc=8012.0, ebno_db=12.0, seed=71, fb=10500.0)
+    new = O.oqpsk_settings(fb=float(fb1), lockingbw=float(fb1))
+    _cmp(O.run_ref("oqpsk", pcm, fb=fb0, lockingbw=fb0, set_at=set_at, set_fb=fb1, set_lockingbw=fb1),
+         O.run_demod(O.oqpsk_settings(fb=float(fb0), lockingbw=float(fb0)), pcm, set_at=set_at, set_settings=new))
+
+
+@pytest.mark.parametrize("Fs0,fb0,Fs1,fb1", [(48000, 600, 48000, 1200), (48000, 1200, 24000, 1200), (24000, 600, 48000, 600)])
+def test_msk_live_rate_change(O, Fs0, fb0, Fs1, fb1):
+    """MskDemodulator::setSettings with another bit rate / sample rate on a running object (mskdemodulator.cpp:135-263; what dataReceived
+    does when audio arrives at another rate, :528-537)."""
+    pcm, _ = G.msk(int(Fs1 * 3), fb=float(fb1), Fs=float(Fs1), fc=1004.0, ebno_db=12.0, seed=77)
+    set_at = 9000
+    new = O.msk_settings(fb=float(fb1), lockingbw=1.5 * fb1, Fs=float(Fs1))
+    _cmp(O.run_ref("msk", pcm, fb=fb0, lockingbw=1.5 * fb0, Fs=Fs0, chunk=3000, set_at=set_at, set_fb=fb1, set_Fs=Fs1, set_lockingbw=1.5 * fb1),
+         O.run_demod(O.msk_settings(fb=float(fb0), lockingbw=1.5 * fb0, Fs=float(Fs0)), pcm, chunk=3000, set_at=set_at, set_settings=new))
