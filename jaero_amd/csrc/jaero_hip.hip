@@ -160,7 +160,7 @@ struct jaero_ctx
     long long pre_n0 = 0;
     int pre_nprev = 0;
     int *d_chanlist = nullptr;
-    int coarse2_grid = 0, coarse2_lds = 0;
+    int coarse2_grid = 0; // workgroups of the persistent coarse-estimate kernels = CUs (k_coarse6_13: twice that)
     jaero_status *d_status = nullptr;
     int16_t *d_pack = nullptr; size_t pack_elems = 0;
     // host mirrors
@@ -607,9 +607,6 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
     DA(c->d_chanlist, nchp);
     DA(c->d_status, nchp);
     {
-        const int E = g.nfft / C2_THREADS;
-        const int a = E * 528, b = C2_THREADS * (E + 1);
-        c->coarse2_lds = (a > b ? a : b) * (int)sizeof(double);
         c->coarse2_grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     DA(c->d_tw, g.nfft);
@@ -747,7 +744,7 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         }
     }
     if (g.nfft_log2 == 14) HIPCHK(hipFuncSetAttribute((const void *)k_coarse6, hipFuncAttributeMaxDynamicSharedMemorySize, C6_XCH * (int)sizeof(double)));
-    else HIPCHK(hipFuncSetAttribute((const void *)k_coarse2<13>, hipFuncAttributeMaxDynamicSharedMemorySize, c->coarse2_lds));
+    else HIPCHK(hipFuncSetAttribute((const void *)k_coarse6_13, hipFuncAttributeMaxDynamicSharedMemorySize, C6_XCH13 * (int)sizeof(double)));
     HIPCHK(hipDeviceSynchronize());
     *out = c;
     return 0;
@@ -1099,7 +1096,7 @@ extern "C" int jaero_profile_kernel(jaero_ctx *c, int which, char *buf, int cap)
         if (g.kind == JAERO_KIND_OQPSK) nm = "k_oqpsk_fb<";
         else nm = c->msk_pairs ? "k_msk_fb<" : "k_msk_samples<";
     }
-    else if (which == 1) nm = (g.nfft_log2 == 14) ? (c->pre8400 ? "k_coarse6_w8400" : "k_coarse6") : "k_coarse2<";
+    else if (which == 1) nm = (g.nfft_log2 == 14) ? (c->pre8400 ? "k_coarse6_w8400" : "k_coarse6") : "k_coarse6_13";
     else if (which == 2) nm = "k_transpose_pcm";
     snprintf(buf, (size_t)cap, "%s", nm);
     return 0;
@@ -1174,7 +1171,12 @@ static void launch_coarse(jaero_ctx *c, const int *d_list, int nlist, hipStream_
         else
             hipLaunchKernelGGL(k_coarse6, dim3(grid), dim3(C2_THREADS), C6_XCH * (int)sizeof(double), st, c->g, c->p, d_list, nlist, c->d_tw);
     }
-    else hipLaunchKernelGGL((k_coarse2<13>), dim3(grid), dim3(C2_THREADS), c->coarse2_lds, st, c->g, c->p, d_list, nlist, c->d_tw);
+    else
+    {
+        // 2^13 = 32 x 16 x 16 on 256 threads: two workgroups per CU (k_coarse6.h)
+        const int grid2 = nlist < 2 * c->coarse2_grid ? nlist : 2 * c->coarse2_grid;
+        hipLaunchKernelGGL(k_coarse6_13, dim3(grid2), dim3(256), C6_XCH13 * (int)sizeof(double), st, c->g, c->p, d_list, nlist, c->d_tw);
+    }
 }
 
 extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layout, int is_device_ptr, void *stream)

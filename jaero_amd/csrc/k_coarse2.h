@@ -1,17 +1,7 @@
-// k_coarse2.h -- register-resident coarse frequency estimator (replaces the four-step LDS/scratch version).
-//
-// Same function as k_coarse.h (CoarseFreqEstimate::ProcessBasebandData + FreqOffsetEstimateSlot,
-// JAERO/coarsefreqestimate.cpp:90-137, JAERO/oqpskdemodulator.cpp:629-677, JAERO/mskdemodulator.cpp:490-519), but the
-// three N-point fp64 FFTs never leave the chip:
-//   * one 512-thread workgroup per channel-estimate (2 waves per SIMD, <=256 VGPRs each), each thread holds
-//     E = N/512 complex points (E = 32 for N = 2^14, 16 for 2^13) in VGPRs;
-//   * N = E x 32 x 16: an E-point FFT per thread in registers, exchange through LDS, 32-point FFTs in registers,
-//     exchange, 16-point FFTs -- real and imaginary planes are exchanged one after the other so the exchange buffer is
-//     N doubles (padded: 135 KB for N = 2^14), LDS strides chosen bank-conflict free for ds_write_b64 / ds_read_b64;
-//   * the output distribution of one transform (thread v holds bins k = v mod 512) is exactly the input distribution of
-//     the next, so FFT -> band-limit mask -> IFFT -> square -> FFT -> |.| -> dB smoothing runs register to register;
-//     the inverse transform is the forward one with real/imag planes swapped (unnormalised, as FFTWrapper's x N / N).
-// HBM traffic per estimate: the packed ring (4 B/sample) + y[] read/write; algorithmic bytes: 524 288 B.
+// k_coarse2.h -- the register-FFT building blocks: CV<L> (L complex points in registers), regfft<L> (radix-4 / radix-2 DFT of them),
+// wg_fft<LOG2N> (an N-point DFT of a 512-thread workgroup's data, N = E x 32 x 16 with two LDS exchanges: k_trident's correlations),
+// c2_log10, c4_twiddle16, c4_lds_barrier.  The coarse-frequency estimator kernels themselves are in k_coarse6.h (round 3); the first
+// register-resident one, k_coarse2<LOG2N>, lived here (rounds 1-2).
 #pragma once
 #include "jaero_device.h"
 #include "fft_consts.h"
@@ -270,147 +260,8 @@ __device__ __forceinline__ double c2_log10(double x)
     return fma((double)e, 0.30102999566398119521, lnm * 0.43429448190325182765);
 }
 
-template <int LOG2N>
-__global__ __launch_bounds__(C2_THREADS) void k_coarse2(const JGeom g, const JPtrs p, const int *__restrict__ chan_list,
-                                                           int nlist, const double2 *__restrict__ tw)
-{
-    constexpr int N = 1 << LOG2N;
-    constexpr int E = N / C2_THREADS;
-    extern __shared__ __attribute__((aligned(16))) double xch[];
-    __shared__ double red_val[C2_THREADS];
-    __shared__ int red_idx[C2_THREADS];
-    __shared__ int sh_bigchange;
-    const int t0 = threadIdx.x;
-    const int nchp = g.nchp;
-
-    CV<E> d;
-    for (int li = blockIdx.x; li < nlist; li += gridDim.x)
-    {
-        int t = t0; // opaque once per estimate: what is derived from it is recomputed (1-2 instructions), not hoisted and spilled
-        asm volatile("" : "+v"(t));
-        const int ch = chan_list ? chan_list[li] : li;
-        const double2 *__restrict__ ring = p.bbring + (size_t)ch * N;
-        const int bb_ptr = p.I[(size_t)I_BB_PTR * nchp + ch];
-        const double lockingbw = p.S[(size_t)S_LOCKINGBW * nchp + ch];
-        const double hzperbin = g.Fs / ((double)N);
-        const int startbin = (int)fmax(round(lockingbw / hzperbin), 1.0);
-        const int stopbin = N - startbin;
-        const int expectedpeakbin = (int)round(g.fb / (2.0 * hzperbin));
-        double *__restrict__ y = p.y + (size_t)ch * N;
-
-        // bbtmpbuff[j] = bbcycbuff[(ptr+j)%N] (time order); for every list entry but the first, these loads were issued
-        // while the previous estimate was in its peak search / state machine (d is free there), hiding the HBM latency
-        if (li == (int)blockIdx.x)
-        {
-#pragma unroll
-            for (int s = 0; s < E; s++)
-            {
-                const double2 v = ring[(bb_ptr + s * C2_THREADS + t) & (N - 1)];
-                d.r[s] = v.x; d.i[s] = v.y;
-            }
-        }
-        wg_fft<LOG2N>(d, xch, tw, t);
-        // band limit (fb != 8400 boxcar, coarsefreqestimate.cpp:99) then inverse transform = forward on swapped planes
-#pragma unroll
-        for (int s = 0; s < E; s++)
-        {
-            const int k = s * C2_THREADS + t;
-            const bool z = (k >= startbin) && (k <= stopbin);
-            const double re = z ? 0.0 : d.r[s], im = z ? 0.0 : d.i[s];
-            d.r[s] = im; d.i[s] = re;
-        }
-        wg_fft<LOG2N>(d, xch, tw, t);
-        // swap back (x N / N = 1), square
-#pragma unroll
-        for (int s = 0; s < E; s++)
-        {
-            const double re = d.i[s], im = d.r[s];
-            d.r[s] = re * re - im * im;
-            d.i[s] = re * im + im * re;
-        }
-        wg_fft<LOG2N>(d, xch, tw, t);
-        __syncthreads(); // the exchange buffer is free: it receives a copy of y for the fold below
-        // smooth with fftshift: y[i] = y[i]*0.9 + 0.1*10*log10(fmax(abs(out[i]),1)), out[i] = X[i ^ N/2]
-        // all old y values are requested before the log10s (their registers: d.i, dead once only |X|^2 is kept): written as
-        // one load-compute-store per element, every element waited out a full HBM round trip (vmcnt counts the stores too)
-        {
-            double yv[E];
-#pragma unroll
-            for (int s = 0; s < E; s++) d.r[s] = d.r[s] * d.r[s] + d.i[s] * d.i[s];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < E; s++) yv[s] = (y + ((s * C2_THREADS) ^ (N / 2)))[t]; // (s*512 + t) ^ N/2: uniform base + t
-            __builtin_amdgcn_sched_barrier(0); // or the scheduler sinks every load to its use again
-            // 10*log10(max(|X|,1)) == 5*log10(max(|X|^2,1)): no hypot; differs from the reference expression by <= 1 ulp
-#pragma unroll
-            for (int s = 0; s < E; s++) d.r[s] = 5.0 * c2_log10(fmax(d.r[s], 1.0));
-#pragma unroll
-            for (int s = 0; s < E; s++)
-            {
-                const int ib = (s * C2_THREADS) ^ (N / 2);
-                const double yn = yv[s] * 0.9 + d.r[s];
-                (y + ib)[t] = yn;
-                (xch + ib)[t] = yn;
-            }
-        }
-        __syncthreads();
-        {
-            const int ln = li + (int)gridDim.x;
-            if (ln < nlist)
-            {
-                const int chn = chan_list ? chan_list[ln] : ln;
-                const double2 *__restrict__ ringn = p.bbring + (size_t)chn * N;
-                const int bpn = p.I[(size_t)I_BB_PTR * nchp + chn];
-#pragma unroll
-                for (int s = 0; s < E; s++)
-                {
-                    const double2 v = ringn[(bpn + s * C2_THREADS + t) & (N - 1)];
-                    d.r[s] = v.x; d.i[s] = v.y;
-                }
-            }
-        }
-
-        // fold + peak search (:116-131)
-        const int i0 = (int)round((-lockingbw / hzperbin) + ((double)(N / 2)));
-        const int i1 = (int)round((lockingbw / hzperbin) + ((double)(N / 2)));
-        double best = 0;
-        int besti = -1;
-        for (int i = i0 + t; i < i1; i += C2_THREADS)
-        {
-            if ((i < 0) || (i >= N)) continue;
-            double val = 0;
-            for (int j = -1; j <= 1; j++)
-            {
-                if (((i - expectedpeakbin - j) < 0) || ((i + expectedpeakbin + j) >= N)) continue;
-                val += (xch[i - expectedpeakbin - j] + xch[i + expectedpeakbin + j]);
-            }
-            if (val > best) { best = val; besti = i; }
-        }
-        red_val[t] = best;
-        red_idx[t] = besti;
-        __syncthreads();
-        for (int s = C2_THREADS / 2; s > 0; s >>= 1)
-        {
-            if (t < s)
-            {
-                const double ov = red_val[t + s];
-                const int oi = red_idx[t + s];
-                const double mv = red_val[t];
-                const int mi = red_idx[t];
-                if (oi >= 0 && (mi < 0 || ov > mv || (ov == mv && oi < mi))) { red_val[t] = ov; red_idx[t] = oi; }
-            }
-            __syncthreads();
-        }
-        if (t == 0) sh_bigchange = coarse_slot(g, p, ch, (red_idx[0] >= 0) ? red_idx[0] : (N / 2), N, hzperbin, lockingbw);
-        __syncthreads();
-        if (sh_bigchange)
-        {
-            double2 *ringw = p.bbring + (size_t)ch * N;
-            for (int i = t; i < N; i += C2_THREADS) { y[i] = 20; ringw[i] = make_double2(0.0, 0.0); }
-        }
-        __syncthreads();
-    }
-}
+// (The estimator kernel built on wg_fft, k_coarse2<LOG2N>, served the MSK rates until round 3: 6.76 ms per 65 536 estimates of 2^13 points,
+// half of its threads idle in the 32-point pass.  k_coarse6.h replaces it: k_coarse6_13, 5.64 ms.  wg_fft stays for k_trident.)
 
 // v[k] *= step^k (k < 16), the powers by products of depth <= 6 (k_pre8400.h's 4096-point transform)
 __device__ __forceinline__ void c4_twiddle16(CV<16> &v, const double2 step) // v[k] *= step^k

@@ -147,21 +147,103 @@ __device__ __forceinline__ void wg_fft14_e32(CV<32> &d, double *xch, const doubl
     }
 }
 
+
+// In-place forward 2^13-point DFT of a 256-thread workgroup's data, natural distribution in and out (slot = index >> 8, thread = index & 255):
+// 8192 = 32 x 16 x 16, the same two exchanges.  Half the threads of k_coarse6 with the same 32 points each, so TWO workgroups share a CU
+// (2 x 64 KiB of LDS, one wavefront of each per SIMD): while one is in an exchange or waits for HBM the other computes -- the overlap a
+// single workgroup cannot have.  k_coarse2<13> (16 x 32 x 16 on 512 threads) left half of them idle in its 32-point pass.
+//   n = 256 n1 + 16 n2 + n3        k = k1 + 32 k2 + 512 k3        (n1, k1 < 32;  n2, n3, k2, k3 < 16)
+//   pass 1: FFT32 over n1, x W_N^(k1 (n mod 256))     exchange 1     pass 2: two FFT16 over n2 (k1 = k1a, k1a + 16), x W_256^(k2 n3)
+//   exchange 2     pass 3: two FFT16 over n3 (k2 = k2lo, k2lo + 8)
+// Exchange 1: L = k1 * 256 + 16 n2 + n3 (both sides touch consecutive doubles per 16 lanes).  Exchange 2: L = k1 + 32 k2 + 513 n3 (the 16
+// lanes of a writer group differ in n3 only: the odd stride spreads them over the 16 bank pairs; readers touch 64 consecutive doubles).
+#define C6_XCH13 8208
+__device__ __forceinline__ void wg_fft13_e32(CV<32> &d, double *xch, const double2 *__restrict__ tw, int t)
+{
+#pragma clang fp contract(fast)
+    const double2 st1 = tw[t], st2 = tw[32 * (t & 15)]; // W_N^(n mod 256); W_256^n3
+    const int k1a = t >> 4, n3 = t & 15;
+    const int e1r = k1a * 256 + n3;   // reader of exchange 1: + (m >> 4) * 4096 + (m & 15) * 16
+    const int e2w = k1a + 513 * n3;   // writer of exchange 2: + 16 g + 32 k2
+    // ---- pass 1 ----
+    c6_fft32(d);
+    c6_twiddle32(d, st1);
+    C6_FENCE;
+    // ---- exchange 1, a plane at a time ----
+    c6_bar();
+#pragma unroll
+    for (int s = 0; s < 32; s++) (xch + c6_k(s) * 256)[t] = d.r[s];
+    c6_bar();
+#pragma unroll
+    for (int m = 0; m < 32; m++) d.r[m] = (xch + (m >> 4) * 4096 + (m & 15) * 16)[e1r];
+    c6_bar();
+#pragma unroll
+    for (int s = 0; s < 32; s++) (xch + c6_k(s) * 256)[t] = d.i[s];
+    c6_bar();
+#pragma unroll
+    for (int m = 0; m < 32; m++) d.i[m] = (xch + (m >> 4) * 4096 + (m & 15) * 16)[e1r];
+    C6_FENCE;
+    // ---- pass 2: slots 0..15 = n2 for k1 = k1a, 16..31 for k1 = k1a + 16 ----
+#pragma unroll
+    for (int g2 = 0; g2 < 2; g2++)
+    {
+        CV<16> in, out;
+#pragma unroll
+        for (int j = 0; j < 16; j++) { in.r[j] = d.r[16 * g2 + j]; in.i[j] = d.i[16 * g2 + j]; }
+        regfft<16>(in, out);
+        c4_twiddle16(out, st2);
+#pragma unroll
+        for (int j = 0; j < 16; j++) { d.r[16 * g2 + j] = out.r[j]; d.i[16 * g2 + j] = out.i[j]; }
+        C6_FENCE;
+    }
+    // ---- exchange 2: slot 16 g + k2 -> L = (k1a + 16 g) + 32 k2 + 513 n3; reader t3 = k1 + 32 k2lo, slot 16 h + n3 ----
+    c6_bar();
+#pragma unroll
+    for (int s = 0; s < 32; s++) (xch + (s >> 4) * 16 + (s & 15) * 32)[e2w] = d.r[s];
+    c6_bar();
+#pragma unroll
+    for (int m = 0; m < 32; m++) d.r[m] = (xch + (m >> 4) * 256 + (m & 15) * 513)[t];
+    c6_bar();
+#pragma unroll
+    for (int s = 0; s < 32; s++) (xch + (s >> 4) * 16 + (s & 15) * 32)[e2w] = d.i[s];
+    c6_bar();
+#pragma unroll
+    for (int m = 0; m < 32; m++) d.i[m] = (xch + (m >> 4) * 256 + (m & 15) * 513)[t];
+    C6_FENCE;
+    // ---- pass 3: FFT16 over n3 for h = 0, 1; X[t + 256 h + 512 k3] -> slot 2 k3 + h (natural) ----
+    {
+        CV<16> in, o0, o1;
+#pragma unroll
+        for (int j = 0; j < 16; j++) { in.r[j] = d.r[j]; in.i[j] = d.i[j]; }
+        regfft<16>(in, o0);
+        C6_FENCE;
+#pragma unroll
+        for (int j = 0; j < 16; j++) { in.r[j] = d.r[16 + j]; in.i[j] = d.i[16 + j]; }
+        regfft<16>(in, o1);
+#pragma unroll
+        for (int k3 = 0; k3 < 16; k3++) { d.r[2 * k3] = o0.r[k3]; d.i[2 * k3] = o0.i[k3]; d.r[2 * k3 + 1] = o1.r[k3]; d.i[2 * k3 + 1] = o1.i[k3]; }
+    }
+}
+
+template <int LOG2N>
 __device__ __forceinline__ void c6_fft(CV<32> &d, double *xch, const double2 *__restrict__ tw, int t)
 {
     int tt = t; // laundered per call: nothing derived from it inside is shared between the three calls of an estimate and kept live
     asm volatile("" : "+v"(tt));
-    wg_fft14_e32(d, xch, tw, tt);
+    if constexpr (LOG2N == 14) wg_fft14_e32(d, xch, tw, tt);
+    else wg_fft13_e32(d, xch, tw, tt);
 }
 
-template <bool W8400>
+template <bool W8400, int LOG2N = 14>
 __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const int *__restrict__ chan_list, int nlist, const double2 *__restrict__ tw)
 {
-    constexpr int N = 1 << 14;
+    constexpr int N = 1 << LOG2N;
     constexpr int E = 32;
+    constexpr int NT = N / E;                                  // 512 threads for 2^14, 256 for 2^13
+    constexpr int XCH = LOG2N == 14 ? C6_XCH : C6_XCH13;
     extern __shared__ __attribute__((aligned(16))) double xch[];
-    __shared__ double red_val[C2_THREADS / 64]; // one entry per wavefront
-    __shared__ int red_idx[C2_THREADS / 64];
+    __shared__ double red_val[NT / 64]; // one entry per wavefront
+    __shared__ int red_idx[NT / 64];
     __shared__ int sh_bigchange;
     const int t0 = threadIdx.x;
     const int nchp = g.nchp;
@@ -201,11 +283,11 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
 #pragma unroll
             for (int s = 0; s < E; s++)
             {
-                const double2 v = ring[(bb_ptr + s * C2_THREADS + t) & (N - 1)];
+                const double2 v = ring[(bb_ptr + s * NT + t) & (N - 1)];
                 d.r[s] = v.x; d.i[s] = v.y;
             }
         }
-        c6_fft(d, xch, tw, t);
+        c6_fft<LOG2N>(d, xch, tw, t);
         // band limit (fb != 8400 boxcar, coarsefreqestimate.cpp:99) then inverse transform = forward on swapped planes
         if constexpr (W8400)
         {
@@ -214,11 +296,11 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
             // the window zeroes), rebuilt only when startbin changes; a window wider than that space (lockingbw >= 10.49 kHz) is made per
             // estimate in the idle exchange buffer.
             const bool persistent = startbin < C4_TABN - 1;
-            double *wt = persistent ? xch + C6_XCH : xch;
+            double *wt = persistent ? xch + XCH : xch;
             if (!persistent || startbin != tab_startbin)
             {
                 c6_bar();
-                for (int i = t; i <= startbin + 1; i += C2_THREADS)
+                for (int i = t; i <= startbin + 1; i += NT)
                 {
                     const double c = cos(M_PI_2 * ((double)i) / ((double)startbin));
                     wt[i] = (i == 0) ? 1.0 : ((i <= startbin) ? c * c : 0.0);
@@ -232,7 +314,7 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
 #pragma unroll
                 for (int s = s0; s < s0 + 8; s++)
                 {
-                    const int k = s * C2_THREADS + t;
+                    const int k = s * NT + t;
                     const int i = (k <= N / 2) ? k : N - k;
                     const double w = wt[i <= startbin ? i : startbin + 1];
                     const double re = d.r[s] * w, im = d.i[s] * w;
@@ -247,13 +329,13 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
 #pragma unroll
             for (int s = 0; s < E; s++)
             {
-                const int k = s * C2_THREADS + t;
+                const int k = s * NT + t;
                 const bool z = (k >= startbin) && (k <= stopbin);
                 const double re = z ? 0.0 : d.r[s], im = z ? 0.0 : d.i[s];
                 d.r[s] = im; d.i[s] = re;
             }
         }
-        c6_fft(d, xch, tw, t);
+        c6_fft<LOG2N>(d, xch, tw, t);
         // swap back (x N / N = 1), square
 #pragma unroll
         for (int s = 0; s < E; s++)
@@ -262,7 +344,7 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
             d.r[s] = re * re - im * im;
             d.i[s] = re * im + im * re;
         }
-        c6_fft(d, xch, tw, t);
+        c6_fft<LOG2N>(d, xch, tw, t);
         c6_bar(); // the exchange buffer is free: it receives a copy of y for the fold below
         // smooth with fftshift: y[i] = y[i]*0.9 + 0.1*10*log10(fmax(abs(out[i]),1)), out[i] = X[i ^ N/2]
         // all 32 old y values are requested before the log10s (their registers: the imaginary plane, dead once only |X|^2 is kept)
@@ -272,7 +354,7 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
             for (int s = 0; s < E; s++) d.r[s] = d.r[s] * d.r[s] + d.i[s] * d.i[s];
             C6_FENCE; // d.i is dead from here: its registers take the y values
 #pragma unroll
-            for (int s = 0; s < E; s++) yv[s] = (y + ((s * C2_THREADS) ^ (N / 2)))[t]; // (s*512 + t) ^ N/2: uniform base + t
+            for (int s = 0; s < E; s++) yv[s] = (y + ((s * NT) ^ (N / 2)))[t]; // (s*NT + t) ^ N/2: uniform base + t
             C6_FENCE; // or the scheduler sinks every load to its use again
             // 10*log10(max(|X|,1)) == 5*log10(max(|X|^2,1)): no hypot; differs from the reference expression by <= 1 ulp
 #pragma unroll
@@ -280,7 +362,7 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
 #pragma unroll
             for (int s = 0; s < E; s++)
             {
-                const int ib = (s * C2_THREADS) ^ (N / 2);
+                const int ib = (s * NT) ^ (N / 2);
                 const double yn = yv[s] * 0.9 + d.r[s];
                 (y + ib)[t] = yn;
                 (xch + ib)[t] = yn;
@@ -298,7 +380,7 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
 #pragma unroll
             for (int s = 0; s < E; s++)
             {
-                const double2 v = ringn[(toffp + s * C2_THREADS) & (N - 1)];
+                const double2 v = ringn[(toffp + s * NT) & (N - 1)];
                 d.r[s] = v.x; d.i[s] = v.y;
             }
         }
@@ -308,7 +390,7 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
         const int i1 = (int)round((lockingbw / hzperbin) + ((double)(N / 2)));
         double best = 0;
         int besti = -1;
-        for (int i = i0 + t; i < i1; i += C2_THREADS)
+        for (int i = i0 + t; i < i1; i += NT)
         {
             if ((i < 0) || (i >= N)) continue;
             double val = 0;
@@ -335,7 +417,7 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
             c6_bar();
             if (t == 0)
             {
-                for (int w = 1; w < C2_THREADS / 64; w++)
+                for (int w = 1; w < NT / 64; w++)
                 {
                     const double ov = red_val[w];
                     const int oi = red_idx[w];
@@ -350,7 +432,7 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
         {
             __syncthreads(); // rare (AFC recentre): this estimate's y stores must have landed before other threads overwrite the same rows
             double2 *ringw = p.bbring + (size_t)ch * N;
-            for (int i = t; i < N; i += C2_THREADS) { y[i] = 20; ringw[i] = make_double2(0.0, 0.0); }
+            for (int i = t; i < N; i += NT) { y[i] = 20; ringw[i] = make_double2(0.0, 0.0); }
         }
         // no barrier here: the next use of LDS is behind the first barrier of the next estimate's transform
     }
@@ -365,4 +447,10 @@ __global__ __launch_bounds__(C2_THREADS) void k_coarse6_w8400(const JGeom g, con
                                                                  int nlist, const double2 *__restrict__ tw)
 {
     coarse6_body<true>(g, p, chan_list, nlist, tw);
+}
+// N = 2^13 (the MSK rates): 256 threads, two workgroups per CU (launch 2 x #CUs workgroups, C6_XCH13 doubles of dynamic LDS each)
+__global__ __launch_bounds__(256, 2) void k_coarse6_13(const JGeom g, const JPtrs p, const int *__restrict__ chan_list,
+                                                        int nlist, const double2 *__restrict__ tw)
+{
+    coarse6_body<false, 13>(g, p, chan_list, nlist, tw);
 }

@@ -87,3 +87,64 @@ def test_lds_accesses_are_conflict_free():
             addr = a[64 * w:64 * w + 64]
             for q in range(4):
                 assert len(set((addr[16 * q:16 * q + 16] % 16).tolist())) == 16, (name, w, q)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# wg_fft13_e32 (k_coarse6_13, the MSK rates): 8192 = 32 x 16 x 16 on 256 threads, n = 256 n1 + 16 n2 + n3, k = k1 + 32 k2 + 512 k3; natural in
+# and out (slot = index >> 8, thread = index & 255).  Pass 1 as above; pass 2 and pass 3 are two 16-point FFTs each (natural order out).
+N13 = 8192
+T13 = np.arange(256)
+TW13 = np.exp(-2j * np.pi * np.arange(N13) / N13)
+XLEN13 = 8208
+
+
+def e13_ex1_write(s):        # pass-1 thread t = 16 n2 + n3 holds k1 = K(s)
+    return K(s) * 256 + T13
+
+
+def e13_ex1_read(m):         # pass-2 thread (k1a = t >> 4, n3 = t & 15), slot m = 16 g + n2: k1 = k1a + 16 g
+    return (m >> 4) * 4096 + (m & 15) * 16 + (T13 >> 4) * 256 + (T13 & 15)
+
+
+def e13_ex2_write(s):        # pass-2 thread (k1a, n3) holds slot s = 16 g + k2: L = k1 + 32 k2 + 513 n3
+    return (s >> 4) * 16 + (s & 15) * 32 + (T13 >> 4) + 513 * (T13 & 15)
+
+
+def e13_ex2_read(m):         # pass-3 thread t3 = k1 + 32 k2lo, slot m = 16 h + n3: k2 = k2lo + 8 h
+    return (m >> 4) * 256 + (m & 15) * 513 + T13
+
+
+def model_fft13(x):
+    d = x.reshape(32, 256).T.copy()                                   # d[t, slot] = x[slot*256 + t]
+    o = fft32_split(d) * np.stack([TW13[T13] ** K(s) for s in range(32)], axis=1)   # W_N^(k1 (n mod 256))
+    L = np.full(N13, np.nan, complex)
+    for s in range(32):
+        L[e13_ex1_write(s)] = o[:, s]
+    d2 = np.stack([L[e13_ex1_read(m)] for m in range(32)], axis=1)
+    k16 = np.arange(16)[None, :]
+    o = np.concatenate([np.fft.fft(d2[:, 16 * g:16 * g + 16], axis=1) * TW13[32 * (T13 & 15)][:, None] ** k16 for g in range(2)], axis=1)
+    L = np.full(XLEN13, np.nan, complex)
+    for s in range(32):
+        L[e13_ex2_write(s)] = o[:, s]
+    d3 = np.stack([L[e13_ex2_read(m)] for m in range(32)], axis=1)
+    out = np.zeros((256, 32), complex)
+    for h in range(2):
+        o3 = np.fft.fft(d3[:, 16 * h:16 * h + 16], axis=1)
+        for k3 in range(16):
+            out[:, 2 * k3 + h] = o3[:, k3]
+    return out.T.reshape(N13)
+
+
+def test_fft13_maps_transform_and_banks():
+    assert sorted(np.concatenate([e13_ex1_write(s) for s in range(32)])) == list(range(N13))
+    assert sorted(np.concatenate([e13_ex1_read(m) for m in range(32)])) == list(range(N13))
+    w = np.concatenate([e13_ex2_write(s) for s in range(32)])
+    r = np.concatenate([e13_ex2_read(m) for m in range(32)])
+    assert len(set(w.tolist())) == N13 and sorted(w) == sorted(r) and w.max() < XLEN13
+    rng = np.random.default_rng(13)
+    x = rng.standard_normal(N13) + 1j * rng.standard_normal(N13)
+    assert np.max(np.abs(model_fft13(x) - np.fft.fft(x))) < 1e-8
+    maps = [e13_ex1_write(s) for s in range(32)] + [e13_ex1_read(m) for m in range(32)] + [e13_ex2_write(s) for s in range(32)] + [e13_ex2_read(m) for m in range(32)]
+    for a in maps:
+        for q in range(16):   # 4 wavefronts x 4 groups of 16 lanes
+            assert len(set((a[16 * q:16 * q + 16] % 16).tolist())) == 16

@@ -2,7 +2,7 @@
 (configs[1]; plus 1024 channels so the persistent coarse kernel runs several estimates per workgroup), 4096-channel burst OQPSK
 (configs[3]) -- and the two bundled recordings from their first to their last sample.
 
-With more channels than the chip has CUs the coarse-frequency kernels (k_coarse4, k_coarse2<13>) and k_trident run as persistent
+With more channels than the chip has CUs the coarse-frequency kernels (k_coarse6, k_coarse6_13) and k_trident run as persistent
 workgroups that each take several estimates from the list and consume the ring / y[] rows they prefetched for the NEXT estimate; the
 banks of at most 70 channels in the other test files never reach that code.  Channels are compared with their own oracle run
 (O.run_demod / O.run_burst, exactly as test_gpu_parity.compare does) at indices spread over the bank: lanes 0 and 63 of a wavefront,
@@ -113,7 +113,7 @@ def test_oqpsk_65536_channels(B, oracle_mod, fb):
 
 
 def test_msk_65536_channels(B, oracle_mod):
-    """The bank `bench.py --workload msk` times: 65 536 channels of 1200 bps MSK (four k_msk_samples wavefronts per CU, k_coarse2<13> with
+    """The bank `bench.py --workload msk` times: 65 536 channels of 1200 bps MSK (four k_msk_samples wavefronts per CU, k_coarse6_13 with
     256 persistent estimates per workgroup and launch, two launches per 4096-sample write).  37 distinct signals, channel c carries
     signal (5 c) mod 37 (so that neighbouring lanes, wavefronts and workgroup iterations all differ); 20 spread channels against the
     oracle run of their signal."""
@@ -152,7 +152,7 @@ def test_msk_65536_channels(B, oracle_mod):
 @pytest.mark.parametrize("nch,nsamp", [(256, 50000), (1024, 30000)])
 def test_msk_1200_banks(B, oracle_mod, nch, nsamp):
     """BASELINE configs[1]: 256-channel synthetic 48 kHz 1200 bps MSK (one estimate per workgroup and launch), and 1024 channels
-    (four persistent iterations of k_coarse2<13> per workgroup); an estimate every 2048 samples."""
+    (two persistent iterations of k_coarse6_13 per workgroup); an estimate every 2048 samples."""
     from jaero_amd import signalgen as G
 
     O = oracle_mod
@@ -443,7 +443,7 @@ def test_burst_msk_65536_channels(B, oracle_mod):
 
 @pytest.mark.parametrize("nch", [4096])
 def test_msk_600_bank(B, oracle_mod, nch):
-    """600 bps MSK at 48 kHz (the 160-tap loop k_msk_samples<160,78>) in a bank: 4096 channels = 16 persistent iterations of k_coarse2<13>
+    """600 bps MSK at 48 kHz (the 160-tap loop k_msk_samples<160,78>) in a bank: 4096 channels = persistent iterations of k_coarse6_13
     per workgroup and launch, 32 estimates per channel (one every 2048 samples); every channel its own lockingbw; 29 distinct signals,
     channel c carries signal (3 c) mod 29."""
     import torch
