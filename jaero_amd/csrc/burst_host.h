@@ -231,7 +231,7 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
     c->m.nch = nch; c->m.nchp = nchp;
     c->m.flags.assign(nchp, 0);
     // burst OQPSK: 39 of its 55 history slots + the taps in LDS; burst MSK: 39 of 80 (1200 bps) or all 160 (600 bps) slots
-    const int lds = (oq ? 2 * 39 * 64 + 64 : 2 * (g.fir_n == 80 ? BMSK_LDSN_1200 : g.fir_n) * 64) * (int)sizeof(double);
+    const int lds = oq ? (2 * 39 * 64 + 64) * (int)sizeof(double) : 2 * (g.fir_n == 80 ? BMSK_FB_LDSN_80 : BMSK_FB_LDSN_160) * 64 * (int)sizeof(double) + BMSK_FB_MAIL_BYTES;
     if (oq)
     {
         HIPCHK(hipFuncSetAttribute((const void *)k_burst_oqpsk_demod<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -240,10 +240,11 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
     else
     {
         if (g.fir_n != 80 && g.fir_n != 160) return fail(JAERO_ENOTSUP, "burst MSK matched filter of %d taps has no kernel", g.fir_n);
-        HIPCHK(hipFuncSetAttribute((const void *)k_burst_msk_demod<false, 80, BMSK_LDSN_1200>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_burst_msk_demod<true, 80, BMSK_LDSN_1200>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_burst_msk_demod<false, 160, 160>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_burst_msk_demod<true, 160, 160>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        // front / back wavefront pairs (k_burst_msk_fb.h): 72 of 80 (two pairs per CU) or 152 of 160 history slots in LDS + 4 KiB of mailboxes
+        HIPCHK(hipFuncSetAttribute((const void *)k_burst_msk_fb<false, 80, BMSK_FB_LDSN_80>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_burst_msk_fb<true, 80, BMSK_FB_LDSN_80>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_burst_msk_fb<false, 160, BMSK_FB_LDSN_160>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_burst_msk_fb<true, 160, BMSK_FB_LDSN_160>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
     HIPCHK(hipFuncSetAttribute((const void *)k_trident, hipFuncAttributeMaxDynamicSharedMemorySize, c->tri_lds));
     HIPCHK(hipDeviceSynchronize());
@@ -273,7 +274,7 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
         prof_end(c, pi, st);
     }
     const bool cs = (c->flags & JAERO_FLAG_CAPTURE_SYMBOLS) != 0;
-    const int lds = (g.kind == JAERO_KIND_BURST_OQPSK ? 2 * 39 * 64 + 64 : 2 * (g.fir_n == 80 ? BMSK_LDSN_1200 : g.fir_n) * 64) * (int)sizeof(double);
+    const int lds = g.kind == JAERO_KIND_BURST_OQPSK ? (2 * 39 * 64 + 64) * (int)sizeof(double) : 2 * (g.fir_n == 80 ? BMSK_FB_LDSN_80 : BMSK_FB_LDSN_160) * 64 * (int)sizeof(double) + BMSK_FB_MAIL_BYTES;
     int first = 1;
     for (int pos = 0; pos < nsamples;)
     {
@@ -302,13 +303,13 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
         {
             if (g.fir_n == 80)
             {
-                if (cs) hipLaunchKernelGGL((k_burst_msk_demod<true, 80, BMSK_LDSN_1200>), dim3(g.ngroups), dim3(64), lds, st, g, p, n, n0, first);
-                else hipLaunchKernelGGL((k_burst_msk_demod<false, 80, BMSK_LDSN_1200>), dim3(g.ngroups), dim3(64), lds, st, g, p, n, n0, first);
+                if (cs) hipLaunchKernelGGL((k_burst_msk_fb<true, 80, BMSK_FB_LDSN_80>), dim3(g.ngroups), dim3(128), lds, st, g, p, n, n0, first);
+                else hipLaunchKernelGGL((k_burst_msk_fb<false, 80, BMSK_FB_LDSN_80>), dim3(g.ngroups), dim3(128), lds, st, g, p, n, n0, first);
             }
             else
             {
-                if (cs) hipLaunchKernelGGL((k_burst_msk_demod<true, 160, 160>), dim3(g.ngroups), dim3(64), lds, st, g, p, n, n0, first);
-                else hipLaunchKernelGGL((k_burst_msk_demod<false, 160, 160>), dim3(g.ngroups), dim3(64), lds, st, g, p, n, n0, first);
+                if (cs) hipLaunchKernelGGL((k_burst_msk_fb<true, 160, BMSK_FB_LDSN_160>), dim3(g.ngroups), dim3(128), lds, st, g, p, n, n0, first);
+                else hipLaunchKernelGGL((k_burst_msk_fb<false, 160, BMSK_FB_LDSN_160>), dim3(g.ngroups), dim3(128), lds, st, g, p, n, n0, first);
             }
         }
         LAUNCHCHK("the burst demodulator");

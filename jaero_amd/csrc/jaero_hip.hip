@@ -30,6 +30,7 @@
 #include "burst_device.h"
 #include "k_burst_front.h"
 #include "k_burst_demod.h"
+#include "k_burst_msk_fb.h"
 #include "k_aerol.h"
 #include "k_aerol_burst.h"
 
@@ -1089,7 +1090,7 @@ extern "C" int jaero_profile_kernel(jaero_ctx *c, int which, char *buf, int cap)
     {
         static const char *bn[5] = {"k_burst_oqpsk_demod", "k_trident", "k_hist_push", "k_hilbert_fft", "k_burst_front"};
         nm = bn[which];
-        if (which == 0 && c->bg.kind == JAERO_KIND_BURST_MSK) nm = "k_burst_msk_demod";
+        if (which == 0 && c->bg.kind == JAERO_KIND_BURST_MSK) nm = "k_burst_msk_fb";
     }
     else if (which == 0)
     {

@@ -1,12 +1,15 @@
 // k_burst_demod.h -- consumer side of the burst demodulators: the tracking chains, one channel per lane.
 //   k_burst_oqpsk_demod : JAERO/burstoqpskdemodulator.cpp:488-515 (trident result applied), :517-733
-//   k_burst_msk_demod   : JAERO/burstmskdemodulator.cpp:524-568 (trident result applied), :571-745
+//   (burst MSK: k_burst_msk_fb.h)
 // Input is val_to_demod = real(cv[n - D1 - D2]) from the ring k_burst_front filled; the trident verdict for the event sample of
 // this segment (if any) was computed by k_trident between the two launches.
 #pragma once
 #include "burst_device.h"
 #include "jaero_device.h"
 #include "k_burst_front.h"
+#ifndef BURST_ABL_NOFIR
+#define BURST_ABL_NOFIR 0 // timing experiment only (wrong results): the matched filters' evaluation removed = the most a front / back split could hide
+#endif
 #include "k_oqpsk_fb.h" // jd_div_const, fb_wt_setfreq, fb_fmod360: exact rewrites (bit-identical results, fewer instructions)
 
 __device__ __forceinline__ void bd_set_phase_deg(double &ptr, double phase_deg) // WaveTable::SetPhaseDeg (DSP.cpp:175-180)
@@ -160,7 +163,8 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
         double sre = 0, sim = 0;
         {
             // output from x[n-FIRN .. n-1] (FIR::FIRUpdateAndProcess excludes the sample being pushed): taps[i] <-> x[n-FIRN+i]
-            jd_fir_eval<FIRN, LDSN, 8>(lre, lim, ltap, tre, tim, fir_slot, lane, sre, sim);
+            if (!BURST_ABL_NOFIR) jd_fir_eval<FIRN, LDSN, 8>(lre, lim, ltap, tre, tim, fir_slot, lane, sre, sim);
+            else { sre = lre[fir_slot * 64 + lane]; sim = lim[fir_slot * 64 + lane]; }
             // push x[n]: the oldest LDS entry moves into the register tail
 #pragma unroll
             for (int j = TAILN - 1; j > 0; j--) { tre[j] = tre[j - 1]; tim[j] = tim[j - 1]; }
@@ -369,359 +373,5 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
 }
 
 // ------------------------------------------------------------------------------------------------ burst MSK
-// Everything after the sample counters runs only while (startstop > 0 || mse < signalthreshold) (:601), so the matched
-// filter, agc2, EbNo, delayedsmpl and delayt8 rings advance per channel: their positions are per-lane state and the rings are
-// per-channel arrays; the matched-filter ring lives in LDS for the launch ([slot][lane], per-lane slot, conflict-free).
-// Round 2: (i) the matched filter reads eight history entries ahead of the sixteen fmas that consume them (it was one LDS round trip per
-// tap: 80 or 160 dependent waits per sample); (ii) the entries leaving the per-channel windows (EbNo, agc2, the two delay lines) are
-// requested at the top of a sample -- their addresses are known there -- instead of where they are consumed, one HBM / L2 round trip
-// each, one after the other; (iii) the EbNo meter's divide / sqrt / two log10 run only where its value can be observed (the
-// JD_EBNO_TAIL samples before the end of a launch, before its one emission per burst, and before the gate closes), as in the burst OQPSK
-// kernel.  78 -> 43 ms per 4096-sample launch of 65 536 channels.
-// LDSN < FIRN keeps only the LDSN newest history entries of each arm in LDS (per-lane ring position) and the older ones in registers
-// (the shift runs under the gate's exec mask).  Tried for 1200 bps to get four wavefronts per CU instead of two (40 instead of 80 KiB each,
-// so that the 1024 wavefronts of a 65 536-channel bank are resident at once instead of in two rounds): the kernel already holds 380
-// registers, the 164 of the tail spill (39 slots: 50 ms per launch, 52 slots: 51 ms, against 43 ms with everything in LDS).  So LDSN = FIRN.
-#define BMSK_LDSN_1200 80
-template <bool CAPSYM, int FIRN, int LDSN>
-__global__ __launch_bounds__(64) void k_burst_msk_demod(const BGeom g, const BPtrs p, int n, long long n0, int first_of_write)
-{
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *lre = lds, *lim = lds + LDSN * 64;
-    constexpr int TAILN = FIRN - LDSN, TAILA = TAILN > 0 ? TAILN : 1;
-    double tre[TAILA], tim[TAILA]; // tre[j] = x_re[newest - LDSN - j]
-    const int lane = threadIdx.x, grp = blockIdx.x, ch = grp * 64 + lane, nchp = g.nchp;
-    const double2 *__restrict__ cis = p.cis;
-    jd_cdouble *taps = (jd_cdouble *)p.taps2; // this bank's own half-sine taps (burst_host.h) through the constant address space: scalar loads, as from the
-                                              // process-global __constant__ table they replace (through a plain pointer they were vector loads in the filter loop: 4.5 -> 3.6 Gsamples/s)
-    const double SPS = g.SPS, samplerate = g.Fs;
-
-    double m2_ptr = BLDF(BS_M2_PTR), m2_step = BLDF(BS_M2_STEP), m2_freq = BLDF(BS_M2_FREQ), mc_freq = BLDF(BS_MC_FREQ);
-    double st_ptr = BLDF(BS_ST_PTR), st_last = BLDF(BS_ST_LAST), sth_ptr = BLDF(BS_STQ_PTR), vol_gain = BLDF(BS_VOL_GAIN);
-    const double st_step = BLDF(BS_ST_STEP);
-    double str_re = BLDF(BS_STR_RE), str_im = BLDF(BS_STR_IM), sav_re = BLDF(BS_SAV_RE), sav_im = BLDF(BS_SAV_IM);
-    double rot_re = BLDF(BS_ROT_RE), rot_im = BLDF(BS_ROT_IM), rot_freq = BLDF(BS_ROT_FREQ);
-    double agc2_sum = BLDF(BS_AGC2_SUM), eb_esum = BLDF(BS_EB_ESUM), eb_e2sum = BLDF(BS_EB_E2SUM), eb_ebno = BLDF(BS_EB_EBNO);
-    double res_x1 = BLDF(BS_RES_X1), res_x2 = BLDF(BS_RES_X2), res_y1 = BLDF(BS_RES_Y1), res_y2 = BLDF(BS_RES_Y2);
-    double msema_sum = BLDF(BS_MSEMA_SUM), mse = BLDF(BS_MSE), diff_last = BLDF(BS_DIFF_LAST);
-    const double thresh = BLDF(BS_THRESH), lockingbw = BLDF(BS_LOCKINGBW);
-
-    int startstop = BLDI(BI_STARTSTOP), cntr = BLDI(BI_CNTR), msema_pos = BLDI(BI_MSEMA_POS), nrx = BLDI(BI_NRX);
-    int fir_pos = BLDI(BI_FIR_POS), agc2_pos = BLDI(BI_AGC2_POS), eb_pos = BLDI(BI_EB_POS), dly_pos = BLDI(BI_DLY_POS), d8_pos = BLDI(BI_D8_POS), a1_pos = BLDI(BI_A1_POS);
-    int soft_cnt = BLDI(BI_SOFT_CNT), sym_cnt = BLDI(BI_SYM_CNT), ev_cnt = BLDI(BI_EV_CNT), overflow = BLDI(BI_OVERFLOW);
-    const int flags = BLDI(BI_FLAGS);
-    const int ev_pos = BLDI(BI_EV_POS);
-    const bool dcd = flags & JF_DCD, afc = flags & JF_AFC;
-    const bool trace = (g.flags & 8u) != 0;
-    (void)first_of_write;
-
-    const double *__restrict__ cvre = p.cvre + (size_t)grp * g.cv_len * 64 + lane;
-    double *agc2_ring = p.agc2_ring + (size_t)ch * g.agc2_len;
-    double *ebe_ring = p.eb_e + (size_t)ch * g.eb_len, *ebe2_ring = p.eb_e2 + (size_t)ch * g.eb_len;
-    double2 *dly_ring = p.dly + (size_t)ch * g.dly_len;
-    double *d8_ring = p.dly8 + (size_t)ch * g.d8_len;
-    double *a1_ring = p.a1 + (size_t)ch * g.d8_len;
-    double *msema_ring = p.msema + (size_t)ch * g.msema_len;
-    int16_t *__restrict__ soft = p.soft + (size_t)ch * g.soft_cap;
-    {
-        const double *fs = p.firsave + (size_t)ch * 2 * FIRN; // [0, LDSN): the LDS ring's slots, [LDSN, FIRN): the register tail
-        for (int k = 0; k < LDSN; k++) { lre[k * 64 + lane] = fs[k]; lim[k * 64 + lane] = fs[FIRN + k]; }
-#pragma unroll
-        for (int j = 0; j < TAILN; j++) { tre[j] = fs[LDSN + j]; tim[j] = fs[FIRN + LDSN + j]; }
-    }
-    int s_val = (int)((n0 - g.D1 - g.D2 + 8LL * g.cv_len) % g.cv_len);
-    const double agc2_len_d = (double)g.agc2_len, eb_len_d = (double)g.eb_len;
-
-    for (int i = 0; i < n; i++)
-    {
-        const long long sample = n0 + i;
-        // ---- trident verdict (:524-568) ----
-        if (i == ev_pos)
-        {
-            const TriResult tr = p.tri[ch];
-            const bool ok = tr.ok && !(dcd) && !(cntr > 0 && cntr < (500 * SPS));
-            if (trace) bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_TRIDENT, ok ? tr.metric : -tr.metric);
-            if (ok)
-            {
-                vol_gain = tr.vol_gain;
-                bd_set_phase_deg(m2_ptr, tr.phase_deg);
-                jd_wt_setfreq(m2_freq, m2_step, tr.freq, samplerate);
-                // CenterFreqChangedSlot(freq) (:327-343)
-                {
-                    double fc = tr.freq;
-                    if (fc < (0.75 * g.fb)) fc = 0.75 * g.fb;
-                    if (fc > (g.Fs / 2.0 - 0.75 * g.fb)) fc = g.Fs / 2.0 - 0.75 * g.fb;
-                    mc_freq = fc; if (mc_freq < 0) mc_freq = 0;
-                    if (afc) jd_wt_setfreq(m2_freq, m2_step, mc_freq, samplerate);
-                    if ((m2_freq - mc_freq) > (lockingbw / 2.0)) jd_wt_setfreq(m2_freq, m2_step, mc_freq + (lockingbw / 2.0), samplerate);
-                    if ((m2_freq - mc_freq) < (-lockingbw / 2.0)) jd_wt_setfreq(m2_freq, m2_step, mc_freq - (lockingbw / 2.0), samplerate);
-                    bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_FREQ, m2_freq);
-                }
-                bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_FREQ, m2_freq);
-                startstop = g.startstopstart;
-                cntr = 0;
-                bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_SIGNAL, 1.0);
-                soft_cnt -= nrx; nrx = 0; // RxDataBits.clear()
-                if (soft_cnt < g.soft_cap) { soft[soft_cnt++] = (int16_t)-1; nrx = 1; } else overflow |= 1;
-                mse = 0;
-                for (int k = 0; k < g.msema_len; k++) msema_ring[k] = 0;
-                msema_pos = 0; msema_sum = 0;
-                sav_re = 1; sav_im = 0; str_re = 1; str_im = 0;
-                rot_re = 1; rot_im = 0; rot_freq = 0;
-                res_x1 = res_x2 = res_y1 = res_y2 = 0;
-                bd_set_phase_deg(st_ptr, 0);
-                bd_set_phase_deg(sth_ptr, 0);
-            }
-        }
-        const double val = cvre[(size_t)s_val * 64];
-        s_val++; if (s_val >= g.cv_len) s_val = 0;
-        // ---- sample counting (:571-598) ----
-        if (startstop > 0)
-        {
-            if (cntr >= (g.startProcessing * SPS)) startstop--;
-            if (cntr < 1000000) cntr++;
-            if (mse < thresh) startstop = g.startstopstart;
-        }
-        if (startstop == 0)
-        {
-            startstop--;
-            bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_SIGNAL, 0.0);
-            cntr = 0;
-            mse = 1;
-        }
-        if (startstop > 0 || mse < thresh)
-        {
-            const double2 c2 = cis[jd_cisidx(m2_ptr)];
-            // window entries this sample replaces / reads: requested now, consumed behind the filter
-            const double e2_old = ebe2_ring[eb_pos], e_old = ebe_ring[eb_pos], agc2_old = agc2_ring[agc2_pos];
-            const int dly_nx = (dly_pos + 1 >= g.dly_len) ? 0 : dly_pos + 1;
-            const int d8_nx = (d8_pos + 1 >= g.d8_len) ? 0 : d8_pos + 1, d8_nx2 = (d8_nx + 1 >= g.d8_len) ? 0 : d8_nx + 1;
-            const double2 ptd_pre = dly_ring[dly_nx];
-            const double d8_a = d8_ring[d8_nx2], d8_b = d8_ring[d8_nx];
-            const double st_ptr_top = st_ptr;
-            const double2 so_pre = cis[jd_cisidx(st_ptr)]; // the symbol oscillator's table entry: valid unless the preamble block below moves st_ptr
-            const double cre = (c2.x * val) * vol_gain, cim = (c2.y * val) * vol_gain;
-            double sre = 0, sim = 0;
-            {
-                // output from x[n-FIRN .. n-1], taps[t] <-> x[n-FIRN+t], oldest first: the register tail, then the LDS ring from its oldest slot
-#pragma unroll
-                for (int t = 0; t < TAILN; t++)
-                {
-                    const double tp = taps[t];
-                    sre = fma(tp, tre[TAILN - 1 - t], sre);
-                    sim = fma(tp, tim[TAILN - 1 - t], sim);
-                }
-                int slot = fir_pos;
-                constexpr int NB = LDSN / 8, REM = LDSN % 8;
-#pragma unroll 1
-                for (int b = 0; b < NB; b++)
-                {
-                    double xr[8], xi[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++)
-                    {
-                        xr[u] = lre[slot * 64 + lane];
-                        xi[u] = lim[slot * 64 + lane];
-                        slot++; if (slot >= LDSN) slot = 0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u++)
-                    {
-                        const double tp = taps[TAILN + 8 * b + u];
-                        sre = fma(tp, xr[u], sre);
-                        sim = fma(tp, xi[u], sim);
-                    }
-                }
-                if constexpr (REM > 0)
-                {
-                    double xr[REM], xi[REM];
-#pragma unroll
-                    for (int u = 0; u < REM; u++)
-                    {
-                        xr[u] = lre[slot * 64 + lane];
-                        xi[u] = lim[slot * 64 + lane];
-                        slot++; if (slot >= LDSN) slot = 0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < REM; u++)
-                    {
-                        const double tp = taps[TAILN + 8 * NB + u];
-                        sre = fma(tp, xr[u], sre);
-                        sim = fma(tp, xi[u], sim);
-                    }
-                }
-                // push x[n]: the oldest LDS entry moves into the register tail (this block runs under the gate's exec mask)
-                if constexpr (TAILN > 0)
-                {
-#pragma unroll
-                    for (int j = TAILN - 1; j > 0; j--) { tre[j] = tre[j - 1]; tim[j] = tim[j - 1]; }
-                    tre[0] = lre[fir_pos * 64 + lane]; tim[0] = lim[fir_pos * 64 + lane];
-                }
-                lre[fir_pos * 64 + lane] = cre; lim[fir_pos * 64 + lane] = cim;
-                fir_pos++; if (fir_pos >= LDSN) fir_pos = 0;
-            }
-            if (cntr > (g.startProcessing * SPS) && cntr < g.endRotation)
-            {
-                double t_re = sre, t_im = sim;
-                bd_cmul(t_re, t_im, str_re, str_im);
-                bd_cmul(t_re, t_im, 0.0, 1.0);
-                const double er = jd_tanh(t_im) * (t_re);
-                double sn, cs;
-                sincos(er * 0.5, &sn, &cs);
-                bd_cmul(str_re, str_im, cs, sn);
-                sav_re = sav_re * 0.999 + 0.001 * str_re; sav_im = sav_im * 0.999 + 0.001 * str_im;
-                // a1.update(): integer delay SPS/2 -> weighting 0: the value written d8_len-1 updates ago
-                a1_ring[a1_pos] = t_re;
-                a1_pos++; if (a1_pos >= g.d8_len) a1_pos = 0;
-                t_im = 0.0 * a1_ring[(a1_pos + 1 >= g.d8_len) ? 0 : a1_pos + 1] + 1.0 * a1_ring[a1_pos];
-                double progress = (double)cntr - (SPS * (g.startProcessing));
-                const double goal = g.endRotation - (SPS * g.startProcessing);
-                progress = progress / goal;
-                const double2 cq = cis[jd_cisidx(sth_ptr)];
-                const double e_re = cq.x * t_re - cq.y * (-t_im), e_im = cq.x * (-t_im) + cq.y * t_re;
-                double st_err = atan2(e_im, e_re);
-                st_err *= 0.5 * (1.0 - progress * progress);
-                jd_wt_advance_fraction(sth_ptr, -(1.0 / (2.0 * M_PI)) * st_err * 0.05);
-                bd_set_phase_deg(st_ptr, (360.0 * sth_ptr / ((double)JD_WTSIZE)) + (360.0 * (1.0 - g.ee)));
-            }
-            bd_cmul(sre, sim, sav_re, sav_im);
-            {
-                double sn, cs;
-                sincos(rot_freq, &sn, &cs);
-                bd_cmul(rot_re, rot_im, cs, sn);
-            }
-            bd_cmul(sre, sim, rot_re, rot_im);
-            const double sabs = hypot(sre, sim);
-            {
-                const double sq = sabs * sabs;
-                double *e2p = ebe2_ring + eb_pos, *ep = ebe_ring + eb_pos;
-                eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq); *e2p = fabs(sq);
-                eb_esum = eb_esum - e_old; eb_esum = eb_esum + fabs(sabs); *ep = fabs(sabs);
-                eb_pos++; if (eb_pos >= g.eb_len) eb_pos = 0;
-                // the value is observable once per burst (the emission below), at the end of a launch (status) and where the gate closes;
-                // its IIR forgets a term after k samples as 0.8^k, so the arithmetic runs only in the JD_EBNO_TAIL samples before those
-                const int to_emit = (g.endRotation + (int)(200 * SPS)) - cntr;
-                if (i >= n - JD_EBNO_TAIL || (to_emit >= 0 && to_emit < JD_EBNO_TAIL) || startstop <= JD_EBNO_TAIL)
-                {
-                    const double e2val = eb_e2sum / eb_len_d, mean = eb_esum / eb_len_d;
-                    const double var = e2val - (mean * mean);
-                    const double alpha = sqrt(2.0) / mean;
-                    double tebno = 10.0 * (log10(2.0) - log10(((var * alpha * alpha) - 0.0085))) - 5.0;
-                    if (isnan(tebno)) tebno = 50;
-                    if (tebno > 50.0) tebno = 50;
-                    eb_ebno = eb_ebno * 0.8 + 0.2 * tebno;
-                }
-            }
-            if (cntr == g.endRotation + (200 * SPS)) bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_EBNO, eb_ebno);
-            {
-                double *ap = agc2_ring + agc2_pos;
-                agc2_sum = agc2_sum - agc2_old; agc2_sum = agc2_sum + fabs(sabs); *ap = fabs(sabs);
-                agc2_pos++; if (agc2_pos >= g.agc2_len) agc2_pos = 0;
-                double gain = 1.414213562 / fmax(agc2_sum / agc2_len_d, 0.000001);
-                gain = fmax(gain, 0.000001);
-                sre *= gain; sim *= gain;
-            }
-            const double abval = hypot(sre, sim);
-            if (abval > 2.84) { const double k = (2.84 / abval); sre = k * sre; sim = k * sim; }
-            // delayedsmpl.update_dont_touch(sig2)
-            dly_ring[dly_pos] = make_double2(sre, sim);
-            dly_pos = dly_nx;
-            const double2 ptd = ptd_pre; // = dly_ring[dly_pos]: the oldest entry, not the one just written (dly_len >= 2)
-            const double pm_re = sre, pm_im = ptd.y;
-            double st_eta = hypot(pm_re, pm_im);
-            {
-                double y = 0;
-                y += res_x2 * g.res_b2; y += res_x1 * g.res_b1; y += st_eta * g.res_b0;
-                y -= res_y2 * g.res_a2; y -= res_y1 * g.res_a1;
-                res_x2 = res_x1; res_x1 = st_eta; res_y2 = res_y1; res_y1 = y;
-                st_eta = y;
-            }
-            // delayt8.update(st_eta): integer delay SPS/2
-            d8_ring[d8_pos] = st_eta;
-            d8_pos = d8_nx;
-            const double d8out = 0.0 * d8_a + 1.0 * d8_b; // d8_ring[d8_pos + 1] and d8_ring[d8_pos]: older than the entry just written (d8_len >= 3)
-            {
-                double2 so = so_pre;
-                if (st_ptr != st_ptr_top) so = cis[jd_cisidx(st_ptr)];
-                const double m_re = st_eta, m_im = -d8out;
-                const double o_re = so.x * m_re - so.y * m_im, o_im = so.x * m_im + so.y * m_re;
-                const double st_angle_error = atan2(o_im, o_re);
-                if (cntr > g.endRotation) jd_wt_advance_fraction(st_ptr, -st_angle_error * 0.002 / 360.0);
-            }
-            double frac;
-            if (jd_wt_passed(st_last, st_ptr, st_step, g.ee, frac))
-            {
-                const double ct_xt = jd_tanh(sim) * sre;
-                const double ct_xt_d = jd_tanh(ptd.x) * ptd.y;
-                double ct_ec = ct_xt_d - ct_xt;
-                if (ct_ec > M_PI) ct_ec = M_PI;
-                if (ct_ec < -M_PI) ct_ec = -M_PI;
-                if (ct_ec > M_PI_2) ct_ec = M_PI_2;
-                if (ct_ec < -M_PI_2) ct_ec = -M_PI_2;
-                if (cntr > (g.startProcessing * SPS))
-                {
-                    double sn, cs;
-                    sincos(ct_ec * 0.25, &sn, &cs);
-                    bd_cmul(rot_re, rot_im, cs, sn);
-                    if (cntr > g.endRotation) rot_freq = rot_freq + ct_ec * 0.0001;
-                    const double tda = (fabs((pm_re * 0.75)) - 1.0), tdb = (fabs((pm_im * 0.75)) - 1.0);
-                    const double e = (tda * tda) + (tdb * tdb);
-                    double *mp = msema_ring + msema_pos;
-                    msema_sum = msema_sum - *mp; msema_sum = msema_sum + fabs(e); *mp = fabs(e);
-                    msema_pos++; if (msema_pos >= g.msema_len) msema_pos = 0;
-                    mse = msema_sum / ((double)g.msema_len);
-                }
-                if (CAPSYM)
-                {
-                    if (sym_cnt < g.sym_cap) { double *sp = p.sym + ((size_t)ch * g.sym_cap + sym_cnt) * 3; sp[0] = pm_re; sp[1] = pm_im; sp[2] = mse; sym_cnt++; }
-                    else overflow |= 2;
-                }
-                // DiffDecode::UpdateSoft x2 (DSP.cpp:531-563)
-                double imagin, realv;
-                {
-                    const double sf = pm_im;
-                    if (sf < 0 && diff_last < 0) imagin = diff_last;
-                    else if (sf > 0 && diff_last > 0) imagin = -diff_last;
-                    else imagin = fabs(diff_last);
-                    diff_last = sf;
-                }
-                {
-                    const double sf = pm_re;
-                    if (sf < 0 && diff_last < 0) realv = diff_last;
-                    else if (sf > 0 && diff_last > 0) realv = -diff_last;
-                    else realv = fabs(diff_last);
-                    diff_last = sf;
-                }
-                realv = -realv;
-                const int b0 = jd_softbit((imagin) * 127.0 + 128.0);
-                const int b1 = jd_softbit((realv) * 127.0 + 128.0);
-                if (soft_cnt + 2 <= g.soft_cap) { soft[soft_cnt] = (int16_t)b0; soft[soft_cnt + 1] = (int16_t)b1; soft_cnt += 2; nrx += 2; }
-                else overflow |= 1;
-                if (nrx >= 12) nrx = 0;
-            }
-            // st_osc / st_osc_half / mixer2 WTnextFrame (:736-740)
-            st_last = st_ptr;
-            st_ptr += st_step;
-            while (((int)st_ptr) >= JD_WTSIZE) st_ptr -= JD_WTSIZE;
-            sth_ptr += st_step;
-            while (((int)sth_ptr) >= JD_WTSIZE) sth_ptr -= JD_WTSIZE;
-            jd_wt_next(m2_ptr, m2_step);
-        }
-    }
-    BLDF(BS_M2_PTR) = m2_ptr; BLDF(BS_M2_STEP) = m2_step; BLDF(BS_M2_FREQ) = m2_freq; BLDF(BS_MC_FREQ) = mc_freq;
-    BLDF(BS_ST_PTR) = st_ptr; BLDF(BS_ST_LAST) = st_last; BLDF(BS_STQ_PTR) = sth_ptr; BLDF(BS_VOL_GAIN) = vol_gain;
-    BLDF(BS_STR_RE) = str_re; BLDF(BS_STR_IM) = str_im; BLDF(BS_SAV_RE) = sav_re; BLDF(BS_SAV_IM) = sav_im;
-    BLDF(BS_ROT_RE) = rot_re; BLDF(BS_ROT_IM) = rot_im; BLDF(BS_ROT_FREQ) = rot_freq;
-    BLDF(BS_AGC2_SUM) = agc2_sum; BLDF(BS_EB_ESUM) = eb_esum; BLDF(BS_EB_E2SUM) = eb_e2sum; BLDF(BS_EB_EBNO) = eb_ebno;
-    BLDF(BS_RES_X1) = res_x1; BLDF(BS_RES_X2) = res_x2; BLDF(BS_RES_Y1) = res_y1; BLDF(BS_RES_Y2) = res_y2;
-    BLDF(BS_MSEMA_SUM) = msema_sum; BLDF(BS_MSE) = mse; BLDF(BS_DIFF_LAST) = diff_last;
-    BLDI(BI_STARTSTOP) = startstop; BLDI(BI_CNTR) = cntr; BLDI(BI_MSEMA_POS) = msema_pos; BLDI(BI_NRX) = nrx;
-    BLDI(BI_FIR_POS) = fir_pos; BLDI(BI_AGC2_POS) = agc2_pos; BLDI(BI_EB_POS) = eb_pos; BLDI(BI_DLY_POS) = dly_pos; BLDI(BI_D8_POS) = d8_pos; BLDI(BI_A1_POS) = a1_pos;
-    BLDI(BI_SOFT_CNT) = soft_cnt; BLDI(BI_SYM_CNT) = sym_cnt; BLDI(BI_EV_CNT) = ev_cnt; BLDI(BI_OVERFLOW) = overflow;
-    {
-        double *fs = p.firsave + (size_t)ch * 2 * FIRN;
-        for (int k = 0; k < LDSN; k++) { fs[k] = lre[k * 64 + lane]; fs[FIRN + k] = lim[k * 64 + lane]; }
-#pragma unroll
-        for (int j = 0; j < TAILN; j++) { fs[LDSN + j] = tre[j]; fs[FIRN + LDSN + j] = tim[j]; }
-    }
-}
+// k_burst_msk_fb.h (round 3): the tracking chain as a front / back wavefront pair.  The single-wavefront kernel k_burst_msk_demod lived here
+// (rounds 1-2: 78 -> 43 ms per 4096-sample launch of 65 536 channels; what it taught is in that header and in DESIGN 10).

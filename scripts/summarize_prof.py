@@ -28,7 +28,7 @@ def role(name):
         return "sample_loop"
     if "k_coarse" in name:
         return "coarse_freq"
-    for k, r in (("k_burst_front", "front"), ("k_hilbert", "hilbert"), ("k_trident", "trident"), ("k_burst_oqpsk_demod", "demod"), ("k_burst_msk_demod", "demod")):
+    for k, r in (("k_burst_front", "front"), ("k_hilbert", "hilbert"), ("k_trident", "trident"), ("k_burst_oqpsk_demod", "demod"), ("k_burst_msk_fb", "demod")):
         if k in name:
             return r
     return None

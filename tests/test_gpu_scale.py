@@ -403,7 +403,7 @@ def test_msk_family_banks_alive_together(B, oracle_mod):
 
 
 def test_burst_msk_65536_channels(B, oracle_mod):
-    """The bank `bench.py --workload burst_msk` times: 65 536 channels of 1200 bps burst MSK (k_burst_msk_demod in two residency rounds,
+    """The bank `bench.py --workload burst_msk` times: 65 536 channels of 1200 bps burst MSK (k_burst_msk_fb pairs in two residency rounds,
     per-lane ring positions, k_trident's persistent workgroups).  37 distinct streams with their bursts at different offsets, channel c
     carries stream (5 c) mod 37; 20 spread channels against the oracle run of their stream: soft bits with markers, events."""
     import torch
