@@ -364,7 +364,7 @@ def test_msk_live_set_settings(B, oracle_mod):
     bank.close()
 
 
-@pytest.mark.parametrize("fb0,fb1,nch", [(8400, 10500, 3), (8400, 8400, 1), (10500, 8400, 2)])
+@pytest.mark.parametrize("fb0,fb1,nch", [(8400, 10500, 3), (8400, 8400, 1), (10500, 8400, 2), (10500, 8400, 130), (8400, 10500, 67)])
 def test_oqpsk_live_rate_change_carries_state_over(B, oracle_mod, fb0, fb1, nch):
     """setSettings with another bit rate on a running bank: the reference rebuilds AGC, filters, delays, resonator and
     the 8400 bps prefilter inside the old object and KEEPS oscillator phases, loop states, the symbol-rate windows, the coarse ring and the
@@ -384,7 +384,7 @@ def test_oqpsk_live_rate_change_carries_state_over(B, oracle_mod, fb0, fb1, nch)
     feed(bank, pcm[:, :set_at], chunk)
     bank.set_settings(bank_settings("oqpsk", o1), channel=-1 if nch > 1 else 0)  # nothing was read yet: the outputs so far move to the new bank
     feed(bank, pcm[:, set_at:], chunk)
-    for c in range(nch):
+    for c in (range(nch) if nch <= 8 else sorted({0, 1, 62, 63, 64, nch - 1})):  # (several channel groups: the padding lanes carry state too)
         ref = O.run_demod(oracle_settings(O, "oqpsk", o0), pcm[c], chunk=chunk, capture_symbols=True, set_at=set_at,
                           set_settings=oracle_settings(O, "oqpsk", o1))
         soft, sym, log = bank.read_softbits(c), bank.read_symbols(c), bank.read_status_log(c)
