@@ -9,6 +9,7 @@
 #include "k_coarse5.h"
 #include "k_coarse4.h"
 #include "../../jaero_amd/csrc/k_coarse6.h"
+#include "k_coarse7.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -60,9 +61,21 @@ __global__ __launch_bounds__(C2_THREADS) void k_fft_test6(const double2 *x, doub
     CV<32> d;
 #pragma unroll
     for (int s = 0; s < 32; s++) { const double2 v = x[s * 512 + t]; d.r[s] = v.x; d.i[s] = v.y; }
-    c6_fft(d, xch, tw, t);
+    c6_fft<14>(d, xch, tw, t);
 #pragma unroll
     for (int s = 0; s < 32; s++) X[s * 512 + t] = make_double2(d.r[s], d.i[s]);
+}
+
+__global__ __launch_bounds__(256) void k_fft_test7(const double2 *x, double2 *X, const double2 *tw)
+{
+    extern __shared__ __attribute__((aligned(16))) double xch[];
+    const int t = threadIdx.x;
+    CV<64> d;
+#pragma unroll
+    for (int s = 0; s < 64; s++) { const double2 v = x[s * 256 + t]; d.r[s] = v.x; d.i[s] = v.y; }
+    wg_fft14_e64(d, xch, tw, t);
+#pragma unroll
+    for (int s = 0; s < 64; s++) X[s * 256 + t] = make_double2(d.r[s], d.i[s]);
 }
 
 static void host_fft(std::vector<double> &re, std::vector<double> &im)

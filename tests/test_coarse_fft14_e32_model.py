@@ -148,3 +148,92 @@ def test_fft13_maps_transform_and_banks():
     for a in maps:
         for q in range(16):   # 4 wavefronts x 4 groups of 16 lanes
             assert len(set((a[16 * q:16 * q + 16] % 16).tolist())) == 16
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# wg_fft14_e64 (scripts/ubench/k_coarse7.h, an experiment that did not reach the library: its 64-point pass does not fit 256 registers):
+# 16384 = 64 x 16 x 16 on 256 threads with 64 points each, so that TWO workgroups share a CU (64 KiB of LDS each:
+# every exchange moves a plane in two halves).  n = 256 n1 + 16 n2 + n3, k = k1 + 64 k2 + 1024 k3; natural in and out (slot = index >> 8,
+# thread = index & 255).  A 64-point register FFT = a radix-4 stage + four 16-point FFTs; its outputs stay in SPLIT-4 order: slot 16 m + q
+# holds X[4 q + m].
+N64 = 16384
+T64 = np.arange(256)
+TW64 = np.exp(-2j * np.pi * np.arange(N64) / N64)
+
+
+def K4(s):
+    """index held by slot s after a split-4-order 64-point FFT"""
+    return 4 * (s & 15) + (s >> 4)
+
+
+def fft64_split(d):
+    o = np.fft.fft(d, axis=1)
+    return np.stack([o[:, K4(s)] for s in range(64)], axis=1)
+
+
+def e64_ex1_write(k1):       # half = k1 >> 5; pass-1 thread t = 16 n2 + n3
+    return (k1 & 31) * 256 + T64
+
+
+def e64_ex1_read(g, n2):     # pass-2 thread (k1a = t >> 4, n3 = t & 15), group g: k1 = k1a + 16 g (half g >> 1)
+    return ((T64 >> 4) + 16 * (g & 1)) * 256 + 16 * n2 + (T64 & 15)
+
+
+def e64_ex2_write(g, k2):    # pass-2 thread (k1a, n3) holds (g, k2): L = k1 + 64 (k2 & 7) + 513 n3, half = k2 >> 3
+    return (T64 >> 4) + 16 * g + 64 * (k2 & 7) + 513 * (T64 & 15)
+
+
+def e64_ex2_read(h, n3):     # pass-3 thread t3 = k1 + 64 k2lo, group h: k2 = k2lo + 4 h (half h >> 1)
+    return T64 + 256 * (h & 1) + 513 * n3
+
+
+def model_fft64(x):
+    d = x.reshape(64, 256).T.copy()                                   # d[t, slot] = x[slot*256 + t]
+    o = fft64_split(d) * np.stack([TW64[T64] ** K4(s) for s in range(64)], axis=1)   # W_N^(k1 (n mod 256)), slot s holds k1 = K4(s)
+    d2 = np.zeros((256, 64), complex)                                 # slot 16 g + n2
+    for half in range(2):
+        L = np.full(8192, np.nan, complex)
+        for s in range(64):
+            if K4(s) >> 5 == half:
+                L[e64_ex1_write(K4(s))] = o[:, s]
+        for g in range(4):
+            if g >> 1 == half:
+                for n2 in range(16):
+                    d2[:, 16 * g + n2] = L[e64_ex1_read(g, n2)]
+    k16 = np.arange(16)[None, :]
+    o = np.concatenate([np.fft.fft(d2[:, 16 * g:16 * g + 16], axis=1) * TW64[64 * (T64 & 15)][:, None] ** k16 for g in range(4)], axis=1)  # W_256^(k2 n3)
+    d3 = np.zeros((256, 64), complex)                                 # slot 16 h + n3
+    for half in range(2):
+        L = np.full(8208, np.nan, complex)
+        for g in range(4):
+            for k2 in range(16):
+                if k2 >> 3 == half:
+                    L[e64_ex2_write(g, k2)] = o[:, 16 * g + k2]
+        for h in range(4):
+            if h >> 1 == half:
+                for n3 in range(16):
+                    d3[:, 16 * h + n3] = L[e64_ex2_read(h, n3)]
+    out = np.zeros((256, 64), complex)
+    for h in range(4):
+        o3 = np.fft.fft(d3[:, 16 * h:16 * h + 16], axis=1)
+        for k3 in range(16):
+            out[:, 4 * k3 + h] = o3[:, k3]                            # k = t3 + 256 h + 1024 k3 -> natural slot h + 4 k3
+    return out.T.reshape(N64)
+
+
+def test_fft64_maps_transform_and_banks():
+    for half in range(2):
+        w = np.concatenate([e64_ex1_write(k1) for k1 in range(64) if k1 >> 5 == half])
+        r = np.concatenate([e64_ex1_read(g, n2) for g in range(4) if g >> 1 == half for n2 in range(16)])
+        assert sorted(w) == list(range(8192)) and sorted(r) == list(range(8192))
+        w = np.concatenate([e64_ex2_write(g, k2) for g in range(4) for k2 in range(16) if k2 >> 3 == half])
+        r = np.concatenate([e64_ex2_read(h, n3) for h in range(4) if h >> 1 == half for n3 in range(16)])
+        assert len(set(w.tolist())) == 8192 and sorted(w) == sorted(r) and w.max() < 8208
+    rng = np.random.default_rng(64)
+    x = rng.standard_normal(N64) + 1j * rng.standard_normal(N64)
+    assert np.max(np.abs(model_fft64(x) - np.fft.fft(x))) < 1e-8
+    maps = [e64_ex1_write(k1) for k1 in range(64)] + [e64_ex1_read(g, n2) for g in range(4) for n2 in range(16)]
+    maps += [e64_ex2_write(g, k2) for g in range(4) for k2 in range(16)] + [e64_ex2_read(h, n3) for h in range(4) for n3 in range(16)]
+    for a in maps:
+        for q in range(16):
+            assert len(set((a[16 * q:16 * q + 16] % 16).tolist())) == 16
