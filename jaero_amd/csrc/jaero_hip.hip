@@ -171,7 +171,6 @@ struct jaero_ctx
     bool burst = false;
     BGeom bg{};
     BPtrs bp{};
-    TriScratch *d_tri_scratch = nullptr;
     int tri_grid = 0, tri_lds = 0;
     long long nsamples_total = 0; // samples written so far (uniform ring slots and event time stamps derive from it)
     // generic views of the per-channel output buffers (either kind)

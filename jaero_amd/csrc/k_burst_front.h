@@ -284,33 +284,56 @@ __global__ __launch_bounds__(64) void k_burst_front(const BGeom g, const BPtrs p
 // window, run register-resident with wg_fft<14> (k_coarse2.h).  Only bins below N/2 are ever read by the reference.
 #define TRI_N 32768
 #define TRI_H 16384
-struct TriScratch { double2 base[TRI_H]; double d[TRI_H]; };
 
-__device__ __forceinline__ void tri_argmax_first(double v, int idx, double *red_val, int *red_idx, int t)
+// first maximum over the workgroup: the largest value, among equals the lowest index (what an ascending scan with a strict compare keeps);
+// idx < 0 = "no candidate".  Wavefront reduction through shuffles, one LDS round for the eight wavefront results.  All threads get the result.
+__device__ __forceinline__ void tri_argmax_first(double &v, int &idx, double *red_val, int *red_idx, int t)
 {
-    red_val[t] = v; red_idx[t] = idx;
-    __syncthreads();
-    for (int s = C2_THREADS / 2; s > 0; s >>= 1)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
     {
-        if (t < s)
-        {
-            const double ov = red_val[t + s]; const int oi = red_idx[t + s];
-            const double mv = red_val[t]; const int mi = red_idx[t];
-            if (oi >= 0 && (mi < 0 || ov > mv || (ov == mv && oi < mi))) { red_val[t] = ov; red_idx[t] = oi; }
-        }
-        __syncthreads();
+        const double ov = __shfl_xor(v, off, 64);
+        const int oi = __shfl_xor(idx, off, 64);
+        if (oi >= 0 && (idx < 0 || ov > v || (ov == v && oi < idx))) { v = ov; idx = oi; }
+    }
+    __syncthreads(); // the previous reduction's results have been read
+    if ((t & 63) == 0) { red_val[t >> 6] = v; red_idx[t >> 6] = idx; }
+    __syncthreads();
+    v = red_val[0]; idx = red_idx[0];
+#pragma unroll
+    for (int w = 1; w < C2_THREADS / 64; w++)
+    {
+        const double ov = red_val[w];
+        const int oi = red_idx[w];
+        if (oi >= 0 && (idx < 0 || ov > v || (ov == v && oi < idx))) { v = ov; idx = oi; }
     }
 }
 
-__global__ __launch_bounds__(C2_THREADS) void k_trident(const BGeom g, const BPtrs p, TriScratch *scratch, long long n0)
+// One workgroup per event (persistent over the device-side event list).  Round 3: the spectra never leave the chip (before, both went through
+// a global scratch between barrier-separated loops: ~1 MB written and read per event, 54-94 GB per busy launch).  The eight 2^13-point
+// transforms of an event (X[4q + r] for the base and the top window, r = 0 .. 3) leave bin k = 4 (s * 512 + t) + r of BOTH windows in the same
+// register of the same thread.  The strongest base bin is tracked on the fly with its complex value (first maximum: ties go to the lower bin).
+//   burst OQPSK: the trident sum d[k - b] + d[k + b] - d[k], d = |top| - |base|, has b = round(fb / 4 / hzperbin) = 1792 = 4 x 448 at the one
+//     rate this demodulator exists for (10.5 kbps at 48 kHz; burst_create refuses anything else), so it only combines bins of ONE residue
+//     class r: passes run base r, top r, the eight |base| values of a thread wait in registers, the class's 4096 differences go through
+//     LDS (32 KiB behind the exchange buffer) and are searched at once.
+//   burst MSK: d = |top| and the two searches are per-bin conditions around the strongest base bin: four base passes, the reduction, four top
+//     passes whose candidates are tracked on the fly.  Nothing is stored at all.
+#define TRI_DL 4096 // doubles of LDS behind wg_fft<13>'s exchange buffer (8704 doubles)
+#define TRI_XCH 8704
+__global__ __launch_bounds__(C2_THREADS) void k_trident(const BGeom g, const BPtrs p, long long n0)
 {
-    extern __shared__ __attribute__((aligned(16))) double xch[];
-    __shared__ double red_val[C2_THREADS];
-    __shared__ int red_idx[C2_THREADS];
+    extern __shared__ __attribute__((aligned(16))) double xch[]; // TRI_XCH + TRI_DL doubles
+    __shared__ double red_val[C2_THREADS / 64];
+    __shared__ int red_idx[C2_THREADS / 64];
+    __shared__ double sh_bb[2];
+    double *dl = xch + TRI_XCH;
     const int t = threadIdx.x, nchp = g.nchp;
     const int nev = *p.ev_count;
-    TriScratch *sc = scratch + blockIdx.x;
     const bool oq = g.kind == JAERO_KIND_BURST_OQPSK_D;
+    const double hzperbin = g.Fs / ((double)TRI_N);
+    const int b = jd_qround((0.25 * g.fb) / hzperbin), b4 = b >> 2;       // OQPSK: 1792, 448
+    const int psb = jd_qround((0.5 * g.fb) / hzperbin);                   // MSK
     for (int li = blockIdx.x; li < nev; li += gridDim.x)
     {
         const int ch = p.ev_list[li];
@@ -319,13 +342,28 @@ __global__ __launch_bounds__(C2_THREADS) void k_trident(const BGeom g, const BPt
         // window: cval_d[e - tri_sz + k] = cv[e - tri_sz - D1 + k], e = n0 + evp
         const long long w0 = n0 + evp - g.tri_sz - g.D1 + 8LL * g.cv_len;
         const double *__restrict__ cvre = p.cvre + (size_t)grp * g.cv_len * 64 + lane;
+        double mag[8];                          // OQPSK: |base[k]| of this thread's bins of the current class
+        double bv = -1.0, bre = 0.0, bim = 0.0; // strongest base bin of this thread ...
+        int bi = -1;
+        double minval = 0.0;                    // ... and of the event (MSK: known after the fourth pass)
+        int minvalbin = 0;
+        double mv = 0.0; int mi = -1;           // OQPSK: largest trident sum
+        double lv = 0.0; int lidx = -1;         // MSK: strongest top bin below / above the strongest base bin
+        double hv = 0.0; int hidx = -1;
         // X[4q + r] = sum_{n<8192} (x[n] + x[n+8192] (-j)^r) W_32768^(n r) W_8192^(n q): four 2^13-point transforms per window (the
-        // windows are <= 2^14 samples followed by zeros).  2^13 points over 512 threads = 16 per thread: wg_fft<13> runs without
-        // spilling, unlike the 32-points-per-thread 2^14 transform.  Only bins below N/2 are needed: q < 4096 (slots s < 8).
+        // windows are <= 2^14 samples followed by zeros).  2^13 points over 512 threads = 16 per thread (wg_fft<13>).  Only bins below
+        // N/2 are needed: q < 4096 (slots s < 8).
         for (int pass = 0; pass < 8; pass++)
         {
-            const int which = pass >> 2, r = pass & 3; // which: 0 base, 1 top
+            const int which = oq ? (pass & 1) : (pass >> 2), r = oq ? (pass >> 1) : (pass & 3); // which: 0 base, 1 top
             const int off = which ? g.nb : 0, len = which ? g.nt : g.nb;
+            if (!oq && pass == 4)
+            {
+                minval = bv; minvalbin = bi;
+                tri_argmax_first(minval, minvalbin, red_val, red_idx, t);
+                if (bi == minvalbin) { sh_bb[0] = bre; sh_bb[1] = bim; } // exactly one thread holds that bin
+                if (!(minval > 0.0)) minvalbin = 0; // MSK starts from minval = 0 with a strict compare
+            }
             CV<16> d;
             const int slot0 = (int)((w0 + off) % g.cv_len); // wave-uniform; off + len <= tri_sz < cv_len: at most one wrap below
 #pragma unroll
@@ -357,54 +395,60 @@ __global__ __launch_bounds__(C2_THREADS) void k_trident(const BGeom g, const BPt
             }
             wg_fft<13>(d, xch, p.tw14, t);
             // thread t slot s holds X[4 (s*512 + t) + r]
-#pragma unroll
-            for (int s = 0; s < 8; s++)
+            if (which == 0)
             {
-                const int k = 4 * (s * C2_THREADS + t) + r;
-                if (which == 0) sc->base[k] = make_double2(d.r[s], d.i[s]);
-                else
+#pragma unroll
+                for (int s = 0; s < 8; s++)
                 {
-                    const double2 b = sc->base[k];
-                    const double at = hypot(d.r[s], d.i[s]);
-                    sc->d[k] = oq ? (at - hypot(b.x, b.y)) : at;
+                    const int k = 4 * (s * C2_THREADS + t) + r;
+                    const double a = hypot(d.r[s], d.i[s]);
+                    mag[s] = a;
+                    if (a > bv || (a == bv && k < bi)) { bv = a; bi = k; bre = d.r[s]; bim = d.i[s]; }
                 }
             }
-            __syncthreads();
+            else if (oq)
+            {
+#pragma unroll
+                for (int s = 0; s < 8; s++) dl[s * C2_THREADS + t] = hypot(d.r[s], d.i[s]) - mag[s]; // d[4 q + r] at q
+                __syncthreads();
+                // firstbin = b <= k < lstbin = N/2 - b, k = 4 q + r:  b4 <= q < 4096 - b4 for every r (b is a multiple of 4)
+                for (int q = b4 + t; q < (TRI_H >> 2) - b4; q += C2_THREADS)
+                {
+                    const double tv = dl[q - b4] + dl[q + b4] - dl[q];
+                    const int k = 4 * q + r;
+                    if (mi < 0 || tv > mv || (tv == mv && k < mi)) { mv = tv; mi = k; }
+                }
+            }
+            else
+            {
+#pragma unroll
+                for (int s = 0; s < 8; s++)
+                {
+                    const int k = 4 * (s * C2_THREADS + t) + r;
+                    if (k > 50)
+                    {
+                        const double a = hypot(d.r[s], d.i[s]);
+                        if ((k < minvalbin - (psb / 2)) && (a > lv || (a == lv && lidx >= 0 && k < lidx))) { lv = a; lidx = k; }
+                        if ((k > minvalbin + (psb / 2)) && (a > hv || (a == hv && hidx >= 0 && k < hidx))) { hv = a; hidx = k; }
+                    }
+                }
+            }
         }
-        __threadfence_block();
-        __syncthreads();
-        const double hzperbin = g.Fs / ((double)TRI_N);
-        // strongest base bin: first maximum over [0, N/2)
-        double bv = -1.0; int bi = -1;
-        for (int k = t; k < TRI_H; k += C2_THREADS)
-        {
-            const double2 b = sc->base[k];
-            const double a = hypot(b.x, b.y);
-            if (a > bv) { bv = a; bi = k; }
-        }
-        tri_argmax_first(bv, bi, red_val, red_idx, t);
-        const double minval = red_val[0];
-        const int minvalbin = (minval > 0.0) ? red_idx[0] : 0; // MSK starts from minval = 0 with a strict compare
-        __syncthreads();
         TriResult res;
         res.pad = 0;
         if (oq)
         {
-            const int b = jd_qround((0.25 * g.fb) / hzperbin);
-            const int firstbin = b, lstbin = TRI_H - b;
-            double mv = 0.0; int mi = -1;
-            for (int k = firstbin + t; k < lstbin; k += C2_THREADS)
-            {
-                const double tv = sc->d[k - b] + sc->d[k + b] - sc->d[k];
-                if (mi < 0 || tv > mv) { mv = tv; mi = k; }
-            }
-            tri_argmax_first(mv, mi, red_val, red_idx, t);
-            const double maxval = red_val[0];
-            const int maxvalbin = red_idx[0];
-            __syncthreads();
+            minval = bv; minvalbin = bi;
+            tri_argmax_first(minval, minvalbin, red_val, red_idx, t);
+            if (bi == minvalbin) { sh_bb[0] = bre; sh_bb[1] = bim; }
+            if (!(minval > 0.0)) minvalbin = 0;
+            tri_argmax_first(mv, mi, red_val, red_idx, t); // (its barriers also publish sh_bb)
+            const double maxval = mv;
+            const int maxvalbin = mi;
             res.ok = (maxval > 500.0) && (fabs((((double)(maxvalbin - minvalbin))) * hzperbin) < 20.0);
-            const double2 bb = sc->base[minvalbin];
-            const double carrierphase = atan2(bb.y, bb.x) - (M_PI / 4.0);
+            // with an all-zero base window base[0] = 0 stands in, as in the reference
+            const double bbx = (minval > 0.0) ? sh_bb[0] : 0.0, bby = (minval > 0.0) ? sh_bb[1] : 0.0;
+            const double carrierphase = atan2(bby, bbx) - (M_PI / 4.0);
             res.freq = hzperbin * (double)minvalbin;
             res.phase_deg = (180.0 / M_PI) * carrierphase;
             res.vol_gain = 1.4142 * 500.0 / minval;
@@ -412,34 +456,20 @@ __global__ __launch_bounds__(C2_THREADS) void k_trident(const BGeom g, const BPt
         }
         else
         {
-            const int psb = jd_qround((0.5 * g.fb) / hzperbin);
-            double lv = 0.0; int lidx = -1;
-            double hv = 0.0; int hidx = -1;
-            for (int k = t; k < TRI_H; k += C2_THREADS)
-            {
-                if (k > 50)
-                {
-                    const double a = sc->d[k];
-                    if ((k < minvalbin - (psb / 2)) && a > lv) { lv = a; lidx = k; }
-                    if ((k > minvalbin + (psb / 2)) && a > hv) { hv = a; hidx = k; }
-                }
-            }
             tri_argmax_first(lv, lidx, red_val, red_idx, t);
-            const int maxtoppos = (red_idx[0] >= 0) ? red_idx[0] : 0;
-            __syncthreads();
+            const int maxtoppos = (lidx >= 0) ? lidx : 0;
             tri_argmax_first(hv, hidx, red_val, red_idx, t);
-            const int maxtopposhigh = (red_idx[0] >= 0) ? red_idx[0] : 0;
-            __syncthreads();
+            const int maxtopposhigh = (hidx >= 0) ? hidx : 0;
             const int distfrompeak = abs(maxtoppos - minvalbin);
             res.ok = (minval > 500.0) && (abs(distfrompeak - psb) < abs(psb / 20));
-            const double2 bb = sc->base[minvalbin];
-            const double carrierphase = atan2(bb.y, bb.x) - (M_PI / 4.0);
+            const double bbx = (minval > 0.0) ? sh_bb[0] : 0.0, bby = (minval > 0.0) ? sh_bb[1] : 0.0;
+            const double carrierphase = atan2(bby, bbx) - (M_PI / 4.0);
             res.freq = ((double)((maxtopposhigh + maxtoppos) / 2)) * hzperbin;
             res.phase_deg = (180.0 / M_PI) * carrierphase;
             res.vol_gain = 1.4142 * (500.0 / (minval / 3));
             res.metric = minval;
         }
         if (t == 0) p.tri[ch] = res;
-        __syncthreads();
+        __syncthreads(); // sh_bb and the reduction words are free for the next event
     }
 }

@@ -420,3 +420,25 @@ def test_msk_live_rate_change_carries_state_over(B, oracle_mod, Fs0, fb0, Fs1, f
                           set_settings=oracle_settings(O, "msk", o1))
         compare(bank.read_softbits(c), bank.read_symbols(c), bank.read_status_log(c), ref)
     bank.close()
+
+
+def test_live_rate_change_keeps_flags_and_dcd(B, oracle_mod):
+    """AFC and the DCD input are members the reference's setSettings does not touch: after a re-created bank (8400 -> 10500 bps) the channel
+    still runs with AFC on and DCD set, as the oracle object that got the same calls."""
+    from jaero_amd import signalgen as G
+
+    O = oracle_mod
+    nsamp, set_at, dcd_at, chunk = 200000, 24576, 12288, 4096
+    pcm, _ = G.oqpsk(nsamp, fc=8031.0, ebno_db=15.0, seed=G.SEED_BASE + 7300)
+    o0, o1 = {"fb": 8400.0, "lockingbw": 8400.0}, {"fb": 10500.0, "lockingbw": 10500.0}
+    bank = B.DemodulatorBank([bank_settings("oqpsk", o0)], ebno=True, status_log=True, capture_symbols=True, max_write_samples=chunk,
+                             softbit_capacity=nsamp)
+    bank.set_flags(afc=True)
+    feed(bank, pcm.reshape(1, -1)[:, :set_at], chunk, dcd_at=dcd_at)
+    bank.set_settings(bank_settings("oqpsk", o1), channel=0)
+    feed(bank, pcm.reshape(1, -1)[:, set_at:], chunk)
+    ref = O.run_demod(oracle_settings(O, "oqpsk", o0), pcm, chunk=chunk, afc=True, dcd_at=dcd_at, capture_symbols=True, set_at=set_at,
+                      set_settings=oracle_settings(O, "oqpsk", o1))
+    assert np.ptp(ref["status"][:, 2]) > 1.0  # AFC moved freq_center in the reference run: the flag matters on this input
+    compare(bank.read_softbits(0), bank.read_symbols(0), bank.read_status_log(0), ref)
+    bank.close()
