@@ -76,6 +76,10 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
     double stq_ptr = BLDF(BS_STQ_PTR), vol_gain = BLDF(BS_VOL_GAIN);
     double str_re = BLDF(BS_STR_RE), str_im = BLDF(BS_STR_IM), sav_re = BLDF(BS_SAV_RE), sav_im = BLDF(BS_SAV_IM);
     double rot_re = BLDF(BS_ROT_RE), rot_im = BLDF(BS_ROT_IM), rot_freq = BLDF(BS_ROT_FREQ);
+    // cis(rot_freq), formed where rot_freq changes (verdict, symbol instants) instead of in every sample: the same function of the same
+    // argument, off the per-sample chain (the instant block runs in nearly every sample anyway, and there this sincos overlaps the other one)
+    double rfs, rfc;
+    sincos(rot_freq, &rfs, &rfc);
     double a1_1 = BLDF(BS_A1_1), a1_2 = BLDF(BS_A1_2), a1_3 = BLDF(BS_A1_3), a1_4 = BLDF(BS_A1_4), a1_5 = BLDF(BS_A1_5);
     double agc2_sum = BLDF(BS_AGC2_SUM), eb_esum = BLDF(BS_EB_ESUM), eb_e2sum = BLDF(BS_EB_E2SUM), eb_ebno = BLDF(BS_EB_EBNO);
     double d1 = BLDF(BS_D1), d41_1 = BLDF(BS_D41_1), d41_2 = BLDF(BS_D41_2), d41_3 = BLDF(BS_D41_3);
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
                 cntr = 0;
                 rot_re = 1; rot_im = 0;
                 insertpre = 1;
-                rot_freq = 0;
+                rot_freq = 0; rfs = 0.0; rfc = 1.0; // = sincos(0)
                 sav_re = 1; sav_im = 0;
                 bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_SIGNAL, 1.0);
                 mse = 0;
@@ -158,6 +162,10 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
         }
         // ---- mix + rrc (:517-521) ----
         const double2 c2 = cis[jd_cisidx(m2_ptr)];
+        // the symbol oscillator's table entry, needed by the timing loop far below: requested here, under the matched filter (valid unless the
+        // preamble block moves st_ptr in between; asked for where it is used it was an L2 round trip on every sample's chain)
+        const double st_ptr_top = st_ptr;
+        const double2 so_pre = cis[jd_cisidx(st_ptr)];
         const double xin = (vol_gain * val);
         const double cre = c2.x * xin, cim = c2.y * xin;
         double sre = 0, sim = 0;
@@ -210,11 +218,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
         }
         // ---- carrier phase correction, EbNo, AGC, clip (:570-590) ----
         bd_cmul(sre, sim, sav_re, sav_im);
-        {
-            double sn, cs;
-            sincos(rot_freq, &sn, &cs);
-            bd_cmul(rot_re, rot_im, cs, sn);
-        }
+        bd_cmul(rot_re, rot_im, rfc, rfs);
         bd_cmul(sre, sim, rot_re, rot_im);
         const double sig2abs = hypot(sre, sim);
         {
@@ -268,7 +272,8 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
         }
         const double d8out = w8 * d8_1 + w8c * d8_2; d8_2 = d8_1; d8_1 = st_eta;
         {
-            const double2 so = cis[jd_cisidx(st_ptr)];
+            double2 so = so_pre;
+            if (st_ptr != st_ptr_top) so = cis[jd_cisidx(st_ptr)];
             const double m_re = st_eta, m_im = -d8out;
             const double o_re = so.x * m_re - so.y * m_im, o_im = so.x * m_im + so.y * m_re;
             const double st_angle_error = atan2(o_im, o_re);
@@ -310,6 +315,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
                     sincos(ct_ec * 0.1, &sn, &cs);
                     bd_cmul(rot_re, rot_im, cs, sn);
                     rot_freq = rot_freq + ct_ec * 0.0001;
+                    sincos(rot_freq, &rfs, &rfc);
                     const double tda = (fabs(q_re) - 1.0), tdb = (fabs(q_im) - 1.0);
                     const double e = (tda * tda) + (tdb * tdb);
                     double *mp = msema_ring + msema_pos;

@@ -145,6 +145,8 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
     const double st_step = BLDF(BS_ST_STEP);
     double str_re = BLDF(BS_STR_RE), str_im = BLDF(BS_STR_IM), sav_re = BLDF(BS_SAV_RE), sav_im = BLDF(BS_SAV_IM);
     double rot_re = BLDF(BS_ROT_RE), rot_im = BLDF(BS_ROT_IM), rot_freq = BLDF(BS_ROT_FREQ);
+    double rfs, rfc; // cis(rot_freq), formed where rot_freq changes instead of in every gated sample (k_burst_demod.h)
+    sincos(rot_freq, &rfs, &rfc);
     double agc2_sum = BLDF(BS_AGC2_SUM), eb_esum = BLDF(BS_EB_ESUM), eb_e2sum = BLDF(BS_EB_E2SUM), eb_ebno = BLDF(BS_EB_EBNO);
     double res_x1 = BLDF(BS_RES_X1), res_x2 = BLDF(BS_RES_X2), res_y1 = BLDF(BS_RES_Y1), res_y2 = BLDF(BS_RES_Y2);
     double msema_sum = BLDF(BS_MSEMA_SUM), mse = BLDF(BS_MSE), diff_last = BLDF(BS_DIFF_LAST);
@@ -205,7 +207,7 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
                 for (int k = 0; k < g.msema_len; k++) msema_ring[k] = 0;
                 msema_pos = 0; msema_sum = 0;
                 sav_re = 1; sav_im = 0; str_re = 1; str_im = 0;
-                rot_re = 1; rot_im = 0; rot_freq = 0;
+                rot_re = 1; rot_im = 0; rot_freq = 0; rfs = 0.0; rfc = 1.0;
                 res_x1 = res_x2 = res_y1 = res_y2 = 0;
                 bd_set_phase_deg(st_ptr, 0);
                 bd_set_phase_deg(sth_ptr, 0);
@@ -278,11 +280,7 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
                 bd_set_phase_deg(st_ptr, (360.0 * sth_ptr / ((double)JD_WTSIZE)) + (360.0 * (1.0 - g.ee)));
             }
             bd_cmul(sre, sim, sav_re, sav_im);
-            {
-                double sn, cs;
-                sincos(rot_freq, &sn, &cs);
-                bd_cmul(rot_re, rot_im, cs, sn);
-            }
+            bd_cmul(rot_re, rot_im, rfc, rfs);
             bd_cmul(sre, sim, rot_re, rot_im);
             const double sabs = hypot(sre, sim);
             {
@@ -356,7 +354,7 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
                     double sn, cs;
                     sincos(ct_ec * 0.25, &sn, &cs);
                     bd_cmul(rot_re, rot_im, cs, sn);
-                    if (cntr > g.endRotation) rot_freq = rot_freq + ct_ec * 0.0001;
+                    if (cntr > g.endRotation) { rot_freq = rot_freq + ct_ec * 0.0001; sincos(rot_freq, &rfs, &rfc); }
                     const double tda = (fabs((pm_re * 0.75)) - 1.0), tdb = (fabs((pm_im * 0.75)) - 1.0);
                     const double e = (tda * tda) + (tdb * tdb);
                     double *mp = msema_ring + msema_pos;
