@@ -7,9 +7,6 @@
 #include "burst_device.h"
 #include "jaero_device.h"
 #include "k_burst_front.h"
-#ifndef BURST_ABL_NOFIR
-#define BURST_ABL_NOFIR 0 // timing experiment only (wrong results): the matched filters' evaluation removed = the most a front / back split could hide
-#endif
 #include "k_oqpsk_fb.h" // jd_div_const, fb_wt_setfreq, fb_fmod360: exact rewrites (bit-identical results, fewer instructions)
 
 __device__ __forceinline__ void bd_set_phase_deg(double &ptr, double phase_deg) // WaveTable::SetPhaseDeg (DSP.cpp:175-180)
@@ -171,8 +168,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
         double sre = 0, sim = 0;
         {
             // output from x[n-FIRN .. n-1] (FIR::FIRUpdateAndProcess excludes the sample being pushed): taps[i] <-> x[n-FIRN+i]
-            if (!BURST_ABL_NOFIR) jd_fir_eval<FIRN, LDSN, 8>(lre, lim, ltap, tre, tim, fir_slot, lane, sre, sim);
-            else { sre = lre[fir_slot * 64 + lane]; sim = lim[fir_slot * 64 + lane]; }
+            jd_fir_eval<FIRN, LDSN, 8>(lre, lim, ltap, tre, tim, fir_slot, lane, sre, sim);
             // push x[n]: the oldest LDS entry moves into the register tail
 #pragma unroll
             for (int j = TAILN - 1; j > 0; j--) { tre[j] = tre[j - 1]; tim[j] = tim[j - 1]; }

@@ -1,7 +1,7 @@
 // k_burst_msk_fb.h -- the burst MSK tracking chain as a front / back wavefront pair (the MSK half).
 //
-// Same function as k_burst_msk_demod (k_burst_demod.h; JAERO/burstmskdemodulator.cpp:524-745), which it replaces in the library.  Measured
-// there (round 3, timing-only build without the filter, scripts/ubench): the half-sine matched filter -- 80 or 160 taps, its history advancing
+// Same function as the single-wavefront kernel k_burst_msk_demod of rounds 1-2 (JAERO/burstmskdemodulator.cpp:524-745), which it replaces.  Measured
+// there (round 3, a timing-only build with the filter's evaluation compiled out; the switches left with commit history, the numbers are in DESIGN 10): the half-sine matched filter -- 80 or 160 taps, its history advancing
 // per channel only while that channel's gate is open -- is 44 % of the kernel (44.6 -> 25.1 ms per 4096-sample launch of 65 536 channels),
 // on a chip where that kernel keeps two of a CU's four SIMDs idle (80 KiB of filter history per wavefront, two wavefronts per CU).
 //   front half (wavefront 0): the input ring, the mix with mixer2's table entry, the push into the history, the filter.  The reference's
@@ -18,9 +18,6 @@
 // Results are bit-identical to k_burst_msk_demod's (same operations in the same order); every burst-MSK bank test runs on this kernel.
 #pragma once
 #include "k_burst_demod.h"
-#ifndef BMSK_FB_ABL
-#define BMSK_FB_ABL 0 // timing experiments only (wrong results): 1 = the front half does not evaluate the filter, 2 = the back half skips the gated block
-#endif
 
 struct BmskMail
 {
@@ -117,7 +114,7 @@ __device__ __forceinline__ void bmsk_front(const BGeom &g, const BPtrs &p, doubl
             lre[fir_pos * 64 + lane] = cre; lim[fir_pos * 64 + lane] = cim;
             fir_pos++; if (fir_pos >= LDSN) fir_pos = 0;
         }
-        if (i + 1 < n && BMSK_FB_ABL != 1)
+        if (i + 1 < n)
         {
             // no channel of this wavefront pushed: every history is what it was, and so is every output (between bursts: most samples)
             if (__builtin_amdgcn_ballot_w64(gate != 0) != 0ull) evaluate(osre, osim);
@@ -244,7 +241,7 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
             c2_idx = jd_cisidx(m2n);
             nx_c2 = cis[c2_idx];
         }
-        if (gate && BMSK_FB_ABL != 2)
+        if (gate)
         {
             // window entries this sample replaces / reads: requested now, consumed behind the filter
             const double e2_old = ebe2_ring[eb_pos], e_old = ebe_ring[eb_pos], agc2_old = agc2_ring[agc2_pos];
