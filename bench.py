@@ -203,9 +203,26 @@ def measured_traffic(pmc_file: str, cls: str, kernel_that_ran: str, nch: int):
             return None, f"profiles/{pmc_file} has no entry for {cls}"
         if not kernel_that_ran or kernel_that_ran.rstrip("<") not in str(ent.get("kernel", "")):
             return None, (f"STALE: profiles/{pmc_file}@{pj.get('tag', 'untagged')} was taken on {ent.get('kernel')!r}, this run launched {kernel_that_ran!r}: "
-                          f"redo the --pmc passes (scripts/gpu_round.sh)")
+                          f"redo the --pmc passes (scripts/gpu_evidence.sh)")
         t = ent["hbm_bytes_per_launch"] * nch / float(pj.get("channels_per_gpu", nch))
         return t, f"profiles/{pmc_file}@{pj.get('tag', 'untagged')} (rocprofv3 --pmc passes of this command, not this run; kernel name checked)"
+    except Exception as e:
+        return None, f"profiles/{pmc_file} unreadable: {e}"
+
+
+def burst_traffic(pmc_file: str, kernel_that_ran: str, nch: int):
+    """As measured_traffic, for the burst workloads' summaries (entries keyed by kernel name): HBM bytes per launch of the dominant kernel,
+    mean over the launches that did work (>= 10 % of the largest; a burst kernel's launches differ with the bursts in flight)."""
+    path = os.path.join(ROOT, "profiles", pmc_file)
+    if not os.path.exists(path):
+        return None, f"profiles/{pmc_file} missing: no --pmc pass of this workload committed"
+    try:
+        pj = json.load(open(path))
+        for k, ent in pj.items():
+            if isinstance(ent, dict) and kernel_that_ran and kernel_that_ran.rstrip("<") in k and ent.get("hbm_bytes_per_launch") is not None:
+                t = ent["hbm_bytes_per_launch"] * nch / float(pj.get("channels_per_gpu", nch))
+                return t, f"profiles/{pmc_file}@{pj.get('tag', 'untagged')} (rocprofv3 --pmc passes of this command, not this run; kernel name checked)"
+        return None, f"STALE: profiles/{pmc_file}@{pj.get('tag', 'untagged')} has no entry for {kernel_that_ran!r}: redo the --pmc passes (scripts/gpu_evidence.sh)"
     except Exception as e:
         return None, f"profiles/{pmc_file} unreadable: {e}"
 
@@ -309,6 +326,7 @@ def burst_line(bank, rank, world, nch, chunk, K, W, dt, value, msk=False, extra=
     avg_ms = ms[dom] / launches
     units = K * chunk * nch / launches
     achieved = per_sample * units / (avg_ms * 1e-3) / 1e9
+    traffic, traffic_from = burst_traffic("pmc_summary_burst_msk.json" if msk else "pmc_summary_burst_oqpsk.json", bank.profile_kernel(names.index(dom)), nch)
     line = {
         "metric": ("Msamples/s of real 48 kHz PCM through the 1200 bps burst MSK demodulator hot path" if msk else
                    "Msamples/s of real 48 kHz PCM through the 10.5 kbps burst OQPSK demodulator hot path"),
@@ -327,7 +345,7 @@ def burst_line(bank, rank, world, nch, chunk, K, W, dt, value, msk=False, extra=
                    "whole_path_hbm_frac_at_187B_per_sample": round(value * 1e6 * ALG_BYTES_WHOLE_PATH_BURST / 1e9 / (HBM_PEAK_GBS * world), 5),
                    "kernel_ms_total": {k: round(v, 3) for k, v in ms.items()}, "kernel_launches": nl},
         "roofline": {"bound": "hbm", "kernel": dom, "kernel_name": bank.profile_kernel(names.index(dom)), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_from": "no --pmc pass of this workload committed",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_from": traffic_from,
                      "alg_bytes_per_sample": per_sample, "samples_per_launch": units, "avg_launch_ms": round(avg_ms, 4)},
     }
     tr, tr_from = measured_traffic("pmc_summary_burst_msk.json" if msk else "pmc_summary_burst_oqpsk.json", dom, bank.profile_kernel(names.index(dom)), nch)
