@@ -17,6 +17,7 @@
  *     JAERO/oqpskdemodulator.cpp:149-163, JAERO/mskdemodulator.cpp:105-118
  *   DCDstatSlot(bool)            JAERO/oqpskdemodulator.cpp:679-684   jaero_set_dcd
  *   CenterFreqChangedSlot(double) JAERO/oqpskdemodulator.cpp:291-310  jaero_center_freq_changed
+ *   (two objects per stereo device: JAERO/audioburstoqpskdemodulator.cpp:8-10: channels are independent)  jaero_comm_* / jaero_fan_out_pcm / jaero_gather_softbits
  *   writeData(const char*,qint64) JAERO/oqpskdemodulator.cpp:334-627, jaero_write
  *                                 JAERO/mskdemodulator.cpp:313-488
  *   signal processDemodulatedSoftBits(QVector<short>)                jaero_read_softbits / jaero_softbits_view
@@ -257,6 +258,26 @@ int jaero_debug_read_prefiltered(jaero_ctx *ctx, int channel, double *out_reim, 
 /* Test hook: the Viterbi decoder picks its layout by size (one block per wavefront below 16 384 blocks, one per lane from there); tests
  * force one so that both meet the oracle at small sizes.  mode: 0 = by size (default), 1 = wave, 2 = lanes.  Process-wide. */
 int jaero_debug_viterbi_layout(int mode);
+
+/* ------------------------------------------------------------------------------------------------ multi-GPU edge operations
+ * The path shards by channel with no steady-state exchange (the reference runs its two stereo burst channels as two unrelated objects,
+ * JAERO/audioburstoqpskdemodulator.cpp:8-10); the north star names two operations at the edges: fan out shared PCM, gather decoded bits.
+ * One jaero_comm per GPU (one process or thread each): RCCL point-to-point sends over xGMI, grouped per call; contiguous channel ranges
+ * [rank * N / W, (rank + 1) * N / W) (jaero_shard_range), the same as jaero_amd/dist.py.  RCCL is loaded on first use (dlopen): hosts with
+ * one GPU never need it.  world = 1 with id = NULL is a communicator without RCCL (both operations are local copies). */
+typedef struct jaero_comm jaero_comm;
+#define JAERO_COMM_ID_BYTES 128
+int jaero_shard_range(int nch_total, int rank, int world, int *lo, int *hi);
+int jaero_comm_get_unique_id(void *id_128_bytes);            /* on one rank; hand the 128 bytes to the others (= ncclGetUniqueId) */
+int jaero_comm_create(int device, int rank, int world, const void *id_128_bytes, jaero_comm **out);
+void jaero_comm_destroy(jaero_comm *comm);
+/* rank `src` holds frame-major PCM [nsamples][nch_total] on its device (the layout jaero_write takes with JAERO_PCM_FRAME_MAJOR); every
+ * rank receives its channel slice, contiguous, [nsamples][hi - lo], in d_mine.  Enqueued on `stream`. */
+int jaero_fan_out_pcm(jaero_comm *comm, int src, const int16_t *d_frames_all, int nsamples, int nch_total, int16_t *d_mine, void *stream);
+/* every rank's soft-bit rows [hi - lo][cap] and counts [hi - lo] (the buffers behind jaero_softbits_view) arrive on rank `dst` as
+ * [nch_total][cap] / [nch_total].  Enqueued on `stream`. */
+int jaero_gather_softbits(jaero_comm *comm, int dst, const int16_t *d_soft, const int *d_counts, int nch_total, int cap,
+                          int16_t *d_soft_all, int *d_counts_all, void *stream);
 
 /* introspection */
 int jaero_abi_version(void);

@@ -30,6 +30,7 @@ EXPORTS = [
     "jaero_aerol_tick_dcd", "jaero_aerol_profile_enable", "jaero_aerol_profile_read", "jaero_aerol_read_voice",
     "jaero_ingest_create", "jaero_ingest_destroy", "jaero_ingest_push", "jaero_ingest_queued", "jaero_ingest_pump",
     "jaero_ingest_stats",
+    "jaero_shard_range", "jaero_comm_get_unique_id", "jaero_comm_create", "jaero_comm_destroy", "jaero_fan_out_pcm", "jaero_gather_softbits",
 ]
 
 
@@ -134,6 +135,13 @@ def lib():
     L.jaero_ingest_queued.argtypes = [vp, ip]
     L.jaero_ingest_pump.argtypes = [vp, ip, vp, C.POINTER(ip)]
     L.jaero_ingest_stats.argtypes = [vp, vp]
+    L.jaero_shard_range.argtypes = [ip, ip, ip, C.POINTER(ip), C.POINTER(ip)]
+    L.jaero_comm_get_unique_id.argtypes = [vp]
+    L.jaero_comm_create.argtypes = [ip, ip, ip, vp, C.POINTER(vp)]
+    L.jaero_comm_destroy.argtypes = [vp]
+    L.jaero_comm_destroy.restype = None
+    L.jaero_fan_out_pcm.argtypes = [vp, ip, vp, ip, ip, vp, vp]
+    L.jaero_gather_softbits.argtypes = [vp, ip, vp, vp, ip, ip, vp, vp, vp]
     for name in EXPORTS:
         getattr(L, name)  # raises AttributeError if a declared symbol is not exported
     _lib = L

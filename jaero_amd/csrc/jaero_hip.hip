@@ -1696,3 +1696,4 @@ extern "C" int jaero_viterbi_continuous(int device, const uint8_t *soft, int nst
 
 #include "aerol_host.h"
 #include "ingest_host.h"
+#include "edge_host.h"

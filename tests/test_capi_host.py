@@ -90,3 +90,20 @@ def test_schedule_matches_reference_counters(oracle_mod, kind, power, cpu, write
     ref = _oracle_triggers(oracle_mod, kind, bool(cpu), writes)
     assert list(out[:n]) == ref
     assert nseg.value >= n
+
+
+def test_shard_range_matches_the_python_helper():
+    """jaero_shard_range (the C ABI's multi-GPU edge operations) = jaero_amd.dist.shard_range: contiguous, covering, in rank order."""
+    from jaero_amd import dist
+
+    L = capi.lib()
+    for n, w in ((65536, 8), (32768, 8), (4096, 3), (7, 4), (0, 2), (5, 1)):
+        prev = 0
+        for r in range(w):
+            lo, hi = C.c_int(), C.c_int()
+            assert L.jaero_shard_range(n, r, w, C.byref(lo), C.byref(hi)) == 0
+            assert (lo.value, hi.value) == dist.shard_range(n, r, w) and lo.value == prev
+            prev = hi.value
+        assert prev == n
+    lo, hi = C.c_int(), C.c_int()
+    assert L.jaero_shard_range(8, 2, 2, C.byref(lo), C.byref(hi)) != 0
