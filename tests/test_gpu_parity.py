@@ -442,3 +442,34 @@ def test_live_rate_change_keeps_flags_and_dcd(B, oracle_mod):
     assert np.ptp(ref["status"][:, 2]) > 1.0  # AFC moved freq_center in the reference run: the flag matters on this input
     compare(bank.read_softbits(0), bank.read_symbols(0), bank.read_status_log(0), ref)
     bank.close()
+
+
+@pytest.mark.parametrize("kind", ["oqpsk", "msk"])
+def test_empty_single_sample_and_maximum_writes(B, oracle_mod, kind):
+    """writeData with len 0 returns at once in the reference (oqpskdemodulator.cpp:336, mskdemodulator.cpp:315): empty writes between real ones
+    change nothing; one-sample writes, a write of exactly max_write_samples and one sample more (refused, state untouched) around them."""
+    from jaero_amd import capi
+    from jaero_amd import signalgen as G
+
+    O = oracle_mod
+    nch, nsamp, maxw = 2, 30000, 8192
+    pcm, _, _ = G.channel_bank(kind, nch, nsamp, ebno_db=12.0, seed0=G.SEED_BASE + 9300, **({"fb": 1200.0} if kind == "msk" else {}))
+    opts = {} if kind == "oqpsk" else {"fb": 1200.0, "lockingbw": 1800.0}
+    bank = B.DemodulatorBank([bank_settings(kind, opts) for _ in range(nch)], ebno=True, status_log=True, capture_symbols=True,
+                             max_write_samples=maxw, softbit_capacity=nsamp)
+    sizes = [0, 1, 1, 0, maxw, 0, 777, 1, 4096, 0]
+    s = 0
+    for m in sizes:
+        bank.write(pcm[:, s:s + m])
+        s += m
+    with pytest.raises(capi.JaeroError):
+        bank.write(pcm[:, s:s + maxw + 1])  # more than the bank was created for: refused ...
+    while s < nsamp:                       # ... and nothing was consumed
+        m = min(3000, nsamp - s)
+        bank.write(pcm[:, s:s + m])
+        s += m
+    real = [m for m in sizes if m] + [3000] * 40
+    for c in range(nch):
+        ref = O.run_demod(oracle_settings(O, kind, opts), pcm[c], chunk=real, capture_symbols=True)
+        compare(bank.read_softbits(c), bank.read_symbols(c), bank.read_status_log(c), ref)
+    bank.close()
