@@ -131,6 +131,8 @@ void jaero_destroy(jaero_ctx *ctx);
  *     object: oscillator phases, loop-filter / rotator / timing states, the symbol-rate windows (MSK: msema, the first entries of dt and
  *     delayedsmpl in buffer order), the EbNo meter of the OQPSK kind, the coarse ring and the smoothed spectrum, flags, unread outputs.
  *     Control plane: allocates and synchronises the device; pointers from the *_view calls are stale afterwards.  An OQPSK bank keeps Fs.
+ *     The new bank exists beside the old one until the state has moved: a bank that fills more than half of the device memory cannot change
+ *     rate this way (JAERO_ENOMEM, the old bank stays as it was).
  *   - JAERO_EINVAL: another kind (another class in the reference), or fb / Fs / FFT power for one channel of several;
  *     JAERO_ENOTSUP: burst banks (create a new bank; the Qt adaptors of integration/qt do), one channel of an 8400 bps bank. */
 int jaero_set_settings(jaero_ctx *ctx, int channel, const jaero_settings *s);
