@@ -922,6 +922,7 @@ __global__ void k_carry_dly(const double2 *__restrict__ od, int Lo, const int *_
 static int rebank_with_carry_over(jaero_ctx *c, const jaero_settings *s)
 {
     const JGeom og = c->g;
+    if (c->poisoned) return fail(JAERO_EHIP, "jaero_set_settings: a launch inside an earlier jaero_write failed; this bank's state cannot be carried over");
     if (og.kind == JAERO_KIND_OQPSK && s->Fs != og.Fs) return fail(JAERO_ENOTSUP, "jaero_set_settings: an OQPSK bank keeps its sample rate");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->last_stream));
