@@ -361,6 +361,64 @@ def burst_line(bank, rank, world, nch, chunk, K, W, dt, value, msk=False, extra=
     print(json.dumps(line), flush=True)
 
 
+
+def aerol_oracle_check(kind: str, bank, nch: int, stream_of, nrows_cap: int, first: int = 4):
+    """The three Aero-L workloads' post-clock check: sampled channels of the timed bank (wave edges, neighbouring wavefronts, the end)
+    against the oracle fed the SAME soft bits -- signal-unit rows / packets / voice rows and event rows EXACTLY equal.  Reads consume, so
+    every channel is read once here; returns (oracle_check dict, CRC-clean units or packets in the first `first` channels)."""
+    from oracle import oracle as O  # checker only, after the clock has stopped
+
+    O.build()
+    check = spread_channels(nch, ARGS.check_channels) if ARGS.check_channels > 0 else []
+    oc = {"channels": [int(c) for c in check], "rows_equal": True, "events_equal": True, "rows_compared": 0, "events_compared": 0, "crc_clean_rows": 0}
+    good, cache = 0, {}
+    for c in sorted(set(check) | set(range(min(first, nch)))):
+        if kind == "burst":
+            got = {"rows": bank.read_packets(c, nrows_cap), "events": bank.read_events(c, 4096)}
+            good += len(got["rows"]) if c < first else 0
+        else:
+            got = {"rows": bank.read_sus(c, nrows_cap), "events": bank.read_events(c, 4096)}
+            if kind == "c":
+                got["voice"] = bank.read_voice(c, nrows_cap)
+            good += int(got["rows"][:, 14].sum()) if c < first else 0
+        if c not in check:
+            continue
+        x = stream_of(c)
+        key = x.tobytes()
+        if key not in cache:
+            if kind == "p":
+                o = O.run_aerol(10500, x, 1 << 20)
+                cache[key] = {"rows": o["sus"], "events": o["events"]}
+            elif kind == "burst":
+                o = O.run_aerol_burst(10500, x)
+                cache[key] = {"rows": O.packets_from_rows(o["packets"]), "events": o["events"]}
+            else:
+                a = O.AeroL(8400)
+                for s_ in range(0, len(x), 32):
+                    a.write(x[s_:s_ + 32])
+                fn, voice = a.take_voice()
+                cache[key] = {"voice": (fn, voice), "rows": a.take_sus(), "events": a.take_events()}
+        want = cache[key]
+        same_rows = (got["rows"] == want["rows"]) if kind == "burst" else bool(np.array_equal(got["rows"], want["rows"]))
+        if kind == "c":
+            same_rows = same_rows and bool(np.array_equal(got["voice"][0], want["voice"][0])) and bool(np.array_equal(got["voice"][1], want["voice"][1]))
+            oc["voice_rows_compared"] = oc.get("voice_rows_compared", 0) + len(want["voice"][0])
+        oc["rows_equal"] &= bool(same_rows)
+        oc["events_equal"] &= bool(np.array_equal(got["events"], want["events"]))
+        oc["rows_compared"] += len(want["rows"])
+        oc["events_compared"] += len(want["events"])
+        if kind != "burst":
+            oc["crc_clean_rows"] += int(np.asarray(want["rows"])[:, 14].sum()) if len(want["rows"]) else 0
+    return oc, good
+
+
+def aerol_check_or_exit(line, oc, what: str):
+    line["config"]["oracle_check"] = oc
+    if oc["channels"] and not (oc["rows_equal"] and oc["events_equal"] and oc["rows_compared"] > 0):
+        print(json.dumps(line), flush=True)
+        raise SystemExit(f"bench.py: {what} of a sampled channel differ from the oracle's on the same soft bits")
+
+
 def aerol_bench():
     """Aero-L bit pipeline: a step = one 0.5 s P-channel frame (5250 soft bits) for every channel, soft bits resident in HBM.
     Metric: soft bits per second (all channels).  Algorithmic bytes per soft bit: 2 (int16 in) + 1 (deinterleaved block write) + 1
@@ -392,10 +450,12 @@ def aerol_bench():
     idx = torch.arange(nch, device=dev) % nuniq
     if ARGS.idle_frac > 0:  # noise-only channels scattered over the bank (every wavefront gets some): stream index nuniq = noise
         noise = np.clip(np.round(128 + prng.normal(0.0, 40.0, size=host.shape[1])), 0, 255).astype(np.int16)
+        host = np.concatenate([host, noise[None, :]])
         soft = torch.cat([soft, torch.from_numpy(noise[None, :]).to(dev)])
         g = torch.Generator(device="cpu").manual_seed(5)
         idle = (torch.rand(nch, generator=g) < ARGS.idle_frac).to(dev)
         idx = torch.where(idle, torch.full_like(idx, nuniq), idx)
+    idx_host = idx.cpu().numpy()
     counts = torch.full((nch,), flen, dtype=torch.int32, device=dev)
     bank = AeroLBank(nch, fb, device=local, max_softbits_per_write=flen + 8, su_capacity=26 * (K + W) + 8)
     stream = torch.cuda.current_stream().cuda_stream
@@ -415,7 +475,7 @@ def aerol_bench():
     ms, nl = {}, {}
     for w, nm in enumerate(names):
         ms[nm], nl[nm] = bank.profile_read(w)
-    good = sum(int(bank.read_sus(c, 26 * (K + W) + 8)[:, 14].sum()) for c in range(min(4, nch)))
+    oc, good = aerol_oracle_check("p", bank, nch, lambda c: host[idx_host[c]][: (K + W) * flen], 26 * (K + W) + 8)
     if rank == 0:
         value = float(K) * flen * nch * world / dt / 1e6
         dom = max(names, key=lambda k: ms[k])
@@ -444,6 +504,7 @@ def aerol_bench():
                                  "the HBM figure is reported because the contract asks for it"},
         }
         line["config"].update(rank_fields(world, shared, dts, value * 1e6 * dt / world))
+        aerol_check_or_exit(line, oc, "signal-unit rows / events")
         if world == 1 and not ARGS.no_cpu_baseline:
             from oracle import oracle as O  # cpu_baseline leg only
             x = np.tile(host[0], max(1, int(2_000_000 / host.shape[1]) + 1))[:2_000_000]
@@ -512,8 +573,8 @@ def aerol_c_bench():
     ms, nl = {}, {}
     for w, nm in enumerate(names):
         ms[nm], nl[nm] = bank.profile_read(w)
-    good = sum(int(bank.read_sus(c, 3 * (K + W) + 8)[:, 14].sum()) for c in range(min(4, nch)))
-    nvoice = len(bank.read_voice(0, K + W + 8)[0])
+    oc, good = aerol_oracle_check("c", bank, nch, lambda c: host[c % nuniq], 3 * (K + W) + 8)
+    nvoice = oc.get("voice_rows_compared", 0)
     if rank == 0:
         value = float(K) * flen * nch * world / dt / 1e6
         alg = 7.2
@@ -527,7 +588,7 @@ def aerol_c_bench():
                                    f"frame streams at different frame phases replicated over the channels, arm inversions mixed",
                        "channels_per_gpu": nch, "total_channels": nch * world, "frames_per_s": round(float(K) * nch * world / dt, 1),
                        "realtime_channel_equivalents": int(value * 1e6 / 8400),
-                       "crc_clean_units_in_first_channels": good, "channels_checked": min(4, nch), "voice_frames_channel0": nvoice,
+                       "crc_clean_units_in_first_channels": good, "channels_checked": min(4, nch), "voice_frames_checked": nvoice,
                        "kernel_ms_per_step": {k: round(v / K, 4) for k, v in ms.items()}, "kernel_launches": nl},
             "roofline": {"bound": "hbm", "kernel": "whole step (k_aerolc_bits + k_viterbi + k_aerolc_post)", "achieved": round(alg * value * 1e6 / 1e9 / world, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * value * 1e6 / 1e9 / world / HBM_PEAK_GBS, 6), "traffic": None,
@@ -535,6 +596,7 @@ def aerol_c_bench():
                          "note": "integer work bound by VALU issue and per-lane byte accesses (one lane walks a channel's soft bits), two orders below the HBM roof"},
         }
         line["config"].update(rank_fields(world, shared, dts, value * 1e6 * dt / world))
+        aerol_check_or_exit(line, oc, "signal-unit / voice rows / events")
         if world == 1 and not ARGS.no_cpu_baseline:
             from oracle import oracle as O  # cpu_baseline leg only
             x = np.tile(host[0], max(1, int(1_000_000 / host.shape[1]) + 1))[:1_000_000]
@@ -718,7 +780,7 @@ def aerol_burst_bench():
         bank.write_device(frames[i].data_ptr(), counts.data_ptr(), per, per, stream)
 
     dt, dts = run_timed(step, W, K, world, dev)
-    npk = sum(len(bank.read_packets(c)) for c in range(min(4, nch)))
+    oc, npk = aerol_oracle_check("burst", bank, nch, lambda c: host[c % nuniq], 8 * (K + W) + 8)
     if rank == 0:
         value = float(K) * per * nch * world / dt / 1e6
         # algorithmic bytes per soft bit: 2 (int16 in) + 1 (block write); every trial re-reads the block, deinterleaves and decodes it:
@@ -740,6 +802,7 @@ def aerol_burst_bench():
                                  "are integer-VALU work, see the aerol workload"},
         }
         line["config"].update(rank_fields(world, shared, dts, value * 1e6 * dt / world))
+        aerol_check_or_exit(line, oc, "R/T packets / events")
         if world == 1 and not ARGS.no_cpu_baseline:
             from oracle import oracle as O  # cpu_baseline leg only
             x = np.tile(host[0], max(1, int(1_000_000 / host.shape[1]) + 1))[:1_000_000]

@@ -32,8 +32,28 @@ __device__ __forceinline__ CoarseSlotState coarse_slot_load(const JGeom &g, cons
     c.ebno = S[(size_t)S_EB_EBNO * nchp];
     return c;
 }
+// The same thirteen values through ordinary (vector) loads, for a caller that requests them long before it needs them: every lane reads
+// the same addresses (one request per instruction), the values arrive in order with the loads around them (vmcnt), and no scalar load
+// is in flight while LDS results are waited for (lgkmcnt counts both; scalar loads return out of order, so any LDS wait becomes a wait
+// for them too -- what made the early request through coarse_slot_load slower in round 3).
+__device__ __forceinline__ CoarseSlotState coarse_slot_load_v(const JGeom &g, const JPtrs &p, int ch)
+{
+    const int nchp = g.nchp;
+    const int *I = p.I + ch;
+    const double *S = p.S + ch;
+    CoarseSlotState c;
+    c.emptying = I[(size_t)I_EMPTYING * nchp]; c.flags = I[(size_t)I_FLAGS * nchp]; c.countdown = I[(size_t)I_COUNTDOWN * nchp];
+    c.countdown2 = I[(size_t)I_COUNTDOWN2 * nchp]; c.nest = I[(size_t)I_NEST * nchp]; c.log_cnt = I[(size_t)I_LOG_CNT * nchp];
+    c.mse = S[(size_t)S_MSE * nchp]; c.thr = S[(size_t)S_THRESH * nchp];
+    c.m2_freq = S[(size_t)S_M2_FREQ * nchp]; c.m2_step = S[(size_t)S_M2_STEP * nchp];
+    c.mc_freq = S[(size_t)S_MC_FREQ * nchp]; c.mc_step = S[(size_t)S_MC_STEP * nchp];
+    c.ebno = S[(size_t)S_EB_EBNO * nchp];
+    return c;
+}
 // Returns 1 when the AFC recentre fired (caller then performs bigchange(): y[i]=20 and zeroes the ring).
-__device__ __forceinline__ int coarse_slot_apply(const JGeom &g, const JPtrs &p, int ch, const CoarseSlotState &c, int zmaxloc, int N, double hzperbin, double lockingbw)
+// writer = false: evaluate only (every thread of the workgroup can know the outcome without a broadcast; one of them writes)
+__device__ __forceinline__ int coarse_slot_apply(const JGeom &g, const JPtrs &p, int ch, const CoarseSlotState &c, int zmaxloc, int N, double hzperbin, double lockingbw,
+                                                 const bool writer = true)
 {
     const int nchp = g.nchp;
     int *I = p.I + ch;
@@ -64,7 +84,7 @@ __device__ __forceinline__ int coarse_slot_apply(const JGeom &g, const JPtrs &p,
             else jd_wt_setfreq(m2_freq, m2_step, mc_freq + freq_offset_est, Fs);
         }
         else countdown2 = 5;
-        CI(I_COUNTDOWN2) = countdown2;
+        if (writer) CI(I_COUNTDOWN2) = countdown2;
         if ((mse > thr) && (fabs(m2_freq - (mc_freq + freq_offset_est)) > 3.0))
             jd_wt_setfreq(m2_freq, m2_step, mc_freq + freq_offset_est, Fs);
         if ((afc) && (mse < thr) && (fabs(m2_freq - mc_freq) > 3.0))
@@ -93,6 +113,7 @@ __device__ __forceinline__ int coarse_slot_apply(const JGeom &g, const JPtrs &p,
         if (mc_freq > (Fs / 2.0 - lbw / 2.0)) jd_wt_setfreq(mc_freq, mc_step, Fs / 2.0 - lbw / 2.0, Fs);
         emptying = 4; // coarsefreqestimate->bigchange()
     }
+    if (!writer) return big ? 1 : 0;
     CI(I_EMPTYING) = emptying;
     CI(I_COUNTDOWN) = countdown;
     CS(S_M2_FREQ) = m2_freq; CS(S_M2_STEP) = m2_step;

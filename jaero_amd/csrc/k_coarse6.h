@@ -29,6 +29,36 @@ __device__ __forceinline__ double2 c6_sq(const double2 a)
     return make_double2(a.x * a.x - a.y * a.y, 2.0 * (a.x * a.y));
 }
 
+#ifndef C6_TRACE
+#define C6_TRACE(i) // scripts/ubench/coarse_trace.hip defines it to record a clock per phase
+#endif
+
+// (value, bin) of the wavefront's first maximum in every lane: value descending, bin ascending, bin < 0 = no candidate.  The order is total,
+// so any reduction tree gives the reference's ascending scan's answer.  Six DPP steps (quad permutes, half-row / row mirrors, the two
+// row broadcasts of gfx9), then lane 63 holds the result.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ void c6_argmax_step(double &bv, int &bi)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(bv), __double2loint(bv), CTRL, ROWMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(bv), __double2hiint(bv), CTRL, ROWMASK, 0xf, false);
+    const int oi = __builtin_amdgcn_update_dpp(bi, bi, CTRL, ROWMASK, 0xf, false);
+    const double ov = __hiloint2double(hi, lo);
+    const bool take = (oi >= 0) & ((bi < 0) | (ov > bv) | ((ov == bv) & (oi < bi)));
+    bv = take ? ov : bv;
+    bi = take ? oi : bi;
+}
+__device__ __forceinline__ void c6_wave_argmax(double &bv, int &bi)
+{
+    c6_argmax_step<0xB1, 0xf>(bv, bi);  // quad_perm [1,0,3,2]
+    c6_argmax_step<0x4E, 0xf>(bv, bi);  // quad_perm [2,3,0,1]
+    c6_argmax_step<0x141, 0xf>(bv, bi); // row_half_mirror
+    c6_argmax_step<0x140, 0xf>(bv, bi); // row_mirror: every lane of a row of 16 holds the row's result
+    c6_argmax_step<0x142, 0xa>(bv, bi); // row_bcast:15 into rows 1 and 3
+    c6_argmax_step<0x143, 0xc>(bv, bi); // row_bcast:31 into rows 2 and 3: lane 63 holds the wavefront's
+    bv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(bv), 63), __builtin_amdgcn_readlane(__double2loint(bv), 63));
+    bi = __builtin_amdgcn_readlane(bi, 63);
+}
+
 #define C6_XCH 16448 // doubles: one plane of the whole transform (exchange 2: 16 rows at stride 513, + 8208 for the upper half of k2)
 
 __device__ __forceinline__ constexpr int c6_k(int s) { return s < 16 ? 2 * s : 2 * (s - 16) + 1; }
@@ -234,7 +264,7 @@ __device__ __forceinline__ void c6_fft(CV<32> &d, double *xch, const double2 *__
     else wg_fft13_e32(d, xch, tw, tt);
 }
 
-template <bool W8400, int LOG2N = 14>
+template <bool W8400, int LOG2N = 14, int EPI = 0>
 __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const int *__restrict__ chan_list, int nlist, const double2 *__restrict__ tw)
 {
     constexpr int N = 1 << LOG2N;
@@ -287,7 +317,9 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
                 d.r[s] = v.x; d.i[s] = v.y;
             }
         }
+        C6_TRACE(0);
         c6_fft<LOG2N>(d, xch, tw, t);
+        C6_TRACE(1);
         // band limit (fb != 8400 boxcar, coarsefreqestimate.cpp:99) then inverse transform = forward on swapped planes
         if constexpr (W8400)
         {
@@ -336,6 +368,7 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
             }
         }
         c6_fft<LOG2N>(d, xch, tw, t);
+        C6_TRACE(2);
         // swap back (x N / N = 1), square
 #pragma unroll
         for (int s = 0; s < E; s++)
@@ -345,6 +378,7 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
             d.i[s] = re * im + im * re;
         }
         c6_fft<LOG2N>(d, xch, tw, t);
+        C6_TRACE(3);
         c6_bar(); // the exchange buffer is free: it receives a copy of y for the fold below
         // smooth with fftshift: y[i] = y[i]*0.9 + 0.1*10*log10(fmax(abs(out[i]),1)), out[i] = X[i ^ N/2]
         // all 32 old y values are requested before the log10s (their registers: the imaginary plane, dead once only |X|^2 is kept)
@@ -368,7 +402,13 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
                 (xch + ib)[t] = yn;
             }
         }
+        C6_TRACE(4);
         c6_bar(); // the fold reads the LDS copy; the stores to y[] drain in the background
+        C6_TRACE(5);
+        // the channel's acquisition state, needed behind the peak search: requested here, where the fewest registers are live (the spectrum
+        // and the y values are gone, the next ring not yet requested) and in front of the ring prefetch (vmcnt retires in order)
+        CoarseSlotState cst;
+        if constexpr (EPI == 1) cst = coarse_slot_load_v(g, p, ch);
         if (has_next)
         {
             // laundered: known since the top of the estimate, the 32 ring addresses would otherwise be computed there and kept (spilled)
@@ -385,11 +425,45 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
             }
         }
 
+        C6_TRACE(6);
         // fold + peak search (:116-131)
         const int i0 = (int)round((-lockingbw / hzperbin) + ((double)(N / 2)));
         const int i1 = (int)round((lockingbw / hzperbin) + ((double)(N / 2)));
         double best = 0;
         int besti = -1;
+        // every index the fold touches lies inside the spectrum (always, unless lockingbw + fb/2 reaches Fs/2): no per-term range checks
+        const bool fold_inside = (i0 - expectedpeakbin - 1 >= 0) && (i1 + expectedpeakbin < N) && (i0 >= 0);
+        if (EPI == 1 && fold_inside)
+        {
+            // four candidate bins at a time, straight-line: their 24 LDS reads are requested together (the rolled loop with the reference's
+            // range checks as branches waited for three LDS round trips per bin: 4.2 us per estimate, scripts/ubench/coarse_trace.hip)
+            const int nblk = (i1 - i0 + 4 * NT - 1) / (4 * NT);
+            for (int b = 0; b < nblk; b++)
+            {
+                double val[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                {
+                    const int i = i0 + t + (4 * b + u) * NT;
+                    const int ic = i < i1 ? i : i1 - 1;
+                    const double *lo = xch + (ic - expectedpeakbin), *hi = xch + (ic + expectedpeakbin);
+                    double v = 0;
+                    v += (lo[1] + hi[-1]);  // j = -1
+                    v += (lo[0] + hi[0]);   // j = 0
+                    v += (lo[-1] + hi[1]);  // j = 1
+                    val[u] = v;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                {
+                    const int i = i0 + t + (4 * b + u) * NT;
+                    const bool take = (i < i1) & (val[u] > best);
+                    best = take ? val[u] : best;
+                    besti = take ? i : besti;
+                }
+            }
+        }
+        else
         for (int i = i0 + t; i < i1; i += NT)
         {
             if ((i < 0) || (i >= N)) continue;
@@ -401,39 +475,71 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
             }
             if (val > best) { best = val; besti = i; }
         }
+        C6_TRACE(7);
         // first maximum over the workgroup (ties: the lower bin, as the reference's ascending scan keeps the first): wavefront
         // reduction through shuffles, then one LDS round for the eight wavefront results -- no barrier drains the ring prefetch in flight
+        int bigchange;
         {
             double bv = best;
             int bi = besti;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1)
+            if constexpr (EPI == 1)
             {
-                const double ov = __shfl_xor(bv, off, 64);
-                const int oi = __shfl_xor(bi, off, 64);
-                if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+                c6_wave_argmax(bv, bi); // data-parallel-primitive moves: no LDS round trip per step
+                if ((t & 63) == 0) { red_val[t >> 6] = bv; red_idx[t >> 6] = bi; }
             }
-            if ((t & 63) == 0) { red_val[t >> 6] = bv; red_idx[t >> 6] = bi; }
-            c6_bar();
-            if (t == 0)
+            else
             {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1)
+                {
+                    const double ov = __shfl_xor(bv, off, 64);
+                    const int oi = __shfl_xor(bi, off, 64);
+                    if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+                }
+                if ((t & 63) == 0) { red_val[t >> 6] = bv; red_idx[t >> 6] = bi; }
+            }
+            C6_TRACE(8);
+            c6_bar();
+            if constexpr (EPI == 1)
+            {
+                // every thread finishes the reduction and evaluates the slot itself (thread 0 writes): no single-thread section with the
+                // workgroup waiting at a second barrier behind it, no flag to broadcast
+                bv = red_val[0]; bi = red_idx[0];
+#pragma unroll
                 for (int w = 1; w < NT / 64; w++)
                 {
                     const double ov = red_val[w];
                     const int oi = red_idx[w];
                     if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
                 }
-                red_idx[0] = bi;
+                bigchange = coarse_slot_apply(g, p, ch, cst, (bi >= 0) ? bi : (N / 2), N, hzperbin, lockingbw, t == 0);
+                C6_TRACE(9);
+            }
+            else
+            {
+                if (t == 0)
+                {
+                    for (int w = 1; w < NT / 64; w++)
+                    {
+                        const double ov = red_val[w];
+                        const int oi = red_idx[w];
+                        if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+                    }
+                    red_idx[0] = bi;
+                }
+                if (t == 0) sh_bigchange = coarse_slot(g, p, ch, (red_idx[0] >= 0) ? red_idx[0] : (N / 2), N, hzperbin, lockingbw);
+                C6_TRACE(9);
+                c6_bar();
+                bigchange = sh_bigchange;
             }
         }
-        if (t == 0) sh_bigchange = coarse_slot(g, p, ch, (red_idx[0] >= 0) ? red_idx[0] : (N / 2), N, hzperbin, lockingbw);
-        c6_bar();
-        if (sh_bigchange)
+        if (bigchange)
         {
             __syncthreads(); // rare (AFC recentre): this estimate's y stores must have landed before other threads overwrite the same rows
             double2 *ringw = p.bbring + (size_t)ch * N;
             for (int i = t; i < N; i += NT) { y[i] = 20; ringw[i] = make_double2(0.0, 0.0); }
         }
+        C6_TRACE(10);
         // no barrier here: the next use of LDS is behind the first barrier of the next estimate's transform
     }
 }

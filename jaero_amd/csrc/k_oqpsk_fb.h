@@ -75,34 +75,17 @@ __device__ __forceinline__ double fb_fmod360(double x)
     return fmod(x, 360.0);
 }
 
-#ifndef FB_PAIRSYNC
-#define FB_PAIRSYNC 0 // experiment (round 3): the two halves of a pair wait for EACH OTHER through sequence words in LDS instead of for the whole workgroup
-#endif
 struct FbLds
 {
     double *lre, *lim, *ltap; // [LDSN][64], [LDSN][64], [64]
     double *data;             // [2][3][64]  F -> B: sre, sim, abval of a sample
     int *idx;                 // [2][64]     B -> F: table index of mixer2 for a sample
-    volatile int *seq;        // FB_PAIRSYNC: [2] sequence words (front, back)
-    int me, count;            // FB_PAIRSYNC: which word is mine, how many sync points I have passed
 };
 template <int LDSN>
 constexpr int fb_pair_doubles() { return 2 * LDSN * 64 + 64 + 2 * 3 * 64 + 64; }
 
-#if FB_PAIRSYNC
-// pair-local sync point: my LDS traffic done, my sequence word = number of sync points passed, wait until the partner's is as large
-__device__ __forceinline__ void fb_pair_sync(FbLds &L)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    L.count++;
-    if ((threadIdx.x & 63) == 0) L.seq[L.me] = L.count;
-    while (L.seq[L.me ^ 1] < L.count) __builtin_amdgcn_s_sleep(1);
-    asm volatile("" ::: "memory");
-}
-#define FB_SYNC(L) fb_pair_sync(L)
-#else
+// one LDS-only barrier per sample; waiting for the partner half alone through sequence words in LDS measured slower (13.9 against 12.8 ms)
 #define FB_SYNC(L) fb_barrier()
-#endif
 __device__ __forceinline__ void fb_barrier()
 {
     // LDS traffic of this wavefront done, then the workgroup barrier.  NOT __syncthreads(): that also drains vmcnt, i.e. every
@@ -647,14 +630,6 @@ __global__ __launch_bounds__(PAIRS * 128) void k_oqpsk_fb(const JGeom g, const J
     L.lre = base; L.lim = base + LDSN * 64; L.ltap = base + 2 * LDSN * 64;
     L.data = L.ltap + 64;
     L.idx = (int *)(L.data + 2 * 3 * 64);
-#if FB_PAIRSYNC
-    L.seq = (volatile int *)(L.ltap + 56); // the taps take 55 of the 64 doubles there
-    L.me = back ? 1 : 0; L.count = 0;
-    if (lane == 0) L.seq[L.me] = 0;
-    fb_barrier(); // the one workgroup barrier: every sequence word is zero before anyone waits on one
-    if (grp >= g.ngroups) return;
-#else
-    L.seq = nullptr; L.me = 0; L.count = 0;
     if (grp >= g.ngroups)
     {
         const int nB = n - (only_a_last ? 1 : 0);
@@ -662,7 +637,6 @@ __global__ __launch_bounds__(PAIRS * 128) void k_oqpsk_fb(const JGeom g, const J
         for (int i = 0; i < nbar; i++) fb_barrier();
         return;
     }
-#endif
     if (back) fb_back<CAPSYM, PRE8400>(g, p, L, n, only_a_last, grp, lane);
     else fb_front<FIRN, LDSN, EBNO, PRE8400>(g, p, L, pcm, pcm_stride, n, skip_a_first, only_a_last, fir_slot0, grp, lane, tp, prefilt);
 }

@@ -1,0 +1,52 @@
+#!/bin/bash
+# round-4 GPU passes: usage scripts/gpu_r4.sh <tag> <what...>   (what: ubench newtests aerolbench tests bench ...)
+set -u
+TAG=${1:-r4}; shift || true
+WHAT=${*:-ubench newtests aerolbench}
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
+has() { [[ " $WHAT " == *" $1 "* ]]; }
+cd "$R"
+if has ubench; then
+  timeout 300 scripts/ubench/atan2_rates 64 > "$OUT/atan2_rates.txt" 2>&1; cat "$OUT/atan2_rates.txt"
+fi
+if has coarse; then
+  timeout 300 scripts/ubench/coarse_notrace 65536 4 > "$OUT/coarse_ab.txt" 2>&1; cat "$OUT/coarse_ab.txt"
+  timeout 300 scripts/ubench/coarse_trace 65536 2 > "$OUT/coarse_trace.txt" 2>&1; grep -v "per launch" "$OUT/coarse_trace.txt"
+fi
+if has newtests; then
+  timeout 1200 python -m pytest tests/test_gpu_scale_aerol.py tests/test_gpu_scale.py -m gpu -q -k "65536_channels and aerol or ragged" --durations=8 --tb=short > "$OUT/pytest_new.log" 2>&1
+  tail -25 "$OUT/pytest_new.log"
+fi
+if has aerolbench; then
+  for wl in aerol aerol_burst aerol_c; do
+    ( timeout 600 python bench.py --workload $wl --no-cpu-baseline 2> "$OUT/bench_$wl.err" | tail -1 ) > "$OUT/bench_line_$wl.json"; cut -c1-1500 "$OUT/bench_line_$wl.json"; echo; tail -3 "$OUT/bench_$wl.err"
+  done
+fi
+if has tests; then
+  timeout 1500 python -m pytest tests -m gpu -q --durations=10 --tb=short > "$OUT/pytest_gpu_full.log" 2>&1
+  tail -22 "$OUT/pytest_gpu_full.log"
+fi
+if has bench; then
+  ( timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2> "$OUT/bench.err" | tail -1 ) > "$OUT/bench_line.json"; cut -c1-600 "$OUT/bench_line.json"; echo; tail -2 "$OUT/bench.err"
+fi
+du -sh "$OUT"
+if has abbench; then
+  # A/B: this tree's library against gpurun_tmp/libjaero_hip_old.so (the build before the change under test), same box, same run
+  for wl in oqpsk msk; do
+    ( timeout 600 python bench.py --workload $wl --steps 12 --warmup 4 --no-cpu-baseline --as-written 0 2> "$OUT/ab_new_$wl.err" | tail -1 ) > "$OUT/ab_new_$wl.json"
+  done
+  cp jaero_amd/libjaero_hip.so /tmp/libjaero_hip_new.so; cp gpurun_tmp/libjaero_hip_old.so jaero_amd/libjaero_hip.so
+  for wl in oqpsk msk; do
+    ( timeout 600 python bench.py --workload $wl --steps 12 --warmup 4 --no-cpu-baseline --as-written 0 2> "$OUT/ab_old_$wl.err" | tail -1 ) > "$OUT/ab_old_$wl.json"
+  done
+  cp /tmp/libjaero_hip_new.so jaero_amd/libjaero_hip.so
+  python - <<PY
+import json
+for wl in ("oqpsk","msk"):
+    for v in ("new","old"):
+        try:
+            l=json.load(open("$OUT/ab_%s_%s.json"%(v,wl)))
+            print(wl, v, l["value"], l["ms_per_step"], l["config"].get("kernel_ms_per_step") or l["config"].get("kernel_ms_total"), (l["config"].get("oracle_check") or {}))
+        except Exception as e: print(wl, v, "ERR", e, open("$OUT/ab_%s_%s.err"%(v,wl)).read()[-400:])
+PY
+fi

@@ -1,0 +1,145 @@
+// jd_atan2.h -- atan2 for the sample loops, rounded as the host libm (glibc 2.35) rounds it as nearly as any function can be; and
+// glibc 2.35's hypot restated (kept for the record: it is four times the device library's cost and not used by the kernels).
+//
+// Why: the timing loops feed atan2 of every sample back into two oscillators (JAERO/oqpskdemodulator.cpp:472-494,
+// JAERO/mskdemodulator.cpp:384-408), so the closer the result is to the reference's double the closer the loops track it.  Measured
+// (scripts/ubench/atan2_rates.hip, MI355X, 6.7e7 operand pairs of the timing detector's kind): the device library's atan2 differs from the
+// host libm's in 26.9 % of the calls (by one ulp; 523 calls by more), its hypot in 14.5 %.  glibc 2.35's atan2 itself is NOT correctly
+// rounded (within 0.503 ulp: 9.5e-4 of its results are the other neighbour -- scripts/atan2_check.c against __float128 -- and which ones
+// depends on whether its ifunc picked the fma build, so "the host's bits" are not a function of the arguments alone).  The nearest a
+// device function can get is therefore the correctly rounded value, and that is what this one returns in all but ~2e-7 of the calls:
+//   u = min/max, c = round(64 u)/64, t = (min - c max)/(max + c min) as a double-double quotient (|t| <= 2^-7), atan(t) by
+//   t - t^3/3 + t^5/5 - t^7/7 + t^9/9, atan(c) from a 64-entry table held one entry per LANE (ds_bpermute: no memory access), the
+//   quadrant constant folded in BEFORE the one final rounding.  The unrounded (hi + lo) is within 0.4 x 2^-64 of the result
+//   (scripts/atan2_check.c, 2e8 operand pairs against __float128), i.e. the rounded result is within 0.5002 ulp.  ~55 fp64 instructions,
+//   straight-line.  (With Ziv's rounding test and a double-double second stage it was correctly rounded on all 2e8 pairs, and at 274 ns
+//   per dependent call against the device library's 145 ns slower than what it replaces: the second stage runs whenever one lane of 64
+//   needs it.  Not kept.)
+//   Zeros, infinities, NaN, exponents outside 2^+-300: the device library's atan2, as before.
+// scripts/atan2_check.c compiles THIS header for the host (the hardware hooks replaced by portable C, the reciprocal seed deliberately
+// bad) and compares with the host libm and with __float128.
+#pragma once
+#include <stdint.h>
+
+#ifndef JDA_HOST_CHECK
+#include <hip/hip_runtime.h>
+#define JDA_FN __device__ __forceinline__
+#define JDA_RCP(x) __builtin_amdgcn_rcp(x)
+#define JDA_SQRT(x) __builtin_sqrt(x)
+#define JDA_FMA(a, b, c) __builtin_fma(a, b, c)
+#define JDA_LIB_ATAN2(y, x) atan2(y, x)
+#define JDA_LIB_HYPOT(x, y) hypot(x, y)
+__device__ __forceinline__ uint32_t jda_hi32(double x) { return (uint32_t)__double2hiint(x); }
+__device__ __forceinline__ uint32_t jda_lo32(double x) { return (uint32_t)__double2loint(x); }
+__device__ __forceinline__ double jda_words(uint32_t h, uint32_t l) { return __hiloint2double((int)h, (int)l); }
+#endif
+
+#include "jd_atan2_tbl.h"
+
+#define JDA_PIO2_HI 0x1.921fb54442d18p+0
+#define JDA_PIO2_LO 0x1.1a62633145c07p-54
+
+// the per-lane copy of the table (entry i = 1..64 in lane i - 1): {hi word, lo word of atan(i/64)'s leading double, the float tail}
+struct JdAtanLane
+{
+    int hi_h, hi_l, lo_f;
+};
+#ifndef JDA_HOST_CHECK
+__device__ __forceinline__ JdAtanLane jd_atan_lane_table(int lane)
+{
+    JdAtanLane t;
+    const double h = JD_ATAN_HI[(lane & 63) + 1];
+    t.hi_h = __double2hiint(h); t.hi_l = __double2loint(h);
+    t.lo_f = __float_as_int(JD_ATAN_LOF[(lane & 63) + 1]);
+    return t;
+}
+// entry i (0..64) for this lane; EVERY lane of the wavefront must be active (a bpermute reads other lanes' registers)
+__device__ __forceinline__ void jda_fetch(const JdAtanLane &T, int i, double &A_hi, double &A_lo)
+{
+    const int addr = (i - 1) << 2; // i = 0 reads lane 63 (address wraps) and is discarded below
+    const int hh = __builtin_amdgcn_ds_bpermute(addr, T.hi_h);
+    const int hl = __builtin_amdgcn_ds_bpermute(addr, T.hi_l);
+    const int lf = __builtin_amdgcn_ds_bpermute(addr, T.lo_f);
+    const bool z = i == 0;
+    A_hi = __hiloint2double(z ? 0 : hh, z ? 0 : hl);
+    A_lo = (double)__int_as_float(z ? 0 : lf);
+}
+#endif
+
+JDA_FN double jd_atan2(double y, double x, const JdAtanLane &T)
+{
+    const uint32_t hx = jda_hi32(x), hy = jda_hi32(y);
+    // both exponents in [2^-300, 2^300): no zero, infinity, NaN, denormal; no intermediate under- or overflow below.  The straight-line
+    // part runs for EVERY lane (on whatever the out-of-range lanes hold) and the library call replaces their result at the end: the table
+    // lookup is a ds_bpermute, which reads other lanes' registers and returns nothing for lanes the exec mask has switched off -- with the
+    // usual early return, one padding lane of a ragged bank on the library path corrupted its neighbours' table entries.
+    const uint32_t ex = (hx & 0x7fffffffu) - 0x2d300000u, ey = (hy & 0x7fffffffu) - 0x2d300000u;
+    const bool special = ex >= 0x25800000u || ey >= 0x25800000u;
+    const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
+    const bool sw = ay > ax;
+    const double mx = sw ? ay : ax, mn = sw ? ax : ay;
+    const bool xneg = (int32_t)hx < 0;
+    // index: u0 within 2^-13 of mn/mx is enough (c only has to be NEAR u)
+    const double u0 = mn * JDA_RCP(mx);
+    const double k = JDA_FMA(u0, 64.0, 0x1.8p52);
+    const int i = (int)(jda_lo32(k) & 0x7fu);
+    const double c = (k - 0x1.8p52) * 0.015625;
+    double A_hi, A_lo;
+    jda_fetch(T, i > 64 ? 64 : i, A_hi, A_lo);
+    // n = mn - c mx
+    const double ph = c * mx, pl = JDA_FMA(c, mx, -ph);
+    const double s = mn - ph; // exact (Sterbenz; c = 0: ph = 0)
+    const double n_hi = s - pl, n_lo = (s - n_hi) - pl;
+    // d = mx + c mn
+    const double qh = c * mn, ql = JDA_FMA(c, mn, -qh);
+    const double d_hi = mx + qh, d_lo = (qh - (d_hi - mx)) + ql;
+    // 1 / d_hi: two Newton steps from the hardware seed (any seed good to 2^-13 gives 2^-52)
+    double rd = JDA_RCP(d_hi);
+    rd = JDA_FMA(JDA_FMA(-d_hi, rd, 1.0), rd, rd);
+    rd = JDA_FMA(JDA_FMA(-d_hi, rd, 1.0), rd, rd);
+    const double t_hi = n_hi * rd;
+    const double e = JDA_FMA(-t_hi, d_lo, JDA_FMA(-d_hi, t_hi, n_hi) + n_lo);
+    const double t_lo = e * rd;
+    const double t2 = t_hi * t_hi;
+    const double P = JDA_FMA(t2, JDA_FMA(t2, JDA_FMA(t2, 0x1.c71c71c71c71cp-4, -0x1.2492492492492p-3), 0x1.999999999999ap-3), -0x1.5555555555555p-2);
+    double lo = JDA_FMA(t_hi * t2, P, t_lo) + A_lo;
+    const double s1 = A_hi + t_hi;
+    lo += t_hi - (s1 - A_hi);
+    // quadrant: |result| = m pi/2 + sigma (s1 + lo)
+    const double m = sw ? 1.0 : (xneg ? 2.0 : 0.0);
+    const double sigma = (sw != xneg) ? -1.0 : 1.0;
+    const double K_hi = m * JDA_PIO2_HI, hs = sigma * s1;
+    const double R = K_hi + hs;
+    const double lo2 = JDA_FMA(sigma, lo, m * JDA_PIO2_LO) + (hs - (R - K_hi));
+    const double z = R + lo2; // the one rounding
+    double res = jda_words((jda_hi32(z) & 0x7fffffffu) | (hy & 0x80000000u), jda_lo32(z));
+    if (special) res = JDA_LIB_ATAN2(y, x);
+    return res;
+}
+
+// ---- hypot -----------------------------------------------------------------------------------------------------------------------
+// glibc 2.35 sysdeps/ieee754/dbl-64/e_hypot.c, the branch without a fast fma (the x86-64 baseline build).  Operands of the sample
+// loops are AGC'd samples: never near the scaling thresholds (2^+-511); those, infinities and NaN go to the device library.
+JDA_FN double jd_hypot(double x, double y)
+{
+    x = __builtin_fabs(x); y = __builtin_fabs(y);
+    const double ax = x < y ? y : x, ay = x < y ? x : y;
+    if (!(ax < 0x1p+511 && ay > 0x1p-459)) return JDA_LIB_HYPOT(x, y);
+    if (ax >= ay * 0x1p+54) return ax + ay; // glibc: ax >= ay / EPS, EPS = 2^-54: the same comparison, the quotient is exact
+    double h = JDA_SQRT(ax * ax + ay * ay);
+    double t1, t2;
+    if (h <= 2.0 * ay)
+    {
+        const double delta = h - ay;
+        t1 = ax * (2.0 * delta - ax);
+        t2 = (delta - 2.0 * (ax - ay)) * delta;
+    }
+    else
+    {
+        const double delta = h - ax;
+        t1 = 2.0 * delta * (ax - 2.0 * ay);
+        t2 = (4.0 * delta - ay) * ay + delta * delta;
+    }
+    h -= (t1 + t2) / (2.0 * h);
+    return h;
+}

@@ -472,3 +472,73 @@ def test_msk_600_bank(B, oracle_mod, nch):
         nsoft += len(ref["soft"])
     assert nsoft > 20 * 400
     bank.close()
+
+
+RAGGED_NCH = 33091  # 518 wave groups (the last one with 3 of 64 channels) -> 130 four-pair workgroups, the last with 2 of its 4 pairs
+RAGGED_CHECK = sorted({0, 63, 64, 4095, 16383, 16384, 20000, 30001, 32767, 32768, 33023, 33024, 33087, 33088, 33089, 33090})
+
+
+@pytest.mark.parametrize("fb", [10500.0, 8400.0])
+def test_oqpsk_ragged_last_workgroup(B, oracle_mod, fb):
+    """The four-pair sample kernels (chosen above 32 768 channels) with a bank that does not fill their last workgroup: 33 091 channels =
+    518 groups, so workgroup 129 holds pairs for groups 516 and 517 and two pairs that only keep the barrier count
+    (k_oqpsk_fb.h `grp >= g.ngroups`; twice as many barriers at 8400 bps, where the halves take turns), and the last group has 3 live
+    lanes.  Four coarse estimates per channel; 16 channels incl. the whole last group against their oracle runs."""
+    import torch
+
+    from jaero_amd import capi
+    from jaero_amd import signalgen as G
+
+    O = oracle_mod
+    nch, chunk, nsteps = RAGGED_NCH, 4096, 4
+    dev = torch.device("cuda", 0)
+    gen = G.OqpskTorchStream(nch, nsteps * chunk, dev, fb=fb, ebno_db=11.0, seed=G.SEED_BASE + 33091, nphase=32)
+    st = B.OqpskSettings(fb=fb, lockingbw=fb, coarsefreqest_fft_power=14)
+    bank = B.DemodulatorBank(st, nch, ebno=True, status_log=True, max_write_samples=chunk, softbit_capacity=int(nsteps * chunk * fb / 48000) + 64)
+    cidx = torch.tensor(RAGGED_CHECK, dtype=torch.long, device=dev)
+    host = []
+    for i in range(nsteps):
+        blk = gen.render(i * chunk, chunk)
+        host.append(blk[:, cidx].cpu().numpy())
+        bank.write(blk, layout=capi.PCM_FRAME_MAJOR)
+        del blk
+    x = np.concatenate(host)
+    nsoft = 0
+    for k, c in enumerate(RAGGED_CHECK):
+        ref = O.run_demod(O.oqpsk_settings(fb=fb, lockingbw=fb), np.ascontiguousarray(x[:, k]), chunk=chunk)
+        assert ref["status"].shape[0] == nsteps
+        compare(bank.read_softbits(c), None, bank.read_status_log(c), ref)
+        nsoft += len(ref["soft"])
+    assert nsoft > len(RAGGED_CHECK) * 500
+    bank.close()
+
+
+def test_msk_ragged_last_workgroup(B, oracle_mod):
+    """k_msk_fb<80,32,...,4,22> (1200 bps MSK above 32 768 channels) with the same ragged bank: the back halves of absent groups must
+    keep the barrier count while the front halves of live ones wait for their partial filter sums."""
+    import torch
+
+    from jaero_amd import capi
+    from jaero_amd import signalgen as G
+
+    O = oracle_mod
+    nch, chunk, nsteps, nuniq = RAGGED_NCH, 4096, 4, 37
+    dev = torch.device("cuda", 0)
+    nsamp = nsteps * chunk
+    uniq = np.stack([G.msk(nsamp, fb=1200.0, fc=1000.0 + 4.0 * (u % 9 - 4), ebno_db=11.0, seed=G.SEED_BASE + 330 + u)[0] for u in range(nuniq)])
+    idx = (torch.arange(nch, device=dev) * 5) % nuniq
+    pcm = torch.from_numpy(np.ascontiguousarray(uniq.T)).to(dev)[:, idx].contiguous()
+    bank = B.DemodulatorBank(B.MskSettings(fb=1200.0, lockingbw=1800.0, freq_center=1000.0), nch, ebno=True, status_log=True,
+                             max_write_samples=chunk, softbit_capacity=int(nsamp * 1200 / 48000) + 64)
+    for s0 in range(0, nsamp, chunk):
+        bank.write(pcm[s0:s0 + chunk], layout=capi.PCM_FRAME_MAJOR)
+    refs, nsoft = {}, 0
+    for c in RAGGED_CHECK:
+        u = (c * 5) % nuniq
+        if u not in refs:
+            refs[u] = O.run_demod(O.msk_settings(fb=1200.0, lockingbw=1800.0), uniq[u], chunk=chunk)
+        assert refs[u]["status"].shape[0] == 2 * nsteps  # 2^13-point estimates every 2048 samples
+        compare(bank.read_softbits(c), None, bank.read_status_log(c), refs[u])
+        nsoft += len(refs[u]["soft"])
+    assert nsoft > len(RAGGED_CHECK) * 100
+    bank.close()
