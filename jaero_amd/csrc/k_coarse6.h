@@ -264,7 +264,19 @@ __device__ __forceinline__ void c6_fft(CV<32> &d, double *xch, const double2 *__
     else wg_fft13_e32(d, xch, tw, tt);
 }
 
-template <bool W8400, int LOG2N = 14, int EPI = 0>
+// the 8400 bps window's startbin + 2 table entries (coarsefreqestimate.cpp:61-74).  Out of line on purpose: it runs when a channel's locking
+// bandwidth changes, and inlined into the persistent estimate loop the cosine's constants were hoisted out of that loop and kept -- spilled --
+// across every estimate's three transforms.
+__device__ __noinline__ void c6_build_window(double *wt, int startbin, int t, int nthreads)
+{
+    for (int i = t; i <= startbin + 1; i += nthreads)
+    {
+        const double c = cos(M_PI_2 * ((double)i) / ((double)startbin));
+        wt[i] = (i == 0) ? 1.0 : ((i <= startbin) ? c * c : 0.0);
+    }
+}
+
+template <bool W8400, int LOG2N = 14>
 __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const int *__restrict__ chan_list, int nlist, const double2 *__restrict__ tw)
 {
     constexpr int N = 1 << LOG2N;
@@ -274,7 +286,6 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
     extern __shared__ __attribute__((aligned(16))) double xch[];
     __shared__ double red_val[NT / 64]; // one entry per wavefront
     __shared__ int red_idx[NT / 64];
-    __shared__ int sh_bigchange;
     const int t0 = threadIdx.x;
     const int nchp = g.nchp;
     int tab_startbin = -1; // W8400: the startbin the window table behind the exchange buffer was made for
@@ -300,10 +311,16 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
         const double lockingbw = jd_sload(p.S + (size_t)S_LOCKINGBW * nchp + ch);
         double fs_l = g.Fs; // opaque per estimate, as t: hoisted out of the loop Fs / N would be kept (spilled) across it, and a reload's wait
         asm volatile("" : "+s"(fs_l)); // stands behind every vector load in flight (vmcnt counts in order)
-        const double hzperbin = fs_l * (1.0 / ((double)N)); // N a power of two: the same bits as the reference's quotient
-        const int startbin = (int)fmax(round(lockingbw / hzperbin), 1.0);
+        // wave-uniform values that vector instructions compute (there is no scalar fp64): the integers go to scalar registers at once, the
+        // doubles are formed again where the epilogue needs them -- left in vector registers they stay live across the three transforms
+        // (k_coarse6_w8400 spilled 17 of them until round 4, and a reload's wait stands behind every load in flight)
+        int startbin, expectedpeakbin;
+        {
+            const double hzperbin = fs_l * (1.0 / ((double)N)); // N a power of two: the same bits as the reference's quotient
+            startbin = __builtin_amdgcn_readfirstlane((int)fmax(round(lockingbw / hzperbin), 1.0));
+            expectedpeakbin = __builtin_amdgcn_readfirstlane((int)round(g.fb / (2.0 * hzperbin)));
+        }
         const int stopbin = N - startbin;
-        const int expectedpeakbin = (int)round(g.fb / (2.0 * hzperbin));
         double *__restrict__ y = p.y + (size_t)ch * N;
 
         // bbtmpbuff[j] = bbcycbuff[(ptr+j)%N] (time order); for every list entry but the first these loads were issued while the
@@ -332,13 +349,9 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
             if (!persistent || startbin != tab_startbin)
             {
                 c6_bar();
-                for (int i = t; i <= startbin + 1; i += NT)
-                {
-                    const double c = cos(M_PI_2 * ((double)i) / ((double)startbin));
-                    wt[i] = (i == 0) ? 1.0 : ((i <= startbin) ? c * c : 0.0);
-                }
+                c6_build_window(wt, startbin, t, NT);
                 c6_bar();
-                if (persistent) tab_startbin = startbin;
+                if (persistent) tab_startbin = startbin; // (a scalar register: startbin is one)
             }
 #pragma unroll
             for (int s0 = 0; s0 < E; s0 += 8)
@@ -379,16 +392,24 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
         }
         c6_fft<LOG2N>(d, xch, tw, t);
         C6_TRACE(3);
+        // ---- epilogue.  Round 4 timed it phase by phase (scripts/ubench/coarse_trace.hip): 21 of an estimate's 52 us, most of it latency
+        // chains with the whole workgroup waiting -- the fold's range checks as branches (three LDS round trips per candidate bin: 4.2 us), a
+        // wavefront reduction through ds_bpermute (0.9 us), thread 0 alone loading the channel's state and evaluating the slot between two
+        // barriers (3 us) -- and the rest the CU's own memory phase: a CU gets ~45 GB/s out of loads that miss L2 (the 45 loads behind the y
+        // stores take a wavefront 7-8 us to issue), and no registers are free to request any of it a transform earlier (the transform needs
+        // 196 of 256; holding 20 y values across it made it slower than the wait they save, touching the lines with one-dword loads cost more
+        // issue time than it saved).  What is here now: 13.2 -> 12.6 ms per 65 536 estimates.
         c6_bar(); // the exchange buffer is free: it receives a copy of y for the fold below
         // smooth with fftshift: y[i] = y[i]*0.9 + 0.1*10*log10(fmax(abs(out[i]),1)), out[i] = X[i ^ N/2]
-        // all 32 old y values are requested before the log10s (their registers: the imaginary plane, dead once only |X|^2 is kept)
+        // all 32 old y values are requested before the log10s (their registers: the imaginary plane, dead once only |X|^2 is kept); y and the
+        // ring are streamed (read once, written once per estimate): non-temporal accesses
         {
             double yv[E];
 #pragma unroll
             for (int s = 0; s < E; s++) d.r[s] = d.r[s] * d.r[s] + d.i[s] * d.i[s];
             C6_FENCE; // d.i is dead from here: its registers take the y values
 #pragma unroll
-            for (int s = 0; s < E; s++) yv[s] = (y + ((s * NT) ^ (N / 2)))[t]; // (s*NT + t) ^ N/2: uniform base + t
+            for (int s = 0; s < E; s++) yv[s] = __builtin_nontemporal_load((y + ((s * NT) ^ (N / 2))) + t); // (s*NT + t) ^ N/2: uniform base + t
             C6_FENCE; // or the scheduler sinks every load to its use again
             // 10*log10(max(|X|,1)) == 5*log10(max(|X|^2,1)): no hypot; differs from the reference expression by <= 1 ulp
 #pragma unroll
@@ -398,7 +419,7 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
             {
                 const int ib = (s * NT) ^ (N / 2);
                 const double yn = yv[s] * 0.9 + d.r[s];
-                (y + ib)[t] = yn;
+                __builtin_nontemporal_store(yn, (y + ib) + t);
                 (xch + ib)[t] = yn;
             }
         }
@@ -407,36 +428,40 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
         C6_TRACE(5);
         // the channel's acquisition state, needed behind the peak search: requested here, where the fewest registers are live (the spectrum
         // and the y values are gone, the next ring not yet requested) and in front of the ring prefetch (vmcnt retires in order)
-        CoarseSlotState cst;
-        if constexpr (EPI == 1) cst = coarse_slot_load_v(g, p, ch);
+        const CoarseSlotState cst = coarse_slot_load_v(g, p, ch);
+        C6_TRACE(14);
         if (has_next)
         {
             // laundered: known since the top of the estimate, the 32 ring addresses would otherwise be computed there and kept (spilled)
             // across the three transforms -- and every reload waits for all vector loads in flight, which serialises this prefetch
             int bpn = bp_next, chn = ch_next, tp = t;
             asm volatile("" : "+v"(bpn), "+v"(chn), "+v"(tp));
-            const double2 *__restrict__ ringn = p.bbring + (size_t)chn * N;
+            typedef double c6_v2 __attribute__((ext_vector_type(2)));
+            const c6_v2 *__restrict__ ringn = (const c6_v2 *)(p.bbring + (size_t)chn * N);
             const int toffp = bpn + tp;
 #pragma unroll
             for (int s = 0; s < E; s++)
             {
-                const double2 v = ringn[(toffp + s * NT) & (N - 1)];
+                const c6_v2 v = __builtin_nontemporal_load(ringn + ((toffp + s * NT) & (N - 1)));
                 d.r[s] = v.x; d.i[s] = v.y;
+                if (s == 15) { C6_TRACE(15); }
             }
         }
 
         C6_TRACE(6);
         // fold + peak search (:116-131)
-        const int i0 = (int)round((-lockingbw / hzperbin) + ((double)(N / 2)));
-        const int i1 = (int)round((lockingbw / hzperbin) + ((double)(N / 2)));
+        double fs_e = g.Fs; // opaque again: the value above must not be kept for this
+        asm volatile("" : "+s"(fs_e));
+        const double hzperbin = fs_e * (1.0 / ((double)N));
+        const int i0 = __builtin_amdgcn_readfirstlane((int)round((-lockingbw / hzperbin) + ((double)(N / 2))));
+        const int i1 = __builtin_amdgcn_readfirstlane((int)round((lockingbw / hzperbin) + ((double)(N / 2))));
         double best = 0;
         int besti = -1;
         // every index the fold touches lies inside the spectrum (always, unless lockingbw + fb/2 reaches Fs/2): no per-term range checks
         const bool fold_inside = (i0 - expectedpeakbin - 1 >= 0) && (i1 + expectedpeakbin < N) && (i0 >= 0);
-        if (EPI == 1 && fold_inside)
+        if (fold_inside)
         {
-            // four candidate bins at a time, straight-line: their 24 LDS reads are requested together (the rolled loop with the reference's
-            // range checks as branches waited for three LDS round trips per bin: 4.2 us per estimate, scripts/ubench/coarse_trace.hip)
+            // four candidate bins at a time, straight-line: their 24 LDS reads are requested together
             const int nblk = (i1 - i0 + 4 * NT - 1) / (4 * NT);
             for (int b = 0; b < nblk; b++)
             {
@@ -464,74 +489,44 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
             }
         }
         else
-        for (int i = i0 + t; i < i1; i += NT)
         {
-            if ((i < 0) || (i >= N)) continue;
-            double val = 0;
-            for (int j = -1; j <= 1; j++)
+            for (int i = i0 + t; i < i1; i += NT)
             {
-                if (((i - expectedpeakbin - j) < 0) || ((i + expectedpeakbin + j) >= N)) continue;
-                val += (xch[i - expectedpeakbin - j] + xch[i + expectedpeakbin + j]);
+                if ((i < 0) || (i >= N)) continue;
+                double val = 0;
+                for (int j = -1; j <= 1; j++)
+                {
+                    if (((i - expectedpeakbin - j) < 0) || ((i + expectedpeakbin + j) >= N)) continue;
+                    val += (xch[i - expectedpeakbin - j] + xch[i + expectedpeakbin + j]);
+                }
+                if (val > best) { best = val; besti = i; }
             }
-            if (val > best) { best = val; besti = i; }
         }
         C6_TRACE(7);
-        // first maximum over the workgroup (ties: the lower bin, as the reference's ascending scan keeps the first): wavefront
-        // reduction through shuffles, then one LDS round for the eight wavefront results -- no barrier drains the ring prefetch in flight
+        // first maximum over the workgroup (ties: the lower bin, as the reference's ascending scan keeps the first): DPP moves inside a
+        // wavefront, one LDS round for the wavefronts' results, and then EVERY thread finishes the reduction and evaluates the slot itself
+        // (thread 0 writes): no single-thread section with the workgroup waiting at a second barrier behind it, no flag to broadcast, and no
+        // barrier that would drain the ring prefetch in flight
         int bigchange;
         {
             double bv = best;
             int bi = besti;
-            if constexpr (EPI == 1)
-            {
-                c6_wave_argmax(bv, bi); // data-parallel-primitive moves: no LDS round trip per step
-                if ((t & 63) == 0) { red_val[t >> 6] = bv; red_idx[t >> 6] = bi; }
-            }
-            else
-            {
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1)
-                {
-                    const double ov = __shfl_xor(bv, off, 64);
-                    const int oi = __shfl_xor(bi, off, 64);
-                    if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
-                }
-                if ((t & 63) == 0) { red_val[t >> 6] = bv; red_idx[t >> 6] = bi; }
-            }
+            c6_wave_argmax(bv, bi);
+            if ((t & 63) == 0) { red_val[t >> 6] = bv; red_idx[t >> 6] = bi; }
             C6_TRACE(8);
             c6_bar();
-            if constexpr (EPI == 1)
-            {
-                // every thread finishes the reduction and evaluates the slot itself (thread 0 writes): no single-thread section with the
-                // workgroup waiting at a second barrier behind it, no flag to broadcast
-                bv = red_val[0]; bi = red_idx[0];
+            bv = red_val[0]; bi = red_idx[0];
 #pragma unroll
-                for (int w = 1; w < NT / 64; w++)
-                {
-                    const double ov = red_val[w];
-                    const int oi = red_idx[w];
-                    if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
-                }
-                bigchange = coarse_slot_apply(g, p, ch, cst, (bi >= 0) ? bi : (N / 2), N, hzperbin, lockingbw, t == 0);
-                C6_TRACE(9);
-            }
-            else
+            for (int w = 1; w < NT / 64; w++)
             {
-                if (t == 0)
-                {
-                    for (int w = 1; w < NT / 64; w++)
-                    {
-                        const double ov = red_val[w];
-                        const int oi = red_idx[w];
-                        if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
-                    }
-                    red_idx[0] = bi;
-                }
-                if (t == 0) sh_bigchange = coarse_slot(g, p, ch, (red_idx[0] >= 0) ? red_idx[0] : (N / 2), N, hzperbin, lockingbw);
-                C6_TRACE(9);
-                c6_bar();
-                bigchange = sh_bigchange;
+                const double ov = red_val[w];
+                const int oi = red_idx[w];
+                const bool take = (oi >= 0) & ((bi < 0) | (ov > bv) | ((ov == bv) & (oi < bi)));
+                bv = take ? ov : bv;
+                bi = take ? oi : bi;
             }
+            bigchange = coarse_slot_apply(g, p, ch, cst, (bi >= 0) ? bi : (N / 2), N, hzperbin, lockingbw, t == 0);
+            C6_TRACE(9);
         }
         if (bigchange)
         {

@@ -1,6 +1,7 @@
 // Where one estimate of k_coarse6 spends its time, phase by phase (a 100 MHz clock read by thread 0 of one workgroup at the C6_TRACE points
-// of jaero_amd/csrc/k_coarse6.h), and A/B timing + parity of epilogue variants (template parameter EPI of coarse6_body).
-// Not part of the product library.
+// of jaero_amd/csrc/k_coarse6.h), and the launch times of the three product kernels.  (Round 4 used it to A/B epilogue variants through a
+// template parameter of coarse6_body; what won is the product code, the losers' numbers are in DESIGN 9 item 15.)  Parity of the
+// kernel against its predecessors: scripts/ubench/coarse_bench.hip.  Not part of the product library.
 //   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DTRACE] -o scripts/ubench/coarse_trace scripts/ubench/coarse_trace.hip
 //   run:   scripts/ubench/coarse_trace [channels = 65536] [launches = 4]
 #include <hip/hip_runtime.h>
@@ -25,19 +26,6 @@ __device__ unsigned long long *g_trace;
 #include <algorithm>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
-
-template <int EPI> __global__ __launch_bounds__(C2_THREADS) void k6(const JGeom g, const JPtrs p, const int *cl, int nlist, const double2 *tw)
-{
-    coarse6_body<false, 14, EPI>(g, p, cl, nlist, tw);
-}
-template <int EPI> __global__ __launch_bounds__(C2_THREADS) void k6w(const JGeom g, const JPtrs p, const int *cl, int nlist, const double2 *tw)
-{
-    coarse6_body<true, 14, EPI>(g, p, cl, nlist, tw);
-}
-template <int EPI> __global__ __launch_bounds__(256, 2) void k613(const JGeom g, const JPtrs p, const int *cl, int nlist, const double2 *tw)
-{
-    coarse6_body<false, 13, EPI>(g, p, cl, nlist, tw);
-}
 
 __global__ void k_fill(double2 *ring, int nch, int N, unsigned seed)
 {
@@ -82,15 +70,14 @@ int main(int argc, char **argv)
             I[(size_t)I_FLAGS * nch + c] = (c % 11 == 0) ? JF_AFC : 0;
             I[(size_t)I_BB_PTR * nch + c] = (c * 977) & (N - 1);
         }
-        const int NV = 2;
-        Side sd[NV];
+        Side sd[1];
+        const int NV = 1;
         for (int k = 0; k < NV; k++)
         {
             CK(hipMalloc(&sd[k].S, S.size() * 8)); CK(hipMalloc(&sd[k].I, I.size() * 4)); CK(hipMalloc(&sd[k].y, (size_t)nch * N * 8));
             CK(hipMalloc(&sd[k].slog, (size_t)nch * g.log_cap * 6 * 8));
             CK(hipMemcpy(sd[k].S, S.data(), S.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(sd[k].I, I.data(), I.size() * 4, hipMemcpyHostToDevice));
             CK(hipMemset(sd[k].y, 0, (size_t)nch * N * 8)); CK(hipMemset(sd[k].slog, 0, (size_t)nch * g.log_cap * 6 * 8));
-            // a ring per side: an AFC recentre zeroes the channel's ring
             CK(hipMalloc(&sd[k].ring, (size_t)nch * N * sizeof(double2)));
             hipLaunchKernelGGL(k_fill, dim3((unsigned)(((size_t)nch * N + 255) / 256)), dim3(256), 0, 0, sd[k].ring, nch, N, 12345u);
         }
@@ -98,85 +85,53 @@ int main(int argc, char **argv)
         const int lds = (LOG2N == 14 ? C6_XCH : C6_XCH13) * 8;
         const int grid = LOG2N == 14 ? (nch < ncu ? nch : ncu) : (nch < 2 * ncu ? nch : 2 * ncu);
         const int nthr = LOG2N == 14 ? C2_THREADS : 256;
-        CK(hipFuncSetAttribute((const void *)k6<0>, hipFuncAttributeMaxDynamicSharedMemorySize, C6_XCH * 8));
-        CK(hipFuncSetAttribute((const void *)k6<1>, hipFuncAttributeMaxDynamicSharedMemorySize, C6_XCH * 8));
-        CK(hipFuncSetAttribute((const void *)k6w<0>, hipFuncAttributeMaxDynamicSharedMemorySize, C6_XCH * 8 + C4_TABN * 8));
-        CK(hipFuncSetAttribute((const void *)k6w<1>, hipFuncAttributeMaxDynamicSharedMemorySize, C6_XCH * 8 + C4_TABN * 8));
-        CK(hipFuncSetAttribute((const void *)k613<0>, hipFuncAttributeMaxDynamicSharedMemorySize, C6_XCH13 * 8));
-        CK(hipFuncSetAttribute((const void *)k613<1>, hipFuncAttributeMaxDynamicSharedMemorySize, C6_XCH13 * 8));
-        auto launch = [&](int epi, int side) {
-            if (LOG2N == 14)
-            {
-                if (epi == 0) hipLaunchKernelGGL(k6<0>, dim3(grid), dim3(nthr), lds, 0, g, ptrs(side), (const int *)nullptr, nch, (const double2 *)tw);
-                else hipLaunchKernelGGL(k6<1>, dim3(grid), dim3(nthr), lds, 0, g, ptrs(side), (const int *)nullptr, nch, (const double2 *)tw);
-            }
-            else
-            {
-                if (epi == 0) hipLaunchKernelGGL(k613<0>, dim3(grid), dim3(nthr), lds, 0, g, ptrs(side), (const int *)nullptr, nch, (const double2 *)tw);
-                else hipLaunchKernelGGL(k613<1>, dim3(grid), dim3(nthr), lds, 0, g, ptrs(side), (const int *)nullptr, nch, (const double2 *)tw);
-            }
+        CK(hipFuncSetAttribute((const void *)k_coarse6, hipFuncAttributeMaxDynamicSharedMemorySize, C6_XCH * 8));
+        CK(hipFuncSetAttribute((const void *)k_coarse6_w8400, hipFuncAttributeMaxDynamicSharedMemorySize, C6_XCH * 8 + C4_TABN * 8));
+        CK(hipFuncSetAttribute((const void *)k_coarse6_13, hipFuncAttributeMaxDynamicSharedMemorySize, C6_XCH13 * 8));
+        auto launch = [&](int which, int side) {
+            if (LOG2N == 13) hipLaunchKernelGGL(k_coarse6_13, dim3(grid), dim3(nthr), lds, 0, g, ptrs(side), (const int *)nullptr, nch, (const double2 *)tw);
+            else if (which == 1) hipLaunchKernelGGL(k_coarse6_w8400, dim3(grid), dim3(nthr), lds + C4_TABN * 8, 0, g, ptrs(side), (const int *)nullptr, nch, (const double2 *)tw);
+            else hipLaunchKernelGGL(k_coarse6, dim3(grid), dim3(nthr), lds, 0, g, ptrs(side), (const int *)nullptr, nch, (const double2 *)tw);
         };
-        // parity: six launches of each on fresh state (y accumulates, the countdowns run down, AFC channels recentre), then compare everything
-        for (int r = 0; r < 6; r++) { launch(0, 0); launch(1, 1); }
-        CK(hipDeviceSynchronize()); CK(hipGetLastError());
-        {
-            std::vector<double> ya((size_t)N), yb((size_t)N), la((size_t)g.log_cap * 6), lb((size_t)g.log_cap * 6);
-            std::vector<double> Sa(S.size()), Sb(S.size()); std::vector<int> Ia(I.size()), Ib(I.size());
-            CK(hipMemcpy(Sa.data(), sd[0].S, S.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(Sb.data(), sd[1].S, S.size() * 8, hipMemcpyDeviceToHost));
-            CK(hipMemcpy(Ia.data(), sd[0].I, I.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(Ib.data(), sd[1].I, I.size() * 4, hipMemcpyDeviceToHost));
-            const bool state_same = memcmp(Sa.data(), Sb.data(), S.size() * 8) == 0 && memcmp(Ia.data(), Ib.data(), I.size() * 4) == 0;
-            long ydiff = 0, ldiff = 0; int nbig = 0;
-            const int ncheck = nch < 1024 ? nch : 1024;
-            for (int k = 0; k < ncheck; k++)
-            {
-                const int c = (int)(((long long)k * (nch - 1)) / (ncheck > 1 ? ncheck - 1 : 1));
-                CK(hipMemcpy(ya.data(), sd[0].y + (size_t)c * N, N * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(yb.data(), sd[1].y + (size_t)c * N, N * 8, hipMemcpyDeviceToHost));
-                if (memcmp(ya.data(), yb.data(), N * 8) != 0) ydiff++;
-                CK(hipMemcpy(la.data(), sd[0].slog + (size_t)c * g.log_cap * 6, la.size() * 8, hipMemcpyDeviceToHost));
-                CK(hipMemcpy(lb.data(), sd[1].slog + (size_t)c * g.log_cap * 6, lb.size() * 8, hipMemcpyDeviceToHost));
-                if (memcmp(la.data(), lb.data(), la.size() * 8) != 0) ldiff++;
-                if (ya[5] == 20.0) nbig++;
-            }
-            printf("N = 2^%d  EPI 1 against EPI 0 after 6 launches: state arrays %s, y rows that differ %ld of %d, status logs that differ %ld (channels just recentred: %d)  -> %s\n", LOG2N,
-                   state_same ? "identical" : "DIFFER", ydiff, ncheck, ldiff, nbig, (state_same && !ydiff && !ldiff) ? "OK" : "MISMATCH");
-        }
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         auto timeit = [&](const char *name, int epi) {
-            launch(epi, epi); CK(hipDeviceSynchronize());
+            launch(epi, 0); CK(hipDeviceSynchronize());
             CK(hipEventRecord(e0, 0));
-            for (int r = 0; r < nl; r++) launch(epi, epi);
+            for (int r = 0; r < nl; r++) launch(epi, 0);
             CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
             CK(hipGetLastError());
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             printf("N = 2^%d  %-28s %8.3f ms per launch  (%6.2f us per estimate and workgroup, alg %d KiB/estimate -> %6.1f GB/s)\n", LOG2N, name, ms / nl, ms / nl * 1e3 / ((double)nch / grid),
                    32 * N / 1024, 32.0 * N * nch / (ms / nl * 1e-3) / 1e9);
         };
-        for (int rep = 0; rep < 2; rep++) { timeit("EPI 0 (product)", 0); timeit("EPI 1", 1); }
+        for (int rep = 0; rep < 2; rep++) { timeit(LOG2N == 14 ? "k_coarse6" : "k_coarse6_13", 0); if (LOG2N == 14) timeit("k_coarse6_w8400", 1); }
 #ifdef TRACE
-        for (int epi = 0; epi < 2; epi++)
+        for (int epi = 0; epi < (LOG2N == 14 ? 2 : 1); epi++)
         {
             unsigned long long *dtr; CK(hipMalloc(&dtr, 256 * 16 * 8)); CK(hipMemset(dtr, 0, 256 * 16 * 8));
             CK(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &dtr, sizeof(dtr)));
-            launch(epi, epi); CK(hipDeviceSynchronize());
+            launch(epi, 0); CK(hipDeviceSynchronize());
             std::vector<unsigned long long> tr(256 * 16);
             CK(hipMemcpy(tr.data(), dtr, tr.size() * 8, hipMemcpyDeviceToHost));
             unsigned long long *nul = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &nul, sizeof(nul)));
             const int iters = nch / grid < 256 ? nch / grid : 256;
-            const char *ph[] = {"FFT 1", "band limit + FFT 2", "square + FFT 3", "|X|^2, y loads, 32 log10, y stores + LDS copy", "barrier", "ring prefetch issue", "fold", "shuffle reduce",
-                                "barrier + reduce 8 + slot", "second barrier / recentre", "loop latch -> next top"};
-            double acc[11] = {0}; int cnt = 0;
+            const int order[] = {0, 1, 2, 3, 4, 5, 14, 15, 6, 7, 8, 9, 10};
+            const char *ph[] = {"FFT 1", "band limit + FFT 2", "square + FFT 3", "barrier, |X|^2, y loads, 32 log10, combine, y stores + LDS copy", "barrier",
+                                "state loads issued", "ring loads 0..15 issued", "ring loads 16..31 issued", "fold", "wavefront reduce", "barrier + reduce 8 + slot (every thread)", "recentre (rare)", "loop latch -> next top"};
+            const int NP = 13;
+            double acc[NP] = {0}; int cnt = 0;
             for (int it = 4; it + 1 < iters; it++)
             {
                 bool ok = true;
-                for (int k = 0; k <= 10; k++) if (!tr[it * 16 + k]) ok = false;
+                for (int k = 0; k < NP; k++) if (!tr[it * 16 + order[k]]) ok = false;
                 if (!ok || !tr[(it + 1) * 16]) continue;
-                for (int k = 0; k < 10; k++) acc[k] += (double)(tr[it * 16 + k + 1] - tr[it * 16 + k]) * 0.01;
-                acc[10] += (double)(tr[(it + 1) * 16] - tr[it * 16 + 10]) * 0.01;
+                for (int k = 0; k + 1 < NP; k++) acc[k] += (double)(tr[it * 16 + order[k + 1]] - tr[it * 16 + order[k]]) * 0.01;
+                acc[NP - 1] += (double)(tr[(it + 1) * 16] - tr[it * 16 + order[NP - 1]]) * 0.01;
                 cnt++;
             }
-            double tot = 0; for (int k = 0; k < 11; k++) tot += acc[k] / (cnt ? cnt : 1);
-            printf("N = 2^%d  EPI %d: phases of one estimate on workgroup %d, mean over %d estimates (us), total %.2f\n", LOG2N, epi, C6_TRACE_WG, cnt, tot);
-            for (int k = 0; k < 11; k++) printf("    %-48s %6.2f\n", ph[k], acc[k] / (cnt ? cnt : 1));
+            double tot = 0; for (int k = 0; k < NP; k++) tot += acc[k] / (cnt ? cnt : 1);
+            printf("N = 2^%d  %s: phases of one estimate on workgroup %d, mean over %d estimates (us), total %.2f\n", LOG2N, LOG2N == 13 ? "k_coarse6_13" : epi ? "k_coarse6_w8400" : "k_coarse6", C6_TRACE_WG, cnt, tot);
+            for (int k = 0; k < NP; k++) printf("    %-48s %6.2f\n", ph[k], acc[k] / (cnt ? cnt : 1));
             CK(hipFree(dtr));
         }
 #endif
