@@ -66,7 +66,8 @@ public slots:
     void CenterFreqChangedSlot(double f) { if (ctx) jaero_center_freq_changed(ctx, 0, f); }          // :291-310
     void DCDstatSlot(bool d) { dcd = d; if (ctx) jaero_set_dcd(ctx, -1, d); }                       // :679-684
     // OqpskDemodulator::dataReceived only warns about another rate (:686-693); MskDemodulator::dataReceived re-applies its last settings with
-    // the incoming rate (mskdemodulator.cpp:528-537) -- here: a new one-channel bank at that rate (applySettings)
+    // the incoming rate (mskdemodulator.cpp:528-537) -- here: jaero_set_settings with that rate, which carries the demodulator's state into
+    // a bank at the new rate behind the same handle (applySettings)
     void dataReceived(const QByteArray &audio, quint32 sampleRate)
     {
         if (double(sampleRate) != Fs && kind == JAERO_KIND_MSK && ctx)
@@ -91,14 +92,35 @@ protected:
             pushFlags();
             jaero_set_dcd(ctx, -1, dcd);
         }
-        else if (jaero_set_settings(ctx, 0, &js) != JAERO_OK)
+        else
         {
             // A change of rate / sample rate / FFT size (and any setSettings at 8400 bps) re-creates the one-channel bank behind the handle
             // with what the reference's setSettings keeps in the old object -- oscillator phases, loop states, symbol-rate windows, coarse
             // ring and spectrum (jaero_hip.h).  Soft bits that did not fill a group yet stay in `pending`, as RxDataBits survives there.
-            // What is left to fail: bad settings, out of memory.
-            emit WarningTextSignal(QString("libjaero_hip: %1").arg(jaero_last_error()));
-            return;
+            const int rc = jaero_set_settings(ctx, 0, &js);
+            if (rc == JAERO_EINVAL)
+            {
+                // bad settings: nothing changed, the demodulator keeps running as it was (the reference has no such case)
+                emit WarningTextSignal(QString("libjaero_hip: %1").arg(jaero_last_error()));
+                return;
+            }
+            if (rc != JAERO_OK)
+            {
+                // the carry-over itself failed (no memory for the sibling bank, unread outputs larger than the new buffers, a bank whose
+                // write failed earlier): audio at the new rate must not run into the old-rate bank, and retrying the carry-over on every
+                // call would cost a create / destroy each time -- start afresh at the new settings, as the adaptors did before round 3
+                emit WarningTextSignal(QString("libjaero_hip: %1; restarting the demodulator at the new settings").arg(jaero_last_error()));
+                jaero_destroy(ctx);
+                ctx = nullptr;
+                if (jaero_create(0, 1, &js, 0, JAERO_FLAG_EBNO | JAERO_FLAG_STATUS_LOG, maxWrite, 0, &ctx) != JAERO_OK)
+                {
+                    emit WarningTextSignal(QString("libjaero_hip: %1").arg(jaero_last_error()));
+                    ctx = nullptr;
+                    return;
+                }
+                pushFlags();
+                jaero_set_dcd(ctx, -1, dcd);
+            }
         }
         cur = js;
         if (js.Fs != Fs) { Fs = js.Fs; emit SampleRateChanged(Fs); }

@@ -273,6 +273,7 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
     const bool cs = (c->flags & JAERO_FLAG_CAPTURE_SYMBOLS) != 0;
     const int lds = g.kind == JAERO_KIND_BURST_OQPSK ? (2 * 39 * 64 + 64) * (int)sizeof(double) : 2 * (g.fir_n == 80 ? BMSK_FB_LDSN_80 : BMSK_FB_LDSN_160) * 64 * (int)sizeof(double) + BMSK_FB_MAIL_BYTES;
     int first = 1;
+    c->poisoned = true; // the history push above is idempotent (same slots if the write is repeated); from here on state advances
     for (int pos = 0; pos < nsamples;)
     {
         const int n = (nsamples - pos) < g.maxseg ? (nsamples - pos) : g.maxseg;

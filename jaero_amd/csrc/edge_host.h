@@ -41,6 +41,15 @@ static int rccl_load()
 }
 #define RCCLCHK(call, what) do { const int r_ = (call); if (r_ != 0) return fail(JAERO_EHIP, "RCCL %s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "error"); } while (0)
 #define JRCCL_CHAR 0 /* ncclInt8 / ncclChar: payloads are moved as bytes */
+// An open ncclGroupStart must be closed on EVERY way out: a Send / Recv that fails inside the group returns through RCCLCHK, and with the
+// thread's group depth left above zero every later RCCL call on that thread (ncclCommDestroy included) would be queued or hang.
+struct JRcclGroup
+{
+    bool open = false;
+    int start() { const int r = g_rccl.GroupStart(); open = (r == 0); return r; }
+    int end() { open = false; return g_rccl.GroupEnd(); }
+    ~JRcclGroup() { if (open) g_rccl.GroupEnd(); }
+};
 
 struct jaero_comm
 {
@@ -48,6 +57,8 @@ struct jaero_comm
     void *nccl = nullptr;          // ncclComm_t, or null: a one-rank communicator without RCCL
     int16_t *stage = nullptr;      // fan-out source: packed slices of the peers
     size_t stage_elems = 0;
+    hipEvent_t stage_ev = nullptr; // recorded behind the sends that read `stage`: the next call's packing (on whatever stream) waits for it
+    bool stage_busy = false;
 };
 
 static inline void shard_range(int nch_total, int rank, int world, int &lo, int &hi)
@@ -106,6 +117,7 @@ extern "C" void jaero_comm_destroy(jaero_comm *c)
     if (!c) return;
     hipSetDevice(c->device);
     if (c->nccl) g_rccl.CommDestroy(c->nccl);
+    if (c->stage_ev) hipEventDestroy(c->stage_ev);
     if (c->stage) hipFree(c->stage);
     delete c;
 }
@@ -128,7 +140,9 @@ extern "C" int jaero_fan_out_pcm(jaero_comm *c, int src, const int16_t *d_frames
         RCCLCHK(g_rccl.Recv(d_mine, (size_t)nsamples * (hi - lo) * sizeof(int16_t), JRCCL_CHAR, src, c->nccl, st), "ncclRecv");
         return 0;
     }
-    // the source packs every rank's column slice contiguously (its own straight into d_mine) and sends them in one group
+    // the source packs every rank's column slice contiguously (its own straight into d_mine) and sends them in one group.  The staging
+    // buffer belongs to the communicator: a call on another stream than the previous one waits for that call's sends first.
+    if (c->stage_busy) HIPCHK(hipStreamWaitEvent(st, c->stage_ev, 0));
     const size_t need = (size_t)nsamples * (nch_total - (hi - lo));
     if (c->nccl && need > c->stage_elems)
     {
@@ -164,7 +178,8 @@ extern "C" int jaero_fan_out_pcm(jaero_comm *c, int src, const int16_t *d_frames
                 off += (size_t)nsamples * (h - l);
             }
         HIPCHK(hipGetLastError());
-        RCCLCHK(g_rccl.GroupStart(), "ncclGroupStart");
+        JRcclGroup grp;
+        RCCLCHK(grp.start(), "ncclGroupStart");
         off = 0;
         for (int r = 0; r < c->world; r++)
             if (r != src)
@@ -181,7 +196,10 @@ extern "C" int jaero_fan_out_pcm(jaero_comm *c, int src, const int16_t *d_frames
             RCCLCHK(g_rccl.Send(self_buf, n, JRCCL_CHAR, 0, c->nccl, st), "ncclSend (self)");
             RCCLCHK(g_rccl.Recv(d_mine, n, JRCCL_CHAR, 0, c->nccl, st), "ncclRecv (self)");
         }
-        RCCLCHK(g_rccl.GroupEnd(), "ncclGroupEnd");
+        RCCLCHK(grp.end(), "ncclGroupEnd");
+        if (!c->stage_ev) HIPCHK(hipEventCreateWithFlags(&c->stage_ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(c->stage_ev, st));
+        c->stage_busy = true;
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -200,10 +218,11 @@ extern "C" int jaero_gather_softbits(jaero_comm *c, int dst, const int16_t *d_so
     if (c->rank != dst)
     {
         if (!c->nccl) return fail(JAERO_EINVAL, "jaero_gather_softbits: a one-rank communicator has no peer %d", dst);
-        RCCLCHK(g_rccl.GroupStart(), "ncclGroupStart");
+        JRcclGroup grp;
+        RCCLCHK(grp.start(), "ncclGroupStart");
         RCCLCHK(g_rccl.Send(d_soft, mine_b, JRCCL_CHAR, dst, c->nccl, st), "ncclSend");
         RCCLCHK(g_rccl.Send(d_counts, mine_c, JRCCL_CHAR, dst, c->nccl, st), "ncclSend");
-        RCCLCHK(g_rccl.GroupEnd(), "ncclGroupEnd");
+        RCCLCHK(grp.end(), "ncclGroupEnd");
         return 0;
     }
     const bool self_loop = c->nccl && c->world == 1;
@@ -214,7 +233,8 @@ extern "C" int jaero_gather_softbits(jaero_comm *c, int dst, const int16_t *d_so
     }
     if (c->nccl)
     {
-        RCCLCHK(g_rccl.GroupStart(), "ncclGroupStart");
+        JRcclGroup grp;
+        RCCLCHK(grp.start(), "ncclGroupStart");
         for (int r = 0; r < c->world; r++)
         {
             if (r == dst && !self_loop) continue;
@@ -228,7 +248,7 @@ extern "C" int jaero_gather_softbits(jaero_comm *c, int dst, const int16_t *d_so
             RCCLCHK(g_rccl.Send(d_soft, mine_b, JRCCL_CHAR, 0, c->nccl, st), "ncclSend (self)");
             RCCLCHK(g_rccl.Send(d_counts, mine_c, JRCCL_CHAR, 0, c->nccl, st), "ncclSend (self)");
         }
-        RCCLCHK(g_rccl.GroupEnd(), "ncclGroupEnd");
+        RCCLCHK(grp.end(), "ncclGroupEnd");
     }
     return 0;
 }

@@ -496,7 +496,10 @@ extern "C" void jaero_destroy(jaero_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
-    hipDeviceSynchronize();
+    // this bank's work only (its last stream and the default stream its control-plane copies use): other banks keep running until hipFree's
+    // own implicit synchronisation, which cannot be avoided
+    hipStreamSynchronize(c->last_stream);
+    hipStreamSynchronize(0);
     for (void *q : c->allocs) hipFree(q);
     for (auto &e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (c->order_ev) hipEventDestroy(c->order_ev);
@@ -765,8 +768,13 @@ static int upload_flags(jaero_ctx *c, int lo, int hi, int mask, int bits)
     return 0;
 }
 
+// a bank whose write failed part-way (device state and the host's schedule mirror disagree) accepts nothing but jaero_destroy: setters would
+// change a state nobody can continue from, readers would hand out half-written outputs without saying so
+#define POISONCHK(c, who) do { if ((c) && (c)->poisoned) return fail(JAERO_EHIP, who ": an earlier jaero_write of this bank failed part-way; destroy the bank and create a new one"); } while (0)
+
 extern "C" int jaero_set_flags(jaero_ctx *c, int channel, int afc, int sql, int cpu_reduce)
 {
+    POISONCHK(c, "jaero_set_flags");
     if (!c || channel < -1 || channel >= c->o_nch) return fail(JAERO_EINVAL, "jaero_set_flags: bad channel");
     HIPCHK(hipSetDevice(c->device));
     const int lo = channel < 0 ? 0 : channel, hi = channel < 0 ? c->o_nchp : channel + 1;
@@ -777,6 +785,7 @@ extern "C" int jaero_set_flags(jaero_ctx *c, int channel, int afc, int sql, int 
 
 extern "C" int jaero_set_dcd(jaero_ctx *c, int channel, int dcd)
 {
+    POISONCHK(c, "jaero_set_dcd");
     if (!c || channel < -1 || channel >= c->o_nch) return fail(JAERO_EINVAL, "jaero_set_dcd: bad channel");
     HIPCHK(hipSetDevice(c->device));
     const int lo = channel < 0 ? 0 : channel, hi = channel < 0 ? c->o_nchp : channel + 1;
@@ -786,6 +795,7 @@ extern "C" int jaero_set_dcd(jaero_ctx *c, int channel, int dcd)
 
 extern "C" int jaero_center_freq_changed(jaero_ctx *c, int channel, double hz)
 {
+    POISONCHK(c, "jaero_center_freq_changed");
     if (!c || channel < -1 || channel >= c->o_nch) return fail(JAERO_EINVAL, "jaero_center_freq_changed: bad channel");
     HIPCHK(hipSetDevice(c->device));
     if (c->burst)
@@ -919,6 +929,7 @@ __global__ void k_carry_dly(const double2 *__restrict__ od, int Lo, const int *_
 // 175-289, mskdemodulator.cpp:135-263).  Here: a sibling bank is created for the new settings, those survivors are copied into it, the same
 // in-place setSettings as above runs on it, and it takes the place of the old bank behind the handle.  Whole banks only; control plane (it
 // allocates and synchronises).  Outputs not read yet move along; device pointers obtained from the views are stale.
+static void prof_collect(jaero_ctx *c);
 static int rebank_with_carry_over(jaero_ctx *c, const jaero_settings *s)
 {
     const JGeom og = c->g;
@@ -974,7 +985,7 @@ static int rebank_with_carry_over(jaero_ctx *c, const jaero_settings *s)
         hipMemcpy(d_t0, c->dly_t0.data(), sizeof(int) * nchp, hipMemcpyHostToDevice);
         // the old bank's shared slot counter stands at nB_total: a channel whose pointer restarted at slot t0 has its buffer index 0 there
         hipLaunchKernelGGL(k_carry_dly, dim3((nchp + 255) / 256), dim3(256), 0, 0, (const double2 *)c->p.dly, og.sps + 1, (const int *)d_t0, (double2 *)n->p.dly, ng.sps + 1, nchp);
-        hipDeviceSynchronize();
+        hipStreamSynchronize(0); // this copy's stream only: other banks on the GPU keep running
         hipFree(d_t0);
     }
     {
@@ -995,9 +1006,13 @@ static int rebank_with_carry_over(jaero_ctx *c, const jaero_settings *s)
 #undef CP
 #undef CP2
     n->m.flags = c->m.flags;
+    // kernel timings of the launches since the last jaero_profile_read belong to the handle, not to the bank behind it: drained into the
+    // totals here (their events go with the old bank)
+    if (c->prof) prof_collect(c);
     n->prof = c->prof;
+    for (size_t k = 0; k < sizeof(c->slots) / sizeof(c->slots[0]); k++) n->slots[k] = c->slots[k];
     if ((rc = apply_live_settings(n, 0, ng.nchp, s))) return fin(rc); // the padding lanes too: their window positions came over with I and must fit the new lengths
-    if (hipDeviceSynchronize() != hipSuccess) return fin(fail(JAERO_EHIP, "jaero_set_settings: carry-over failed"));
+    if (hipStreamSynchronize(n->last_stream) != hipSuccess || hipStreamSynchronize(0) != hipSuccess) return fin(fail(JAERO_EHIP, "jaero_set_settings: carry-over failed"));
     std::swap(*c, *n);
     jaero_destroy(n); // the old bank
     return 0;
@@ -1008,6 +1023,7 @@ extern "C" int jaero_set_settings(jaero_ctx *c, int channel, const jaero_setting
     // setSettings on a live object (oqpskdemodulator.cpp:175-289, mskdemodulator.cpp:135-263): retunes the mixers
     // (phase kept), recreates AGC / matched filters / timing delays / resonator, restarts the coarse ring pointer.
     if (!c || !s || channel < -1 || channel >= c->o_nch) return fail(JAERO_EINVAL, "jaero_set_settings: bad arguments");
+    POISONCHK(c, "jaero_set_settings");
     if (c->burst) return fail(JAERO_ENOTSUP, "jaero_set_settings on a live burst bank is not implemented; create a new bank");
     int rc = validate_settings(*s);
     if (rc) return rc;
@@ -1197,7 +1213,8 @@ extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int l
         HIPCHK(hipStreamWaitEvent(st, c->order_ev, 0));
     }
     c->last_stream = st;
-    c->poisoned = true; // until this write has been enqueued completely
+    // poisoned is raised where the first launch that advances device state or the schedule mirror is about to be enqueued (a failed copy of
+    // the input, transpose or history push leaves both as they were: the caller may simply write again) and lowered when the whole write is in
     if (c->burst)
     {
         const int rc = burst_write(c, pcm, nsamples, layout, is_device_ptr, st);
@@ -1225,6 +1242,7 @@ extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int l
         frames = c->d_pcm_frames; stride = nchp;
     }
 
+    c->poisoned = true; // from here on device state and mirror advance together or not at all
     if (c->pre8400)
     {
         // the whole write is prefiltered first (oqpskdemodulator.cpp:343-381); its oscillator takes the mean of mixer2's frequency over
@@ -1372,6 +1390,7 @@ static int check_overflow(jaero_ctx *c, int ch, int bit)
 
 extern "C" int jaero_read_softbits(jaero_ctx *c, int ch, int16_t *dst, int cap, int *n)
 {
+    POISONCHK(c, "jaero_read_softbits");
     if (!c || !dst || !n || ch < 0 || ch >= c->o_nch || cap < 0) return fail(JAERO_EINVAL, "jaero_read_softbits: bad arguments");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->last_stream));
@@ -1398,6 +1417,7 @@ extern "C" int jaero_read_softbits(jaero_ctx *c, int ch, int16_t *dst, int cap, 
 
 extern "C" int jaero_read_softbits_all(jaero_ctx *c, int16_t *dst, int capc, int *counts)
 {
+    POISONCHK(c, "jaero_read_softbits_all");
     if (!c || !dst || !counts || capc <= 0) return fail(JAERO_EINVAL, "jaero_read_softbits_all: bad arguments");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = c->last_stream;
@@ -1457,6 +1477,7 @@ __global__ void k_burst_keep_tail(int *__restrict__ cnt, const int *__restrict__
 
 extern "C" int jaero_softbits_view(jaero_ctx *c, void **dev_softbits, void **dev_counts, int *capacity)
 {
+    POISONCHK(c, "jaero_softbits_view");
     if (!c) return fail(JAERO_EINVAL, "null ctx");
     if (dev_softbits) *dev_softbits = c->o_soft;
     if (c->burst && dev_counts)
@@ -1481,6 +1502,7 @@ extern "C" int jaero_softbits_view(jaero_ctx *c, void **dev_softbits, void **dev
 
 extern "C" int jaero_discard_softbits(jaero_ctx *c, void *stream)
 {
+    POISONCHK(c, "jaero_discard_softbits");
     if (!c) return fail(JAERO_EINVAL, "null ctx");
     HIPCHK(hipSetDevice(c->device));
     if (c->burst)
@@ -1497,6 +1519,7 @@ extern "C" int jaero_discard_softbits(jaero_ctx *c, void *stream)
 
 extern "C" int jaero_read_status(jaero_ctx *c, int ch, jaero_status *stt)
 {
+    POISONCHK(c, "jaero_read_status");
     if (!c || !stt || ch < 0 || ch >= c->o_nch) return fail(JAERO_EINVAL, "jaero_read_status: bad arguments");
     HIPCHK(hipSetDevice(c->device));
     if (c->burst) hipLaunchKernelGGL(k_status_burst, dim3(1), dim3(64), 0, c->last_stream, c->bg, c->bp, ch, 1, c->d_status);
@@ -1531,15 +1554,18 @@ static int read_rows(jaero_ctx *c, int ch, double *rows, int caprows, int *nrows
 }
 extern "C" int jaero_read_status_log(jaero_ctx *c, int ch, double *rows, int caprows, int *nrows)
 {
+    POISONCHK(c, "jaero_read_status_log");
     if (c && c->burst) return fail(JAERO_ENOTSUP, "burst banks have an event log (jaero_read_events), not a status log");
     return read_rows(c, ch, rows, caprows, nrows, c ? c->p.I + (size_t)I_LOG_CNT * c->g.nchp : nullptr, c ? c->p.slog : nullptr, c ? c->g.log_cap : 0, 6, 4);
 }
 extern "C" int jaero_read_symbols(jaero_ctx *c, int ch, double *rows, int caprows, int *nrows)
 {
+    POISONCHK(c, "jaero_read_symbols");
     return read_rows(c, ch, rows, caprows, nrows, c ? c->o_sym_cnt : nullptr, c ? c->o_sym : nullptr, c ? c->o_sym_cap : 0, 3, 2);
 }
 extern "C" int jaero_read_events(jaero_ctx *c, int ch, double *rows, int caprows, int *nrows)
 {
+    POISONCHK(c, "jaero_read_events");
     if (c && !c->burst) return fail(JAERO_ENOTSUP, "continuous banks have a status log (jaero_read_status_log), not an event log");
     return read_rows(c, ch, rows, caprows, nrows, c ? c->bp.I + (size_t)BI_EV_CNT * c->bg.nchp : nullptr, c ? c->bp.evlog : nullptr, c ? c->bg.ev_cap : 0, 3, 4);
 }

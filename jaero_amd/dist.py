@@ -47,8 +47,13 @@ def ranks_share_a_device() -> bool:
     import torch
 
     n = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-    return n > 0 and lw > n
+    if n == 0:
+        return False
+    if "LOCAL_WORLD_SIZE" in os.environ:
+        return int(os.environ["LOCAL_WORLD_SIZE"]) > n
+    # launchers other than torchrun (srun, mpirun) do not export LOCAL_WORLD_SIZE, and WORLD_SIZE counts every node's ranks: all that is
+    # known about this node is this rank's own local index -- it shares a device exactly when that index does not name one
+    return int(os.environ.get("LOCAL_RANK", "0")) >= n
 
 
 def device_index(local: int) -> int:
@@ -71,7 +76,10 @@ def fan_out_pcm(frames, nch_total: int, nsamples: int, src: int = 0, device=None
     lo, hi = shard_range(nch_total, rank, world)
     if device is None:
         device = frames.device if frames is not None else torch.device("cpu")
-    mine = torch.empty((nsamples, hi - lo), dtype=torch.int16, device=device)
+    # gloo's point-to-point path takes host tensors only: staged through the host there (the control plane of ranks that share a device)
+    via_host = dist.get_backend() == "gloo" and torch.device(device).type != "cpu"
+    wire = torch.device("cpu") if via_host else device
+    mine = torch.empty((nsamples, hi - lo), dtype=torch.int16, device=wire)
     # point-to-point (xGMI is point-to-point; the volumes are tiny next to one link): src sends each peer its slice
     if rank == src:
         reqs = []
@@ -81,12 +89,12 @@ def fan_out_pcm(frames, nch_total: int, nsamples: int, src: int = 0, device=None
             if r == src:
                 mine.copy_(part)
             else:
-                reqs.append(dist.isend(part, dst=r))
+                reqs.append(dist.isend(part.to(wire), dst=r))
         for q in reqs:
             q.wait()
     else:
         dist.recv(mine, src=src)
-    return mine
+    return mine.to(device) if via_host else mine
 
 
 def gather_softbits(soft, counts, nch_total: int, dst: int = 0):
@@ -99,9 +107,11 @@ def gather_softbits(soft, counts, nch_total: int, dst: int = 0):
         return soft, counts
     rank, world = dist.get_rank(), dist.get_world_size()
     cap = soft.shape[1]
+    via_host = dist.get_backend() == "gloo" and soft.device.type != "cpu"  # gloo moves host tensors only
+    wire = torch.device("cpu") if via_host else soft.device
     if rank == dst:
-        soft_all = torch.empty((nch_total, cap), dtype=soft.dtype, device=soft.device)
-        counts_all = torch.empty((nch_total,), dtype=counts.dtype, device=counts.device)
+        soft_all = torch.empty((nch_total, cap), dtype=soft.dtype, device=wire)
+        counts_all = torch.empty((nch_total,), dtype=counts.dtype, device=wire)
         for r in range(world):
             l, h = shard_range(nch_total, r, world)
             if r == dst:
@@ -110,7 +120,7 @@ def gather_softbits(soft, counts, nch_total: int, dst: int = 0):
             else:
                 dist.recv(soft_all[l:h], src=r)
                 dist.recv(counts_all[l:h], src=r)
-        return soft_all, counts_all
-    dist.send(soft.contiguous(), dst=dst)
-    dist.send(counts.contiguous(), dst=dst)
+        return (soft_all.to(soft.device), counts_all.to(counts.device)) if via_host else (soft_all, counts_all)
+    dist.send(soft.contiguous().to(wire), dst=dst)
+    dist.send(counts.contiguous().to(wire), dst=dst)
     return None, None
