@@ -78,6 +78,7 @@ struct BGeom
     double fa_w, bt_w, pd_thr;
     // demod
     int fir_n, agc2_len, eb_len, msema_len, a1_lag, dly_len, d8_len;
+    int dly_ring, d8_ring; // burst MSK: sizes of the delayedsmpl / delayt8 rings, dly_len / d8_len rounded up to whole 64-byte cells of eight entries (k_burst_msk_fb.h)
     double a1_w, w4, w8, ee;
     double res_b0, res_b1, res_b2, res_a1, res_a2;
     double stref_freq, stq_step;

@@ -88,6 +88,7 @@ static void burst_fill_geometry(BGeom &g, const jaero_settings &s, int nch, unsi
         g.fa_len = g.fa_lag + 1;
         g.a1_lag = (int)(SPS / 2); g.a1_w = 0.0;
         g.d8_len = (int)(SPS / 2) + 1; g.dly_len = (int)SPS + 1;
+        g.d8_ring = (g.d8_len + 7) / 8 * 8; g.dly_ring = (g.dly_len + 7) / 8 * 8;
         g.stref_freq = s.fb / 2.0;
         g.stq_step = (s.fb / 2.0) * ((double)JD_WTSIZE) / ((float)(double)(int)s.Fs);
         g.fir_n = 2 * (int)SPS;
@@ -132,7 +133,7 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
     DA(p.agc2_ring, (size_t)nchp * g.agc2_len);
     DA(p.eb_e, (size_t)nchp * g.eb_len); DA(p.eb_e2, (size_t)nchp * g.eb_len);
     DA(p.firsave, (size_t)nchp * 2 * g.fir_n);
-    if (!oq) { DA(p.dly, (size_t)nchp * g.dly_len); DA(p.dly8, (size_t)nchp * g.d8_len); DA(p.a1, (size_t)nchp * g.d8_len); }
+    if (!oq) { DA(p.dly, (size_t)nchp * g.dly_ring); DA(p.dly8, (size_t)nchp * g.d8_ring); DA(p.a1, (size_t)nchp * g.d8_len); }
     DA(p.msema, (size_t)nchp * g.msema_len);
     DA(p.soft, (size_t)nchp * g.soft_cap);
     if (g.sym_cap) DA(p.sym, (size_t)nchp * g.sym_cap * 3);
@@ -228,7 +229,7 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
     c->m.nch = nch; c->m.nchp = nchp;
     c->m.flags.assign(nchp, 0);
     // burst OQPSK: 39 of its 55 history slots + the taps in LDS; burst MSK: 39 of 80 (1200 bps) or all 160 (600 bps) slots
-    const int lds = oq ? (2 * 39 * 64 + 64) * (int)sizeof(double) : 2 * (g.fir_n == 80 ? BMSK_FB_LDSN_80 : BMSK_FB_LDSN_160) * 64 * (int)sizeof(double) + BMSK_FB_MAIL_BYTES;
+    const int lds = oq ? (2 * 39 * 64 + 64) * (int)sizeof(double) : 2 * (g.fir_n == 80 ? BMSK_FB_LDSN_80 : BMSK_FB_LDSN_160) * 64 * (int)sizeof(double) + BMSK_FB_MAIL_BYTES + BMSK_FB_WC_BYTES;
     if (oq)
     {
         HIPCHK(hipFuncSetAttribute((const void *)k_burst_oqpsk_demod<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -271,7 +272,7 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
         prof_end(c, pi, st);
     }
     const bool cs = (c->flags & JAERO_FLAG_CAPTURE_SYMBOLS) != 0;
-    const int lds = g.kind == JAERO_KIND_BURST_OQPSK ? (2 * 39 * 64 + 64) * (int)sizeof(double) : 2 * (g.fir_n == 80 ? BMSK_FB_LDSN_80 : BMSK_FB_LDSN_160) * 64 * (int)sizeof(double) + BMSK_FB_MAIL_BYTES;
+    const int lds = g.kind == JAERO_KIND_BURST_OQPSK ? (2 * 39 * 64 + 64) * (int)sizeof(double) : 2 * (g.fir_n == 80 ? BMSK_FB_LDSN_80 : BMSK_FB_LDSN_160) * 64 * (int)sizeof(double) + BMSK_FB_MAIL_BYTES + BMSK_FB_WC_BYTES;
     int first = 1;
     c->poisoned = true; // the history push above is idempotent (same slots if the write is repeated); from here on state advances
     for (int pos = 0; pos < nsamples;)

@@ -13,8 +13,17 @@
 //     retuned by a trident verdict, so its table entry for the next sample is requested a whole sample ahead) and
 //     the front half has published the filter output for sample i; behind it the front half pushes sample i (where the gate is open) and
 //     forms the output for the next gated sample while the back half tracks sample i.  Mailboxes are double-buffered on i & 1.
-// LDS per pair: 2 x LDSN x 64 doubles of history + 5.5 KiB of mailboxes: LDSN = 72 of 80 taps (two pairs per CU: all four SIMDs busy), 152 of 160
-// (one pair per CU); the FIRN - LDSN oldest entries of each arm sit in the front half's registers, shifted under the gate's exec mask.
+// LDS per pair: 2 x LDSN x 64 doubles of history + 5.5 KiB of mailboxes + 24 KiB of write-combining cells (round 4, below): LDSN = 48 of 80
+// taps (two pairs per CU: all four SIMDs busy), 128 of 160 (one pair per CU); the FIRN - LDSN = 32 oldest entries of each arm sit in the
+// front half's registers, shifted under the gate's exec mask.
+// Round 4, the back half's window stores.  The EbNo, AGC2 and delay windows advance once per GATED sample of their own channel, so their
+// positions are per lane and their rings [channel][entry]; one 8-byte store per ring and gated sample, into a 64-byte sector that the
+// channel comes back to a sample later -- with 65 536 channels' sectors in flight L2 has evicted it by then, and every store cost a partial
+// sector write: 61 GB per busy launch for 7 GB of entries (profiles/pmc_summary_burst_msk.json, round 3).  Now a lane's entries of the
+// current cell of eight go to LDS ([ring][entry & 7][lane]) and leave as one complete sector when the cell is full.  All five windows
+// (EbNo e and e^2, AGC2, delayt8, delayedsmpl) advance together, start together and have sizes that are multiples of eight (the two delay
+// rings are rounded up to whole cells: a delay line needs "the entry written D pushes ago", not a ring of exactly D + 1), so one phase
+// serves them all and a cell never wraps.  Entries read back (the ones leaving a window) are at least 19 pushes old: long flushed.
 // Results are bit-identical to k_burst_msk_demod's (same operations in the same order); every burst-MSK bank test runs on this kernel.
 #pragma once
 #include "k_burst_demod.h"
@@ -24,10 +33,13 @@ struct BmskMail
     double *out; // [2][2][64] filter output (re, im) for the sample of that parity
     double *in;  // [2][3][64] mixer2's table entry (re, im) for the sample and vol_gain
     int *gate;   // [2][64]    1 = the sample is pushed (the channel's gate is open)
+    double *wc;  // [BMSK_FB_WC_RINGS][8][64] the back half's write-combining cells
 };
 #define BMSK_FB_MAIL_BYTES (2 * 2 * 64 * 8 + 2 * 3 * 64 * 8 + 2 * 64 * 4) // 5632
-#define BMSK_FB_LDSN_80 72
-#define BMSK_FB_LDSN_160 152
+#define BMSK_FB_LDSN_80 48
+#define BMSK_FB_LDSN_160 128
+#define BMSK_FB_WC_RINGS 6 // e^2, e, agc2, delayt8, delayedsmpl re / im
+#define BMSK_FB_WC_BYTES (BMSK_FB_WC_RINGS * 8 * 64 * 8) // 24576
 
 template <int FIRN, int LDSN>
 __device__ __forceinline__ void bmsk_front(const BGeom &g, const BPtrs &p, double *lre, double *lim, const BmskMail &M, int n, long long n0, int grp, int lane)
@@ -160,8 +172,28 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
 
     double *agc2_ring = p.agc2_ring + (size_t)ch * g.agc2_len;
     double *ebe_ring = p.eb_e + (size_t)ch * g.eb_len, *ebe2_ring = p.eb_e2 + (size_t)ch * g.eb_len;
-    double2 *dly_ring = p.dly + (size_t)ch * g.dly_len;
-    double *d8_ring = p.dly8 + (size_t)ch * g.d8_len;
+    double2 *dly_ring = p.dly + (size_t)ch * g.dly_ring;
+    double *d8_ring = p.dly8 + (size_t)ch * g.d8_ring;
+    // write-combining cells: this lane's column of [ring][entry & 7][lane]
+    double *wc = M.wc + lane;
+    enum { WC_E2 = 0, WC_E = 1, WC_AGC2 = 2, WC_D8 = 3, WC_DX = 4, WC_DY = 5 };
+    auto wc_at = [&](int ring, int k) -> double & { return wc[(ring * 8 + k) * 64]; };
+    // the cell being filled holds the entries pushed since its start: back from HBM (the previous launch wrote them out entry by entry)
+    {
+        const int ph = eb_pos & 7; // = agc2_pos & 7 = dly_pos & 7 = d8_pos & 7: the five windows advance together
+        for (int k = 0; k < ph; k++)
+        {
+            wc_at(WC_E2, k) = ebe2_ring[eb_pos - ph + k]; wc_at(WC_E, k) = ebe_ring[eb_pos - ph + k];
+            wc_at(WC_AGC2, k) = agc2_ring[agc2_pos - ph + k]; wc_at(WC_D8, k) = d8_ring[d8_pos - ph + k];
+            const double2 v = dly_ring[dly_pos - ph + k];
+            wc_at(WC_DX, k) = v.x; wc_at(WC_DY, k) = v.y;
+        }
+    }
+    auto wc_flush4 = [&](int ring, double *dst) __attribute__((always_inline)) { // eight entries of one ring: one 64-byte sector
+        double2 *d2 = (double2 *)dst;
+#pragma unroll
+        for (int k = 0; k < 4; k++) d2[k] = make_double2(wc_at(ring, 2 * k), wc_at(ring, 2 * k + 1));
+    };
     double *a1_ring = p.a1 + (size_t)ch * g.d8_len;
     double *msema_ring = p.msema + (size_t)ch * g.msema_len;
     int16_t *__restrict__ soft = p.soft + (size_t)ch * g.soft_cap;
@@ -245,10 +277,12 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
         {
             // window entries this sample replaces / reads: requested now, consumed behind the filter
             const double e2_old = ebe2_ring[eb_pos], e_old = ebe_ring[eb_pos], agc2_old = agc2_ring[agc2_pos];
-            const int dly_nx = (dly_pos + 1 >= g.dly_len) ? 0 : dly_pos + 1;
-            const int d8_nx = (d8_pos + 1 >= g.d8_len) ? 0 : d8_pos + 1, d8_nx2 = (d8_nx + 1 >= g.d8_len) ? 0 : d8_nx + 1;
-            const double2 ptd_pre = dly_ring[dly_nx];
-            const double d8_a = d8_ring[d8_nx2], d8_b = d8_ring[d8_nx];
+            // the delay rings are whole cells (g.dly_ring >= dly_len, g.d8_ring >= d8_len): "the oldest entry of a ring of dly_len" is the one
+            // written dly_len - 1 pushes ago, "the one behind it" dly_len - 2 ago
+            auto back = [](int pos, int lag, int ring) { const int q = pos - lag; return q < 0 ? q + ring : q; };
+            const double2 ptd_pre = dly_ring[back(dly_pos, g.dly_len - 1, g.dly_ring)];
+            const double d8_a = d8_ring[back(d8_pos, g.d8_len - 2, g.d8_ring)], d8_b = d8_ring[back(d8_pos, g.d8_len - 1, g.d8_ring)];
+            const int ph = eb_pos & 7;
             const double st_ptr_top = st_ptr;
             const double2 so_pre = cis[jd_cisidx(st_ptr)]; // the symbol oscillator's table entry: valid unless the preamble block below moves st_ptr
             double sre = M.out[(i & 1) * 128 + lane], sim = M.out[(i & 1) * 128 + 64 + lane]; // formed while the previous sample was tracked
@@ -282,10 +316,8 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
             const double sabs = hypot(sre, sim);
             {
                 const double sq = sabs * sabs;
-                double *e2p = ebe2_ring + eb_pos, *ep = ebe_ring + eb_pos;
-                eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq); *e2p = fabs(sq);
-                eb_esum = eb_esum - e_old; eb_esum = eb_esum + fabs(sabs); *ep = fabs(sabs);
-                eb_pos++; if (eb_pos >= g.eb_len) eb_pos = 0;
+                eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq); wc_at(WC_E2, ph) = fabs(sq);
+                eb_esum = eb_esum - e_old; eb_esum = eb_esum + fabs(sabs); wc_at(WC_E, ph) = fabs(sabs);
                 // the value is observable once per burst (the emission below), at the end of a launch (status) and where the gate closes;
                 // its IIR forgets a term after k samples as 0.8^k, so the arithmetic runs only in the JD_EBNO_TAIL samples before those
                 const int to_emit = (g.endRotation + (int)(200 * SPS)) - cntr;
@@ -302,9 +334,7 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
             }
             if (cntr == g.endRotation + (200 * SPS)) bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_EBNO, eb_ebno);
             {
-                double *ap = agc2_ring + agc2_pos;
-                agc2_sum = agc2_sum - agc2_old; agc2_sum = agc2_sum + fabs(sabs); *ap = fabs(sabs);
-                agc2_pos++; if (agc2_pos >= g.agc2_len) agc2_pos = 0;
+                agc2_sum = agc2_sum - agc2_old; agc2_sum = agc2_sum + fabs(sabs); wc_at(WC_AGC2, ph) = fabs(sabs);
                 double gain = 1.414213562 / fmax(agc2_sum / agc2_len_d, 0.000001);
                 gain = fmax(gain, 0.000001);
                 sre *= gain; sim *= gain;
@@ -312,9 +342,8 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
             const double abval = hypot(sre, sim);
             if (abval > 2.84) { const double k = (2.84 / abval); sre = k * sre; sim = k * sim; }
             // delayedsmpl.update_dont_touch(sig2)
-            dly_ring[dly_pos] = make_double2(sre, sim);
-            dly_pos = dly_nx;
-            const double2 ptd = ptd_pre; // = dly_ring[dly_pos]: the oldest entry, not the one just written (dly_len >= 2)
+            wc_at(WC_DX, ph) = sre; wc_at(WC_DY, ph) = sim;
+            const double2 ptd = ptd_pre; // the oldest entry, not the one just written (dly_len >= 2)
             const double pm_re = sre, pm_im = ptd.y;
             double st_eta = hypot(pm_re, pm_im);
             {
@@ -325,9 +354,21 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
                 st_eta = y;
             }
             // delayt8.update(st_eta): integer delay SPS/2
-            d8_ring[d8_pos] = st_eta;
-            d8_pos = d8_nx;
-            const double d8out = 0.0 * d8_a + 1.0 * d8_b; // d8_ring[d8_pos + 1] and d8_ring[d8_pos]: older than the entry just written (d8_len >= 3)
+            wc_at(WC_D8, ph) = st_eta;
+            const double d8out = 0.0 * d8_a + 1.0 * d8_b; // the two oldest entries of a ring of d8_len: older than the entry just written (d8_len >= 3)
+            // the five windows' entries of this gated sample are in their cell; a full cell leaves as whole sectors, then all advance
+            if (ph == 7)
+            {
+                wc_flush4(WC_E2, ebe2_ring + (eb_pos - 7)); wc_flush4(WC_E, ebe_ring + (eb_pos - 7));
+                wc_flush4(WC_AGC2, agc2_ring + (agc2_pos - 7)); wc_flush4(WC_D8, d8_ring + (d8_pos - 7));
+                double2 *dd = dly_ring + (dly_pos - 7);
+#pragma unroll
+                for (int k = 0; k < 8; k++) dd[k] = make_double2(wc_at(WC_DX, k), wc_at(WC_DY, k));
+            }
+            eb_pos++; if (eb_pos >= g.eb_len) eb_pos = 0;
+            agc2_pos++; if (agc2_pos >= g.agc2_len) agc2_pos = 0;
+            dly_pos++; if (dly_pos >= g.dly_ring) dly_pos = 0;
+            d8_pos++; if (d8_pos >= g.d8_ring) d8_pos = 0;
             {
                 double2 so = so_pre;
                 if (st_ptr != st_ptr_top) so = cis[jd_cisidx(st_ptr)];
@@ -396,6 +437,16 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
             jd_wt_next(m2_ptr, m2_step);
         }
     }
+    {
+        // the cell being filled goes out entry by entry (once per launch): the next launch reads it back
+        const int ph = eb_pos & 7;
+        for (int k = 0; k < ph; k++)
+        {
+            ebe2_ring[eb_pos - ph + k] = wc_at(WC_E2, k); ebe_ring[eb_pos - ph + k] = wc_at(WC_E, k);
+            agc2_ring[agc2_pos - ph + k] = wc_at(WC_AGC2, k); d8_ring[d8_pos - ph + k] = wc_at(WC_D8, k);
+            dly_ring[dly_pos - ph + k] = make_double2(wc_at(WC_DX, k), wc_at(WC_DY, k));
+        }
+    }
     BLDF(BS_M2_PTR) = m2_ptr; BLDF(BS_M2_STEP) = m2_step; BLDF(BS_M2_FREQ) = m2_freq; BLDF(BS_MC_FREQ) = mc_freq;
     BLDF(BS_ST_PTR) = st_ptr; BLDF(BS_ST_LAST) = st_last; BLDF(BS_STQ_PTR) = sth_ptr; BLDF(BS_VOL_GAIN) = vol_gain;
     BLDF(BS_STR_RE) = str_re; BLDF(BS_STR_IM) = str_im; BLDF(BS_SAV_RE) = sav_re; BLDF(BS_SAV_IM) = sav_im;
@@ -417,6 +468,7 @@ __global__ __launch_bounds__(128) void k_burst_msk_fb(const BGeom g, const BPtrs
     M.out = lds + 2 * LDSN * 64;
     M.in = M.out + 256;
     M.gate = (int *)(M.in + 384);
+    M.wc = (double *)((char *)M.out + BMSK_FB_MAIL_BYTES);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, grp = blockIdx.x;
     if (n <= 0) return;
     if (wave == 0) bmsk_front<FIRN, LDSN>(g, p, lre, lim, M, n, n0, grp, lane);

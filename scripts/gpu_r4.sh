@@ -50,3 +50,11 @@ for wl in ("oqpsk","msk"):
         except Exception as e: print(wl, v, "ERR", e, open("$OUT/ab_%s_%s.err"%(v,wl)).read()[-400:])
 PY
 fi
+if has burstmsk; then
+  timeout 1200 python -m pytest tests -m gpu -q -k "burst" --tb=short > "$OUT/pytest_burst.log" 2>&1; tail -8 "$OUT/pytest_burst.log"
+  ( timeout 600 python bench.py --workload burst_msk --no-cpu-baseline 2> "$OUT/bench_burst_msk.err" | tail -1 ) > "$OUT/bench_line_burst_msk.json"; cut -c1-400 "$OUT/bench_line_burst_msk.json"; echo; tail -2 "$OUT/bench_burst_msk.err"
+  python - <<PY
+import json
+l=json.load(open("$OUT/bench_line_burst_msk.json")); print(l["value"], l["ms_per_step"], l["config"].get("kernel_ms_per_step"), l["config"].get("oracle_check"))
+PY
+fi
