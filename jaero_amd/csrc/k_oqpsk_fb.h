@@ -379,6 +379,7 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, FbLds &L
     double res_x1 = LDF(S_RES_X1), res_x2 = LDF(S_RES_X2), res_y1 = LDF(S_RES_Y1), res_y2 = LDF(S_RES_Y2);
     double lf_x1 = LDF(S_LF_X1), lf_x2 = LDF(S_LF_X2), lf_y1 = LDF(S_LF_Y1), lf_y2 = LDF(S_LF_Y2);
     double sig2l_re = LDF(S_SIG2L_RE), sig2l_im = LDF(S_SIG2L_IM), ptd_re = LDF(S_PTD_RE), ptd_im = LDF(S_PTD_IM);
+    double ptd_th = jd_tanh(ptd_re); // kept beside ptd_re inside a launch (see the instant block); formed again here rather than stored
     double marg_sum = LDF(S_MARG_SUM), pm_sum = LDF(S_PM_SUM), msema_sum = LDF(S_MSEMA_SUM), mse = LDF(S_MSE);
     const double thresh = LDF(S_THRESH);
     int marg_pos = LDI(I_MARG_POS), dt_pos = LDI(I_DT_POS), pm_pos = LDI(I_PM_POS), msema_pos = LDI(I_MSEMA_POS);
@@ -429,7 +430,8 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, FbLds &L
         const double in_re = q_re, in_im = q_im;
         q_re = px_dt.x; q_im = px_dt.y;
         {
-            const double cr = cos(marg_val), sr = sin(marg_val);
+            double sr, cr;
+            sincos(marg_val, &sr, &cr); // the same two values as cos() and sin() (one argument reduction, the same kernels)
             const double nr = q_re * cr - q_im * sr;
             const double ni = q_re * sr + q_im * cr;
             q_re = nr; q_im = ni;
@@ -541,11 +543,17 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, FbLds &L
             const double pt_re = pt_this * sre + pt_last * sig2l_re;
             const double pt_im = pt_this * sim + pt_last * sig2l_im;
             yui++; yui %= 2;
-            if (!yui) { ptd_re = pt_re; ptd_im = pt_im; }
+            // The carrier detector needs tanh(pt_im) of this instant and tanh(ptd_re) of the instant half a symbol earlier (:509-512).  With
+            // some lanes of the wavefront at either kind of instant in nearly every sample, both branches run every sample: ONE evaluation
+            // here serves both -- the lanes at the earlier kind of instant take the tanh of the value they are about to keep as ptd_re and
+            // keep it with it.  Same argument, same function: the same bits as evaluating it half a symbol later (~100 instructions per
+            // sample less in the back half).
+            const double th = jd_tanh(yui ? pt_im : pt_re);
+            if (!yui) { ptd_re = pt_re; ptd_im = pt_im; ptd_th = th; }
             else
             {
-                const double ct_xt = jd_tanh(pt_im) * pt_re;
-                const double ct_xt_d = jd_tanh(ptd_re) * ptd_im;
+                const double ct_xt = th * pt_re;
+                const double ct_xt_d = ptd_th * ptd_im;
                 double ct_ec = ct_xt_d - ct_xt;
                 if (ct_ec > M_PI) ct_ec = M_PI;
                 if (ct_ec < -M_PI) ct_ec = -M_PI;

@@ -58,3 +58,10 @@ import json
 l=json.load(open("$OUT/bench_line_burst_msk.json")); print(l["value"], l["ms_per_step"], l["config"].get("kernel_ms_per_step"), l["config"].get("oracle_check"))
 PY
 fi
+if has bench8400; then
+  ( timeout 600 python bench.py --workload oqpsk8400 --as-written 0 --no-cpu-baseline 2> "$OUT/bench_8400.err" | tail -1 ) > "$OUT/bench_line_oqpsk8400.json"
+  python - <<PY
+import json
+l=json.load(open("$OUT/bench_line_oqpsk8400.json")); print("8400:", l["value"], l["ms_per_step"], l["config"].get("kernel_ms_per_step"), l["config"].get("oracle_check"))
+PY
+fi
