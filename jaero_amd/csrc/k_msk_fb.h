@@ -389,6 +389,88 @@ __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const M
         a[0] = acc_prev_re; a[64] = acc_prev_im;             // sample 0
         a[128] = acc_last_re; a[128 + 64] = acc_last_im;     // sample 1
     }
+    // The output half of a symbol -- marg / dt / rotation by the averaged error / MSE / soft bits (mskdemodulator.cpp:428-469) -- feeds nothing
+    // back into the loops, so it is queued at the instant and run for all lanes together every MFB_DEFER samples (round 4; k_oqpsk_fb has
+    // done this since round 2).  With 40 samples per symbol some lane of 64 is at an instant in 80 % of the samples: run in place, the
+    // ~700 instructions of this half (two window divisions, cos, sin, the differential decode) ran in 80 % of them for one lane in 64.  A lane
+    // has at most one symbol queued (instants are ~SPS >= 20 samples apart, the queue empties every 16); one about to queue a second goes first.
+    // The entries leaving the three windows are requested one sample after the instant and used when the queue empties.
+    constexpr int MFB_DEFER = 16;
+    bool pend = false, need_px = false;
+    double pd_ec = 0, pd_re = 0, pd_im = 0, px_marg = 0, px_ms = 0;
+    double2 px_dt = make_double2(0.0, 0.0);
+    auto request_px = [&]() __attribute__((always_inline)) {
+        px_marg = marg_ring[marg_pos];
+        int dn = dt_pos + 1; if (dn >= g.dt_len) dn = 0;
+        px_dt = dt_ring[dn]; // dt_len = SPS/2 + 1 > 1
+        px_ms = msema_ring[msema_pos];
+        need_px = false;
+    };
+    auto output_half = [&]() __attribute__((always_inline)) {
+        const double ct_ec = pd_ec;
+        double q_re = pd_re, q_im = pd_im;
+        {
+            const double v = ct_ec / 2.0;
+            double *mp = marg_ring + marg_pos;
+            marg_sum = marg_sum - px_marg; marg_sum = marg_sum + v; *mp = v;
+            marg_pos++; if (marg_pos >= g.marg_len) marg_pos = 0;
+        }
+        const double marg_val = marg_sum / ((double)g.marg_len);
+        {
+            dt_ring[dt_pos] = make_double2(q_re, q_im);
+            dt_pos++; if (dt_pos >= g.dt_len) dt_pos = 0;
+            q_re = px_dt.x; q_im = px_dt.y;
+        }
+        {
+            const double cr = cos(marg_val), sr = sin(marg_val);
+            const double nr = q_re * cr - q_im * sr;
+            const double ni = q_re * sr + q_im * cr;
+            q_re = nr; q_im = ni;
+        }
+        {
+            const double tda = (fabs(q_re * 0.75) - 1.0), tdb = (fabs(q_im * 0.75) - 1.0);
+            const double e = (tda * tda) + (tdb * tdb);
+            double *ep = msema_ring + msema_pos;
+            msema_sum = msema_sum - px_ms; msema_sum = msema_sum + fabs(e); *ep = fabs(e);
+            msema_pos++; if (msema_pos >= g.msema_len) msema_pos = 0;
+            mse = msema_sum / ((double)g.msema_len);
+        }
+        if (CAPSYM)
+        {
+            if (sym_cnt < g.sym_cap)
+            {
+                double *sp = p.sym + ((size_t)ch * g.sym_cap + sym_cnt) * 3;
+                sp[0] = q_re; sp[1] = q_im; sp[2] = mse;
+                sym_cnt++;
+            }
+            else overflow |= 2;
+        }
+        // soft differential decode + demap (:450-469, DSP.cpp:531-563)
+        int b0, b1;
+        {
+            double soft_in = q_im, r;
+            if (soft_in < 0 && diff_last < 0) r = diff_last;
+            else if (soft_in > 0 && diff_last > 0) r = -diff_last;
+            else r = fabs(diff_last);
+            diff_last = soft_in;
+            b0 = jd_softbit((r) * 127.0 + 128.0);
+            soft_in = q_re;
+            if (soft_in < 0 && diff_last < 0) r = diff_last;
+            else if (soft_in > 0 && diff_last > 0) r = -diff_last;
+            else r = fabs(diff_last);
+            diff_last = soft_in;
+            r = -r;
+            b1 = jd_softbit((r) * 127.0 + 128.0);
+        }
+        if (soft_cnt + 2 <= g.soft_cap)
+        {
+            soft[soft_cnt] = (int16_t)b0;
+            soft[soft_cnt + 1] = (int16_t)b1;
+            soft_cnt += 2;
+        }
+        else overflow |= 1;
+        pend = false;
+    };
     // mailbox: the table index of mixer2 for sample 0
     L.idx[lane] = jd_cisidx(m2_ptr);
     double2 nx_cst = cis[jd_cisidx(st_ptr)];
@@ -456,15 +538,13 @@ __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const M
             else jd_wt_advance_fraction(st_ptr, -(1.0 - weighting) * st_angle_error * (0.003 / 360.0));
         }
 
+        if (need_px) request_px(); // for the symbol queued in the previous sample
         double frac;
-        if (jd_wt_passed(st_last, st_ptr, st_step, g.ee, frac))
+        const bool inst = jd_wt_passed(st_last, st_ptr, st_step, g.ee, frac);
+        if (pend && (inst || (i & (MFB_DEFER - 1)) == 0)) output_half();
+        if (inst)
         {
-            // entries leaving the three symbol-rate windows (per-channel arrays in HBM), requested together ahead of their use
-            const double marg_old = marg_ring[marg_pos];
-            int dn = dt_pos + 1; if (dn >= g.dt_len) dn = 0;
-            const double2 dt_old = dt_ring[dn]; // dt_len = SPS/2 + 1 > 1
-            const double ms_old = msema_ring[msema_pos];
-            // carrier tracking (:411-426)
+            // carrier tracking (:411-426): the half of the symbol that feeds back
             const double ct_xt = tanh(sim) * sre;
             const double ct_xt_d = tanh(ptd.x) * ptd.y;
             double ct_ec = ct_xt_d - ct_xt;
@@ -476,67 +556,7 @@ __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const M
             if (dcd) carrier_aggression = 8.0 * g.correctionfactor;
             jd_wt_inc_phase_deg(m2_ptr, carrier_aggression * 1.0 * ct_ec);
             jd_wt_setfreq(m2_freq, m2_step, (carrier_aggression * 0.01 * ct_ec) + m2_freq, samplerate);
-
-            {
-                const double v = ct_ec / 2.0;
-                double *mp = marg_ring + marg_pos;
-                marg_sum = marg_sum - marg_old; marg_sum = marg_sum + v; *mp = v;
-                marg_pos++; if (marg_pos >= g.marg_len) marg_pos = 0;
-            }
-            const double marg_val = marg_sum / ((double)g.marg_len);
-            {
-                dt_ring[dt_pos] = make_double2(q_re, q_im);
-                dt_pos++; if (dt_pos >= g.dt_len) dt_pos = 0;
-                q_re = dt_old.x; q_im = dt_old.y;
-            }
-            {
-                const double cr = cos(marg_val), sr = sin(marg_val);
-                const double nr = q_re * cr - q_im * sr;
-                const double ni = q_re * sr + q_im * cr;
-                q_re = nr; q_im = ni;
-            }
-            {
-                const double tda = (fabs(q_re * 0.75) - 1.0), tdb = (fabs(q_im * 0.75) - 1.0);
-                const double e = (tda * tda) + (tdb * tdb);
-                double *ep = msema_ring + msema_pos;
-                msema_sum = msema_sum - ms_old; msema_sum = msema_sum + fabs(e); *ep = fabs(e);
-                msema_pos++; if (msema_pos >= g.msema_len) msema_pos = 0;
-                mse = msema_sum / ((double)g.msema_len);
-            }
-            if (CAPSYM)
-            {
-                if (sym_cnt < g.sym_cap)
-                {
-                    double *sp = p.sym + ((size_t)ch * g.sym_cap + sym_cnt) * 3;
-                    sp[0] = q_re; sp[1] = q_im; sp[2] = mse;
-                    sym_cnt++;
-                }
-                else overflow |= 2;
-            }
-            // soft differential decode + demap (:450-469, DSP.cpp:531-563)
-            int b0, b1;
-            {
-                double soft_in = q_im, r;
-                if (soft_in < 0 && diff_last < 0) r = diff_last;
-                else if (soft_in > 0 && diff_last > 0) r = -diff_last;
-                else r = fabs(diff_last);
-                diff_last = soft_in;
-                b0 = jd_softbit((r) * 127.0 + 128.0);
-                soft_in = q_re;
-                if (soft_in < 0 && diff_last < 0) r = diff_last;
-                else if (soft_in > 0 && diff_last > 0) r = -diff_last;
-                else r = fabs(diff_last);
-                diff_last = soft_in;
-                r = -r;
-                b1 = jd_softbit((r) * 127.0 + 128.0);
-            }
-            if (soft_cnt + 2 <= g.soft_cap)
-            {
-                soft[soft_cnt] = (int16_t)b0;
-                soft[soft_cnt + 1] = (int16_t)b1;
-                soft_cnt += 2;
-            }
-            else overflow |= 1;
+            pend = true; need_px = true; pd_ec = ct_ec; pd_re = q_re; pd_im = q_im;
         }
 
         // advance the NCOs (:480-483) and hand the next sample's carrier table index to the front half
@@ -549,6 +569,8 @@ __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const M
         nx_cst = cis[jd_cisidx(st_ptr)]; // the symbol NCO's table value for the next sample: in flight across the barrier
         fb_barrier();
     }
+    if (need_px) request_px();
+    if (pend) output_half();
 
     LDF(S_M2_PTR) = m2_ptr; LDF(S_M2_STEP) = m2_step; LDF(S_M2_FREQ) = m2_freq;
     LDF(S_ST_PTR) = st_ptr; LDF(S_ST_STEP) = st_step; LDF(S_ST_LAST) = st_last;

@@ -7,7 +7,7 @@
 # Everything lands in gpurun_out/<tag>/; copy what is to be judged into profiles/ (scripts/collect_evidence.py <tag>).
 set -u
 TAG=${1:-evidence}; shift || true
-WHAT=${*:-smoke tests bench prof pmc sq workloads gpus2}
+WHAT=${*:-smoke tests bench prof pmc sq workloads gpus2 gpus8}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 has() { [[ " $WHAT " == *" $1 "* ]]; }
@@ -51,6 +51,11 @@ if has workloads; then
   done
 fi
 if has gpus2; then ( timeout 600 python bench.py --gpus 2 --channels 16384 --steps 8 --warmup 3 --no-cpu-baseline 2> "$OUT/bench_gpus2.err" | tail -1 ) > "$OUT/bench_line_gpus2_shared_device.json"; cut -c1-200 "$OUT/bench_line_gpus2_shared_device.json"; echo; fi
+if has gpus8; then
+  # the driver's 8-GPU command on this 1-GPU lease: eight ranks share the device (gloo control plane, RCCL edge operations skipped, flagged in
+  # the line) -- BASELINE configs[4] as written, 4096 channels per GPU
+  ( timeout 900 python bench.py --gpus 8 --channels 4096 --steps 8 --warmup 3 --no-cpu-baseline 2> "$OUT/bench_gpus8.err" | tail -1 ) > "$OUT/bench_line_gpus8_shared_device.json"; cut -c1-300 "$OUT/bench_line_gpus8_shared_device.json"; echo; tail -3 "$OUT/bench_gpus8.err"
+fi
 find "$OUT" -name "*.csv" -size +6M -delete
 find "$OUT" -type d -name "pmc*_SIZE" -prune -exec rm -rf {} + 2>/dev/null
 du -sh "$OUT"

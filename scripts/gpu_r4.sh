@@ -65,3 +65,11 @@ import json
 l=json.load(open("$OUT/bench_line_oqpsk8400.json")); print("8400:", l["value"], l["ms_per_step"], l["config"].get("kernel_ms_per_step"), l["config"].get("oracle_check"))
 PY
 fi
+if has msk; then
+  timeout 1200 python -m pytest tests -m gpu -q -k "msk and not burst" --tb=short > "$OUT/pytest_msk.log" 2>&1; tail -6 "$OUT/pytest_msk.log"
+  ( timeout 600 python bench.py --workload msk --no-cpu-baseline 2> "$OUT/bench_msk.err" | tail -1 ) > "$OUT/bench_line_msk.json"; tail -2 "$OUT/bench_msk.err"
+  python - <<PY
+import json
+l=json.load(open("$OUT/bench_line_msk.json")); print("msk:", l["value"], l["ms_per_step"], l["config"].get("kernel_ms_per_step"), l["config"].get("kernel_hbm_frac"), l["config"].get("oracle_check"))
+PY
+fi
