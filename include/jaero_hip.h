@@ -66,7 +66,10 @@ extern "C" {
 #define JAERO_EINVAL (-1)   /* bad argument / unsupported settings combination        */
 #define JAERO_ENODEV (-2)   /* no usable HIP device                                    */
 #define JAERO_ENOMEM (-3)   /* device or host allocation failed                        */
-#define JAERO_EHIP (-4)     /* a HIP runtime call failed (see jaero_last_error)        */
+#define JAERO_EHIP (-4)     /* a HIP runtime call failed (see jaero_last_error); also: every call but jaero_destroy on a bank whose
+                             * jaero_write failed AFTER its first state-advancing launch (device state and the host's schedule mirror
+                             * disagree: nothing can continue from there).  A write that failed earlier -- input copy, transpose --
+                             * left the bank as it was and may be repeated. */
 #define JAERO_EOVERFLOW (-5)/* soft-bit / log capacity exceeded since the last read    */
 #define JAERO_ENOTSUP (-6)  /* kind / rate not implemented                             */
 #define JAERO_W_RATE 1      /* (jaero_ingest_push only) warning: sample rate differs, data queued anyway */

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
     double d42_1 = BLDF(BS_D42_1), d42_2 = BLDF(BS_D42_2), d42_3 = BLDF(BS_D42_3), d8_1 = BLDF(BS_D8_1), d8_2 = BLDF(BS_D8_2);
     double res_x1 = BLDF(BS_RES_X1), res_x2 = BLDF(BS_RES_X2), res_y1 = BLDF(BS_RES_Y1), res_y2 = BLDF(BS_RES_Y2);
     double sig2l_re = BLDF(BS_SIG2L_RE), sig2l_im = BLDF(BS_SIG2L_IM), ptd_re = BLDF(BS_PTD_RE), ptd_im = BLDF(BS_PTD_IM);
+    double ptd_th = jd_tanh(ptd_re); // kept beside ptd_re inside a launch; formed again here rather than stored
     double msema_sum = BLDF(BS_MSEMA_SUM), mse = BLDF(BS_MSE), lastmse = BLDF(BS_LASTMSE);
     const double thresh = BLDF(BS_THRESH);
     if (first_of_write) lastmse = mse; // double lastmse=mse at the top of writeDataSlot (:318)
@@ -294,12 +295,14 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
             {
                 if ((even && yui == 1) || (!even && yui == 0)) { yui++; yui %= 2; }
             }
-            if (!yui) { ptd_re = pt_re; ptd_im = pt_im; }
+            // one tanh per instant for both kinds of instant (k_oqpsk_fb.h, round 4): the earlier instant keeps tanh(ptd_re) beside ptd_re
+            const double th = jd_tanh(yui ? pt_im : pt_re);
+            if (!yui) { ptd_re = pt_re; ptd_im = pt_im; ptd_th = th; }
             else
             {
                 const double q_re = pt_re, q_im = ptd_im;
-                const double ct_xt = jd_tanh(pt_im) * pt_re;
-                const double ct_xt_d = jd_tanh(ptd_re) * ptd_im;
+                const double ct_xt = th * pt_re;
+                const double ct_xt_d = ptd_th * ptd_im;
                 double ct_ec = ct_xt_d - ct_xt;
                 if (ct_ec > M_PI) ct_ec = M_PI;
                 if (ct_ec < -M_PI) ct_ec = -M_PI;

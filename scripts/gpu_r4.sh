@@ -73,3 +73,28 @@ import json
 l=json.load(open("$OUT/bench_line_msk.json")); print("msk:", l["value"], l["ms_per_step"], l["config"].get("kernel_ms_per_step"), l["config"].get("kernel_hbm_frac"), l["config"].get("oracle_check"))
 PY
 fi
+if has calib; then
+  cd /tmp
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/calib_$c" -o pmc -- "$R/scripts/ubench/hbm_counters" > "$OUT/calib_$c.log" 2>&1
+    f=$(find "$OUT/calib_$c" -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/calib_$c.csv"
+  done
+  cd "$R"
+  python - <<PY
+import csv, json, collections
+moved = {"rd8_rows": 8589934592, "wr8_rows": 8589934592, "wr16_own": 17179869184, "rd16_stream": 17179869184, "wr16_stream": 17179869184, "rd8_rows_nt": 8589934592, "wr8_rows_nt": 8589934592, "rd16_stream_nt": 17179869184}
+res = collections.defaultdict(dict)
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    try:
+        for r in csv.DictReader(open("$OUT/calib_%s.csv" % c)):
+            k = r["Kernel_Name"].split("(")[0]
+            if k in moved: res[k][c + "_KiB"] = float(r["Counter_Value"])
+    except Exception as e: print("calib", c, e)
+for k, v in res.items():
+    v["bytes_moved"] = moved[k]
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        if c + "_KiB" in v: v[c + "_bytes_over_moved"] = round(v[c + "_KiB"] * 1024 / moved[k], 4)
+json.dump({"what": "scripts/ubench/hbm_counters.hip under rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes), MI355X; round 4 adds the non-temporal rows", "kernels": res}, open("$OUT/counter_calibration.json", "w"), indent=1)
+print(json.dumps(res, indent=0))
+PY
+fi

@@ -40,6 +40,27 @@ __global__ __launch_bounds__(64) void wr16_stream(double2 *p)
     double2 *q = p + (size_t)blockIdx.x * ROWS * 64 + threadIdx.x;
     for (int r = 0; r < ROWS; r++) q[(size_t)r * 64] = make_double2((double)r, 2.0);
 }
+// the same rows with the non-temporal hint k_coarse6 gives its streamed accesses since round 4 (y[] read and written once per estimate, the ring read once)
+__global__ __launch_bounds__(64) void rd8_rows_nt(const double *p, double *out)
+{
+    const double *q = p + (size_t)blockIdx.x * ROWS * 64 + threadIdx.x;
+    double a = 0;
+    for (int r = 0; r < ROWS; r++) a += __builtin_nontemporal_load(q + (size_t)r * 64);
+    if (a == 1.2345) out[0] = a;
+}
+__global__ __launch_bounds__(64) void wr8_rows_nt(double *p)
+{
+    double *q = p + (size_t)blockIdx.x * ROWS * 64 + threadIdx.x;
+    for (int r = 0; r < ROWS; r++) __builtin_nontemporal_store((double)r, q + (size_t)r * 64);
+}
+__global__ __launch_bounds__(64) void rd16_stream_nt(const double2 *p, double *out)
+{
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    const v2 *q = (const v2 *)p + (size_t)blockIdx.x * ROWS * 64 + threadIdx.x;
+    double a = 0;
+    for (int r = 0; r < ROWS; r++) { const v2 v = __builtin_nontemporal_load(q + (size_t)r * 64); a += v.x + v.y; }
+    if (a == 1.2345) out[0] = a;
+}
 int main()
 {
     const int waves = 4096;
@@ -54,6 +75,9 @@ int main()
     hipLaunchKernelGGL(wr16_own, dim3(waves), dim3(64), 0, 0, d);
     hipLaunchKernelGGL(rd16_stream, dim3(waves), dim3(64), 0, 0, (const double2 *)d, o);
     hipLaunchKernelGGL(wr16_stream, dim3(waves), dim3(64), 0, 0, d);
+    hipLaunchKernelGGL(rd8_rows_nt, dim3(waves), dim3(64), 0, 0, (const double *)d, o);
+    hipLaunchKernelGGL(wr8_rows_nt, dim3(waves), dim3(64), 0, 0, (double *)d);
+    hipLaunchKernelGGL(rd16_stream_nt, dim3(waves), dim3(64), 0, 0, (const double2 *)d, o);
     hipDeviceSynchronize();
     return 0;
 }
