@@ -98,3 +98,11 @@ json.dump({"what": "scripts/ubench/hbm_counters.hip under rocprofv3 --kernel-tra
 print(json.dumps(res, indent=0))
 PY
 fi
+if has burstoqpsk; then
+  timeout 1200 python -m pytest tests -m gpu -q -k "burst" --tb=short > "$OUT/pytest_burst.log" 2>&1; tail -4 "$OUT/pytest_burst.log"
+  ( timeout 600 python bench.py --workload burst_oqpsk --no-cpu-baseline 2> "$OUT/bench_burst_oqpsk.err" | tail -1 ) > "$OUT/bench_line_burst_oqpsk.json"; tail -2 "$OUT/bench_burst_oqpsk.err"
+  python - <<PY
+import json
+l=json.load(open("$OUT/bench_line_burst_oqpsk.json")); print("burst_oqpsk:", l["value"], l["ms_per_step"], {k:round(v/l["steps"],3) for k,v in l["config"].get("kernel_ms_total",{}).items()}, l["config"].get("oracle_check"))
+PY
+fi
