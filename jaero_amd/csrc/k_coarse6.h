@@ -398,12 +398,17 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
         // barriers (3 us) -- and the rest the CU's own memory phase: a CU gets ~45 GB/s out of loads that miss L2 (the 45 loads behind the y
         // stores take a wavefront 7-8 us to issue), and no registers are free to request any of it a transform earlier (the transform needs
         // 196 of 256; holding 20 y values across it made it slower than the wait they save, touching the lines with one-dword loads cost more
-        // issue time than it saved).  What is here now: 13.2 -> 12.6 ms per 65 536 estimates.
+        // issue time than it saved).  What is here now: 13.2 -> 12.4 ms per 65 536 estimates.
         c6_bar(); // the exchange buffer is free: it receives a copy of y for the fold below
         // smooth with fftshift: y[i] = y[i]*0.9 + 0.1*10*log10(fmax(abs(out[i]),1)), out[i] = X[i ^ N/2]
         // all 32 old y values are requested before the log10s (their registers: the imaginary plane, dead once only |X|^2 is kept); y and the
         // ring are streamed (read once, written once per estimate): non-temporal accesses
+        CoarseSlotState cst;
         {
+            // One pass per slot: log10, smooth, store, LDS copy -- and, into the four registers that frees, the NEXT estimate's ring entry of
+            // that slot.  Requested in one burst behind the barrier, the 32 ring loads (and the 32 y stores in front of them) stalled every
+            // wavefront of the workgroup at the same place for 7 us (a CU issues ~45 GB/s of loads that miss L2); spread over the logarithms,
+            // one wavefront of a SIMD waits at a load while the other computes (12.6 -> 12.4 ms per 65 536 estimates).
             double yv[E];
 #pragma unroll
             for (int s = 0; s < E; s++) d.r[s] = d.r[s] * d.r[s] + d.i[s] * d.i[s];
@@ -411,29 +416,11 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
 #pragma unroll
             for (int s = 0; s < E; s++) yv[s] = __builtin_nontemporal_load((y + ((s * NT) ^ (N / 2))) + t); // (s*NT + t) ^ N/2: uniform base + t
             C6_FENCE; // or the scheduler sinks every load to its use again
-            // 10*log10(max(|X|,1)) == 5*log10(max(|X|^2,1)): no hypot; differs from the reference expression by <= 1 ulp
-#pragma unroll
-            for (int s = 0; s < E; s++) d.r[s] = 5.0 * c2_log10(fmax(d.r[s], 1.0));
-#pragma unroll
-            for (int s = 0; s < E; s++)
-            {
-                const int ib = (s * NT) ^ (N / 2);
-                const double yn = yv[s] * 0.9 + d.r[s];
-                __builtin_nontemporal_store(yn, (y + ib) + t);
-                (xch + ib)[t] = yn;
-            }
-        }
-        C6_TRACE(4);
-        c6_bar(); // the fold reads the LDS copy; the stores to y[] drain in the background
-        C6_TRACE(5);
-        // the channel's acquisition state, needed behind the peak search: requested here, where the fewest registers are live (the spectrum
-        // and the y values are gone, the next ring not yet requested) and in front of the ring prefetch (vmcnt retires in order)
-        const CoarseSlotState cst = coarse_slot_load_v(g, p, ch);
-        C6_TRACE(14);
-        if (has_next)
-        {
-            // laundered: known since the top of the estimate, the 32 ring addresses would otherwise be computed there and kept (spilled)
-            // across the three transforms -- and every reload waits for all vector loads in flight, which serialises this prefetch
+            // the channel's acquisition state, needed behind the peak search: in front of everything else that is requested below (vmcnt
+            // retires in order), as ordinary loads
+            cst = coarse_slot_load_v(g, p, ch);
+            // laundered: known since the top of the estimate, the 32 ring addresses would otherwise be computed there and kept (spilled) across
+            // the three transforms -- and every reload waits for all vector loads in flight
             int bpn = bp_next, chn = ch_next, tp = t;
             asm volatile("" : "+v"(bpn), "+v"(chn), "+v"(tp));
             typedef double c6_v2 __attribute__((ext_vector_type(2)));
@@ -442,12 +429,23 @@ __device__ __forceinline__ void coarse6_body(const JGeom g, const JPtrs p, const
 #pragma unroll
             for (int s = 0; s < E; s++)
             {
-                const c6_v2 v = __builtin_nontemporal_load(ringn + ((toffp + s * NT) & (N - 1)));
-                d.r[s] = v.x; d.i[s] = v.y;
-                if (s == 15) { C6_TRACE(15); }
+                const int ib = (s * NT) ^ (N / 2);
+                // 10*log10(max(|X|,1)) == 5*log10(max(|X|^2,1)): no hypot; differs from the reference expression by <= 1 ulp
+                const double yn = yv[s] * 0.9 + 5.0 * c2_log10(fmax(d.r[s], 1.0));
+                __builtin_nontemporal_store(yn, (y + ib) + t);
+                (xch + ib)[t] = yn;
+                {
+                    // unconditional: without a next estimate ch_next / bp_next still name this one (valid memory, result unused) -- under
+                    // `if (has_next)` the old contents of d.r[s] had to stay live beside the new ones (151 spilled registers)
+                    const c6_v2 v = __builtin_nontemporal_load(ringn + ((toffp + s * NT) & (N - 1)));
+                    d.r[s] = v.x; d.i[s] = v.y;
+                }
+                if ((s & 3) == 3) C6_FENCE; // four slots at a time: the scheduler may not gather the loads at either end again
             }
+            C6_TRACE(4);
+            c6_bar(); // the fold reads the LDS copy; the stores to y[] drain in the background
+            C6_TRACE(5);
         }
-
         C6_TRACE(6);
         // fold + peak search (:116-131)
         double fs_e = g.Fs; // opaque again: the value above must not be kept for this

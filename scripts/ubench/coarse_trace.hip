@@ -115,10 +115,10 @@ int main(int argc, char **argv)
             CK(hipMemcpy(tr.data(), dtr, tr.size() * 8, hipMemcpyDeviceToHost));
             unsigned long long *nul = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &nul, sizeof(nul)));
             const int iters = nch / grid < 256 ? nch / grid : 256;
-            const int order[] = {0, 1, 2, 3, 4, 5, 14, 15, 6, 7, 8, 9, 10};
-            const char *ph[] = {"FFT 1", "band limit + FFT 2", "square + FFT 3", "barrier, |X|^2, y loads, 32 log10, combine, y stores + LDS copy", "barrier",
-                                "state loads issued", "ring loads 0..15 issued", "ring loads 16..31 issued", "fold", "wavefront reduce", "barrier + reduce 8 + slot (every thread)", "recentre (rare)", "loop latch -> next top"};
-            const int NP = 13;
+            const int order[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10};
+            const char *ph[] = {"FFT 1", "band limit + FFT 2", "square + FFT 3", "barrier, |X|^2, y loads, per slot: log10, smooth, y store, LDS copy, next ring load", "barrier",
+                                "(fold set-up)", "fold", "wavefront reduce", "barrier + reduce 8 + slot (every thread)", "recentre (rare)", "loop latch -> next top"};
+            const int NP = 11;
             double acc[NP] = {0}; int cnt = 0;
             for (int it = 4; it + 1 < iters; it++)
             {
