@@ -140,11 +140,11 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
     DA(p.evlog, (size_t)nchp * g.ev_cap * 3);
     DA(c->d_pcm_raw, (size_t)c->max_write * nch);
     DA(c->d_status, nchp);
-    c->tri_grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->tri_grid = 2 * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256); // two 256-thread workgroups per CU
     if (c->tri_grid > nchp) c->tri_grid = nchp;
     if (oq && ((int)floor((0.25 * g.fb) / (g.Fs / (double)TRI_N) + 0.5)) % 4 != 0)
         return fail(JAERO_ENOTSUP, "burst OQPSK at fb %g / Fs %g: k_trident searches one residue class of bins at a time and needs round(fb / 4 / hzperbin) to be a multiple of 4", g.fb, g.Fs);
-    c->tri_lds = (TRI_XCH + TRI_DL) * (int)sizeof(double); // wg_fft<13>'s exchange buffer + one residue class of trident differences (k_trident)
+    c->tri_lds = TRI_XCH * (int)sizeof(double); // wg_fft13_e32's exchange buffer (k_trident; one residue class of trident differences shares it)
     double2 *d_cis = nullptr, *d_tw = nullptr, *d_tw15 = nullptr;
     double *d_taps = nullptr, *d_hil = nullptr;
     DA(d_cis, JD_WTSIZE); DA(d_tw, TRI_H); DA(d_tw15, TRI_H); DA(d_taps, 2 * g.fir_n); DA(d_hil, g.hil_ntaps / 4);
@@ -289,7 +289,7 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
         LAUNCHCHK("k_burst_front");
         prof_end(c, pi, st);
         pi = prof_begin(c, 1, st);
-        hipLaunchKernelGGL(k_trident, dim3(c->tri_grid), dim3(C2_THREADS), c->tri_lds, st, g, p, n0);
+        hipLaunchKernelGGL(k_trident, dim3(c->tri_grid), dim3(TRI_THREADS), c->tri_lds, st, g, p, n0);
         LAUNCHCHK("k_trident");
         prof_end(c, pi, st);
         pi = prof_begin(c, 0, st);

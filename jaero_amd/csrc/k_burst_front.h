@@ -5,6 +5,7 @@
 #include "burst_device.h"
 #include "jaero_device.h"
 #include "k_coarse2.h"
+#include "k_coarse6.h" // wg_fft13_e32
 #include "k_pre8400.h" // pf_fft4096
 
 #define BLDF(f) (p.S[(size_t)(f) * nchp + ch])
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(64) void k_burst_front(const BGeom g, const BPtrs p
 
 // first maximum over the workgroup: the largest value, among equals the lowest index (what an ascending scan with a strict compare keeps);
 // idx < 0 = "no candidate".  Wavefront reduction through shuffles, one LDS round for the eight wavefront results.  All threads get the result.
+template <int NTHREADS>
 __device__ __forceinline__ void tri_argmax_first(double &v, int &idx, double *red_val, int *red_idx, int t)
 {
 #pragma unroll
@@ -301,7 +303,7 @@ __device__ __forceinline__ void tri_argmax_first(double &v, int &idx, double *re
     __syncthreads();
     v = red_val[0]; idx = red_idx[0];
 #pragma unroll
-    for (int w = 1; w < C2_THREADS / 64; w++)
+    for (int w = 1; w < NTHREADS / 64; w++)
     {
         const double ov = red_val[w];
         const int oi = red_idx[w];
@@ -319,15 +321,18 @@ __device__ __forceinline__ void tri_argmax_first(double &v, int &idx, double *re
 //     LDS (32 KiB behind the exchange buffer) and are searched at once.
 //   burst MSK: d = |top| and the two searches are per-bin conditions around the strongest base bin: four base passes, the reduction, four top
 //     passes whose candidates are tracked on the fly.  Nothing is stored at all.
-#define TRI_DL 4096 // doubles of LDS behind wg_fft<13>'s exchange buffer (8704 doubles)
-#define TRI_XCH 8704
-__global__ __launch_bounds__(C2_THREADS) void k_trident(const BGeom g, const BPtrs p, long long n0)
+// Round 4: 256 threads x 32 points on wg_fft13_e32 (k_coarse6.h: 32 x 16 x 16, two exchanges, natural order in and out) instead of 512 x 16
+// on wg_fft<13> (16 x 32 x 16: half its threads idle in the middle pass, 74 spilled registers); two workgroups per CU (64 KiB of LDS each),
+// the residue class's differences share the exchange buffer (it is idle between a transform's last read and the next one's first barrier).
+#define TRI_THREADS 256
+#define TRI_XCH C6_XCH13
+__global__ __launch_bounds__(TRI_THREADS, 2) void k_trident(const BGeom g, const BPtrs p, long long n0)
 {
-    extern __shared__ __attribute__((aligned(16))) double xch[]; // TRI_XCH + TRI_DL doubles
-    __shared__ double red_val[C2_THREADS / 64];
-    __shared__ int red_idx[C2_THREADS / 64];
+    extern __shared__ __attribute__((aligned(16))) double xch[]; // TRI_XCH doubles
+    __shared__ double red_val[TRI_THREADS / 64];
+    __shared__ int red_idx[TRI_THREADS / 64];
     __shared__ double sh_bb[2];
-    double *dl = xch + TRI_XCH;
+    double *dl = xch; // one residue class of trident differences (4096 doubles), between two transforms
     const int t = threadIdx.x, nchp = g.nchp;
     const int nev = *p.ev_count;
     const bool oq = g.kind == JAERO_KIND_BURST_OQPSK_D;
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(C2_THREADS) void k_trident(const BGeom g, const BPt
         // window: cval_d[e - tri_sz + k] = cv[e - tri_sz - D1 + k], e = n0 + evp
         const long long w0 = n0 + evp - g.tri_sz - g.D1 + 8LL * g.cv_len;
         const double *__restrict__ cvre = p.cvre + (size_t)grp * g.cv_len * 64 + lane;
-        double mag[8];                          // OQPSK: |base[k]| of this thread's bins of the current class
+        double mag[16];                         // OQPSK: |base[k]| of this thread's bins of the current class
         double bv = -1.0, bre = 0.0, bim = 0.0; // strongest base bin of this thread ...
         int bi = -1;
         double minval = 0.0;                    // ... and of the event (MSK: known after the fourth pass)
@@ -351,8 +356,8 @@ __global__ __launch_bounds__(C2_THREADS) void k_trident(const BGeom g, const BPt
         double lv = 0.0; int lidx = -1;         // MSK: strongest top bin below / above the strongest base bin
         double hv = 0.0; int hidx = -1;
         // X[4q + r] = sum_{n<8192} (x[n] + x[n+8192] (-j)^r) W_32768^(n r) W_8192^(n q): four 2^13-point transforms per window (the
-        // windows are <= 2^14 samples followed by zeros).  2^13 points over 512 threads = 16 per thread (wg_fft<13>).  Only bins below
-        // N/2 are needed: q < 4096 (slots s < 8).
+        // windows are <= 2^14 samples followed by zeros).  2^13 points over 256 threads = 32 per thread: n = s * 256 + t on entry,
+        // q = s * 256 + t on exit.  Only bins below N/2 are needed: q < 4096 (slots s < 16).
         for (int pass = 0; pass < 8; pass++)
         {
             const int which = oq ? (pass & 1) : (pass >> 2), r = oq ? (pass >> 1) : (pass & 3); // which: 0 base, 1 top
@@ -360,18 +365,18 @@ __global__ __launch_bounds__(C2_THREADS) void k_trident(const BGeom g, const BPt
             if (!oq && pass == 4)
             {
                 minval = bv; minvalbin = bi;
-                tri_argmax_first(minval, minvalbin, red_val, red_idx, t);
+                tri_argmax_first<TRI_THREADS>(minval, minvalbin, red_val, red_idx, t);
                 if (bi == minvalbin) { sh_bb[0] = bre; sh_bb[1] = bim; } // exactly one thread holds that bin
                 if (!(minval > 0.0)) minvalbin = 0; // MSK starts from minval = 0 with a strict compare
             }
-            CV<16> d;
+            CV<32> d;
             const int slot0 = (int)((w0 + off) % g.cv_len); // wave-uniform; off + len <= tri_sz < cv_len: at most one wrap below
 #pragma unroll
-            for (int s = 0; s < 16; s++)
+            for (int s = 0; s < 32; s++)
             {
-                const int n = s * C2_THREADS + t;
+                const int n = s * TRI_THREADS + t;
                 double x0 = 0.0, x1 = 0.0;
-                if (s * C2_THREADS < len && n < len)
+                if (s * TRI_THREADS < len && n < len)
                 {
                     int sl = slot0 + n; if (sl >= g.cv_len) sl -= g.cv_len;
                     x0 = cvre[(size_t)sl * 64];
@@ -393,14 +398,14 @@ __global__ __launch_bounds__(C2_THREADS) void k_trident(const BGeom g, const BPt
                     d.r[s] = fr * w.x - fi * w.y; d.i[s] = fr * w.y + fi * w.x;
                 }
             }
-            wg_fft<13>(d, xch, p.tw14, t);
-            // thread t slot s holds X[4 (s*512 + t) + r]
+            wg_fft13_e32(d, xch, p.tw14, t);
+            // thread t slot s holds X[4 (s*256 + t) + r]
             if (which == 0)
             {
 #pragma unroll
-                for (int s = 0; s < 8; s++)
+                for (int s = 0; s < 16; s++)
                 {
-                    const int k = 4 * (s * C2_THREADS + t) + r;
+                    const int k = 4 * (s * TRI_THREADS + t) + r;
                     const double a = hypot(d.r[s], d.i[s]);
                     mag[s] = a;
                     if (a > bv || (a == bv && k < bi)) { bv = a; bi = k; bre = d.r[s]; bim = d.i[s]; }
@@ -408,11 +413,12 @@ __global__ __launch_bounds__(C2_THREADS) void k_trident(const BGeom g, const BPt
             }
             else if (oq)
             {
+                __syncthreads(); // every thread has read its last exchange values: the buffer takes the class's differences
 #pragma unroll
-                for (int s = 0; s < 8; s++) dl[s * C2_THREADS + t] = hypot(d.r[s], d.i[s]) - mag[s]; // d[4 q + r] at q
+                for (int s = 0; s < 16; s++) dl[s * TRI_THREADS + t] = hypot(d.r[s], d.i[s]) - mag[s]; // d[4 q + r] at q
                 __syncthreads();
                 // firstbin = b <= k < lstbin = N/2 - b, k = 4 q + r:  b4 <= q < 4096 - b4 for every r (b is a multiple of 4)
-                for (int q = b4 + t; q < (TRI_H >> 2) - b4; q += C2_THREADS)
+                for (int q = b4 + t; q < (TRI_H >> 2) - b4; q += TRI_THREADS)
                 {
                     const double tv = dl[q - b4] + dl[q + b4] - dl[q];
                     const int k = 4 * q + r;
@@ -422,9 +428,9 @@ __global__ __launch_bounds__(C2_THREADS) void k_trident(const BGeom g, const BPt
             else
             {
 #pragma unroll
-                for (int s = 0; s < 8; s++)
+                for (int s = 0; s < 16; s++)
                 {
-                    const int k = 4 * (s * C2_THREADS + t) + r;
+                    const int k = 4 * (s * TRI_THREADS + t) + r;
                     if (k > 50)
                     {
                         const double a = hypot(d.r[s], d.i[s]);
@@ -439,10 +445,10 @@ __global__ __launch_bounds__(C2_THREADS) void k_trident(const BGeom g, const BPt
         if (oq)
         {
             minval = bv; minvalbin = bi;
-            tri_argmax_first(minval, minvalbin, red_val, red_idx, t);
+            tri_argmax_first<TRI_THREADS>(minval, minvalbin, red_val, red_idx, t);
             if (bi == minvalbin) { sh_bb[0] = bre; sh_bb[1] = bim; }
             if (!(minval > 0.0)) minvalbin = 0;
-            tri_argmax_first(mv, mi, red_val, red_idx, t); // (its barriers also publish sh_bb)
+            tri_argmax_first<TRI_THREADS>(mv, mi, red_val, red_idx, t); // (its barriers also publish sh_bb)
             const double maxval = mv;
             const int maxvalbin = mi;
             res.ok = (maxval > 500.0) && (fabs((((double)(maxvalbin - minvalbin))) * hzperbin) < 20.0);
@@ -456,9 +462,9 @@ __global__ __launch_bounds__(C2_THREADS) void k_trident(const BGeom g, const BPt
         }
         else
         {
-            tri_argmax_first(lv, lidx, red_val, red_idx, t);
+            tri_argmax_first<TRI_THREADS>(lv, lidx, red_val, red_idx, t);
             const int maxtoppos = (lidx >= 0) ? lidx : 0;
-            tri_argmax_first(hv, hidx, red_val, red_idx, t);
+            tri_argmax_first<TRI_THREADS>(hv, hidx, red_val, red_idx, t);
             const int maxtopposhigh = (hidx >= 0) ? hidx : 0;
             const int distfrompeak = abs(maxtoppos - minvalbin);
             res.ok = (minval > 500.0) && (abs(distfrompeak - psb) < abs(psb / 20));

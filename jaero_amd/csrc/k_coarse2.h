@@ -1,6 +1,5 @@
 // k_coarse2.h -- the register-FFT building blocks: CV<L> (L complex points in registers), regfft<L> (radix-4 / radix-2 DFT of them),
-// wg_fft<LOG2N> (an N-point DFT of a 512-thread workgroup's data, N = E x 32 x 16 with two LDS exchanges: k_trident's correlations),
-// c2_log10, c4_twiddle16, c4_lds_barrier.  The coarse-frequency estimator kernels themselves are in k_coarse6.h (round 3); the first
+// c2_log10, c4_twiddle16, c4_lds_barrier (wg_fft<LOG2N>, the 512-thread E x 32 x 16 transform k_trident used until round 4, left with it).  The coarse-frequency estimator kernels themselves are in k_coarse6.h (round 3); the first
 // register-resident one, k_coarse2<LOG2N>, lived here (rounds 1-2).
 #pragma once
 #include "jaero_device.h"
@@ -114,121 +113,6 @@ __device__ __forceinline__ void twiddle_powers(const double2 base, const double2
     A[0] = make_double2(1.0, 0.0);
     A[1] = s4; A[2] = cmul2(s4, s4); A[3] = cmul2(A[2], s4); A[4] = cmul2(A[2], A[2]);
     A[5] = cmul2(A[4], s4); A[6] = cmul2(A[3], A[3]); A[7] = cmul2(A[4], A[3]);
-}
-
-// In-place forward N-point DFT of the workgroup's data, 512 threads, N = E x 32 x 16 (E = N/512 = 32 or 16).
-// On entry thread t holds x[s*512 + t] in slot s (s < E); on exit thread t holds X[s*512 + t] in slot s.
-// xch: LDS exchange buffer of max(E*528, 512*(E+1)) doubles.
-// TWS: the twiddle table holds W_(N*TWS)^k (a table made for a TWS times longer transform), read with stride TWS.
-template <int LOG2N, int TWS = 1>
-__device__ __forceinline__ void wg_fft(CV<(1 << LOG2N) / C2_THREADS> &d, double *xch, const double2 *__restrict__ tw, int t)
-{
-#pragma clang fp contract(fast)
-    constexpr int N = 1 << LOG2N;
-    constexpr int E = N / C2_THREADS;          // 32 or 16
-    constexpr int LOGE = (E == 32) ? 5 : 4;
-    constexpr int G3 = E / 16;                 // 16-point FFTs per thread in pass 3
-    constexpr int S1 = 528, S2 = E + 1;
-    const int n3 = t & 15, n2 = t >> 4;        // pass-1 identity of this thread: (n2, n3) = n mod 512
-    // the three table values of this transform, requested before the first butterfly (each used to be loaded, and waited
-    // for, where it is consumed)
-    const double2 tw_p1 = tw[((16 * n2) & (N - 1)) * TWS];
-    const double2 tw_p2b = tw[((n3 * (t >> 4)) & (N - 1)) * TWS], tw_p2s = tw[((n3 * E) & (N - 1)) * TWS];
-
-    // ---- pass 1: E-point FFT over n1, twiddle W_N^(16*n2*k1) ----
-    {
-        CV<E> a;
-        regfft<E>(d, a);
-        __builtin_amdgcn_sched_barrier(0);
-        double2 B[4], A[8];
-        twiddle_powers<E>(make_double2(1.0, 0.0), tw_p1, B, A);
-#pragma unroll
-        for (int k1 = 0; k1 < E; k1++)
-        {
-            const double2 w = (k1 < 4) ? B[k1 & 3] : cmul2(A[k1 >> 2], B[k1 & 3]);
-            d.r[k1] = a.r[k1] * w.x - a.i[k1] * w.y;
-            d.i[k1] = a.r[k1] * w.y + a.i[k1] * w.x;
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- exchange 1: L1[k1][n2][n3] (k1 stride 528); pass-2 thread u: n3 = u&15, k1 = u>>4 (active if k1 < E) ----
-    CV<32> b;
-    const int k1u = t >> 4;
-    const bool act2 = k1u < E;
-    {
-        __syncthreads();
-#pragma unroll
-        for (int k1 = 0; k1 < E; k1++) xch[k1 * S1 + t] = d.r[k1];
-        __syncthreads();
-        if (act2)
-        {
-#pragma unroll
-            for (int m = 0; m < 32; m++) b.r[m] = xch[k1u * S1 + m * 16 + n3];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k1 = 0; k1 < E; k1++) xch[k1 * S1 + t] = d.i[k1];
-        __syncthreads();
-        if (act2)
-        {
-#pragma unroll
-            for (int m = 0; m < 32; m++) b.i[m] = xch[k1u * S1 + m * 16 + n3];
-        }
-    }
-    // ---- pass 2: 32-point FFT over n2, twiddle W_N^(n3*(k1 + E*k2)) ----
-    if (act2)
-    {
-        CV<32> c;
-        __builtin_amdgcn_sched_barrier(0);
-        regfft<32>(b, c);
-        __builtin_amdgcn_sched_barrier(0);
-        double2 B[4], A[8];
-        twiddle_powers<E>(tw_p2b, tw_p2s, B, A);
-#pragma unroll
-        for (int k2 = 0; k2 < 32; k2++)
-        {
-            const double2 w = (k2 < 4) ? B[k2 & 3] : cmul2(A[k2 >> 2], B[k2 & 3]);
-            b.r[k2] = c.r[k2] * w.x - c.i[k2] * w.y;
-            b.i[k2] = c.r[k2] * w.y + c.i[k2] * w.x;
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- exchange 2: M[(k2*16 + n3)][k1] (row stride E+1); pass-3 thread v: k1 = v & (E-1), k2 = (v >> LOGE) + (512/E) r ----
-    {
-        const int k1v = t & (E - 1), k2b = t >> LOGE;
-        CV<16> c[G3];
-        __syncthreads();
-        if (act2)
-        {
-#pragma unroll
-            for (int k2 = 0; k2 < 32; k2++) xch[(k2 * 16 + n3) * S2 + k1u] = b.r[k2];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < G3; r++)
-#pragma unroll
-            for (int m = 0; m < 16; m++) c[r].r[m] = xch[((k2b + (C2_THREADS / E) * r) * 16 + m) * S2 + k1v];
-        __syncthreads();
-        if (act2)
-        {
-#pragma unroll
-            for (int k2 = 0; k2 < 32; k2++) xch[(k2 * 16 + n3) * S2 + k1u] = b.i[k2];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < G3; r++)
-#pragma unroll
-            for (int m = 0; m < 16; m++) c[r].i[m] = xch[((k2b + (C2_THREADS / E) * r) * 16 + m) * S2 + k1v];
-        // ---- pass 3: 16-point FFT over n3; X[k1 + E*k2 + 32E*k3] -> slot r + G3*k3 ----
-#pragma unroll
-        for (int r = 0; r < G3; r++)
-        {
-            CV<16> o;
-            regfft<16>(c[r], o);
-#pragma unroll
-            for (int k3 = 0; k3 < 16; k3++) { d.r[r + G3 * k3] = o.r[k3]; d.i[r + G3 * k3] = o.i[k3]; }
-        }
-    }
 }
 
 // log10(x) for x >= 1, ~2 ulp, ~30 instructions (ocml's correctly-rounded log10 costs ~110 and the kernel needs N of them per
