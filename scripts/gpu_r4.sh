@@ -106,3 +106,12 @@ import json
 l=json.load(open("$OUT/bench_line_burst_oqpsk.json")); print("burst_oqpsk:", l["value"], l["ms_per_step"], {k:round(v/l["steps"],3) for k,v in l["config"].get("kernel_ms_total",{}).items()}, l["config"].get("oracle_check"))
 PY
 fi
+if has t8400; then
+  timeout 1200 python -m pytest tests -m gpu -q -k "8400 or msk_600 or jfastfir or rate_change" --tb=short > "$OUT/pytest_8400.log" 2>&1; tail -4 "$OUT/pytest_8400.log"
+fi
+if has prof8400; then
+  cd /tmp
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_8400" -o stats -- python "$R/bench.py" --workload oqpsk8400 --steps 6 --warmup 2 --no-cpu-baseline --as-written 0 --check-channels 0 --preroll 40 > "$OUT/prof8400.json" 2> "$OUT/prof8400.err"
+  f=$(find "$OUT/prof_8400" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -E "k_|Name" "$f" | cut -c1-170 | head -12
+  cd "$R"
+fi

@@ -441,11 +441,12 @@ def test_burst_msk_65536_channels(B, oracle_mod):
     bank.close()
 
 
-@pytest.mark.parametrize("nch", [4096])
+@pytest.mark.parametrize("nch", [4096, 4099])
 def test_msk_600_bank(B, oracle_mod, nch):
-    """600 bps MSK at 48 kHz (the 160-tap loop k_msk_samples<160,78>) in a bank: 4096 channels = persistent iterations of k_coarse6_13
-    per workgroup and launch, 32 estimates per channel (one every 2048 samples); every channel its own lockingbw; 29 distinct signals,
-    channel c carries signal (3 c) mod 29."""
+    """600 bps MSK at 48 kHz (the 160-tap loop, k_msk_fb<160,72,...,2,52>: two front / back pairs per workgroup) in a bank: 4096 channels =
+    persistent iterations of k_coarse6_13 per workgroup and launch, 32 estimates per channel (one every 2048 samples); every channel its own
+    lockingbw; 29 distinct signals, channel c carries signal (3 c) mod 29.  4099 channels = 65 groups (the last with three live lanes): the last of the 33
+    two-pair workgroups holds one live pair and one that only keeps the barrier count."""
     import torch
 
     from jaero_amd import capi
