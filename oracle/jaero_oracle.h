@@ -73,6 +73,9 @@ typedef struct jo_burst jo_burst;
 /* = constructor + setAFC/SQL/CPUReduce defaults + setSettings + start(); kind = JO_KIND_BURST_* */
 jo_burst *jo_burst_create(const jo_settings *s);
 void jo_burst_destroy(jo_burst *d);
+/* BurstOqpskDemodulator::setSettings / BurstMskDemodulator::setSettings on the live object (burstoqpskdemodulator.cpp:202-277,
+ * burstmskdemodulator.cpp:150-325) */
+void jo_burst_set_settings(jo_burst *d, const jo_settings *s);
 void jo_burst_set_flags(jo_burst *d, int afc, int sql, int cpu_reduce);
 void jo_burst_set_dcd(jo_burst *d, int dcd); /* BurstMskDemodulator::DCDstatSlot */
 /* = writeData (mono) */

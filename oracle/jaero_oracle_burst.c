@@ -877,6 +877,14 @@ void jo_burst_destroy(jo_burst *d)
     free(d->soft.p); free(d->events.p); free(d->symbols.p);
     free(d);
 }
+/* setSettings on the LIVE object (a user pressing OK in the settings dialog): the same functions the constructor path runs -- new AGCs, EbNo
+ * meter and moving averages, Hilbert filter / peak detector / trident fill restarted, and DelayThing::setLength (DSP.h:447-453) keeping the
+ * old CONTENTS of d1 / d2 / the peak detector's lines (delayedsmpl for burst MSK) with the pointer back at zero.  The bit rate and sample rate
+ * of a live object may change too (all lengths follow). */
+void jo_burst_set_settings(jo_burst *d, const jo_settings *s)
+{
+    if (d->kind == JO_KIND_BURST_OQPSK) boqpsk_set_settings(d, s); else bmsk_set_settings(d, s);
+}
 void jo_burst_set_flags(jo_burst *d, int afc, int sql, int cpu_reduce) { d->afc = afc; d->sql = sql; d->cpuReduce = cpu_reduce; }
 void jo_burst_set_dcd(jo_burst *d, int dcd) { d->dcd = dcd; }
 void jo_burst_trace(jo_burst *d, int on) { d->trace = on; }

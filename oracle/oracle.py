@@ -300,6 +300,12 @@ class BurstDemod:
     def center_freq_changed(self, hz: float):
         self.L.jo_burst_center_freq_changed(self.h, float(hz))
 
+    def set_settings(self, settings: Settings):
+        """setSettings on the live object (burstoqpskdemodulator.cpp:202-277, burstmskdemodulator.cpp:150-325)."""
+        self.L.jo_burst_set_settings.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.jo_burst_set_settings.restype = None
+        self.L.jo_burst_set_settings(self.h, C.byref(settings))
+
     def take_soft(self):
         return _drain(self.L.jo_burst_take_soft, self.h, 1, np.int16, 1 << 16)
 
@@ -323,14 +329,19 @@ class BurstDemod:
 
 
 def run_burst(settings: Settings, pcm: np.ndarray, chunk: int = 4096, afc=False, sql=False, capture_symbols=False, trace=False,
-              center_at: int = -1, center_hz: float = 0.0):
-    """Feed pcm in `chunk`-sample writes (CenterFreqChangedSlot(center_hz) in front of the first write at or behind sample `center_at`);
+              center_at: int = -1, center_hz: float = 0.0, set_at=(), set_settings=None):
+    """Feed pcm in `chunk`-sample writes (CenterFreqChangedSlot(center_hz) in front of the first write at or behind sample `center_at`;
+    setSettings(set_settings) on the live object in front of the first write at or behind each sample of `set_at`);
     returns dict(soft, events[, symbols], pending, mse, freq_est)."""
     d = BurstDemod(settings, afc=afc, sql=sql, capture_symbols=capture_symbols, trace=trace)
+    set_at = sorted([set_at] if np.isscalar(set_at) else list(set_at))
     for s in range(0, pcm.shape[0], chunk):
         if center_at >= 0 and s >= center_at:
             d.center_freq_changed(center_hz)
             center_at = -1
+        while set_at and s >= set_at[0]:
+            d.set_settings(set_settings if set_settings is not None else settings)
+            set_at.pop(0)
         d.write(pcm[s:s + chunk])
     out = {"soft": d.take_soft(), "events": d.take_events(), "pending": d.pending, "mse": d.mse, "freq_est": d.freq_est}
     if capture_symbols:

@@ -107,7 +107,7 @@ static std::function<void()> g_set_again;
 template <class DEMOD>
 static double feed(DEMOD &d, const QByteArray &pcm)
 {
-    long set_at = (long)getd("set_at", -1);
+    long set_at = (long)getd("set_at", -1), set_at2 = (long)getd("set_at2", -1); // set_at2: a second setSettings (inside the first one's transient)
     int chunk = geti("chunk", 4096);
     long dcd_at = (long)getd("dcd_at", -1);         // sample index at which DCDstatSlot(true) is called (chunk aligned)
     long dcd_off_at = (long)getd("dcd_off_at", -1);
@@ -123,6 +123,7 @@ static double feed(DEMOD &d, const QByteArray &pcm)
         if (dcd_off_at >= 0 && s >= dcd_off_at) { d.DCDstatSlot(false); dcd_off_at = -1; }
         if (cf_at >= 0 && s >= cf_at) { d.CenterFreqChangedSlot(cf_hz); cf_at = -1; }
         if (set_at >= 0 && s >= set_at) { if (g_set_again) g_set_again(); set_at = -1; }
+        if (set_at2 >= 0 && s >= set_at2) { if (g_set_again) g_set_again(); set_at2 = -1; }
         long n = chunk;
         if (s + n > nsamp) n = nsamp - s;
         g_write_start = s;
@@ -208,7 +209,14 @@ static double run_burstoqpsk(const QByteArray &pcm, Capture &c)
     d.setScatterPointType(BurstOqpskDemodulator::SPT_None);
     d.setSettings(s);
     d.start();
-    return feed(d, pcm);
+    g_set_again = [&d, s]() mutable {
+        s.freq_center = getd("set_freq_center", s.freq_center); s.lockingbw = getd("set_lockingbw", s.lockingbw);
+        s.signalthreshold = getd("set_threshold", s.signalthreshold);
+        d.setSettings(s);
+    };
+    const double secs = feed(d, pcm);
+    g_set_again = nullptr;
+    return secs;
 }
 
 static double run_burstmsk(const QByteArray &pcm, Capture &c)
@@ -225,7 +233,14 @@ static double run_burstmsk(const QByteArray &pcm, Capture &c)
     d.DCDstatSlot(false);
     d.setSettings(s);
     d.start();
-    return feed(d, pcm);
+    g_set_again = [&d, s]() mutable {
+        s.fb = getd("set_fb", s.fb); s.freq_center = getd("set_freq_center", s.freq_center); s.lockingbw = getd("set_lockingbw", s.lockingbw);
+        s.signalthreshold = getd("set_threshold", s.signalthreshold);
+        d.setSettings(s);
+    };
+    const double secs = feed(d, pcm);
+    g_set_again = nullptr;
+    return secs;
 }
 
 int main(int argc, char **argv)

@@ -142,3 +142,44 @@ def test_bundled_recordings(oracle_mod, f):
     o = oracle_mod.run_burst(oracle_mod.burst_msk_settings(), x, chunk=4096)
     assert np.array_equal(o["soft"], g["soft"])
     assert np.array_equal(as_write_stamps(o["events"], 4096), g["events"])
+
+
+# setSettings on the live object (a user pressing OK in the settings dialog while audio runs): what survives is a member-by-member mixture --
+# new AGCs / EbNo meter / moving averages, Hilbert filter, peak detector and trident fill restarted, but DelayThing::setLength (DSP.h:447-453)
+# keeps the old CONTENTS of d1 / d2 with the pointer back at zero, startstop / mse / oscillator phases stay (burst OQPSK), cntr and the matched
+# filters restart (burst MSK).  Positions: idle, between the peak detector's firing and the trident check, while the delayed burst runs
+# through the demodulator, and twice in a row (the second call inside the first one's transient).
+SET_CASES_OQPSK = [(25000, -1), (31500, -1), (35000, -1), (40000, -1), (31000, 33000), (52000, 53000)]
+
+
+@pytest.mark.parametrize("set_at,set_at2", SET_CASES_OQPSK)
+def test_burst_oqpsk_set_settings_vs_ref(R, set_at, set_at2):
+    pcm, _ = G.burst_oqpsk(130000, burst_starts=[30000, 80000], ndata_sym=800, fc=7990.0, ebno_db=14.0, seed=91)
+    kw = dict(set_at=set_at, set_lockingbw=9000, set_freq_center=7000, set_threshold=0.55)
+    if set_at2 >= 0:
+        kw["set_at2"] = set_at2
+    r = R.run_ref("burstoqpsk", pcm, chunk=1000, **kw)
+    new = R.burst_oqpsk_settings(freq_center=7000.0)
+    new.lockingbw, new.signalthreshold = 9000.0, 0.55
+    o = R.run_burst(R.burst_oqpsk_settings(), pcm, chunk=1000, set_at=[a for a in (set_at, set_at2) if a >= 0], set_settings=new)
+    assert np.array_equal(r["soft"], o["soft"])
+    assert np.array_equal(r["events"], as_write_stamps(o["events"], 1000))
+    assert (o["events"][:, 0] == -(-set_at // 1000) * 1000).any()  # setSettings' own Plottables emission, in front of the first write at or behind set_at
+    assert (o["soft"] == -1).sum() >= 1
+
+
+@pytest.mark.parametrize("fb,set_at,set_at2", [(1200, 20000, -1), (1200, 33000, -1), (1200, 45000, -1), (1200, 60000, 64000), (600, 50000, -1), (600, 90000, 100000)])
+def test_burst_msk_set_settings_vs_ref(R, fb, set_at, set_at2):
+    n = int(48000 * 5 * (1200 / fb))
+    starts = [30000, 130000] if fb == 1200 else [40000, 260000]
+    pcm, _ = G.burst_msk(n, burst_starts=starts, fb=float(fb), fc=1900.0, ebno_db=18.0, seed=17 + fb)
+    kw = dict(set_at=set_at, set_lockingbw=1500, set_freq_center=1200, set_threshold=0.55)
+    if set_at2 >= 0:
+        kw["set_at2"] = set_at2
+    r = R.run_ref("burstmsk", pcm, fb=fb, lockingbw=1800, chunk=1000, **kw)
+    new = R.burst_msk_settings(freq_center=1200.0, fb=float(fb), lockingbw=1500.0)
+    new.signalthreshold = 0.55
+    o = R.run_burst(R.burst_msk_settings(fb=float(fb), lockingbw=1800.0), pcm, chunk=1000, set_at=[a for a in (set_at, set_at2) if a >= 0], set_settings=new)
+    assert np.array_equal(r["soft"], o["soft"])
+    assert np.array_equal(r["events"], as_write_stamps(o["events"], 1000))
+    assert (o["events"][:, 0] == -(-set_at // 1000) * 1000).any()
