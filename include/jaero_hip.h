@@ -136,8 +136,15 @@ void jaero_destroy(jaero_ctx *ctx);
  *     Control plane: allocates and synchronises the device; pointers from the *_view calls are stale afterwards.  An OQPSK bank keeps Fs.
  *     The new bank exists beside the old one until the state has moved: a bank that fills more than half of the device memory cannot change
  *     rate this way (JAERO_ENOMEM, the old bank stays as it was).
+ *   - burst banks (JAERO/burstoqpskdemodulator.cpp:202-277, JAERO/burstmskdemodulator.cpp:150-325), one or all channels, same fb and Fs: in
+ *     place and on that stream too.  AGCs, EbNo meter, burst-timing averages and the Hilbert filter restart from empty, the peak detector is
+ *     locked for twice its length and the trident buffer refills (and is checked once, whatever is in the air), mixer2 returns to
+ *     freq_center; d1 / d2 / the peak detector's lines (burst MSK: delayedsmpl) keep their CONTENTS with the pointer back at zero, as
+ *     DelayThing::setLength leaves them; startstop, the oscillator phases and RxDataBits survive (burst MSK: cntr = 0, mse = 10, dcd = false,
+ *     new matched filters).  A Plottables row is appended to the channel's event log.
  *   - JAERO_EINVAL: another kind (another class in the reference), or fb / Fs / FFT power for one channel of several;
- *     JAERO_ENOTSUP: burst banks (create a new bank; the Qt adaptors of integration/qt do), one channel of an 8400 bps bank. */
+ *     JAERO_ENOTSUP: one channel of an 8400 bps bank; another fb / Fs for a burst bank (create a new bank; the Qt adaptors of
+ *     integration/qt do). */
 int jaero_set_settings(jaero_ctx *ctx, int channel, const jaero_settings *s);
 int jaero_set_flags(jaero_ctx *ctx, int channel, int afc, int sql, int cpu_reduce);
 int jaero_set_dcd(jaero_ctx *ctx, int channel, int dcd);

@@ -11,6 +11,7 @@
 // Built by `make -C oracle adaptor` into oracle/_ref/ (it links the reference's objects, which never enter this repository).
 #include <QCoreApplication>
 #include <QBuffer>
+#include <functional>
 #include <QFile>
 #include <QMap>
 #include <cstdio>
@@ -49,6 +50,8 @@ struct BurstMskZ : public BurstMskDemodulator
 };
 
 static QIODevice *g_sink = nullptr;
+// set_at=N [set_lockingbw= set_freq_center=]: setSettings on the live demodulator in front of the first write at or behind sample N
+static std::function<void()> g_set_again;
 template <class DEMOD>
 static void run_burst(DEMOD &d, AeroL &a, const QByteArray &pcm, int chunk)
 {
@@ -62,7 +65,12 @@ static void run_burst(DEMOD &d, AeroL &a, const QByteArray &pcm, int chunk)
     d.start();
     const char *p = pcm.constData();
     const long nb = pcm.size();
-    for (long s = 0; s < nb; s += 2L * chunk) d.write(p + s, (nb - s < 2L * chunk) ? nb - s : 2L * chunk);
+    long set_at = kv.contains("set_at") ? 2L * kv["set_at"].toLong() : -1;
+    for (long s = 0; s < nb; s += 2L * chunk)
+    {
+        if (set_at >= 0 && s >= set_at) { if (g_set_again) g_set_again(); set_at = -1; }
+        d.write(p + s, (nb - s < 2L * chunk) ? nb - s : 2L * chunk);
+    }
     d.stop();
 }
 
@@ -148,6 +156,7 @@ int main(int argc, char **argv)
             d->setAFC(false); d->setSQL(false); d->setCPUReduce(false);
             d->setScatterPointType(BurstOqpskDemodulator::SPT_None);
             d->setSettings(s);
+            g_set_again = [d, s]() mutable { s.lockingbw = getd("set_lockingbw", s.lockingbw); s.freq_center = getd("set_freq_center", s.freq_center); d->setSettings(s); };
             run_burst<BurstOqpskDemodulator>(*d, *ap, pcm, chunk);
         }
         else
@@ -158,6 +167,7 @@ int main(int argc, char **argv)
             d.setAFC(false); d.setSQL(false); d.setCPUReduce(false);
             d.setScatterPointType(HipBurstOqpskDemodulator::SPT_None);
             d.setSettings(s);
+            g_set_again = [&d, s]() mutable { s.lockingbw = getd("set_lockingbw", s.lockingbw); s.freq_center = getd("set_freq_center", s.freq_center); d.setSettings(s); };
             run_burst(d, *ap, pcm, chunk);
         }
     }
@@ -176,6 +186,7 @@ int main(int argc, char **argv)
             d->DCDstatSlot(false);
             d->setSettings(s);
             QObject::connect(ap, &AeroL::DataCarrierDetect, d, &BurstMskDemodulator::DCDstatSlot); // only the MSK burst class has the input
+            g_set_again = [d, s]() mutable { s.lockingbw = getd("set_lockingbw", s.lockingbw); s.freq_center = getd("set_freq_center", s.freq_center); d->setSettings(s); };
             run_burst<BurstMskDemodulator>(*d, *ap, pcm, chunk);
         }
         else
@@ -188,6 +199,7 @@ int main(int argc, char **argv)
             d.DCDstatSlot(false);
             d.setSettings(s);
             QObject::connect(ap, &AeroL::DataCarrierDetect, &d, &HipBurstMskDemodulator::DCDstatSlot);
+            g_set_again = [&d, s]() mutable { s.lockingbw = getd("set_lockingbw", s.lockingbw); s.freq_center = getd("set_freq_center", s.freq_center); d.setSettings(s); };
             run_burst(d, *ap, pcm, chunk);
         }
     }

@@ -252,7 +252,17 @@ public slots:
 protected:
     void applySettings(const jaero_settings &js)
     {
-        // a burst bank has no live setSettings (JAERO_ENOTSUP): the one-channel bank is replaced, the channel restarts as a new demodulator
+        // Same bit rate and sample rate: setSettings on the live object (jaero_set_settings on a burst bank, k_burst_settings.h) -- AGCs, EbNo
+        // meter, Hilbert filter, peak detector and trident fill restart, the delay lines keep their contents with the pointers at zero,
+        // RxDataBits (`pending`) survives, as in the reference.  Another rate is another bank: the one-channel bank is replaced.
+        if (ctx && js.fb == fb && js.Fs == Fs && jaero_set_settings(ctx, 0, &js) == JAERO_OK)
+        {
+            if (kind == JAERO_KIND_BURST_MSK) dcd = false; // burstmskdemodulator.cpp:322
+            lockingbw = js.lockingbw;
+            freq_center = js.freq_center;
+            drainEvents(); // the Plottables emission at the end of setSettings
+            return;
+        }
         if (ctx) { jaero_destroy(ctx); ctx = nullptr; }
         if (jaero_create(0, 1, &js, 0, 0, maxWrite, 0, &ctx) != JAERO_OK)
         {

@@ -44,6 +44,7 @@ enum // double state
     BS_RES_X1, BS_RES_X2, BS_RES_Y1, BS_RES_Y2,
     BS_SIG2L_RE, BS_SIG2L_IM, BS_PTD_RE, BS_PTD_IM,
     BS_MSEMA_SUM, BS_MSE, BS_LASTMSE, BS_THRESH, BS_LOCKINGBW, BS_DIFF_LAST,
+    BS_RESET_AT, // absolute index of the first sample behind the channel's last setSettings (0: the constructor's): where the reference's DelayThing pointers stand follows from it
     BS_NFIELDS
 };
 enum // int state
@@ -52,6 +53,8 @@ enum // int state
     BI_STARTSTOP, BI_CNTR, BI_YUI, BI_INSERTPRE, BI_MSEMA_POS, BI_NRX,
     BI_FIR_POS, BI_AGC2_POS, BI_EB_POS, BI_DLY_POS, BI_D8_POS, BI_A1_POS, // burst MSK: rings that advance only while gated on
     BI_SOFT_CNT, BI_SYM_CNT, BI_EV_CNT, BI_OVERFLOW, BI_FLAGS,
+    BI_BT_HOLD, // samples for which bt_d1 (a Delay<> refilled with zeros by setSettings) still returns zeros (k_burst_front<true>)
+    BI_GCNT,    // burst MSK: gated samples since the last setSettings, modulo dly_len = where delayedsmpl's buffer_ptr stands in the reference
     BI_NFIELDS
 };
 

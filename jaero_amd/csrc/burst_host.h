@@ -285,7 +285,12 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
         LAUNCHCHK("k_hilbert_fft");
         prof_end(c, pi, st);
         pi = prof_begin(c, 4, st);
-        hipLaunchKernelGGL(k_burst_front, dim3(g.ngroups), dim3(64), 0, st, g, p, n, n0);
+        if (c->bt_hold_left > 0)
+        {
+            hipLaunchKernelGGL(k_burst_front<true>, dim3(g.ngroups), dim3(64), 0, st, g, p, n, n0);
+            c->bt_hold_left -= n;
+        }
+        else hipLaunchKernelGGL(k_burst_front<false>, dim3(g.ngroups), dim3(64), 0, st, g, p, n, n0);
         LAUNCHCHK("k_burst_front");
         prof_end(c, pi, st);
         pi = prof_begin(c, 1, st);
@@ -318,5 +323,29 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
         pos += n;
     }
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// jaero_set_settings on live channels [lo, hi) of a burst bank: what BurstOqpskDemodulator::setSettings / BurstMskDemodulator::setSettings do to an
+// object that has been running (k_burst_settings.h), on the bank's stream like every other call.  A bank's bit rate and sample rate are fixed
+// (ring lengths, kernel instantiations): another fb / Fs is another bank.
+static int burst_set_settings(jaero_ctx *c, int channel, const jaero_settings *s)
+{
+    const BGeom &g = c->bg;
+    if (s->kind != g.kind) return fail(JAERO_EINVAL, "jaero_set_settings: the kind of a bank is fixed (another demodulator class in the reference); create a new bank");
+    if (s->fb != g.fb || s->Fs != g.Fs)
+        return fail(JAERO_ENOTSUP, "jaero_set_settings on a burst bank: fb %g / Fs %g are fixed (this bank: %g / %g); create a new bank", s->fb, s->Fs, g.fb, g.Fs);
+    HIPCHK(hipSetDevice(c->device));
+    const int lo = channel < 0 ? 0 : channel, hi = channel < 0 ? g.nch : channel + 1;
+    BSetVals v;
+    v.freq_center = s->freq_center; v.lockingbw = s->lockingbw; v.signalthreshold = s->signalthreshold;
+    hipLaunchKernelGGL(k_burst_apply_settings, dim3((hi - lo + 63) / 64, 65), dim3(64), 0, c->last_stream, g, c->bp, lo, hi, v, (long long)c->nsamples_total);
+    HIPCHK(hipGetLastError());
+    for (int ch = lo; ch < hi; ch++)
+    {
+        c->settings[ch] = *s;
+        if (g.kind == JAERO_KIND_BURST_MSK) c->m.flags[ch] &= ~JF_DCD; // dcd = false at the end of BurstMskDemodulator::setSettings
+    }
+    c->bt_hold_left = g.bt_lag;
     return 0;
 }

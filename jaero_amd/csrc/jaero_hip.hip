@@ -31,6 +31,7 @@
 #include "k_burst_front.h"
 #include "k_burst_demod.h"
 #include "k_burst_msk_fb.h"
+#include "k_burst_settings.h"
 #include "k_aerol.h"
 #include "k_aerol_burst.h"
 
@@ -173,6 +174,7 @@ struct jaero_ctx
     BPtrs bp{};
     int tri_grid = 0, tri_lds = 0;
     long long nsamples_total = 0; // samples written so far (uniform ring slots and event time stamps derive from it)
+    int bt_hold_left = 0;         // burst: samples behind the last jaero_set_settings for which k_burst_front<true> must run (bt_d1 refilled with zeros)
     // generic views of the per-channel output buffers (either kind)
     int o_nchp = 0, o_nch = 0, o_soft_cap = 0, o_sym_cap = 0;
     int16_t *o_soft = nullptr; double *o_sym = nullptr;
@@ -1024,9 +1026,9 @@ extern "C" int jaero_set_settings(jaero_ctx *c, int channel, const jaero_setting
     // (phase kept), recreates AGC / matched filters / timing delays / resonator, restarts the coarse ring pointer.
     if (!c || !s || channel < -1 || channel >= c->o_nch) return fail(JAERO_EINVAL, "jaero_set_settings: bad arguments");
     POISONCHK(c, "jaero_set_settings");
-    if (c->burst) return fail(JAERO_ENOTSUP, "jaero_set_settings on a live burst bank is not implemented; create a new bank");
     int rc = validate_settings(*s);
     if (rc) return rc;
+    if (c->burst) return burst_set_settings(c, channel, s);
     const JGeom &g = c->g;
     if (s->kind != g.kind) return fail(JAERO_EINVAL, "jaero_set_settings: the kind of a bank is fixed (another demodulator class in the reference); create a new bank");
     const bool whole = channel < 0 || g.nch == 1;

@@ -122,6 +122,9 @@ __global__ void k_hist_push_chmajor(const int16_t *__restrict__ src, int nch, in
 __device__ __forceinline__ int bwrap(int s, int len) { return s >= len ? s - len : s; }
 __device__ __forceinline__ int bback(int s, int lag, int len) { s -= lag; return s < 0 ? s + len : s; }
 
+// HOLD: the launches that cover the first bt_lag samples behind a setSettings (burst_host.h keeps count): bt_d1 was refilled with zeros there
+// (Delay<>::setdelay, DSP.h:349-356) while the ring its two taps are read from still holds the samples d1 needs later.
+template <bool HOLD>
 __global__ __launch_bounds__(64) void k_burst_front(const BGeom g, const BPtrs p, int n, long long n0)
 {
     const int lane = threadIdx.x, grp = blockIdx.x, ch = grp * 64 + lane, nchp = g.nchp;
@@ -129,6 +132,7 @@ __global__ __launch_bounds__(64) void k_burst_front(const BGeom g, const BPtrs p
     int cntdown = BLDI(BI_CNTDOWN), maxposcd = BLDI(BI_MAXPOSCD), tri_ptr = BLDI(BI_TRI_PTR);
     const int flags = BLDI(BI_FLAGS);
     int ev_pos = -1, ev_cnt = BLDI(BI_EV_CNT);
+    int hold = HOLD ? BLDI(BI_BT_HOLD) : 0;
     const bool trace = (g.flags & 8u) != 0; // JAERO_FLAG_TRACE
 
     const double *__restrict__ hre = p.hre + (size_t)grp * g.maxseg * 64 + lane;
@@ -189,9 +193,16 @@ __global__ __launch_bounds__(64) void k_burst_front(const BGeom g, const BPtrs p
             cvre[(size_t)s_cv * 64] = c_re; cvim[(size_t)s_cv * 64] = c_im;
             // bt_d1.update(cval) (Delay<cpx>, DSP.h:341-379): weighting*newer + (1-weighting)*older; with an integer delay
             // (burst MSK) the "newer" entry is the one just written
-            double nr = cn_r[k], ni = cn_i[k];
+            double nr = cn_r[k], ni = cn_i[k], orr = co_r[k], oi = co_i[k];
             if (g.bt_lag == 1) { nr = c_re; ni = c_im; }
-            const double dl_re = btw * nr + btwc * co_r[k], dl_im = btw * ni + btwc * co_i[k];
+            if (HOLD)
+            {
+                // the older tap was written bt_lag samples ago, the newer one bt_lag - 1: zeros until setSettings lies that far back
+                if (hold > 0) { orr = 0.0; oi = 0.0; }
+                if (hold > 1) { nr = 0.0; ni = 0.0; }
+                if (hold > 0) hold--;
+            }
+            const double dl_re = btw * nr + btwc * orr, dl_im = btw * ni + btwc * oi;
             // cval*std::conj(dl)
             const double pr = c_re * dl_re - c_im * (-dl_im), pi = c_re * (-dl_im) + c_im * dl_re;
             // bt_ma1.UpdateSigned (TMovingAverage<complex>, DSP.h:184-192)
@@ -272,6 +283,7 @@ __global__ __launch_bounds__(64) void k_burst_front(const BGeom g, const BPtrs p
     BLDF(BS_AGC_SUM) = agc_sum; BLDF(BS_MA1_RE) = ma1_re; BLDF(BS_MA1_IM) = ma1_im; BLDF(BS_MAV1_SUM) = mav1_sum; BLDF(BS_LASTDY) = lastdy;
     BLDI(BI_CNTDOWN) = cntdown; BLDI(BI_MAXPOSCD) = maxposcd; BLDI(BI_TRI_PTR) = tri_ptr; BLDI(BI_EV_POS) = ev_pos; BLDI(BI_EV_CNT) = ev_cnt;
     (void)flags;
+    if (HOLD) BLDI(BI_BT_HOLD) = hold;
     if (ev_pos >= 0 && ch < g.nch)
     {
         const int k = atomicAdd(p.ev_count, 1);

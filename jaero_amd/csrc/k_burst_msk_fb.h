@@ -163,6 +163,7 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
 
     int startstop = BLDI(BI_STARTSTOP), cntr = BLDI(BI_CNTR), msema_pos = BLDI(BI_MSEMA_POS), nrx = BLDI(BI_NRX);
     int agc2_pos = BLDI(BI_AGC2_POS), eb_pos = BLDI(BI_EB_POS), dly_pos = BLDI(BI_DLY_POS), d8_pos = BLDI(BI_D8_POS), a1_pos = BLDI(BI_A1_POS);
+    const int eb_pos0 = eb_pos;
     int soft_cnt = BLDI(BI_SOFT_CNT), sym_cnt = BLDI(BI_SYM_CNT), ev_cnt = BLDI(BI_EV_CNT), overflow = BLDI(BI_OVERFLOW);
     const int flags = BLDI(BI_FLAGS);
     const int ev_pos = BLDI(BI_EV_POS);
@@ -456,6 +457,13 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
     BLDF(BS_MSEMA_SUM) = msema_sum; BLDF(BS_MSE) = mse; BLDF(BS_DIFF_LAST) = diff_last;
     BLDI(BI_STARTSTOP) = startstop; BLDI(BI_CNTR) = cntr; BLDI(BI_MSEMA_POS) = msema_pos; BLDI(BI_NRX) = nrx;
     BLDI(BI_AGC2_POS) = agc2_pos; BLDI(BI_EB_POS) = eb_pos; BLDI(BI_DLY_POS) = dly_pos; BLDI(BI_D8_POS) = d8_pos; BLDI(BI_A1_POS) = a1_pos;
+    {
+        // where the reference's delayedsmpl.buffer_ptr stands (k_burst_apply_settings needs it; DelayThing::setLength keeps the contents and
+        // restarts the pointer): the gated samples of this launch = how far the EbNo window moved (a launch is shorter than that ring)
+        int adv = eb_pos - eb_pos0;
+        if (adv < 0) adv += g.eb_len;
+        BLDI(BI_GCNT) = (BLDI(BI_GCNT) + adv) % g.dly_len;
+    }
     BLDI(BI_SOFT_CNT) = soft_cnt; BLDI(BI_SYM_CNT) = sym_cnt; BLDI(BI_EV_CNT) = ev_cnt; BLDI(BI_OVERFLOW) = overflow;
 }
 

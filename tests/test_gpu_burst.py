@@ -199,3 +199,150 @@ def test_burst_msk_center_freq_changed(B, oracle_mod, afc, hz):
     b2 = bank_for(B, "burstoqpsk", {}, 1, max_write_samples=chunk, softbit_capacity=1000)
     b2.center_freq_changed(7000.0)
     b2.close()
+
+
+# ---------------------------------------------------------------------------------------------- setSettings on live burst channels
+def oracle_with_sets(O, sett, pcm, sets, capture_symbols=True, trace=True):
+    """The oracle object fed in pieces that end at the set points; sets = [(sample, Settings)] in ascending order."""
+    d = O.BurstDemod(sett, capture_symbols=capture_symbols, trace=trace)
+    s = 0
+    for at, new in list(sets) + [(len(pcm), None)]:
+        while s < at:
+            e = min(s + 4096, at)
+            d.write(pcm[s:e])
+            s = e
+        if new is not None:
+            d.set_settings(new)
+    out = {"soft": d.take_soft(), "events": d.take_events()}
+    if capture_symbols:
+        out["symbols"] = d.take_symbols()
+    return out
+
+
+def check_symbols_behind_sets(sym, ref, tag, nsets, sps):
+    """SYM_TOL, except where the reference itself runs on rounding noise.  The restarted Hilbert filter's real part is -x[n - 1024]: exactly
+    zero for the 1024 samples behind its latency (zero here too: the channel's history was cleared), but the reference's FFT leaves ~1e-17
+    there, and the two AGCs that restart from empty averages (gain limit 1.4e6 each) turn that into symbols of up to 2e-5 (at most
+    1024 / SamplesPerSymbol rows per call).  If a burst is running through the call, the reference's symbol-timing loop steers on
+    arg(that noise) for those samples -- arbitrary angles, where the exact zeros here give arg = 0 -- and the rest of that burst's symbols
+    come out ~1e-4 off (hard decisions equal, soft bytes within one: check_soft).  Everything else: SYM_TOL."""
+    assert sym.shape == ref.shape, tag
+    d = np.abs(sym - ref).max(axis=1)
+    off = d >= SYM_TOL
+    assert d.max(initial=0.0) < 2e-3, tag
+    assert off.sum() <= nsets * (1024 / sps + 2) + 0.03 * len(ref), tag
+
+
+def feed_with_sets(bank, pcm, rng, lo, hi, calls):
+    """Ragged writes with a boundary at every call's sample; calls = [(sample, channel or -1, settings)] in ascending order."""
+    s, n = 0, pcm.shape[1]
+    calls = list(calls)
+    while s < n:
+        while calls and calls[0][0] == s:
+            _, ch, new = calls.pop(0)
+            bank.set_settings(new, channel=ch)
+        m = min(int(rng.integers(lo, hi)), n - s)
+        if calls:
+            m = min(m, calls[0][0] - s)
+        bank.write(pcm[:, s:s + m])
+        s += m
+    assert not calls
+
+
+def oqpsk_set_case():
+    nch, n = 70, 200000
+    rng = np.random.default_rng(4242)
+    pcm = np.zeros((nch, n), np.int16)
+    starts = {}
+    for c in range(nch):
+        # the second burst more than a second behind the last call: setSettings replaces the AGC (a one-second moving average that starts from
+        # zeros), and the reference loses most bursts that arrive before it has filled
+        starts[c] = [int(rng.integers(25000, 40000)), int(rng.integers(140000, 155000))]
+        pcm[c], _ = G.burst_oqpsk(n, burst_starts=starts[c], ndata_sym=700, fc=8000.0 + rng.uniform(-60, 60), ebno_db=float(rng.uniform(11, 18)),
+                                  seed=G.SEED_BASE + 900 + c)
+    per = {  # channel -> samples of its own calls
+        1: [20011], 2: [starts[2][0] + 1500], 3: [starts[3][0] + 5000], 5: [starts[5][0] + 9000], 7: [starts[7][0] + 1000, starts[7][0] + 3000],
+        63: [starts[63][0] + 4000], 64: [starts[64][0] + 2600], 69: [5, 17], 40: [starts[40][0] + 20000, starts[40][0] + 20009],
+    }
+    return pcm, per, 80001, sorted(set(per) | {0, 4, 6, 62, 65, 68}), rng
+
+
+def test_burst_oqpsk_set_settings_live(B, oracle_mod):
+    """BurstOqpskDemodulator::setSettings (burstoqpskdemodulator.cpp:202-277) on live channels of a 70-channel bank: single channels at their
+    own moments (idle, between peak and trident check, inside the delayed burst, twice within one delay-line length), neighbours in the same
+    wavefront untouched, then the whole bank at once -- every checked channel against the oracle given the same calls at the same samples
+    (the oracle's live setSettings = the unmodified reference's: tests/test_oracle_burst.py).  With the trace on, the event log carries every
+    firing of the peak detector and the metric of every trident check, so the check that runs 2633 samples behind each call -- on the ROTATED
+    contents of d1 -- is compared too."""
+    pcm, per, whole, check, rng = oqpsk_set_case()
+    nch = pcm.shape[0]
+    new = B.BurstOqpskSettings(freq_center=7000.0, lockingbw=9000.0, signalthreshold=0.55)
+    onew = oracle_mod.burst_oqpsk_settings(freq_center=7000.0)
+    onew.lockingbw, onew.signalthreshold = 9000.0, 0.55
+    calls = sorted([(at, c, new) for c, ats in per.items() for at in ats] + [(whole, -1, new)], key=lambda x: x[0])
+    bank = bank_for(B, "burstoqpsk", {}, nch, capture_symbols=True, trace=True, max_write_samples=5000, softbit_capacity=40000)
+    feed_with_sets(bank, pcm, rng, 1, 5000, calls)
+    nacc = 0
+    for c in check:
+        sets = sorted([(at, onew) for at in per.get(c, [])] + [(whole, onew)], key=lambda x: x[0])
+        ref = oracle_with_sets(oracle_mod, oracle_mod.burst_oqpsk_settings(), pcm[c], sets)
+        check_soft(bank.read_softbits(c), ref["soft"], f"channel {c}")
+        check_events(bank.read_events(c), ref["events"])
+        check_symbols_behind_sets(bank.read_symbols(c), ref["symbols"], c, len(sets), 2 * 48000 / 10500)
+        nacc += int((ref["soft"] == -1).sum())
+    assert nacc >= 15
+    bank.close()
+
+
+def msk_set_case(fb):
+    nch = 6
+    k = 1200 // fb
+    n = 240000 * k
+    rng = np.random.default_rng(fb + 1)
+    pcm = np.zeros((nch, n), np.int16)
+    starts = {}
+    for c in range(nch):
+        starts[c] = [int(k * rng.integers(28000, 36000)), int(k * rng.integers(150000, 160000))]
+        pcm[c], _ = G.burst_msk(n, burst_starts=starts[c], fb=float(fb), fc=1900.0 + rng.uniform(-200, 200), ebno_db=float(rng.uniform(15, 22)),
+                                seed=G.SEED_BASE + 950 + c)
+    per = {0: [k * 20000 + 3], 1: [starts[1][0] + k * 3000], 2: [starts[2][0] + k * 15000], 3: [starts[3][0] + k * 30000, starts[3][0] + k * 34000],
+           4: [starts[4][0] + k * 24000, starts[4][0] + k * 24011]}
+    return pcm, per, k * 90000 + 1, rng
+
+
+@pytest.mark.parametrize("fb", [1200, 600])
+def test_burst_msk_set_settings_live(B, oracle_mod, fb):
+    """BurstMskDemodulator::setSettings (burstmskdemodulator.cpp:150-325) on live channels: matched filters, AGCs, EbNo meter and resonator
+    restart, cntr = 0 and mse = 10 in the middle of a burst, delayedsmpl keeps its contents with the pointer at zero."""
+    pcm, per, whole, rng = msk_set_case(fb)
+    nch = pcm.shape[0]
+    opts = dict(fb=fb, lockingbw=1.5 * fb)
+    new = B.BurstMskSettings(freq_center=1200.0, fb=float(fb), lockingbw=1.25 * fb, signalthreshold=0.55)
+    onew = oracle_mod.burst_msk_settings(freq_center=1200.0, fb=float(fb), lockingbw=1.25 * fb)
+    onew.signalthreshold = 0.55
+    calls = sorted([(at, c, new) for c, ats in per.items() for at in ats] + [(whole, -1, new)], key=lambda x: x[0])
+    bank = bank_for(B, "burstmsk", opts, nch, capture_symbols=True, trace=True, max_write_samples=8192, softbit_capacity=60000)
+    feed_with_sets(bank, pcm, rng, 100, 8192, calls)
+    nacc = 0
+    for c in range(nch):
+        sets = sorted([(at, onew) for at in per.get(c, [])] + [(whole, onew)], key=lambda x: x[0])
+        ref = oracle_with_sets(oracle_mod, oracle_settings(oracle_mod, "burstmsk", opts), pcm[c], sets)
+        check_soft(bank.read_softbits(c), ref["soft"], f"channel {c}")
+        check_events(bank.read_events(c), ref["events"])
+        check_symbols_behind_sets(bank.read_symbols(c), ref["symbols"], c, len(sets), 48000 / fb)
+        nacc += int((ref["soft"] == -1).sum())
+    assert nacc >= 6
+    bank.close()
+
+
+def test_burst_set_settings_refusals(B):
+    """A burst bank's bit rate and sample rate are fixed: another fb is another bank (JAERO_ENOTSUP), another kind another class (JAERO_EINVAL)."""
+    from jaero_amd import capi
+
+    bank = bank_for(B, "burstmsk", dict(fb=1200, lockingbw=1800.0), 2, max_write_samples=4096)
+    with pytest.raises(capi.JaeroError):
+        bank.set_settings(B.BurstMskSettings(fb=600.0, lockingbw=900.0))
+    with pytest.raises(capi.JaeroError):
+        bank.set_settings(B.BurstOqpskSettings())
+    bank.set_settings(B.BurstMskSettings(fb=1200.0, lockingbw=1500.0), channel=1)
+    bank.close()

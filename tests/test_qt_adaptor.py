@@ -149,6 +149,38 @@ def test_hip_burst_adaptor_groups_msk(fb):
 
 @pytest.mark.gpu
 @have_demo
+@pytest.mark.parametrize("set_at", [70000, 41500])
+def test_hip_burst_adaptor_live_set_settings_oqpsk(set_at):
+    """A user pressing OK in the settings dialog while burst audio runs: BurstOqpskDemodulator::setSettings on the live object
+    (burstoqpskdemodulator.cpp:202-277).  The adaptor passes it to jaero_set_settings (k_burst_settings.h) instead of replacing its bank;
+    under the unmodified AeroL it prints what the all-reference chain prints for the same episode -- between two bursts (the later packets
+    decode, the trident check that runs 2633 samples behind the call sees the rotated contents of d1), and right behind the first burst's
+    peak (that packet is lost on both sides)."""
+    pcm = rt_burst_pcm()
+    kw = dict(set_at=set_at, set_lockingbw=9000, set_freq_center=7900)
+    ref = run_demo("ref", "burstoqpsk", pcm, **kw)
+    hip = run_demo("hip", "burstoqpsk", pcm, **kw)
+    plain = run_demo("ref", "burstoqpsk", pcm)
+    assert len(ref) > 100 and ref != plain  # the call leaves a trace in the reference's output ...
+    assert hip == ref                       # ... and the same one here
+
+
+@pytest.mark.gpu
+@have_demo
+def test_hip_burst_adaptor_live_set_settings_msk():
+    """The same for BurstMskDemodulator::setSettings (burstmskdemodulator.cpp:150-325) in the middle of the first burst: cntr = 0 and
+    mse = 10 with startstop still counting, matched filters and AGCs empty, delayedsmpl rotated; the groups AeroL receives are compared."""
+    pcm, _ = G.burst_msk(48000 * 6, burst_starts=[30000, 170000], ndata=400, fb=1200.0, fc=1007.0, ebno_db=18.0, seed=G.SEED_BASE + 79)
+    kw = dict(fb=1200, dump=1, set_at=60000, set_lockingbw=1500, set_freq_center=1100)
+    ref = run_demo("ref", "burstmsk", pcm, **kw)
+    hip = run_demo("hip", "burstmsk", pcm, **kw)
+    plain = run_demo("ref", "burstmsk", pcm, fb=1200, dump=1)
+    assert len([ln for ln in ref.split("\n") if ln.startswith("G ")]) >= 20 and ref != plain
+    assert hip == ref
+
+
+@pytest.mark.gpu
+@have_demo
 def test_hip_msk_adaptor_follows_the_incoming_sample_rate():
     """Audio arriving through dataReceived at 24 kHz while the demodulator was set up for 48 kHz: MskDemodulator re-applies its settings
     with that rate (mskdemodulator.cpp:528-537), the adaptor replaces its bank; AeroL prints the same signal units."""
