@@ -81,6 +81,7 @@ struct BGeom
     double fa_w, bt_w, pd_thr;
     // demod
     int fir_n, agc2_len, eb_len, msema_len, a1_lag, dly_len, d8_len;
+    int win_ring; // entries of the ONE ring of |sig2| values that serves the AGC2 window and the EbNo meter's two windows: max(agc2_len, eb_len)
     int dly_ring, d8_ring; // burst MSK: sizes of the delayedsmpl / delayt8 rings, dly_len / d8_len rounded up to whole 64-byte cells of eight entries (k_burst_msk_fb.h)
     double a1_w, w4, w8, ee;
     double res_b0, res_b1, res_b2, res_a1, res_a2;
@@ -103,7 +104,7 @@ struct BPtrs
     int *ev_list, *ev_count;     // compacted channels with a trident event this segment
     TriResult *tri;              // [nchp]
     // demod (burst OQPSK: uniform-slot rings [ng][len][64]; burst MSK: per-channel rings [nchp][len])
-    double *agc2_ring, *eb_e, *eb_e2;
+    double *eb_e;                // |sig2| of the last win_ring (gated) samples: agc2's window, E's window; E2's entries are its squares
     double *firsave;             // OQPSK [ng][2][fir_n][64]; MSK [nchp][2][fir_n]
     double2 *dly; double *dly8, *a1;
     double *msema;               // [nchp][msema_len]

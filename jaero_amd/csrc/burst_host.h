@@ -96,6 +96,7 @@ static void burst_fill_geometry(BGeom &g, const jaero_settings &s, int nch, unsi
     }
     if (g.maxseg > max_write) g.maxseg = (max_write + 15) / 16 * 16;
     g.bt_len = 2 * g.PL + 1;
+    g.win_ring = g.agc2_len > g.eb_len ? g.agc2_len : g.eb_len;
     g.cv_len = g.D1 + (g.D2 > g.tri_sz ? g.D2 : g.tri_sz) + g.maxseg + 64;
     // whole cells of four samples (k_hilbert); k_hilbert_fft's first block starts up to 2047 samples before the segment and looks
     // hil_lat + 2048 samples further back
@@ -130,8 +131,7 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
     DA(p.bt, (size_t)ng * g.bt_len * 64);
     DA(p.ev_list, nchp); DA(p.ev_count, 4);
     DA(p.tri, nchp);
-    DA(p.agc2_ring, (size_t)nchp * g.agc2_len);
-    DA(p.eb_e, (size_t)nchp * g.eb_len); DA(p.eb_e2, (size_t)nchp * g.eb_len);
+    DA(p.eb_e, (size_t)nchp * g.win_ring);
     DA(p.firsave, (size_t)nchp * 2 * g.fir_n);
     if (!oq) { DA(p.dly, (size_t)nchp * g.dly_ring); DA(p.dly8, (size_t)nchp * g.d8_ring); DA(p.a1, (size_t)nchp * g.d8_len); }
     DA(p.msema, (size_t)nchp * g.msema_len);
@@ -142,6 +142,8 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
     DA(c->d_status, nchp);
     c->tri_grid = 2 * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256); // two 256-thread workgroups per CU
     if (c->tri_grid > nchp) c->tri_grid = nchp;
+    if (!oq && ((g.agc2_len | g.eb_len) & 7))
+        return fail(JAERO_ENOTSUP, "burst MSK at fb %g / Fs %g: the AGC2 / EbNo windows (%d, %d entries) are not whole cells of eight", g.fb, g.Fs, g.agc2_len, g.eb_len);
     if (oq && ((int)floor((0.25 * g.fb) / (g.Fs / (double)TRI_N) + 0.5)) % 4 != 0)
         return fail(JAERO_ENOTSUP, "burst OQPSK at fb %g / Fs %g: k_trident searches one residue class of bins at a time and needs round(fb / 4 / hzperbin) to be a multiple of 4", g.fb, g.Fs);
     c->tri_lds = TRI_XCH * (int)sizeof(double); // wg_fft13_e32's exchange buffer (k_trident; one residue class of trident differences shares it)

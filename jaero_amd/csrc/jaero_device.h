@@ -44,7 +44,9 @@ enum
 // ---- int state fields (I) ----
 enum
 {
-    I_AGC_POS, I_EB_POS, I_BB_PTR, I_COARSE_CNT,
+    I_AGC_POS, // write position in the window ring (JPtrs::win)
+    I_AGC_HOLD, // OQPSK: samples for which the AGC (re-created by setSettings) still sees zeros leaving its window while the EbNo meter keeps its values
+    I_BB_PTR, I_COARSE_CNT,
     I_MARG_POS, I_DT_POS, I_PM_POS, I_MSEMA_POS,
     I_YUI, I_SIG2L_INIT, I_FLAGS, I_COUNTDOWN, I_COUNTDOWN2, I_EMPTYING, I_NEST,
     I_SOFT_CNT, I_SYM_CNT, I_LOG_CNT, I_OVERFLOW,
@@ -76,6 +78,7 @@ struct JGeom
     int fir_n;      // 55 (OQPSK) / 2*SPS (MSK)
     int agc_len;    // round(4*Fs) OQPSK, round(Fs) MSK
     int ebno_len;   // 2*Fs
+    int win_len;    // entries of the one ring that holds both windows' samples: max(agc_len, ebno_len) (agc_len without JAERO_FLAG_EBNO)
     int nfft, nfft_log2;
     int marg_len, dt_len, pm_len, msema_len; // dt_len = length+1 (ring size)
     double ee;
@@ -93,8 +96,10 @@ struct JPtrs
 {
     double *S;
     int *I;
-    double *agc_ring;    // [ng][agc_len][64]
-    double *eb_e, *eb_e2;// [ng][ebno_len][64]
+    // [ng][win_len][64]: |sig2| of the last win_len samples.  The reference keeps three buffers of it -- the AGC's moving average, the EbNo meter's E
+    // and (squared) E2 (agc->Update(dabval), ebnomeasure->Update(dabval): oqpskdemodulator.cpp:463-466, mskdemodulator.cpp:375-378; DSP.cpp:370-379,
+    // 408-416, 493-505, 729-744) -- 24 B written and 24 B read per sample where 8 B written and 16 B read say the same
+    double *win;
     double2 *bbring;     // [nchp][nfft] complex double, exactly the reference's bbcycbuff entries
     double *y;           // [nchp][nfft]
     double *marg;        // [nchp][marg_len]

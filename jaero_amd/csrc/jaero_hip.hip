@@ -448,6 +448,7 @@ static void fill_geometry(JGeom &g, const jaero_settings &s, int nch, unsigned f
         }
         g.stref_freq = s.fb / 2;
     }
+    g.win_len = ((flags & JAERO_FLAG_EBNO) && g.ebno_len > g.agc_len) ? g.ebno_len : g.agc_len;
 }
 
 // Tables of the overlap-save filters (k_pre8400_fft, k_hilbert_fft): H = DFT_4096(taps, zero-padded) / 4096 and exp(-2 pi i k / 4096),
@@ -569,8 +570,7 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
     do { if ((rc = dalloc(c, &(ptr), (size_t)(count)))) { jaero_destroy(c); return rc; } } while (0)
     DA(c->p.S, (size_t)S_NFIELDS * nchp);
     DA(c->p.I, (size_t)I_NFIELDS * nchp);
-    DA(c->p.agc_ring, (size_t)ng * g.agc_len * 64);
-    if (flags & JAERO_FLAG_EBNO) { DA(c->p.eb_e, (size_t)ng * g.ebno_len * 64); DA(c->p.eb_e2, (size_t)ng * g.ebno_len * 64); }
+    DA(c->p.win, (size_t)ng * g.win_len * 64);
     DA(c->p.bbring, (size_t)nchp * g.nfft);
     DA(c->p.y, (size_t)nchp * g.nfft);
     DA(c->p.marg, (size_t)nchp * g.marg_len);
@@ -836,14 +836,9 @@ __global__ void k_apply_settings(const JGeom g, const JPtrs p, int ch_lo, const 
         for (int k = threadIdx.x; k < v.nI; k += blockDim.x) p.I[(size_t)v.fI[k] * nchp + ch] = v.vI[k];
     }
     const int tid = blockIdx.y * blockDim.x + threadIdx.x, nth = gridDim.y * blockDim.x;
-    for (int s = tid; s < g.agc_len; s += nth) p.agc_ring[((size_t)grp * g.agc_len + s) * 64 + lane] = 0.0;
+    // OQPSK: the AGC is re-created but the EbNo meter keeps its buffer, and both live in the one window ring: I_AGC_HOLD instead of zeros
+    if (v.zero_eb) for (int s = tid; s < g.win_len; s += nth) p.win[((size_t)grp * g.win_len + s) * 64 + lane] = 0.0;
     for (int s = tid; s < 2 * g.fir_n; s += nth) p.firsave[((size_t)grp * 2 * g.fir_n + s) * 64 + lane] = 0.0;
-    if (v.zero_eb && p.eb_e)
-        for (int s = tid; s < g.ebno_len; s += nth)
-        {
-            p.eb_e[((size_t)grp * g.ebno_len + s) * 64 + lane] = 0.0;
-            p.eb_e2[((size_t)grp * g.ebno_len + s) * 64 + lane] = 0.0;
-        }
     if (v.zero_msk)
     {
         for (int s = tid; s < g.marg_len; s += nth) p.marg[(size_t)ch * g.marg_len + s] = 0.0;
@@ -883,10 +878,11 @@ static int apply_live_settings(jaero_ctx *c, int lo, int hi, const jaero_setting
         setS(S_MSE, 10.0); // setSettings resets mse (mskdemodulator.cpp:180)
         for (int f : {S_AGC_SUM, S_RES_X1, S_RES_X2, S_RES_Y1, S_RES_Y2, S_EB_ESUM, S_EB_E2SUM, S_EB_EBNO, S_MARG_SUM, S_MFB_A0_RE, S_MFB_A0_IM}) setS(f, 0.0);
         setI(I_MARG_POS, 0); setI(I_DT_POS, 0);
-        if (c->p.eb_e) setI(I_EB_POS, 0);
         v.zero_eb = 1; v.zero_msk = 1;
     }
-    setI(I_BB_PTR, 0); setI(I_COARSE_CNT, 0); setI(I_AGC_POS, 0);
+    setI(I_BB_PTR, 0); setI(I_COARSE_CNT, 0);
+    if (g.kind == JAERO_KIND_OQPSK) setI(I_AGC_HOLD, g.agc_len); // new AGC(4, Fs): an empty window; the ring's position and contents stay (the meter's)
+    else setI(I_AGC_POS, 0);
     for (int ch = lo; ch < hi; ch++)
     {
         c->settings[ch] = *s;
@@ -970,11 +966,9 @@ static int rebank_with_carry_over(jaero_ctx *c, const jaero_settings *s)
         CP(n->p.dt, c->p.dt, sizeof(double2) * (size_t)nchp * og.dt_len);
         CP(n->p.pm, c->p.pm, sizeof(double) * (size_t)nchp * og.pm_len);
         if (c->p.symrec && n->p.symrec) CP(n->p.symrec, c->p.symrec, sizeof(double) * (size_t)nchp * JD_SYMREC_LEN * 8); // k_oqpsk_fb keeps the four windows in one record ring
-        if (c->p.eb_e && n->p.eb_e) // the OQPSK EbNo meter is only told the new rates (setup_update, DSP.cpp:723-727)
-        {
-            CP(n->p.eb_e, c->p.eb_e, sizeof(double) * (size_t)og.ngroups * og.ebno_len * 64);
-            CP(n->p.eb_e2, c->p.eb_e2, sizeof(double) * (size_t)og.ngroups * og.ebno_len * 64);
-        }
+        // the OQPSK EbNo meter is only told the new rates (setup_update, DSP.cpp:723-727): its window -- the newest ebno_len entries of the window
+        // ring, at the position that came over with I -- stays; the AGC is new (I_AGC_HOLD, set by apply_live_settings below)
+        if ((c->flags & JAERO_FLAG_EBNO) && og.win_len == ng.win_len) CP(n->p.win, c->p.win, sizeof(double) * (size_t)og.ngroups * og.win_len * 64);
     }
     else
     {

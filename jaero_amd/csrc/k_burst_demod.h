@@ -96,9 +96,10 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
     const bool trace = (g.flags & 8u) != 0;
 
     const double *__restrict__ cvre = p.cvre + (size_t)grp * g.cv_len * 64 + lane;
-    double *agc2_ring = p.agc2_ring + (size_t)grp * g.agc2_len * 64 + lane;
-    double *ebe_ring = p.eb_e + (size_t)grp * g.eb_len * 64 + lane;
-    double *ebe2_ring = p.eb_e2 + (size_t)grp * g.eb_len * 64 + lane;
+    // ONE ring of |sig2|: ebnomeasure->Update(sig2abs) and agc2->Update(sig2abs) (:570,:576) are fed the same value in the same samples and both
+    // start from empty windows at the same moments (constructor, setSettings), so AGC2's moving-average buffer is the newest agc2_len
+    // entries of E's, and E2's entries are E's squared (MovingAverage::Update stores fabs(sig), DSP.cpp:408-416: fabs(x)^2 == fabs(x x))
+    double *ebe_ring = p.eb_e + (size_t)grp * g.win_ring * 64 + lane;
     double *msema_ring = p.msema + (size_t)ch * g.msema_len;
     int16_t *__restrict__ soft = p.soft + (size_t)ch * g.soft_cap;
 
@@ -109,7 +110,9 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
         for (int j = 0; j < TAILN; j++) { tre[j] = fs[(size_t)(LDSN + j) * 64]; tim[j] = fs[(size_t)(FIRN + LDSN + j) * 64]; }
     }
     if (lane < FIRN) ltap[lane] = taps[lane];
-    int fir_slot = (int)(n0 % LDSN), s_agc2 = (int)(n0 % g.agc2_len), s_eb = (int)(n0 % g.eb_len);
+    int fir_slot = (int)(n0 % LDSN), s_eb = (int)(n0 % g.win_ring);
+    int s_agc2 = s_eb - g.agc2_len; if (s_agc2 < 0) s_agc2 += g.win_ring; // the entry written agc2_len samples ago (slot s_eb itself holds the one written win_ring ago)
+    int s_e = s_eb - g.eb_len; if (s_e < 0) s_e += g.win_ring;             // the entry written eb_len samples ago
     int s_val = (int)((n0 - g.D1 - g.D2 + 8LL * g.cv_len) % g.cv_len);
     const double w4 = g.w4, w4c = 1.0 - g.w4, w8 = g.w8, w8c = 1.0 - g.w8, a1w = g.a1_w, a1wc = 1.0 - g.a1_w;
     const double agc2_len_d = (double)g.agc2_len, eb_len_d = (double)g.eb_len;
@@ -118,19 +121,19 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
     const double msema_len_d = (double)g.msema_len, r_msema_len = 1.0 / msema_len_d;
 
     // ring entries of sample i+1 are requested at the top of iteration i (all slots are wave-uniform and data independent)
-    double nx_val = cvre[(size_t)s_val * 64], nx_agc2 = agc2_ring[(size_t)s_agc2 * 64];
-    double nx_e = ebe_ring[(size_t)s_eb * 64], nx_e2 = ebe2_ring[(size_t)s_eb * 64];
+    double nx_val = cvre[(size_t)s_val * 64], nx_agc2 = ebe_ring[(size_t)s_agc2 * 64];
+    double nx_e = ebe_ring[(size_t)s_e * 64];
     for (int i = 0; i < n; i++)
     {
         const long long sample = n0 + i;
-        const double val = nx_val, agc2_old = nx_agc2, e_old = nx_e, e2_old = nx_e2;
+        const double val = nx_val, agc2_old = nx_agc2, e_old = nx_e, e2_old = nx_e * nx_e;
         if (i + 1 < n)
         {
             int sv = s_val + 1; if (sv >= g.cv_len) sv = 0;
-            int sa = s_agc2 + 1; if (sa >= g.agc2_len) sa = 0;
-            int se = s_eb + 1; if (se >= g.eb_len) se = 0;
-            nx_val = cvre[(size_t)sv * 64]; nx_agc2 = agc2_ring[(size_t)sa * 64];
-            nx_e = ebe_ring[(size_t)se * 64]; nx_e2 = ebe2_ring[(size_t)se * 64];
+            int sa = s_agc2 + 1; if (sa >= g.win_ring) sa = 0;
+            int se = s_e + 1; if (se >= g.win_ring) se = 0;
+            nx_val = cvre[(size_t)sv * 64]; nx_agc2 = ebe_ring[(size_t)sa * 64];
+            nx_e = ebe_ring[(size_t)se * 64];
         }
         // ---- trident verdict for this sample (:488-515) ----
         if (i == ev_pos)
@@ -220,10 +223,11 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
         const double sig2abs = hypot(sre, sim);
         {
             const double sq = sig2abs * sig2abs;
-            double *e2p = ebe2_ring + (size_t)s_eb * 64, *ep = ebe_ring + (size_t)s_eb * 64;
-            eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq); *e2p = fabs(sq);
-            eb_esum = eb_esum - e_old; eb_esum = eb_esum + fabs(sig2abs); *ep = fabs(sig2abs);
-            s_eb++; if (s_eb >= g.eb_len) s_eb = 0;
+            double *ep = ebe_ring + (size_t)s_eb * 64;
+            eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq);
+            eb_esum = eb_esum - e_old; eb_esum = eb_esum + fabs(sig2abs); *ep = fabs(sig2abs); // the one store: AGC2 below pushes the same value
+            s_eb++; if (s_eb >= g.win_ring) s_eb = 0;
+            s_e++; if (s_e >= g.win_ring) s_e = 0;
             // The meter's value is observable at the end of a launch (status) and once per burst, at cntr == 384 symbols (:581); its
             // IIR forgets a term after k samples as 0.8^k, so the divide/log10 runs only in the JD_EBNO_TAIL samples before either.
             const double to_emit = ((128.0 + 128.0 + 128.0) * SPS) - (double)cntr;
@@ -244,9 +248,8 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
         }
         if (fabs(cntr - ((128.0 + 128.0 + 128.0) * SPS)) < 0.5) bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_EBNO, eb_ebno);
         {
-            double *ap = agc2_ring + (size_t)s_agc2 * 64;
-            agc2_sum = agc2_sum - agc2_old; agc2_sum = agc2_sum + fabs(sig2abs); *ap = fabs(sig2abs);
-            s_agc2++; if (s_agc2 >= g.agc2_len) s_agc2 = 0;
+            agc2_sum = agc2_sum - agc2_old; agc2_sum = agc2_sum + fabs(sig2abs);
+            s_agc2++; if (s_agc2 >= g.win_ring) s_agc2 = 0;
             double gain = 1.414213562 / fmax(jd_div_const(agc2_sum, agc2_len_d, r_agc2_len), 0.000001);
             gain = fmax(gain, 0.000001);
             sre *= gain; sim *= gain;

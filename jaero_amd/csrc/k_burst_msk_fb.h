@@ -13,7 +13,7 @@
 //     retuned by a trident verdict, so its table entry for the next sample is requested a whole sample ahead) and
 //     the front half has published the filter output for sample i; behind it the front half pushes sample i (where the gate is open) and
 //     forms the output for the next gated sample while the back half tracks sample i.  Mailboxes are double-buffered on i & 1.
-// LDS per pair: 2 x LDSN x 64 doubles of history + 5.5 KiB of mailboxes + 24 KiB of write-combining cells (round 4, below): LDSN = 48 of 80
+// LDS per pair: 2 x LDSN x 64 doubles of history + 5.5 KiB of mailboxes + 16 KiB of write-combining cells (round 4, below): LDSN = 48 of 80
 // taps (two pairs per CU: all four SIMDs busy), 128 of 160 (one pair per CU); the FIRN - LDSN = 32 oldest entries of each arm sit in the
 // front half's registers, shifted under the gate's exec mask.
 // Round 4, the back half's window stores.  The EbNo, AGC2 and delay windows advance once per GATED sample of their own channel, so their
@@ -25,6 +25,11 @@
 // rings are rounded up to whole cells: a delay line needs "the entry written D pushes ago", not a ring of exactly D + 1), so one phase
 // serves them all and a cell never wraps.  Entries read back (the ones leaving a window) are at least 19 pushes old: long flushed.
 // Results are bit-identical to k_burst_msk_demod's (same operations in the same order); every burst-MSK bank test runs on this kernel.
+// Later in round 4: the EbNo meter's E window, its E2 window and AGC2's window were three rings (24 B written and 24 B read per gated sample).
+// ebnomeasure->Update(std::abs(sig2)) and agc2->Update(std::abs(sig2)) (burstmskdemodulator.cpp:634,643) push the SAME value in the same
+// samples and both start from empty buffers at the same moments (constructor, setSettings), and E2's buffer holds the squares of E's
+// (MovingAverage::Update stores fabs(sig), DSP.cpp:408-416).  ONE ring of max(agc2_len, eb_len) entries serves all three: 8 B written,
+// 16 B read (the entries leaving the two windows), the square formed again from the entry -- the same doubles, a third of the traffic.
 #pragma once
 #include "k_burst_demod.h"
 
@@ -38,8 +43,8 @@ struct BmskMail
 #define BMSK_FB_MAIL_BYTES (2 * 2 * 64 * 8 + 2 * 3 * 64 * 8 + 2 * 64 * 4) // 5632
 #define BMSK_FB_LDSN_80 48
 #define BMSK_FB_LDSN_160 128
-#define BMSK_FB_WC_RINGS 6 // e^2, e, agc2, delayt8, delayedsmpl re / im
-#define BMSK_FB_WC_BYTES (BMSK_FB_WC_RINGS * 8 * 64 * 8) // 24576
+#define BMSK_FB_WC_RINGS 4 // |sig2| (the EbNo / AGC2 window ring), delayt8, delayedsmpl re / im
+#define BMSK_FB_WC_BYTES (BMSK_FB_WC_RINGS * 8 * 64 * 8) // 16384
 
 template <int FIRN, int LDSN>
 __device__ __forceinline__ void bmsk_front(const BGeom &g, const BPtrs &p, double *lre, double *lim, const BmskMail &M, int n, long long n0, int grp, int lane)
@@ -162,7 +167,7 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
     const double thresh = BLDF(BS_THRESH), lockingbw = BLDF(BS_LOCKINGBW);
 
     int startstop = BLDI(BI_STARTSTOP), cntr = BLDI(BI_CNTR), msema_pos = BLDI(BI_MSEMA_POS), nrx = BLDI(BI_NRX);
-    int agc2_pos = BLDI(BI_AGC2_POS), eb_pos = BLDI(BI_EB_POS), dly_pos = BLDI(BI_DLY_POS), d8_pos = BLDI(BI_D8_POS), a1_pos = BLDI(BI_A1_POS);
+    int eb_pos = BLDI(BI_EB_POS), dly_pos = BLDI(BI_DLY_POS), d8_pos = BLDI(BI_D8_POS), a1_pos = BLDI(BI_A1_POS); // eb_pos: write position in the window ring
     const int eb_pos0 = eb_pos;
     int soft_cnt = BLDI(BI_SOFT_CNT), sym_cnt = BLDI(BI_SYM_CNT), ev_cnt = BLDI(BI_EV_CNT), overflow = BLDI(BI_OVERFLOW);
     const int flags = BLDI(BI_FLAGS);
@@ -171,21 +176,20 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
     const bool trace = (g.flags & 8u) != 0;
     (void)first_of_write;
 
-    double *agc2_ring = p.agc2_ring + (size_t)ch * g.agc2_len;
-    double *ebe_ring = p.eb_e + (size_t)ch * g.eb_len, *ebe2_ring = p.eb_e2 + (size_t)ch * g.eb_len;
+    double *ebe_ring = p.eb_e + (size_t)ch * g.win_ring;
     double2 *dly_ring = p.dly + (size_t)ch * g.dly_ring;
     double *d8_ring = p.dly8 + (size_t)ch * g.d8_ring;
     // write-combining cells: this lane's column of [ring][entry & 7][lane]
     double *wc = M.wc + lane;
-    enum { WC_E2 = 0, WC_E = 1, WC_AGC2 = 2, WC_D8 = 3, WC_DX = 4, WC_DY = 5 };
+    enum { WC_E = 0, WC_D8 = 1, WC_DX = 2, WC_DY = 3 };
     auto wc_at = [&](int ring, int k) -> double & { return wc[(ring * 8 + k) * 64]; };
     // the cell being filled holds the entries pushed since its start: back from HBM (the previous launch wrote them out entry by entry)
     {
-        const int ph = eb_pos & 7; // = agc2_pos & 7 = dly_pos & 7 = d8_pos & 7: the five windows advance together
+        const int ph = eb_pos & 7; // = dly_pos & 7 = d8_pos & 7: the three rings advance together
         for (int k = 0; k < ph; k++)
         {
-            wc_at(WC_E2, k) = ebe2_ring[eb_pos - ph + k]; wc_at(WC_E, k) = ebe_ring[eb_pos - ph + k];
-            wc_at(WC_AGC2, k) = agc2_ring[agc2_pos - ph + k]; wc_at(WC_D8, k) = d8_ring[d8_pos - ph + k];
+            wc_at(WC_E, k) = ebe_ring[eb_pos - ph + k];
+            wc_at(WC_D8, k) = d8_ring[d8_pos - ph + k];
             const double2 v = dly_ring[dly_pos - ph + k];
             wc_at(WC_DX, k) = v.x; wc_at(WC_DY, k) = v.y;
         }
@@ -277,10 +281,13 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
         if (gate)
         {
             // window entries this sample replaces / reads: requested now, consumed behind the filter
-            const double e2_old = ebe2_ring[eb_pos], e_old = ebe_ring[eb_pos], agc2_old = agc2_ring[agc2_pos];
             // the delay rings are whole cells (g.dly_ring >= dly_len, g.d8_ring >= d8_len): "the oldest entry of a ring of dly_len" is the one
             // written dly_len - 1 pushes ago, "the one behind it" dly_len - 2 ago
             auto back = [](int pos, int lag, int ring) { const int q = pos - lag; return q < 0 ? q + ring : q; };
+            // the entries leaving the EbNo and the AGC2 window: written eb_len / agc2_len gated samples ago (one of the two is the slot this
+            // sample overwrites); at least 5120 pushes old: long flushed
+            const double e_old = ebe_ring[back(eb_pos, g.eb_len, g.win_ring)], agc2_old = ebe_ring[back(eb_pos, g.agc2_len, g.win_ring)];
+            const double e2_old = e_old * e_old;
             const double2 ptd_pre = dly_ring[back(dly_pos, g.dly_len - 1, g.dly_ring)];
             const double d8_a = d8_ring[back(d8_pos, g.d8_len - 2, g.d8_ring)], d8_b = d8_ring[back(d8_pos, g.d8_len - 1, g.d8_ring)];
             const int ph = eb_pos & 7;
@@ -317,7 +324,7 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
             const double sabs = hypot(sre, sim);
             {
                 const double sq = sabs * sabs;
-                eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq); wc_at(WC_E2, ph) = fabs(sq);
+                eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq);
                 eb_esum = eb_esum - e_old; eb_esum = eb_esum + fabs(sabs); wc_at(WC_E, ph) = fabs(sabs);
                 // the value is observable once per burst (the emission below), at the end of a launch (status) and where the gate closes;
                 // its IIR forgets a term after k samples as 0.8^k, so the arithmetic runs only in the JD_EBNO_TAIL samples before those
@@ -335,7 +342,7 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
             }
             if (cntr == g.endRotation + (200 * SPS)) bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_EBNO, eb_ebno);
             {
-                agc2_sum = agc2_sum - agc2_old; agc2_sum = agc2_sum + fabs(sabs); wc_at(WC_AGC2, ph) = fabs(sabs);
+                agc2_sum = agc2_sum - agc2_old; agc2_sum = agc2_sum + fabs(sabs); // (the value is in the ring: the EbNo meter pushed it)
                 double gain = 1.414213562 / fmax(agc2_sum / agc2_len_d, 0.000001);
                 gain = fmax(gain, 0.000001);
                 sre *= gain; sim *= gain;
@@ -360,14 +367,13 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
             // the five windows' entries of this gated sample are in their cell; a full cell leaves as whole sectors, then all advance
             if (ph == 7)
             {
-                wc_flush4(WC_E2, ebe2_ring + (eb_pos - 7)); wc_flush4(WC_E, ebe_ring + (eb_pos - 7));
-                wc_flush4(WC_AGC2, agc2_ring + (agc2_pos - 7)); wc_flush4(WC_D8, d8_ring + (d8_pos - 7));
+                wc_flush4(WC_E, ebe_ring + (eb_pos - 7));
+                wc_flush4(WC_D8, d8_ring + (d8_pos - 7));
                 double2 *dd = dly_ring + (dly_pos - 7);
 #pragma unroll
                 for (int k = 0; k < 8; k++) dd[k] = make_double2(wc_at(WC_DX, k), wc_at(WC_DY, k));
             }
-            eb_pos++; if (eb_pos >= g.eb_len) eb_pos = 0;
-            agc2_pos++; if (agc2_pos >= g.agc2_len) agc2_pos = 0;
+            eb_pos++; if (eb_pos >= g.win_ring) eb_pos = 0;
             dly_pos++; if (dly_pos >= g.dly_ring) dly_pos = 0;
             d8_pos++; if (d8_pos >= g.d8_ring) d8_pos = 0;
             {
@@ -443,8 +449,8 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
         const int ph = eb_pos & 7;
         for (int k = 0; k < ph; k++)
         {
-            ebe2_ring[eb_pos - ph + k] = wc_at(WC_E2, k); ebe_ring[eb_pos - ph + k] = wc_at(WC_E, k);
-            agc2_ring[agc2_pos - ph + k] = wc_at(WC_AGC2, k); d8_ring[d8_pos - ph + k] = wc_at(WC_D8, k);
+            ebe_ring[eb_pos - ph + k] = wc_at(WC_E, k);
+            d8_ring[d8_pos - ph + k] = wc_at(WC_D8, k);
             dly_ring[dly_pos - ph + k] = make_double2(wc_at(WC_DX, k), wc_at(WC_DY, k));
         }
     }
@@ -456,12 +462,12 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
     BLDF(BS_RES_X1) = res_x1; BLDF(BS_RES_X2) = res_x2; BLDF(BS_RES_Y1) = res_y1; BLDF(BS_RES_Y2) = res_y2;
     BLDF(BS_MSEMA_SUM) = msema_sum; BLDF(BS_MSE) = mse; BLDF(BS_DIFF_LAST) = diff_last;
     BLDI(BI_STARTSTOP) = startstop; BLDI(BI_CNTR) = cntr; BLDI(BI_MSEMA_POS) = msema_pos; BLDI(BI_NRX) = nrx;
-    BLDI(BI_AGC2_POS) = agc2_pos; BLDI(BI_EB_POS) = eb_pos; BLDI(BI_DLY_POS) = dly_pos; BLDI(BI_D8_POS) = d8_pos; BLDI(BI_A1_POS) = a1_pos;
+    BLDI(BI_EB_POS) = eb_pos; BLDI(BI_DLY_POS) = dly_pos; BLDI(BI_D8_POS) = d8_pos; BLDI(BI_A1_POS) = a1_pos;
     {
         // where the reference's delayedsmpl.buffer_ptr stands (k_burst_apply_settings needs it; DelayThing::setLength keeps the contents and
-        // restarts the pointer): the gated samples of this launch = how far the EbNo window moved (a launch is shorter than that ring)
+        // restarts the pointer): the gated samples of this launch = how far the window ring's write position moved (a launch is shorter than that ring)
         int adv = eb_pos - eb_pos0;
-        if (adv < 0) adv += g.eb_len;
+        if (adv < 0) adv += g.win_ring;
         BLDI(BI_GCNT) = (BLDI(BI_GCNT) + adv) % g.dly_len;
     }
     BLDI(BI_SOFT_CNT) = soft_cnt; BLDI(BI_SYM_CNT) = sym_cnt; BLDI(BI_EV_CNT) = ev_cnt; BLDI(BI_OVERFLOW) = overflow;

@@ -78,19 +78,15 @@ __global__ __launch_bounds__(64) void k_burst_apply_settings(const BGeom g, cons
         for (int s = y; s < g.hist_len; s += ny) p.pcmhist[hb_idx(s, nchp, ch)] = 0;
         if (oq)
         {
-            double *agc2 = p.agc2_ring + (size_t)grp * g.agc2_len * 64 + lane;
-            double *ebe = p.eb_e + (size_t)grp * g.eb_len * 64 + lane, *ebe2 = p.eb_e2 + (size_t)grp * g.eb_len * 64 + lane;
-            for (int s = y; s < g.agc2_len; s += ny) agc2[(size_t)s * 64] = 0.0;
-            for (int s = y; s < g.eb_len; s += ny) { ebe[(size_t)s * 64] = 0.0; ebe2[(size_t)s * 64] = 0.0; }
+            double *ebe = p.eb_e + (size_t)grp * g.win_ring * 64 + lane; // agc2's and the EbNo meter's windows: one ring (k_burst_demod.h)
+            for (int s = y; s < g.win_ring; s += ny) ebe[(size_t)s * 64] = 0.0;
         }
         else
         {
-            double *agc2 = p.agc2_ring + (size_t)ch * g.agc2_len;
-            double *ebe = p.eb_e + (size_t)ch * g.eb_len, *ebe2 = p.eb_e2 + (size_t)ch * g.eb_len;
+            double *ebe = p.eb_e + (size_t)ch * g.win_ring;
             double *fs = p.firsave + (size_t)ch * 2 * g.fir_n;
             double *d8 = p.dly8 + (size_t)ch * g.d8_ring, *a1 = p.a1 + (size_t)ch * g.d8_len;
-            for (int s = y; s < g.agc2_len; s += ny) agc2[s] = 0.0;
-            for (int s = y; s < g.eb_len; s += ny) { ebe[s] = 0.0; ebe2[s] = 0.0; }
+            for (int s = y; s < g.win_ring; s += ny) ebe[s] = 0.0;
             for (int s = y; s < 2 * g.fir_n; s += ny) fs[s] = 0.0;
             for (int s = y; s < g.d8_ring; s += ny) d8[s] = 0.0;
             for (int s = y; s < g.d8_len; s += ny) a1[s] = 0.0;

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
     double marg_sum = LDF(S_MARG_SUM), msema_sum = LDF(S_MSEMA_SUM), mse = LDF(S_MSE);
     double diff_last = LDF(S_DIFF_LAST);
 
-    int agc_pos = LDI(I_AGC_POS), eb_pos = LDI(I_EB_POS), bb_ptr = LDI(I_BB_PTR), coarse_cnt = LDI(I_COARSE_CNT);
+    int agc_pos = LDI(I_AGC_POS), bb_ptr = LDI(I_BB_PTR), coarse_cnt = LDI(I_COARSE_CNT);
     int marg_pos = LDI(I_MARG_POS), dt_pos = LDI(I_DT_POS), msema_pos = LDI(I_MSEMA_POS);
     const int flags = LDI(I_FLAGS);
     const bool dcd = flags & JF_DCD;
@@ -53,9 +53,9 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
     const double samplerate = g.Fs;
     const int nfft_mask = g.nfft - 1;
     double2 *__restrict__ bbring = p.bbring + (size_t)ch * g.nfft;
-    double *__restrict__ agc_ring = p.agc_ring + (size_t)grp * g.agc_len * 64 + lane;
-    double *__restrict__ ebe_ring = p.eb_e + (size_t)grp * g.ebno_len * 64 + lane;
-    double *__restrict__ ebe2_ring = p.eb_e2 + (size_t)grp * g.ebno_len * 64 + lane;
+    // ONE ring of |sig2| values: the AGC's buffer, the EbNo meter's E buffer and, squared, its E2 buffer (k_msk_fb.h)
+    double *__restrict__ win = p.win + (size_t)grp * g.win_len * 64 + lane;
+    auto wslot = [&](int pos, int lag) { const int q = pos - lag; return q < 0 ? q + g.win_len : q; };
     double *__restrict__ marg_ring = p.marg + (size_t)ch * g.marg_len;
     double2 *__restrict__ dt_ring = p.dt + (size_t)ch * g.dt_len;
     double *__restrict__ msema_ring = p.msema + (size_t)ch * g.msema_len;
@@ -91,9 +91,9 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
     // inputs of sample i+1 are requested at the top of iteration i (see the file header)
     auto ring_next = [](int pos, int len) { pos++; return pos >= len ? 0 : pos; };
     short nx_pcm = (live && n > 0) ? pcm[ch] : (short)0;
-    double nx_agc = agc_ring[(size_t)agc_pos * 64];
+    double nx_agc = win[(size_t)wslot(agc_pos, g.agc_len) * 64];
     double nx_e = 0, nx_e2 = 0;
-    if (EBNO) { nx_e = ebe_ring[(size_t)eb_pos * 64]; nx_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
+    if (EBNO) { nx_e = win[(size_t)wslot(agc_pos, g.ebno_len) * 64]; nx_e2 = nx_e * nx_e; }
     double2 nx_cc = cis[jd_cisidx(mc_ptr)];
     double2 nx_ptd = dly_ring[(size_t)ring_next(dly_slot, dly_len) * 64]; // slot read after this sample's write to dly_slot
     double nx_d8 = d8_ring[(size_t)ring_next(d8_slot, d8_len) * 64];
@@ -110,13 +110,9 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
         if (i + 1 < n)
         {
             nx_pcm = live ? pcm[(size_t)(i + 1) * pcm_stride + ch] : (short)0;
-            nx_agc = agc_ring[(size_t)ring_next(agc_pos, g.agc_len) * 64];
-            if (EBNO)
-            {
-                const int ep = ring_next(eb_pos, g.ebno_len);
-                nx_e = ebe_ring[(size_t)ep * 64];
-                nx_e2 = ebe2_ring[(size_t)ep * 64];
-            }
+            const int wn = ring_next(agc_pos, g.win_len);
+            nx_agc = win[(size_t)wslot(wn, g.agc_len) * 64];
+            if (EBNO) { nx_e = win[(size_t)wslot(wn, g.ebno_len) * 64]; nx_e2 = nx_e * nx_e; }
             nx_ptd = dly_ring[(size_t)ring_next(ring_next(dly_slot, dly_len), dly_len) * 64]; // dly_len, d8_len >= 3
             nx_d8 = d8_ring[(size_t)ring_next(ring_next(d8_slot, d8_len), d8_len) * 64];
         }
@@ -148,11 +144,8 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
         if (EBNO)
         {
             const double sq = dabval * dabval;
-            double *e2p = ebe2_ring + (size_t)eb_pos * 64;
-            double *ep = ebe_ring + (size_t)eb_pos * 64;
-            eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq); *e2p = fabs(sq);
-            eb_esum = eb_esum - e_old; eb_esum = eb_esum + fabs(dabval); *ep = fabs(dabval);
-            eb_pos++; if (eb_pos >= g.ebno_len) eb_pos = 0;
+            eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq);
+            eb_esum = eb_esum - e_old; eb_esum = eb_esum + fabs(dabval);
             if (i >= n - JD_EBNO_TAIL) // wave-uniform; see JD_EBNO_TAIL
             {
                 const double e2val = eb_e2sum / eb_len_d, mean = eb_esum / eb_len_d;
@@ -167,11 +160,11 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
 
         // AGC + clip (:378-382)
         {
-            double *ap = agc_ring + (size_t)agc_pos * 64;
+            double *ap = win + (size_t)agc_pos * 64;
             agc_sum = agc_sum - agc_old;
             agc_sum = agc_sum + fabs(dabval);
-            *ap = fabs(dabval);
-            agc_pos++; if (agc_pos >= g.agc_len) agc_pos = 0;
+            *ap = fabs(dabval); // the one store: the EbNo meter above pushed the same value
+            agc_pos++; if (agc_pos >= g.win_len) agc_pos = 0;
         }
         double gain = 1.414213562 / fmax(agc_sum / agc_len_d, 0.000001);
         gain = fmax(gain, 0.000001);
@@ -328,7 +321,7 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
     LDF(S_RES_X1) = res_x1; LDF(S_RES_X2) = res_x2; LDF(S_RES_Y1) = res_y1; LDF(S_RES_Y2) = res_y2;
     LDF(S_MARG_SUM) = marg_sum; LDF(S_MSEMA_SUM) = msema_sum; LDF(S_MSE) = mse;
     LDF(S_DIFF_LAST) = diff_last;
-    LDI(I_AGC_POS) = agc_pos; LDI(I_EB_POS) = eb_pos; LDI(I_BB_PTR) = bb_ptr; LDI(I_COARSE_CNT) = coarse_cnt;
+    LDI(I_AGC_POS) = agc_pos; LDI(I_BB_PTR) = bb_ptr; LDI(I_COARSE_CNT) = coarse_cnt;
     LDI(I_MARG_POS) = marg_pos; LDI(I_DT_POS) = dt_pos; LDI(I_MSEMA_POS) = msema_pos;
     LDI(I_SOFT_CNT) = soft_cnt; LDI(I_SYM_CNT) = sym_cnt; LDI(I_OVERFLOW) = overflow;
     {

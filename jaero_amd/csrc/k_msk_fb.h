@@ -108,13 +108,14 @@ __device__ __forceinline__ void mfb_front(const JGeom &g, const JPtrs &p, const 
     double mc_ptr = LDF(S_MC_PTR), mc_step = LDF(S_MC_STEP);
     double agc_sum = LDF(S_AGC_SUM);
     double eb_esum = LDF(S_EB_ESUM), eb_e2sum = LDF(S_EB_E2SUM), eb_ebno = LDF(S_EB_EBNO);
-    int agc_pos = LDI(I_AGC_POS), eb_pos = LDI(I_EB_POS), bb_ptr = LDI(I_BB_PTR), coarse_cnt = LDI(I_COARSE_CNT);
+    int agc_pos = LDI(I_AGC_POS), bb_ptr = LDI(I_BB_PTR), coarse_cnt = LDI(I_COARSE_CNT);
     const int flags = LDI(I_FLAGS);
     const int nfft_mask = g.nfft - 1;
     double2 *__restrict__ bbring = p.bbring + (size_t)ch * g.nfft;
-    double *__restrict__ agc_ring = p.agc_ring + (size_t)grp * g.agc_len * 64 + lane;
-    double *__restrict__ ebe_ring = p.eb_e + (size_t)grp * g.ebno_len * 64 + lane;
-    double *__restrict__ ebe2_ring = p.eb_e2 + (size_t)grp * g.ebno_len * 64 + lane;
+    // ONE ring of |sig2| values (JPtrs::win, jaero_device.h): the AGC's moving-average buffer, the EbNo meter's E buffer, and -- squared -- its
+    // E2 buffer; written once per sample at agc_pos, read at the two window lengths behind it
+    double *__restrict__ win = p.win + (size_t)grp * g.win_len * 64 + lane;
+    auto wslot = [&](int pos, int lag) { const int q = pos - lag; return q < 0 ? q + g.win_len : q; };
 
     // coarse ring fill, four entries at a time as one complete 64-byte sector (see k_oqpsk_fb.h)
     double2 cq1 = make_double2(0.0, 0.0), cq2 = cq1, cq3 = cq1;
@@ -174,16 +175,14 @@ __device__ __forceinline__ void mfb_front(const JGeom &g, const JPtrs &p, const 
     const double agc_len_d = (double)g.agc_len, eb_len_d = (double)g.ebno_len;
 
     // MSKEbNoMeasure::Update (DSP.cpp:493-505), AGC + clip (mskdemodulator.cpp:378-382) for one sample; hands {sre, sim} to the back half
-    auto front_sample = [&](double sre, double sim, double agc_old, double e_old, double e2_old, int j, int buf) __attribute__((always_inline)) {
+    auto front_sample = [&](double sre, double sim, double agc_old, double e_old, int j, int buf) __attribute__((always_inline)) {
         const double dabval = sqrt(sre * sre + sim * sim);
         if (EBNO)
         {
             const double sq = dabval * dabval;
-            double *e2p = ebe2_ring + (size_t)eb_pos * 64;
-            double *ep = ebe_ring + (size_t)eb_pos * 64;
-            eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq); *e2p = fabs(sq);
-            eb_esum = eb_esum - e_old; eb_esum = eb_esum + fabs(dabval); *ep = fabs(dabval);
-            eb_pos++; if (eb_pos >= g.ebno_len) eb_pos = 0;
+            const double e2_old = e_old * e_old; // E2's buffer holds fabs(sig * sig) of the same samples (MovingAverage::Update, DSP.cpp:408-416)
+            eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq);
+            eb_esum = eb_esum - e_old; eb_esum = eb_esum + fabs(dabval);
             if (j >= n - JD_EBNO_TAIL) // wave-uniform; see JD_EBNO_TAIL
             {
                 const double e2val = eb_e2sum / eb_len_d, mean = eb_esum / eb_len_d;
@@ -196,11 +195,11 @@ __device__ __forceinline__ void mfb_front(const JGeom &g, const JPtrs &p, const 
             }
         }
         {
-            double *ap = agc_ring + (size_t)agc_pos * 64;
+            double *ap = win + (size_t)agc_pos * 64;
             agc_sum = agc_sum - agc_old;
             agc_sum = agc_sum + fabs(dabval);
-            *ap = fabs(dabval);
-            agc_pos++; if (agc_pos >= g.agc_len) agc_pos = 0;
+            *ap = fabs(dabval); // the one store: the EbNo meter above pushed the same value
+            agc_pos++; if (agc_pos >= g.win_len) agc_pos = 0;
         }
         double gain = 1.414213562 / fmax(agc_sum / agc_len_d, 0.000001);
         gain = fmax(gain, 0.000001);
@@ -212,9 +211,9 @@ __device__ __forceinline__ void mfb_front(const JGeom &g, const JPtrs &p, const 
     };
 
     auto ring_pos_next = [](int pos, int len) { pos++; return pos >= len ? 0 : pos; };
-    double r1_agc = agc_ring[(size_t)agc_pos * 64]; // rows for the next sample to be fronted
-    double r1_e = 0, r1_e2 = 0;
-    if (EBNO) { r1_e = ebe_ring[(size_t)eb_pos * 64]; r1_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
+    double r1_agc = win[(size_t)wslot(agc_pos, g.agc_len) * 64]; // the entries leaving the two windows at the next sample to be fronted
+    double r1_e = 0;
+    if (EBNO) r1_e = win[(size_t)wslot(agc_pos, g.ebno_len) * 64];
     short nx_pcm = (live && n > 0) ? pcm[ch] : (short)0;
     double2 nx_cc = cis[jd_cisidx(mc_ptr)];
 
@@ -224,9 +223,9 @@ __device__ __forceinline__ void mfb_front(const JGeom &g, const JPtrs &p, const 
     {
         double y_re, y_im;
         fir_eval(0, y_re, y_im);
-        front_sample(y_re, y_im, r1_agc, r1_e, r1_e2, 0, 0);
-        r1_agc = agc_ring[(size_t)agc_pos * 64];
-        if (EBNO) { r1_e = ebe_ring[(size_t)eb_pos * 64]; r1_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
+        front_sample(y_re, y_im, r1_agc, r1_e, 0, 0);
+        r1_agc = win[(size_t)wslot(agc_pos, g.agc_len) * 64];
+        if (EBNO) r1_e = win[(size_t)wslot(agc_pos, g.ebno_len) * 64];
     }
     fb_barrier();
 
@@ -268,24 +267,20 @@ __device__ __forceinline__ void mfb_front(const JGeom &g, const JPtrs &p, const 
             nx_pcm = live ? pcm[(size_t)(i + 1) * pcm_stride + ch] : (short)0;
             nx_cc = cis[jd_cisidx(mc_ptr)];
         }
-        double r2_agc = 0, r2_e = 0, r2_e2 = 0;
+        double r2_agc = 0, r2_e = 0;
         if (i + 2 < nB)
         {
-            r2_agc = agc_ring[(size_t)ring_pos_next(agc_pos, g.agc_len) * 64];
-            if (EBNO)
-            {
-                const int ep = ring_pos_next(eb_pos, g.ebno_len);
-                r2_e = ebe_ring[(size_t)ep * 64];
-                r2_e2 = ebe2_ring[(size_t)ep * 64];
-            }
+            const int wn = ring_pos_next(agc_pos, g.win_len);
+            r2_agc = win[(size_t)wslot(wn, g.agc_len) * 64];
+            if (EBNO) r2_e = win[(size_t)wslot(wn, g.ebno_len) * 64];
         }
         __builtin_amdgcn_sched_barrier(0);
         if (i + 1 < nB)
         {
             double y_re, y_im;
             fir_eval(i + 1, y_re, y_im);
-            front_sample(y_re, y_im, r1_agc, r1_e, r1_e2, i + 1, (i + 1) & 1);
-            r1_agc = r2_agc; r1_e = r2_e; r1_e2 = r2_e2;
+            front_sample(y_re, y_im, r1_agc, r1_e, i + 1, (i + 1) & 1);
+            r1_agc = r2_agc; r1_e = r2_e;
         }
         fb_barrier();
     }
@@ -300,7 +295,7 @@ __device__ __forceinline__ void mfb_front(const JGeom &g, const JPtrs &p, const 
     LDF(S_MC_PTR) = mc_ptr; LDF(S_MC_STEP) = mc_step;
     LDF(S_AGC_SUM) = agc_sum;
     LDF(S_EB_ESUM) = eb_esum; LDF(S_EB_E2SUM) = eb_e2sum; LDF(S_EB_EBNO) = eb_ebno;
-    LDI(I_AGC_POS) = agc_pos; LDI(I_EB_POS) = eb_pos; LDI(I_BB_PTR) = bb_ptr; LDI(I_COARSE_CNT) = coarse_cnt;
+    LDI(I_AGC_POS) = agc_pos; LDI(I_BB_PTR) = bb_ptr; LDI(I_COARSE_CNT) = coarse_cnt;
     {
         double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
         for (int k = 0; k < LDSN; k++)

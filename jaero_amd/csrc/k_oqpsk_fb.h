@@ -114,13 +114,15 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &
     double mc_ptr = LDF(S_MC_PTR), mc_step = LDF(S_MC_STEP);
     double agc_sum = LDF(S_AGC_SUM);
     double eb_esum = LDF(S_EB_ESUM), eb_e2sum = LDF(S_EB_E2SUM), eb_ebno = LDF(S_EB_EBNO);
-    int agc_pos = LDI(I_AGC_POS), eb_pos = LDI(I_EB_POS), bb_ptr = LDI(I_BB_PTR), coarse_cnt = LDI(I_COARSE_CNT);
+    int agc_pos = LDI(I_AGC_POS), bb_ptr = LDI(I_BB_PTR), coarse_cnt = LDI(I_COARSE_CNT);
+    int agc_hold = LDI(I_AGC_HOLD); // samples for which the AGC's buffer (re-created by setSettings: zeros) still returns zeros while the meter's keeps its values
     const int flags = LDI(I_FLAGS);
     const int nfft_mask = g.nfft - 1;
     double2 *__restrict__ bbring = p.bbring + (size_t)ch * g.nfft;
-    double *__restrict__ agc_ring = p.agc_ring + (size_t)grp * g.agc_len * 64 + lane;
-    double *__restrict__ ebe_ring = p.eb_e + (size_t)grp * g.ebno_len * 64 + lane;
-    double *__restrict__ ebe2_ring = p.eb_e2 + (size_t)grp * g.ebno_len * 64 + lane;
+    // ONE ring of |sig2| values (JPtrs::win, jaero_device.h): the AGC's moving-average buffer, the EbNo meter's E buffer, and -- squared -- its
+    // E2 buffer; written once per sample at agc_pos, read at the two window lengths behind it
+    double *__restrict__ win = p.win + (size_t)grp * g.win_len * 64 + lane;
+    auto wslot = [&](int pos, int lag) { const int q = pos - lag; return q < 0 ? q + g.win_len : q; };
 
     // Coarse ring fill, four entries at a time: a 16-byte store into the per-channel ring is a quarter of a 64-byte sector; issued one per
     // sample (3.5 us apart) every one of them cost the L2 a sector fill from HBM plus a sector write (measured: 23 GB written and
@@ -177,16 +179,14 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &
 
     // K7 + K8 for one sample: EbNo meter, AGC, clip; hands {sre, sim, abval} to the back half through mailbox `buf`
     // (oqpskdemodulator.cpp:458-470, DSP.cpp:729-744, :370-379); agc_old / e_old / e2_old = the rows leaving the windows
-    auto front_sample = [&](double sre, double sim, double agc_old, double e_old, double e2_old, int j, int buf) __attribute__((always_inline)) {
+    auto front_sample = [&](double sre, double sim, double agc_old, double e_old, int j, int buf) __attribute__((always_inline)) {
         const double dabval = sqrt(sre * sre + sim * sim);
         if (EBNO)
         {
             const double sq = dabval * dabval;
-            double *e2p = ebe2_ring + (size_t)eb_pos * 64;
-            double *ep = ebe_ring + (size_t)eb_pos * 64;
-            eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq); *e2p = fabs(sq);
-            eb_esum = eb_esum - e_old; eb_esum = eb_esum + fabs(dabval); *ep = fabs(dabval);
-            eb_pos++; if (eb_pos >= g.ebno_len) eb_pos = 0;
+            const double e2_old = e_old * e_old; // E2's buffer holds fabs(sig * sig) of the same samples (MovingAverage::Update, DSP.cpp:408-416)
+            eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq);
+            eb_esum = eb_esum - e_old; eb_esum = eb_esum + fabs(dabval);
             if (j >= n - JD_EBNO_TAIL) // wave-uniform; see JD_EBNO_TAIL
             {
                 const double e2val = jd_div_const(eb_e2sum, eb_len_d, r_eb_len), mean = jd_div_const(eb_esum, eb_len_d, r_eb_len);
@@ -203,11 +203,12 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &
             }
         }
         {
-            double *ap = agc_ring + (size_t)agc_pos * 64;
+            if (agc_hold > 0) { agc_old = 0.0; agc_hold--; }
+            double *ap = win + (size_t)agc_pos * 64;
             agc_sum = agc_sum - agc_old;
             agc_sum = agc_sum + fabs(dabval);
-            *ap = fabs(dabval);
-            agc_pos++; if (agc_pos >= g.agc_len) agc_pos = 0;
+            *ap = fabs(dabval); // the one store: the EbNo meter above pushed the same value
+            agc_pos++; if (agc_pos >= g.win_len) agc_pos = 0;
         }
         double gain = 1.414213562 / fmax(jd_div_const(agc_sum, agc_len_d, r_agc_len), 0.000001);
         gain = fmax(gain, 0.000001);
@@ -222,9 +223,9 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &
     // waits for every older request.  All slow requests of a step -- the HBM rows leaving the AGC / EbNo windows TWO samples on, the
     // next PCM value, the coarse ring store -- are therefore issued right behind that wait, a whole step before the next one.
     auto ring_pos_next = [](int pos, int len) { pos++; return pos >= len ? 0 : pos; };
-    double r1_agc = agc_ring[(size_t)agc_pos * 64]; // rows for the next sample to be fronted
-    double r1_e = 0, r1_e2 = 0;
-    if (EBNO) { r1_e = ebe_ring[(size_t)eb_pos * 64]; r1_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
+    double r1_agc = win[(size_t)wslot(agc_pos, g.agc_len) * 64]; // the entries leaving the two windows at the next sample to be fronted
+    double r1_e = 0;
+    if (EBNO) r1_e = win[(size_t)wslot(agc_pos, g.ebno_len) * 64];
     short nx_pcm = (live && n > 0) ? pcm[ch] : (short)0;
     double2 nx_cc = cis[jd_cisidx(mc_ptr)];
 
@@ -239,7 +240,7 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &
             const double2 c_m2 = cis[m2i];
             const double2 pf = nx_pf;
             const double sre = c_m2.x * pf.x - c_m2.y * pf.y, sim = c_m2.x * pf.y + c_m2.y * pf.x;
-            front_sample(sre, sim, r1_agc, r1_e, r1_e2, i, i & 1);
+            front_sample(sre, sim, r1_agc, r1_e, i, i & 1);
             FB_SYNC(L);
             // under the back half's sample i: this sample's coarse ring entry (K3, :410-415) and the next sample's inputs
             const double dval = ((double)nx_pcm) / 32768.0;
@@ -256,8 +257,8 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &
             }
             if (i + 1 < nB)
             {
-                r1_agc = agc_ring[(size_t)agc_pos * 64];
-                if (EBNO) { r1_e = ebe_ring[(size_t)eb_pos * 64]; r1_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
+                r1_agc = win[(size_t)wslot(agc_pos, g.agc_len) * 64];
+                if (EBNO) r1_e = win[(size_t)wslot(agc_pos, g.ebno_len) * 64];
             }
             FB_SYNC(L); // the back half has published the carrier table index of sample i + 1
         }
@@ -269,9 +270,9 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &
     {
         double y_re, y_im;
         jd_fir_eval_sym<FIRN, LDSN, 6>(lre, lim, tp, tre, tim, fir_slot, lane, y_re, y_im);
-        front_sample(y_re, y_im, r1_agc, r1_e, r1_e2, 0, 0);
-        r1_agc = agc_ring[(size_t)agc_pos * 64];
-        if (EBNO) { r1_e = ebe_ring[(size_t)eb_pos * 64]; r1_e2 = ebe2_ring[(size_t)eb_pos * 64]; }
+        front_sample(y_re, y_im, r1_agc, r1_e, 0, 0);
+        r1_agc = win[(size_t)wslot(agc_pos, g.agc_len) * 64];
+        if (EBNO) r1_e = win[(size_t)wslot(agc_pos, g.ebno_len) * 64];
     }
     FB_SYNC(L);
 
@@ -310,24 +311,20 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &
             nx_pcm = live ? pcm[(size_t)(i + 1) * pcm_stride + ch] : (short)0;
             nx_cc = cis[jd_cisidx(mc_ptr)];
         }
-        double r2_agc = 0, r2_e = 0, r2_e2 = 0;
+        double r2_agc = 0, r2_e = 0;
         if (i + 2 < nB)
         {
-            r2_agc = agc_ring[(size_t)ring_pos_next(agc_pos, g.agc_len) * 64];
-            if (EBNO)
-            {
-                const int ep = ring_pos_next(eb_pos, g.ebno_len);
-                r2_e = ebe_ring[(size_t)ep * 64];
-                r2_e2 = ebe2_ring[(size_t)ep * 64];
-            }
+            const int wn = ring_pos_next(agc_pos, g.win_len);
+            r2_agc = win[(size_t)wslot(wn, g.agc_len) * 64];
+            if (EBNO) r2_e = win[(size_t)wslot(wn, g.ebno_len) * 64];
         }
         __builtin_amdgcn_sched_barrier(0);
         if (i + 1 < nB)
         {
             double y_re, y_im;
             jd_fir_eval_sym_static<FIRN, LDSN, 6>(lre, lim, tp, tre, tim, fir_slot, lane, y_re, y_im);
-            front_sample(y_re, y_im, r1_agc, r1_e, r1_e2, i + 1, (i + 1) & 1);
-            r1_agc = r2_agc; r1_e = r2_e; r1_e2 = r2_e2;
+            front_sample(y_re, y_im, r1_agc, r1_e, i + 1, (i + 1) & 1);
+            r1_agc = r2_agc; r1_e = r2_e;
         }
         FB_SYNC(L);
     }
@@ -343,7 +340,8 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &
     LDF(S_MC_PTR) = mc_ptr; LDF(S_MC_STEP) = mc_step;
     LDF(S_AGC_SUM) = agc_sum;
     LDF(S_EB_ESUM) = eb_esum; LDF(S_EB_E2SUM) = eb_e2sum; LDF(S_EB_EBNO) = eb_ebno;
-    LDI(I_AGC_POS) = agc_pos; LDI(I_EB_POS) = eb_pos; LDI(I_BB_PTR) = bb_ptr; LDI(I_COARSE_CNT) = coarse_cnt;
+    LDI(I_AGC_POS) = agc_pos; LDI(I_BB_PTR) = bb_ptr; LDI(I_COARSE_CNT) = coarse_cnt;
+    LDI(I_AGC_HOLD) = agc_hold;
     if constexpr (!PRE8400)
     {
         double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
