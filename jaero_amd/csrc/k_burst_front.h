@@ -387,8 +387,11 @@ __global__ __launch_bounds__(TRI_THREADS, 2) void k_trident(const BGeom g, const
             for (int s = 0; s < 32; s++)
             {
                 const int n = s * TRI_THREADS + t;
+                // rows past the window are zeros whatever their twiddle: at 10.5 kbps / 1200 bps the windows (1170 / 5040, 2960 samples) fill
+                // 5 / 20, 12 of the 32 rows, and the table loads and products of the others were most of this loop
+                if (s * TRI_THREADS >= len) { d.r[s] = 0.0; d.i[s] = 0.0; continue; }
                 double x0 = 0.0, x1 = 0.0;
-                if (s * TRI_THREADS < len && n < len)
+                if (n < len)
                 {
                     int sl = slot0 + n; if (sl >= g.cv_len) sl -= g.cv_len;
                     x0 = cvre[(size_t)sl * 64];
