@@ -246,7 +246,8 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
         HIPCHK(hipFuncSetAttribute((const void *)k_burst_msk_fb<false, 160, BMSK_FB_LDSN_160>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIPCHK(hipFuncSetAttribute((const void *)k_burst_msk_fb<true, 160, BMSK_FB_LDSN_160>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
-    HIPCHK(hipFuncSetAttribute((const void *)k_trident, hipFuncAttributeMaxDynamicSharedMemorySize, c->tri_lds));
+    HIPCHK(hipFuncSetAttribute((const void *)k_trident<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->tri_lds));
+    HIPCHK(hipFuncSetAttribute((const void *)k_trident<false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->tri_lds));
     HIPCHK(hipDeviceSynchronize());
     return 0;
 }
@@ -296,7 +297,8 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
         LAUNCHCHK("k_burst_front");
         prof_end(c, pi, st);
         pi = prof_begin(c, 1, st);
-        hipLaunchKernelGGL(k_trident, dim3(c->tri_grid), dim3(TRI_THREADS), c->tri_lds, st, g, p, n0);
+        if (g.kind == JAERO_KIND_BURST_OQPSK) hipLaunchKernelGGL(k_trident<true>, dim3(c->tri_grid), dim3(TRI_THREADS), c->tri_lds, st, g, p, n0);
+        else hipLaunchKernelGGL(k_trident<false>, dim3(c->tri_grid), dim3(TRI_THREADS), c->tri_lds, st, g, p, n0);
         LAUNCHCHK("k_trident");
         prof_end(c, pi, st);
         pi = prof_begin(c, 0, st);

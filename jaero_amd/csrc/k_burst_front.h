@@ -338,6 +338,7 @@ __device__ __forceinline__ void tri_argmax_first(double &v, int &idx, double *re
 // the residue class's differences share the exchange buffer (it is idle between a transform's last read and the next one's first barrier).
 #define TRI_THREADS 256
 #define TRI_XCH C6_XCH13
+template <bool oq> // burst OQPSK / burst MSK: the two searches keep different things across the transforms
 __global__ __launch_bounds__(TRI_THREADS, 2) void k_trident(const BGeom g, const BPtrs p, long long n0)
 {
     extern __shared__ __attribute__((aligned(16))) double xch[]; // TRI_XCH doubles
@@ -347,7 +348,6 @@ __global__ __launch_bounds__(TRI_THREADS, 2) void k_trident(const BGeom g, const
     double *dl = xch; // one residue class of trident differences (4096 doubles), between two transforms
     const int t = threadIdx.x, nchp = g.nchp;
     const int nev = *p.ev_count;
-    const bool oq = g.kind == JAERO_KIND_BURST_OQPSK_D;
     const double hzperbin = g.Fs / ((double)TRI_N);
     const int b = jd_qround((0.25 * g.fb) / hzperbin), b4 = b >> 2;       // OQPSK: 1792, 448
     const int psb = jd_qround((0.5 * g.fb) / hzperbin);                   // MSK
