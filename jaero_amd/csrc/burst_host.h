@@ -89,6 +89,7 @@ static void burst_fill_geometry(BGeom &g, const jaero_settings &s, int nch, unsi
         g.a1_lag = (int)(SPS / 2); g.a1_w = 0.0;
         g.d8_len = (int)(SPS / 2) + 1; g.dly_len = (int)SPS + 1;
         g.d8_ring = (g.d8_len + 7) / 8 * 8; g.dly_ring = (g.dly_len + 7) / 8 * 8;
+        if ((int)SPS == 40) g.d8_ring = g.d8_len; // 1200 bps: delayt8's ring lives in LDS during a launch (k_burst_msk_fb.h), its HBM copy is exactly d8_len entries
         g.stref_freq = s.fb / 2.0;
         g.stq_step = (s.fb / 2.0) * ((double)JD_WTSIZE) / ((float)(double)(int)s.Fs);
         g.fir_n = 2 * (int)SPS;
@@ -231,7 +232,7 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
     c->m.nch = nch; c->m.nchp = nchp;
     c->m.flags.assign(nchp, 0);
     // burst OQPSK: 39 of its 55 history slots + the taps in LDS; burst MSK: 39 of 80 (1200 bps) or all 160 (600 bps) slots
-    const int lds = oq ? (2 * 39 * 64 + 64) * (int)sizeof(double) : 2 * (g.fir_n == 80 ? BMSK_FB_LDSN_80 : BMSK_FB_LDSN_160) * 64 * (int)sizeof(double) + BMSK_FB_MAIL_BYTES + BMSK_FB_WC_BYTES;
+    const int lds = oq ? (2 * 39 * 64 + 64) * (int)sizeof(double) : 2 * (g.fir_n == 80 ? BMSK_FB_LDSN_80 : BMSK_FB_LDSN_160) * 64 * (int)sizeof(double) + BMSK_FB_MAIL_BYTES + BMSK_FB_WC_BYTES(g.fir_n == 80) + BMSK_FB_D8_BYTES(g.fir_n == 80, g.d8_len);
     if (oq)
     {
         HIPCHK(hipFuncSetAttribute((const void *)k_burst_oqpsk_demod<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -275,7 +276,7 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
         prof_end(c, pi, st);
     }
     const bool cs = (c->flags & JAERO_FLAG_CAPTURE_SYMBOLS) != 0;
-    const int lds = g.kind == JAERO_KIND_BURST_OQPSK ? (2 * 39 * 64 + 64) * (int)sizeof(double) : 2 * (g.fir_n == 80 ? BMSK_FB_LDSN_80 : BMSK_FB_LDSN_160) * 64 * (int)sizeof(double) + BMSK_FB_MAIL_BYTES + BMSK_FB_WC_BYTES;
+    const int lds = g.kind == JAERO_KIND_BURST_OQPSK ? (2 * 39 * 64 + 64) * (int)sizeof(double) : 2 * (g.fir_n == 80 ? BMSK_FB_LDSN_80 : BMSK_FB_LDSN_160) * 64 * (int)sizeof(double) + BMSK_FB_MAIL_BYTES + BMSK_FB_WC_BYTES(g.fir_n == 80) + BMSK_FB_D8_BYTES(g.fir_n == 80, g.d8_len);
     int first = 1;
     c->poisoned = true; // the history push above is idempotent (same slots if the write is repeated); from here on state advances
     for (int pos = 0; pos < nsamples;)

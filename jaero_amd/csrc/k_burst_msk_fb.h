@@ -38,13 +38,16 @@ struct BmskMail
     double *out; // [2][2][64] filter output (re, im) for the sample of that parity
     double *in;  // [2][3][64] mixer2's table entry (re, im) for the sample and vol_gain
     int *gate;   // [2][64]    1 = the sample is pushed (the channel's gate is open)
-    double *wc;  // [BMSK_FB_WC_RINGS][8][64] the back half's write-combining cells
+    double *wc;  // [3 or 4][8][64] the back half's write-combining cells
+    double *d8;  // [d8_len][64] delayt8's ring where it fits (1200 bps: 21 entries), behind the cells
 };
 #define BMSK_FB_MAIL_BYTES (2 * 2 * 64 * 8 + 2 * 3 * 64 * 8 + 2 * 64 * 4) // 5632
 #define BMSK_FB_LDSN_80 48
 #define BMSK_FB_LDSN_160 128
-#define BMSK_FB_WC_RINGS 4 // |sig2| (the EbNo / AGC2 window ring), delayt8, delayedsmpl re / im
-#define BMSK_FB_WC_BYTES (BMSK_FB_WC_RINGS * 8 * 64 * 8) // 16384
+// cells: |sig2| (the EbNo / AGC2 window ring), delayedsmpl re / im, and delayt8 where its ring stays in HBM (600 bps: 41 entries do not fit beside
+// 128 KiB of filter history); at 1200 bps delayt8's 21 entries per lane live in LDS for the launch (10.5 KiB) and cost HBM nothing per sample
+#define BMSK_FB_WC_BYTES(d8lds) (((d8lds) ? 3 : 4) * 8 * 64 * 8)
+#define BMSK_FB_D8_BYTES(d8lds, d8_len) ((d8lds) ? (d8_len) * 64 * 8 : 0)
 
 template <int FIRN, int LDSN>
 __device__ __forceinline__ void bmsk_front(const BGeom &g, const BPtrs &p, double *lre, double *lim, const BmskMail &M, int n, long long n0, int grp, int lane)
@@ -147,7 +150,7 @@ __device__ __forceinline__ void bmsk_front(const BGeom &g, const BPtrs &p, doubl
     }
 }
 
-template <bool CAPSYM>
+template <bool CAPSYM, bool D8LDS>
 __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const BmskMail &M, int n, long long n0, int first_of_write, int grp, int lane)
 {
     const int ch = grp * 64 + lane, nchp = g.nchp;
@@ -181,15 +184,17 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
     double *d8_ring = p.dly8 + (size_t)ch * g.d8_ring;
     // write-combining cells: this lane's column of [ring][entry & 7][lane]
     double *wc = M.wc + lane;
-    enum { WC_E = 0, WC_D8 = 1, WC_DX = 2, WC_DY = 3 };
+    enum { WC_E = 0, WC_DX = 1, WC_DY = 2, WC_D8 = 3 };
+    double *d8l = M.d8 + lane; // D8LDS: entry k of this lane's delayt8 ring at d8l[k * 64]; d8_pos counts modulo d8_len there (no cells)
     auto wc_at = [&](int ring, int k) -> double & { return wc[(ring * 8 + k) * 64]; };
     // the cell being filled holds the entries pushed since its start: back from HBM (the previous launch wrote them out entry by entry)
     {
-        const int ph = eb_pos & 7; // = dly_pos & 7 = d8_pos & 7: the three rings advance together
+        const int ph = eb_pos & 7; // = dly_pos & 7 (= d8_pos & 7 where delayt8 goes through cells): the rings advance together
+        if constexpr (D8LDS) for (int k = 0; k < g.d8_len; k++) d8l[k * 64] = d8_ring[k];
         for (int k = 0; k < ph; k++)
         {
             wc_at(WC_E, k) = ebe_ring[eb_pos - ph + k];
-            wc_at(WC_D8, k) = d8_ring[d8_pos - ph + k];
+            if constexpr (!D8LDS) wc_at(WC_D8, k) = d8_ring[d8_pos - ph + k];
             const double2 v = dly_ring[dly_pos - ph + k];
             wc_at(WC_DX, k) = v.x; wc_at(WC_DY, k) = v.y;
         }
@@ -289,7 +294,9 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
             const double e_old = ebe_ring[back(eb_pos, g.eb_len, g.win_ring)], agc2_old = ebe_ring[back(eb_pos, g.agc2_len, g.win_ring)];
             const double e2_old = e_old * e_old;
             const double2 ptd_pre = dly_ring[back(dly_pos, g.dly_len - 1, g.dly_ring)];
-            const double d8_a = d8_ring[back(d8_pos, g.d8_len - 2, g.d8_ring)], d8_b = d8_ring[back(d8_pos, g.d8_len - 1, g.d8_ring)];
+            double d8_a, d8_b; // the two oldest entries of delayt8's d8_len: written d8_len - 2 and d8_len - 1 pushes ago
+            if constexpr (D8LDS) { d8_a = d8l[back(d8_pos, g.d8_len - 2, g.d8_len) * 64]; d8_b = d8l[back(d8_pos, g.d8_len - 1, g.d8_len) * 64]; }
+            else { d8_a = d8_ring[back(d8_pos, g.d8_len - 2, g.d8_ring)]; d8_b = d8_ring[back(d8_pos, g.d8_len - 1, g.d8_ring)]; }
             const int ph = eb_pos & 7;
             const double st_ptr_top = st_ptr;
             const double2 so_pre = cis[jd_cisidx(st_ptr)]; // the symbol oscillator's table entry: valid unless the preamble block below moves st_ptr
@@ -362,20 +369,20 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
                 st_eta = y;
             }
             // delayt8.update(st_eta): integer delay SPS/2
-            wc_at(WC_D8, ph) = st_eta;
+            if constexpr (D8LDS) d8l[d8_pos * 64] = st_eta; else wc_at(WC_D8, ph) = st_eta;
             const double d8out = 0.0 * d8_a + 1.0 * d8_b; // the two oldest entries of a ring of d8_len: older than the entry just written (d8_len >= 3)
             // the five windows' entries of this gated sample are in their cell; a full cell leaves as whole sectors, then all advance
             if (ph == 7)
             {
                 wc_flush4(WC_E, ebe_ring + (eb_pos - 7));
-                wc_flush4(WC_D8, d8_ring + (d8_pos - 7));
+                if constexpr (!D8LDS) wc_flush4(WC_D8, d8_ring + (d8_pos - 7));
                 double2 *dd = dly_ring + (dly_pos - 7);
 #pragma unroll
                 for (int k = 0; k < 8; k++) dd[k] = make_double2(wc_at(WC_DX, k), wc_at(WC_DY, k));
             }
             eb_pos++; if (eb_pos >= g.win_ring) eb_pos = 0;
             dly_pos++; if (dly_pos >= g.dly_ring) dly_pos = 0;
-            d8_pos++; if (d8_pos >= g.d8_ring) d8_pos = 0;
+            d8_pos++; if (d8_pos >= (D8LDS ? g.d8_len : g.d8_ring)) d8_pos = 0;
             {
                 double2 so = so_pre;
                 if (st_ptr != st_ptr_top) so = cis[jd_cisidx(st_ptr)];
@@ -450,7 +457,7 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
         for (int k = 0; k < ph; k++)
         {
             ebe_ring[eb_pos - ph + k] = wc_at(WC_E, k);
-            d8_ring[d8_pos - ph + k] = wc_at(WC_D8, k);
+            if constexpr (!D8LDS) d8_ring[d8_pos - ph + k] = wc_at(WC_D8, k);
             dly_ring[dly_pos - ph + k] = make_double2(wc_at(WC_DX, k), wc_at(WC_DY, k));
         }
     }
@@ -462,6 +469,7 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
     BLDF(BS_RES_X1) = res_x1; BLDF(BS_RES_X2) = res_x2; BLDF(BS_RES_Y1) = res_y1; BLDF(BS_RES_Y2) = res_y2;
     BLDF(BS_MSEMA_SUM) = msema_sum; BLDF(BS_MSE) = mse; BLDF(BS_DIFF_LAST) = diff_last;
     BLDI(BI_STARTSTOP) = startstop; BLDI(BI_CNTR) = cntr; BLDI(BI_MSEMA_POS) = msema_pos; BLDI(BI_NRX) = nrx;
+    if constexpr (D8LDS) for (int k = 0; k < g.d8_len; k++) d8_ring[k] = d8l[k * 64];
     BLDI(BI_EB_POS) = eb_pos; BLDI(BI_DLY_POS) = dly_pos; BLDI(BI_D8_POS) = d8_pos; BLDI(BI_A1_POS) = a1_pos;
     {
         // where the reference's delayedsmpl.buffer_ptr stands (k_burst_apply_settings needs it; DelayThing::setLength keeps the contents and
@@ -482,9 +490,11 @@ __global__ __launch_bounds__(128) void k_burst_msk_fb(const BGeom g, const BPtrs
     M.out = lds + 2 * LDSN * 64;
     M.in = M.out + 256;
     M.gate = (int *)(M.in + 384);
+    constexpr bool D8LDS = FIRN == 80;
     M.wc = (double *)((char *)M.out + BMSK_FB_MAIL_BYTES);
+    M.d8 = (double *)((char *)M.wc + BMSK_FB_WC_BYTES(D8LDS));
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, grp = blockIdx.x;
     if (n <= 0) return;
     if (wave == 0) bmsk_front<FIRN, LDSN>(g, p, lre, lim, M, n, n0, grp, lane);
-    else bmsk_back<CAPSYM>(g, p, M, n, n0, first_of_write, grp, lane);
+    else bmsk_back<CAPSYM, D8LDS>(g, p, M, n, n0, first_of_write, grp, lane);
 }
