@@ -101,7 +101,8 @@ struct BPtrs
     double *mav1;                // [ng][mav1_len][64]
     double *fa;                  // [ng][fa_len][64]
     double *bt;                  // [ng][bt_len][64]
-    int *ev_list, *ev_count;     // compacted channels with a trident event this segment
+    unsigned long long *ev_mask; // [ng] lanes of each group whose trident buffer filled in this segment (k_burst_front)
+    int *ev_list, *ev_count;     // the same as a list of channels, ascending (k_ev_compact), and its length
     TriResult *tri;              // [nchp]
     // demod (burst OQPSK: uniform-slot rings [ng][len][64]; burst MSK: per-channel rings [nchp][len])
     double *eb_e;                // |sig2| of the last win_ring (gated) samples: agc2's window, E's window; E2's entries are its squares

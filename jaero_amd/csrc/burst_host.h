@@ -130,7 +130,7 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
     DA(p.mav1, (size_t)ng * g.mav1_len * 64);
     DA(p.fa, (size_t)ng * g.fa_len * 64);
     DA(p.bt, (size_t)ng * g.bt_len * 64);
-    DA(p.ev_list, nchp); DA(p.ev_count, 4);
+    DA(p.ev_list, nchp); DA(p.ev_count, 4); DA(p.ev_mask, ng);
     DA(p.tri, nchp);
     DA(p.eb_e, (size_t)nchp * g.win_ring);
     DA(p.firsave, (size_t)nchp * 2 * g.fir_n);
@@ -283,7 +283,6 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
     {
         const int n = (nsamples - pos) < g.maxseg ? (nsamples - pos) : g.maxseg;
         const long long n0 = c->nsamples_total;
-        HIPCHK(hipMemsetAsync(p.ev_count, 0, sizeof(int), st));
         int pi = prof_begin(c, 3, st);
         hipLaunchKernelGGL(k_hilbert_fft, dim3(g.nchp / 8, (int)(((n0 + n - 1) >> 11) - (n0 >> 11) + 1)), dim3(PF_THREADS), 4 * 2 * PRE_L * (int)sizeof(double), st, g, p, n, n0);
         LAUNCHCHK("k_hilbert_fft");
@@ -296,6 +295,8 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
         }
         else hipLaunchKernelGGL(k_burst_front<false>, dim3(g.ngroups), dim3(64), 0, st, g, p, n, n0);
         LAUNCHCHK("k_burst_front");
+        hipLaunchKernelGGL(k_ev_compact, dim3(1), dim3(1024), 0, st, (const unsigned long long *)p.ev_mask, g.ngroups, p.ev_list, p.ev_count);
+        LAUNCHCHK("k_ev_compact");
         prof_end(c, pi, st);
         pi = prof_begin(c, 1, st);
         if (g.kind == JAERO_KIND_BURST_OQPSK) hipLaunchKernelGGL(k_trident<true>, dim3(c->tri_grid), dim3(TRI_THREADS), c->tri_lds, st, g, p, n0);

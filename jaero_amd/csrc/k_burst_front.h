@@ -284,11 +284,44 @@ __global__ __launch_bounds__(64) void k_burst_front(const BGeom g, const BPtrs p
     BLDI(BI_CNTDOWN) = cntdown; BLDI(BI_MAXPOSCD) = maxposcd; BLDI(BI_TRI_PTR) = tri_ptr; BLDI(BI_EV_POS) = ev_pos; BLDI(BI_EV_CNT) = ev_cnt;
     (void)flags;
     if (HOLD) BLDI(BI_BT_HOLD) = hold;
-    if (ev_pos >= 0 && ch < g.nch)
+    // which channels of this group filled their trident buffer in this segment: k_ev_compact turns the masks into the event list IN CHANNEL ORDER
+    // (an atomic append listed them in arrival order, and k_trident's window reads -- a 64-byte sector per 8-byte sample, shared by eight
+    // neighbouring channels -- found nothing of their neighbours' in L2)
+    const unsigned long long em = __ballot(ev_pos >= 0 && ch < g.nch);
+    if (lane == 0) p.ev_mask[grp] = em;
+}
+
+// the event masks of a segment -> the list of channels with a trident event, ascending, and their number.  One workgroup: a thread takes a run
+// of consecutive groups, an LDS scan gives its place in the list.
+__global__ __launch_bounds__(1024) void k_ev_compact(const unsigned long long *__restrict__ mask, int ngroups, int *__restrict__ ev_list, int *__restrict__ ev_count)
+{
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (ngroups + 1023) / 1024;
+    const int g0 = t * per, g1 = (g0 + per < ngroups) ? g0 + per : ngroups;
+    int cnt = 0;
+    for (int gq = g0; gq < g1; gq++) cnt += __popcll(mask[gq]);
+    part[t] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1)
     {
-        const int k = atomicAdd(p.ev_count, 1);
-        p.ev_list[k] = ch;
+        const int v = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
     }
+    int base = part[t] - cnt;
+    for (int gq = g0; gq < g1; gq++)
+    {
+        unsigned long long m = mask[gq];
+        while (m)
+        {
+            const int ln = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            ev_list[base++] = gq * 64 + ln;
+        }
+    }
+    if (t == 1023) *ev_count = part[1023];
 }
 
 // ------------------------------------------------------------------------------------------------ trident check
@@ -351,7 +384,12 @@ __global__ __launch_bounds__(TRI_THREADS, 2) void k_trident(const BGeom g, const
     const double hzperbin = g.Fs / ((double)TRI_N);
     const int b = jd_qround((0.25 * g.fb) / hzperbin), b4 = b >> 2;       // OQPSK: 1792, 448
     const int psb = jd_qround((0.5 * g.fb) / hzperbin);                   // MSK
-    for (int li = blockIdx.x; li < nev; li += gridDim.x)
+    // The list is in channel order and a window read fetches a sector that eight neighbouring channels share: workgroups that run at the same
+    // time on the same XCD (one L2 each; workgroup b runs on XCD b mod 8) take NEIGHBOURING events -- XCD x the x-th eighth of the list.
+    const int nx = gridDim.x < 8 ? 1 : 8;
+    const int xcd = blockIdx.x % nx, wx = blockIdx.x / nx, nwx = (gridDim.x + nx - 1 - xcd) / nx; // this workgroup's rank among its XCD's, their number
+    const int e_lo = (int)(((long long)nev * xcd) / nx), e_hi = (int)(((long long)nev * (xcd + 1)) / nx);
+    for (int li = e_lo + wx; li < e_hi; li += nwx)
     {
         const int ch = p.ev_list[li];
         const int grp = ch >> 6, lane = ch & 63;
