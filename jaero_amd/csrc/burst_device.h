@@ -94,7 +94,7 @@ struct BPtrs
 {
     double *S; int *I;
     int16_t *pcmhist;            // [hist_len][nchp] frame-major PCM history ring
-    double *hre, *him;           // [ng][maxseg][64] analytic signal of the current segment
+    double *him;                 // [ng][maxseg][64] imaginary part of the analytic signal of the current segment (the real part is a delayed copy of the PCM: read from pcmhist)
     double *agc_ring;            // [ng][agc_len][64]
     double *cvre, *cvim;         // [ng][cv_len][64]  AGC'd analytic samples
     double *ma1re, *ma1im;       // [ng][ma1_len][64]

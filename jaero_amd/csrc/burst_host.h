@@ -123,7 +123,7 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
     DA(p.S, (size_t)BS_NFIELDS * nchp);
     DA(p.I, (size_t)BI_NFIELDS * nchp);
     DA(p.pcmhist, (size_t)g.hist_len * nchp);
-    DA(p.hre, (size_t)ng * g.maxseg * 64); DA(p.him, (size_t)ng * g.maxseg * 64);
+    DA(p.him, (size_t)ng * g.maxseg * 64);
     DA(p.agc_ring, (size_t)ng * g.agc_len * 64);
     DA(p.cvre, (size_t)ng * g.cv_len * 64); DA(p.cvim, (size_t)ng * g.cv_len * 64);
     DA(p.ma1re, (size_t)ng * g.ma1_len * 64); DA(p.ma1im, (size_t)ng * g.ma1_len * 64);

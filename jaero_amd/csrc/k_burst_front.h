@@ -23,7 +23,7 @@ __device__ __forceinline__ size_t hb_idx(int slot, int nchp, int ch) { return ((
 // real taps two real channels share one complex transform pair: z = x_a + j x_b,  g (*) z = (g (*) x_a) + j (g (*) x_b).
 //   grid (nchp / 8, 2048-sample blocks the segment touches), 1024 threads = 4 channel pairs x 256 threads, 128 KiB LDS; thread
 //   (c = tid & 3, T = tid >> 2) serves channels ch0 + 2c, ch0 + 2c + 1: the four c of a T read one whole 64-byte history cell row
-//   (8 channels x 4 samples) and write 64 contiguous bytes of hre / him.
+//   (8 channels x 4 samples) and write 64 contiguous bytes of him.
 //   Block: outputs m0 .. m0 + 2047 (m0 an absolute multiple of 2048) = window indices 2048 .. 4095 of x[m0 - L - 2048 .. m0 - L + 2047]
 //   convolved with g (2048 taps): im y[m] = sum_k g[k] x[m - L - k].  4096-point transforms: pf_fft4096 (k_pre8400.h).
 // 1.4 ms per 2048-sample segment of 65 536 channels against 8.9 ms for the direct form it replaced.  Not
@@ -70,11 +70,9 @@ __global__ __launch_bounds__(PF_THREADS) void k_hilbert_fft(const BGeom g, const
         const int i = i0 + T + 256 * (s - 8);
         if (i >= 0 && i < ns)
         {
-            // re y[m] = -x[m - L - 1024]; PCM -> double as the reference does (x / 32768.0); the taps carry no scaling, so scale the sums here
-            const int sr = (int)((n0 + i - g.hil_lat - 1024 + 4LL * H) % H);
-            const size_t o = hb_idx(sr, nchp, cha);
+            // re y[m] = -x[m - L - 1024] is a delayed copy of the input: k_burst_front reads it from the history ring itself (2 bytes instead of
+            // 8 written here and 8 read there).  The taps carry no scaling, so the sums are scaled here, as the reference scales its input.
             const size_t q = ((size_t)grp * g.maxseg + i) * 64 + lane;
-            *(double2 *)(p.hre + q) = make_double2(-(((double)hist[o]) / 32768.0), -(((double)hist[o + 4]) / 32768.0));
             *(double2 *)(p.him + q) = make_double2(d.r[s] / 32768.0, (-d.i[s]) / 32768.0);
         }
     }
@@ -135,8 +133,10 @@ __global__ __launch_bounds__(64) void k_burst_front(const BGeom g, const BPtrs p
     int hold = HOLD ? BLDI(BI_BT_HOLD) : 0;
     const bool trace = (g.flags & 8u) != 0; // JAERO_FLAG_TRACE
 
-    const double *__restrict__ hre = p.hre + (size_t)grp * g.maxseg * 64 + lane;
     const double *__restrict__ him = p.him + (size_t)grp * g.maxseg * 64 + lane;
+    const int16_t *__restrict__ hist = p.pcmhist;
+    // re y[m] = -x[m - L - 1024] (k_hilbert_fft): slot of sample n0's, advanced with the samples
+    const int s_re0 = (int)((n0 - g.hil_lat - 1024 + 4LL * g.hist_len) % g.hist_len);
     double *agc_ring = p.agc_ring + (size_t)grp * g.agc_len * 64 + lane;
     double *cvre = p.cvre + (size_t)grp * g.cv_len * 64 + lane;
     double *cvim = p.cvim + (size_t)grp * g.cv_len * 64 + lane;
@@ -161,7 +161,8 @@ __global__ __launch_bounds__(64) void k_burst_front(const BGeom g, const BPtrs p
         {
             const int ii = (i0 + k < n) ? i0 + k : n - 1;
             const int d = ii - i0; // == k except past the end (results unused there)
-            x_re[k] = hre[(size_t)ii * 64]; x_im[k] = him[(size_t)ii * 64];
+            // PCM -> double as the reference does (x / 32768.0)
+            x_re[k] = -(((double)hist[hb_idx(bwrap(s_re0 + ii, g.hist_len), nchp, ch)]) / 32768.0); x_im[k] = him[(size_t)ii * 64];
             o_agc[k] = agc_ring[(size_t)bwrap(s_agc + d, g.agc_len) * 64];
             o_m1r[k] = ma1r[(size_t)bwrap(s_ma1 + d, g.ma1_len) * 64];
             o_m1i[k] = ma1i[(size_t)bwrap(s_ma1 + d, g.ma1_len) * 64];
