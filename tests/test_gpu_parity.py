@@ -308,6 +308,35 @@ def test_per_channel_settings_and_live_set_settings(B, oracle_mod):
     bank.close()
 
 
+def test_oqpsk_live_set_settings_across_the_windows(B, oracle_mod):
+    """The AGC's 4 s buffer, the EbNo meter's 2 s E buffer and its E2 buffer are ONE ring here (the same |sig2| goes into all three);
+    OqpskDemodulator::setSettings re-creates the AGC but keeps the meter (oqpskdemodulator.cpp:197).  A call behind a full meter window, then
+    more than 4 s of signal: the AGC must see zeros leave its window for exactly 192 000 samples while the meter reads the true entries, and
+    both must read the ring again behind that -- soft bits, symbols and every status row (EbNo included) against the oracle."""
+    from jaero_amd import signalgen as G
+    from jaero_amd.demodulator import OqpskSettings
+
+    O = oracle_mod
+    nsamp, at = 320000, 110592
+    pcm = np.stack([G.oqpsk(nsamp, fc=7990.0, ebno_db=11, seed=15)[0], G.oqpsk(nsamp, fc=8010.0, ebno_db=13, seed=16)[0]])
+    bank = B.DemodulatorBank([OqpskSettings()] * 2, ebno=True, status_log=True, capture_symbols=True, max_write_samples=4096, softbit_capacity=nsamp)
+    feed(bank, pcm[:, :at], 4096)
+    new0 = OqpskSettings(freq_center=7995.0, lockingbw=9000.0)
+    bank.set_settings(new0, channel=0)
+    feed(bank, pcm[:, at:], 4096)
+    d0 = O.Demod(O.oqpsk_settings(), capture_symbols=True)
+    for s in range(0, at, 4096):
+        d0.write(pcm[0, s:s + 4096])
+    d0.set_settings(O.oqpsk_settings(freq_center=7995.0, lockingbw=9000.0))
+    for s in range(at, nsamp, 4096):
+        d0.write(pcm[0, s:s + 4096])
+    refs = [{"soft": d0.take_soft(), "status": d0.take_status(), "pending": d0.pending, "symbols": d0.take_symbols()},
+            O.run_demod(O.oqpsk_settings(), pcm[1], capture_symbols=True)]
+    for c in range(2):
+        compare(bank.read_softbits(c), bank.read_symbols(c), bank.read_status_log(c), refs[c])
+    bank.close()
+
+
 def test_single_channel_mirror_emits_like_reference(B, oracle_mod):
     """OqpskDemodulator mirror: writeData(bytes) -> processDemodulatedSoftBits in groups of 32, status signals."""
     O = oracle_mod
