@@ -143,8 +143,11 @@ void jaero_destroy(jaero_ctx *ctx);
  *     DelayThing::setLength leaves them; startstop, the oscillator phases and RxDataBits survive (burst MSK: cntr = 0, mse = 10, dcd = false,
  *     new matched filters).  A Plottables row is appended to the channel's event log.
  *   - JAERO_EINVAL: another kind (another class in the reference), or fb / Fs / FFT power for one channel of several;
- *     JAERO_ENOTSUP: one channel of an 8400 bps bank; another fb / Fs for a burst bank (create a new bank; the Qt adaptors of
- *     integration/qt do). */
+ *     Burst MSK with its other bit rate (600 <-> 1200 bps; whole bank): as for the continuous kinds a sibling bank takes the old one's place and
+ *     receives what the reference keeps -- the DelayThings' first min(old, new) entries in storage order, startstop, oscillator phases, msema,
+ *     unread outputs.
+ *     JAERO_ENOTSUP: one channel of an 8400 bps bank; another Fs for a burst bank, another fb for burst OQPSK (create a new bank; the Qt
+ *     adaptors of integration/qt do). */
 int jaero_set_settings(jaero_ctx *ctx, int channel, const jaero_settings *s);
 int jaero_set_flags(jaero_ctx *ctx, int channel, int afc, int sql, int cpu_reduce);
 int jaero_set_dcd(jaero_ctx *ctx, int channel, int dcd);

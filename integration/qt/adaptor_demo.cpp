@@ -186,7 +186,7 @@ int main(int argc, char **argv)
             d->DCDstatSlot(false);
             d->setSettings(s);
             QObject::connect(ap, &AeroL::DataCarrierDetect, d, &BurstMskDemodulator::DCDstatSlot); // only the MSK burst class has the input
-            g_set_again = [d, s]() mutable { s.lockingbw = getd("set_lockingbw", s.lockingbw); s.freq_center = getd("set_freq_center", s.freq_center); d->setSettings(s); };
+            g_set_again = [d, s]() mutable { s.fb = getd("set_fb", s.fb); s.lockingbw = getd("set_lockingbw", s.lockingbw); s.freq_center = getd("set_freq_center", s.freq_center); d->setSettings(s); };
             run_burst<BurstMskDemodulator>(*d, *ap, pcm, chunk);
         }
         else
@@ -199,7 +199,7 @@ int main(int argc, char **argv)
             d.DCDstatSlot(false);
             d.setSettings(s);
             QObject::connect(ap, &AeroL::DataCarrierDetect, &d, &HipBurstMskDemodulator::DCDstatSlot);
-            g_set_again = [&d, s]() mutable { s.lockingbw = getd("set_lockingbw", s.lockingbw); s.freq_center = getd("set_freq_center", s.freq_center); d.setSettings(s); };
+            g_set_again = [&d, s]() mutable { s.fb = getd("set_fb", s.fb); s.lockingbw = getd("set_lockingbw", s.lockingbw); s.freq_center = getd("set_freq_center", s.freq_center); d.setSettings(s); };
             run_burst(d, *ap, pcm, chunk);
         }
     }

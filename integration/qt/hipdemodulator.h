@@ -254,10 +254,12 @@ protected:
     {
         // Same bit rate and sample rate: setSettings on the live object (jaero_set_settings on a burst bank, k_burst_settings.h) -- AGCs, EbNo
         // meter, Hilbert filter, peak detector and trident fill restart, the delay lines keep their contents with the pointers at zero,
-        // RxDataBits (`pending`) survives, as in the reference.  Another rate is another bank: the one-channel bank is replaced.
-        if (ctx && js.fb == fb && js.Fs == Fs && jaero_set_settings(ctx, 0, &js) == JAERO_OK)
+        // RxDataBits (`pending`) survives, as in the reference.  Burst MSK also changes its bit rate this way (a sibling bank with the survivors
+        // behind the same handle); whatever the library refuses is answered by replacing the one-channel bank.
+        if (ctx && js.Fs == Fs && jaero_set_settings(ctx, 0, &js) == JAERO_OK)
         {
             if (kind == JAERO_KIND_BURST_MSK) dcd = false; // burstmskdemodulator.cpp:322
+            if (js.fb != fb) { fb = js.fb; emit BitRateChanged(fb, true); } // burst MSK 600 <-> 1200: the bank behind the handle was re-created with the survivors
             lockingbw = js.lockingbw;
             freq_center = js.freq_center;
             drainEvents(); // the Plottables emission at the end of setSettings

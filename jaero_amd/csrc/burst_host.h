@@ -332,6 +332,59 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
     return 0;
 }
 
+// jaero_set_settings with another bit rate on a burst MSK bank (BurstMskDemodulator::setSettings with another fb on the live object,
+// burstmskdemodulator.cpp:150-325): a sibling bank for the new rate takes the old one's place behind the handle; the scalar state comes
+// across as whole columns, k_burst_carry moves the DelayThings' contents in storage order and applies what setSettings re-creates, msema and
+// the outputs not read yet are copied.  Control plane: allocates and synchronises.
+static void prof_collect(jaero_ctx *c);
+static int burst_rebank(jaero_ctx *c, const jaero_settings *s)
+{
+    if (c->poisoned) return fail(JAERO_EHIP, "jaero_set_settings: a launch inside an earlier jaero_write failed; this bank's state cannot be carried over");
+    const BGeom og = c->bg;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->last_stream));
+    jaero_ctx *n = nullptr;
+    int rc = jaero_create(c->device, og.nch, s, 0, c->flags, c->max_write, c->soft_cap_req, &n);
+    if (rc) return rc;
+    const BGeom &ng = n->bg;
+    const int nchp = og.nchp;
+    auto fin = [&](int code) { jaero_destroy(n); return code; };
+#define BCP(dst, src, bytes) do { if (hipMemcpy((dst), (src), (bytes), hipMemcpyDeviceToDevice) != hipSuccess) return fin(fail(JAERO_EHIP, "jaero_set_settings: carry-over copy failed")); } while (0)
+#define BCP2(dst, dpitch, src, spitch, width, rows) do { if (hipMemcpy2D((dst), (dpitch), (src), (spitch), (width), (rows), hipMemcpyDeviceToDevice) != hipSuccess) return fin(fail(JAERO_EHIP, "jaero_set_settings: carry-over copy failed")); } while (0)
+    {
+        // outputs not read yet: soft bits (RxDataBits' pending tail included), captured symbols, event rows
+        std::vector<int> cnt(2 * (size_t)nchp);
+        static_assert(BI_SYM_CNT == BI_SOFT_CNT + 1, "output counters are consecutive columns");
+        if (hipMemcpy(cnt.data(), c->bp.I + (size_t)BI_SOFT_CNT * nchp, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost) != hipSuccess) return fin(fail(JAERO_EHIP, "jaero_set_settings: reading the output counters failed"));
+        int mx[2] = {0, 0};
+        for (int k = 0; k < 2; k++) for (int ch = 0; ch < og.nch; ch++) mx[k] = cnt[(size_t)k * nchp + ch] > mx[k] ? cnt[(size_t)k * nchp + ch] : mx[k];
+        if (mx[0] > ng.soft_cap || mx[1] > ng.sym_cap)
+            return fin(fail(JAERO_EINVAL, "jaero_set_settings: unread outputs (%d soft bits, %d symbols) exceed the new bank's buffers; read them first", mx[0], mx[1]));
+        if (mx[0]) BCP2(n->bp.soft, sizeof(int16_t) * ng.soft_cap, c->bp.soft, sizeof(int16_t) * og.soft_cap, sizeof(int16_t) * mx[0], (size_t)nchp);
+        if (mx[1]) BCP2(n->bp.sym, sizeof(double) * 3 * ng.sym_cap, c->bp.sym, sizeof(double) * 3 * og.sym_cap, sizeof(double) * 3 * mx[1], (size_t)nchp);
+        BCP(n->bp.evlog, c->bp.evlog, sizeof(double) * (size_t)nchp * og.ev_cap * 3);
+    }
+    BCP(n->bp.S, c->bp.S, sizeof(double) * (size_t)BS_NFIELDS * nchp);
+    BCP(n->bp.I, c->bp.I, sizeof(int) * (size_t)BI_NFIELDS * nchp);
+    BCP(n->bp.msema, c->bp.msema, sizeof(double) * (size_t)nchp * og.msema_len); // msema is made once, in the constructor
+    BSetVals v;
+    v.freq_center = s->freq_center; v.lockingbw = s->lockingbw; v.signalthreshold = s->signalthreshold;
+    hipLaunchKernelGGL(k_burst_carry, dim3(nchp / 64), dim3(64), 0, 0, og, c->bp, ng, n->bp, v, (long long)c->nsamples_total);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(0) != hipSuccess) return fin(fail(JAERO_EHIP, "jaero_set_settings: carry-over failed"));
+    n->nsamples_total = c->nsamples_total;
+    n->m.flags = c->m.flags;
+    for (int ch = 0; ch < nchp; ch++) n->m.flags[ch] &= ~JF_DCD;
+    n->bt_hold_left = ng.bt_lag;
+    if (c->prof) prof_collect(c);
+    n->prof = c->prof;
+    for (size_t k = 0; k < sizeof(c->slots) / sizeof(c->slots[0]); k++) n->slots[k] = c->slots[k];
+#undef BCP
+#undef BCP2
+    std::swap(*c, *n);
+    jaero_destroy(n); // the old bank
+    return 0;
+}
+
 // jaero_set_settings on live channels [lo, hi) of a burst bank: what BurstOqpskDemodulator::setSettings / BurstMskDemodulator::setSettings do to an
 // object that has been running (k_burst_settings.h), on the bank's stream like every other call.  A bank's bit rate and sample rate are fixed
 // (ring lengths, kernel instantiations): another fb / Fs is another bank.
@@ -340,7 +393,13 @@ static int burst_set_settings(jaero_ctx *c, int channel, const jaero_settings *s
     const BGeom &g = c->bg;
     if (s->kind != g.kind) return fail(JAERO_EINVAL, "jaero_set_settings: the kind of a bank is fixed (another demodulator class in the reference); create a new bank");
     if (s->fb != g.fb || s->Fs != g.Fs)
-        return fail(JAERO_ENOTSUP, "jaero_set_settings on a burst bank: fb %g / Fs %g are fixed (this bank: %g / %g); create a new bank", s->fb, s->Fs, g.fb, g.Fs);
+    {
+        if (g.kind != JAERO_KIND_BURST_MSK || s->Fs != g.Fs)
+            return fail(JAERO_ENOTSUP, "jaero_set_settings on a burst bank: only burst MSK changes its bit rate (600 / 1200 bps at %g Hz); asked for fb %g / Fs %g", g.Fs, s->fb, s->Fs);
+        if (channel >= 0 && g.nch > 1)
+            return fail(JAERO_EINVAL, "jaero_set_settings: fb is shared by the channels of a bank; change it for the whole bank (channel = -1)");
+        return burst_rebank(c, s);
+    }
     HIPCHK(hipSetDevice(c->device));
     const int lo = channel < 0 ? 0 : channel, hi = channel < 0 ? g.nch : channel + 1;
     BSetVals v;

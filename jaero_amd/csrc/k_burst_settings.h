@@ -56,6 +56,49 @@ __device__ __forceinline__ void bs_rotate(T *col, size_t stride, int base, int l
 }
 __device__ __forceinline__ int bs_slot(long long t, int len) { return (int)((t + 16LL * len) % len); } // t >= -16 len
 
+// the scalar state a burst setSettings leaves behind (see the table at the top), for channel ch of bank (g, p); appends the Plottables row
+__device__ __forceinline__ void bs_apply_scalars(const BGeom &g, const BPtrs &p, int ch, const BSetVals &v, long long T0)
+{
+    const int nchp = g.nchp;
+    const bool oq = g.kind == JAERO_KIND_BURST_OQPSK_D;
+    BLDF(BS_RESET_AT) = (double)T0;
+    // ---- front end ----
+    BLDF(BS_AGC_SUM) = 0.0; BLDF(BS_MA1_RE) = 0.0; BLDF(BS_MA1_IM) = 0.0; BLDF(BS_MAV1_SUM) = 0.0; BLDF(BS_LASTDY) = 0.0;
+    BLDI(BI_CNTDOWN) = 2 * g.PL; BLDI(BI_MAXPOSCD) = -1; BLDI(BI_TRI_PTR) = 0;
+    BLDI(BI_BT_HOLD) = g.bt_lag;
+    // ---- demodulator ----
+    double fc = v.freq_center;
+    if (fc > ((g.Fs / 2.0) - (v.lockingbw / 2.0))) fc = ((g.Fs / 2.0) - (v.lockingbw / 2.0));
+    double m2_freq = BLDF(BS_M2_FREQ), m2_step = BLDF(BS_M2_STEP);
+    jd_wt_setfreq(m2_freq, m2_step, fc, g.Fs); // WaveTable::SetFreq: negative -> 0, phase kept
+    BLDF(BS_M2_FREQ) = m2_freq; BLDF(BS_M2_STEP) = m2_step;
+    BLDF(BS_THRESH) = v.signalthreshold; BLDF(BS_LOCKINGBW) = v.lockingbw;
+    BLDF(BS_AGC2_SUM) = 0.0; BLDF(BS_EB_ESUM) = 0.0; BLDF(BS_EB_E2SUM) = 0.0; BLDF(BS_EB_EBNO) = 0.0;
+    BLDF(BS_SAV_RE) = 1.0; BLDF(BS_SAV_IM) = 0.0; BLDF(BS_ROT_RE) = 1.0; BLDF(BS_ROT_IM) = 0.0;
+    if (oq)
+    {
+        BLDF(BS_A1_1) = 0.0; BLDF(BS_A1_2) = 0.0; BLDF(BS_A1_3) = 0.0; BLDF(BS_A1_4) = 0.0; BLDF(BS_A1_5) = 0.0;
+        BLDI(BI_INSERTPRE) = 0;
+    }
+    else
+    {
+        BLDF(BS_MC_FREQ) = m2_freq; // mixer_center.SetFreq(freq_center) (the same clamp)
+        BLDF(BS_MSE) = 10.0;
+        BLDI(BI_CNTR) = 0;
+        BLDF(BS_RES_X1) = 0.0; BLDF(BS_RES_X2) = 0.0; BLDF(BS_RES_Y1) = 0.0; BLDF(BS_RES_Y2) = 0.0;
+        BLDI(BI_FLAGS) = BLDI(BI_FLAGS) & ~JF_DCD;
+        BLDI(BI_GCNT) = 0;
+        // st_osc.SetFreq(fb / 2), st_osc_half.SetFreq(fb / 2): the same values unless the bit rate changed (k_burst_carry); phases kept
+        double st_freq = BLDF(BS_ST_FREQ), st_step = BLDF(BS_ST_STEP);
+        jd_wt_setfreq(st_freq, st_step, g.stref_freq, g.Fs);
+        BLDF(BS_ST_FREQ) = st_freq; BLDF(BS_ST_STEP) = st_step;
+    }
+    // emit Plottables(mixer2.GetFreqHz(), ...)
+    int ev_cnt = BLDI(BI_EV_CNT), overflow = BLDI(BI_OVERFLOW);
+    bd_event(g, p, ch, ev_cnt, overflow, T0, BEV_FREQ, m2_freq);
+    BLDI(BI_EV_CNT) = ev_cnt; BLDI(BI_OVERFLOW) = overflow;
+}
+
 // grid (ceil(nsel / 64), NY), 64 threads: lane = channel ch_lo + 64 blockIdx.x + lane; row 0 of the grid rewrites the scalar state and rotates the
 // kept lines, the other rows zero the re-created ones (every ring slot of the channel's column).
 __global__ __launch_bounds__(64) void k_burst_apply_settings(const BGeom g, const BPtrs p, int ch_lo, int ch_hi, const BSetVals v, long long T0)
@@ -114,42 +157,92 @@ __global__ __launch_bounds__(64) void k_burst_apply_settings(const BGeom g, cons
         double *bt = p.bt + (size_t)grp * g.bt_len * 64 + lane;
         bs_rotate(bt, 64, bs_slot(T0, g.bt_len), g.bt_len, g.bt_len, (int)(age % g.bt_len));
     }
-    BLDF(BS_RESET_AT) = (double)T0;
-    // ---- front end ----
-    BLDF(BS_AGC_SUM) = 0.0; BLDF(BS_MA1_RE) = 0.0; BLDF(BS_MA1_IM) = 0.0; BLDF(BS_MAV1_SUM) = 0.0; BLDF(BS_LASTDY) = 0.0;
-    BLDI(BI_CNTDOWN) = 2 * g.PL; BLDI(BI_MAXPOSCD) = -1; BLDI(BI_TRI_PTR) = 0;
-    BLDI(BI_BT_HOLD) = g.bt_lag;
-    // ---- demodulator ----
-    double fc = v.freq_center;
-    if (fc > ((g.Fs / 2.0) - (v.lockingbw / 2.0))) fc = ((g.Fs / 2.0) - (v.lockingbw / 2.0));
-    double m2_freq = BLDF(BS_M2_FREQ), m2_step = BLDF(BS_M2_STEP);
-    jd_wt_setfreq(m2_freq, m2_step, fc, g.Fs); // WaveTable::SetFreq: negative -> 0, phase kept
-    BLDF(BS_M2_FREQ) = m2_freq; BLDF(BS_M2_STEP) = m2_step;
-    BLDF(BS_THRESH) = v.signalthreshold; BLDF(BS_LOCKINGBW) = v.lockingbw;
-    BLDF(BS_AGC2_SUM) = 0.0; BLDF(BS_EB_ESUM) = 0.0; BLDF(BS_EB_E2SUM) = 0.0; BLDF(BS_EB_EBNO) = 0.0;
-    BLDF(BS_SAV_RE) = 1.0; BLDF(BS_SAV_IM) = 0.0; BLDF(BS_ROT_RE) = 1.0; BLDF(BS_ROT_IM) = 0.0;
-    if (oq)
+    if (!oq)
     {
-        BLDF(BS_A1_1) = 0.0; BLDF(BS_A1_2) = 0.0; BLDF(BS_A1_3) = 0.0; BLDF(BS_A1_4) = 0.0; BLDF(BS_A1_5) = 0.0;
-        BLDI(BI_INSERTPRE) = 0;
-    }
-    else
-    {
-        BLDF(BS_MC_FREQ) = m2_freq; // mixer_center.SetFreq(freq_center) (the same clamp)
-        BLDF(BS_MSE) = 10.0;
-        BLDI(BI_CNTR) = 0;
-        BLDF(BS_RES_X1) = 0.0; BLDF(BS_RES_X2) = 0.0; BLDF(BS_RES_Y1) = 0.0; BLDF(BS_RES_Y2) = 0.0;
-        BLDI(BI_FLAGS) = BLDI(BI_FLAGS) & ~JF_DCD;
         // delayedsmpl (DelayThing<cpx>, SamplesPerSymbol + 1 entries): the last dly_len entries in front of the write position, rotated by where
         // the reference's pointer stood
         double2 *dly = p.dly + (size_t)ch * g.dly_ring;
         const int pos = BLDI(BI_DLY_POS);
         int base = pos - g.dly_len; if (base < 0) base += g.dly_ring;
         bs_rotate(dly, 1, base, g.dly_ring, g.dly_len, BLDI(BI_GCNT));
-        BLDI(BI_GCNT) = 0;
     }
-    // emit Plottables(mixer2.GetFreqHz(), ...)
-    int ev_cnt = BLDI(BI_EV_CNT), overflow = BLDI(BI_OVERFLOW);
-    bd_event(g, p, ch, ev_cnt, overflow, T0, BEV_FREQ, m2_freq);
-    BLDI(BI_EV_CNT) = ev_cnt; BLDI(BI_OVERFLOW) = overflow;
+    bs_apply_scalars(g, p, ch, v, T0);
+}
+
+// setSettings with ANOTHER bit rate on a live burst MSK bank (the same BurstMskDemodulator object serves 600 and 1200 bps): every length
+// changes, so a sibling bank is created for the new rate (burst_host.h) and this kernel moves over what the reference keeps.  Its scalar
+// state came across as whole columns; here the DelayThings: setLength(new) resizes the QVector -- the first min(old, new) entries stay in
+// STORAGE order, new ones are zero -- and puts the pointer at zero.  storage_old[j] = A_old[(j - P) mod sz_old] (A = the old line's last sz_old
+// inputs in time order, P where its pointer stood); the new bank's ring gets storage_new[j] at the place a read at its own fixed lag will
+// find it, j = 1 .. sz_new - 1 (see the top of this file).  Everything else the reference re-creates is the new bank's zeros.
+__global__ __launch_bounds__(64) void k_burst_carry(const BGeom og, const BPtrs op, const BGeom g, const BPtrs p, const BSetVals v, long long T0)
+{
+    const int ch = blockIdx.x * 64 + threadIdx.x, nchp = g.nchp;
+    if (ch >= g.nchp) return;
+    const int grp = ch >> 6, lane = ch & 63;
+    const long long age = T0 - (long long)op.S[(size_t)BS_RESET_AT * nchp + ch];
+    {
+        const double *ocre = op.cvre + (size_t)grp * og.cv_len * 64 + lane, *ocim = op.cvim + (size_t)grp * og.cv_len * 64 + lane;
+        double *cvre = p.cvre + (size_t)grp * g.cv_len * 64 + lane, *cvim = p.cvim + (size_t)grp * g.cv_len * 64 + lane;
+        // d1 (complex)
+        const int so1 = og.D1 + 1, sn1 = g.D1 + 1, P1 = (int)(age % so1);
+        for (int j = 1; j < sn1; j++)
+        {
+            double re = 0.0, im = 0.0;
+            if (j < so1)
+            {
+                int k = j - P1; if (k < 0) k += so1;
+                const int sl = bs_slot(T0 - so1 + k, og.cv_len);
+                re = ocre[(size_t)sl * 64]; im = ocim[(size_t)sl * 64];
+            }
+            const int dl = bs_slot(T0 - sn1 + j, g.cv_len);
+            cvre[(size_t)dl * 64] = re; cvim[(size_t)dl * 64] = im;
+        }
+        // d2 (real parts of d1's outputs): one d1 lag further back; its newest entry lands on d1's oldest, which d1 never reads again
+        const int so2 = og.D2 + 1, sn2 = g.D2 + 1, P2 = (int)(age % so2);
+        for (int j = 1; j < sn2; j++)
+        {
+            double re = 0.0;
+            if (j < so2)
+            {
+                int k = j - P2; if (k < 0) k += so2;
+                re = ocre[(size_t)bs_slot(T0 - og.D1 - so2 + k, og.cv_len) * 64];
+            }
+            cvre[(size_t)bs_slot(T0 - g.D1 - sn2 + j, g.cv_len) * 64] = re;
+        }
+        // the peak detector's d1 / d3
+        const double *obt = op.bt + (size_t)grp * og.bt_len * 64 + lane;
+        double *bt = p.bt + (size_t)grp * g.bt_len * 64 + lane;
+        const int sob = og.bt_len, snb = g.bt_len, Pb = (int)(age % sob);
+        for (int j = 1; j < snb; j++)
+        {
+            double x = 0.0;
+            if (j < sob)
+            {
+                int k = j - Pb; if (k < 0) k += sob;
+                x = obt[(size_t)bs_slot(T0 - sob + k, sob) * 64];
+            }
+            bt[(size_t)bs_slot(T0 - snb + j, snb) * 64] = x;
+        }
+    }
+    {
+        // delayedsmpl: the new bank's gated rings all start at position 0
+        const double2 *odly = op.dly + (size_t)ch * og.dly_ring;
+        double2 *dly = p.dly + (size_t)ch * g.dly_ring;
+        const int so = og.dly_len, sn = g.dly_len, Pd = op.I[(size_t)BI_GCNT * nchp + ch], opos = op.I[(size_t)BI_DLY_POS * nchp + ch];
+        for (int j = 1; j < sn; j++)
+        {
+            double2 x = make_double2(0.0, 0.0);
+            if (j < so)
+            {
+                int k = j - Pd; if (k < 0) k += so;
+                int sl = opos - so + k; if (sl < 0) sl += og.dly_ring;
+                x = odly[sl];
+            }
+            int dl = j - sn; if (dl < 0) dl += g.dly_ring;
+            dly[dl] = x;
+        }
+        BLDI(BI_FIR_POS) = 0; BLDI(BI_AGC2_POS) = 0; BLDI(BI_EB_POS) = 0; BLDI(BI_DLY_POS) = 0; BLDI(BI_D8_POS) = 0; BLDI(BI_A1_POS) = 0;
+    }
+    bs_apply_scalars(g, p, ch, v, T0);
 }

@@ -335,14 +335,54 @@ def test_burst_msk_set_settings_live(B, oracle_mod, fb):
     bank.close()
 
 
+@pytest.mark.parametrize("fb0,fb1", [(1200, 600), (600, 1200)])
+def test_burst_msk_live_rate_change(B, oracle_mod, fb0, fb1):
+    """BurstMskDemodulator::setSettings with ANOTHER bit rate on the live object (the same class serves 600 and 1200 bps): every length changes;
+    d1 / d2 / the peak detector's lines / delayedsmpl keep their first min(old, new) entries in storage order, startstop and the oscillator
+    phases survive, the rest restarts.  jaero_set_settings re-creates the bank behind the handle with exactly those survivors (burst_rebank,
+    k_burst_carry).  Four channels with staggered bursts, so the call falls into an idle stretch, between peak and trident check, and into the
+    delayed burst; a burst at the new rate follows.  The oracle's live rate change is the unmodified reference's (checked in this file's CPU
+    twin, tests/test_oracle_burst.py)."""
+    nch, n = 4, 48000 * 9
+    k0 = 1200 // fb0
+    at = 70000 * k0 + 13
+    rng = np.random.default_rng(fb0 + 7)
+    pcm = np.zeros((nch, n), np.int16)
+    for c in range(nch):
+        first = at - k0 * [45000, 9000, 22000, 2000][c]
+        a, _ = G.burst_msk(n, burst_starts=[first], fb=float(fb0), fc=1900.0 + 20 * c, ebno_db=18.0, seed=G.SEED_BASE + 970 + c)
+        b, _ = G.burst_msk(n, burst_starts=[at + 150000 + 3000 * c], fb=float(fb1), fc=1880.0 + 20 * c, ebno_db=18.0, seed=G.SEED_BASE + 980 + c)
+        cut = at + 60000
+        pcm[c, :cut] = a[:cut]
+        pcm[c, cut:] = b[cut:]
+    opts0 = dict(fb=fb0, lockingbw=1.5 * fb0)
+    new = B.BurstMskSettings(freq_center=1000.0, fb=float(fb1), lockingbw=1.5 * fb1)
+    onew = oracle_mod.burst_msk_settings(freq_center=1000.0, fb=float(fb1), lockingbw=1.5 * fb1)
+    bank = bank_for(B, "burstmsk", opts0, nch, capture_symbols=True, trace=True, max_write_samples=8192, softbit_capacity=60000)
+    feed_with_sets(bank, pcm, rng, 100, 8192, [(at, -1, new)])
+    nacc = 0
+    for c in range(nch):
+        ref = oracle_with_sets(oracle_mod, oracle_settings(oracle_mod, "burstmsk", opts0), pcm[c], [(at, onew)])
+        check_soft(bank.read_softbits(c), ref["soft"], f"channel {c}")
+        check_events(bank.read_events(c), ref["events"])
+        check_symbols_behind_sets(bank.read_symbols(c), ref["symbols"], c, 1, 48000 / max(fb0, fb1))
+        nacc += int((ref["soft"] == -1).sum())
+    assert nacc >= nch  # every channel decodes its burst at the new rate
+    bank.close()
+
+
 def test_burst_set_settings_refusals(B):
-    """A burst bank's bit rate and sample rate are fixed: another fb is another bank (JAERO_ENOTSUP), another kind another class (JAERO_EINVAL)."""
+    """Another kind is another class (JAERO_EINVAL); burst OQPSK exists at one rate; a bank's bit rate is shared by its channels."""
     from jaero_amd import capi
 
     bank = bank_for(B, "burstmsk", dict(fb=1200, lockingbw=1800.0), 2, max_write_samples=4096)
     with pytest.raises(capi.JaeroError):
-        bank.set_settings(B.BurstMskSettings(fb=600.0, lockingbw=900.0))
-    with pytest.raises(capi.JaeroError):
         bank.set_settings(B.BurstOqpskSettings())
+    with pytest.raises(capi.JaeroError):
+        bank.set_settings(B.BurstMskSettings(fb=600.0, lockingbw=900.0), channel=1)
     bank.set_settings(B.BurstMskSettings(fb=1200.0, lockingbw=1500.0), channel=1)
     bank.close()
+    b2 = bank_for(B, "burstoqpsk", {}, 1, max_write_samples=4096)
+    with pytest.raises(capi.JaeroError):
+        b2.set_settings(B.BurstOqpskSettings(fb=8400.0))
+    b2.close()

@@ -183,3 +183,21 @@ def test_burst_msk_set_settings_vs_ref(R, fb, set_at, set_at2):
     assert np.array_equal(r["soft"], o["soft"])
     assert np.array_equal(r["events"], as_write_stamps(o["events"], 1000))
     assert (o["events"][:, 0] == -(-set_at // 1000) * 1000).any()
+
+
+@pytest.mark.parametrize("fb0,fb1,set_at", [(1200, 600, 60000), (600, 1200, 100000), (1200, 600, 45000), (600, 1200, 61000)])
+def test_burst_msk_live_rate_change_vs_ref(R, fb0, fb1, set_at):
+    """The same BurstMskDemodulator object serves 600 and 1200 bps: setSettings with the other rate on the live object resizes every DelayThing
+    (the first min(old, new) entries stay, in storage order) and restarts the rest.  A burst at the old rate in front of the call (the call
+    falls behind it, into it, or in front of its trident check), one at the new rate behind it: reference against restatement, bit-exact."""
+    n = 48000 * 8
+    a, _ = G.burst_msk(n, burst_starts=[30000], fb=float(fb0), fc=1900.0, ebno_db=18.0, seed=5)
+    b, _ = G.burst_msk(n, burst_starts=[200000], fb=float(fb1), fc=1900.0, ebno_db=18.0, seed=6)
+    pcm = a.copy()
+    pcm[150000:] = b[150000:]
+    r = R.run_ref("burstmsk", pcm, fb=fb0, lockingbw=1.5 * fb0, chunk=1000, set_at=set_at, set_fb=fb1, set_lockingbw=1.5 * fb1)
+    new = R.burst_msk_settings(fb=float(fb1), lockingbw=1.5 * fb1)
+    o = R.run_burst(R.burst_msk_settings(fb=float(fb0), lockingbw=1.5 * fb0), pcm, chunk=1000, set_at=[set_at], set_settings=new)
+    assert np.array_equal(r["soft"], o["soft"])
+    assert np.array_equal(r["events"], as_write_stamps(o["events"], 1000))
+    assert (o["soft"] == -1).sum() >= 1 and (o["events"][:, 0] > 200000).any()  # the burst at the new rate is found

@@ -181,6 +181,24 @@ def test_hip_burst_adaptor_live_set_settings_msk():
 
 @pytest.mark.gpu
 @have_demo
+def test_hip_burst_adaptor_live_rate_change_msk():
+    """Burst 1200 -> burst 600 on the running demodulator (the same BurstMskDemodulator object serves both): the adaptor hands the call to
+    jaero_set_settings, which re-creates its bank with what the reference keeps; the groups AeroL receives for a 600 bps burst that follows
+    are the all-reference chain's."""
+    a, _ = G.burst_msk(48000 * 9, burst_starts=[30000], ndata=300, fb=1200.0, fc=1007.0, ebno_db=18.0, seed=G.SEED_BASE + 81)
+    b, _ = G.burst_msk(48000 * 9, burst_starts=[200000], ndata=300, fb=600.0, fc=1007.0, ebno_db=18.0, seed=G.SEED_BASE + 82)
+    pcm = a.copy()
+    pcm[150000:] = b[150000:]
+    kw = dict(fb=1200, dump=1, set_at=100000, set_fb=600, set_lockingbw=900)
+    ref = run_demo("ref", "burstmsk", pcm, **kw)
+    hip = run_demo("hip", "burstmsk", pcm, **kw)
+    groups = [ln for ln in ref.split("\n") if ln.startswith("G ")]
+    assert len(groups) >= 40 and sum(" -1" in ln for ln in groups) >= 2  # a burst at each rate
+    assert hip == ref
+
+
+@pytest.mark.gpu
+@have_demo
 def test_hip_msk_adaptor_follows_the_incoming_sample_rate():
     """Audio arriving through dataReceived at 24 kHz while the demodulator was set up for 48 kHz: MskDemodulator re-applies its settings
     with that rate (mskdemodulator.cpp:528-537), the adaptor replaces its bank; AeroL prints the same signal units."""
