@@ -441,8 +441,8 @@ class Vorbis:
     def decode_packet(self, pk):
         """One audio packet -> float array [channels, samples] (empty for the first packet)."""
         br = BitReader(pk)
-        if br.read(1) != 0:
-            return None  # not an audio packet
+        if len(pk) == 0 or br.read(1) != 0:
+            return None  # an empty packet / not an audio packet
         flag, mapno = self.modes[br.read(ilog(len(self.modes) - 1))]
         n = self.bs[flag]
         prev_flag = next_flag = 0
