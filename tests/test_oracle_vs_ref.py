@@ -92,3 +92,20 @@ def test_msk_live_rate_change(O, Fs0, fb0, Fs1, fb1):
     new = O.msk_settings(fb=float(fb1), lockingbw=1.5 * fb1, Fs=float(Fs1))
     _cmp(O.run_ref("msk", pcm, fb=fb0, lockingbw=1.5 * fb0, Fs=Fs0, chunk=3000, set_at=set_at, set_fb=fb1, set_Fs=Fs1, set_lockingbw=1.5 * fb1),
          O.run_demod(O.msk_settings(fb=float(fb0), lockingbw=1.5 * fb0, Fs=float(Fs0)), pcm, chunk=3000, set_at=set_at, set_settings=new))
+
+
+@pytest.mark.parametrize("afc,cpu,chunk,dcd_at,center", [(1, 0, 1000, -1, False), (0, 1, 4096, -1, False), (0, 0, 777, 200000, False), (1, 0, 4096, -1, True)])
+def test_oqpsk_on_the_sample_recording(O, afc, cpu, chunk, dcd_at, center):
+    """The reference's own 10.5 kbps recording (tests/golden/recording_oqpsk_10k5.npz: 12 s of samples/10.5k_sample.ogg) with the options the
+    synthetic cases use -- AFC, CPU reduction, odd write sizes, a DCD change, the user moving the centre frequency onto the carrier: reference
+    against restatement, every soft bit and status row."""
+    from conftest import load_golden
+
+    pcm = load_golden("recording_oqpsk_10k5")["pcm"]
+    kv = dict(center_at=150000, center_hz=5760) if center else {}
+    if dcd_at >= 0:
+        kv["dcd_at"] = dcd_at
+    r = O.run_ref("oqpsk", pcm, afc=afc, cpureduce=cpu, chunk=chunk, **kv)
+    o = O.run_demod(O.oqpsk_settings(), pcm, afc=bool(afc), cpu_reduce=bool(cpu), chunk=chunk, **kv)
+    _cmp(r, o)
+    assert len(r["soft"]) > 100000 and r["status"][-1, 5] == 1
