@@ -263,6 +263,12 @@ int jaero_ingest_stats(const jaero_ingest *ing, long long *three);
 int jaero_debug_schedule(int fft_power, int Fs, int cpu_reduce, const int *write_sizes, int nwrites,
                          long long *trigger_samples, int cap, int *segments_out);
 
+/* Host-only: the same for `nch` channels of one bank that hold their own flags (flags0[ch]: 1 AFC, 2 SQL, 4 cpuReduce, 8 DCD) and change them
+ * between writes: events[k] = {before_write, channel (-1: all), kind (0 jaero_set_flags bits, 1 jaero_set_dcd, 2 jaero_set_settings), value}.
+ * Stores (sample, channel) pairs, one per firing of a channel's estimate (JAERO/oqpskdemodulator.cpp:410-431 with per-object cpuReduce). */
+int jaero_debug_schedule_lanes(int fft_power, int Fs, int nch, const int *flags0, const int *write_sizes, int nwrites,
+                               const int *events, int nevents, long long *trig_sample_channel, int cap, int *segments_out);
+
 /* Test hook: the 8400 bps prefilter kernel alone.  n complex samples (re, im interleaved, host pointers) through the kernel
  * RRC(alpha, 2049 taps, 48 kHz, fsym symbols/s) with JFastFir's latency for nfft = 4096 (out[m] = sum_k h[k] x[m - 2048 - k]):
  * JFastFir::SetKernel + update as JAERO/oqpskdemodulator.cpp:278-283,366-368 use it and JAERO/tests/jfastfir_tests.cpp:31-58 pins it. */
@@ -279,7 +285,9 @@ int jaero_debug_viterbi_layout(int mode);
  * JAERO/audioburstoqpskdemodulator.cpp:8-10); the north star names two operations at the edges: fan out shared PCM, gather decoded bits.
  * One jaero_comm per GPU (one process or thread each): RCCL point-to-point sends over xGMI, grouped per call; contiguous channel ranges
  * [rank * N / W, (rank + 1) * N / W) (jaero_shard_range), the same as jaero_amd/dist.py.  RCCL is loaded on first use (dlopen): hosts with
- * one GPU never need it.  world = 1 with id = NULL is a communicator without RCCL (both operations are local copies). */
+ * one GPU never need it.  world = 1 with id = NULL is a communicator without RCCL (both operations are local copies).
+ * ANY RCCL error invalidates the jaero_comm: a group that failed half-queued is closed, the communicator is aborted (ncclCommAbort) and every
+ * later call on it returns JAERO_EHIP -- destroy it and create a new one on every rank. */
 typedef struct jaero_comm jaero_comm;
 #define JAERO_COMM_ID_BYTES 128
 int jaero_shard_range(int nch_total, int rank, int world, int *lo, int *hi);

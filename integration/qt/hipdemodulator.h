@@ -256,7 +256,15 @@ protected:
         // meter, Hilbert filter, peak detector and trident fill restart, the delay lines keep their contents with the pointers at zero,
         // RxDataBits (`pending`) survives, as in the reference.  Burst MSK also changes its bit rate this way (a sibling bank with the survivors
         // behind the same handle); whatever the library refuses is answered by replacing the one-channel bank.
-        if (ctx && js.Fs == Fs && jaero_set_settings(ctx, 0, &js) == JAERO_OK)
+        const int rc = (ctx && js.Fs == Fs) ? jaero_set_settings(ctx, 0, &js) : JAERO_ENOTSUP;
+        if (rc == JAERO_EINVAL)
+        {
+            // settings the library rejects as such (they would fail jaero_create's validation too): warn and keep demodulating with the old
+            // bank, as the continuous adaptor does -- replacing the bank would leave this object without one
+            emit WarningTextSignal(QString("libjaero_hip: %1").arg(jaero_last_error()));
+            return;
+        }
+        if (rc == JAERO_OK)
         {
             if (kind == JAERO_KIND_BURST_MSK) dcd = false; // burstmskdemodulator.cpp:322
             if (js.fb != fb) { fb = js.fb; emit BitRateChanged(fb, true); } // burst MSK 600 <-> 1200: the bank behind the handle was re-created with the survivors

@@ -25,7 +25,7 @@ EXPORTS = [
     "jaero_softbits_view", "jaero_discard_softbits", "jaero_read_status", "jaero_read_status_log",
     "jaero_read_symbols", "jaero_viterbi_decode_soft", "jaero_viterbi_continuous", "jaero_abi_version",
     "jaero_num_channels", "jaero_strerror", "jaero_last_error", "jaero_profile_enable", "jaero_profile_read", "jaero_profile_kernel", "jaero_debug_viterbi_layout",
-    "jaero_debug_schedule", "jaero_debug_prefilter", "jaero_debug_read_prefiltered", "jaero_read_events",
+    "jaero_debug_schedule", "jaero_debug_schedule_lanes", "jaero_debug_prefilter", "jaero_debug_read_prefiltered", "jaero_read_events",
     "jaero_aerol_create", "jaero_aerol_create_burst", "jaero_aerol_read_packets", "jaero_aerol_destroy", "jaero_aerol_write", "jaero_aerol_read_sus", "jaero_aerol_read_events",
     "jaero_aerol_tick_dcd", "jaero_aerol_profile_enable", "jaero_aerol_profile_read", "jaero_aerol_read_voice",
     "jaero_ingest_create", "jaero_ingest_destroy", "jaero_ingest_push", "jaero_ingest_queued", "jaero_ingest_pump",
@@ -114,6 +114,7 @@ def lib():
     L.jaero_profile_read.argtypes = [vp, ip, C.POINTER(dp), C.POINTER(ip), ip]
     L.jaero_profile_kernel.argtypes = [vp, ip, C.c_char_p, ip]
     L.jaero_debug_schedule.argtypes = [ip, ip, ip, vp, ip, vp, ip, C.POINTER(ip)]
+    L.jaero_debug_schedule_lanes.argtypes = [ip, ip, ip, vp, vp, ip, vp, ip, vp, ip, C.POINTER(ip)]
     L.jaero_debug_prefilter.argtypes = [ip, vp, ip, dp, dp, vp]
     L.jaero_debug_read_prefiltered.argtypes = [vp, ip, vp, ip]
     L.jaero_aerol_create.argtypes = [ip, ip, ip, ip, ip, C.POINTER(vp)]

@@ -232,7 +232,7 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
     c->m.nch = nch; c->m.nchp = nchp;
     c->m.flags.assign(nchp, 0);
     // burst OQPSK: 39 of its 55 history slots + the taps in LDS; burst MSK: 39 of 80 (1200 bps) or all 160 (600 bps) slots
-    const int lds = oq ? (2 * 39 * 64 + 64) * (int)sizeof(double) : 2 * (g.fir_n == 80 ? BMSK_FB_LDSN_80 : BMSK_FB_LDSN_160) * 64 * (int)sizeof(double) + BMSK_FB_MAIL_BYTES + BMSK_FB_WC_BYTES(g.fir_n == 80) + BMSK_FB_D8_BYTES(g.fir_n == 80, g.d8_len);
+    const int lds = oq ? (2 * 39 * 64 + 64) * (int)sizeof(double) : 2 * (g.fir_n == 80 ? BMSK_FB_LDSN_80 : BMSK_FB_LDSN_160) * 64 * (int)sizeof(double) + BMSK_FB_MAIL_BYTES + BMSK_FB_WC_BYTES(g.fir_n == 80) + BMSK_FB_D8_BYTES(g.fir_n == 80, g.d8_len) + BMSK_FB_ATAN_BYTES;
     if (oq)
     {
         HIPCHK(hipFuncSetAttribute((const void *)k_burst_oqpsk_demod<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -276,7 +276,7 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
         prof_end(c, pi, st);
     }
     const bool cs = (c->flags & JAERO_FLAG_CAPTURE_SYMBOLS) != 0;
-    const int lds = g.kind == JAERO_KIND_BURST_OQPSK ? (2 * 39 * 64 + 64) * (int)sizeof(double) : 2 * (g.fir_n == 80 ? BMSK_FB_LDSN_80 : BMSK_FB_LDSN_160) * 64 * (int)sizeof(double) + BMSK_FB_MAIL_BYTES + BMSK_FB_WC_BYTES(g.fir_n == 80) + BMSK_FB_D8_BYTES(g.fir_n == 80, g.d8_len);
+    const int lds = g.kind == JAERO_KIND_BURST_OQPSK ? (2 * 39 * 64 + 64) * (int)sizeof(double) : 2 * (g.fir_n == 80 ? BMSK_FB_LDSN_80 : BMSK_FB_LDSN_160) * 64 * (int)sizeof(double) + BMSK_FB_MAIL_BYTES + BMSK_FB_WC_BYTES(g.fir_n == 80) + BMSK_FB_D8_BYTES(g.fir_n == 80, g.d8_len) + BMSK_FB_ATAN_BYTES;
     int first = 1;
     c->poisoned = true; // the history push above is idempotent (same slots if the write is repeated); from here on state advances
     for (int pos = 0; pos < nsamples;)
@@ -288,6 +288,10 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
         LAUNCHCHK("k_hilbert_fft");
         prof_end(c, pi, st);
         pi = prof_begin(c, 4, st);
+        // bt_hold_left is an UPPER BOUND of every lane's BI_BT_HOLD (the per-lane, per-sample counter the kernel obeys): each setSettings sets
+        // both to bt_lag at the same moment, the lane's falls by one per sample, this one by n per segment of n samples -- so while any lane
+        // still holds, the HOLD instantiation runs (for all lanes: those whose counter is 0 compute what <false> computes).  A write that
+        // poisons the bank leaves the counter alone: a poisoned bank accepts nothing but jaero_destroy.
         if (c->bt_hold_left > 0)
         {
             hipLaunchKernelGGL(k_burst_front<true>, dim3(g.ngroups), dim3(64), 0, st, g, p, n, n0);

@@ -16,6 +16,7 @@ struct JRccl
     int (*GetUniqueId)(void *) = nullptr;
     int (*CommInitRank)(void **, int, /* ncclUniqueId by value: 128 bytes */ struct JId128, int) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommAbort)(void *) = nullptr; // optional: used when a group fails half-queued
     int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
@@ -36,19 +37,28 @@ static int rccl_load()
     SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd");
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+    *(void **)(&g_rccl.CommAbort) = dlsym(h, "ncclCommAbort");
     g_rccl.lib = h;
     return 0;
 }
 #define RCCLCHK(call, what) do { const int r_ = (call); if (r_ != 0) return fail(JAERO_EHIP, "RCCL %s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "error"); } while (0)
 #define JRCCL_CHAR 0 /* ncclInt8 / ncclChar: payloads are moved as bytes */
 // An open ncclGroupStart must be closed on EVERY way out: a Send / Recv that fails inside the group returns through RCCLCHK, and with the
-// thread's group depth left above zero every later RCCL call on that thread (ncclCommDestroy included) would be queued or hang.
+// thread's group depth left above zero every later RCCL call on that thread (ncclCommDestroy included) would be queued or hang.  But closing
+// a group COMMITS what was queued before the failure, and the peers' matching operations of a half-queued group never come: the stream or
+// the communicator may then block for good.  So the error path closes the group, ABORTS the communicator (ncclCommAbort where the library
+// has it: queued work is cancelled) and marks the jaero_comm broken -- every later call on it fails with JAERO_EHIP instead of hanging.
+// Any RCCL error invalidates the jaero_comm; destroy it and create a new one on every rank.
+struct jaero_comm;
+static void jaero_comm_break(jaero_comm *c);
 struct JRcclGroup
 {
+    jaero_comm *comm;
     bool open = false;
+    explicit JRcclGroup(jaero_comm *c) : comm(c) {}
     int start() { const int r = g_rccl.GroupStart(); open = (r == 0); return r; }
-    int end() { open = false; return g_rccl.GroupEnd(); }
-    ~JRcclGroup() { if (open) g_rccl.GroupEnd(); }
+    int end() { open = false; const int r = g_rccl.GroupEnd(); if (r != 0) jaero_comm_break(comm); return r; }
+    ~JRcclGroup() { if (open) { g_rccl.GroupEnd(); jaero_comm_break(comm); } }
 };
 
 struct jaero_comm
@@ -59,7 +69,15 @@ struct jaero_comm
     size_t stage_elems = 0;
     hipEvent_t stage_ev = nullptr; // recorded behind the sends that read `stage`: the next call's packing (on whatever stream) waits for it
     bool stage_busy = false;
+    bool broken = false;           // an RCCL call failed inside a group: the communicator was aborted, nothing more can be sent through it
 };
+static void jaero_comm_break(jaero_comm *c)
+{
+    if (!c || c->broken) return;
+    c->broken = true;
+    if (c->nccl && g_rccl.CommAbort) { g_rccl.CommAbort(c->nccl); c->nccl = nullptr; } // (without ncclCommAbort the handle is kept for jaero_comm_destroy)
+}
+#define COMM_BROKEN_CHK(c, who) do { if ((c) && (c)->broken) return fail(JAERO_EHIP, who ": an earlier RCCL operation on this communicator failed; it was aborted -- destroy it and create a new one on every rank"); } while (0)
 
 static inline void shard_range(int nch_total, int rank, int world, int &lo, int &hi)
 {
@@ -126,6 +144,7 @@ extern "C" int jaero_fan_out_pcm(jaero_comm *c, int src, const int16_t *d_frames
 {
     if (!c || src < 0 || src >= c->world || nsamples < 0 || nch_total < 0 || !d_mine || (c->rank == src && !d_frames_all))
         return fail(JAERO_EINVAL, "jaero_fan_out_pcm: bad arguments");
+    COMM_BROKEN_CHK(c, "jaero_fan_out_pcm");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     int lo, hi;
@@ -178,7 +197,7 @@ extern "C" int jaero_fan_out_pcm(jaero_comm *c, int src, const int16_t *d_frames
                 off += (size_t)nsamples * (h - l);
             }
         HIPCHK(hipGetLastError());
-        JRcclGroup grp;
+        JRcclGroup grp(c);
         RCCLCHK(grp.start(), "ncclGroupStart");
         off = 0;
         for (int r = 0; r < c->world; r++)
@@ -210,6 +229,7 @@ extern "C" int jaero_gather_softbits(jaero_comm *c, int dst, const int16_t *d_so
 {
     if (!c || dst < 0 || dst >= c->world || nch_total < 0 || cap <= 0 || !d_soft || !d_counts || (c->rank == dst && (!d_soft_all || !d_counts_all)))
         return fail(JAERO_EINVAL, "jaero_gather_softbits: bad arguments");
+    COMM_BROKEN_CHK(c, "jaero_gather_softbits");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     int lo, hi;
@@ -218,7 +238,7 @@ extern "C" int jaero_gather_softbits(jaero_comm *c, int dst, const int16_t *d_so
     if (c->rank != dst)
     {
         if (!c->nccl) return fail(JAERO_EINVAL, "jaero_gather_softbits: a one-rank communicator has no peer %d", dst);
-        JRcclGroup grp;
+        JRcclGroup grp(c);
         RCCLCHK(grp.start(), "ncclGroupStart");
         RCCLCHK(g_rccl.Send(d_soft, mine_b, JRCCL_CHAR, dst, c->nccl, st), "ncclSend");
         RCCLCHK(g_rccl.Send(d_counts, mine_c, JRCCL_CHAR, dst, c->nccl, st), "ncclSend");
@@ -233,7 +253,7 @@ extern "C" int jaero_gather_softbits(jaero_comm *c, int dst, const int16_t *d_so
     }
     if (c->nccl)
     {
-        JRcclGroup grp;
+        JRcclGroup grp(c);
         RCCLCHK(grp.start(), "ncclGroupStart");
         for (int r = 0; r < c->world; r++)
         {

@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "jd_libm.h" // jd_atan2 (correctly rounded), jd_hypot (glibc 2.35's, bit for bit): what the loops feed back must round as the host's does
 
 #define JD_WTSIZE 19999
 #define JD_WAVE 64

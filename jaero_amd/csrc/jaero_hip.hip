@@ -1192,6 +1192,21 @@ static void launch_coarse(jaero_ctx *c, const int *d_list, int nlist, hipStream_
     }
 }
 
+// Work enqueued on `st` is ordered behind everything the bank enqueued before (on last_stream), and `st` becomes last_stream: the rule for
+// every entry point that takes a caller stream and touches device state (jaero_write, jaero_discard_softbits) -- a discard on stream X
+// followed by a rate-changing jaero_set_settings (which synchronises last_stream only) must not read the counters before the discard lands.
+static int order_behind_last(jaero_ctx *c, hipStream_t st)
+{
+    if (st != c->last_stream)
+    {
+        if (!c->order_ev) HIPCHK(hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(c->order_ev, c->last_stream));
+        HIPCHK(hipStreamWaitEvent(st, c->order_ev, 0));
+    }
+    c->last_stream = st;
+    return 0;
+}
+
 extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layout, int is_device_ptr, void *stream)
 {
     if (!c || !pcm || nsamples < 0) return fail(JAERO_EINVAL, "jaero_write: bad arguments");
@@ -1201,14 +1216,7 @@ extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int l
     if (c->poisoned) return fail(JAERO_EHIP, "jaero_write: an earlier write of this bank failed part-way (its schedule mirror is ahead of the device state): destroy the bank and create a new one");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
-    if (st != c->last_stream)
-    {
-        // setters and earlier writes were enqueued on last_stream: this write is ordered behind them
-        if (!c->order_ev) HIPCHK(hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming));
-        HIPCHK(hipEventRecord(c->order_ev, c->last_stream));
-        HIPCHK(hipStreamWaitEvent(st, c->order_ev, 0));
-    }
-    c->last_stream = st;
+    { const int rc = order_behind_last(c, st); if (rc) return rc; } // setters, discards and earlier writes were enqueued on last_stream
     // poisoned is raised where the first launch that advances device state or the schedule mirror is about to be enqueued (a failed copy of
     // the input, transpose or history push leaves both as they were: the caller may simply write again) and lowered when the whole write is in
     if (c->burst)
@@ -1308,6 +1316,57 @@ extern "C" int jaero_debug_schedule(int fft_power, int Fs, int cpu_reduce, const
             const int next = m.next_segment(pos, ns, n, sa, oa);
             nseg++;
             if (oa) { if (ntrig < cap) trigger_samples[ntrig] = base + pos + n - 1; ntrig++; }
+            pos = next;
+        }
+        base += ns;
+    }
+    if (segments_out) *segments_out = nseg;
+    return ntrig;
+}
+
+// Host-only: the same for a whole group of channels that draw their flags independently and change them between writes -- the part of the
+// scheduler that decides which lanes of a wavefront fire at which sample (Mirror::steps_to_trigger / next_segment / fired).
+// events[k] = {before_write, channel (-1: all), kind, value}: kind 0 = setAFC/SQL/CPUReduce bits (JF_*), kind 1 = DCD, kind 2 = setSettings
+// (the channel's ring position and counter restart); applied before write `before_write`.  Records (sample, channel) per firing.
+extern "C" int jaero_debug_schedule_lanes(int fft_power, int Fs, int nch, const int *flags0, const int *write_sizes, int nwrites,
+                                          const int *events, int nevents, long long *trig_sample_channel, int cap, int *segments_out)
+{
+    if (!write_sizes || !trig_sample_channel || !flags0 || (nevents > 0 && !events) || nch < 1 || fft_power < 4 || fft_power > 20)
+        return fail(JAERO_EINVAL, "jaero_debug_schedule_lanes: bad arguments");
+    Mirror m;
+    m.nch = nch; m.nchp = (nch + 63) / 64 * 64; m.nfft = 1 << fft_power; m.Fs_int = Fs;
+    m.flags.assign(m.nchp, 0); m.bbptr.assign(m.nchp, 0); m.cnt.assign(m.nchp, 0);
+    for (int ch = 0; ch < nch; ch++) m.flags[ch] = flags0[ch] & (JF_AFC | JF_SQL | JF_CPUREDUCE | JF_DCD);
+    long long base = 0;
+    int ntrig = 0, nseg = 0;
+    for (int w = 0; w < nwrites; w++)
+    {
+        for (int k = 0; k < nevents; k++)
+        {
+            const int *e = events + 4 * k;
+            if (e[0] != w) continue;
+            if (e[1] < -1 || e[1] >= nch) return fail(JAERO_EINVAL, "jaero_debug_schedule_lanes: bad channel in event %d", k);
+            const int lo = e[1] < 0 ? 0 : e[1], hi = e[1] < 0 ? m.nchp : e[1] + 1;
+            for (int ch = lo; ch < hi; ch++)
+            {
+                if (e[2] == 0) m.flags[ch] = (m.flags[ch] & JF_DCD) | (e[3] & (JF_AFC | JF_SQL | JF_CPUREDUCE)); // jaero_set_flags
+                else if (e[2] == 1) m.flags[ch] = (m.flags[ch] & ~JF_DCD) | (e[3] ? JF_DCD : 0);               // jaero_set_dcd
+                else { m.bbptr[ch] = 0; m.cnt[ch] = 0; }                                                        // jaero_set_settings
+            }
+        }
+        int pos = 0;
+        const int ns = write_sizes[w];
+        while (pos < ns)
+        {
+            int n, sa, oa;
+            const int next = m.next_segment(pos, ns, n, sa, oa);
+            nseg++;
+            if (oa)
+                for (int ch : m.fired)
+                {
+                    if (ntrig < cap) { trig_sample_channel[2 * ntrig] = base + pos + n - 1; trig_sample_channel[2 * ntrig + 1] = ch; }
+                    ntrig++;
+                }
             pos = next;
         }
         base += ns;
@@ -1501,6 +1560,7 @@ extern "C" int jaero_discard_softbits(jaero_ctx *c, void *stream)
     POISONCHK(c, "jaero_discard_softbits");
     if (!c) return fail(JAERO_EINVAL, "null ctx");
     HIPCHK(hipSetDevice(c->device));
+    { const int rc = order_behind_last(c, (hipStream_t)stream); if (rc) return rc; }
     if (c->burst)
     {
         // what jaero_softbits_view reported as emitted is gone; the not yet emitted tail of every channel moves to the front

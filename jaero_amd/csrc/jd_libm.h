@@ -1,5 +1,5 @@
-// jd_atan2.h -- atan2 for the sample loops, rounded as the host libm (glibc 2.35) rounds it as nearly as any function can be; and
-// glibc 2.35's hypot restated (kept for the record: it is four times the device library's cost and not used by the kernels).
+// jd_libm.h -- atan2 and hypot for the sample loops, rounded as the host libm (glibc 2.35) rounds it as nearly as any function can be; and
+// glibc 2.35's hypot restated operation for operation (bit-identical to the host's).  Both are what the product kernels call (round 5).
 //
 // Why: the timing loops feed atan2 of every sample back into two oscillators (JAERO/oqpskdemodulator.cpp:472-494,
 // JAERO/mskdemodulator.cpp:384-408), so the closer the result is to the reference's double the closer the loops track it.  Measured
@@ -66,7 +66,34 @@ __device__ __forceinline__ void jda_fetch(const JdAtanLane &T, int i, double &A_
 }
 #endif
 
-JDA_FN double jd_atan2(double y, double x, const JdAtanLane &T)
+// the table in LDS (65 leading doubles, 65 float tails: 780 B, JD_ATAN_LDS_BYTES reserved): for call sites under a DIVERGENT branch, where a
+// bpermute cannot be used (it returns nothing from lanes the exec mask has switched off).  One table per workgroup, read-only after
+// jd_atan_lds_init + a barrier.
+#define JD_ATAN_LDS_BYTES 784
+struct JdAtanLds
+{
+    const double *hi; // [65]
+    const float *lo;  // [65]
+};
+#ifndef JDA_HOST_CHECK
+__device__ __forceinline__ JdAtanLds jd_atan_lds_init(void *mem, int tid, int nthreads)
+{
+    double *hi = (double *)mem;
+    float *lo = (float *)(hi + 65);
+    for (int i = tid; i < 65; i += nthreads) { hi[i] = JD_ATAN_HI[i]; lo[i] = JD_ATAN_LOF[i]; }
+    JdAtanLds T;
+    T.hi = hi; T.lo = lo;
+    return T;
+}
+__device__ __forceinline__ void jda_fetch(const JdAtanLds &T, int i, double &A_hi, double &A_lo)
+{
+    A_hi = T.hi[i];
+    A_lo = (double)T.lo[i];
+}
+#endif
+
+template <class JDA_TBL>
+JDA_FN double jd_atan2_t(double y, double x, const JDA_TBL &T)
 {
     const uint32_t hx = jda_hi32(x), hy = jda_hi32(y);
     // both exponents in [2^-300, 2^300): no zero, infinity, NaN, denormal; no intermediate under- or overflow below.  The straight-line
@@ -117,29 +144,39 @@ JDA_FN double jd_atan2(double y, double x, const JdAtanLane &T)
     return res;
 }
 
+JDA_FN double jd_atan2(double y, double x, const JdAtanLane &T) { return jd_atan2_t(y, x, T); }
+#ifndef JDA_HOST_CHECK
+JDA_FN double jd_atan2(double y, double x, const JdAtanLds &T) { return jd_atan2_t(y, x, T); }
+#endif
+
 // ---- hypot -----------------------------------------------------------------------------------------------------------------------
-// glibc 2.35 sysdeps/ieee754/dbl-64/e_hypot.c, the branch without a fast fma (the x86-64 baseline build).  Operands of the sample
-// loops are AGC'd samples: never near the scaling thresholds (2^+-511); those, infinities and NaN go to the device library.
+// glibc 2.35 sysdeps/ieee754/dbl-64/e_hypot.c, the branch without a fast fma (the x86-64 baseline build), operation for operation:
+// h = sqrt(ax ax + ay ay), then ONE correction step h -= (t1 + t2) / (2 h) whose t1, t2 depend on which side of 2 ay the first h fell.
+// Both forms of (t1, t2) are written as straight-line code and selected (a wavefront of 64 channels has lanes on both sides in
+// nearly every call); operands outside glibc's unscaled range (2^-459 < ay, ax < 2^511), infinities and NaN take the device library's
+// value, patched in afterwards; ax >= ay 2^54 returns ax + ay as glibc does.  Bit-identical to the host libm on 6.4e8 operand pairs
+// (scripts/atan2_check.c -DHYPOT).  This -- not atan2 -- is what decides whether the loops track the reference: DESIGN 9 item 18.
 JDA_FN double jd_hypot(double x, double y)
 {
     x = __builtin_fabs(x); y = __builtin_fabs(y);
     const double ax = x < y ? y : x, ay = x < y ? x : y;
-    if (!(ax < 0x1p+511 && ay > 0x1p-459)) return JDA_LIB_HYPOT(x, y);
-    if (ax >= ay * 0x1p+54) return ax + ay; // glibc: ax >= ay / EPS, EPS = 2^-54: the same comparison, the quotient is exact
-    double h = JDA_SQRT(ax * ax + ay * ay);
-    double t1, t2;
-    if (h <= 2.0 * ay)
-    {
-        const double delta = h - ay;
-        t1 = ax * (2.0 * delta - ax);
-        t2 = (delta - 2.0 * (ax - ay)) * delta;
-    }
-    else
-    {
-        const double delta = h - ax;
-        t1 = 2.0 * delta * (ax - 2.0 * ay);
-        t2 = (4.0 * delta - ay) * ay + delta * delta;
-    }
-    h -= (t1 + t2) / (2.0 * h);
-    return h;
+    const bool unscaled = ax < 0x1p+511 && ay > 0x1p-459;
+    const bool far = ax >= ay * 0x1p+54; // glibc: ax >= ay / EPS, EPS = 2^-54: the same comparison, the quotient is exact
+    const double h = JDA_SQRT(ax * ax + ay * ay);
+    const bool near = h <= 2.0 * ay;
+    const double delta = h - (near ? ay : ax);
+    const double t1n = ax * (2.0 * delta - ax), t2n = (delta - 2.0 * (ax - ay)) * delta;
+    const double t1f = 2.0 * delta * (ax - 2.0 * ay), t2f = (4.0 * delta - ay) * ay + delta * delta;
+    const double t1 = near ? t1n : t1f, t2 = near ? t2n : t2f;
+    double res = h - (t1 + t2) / (2.0 * h);
+    if (far) res = ax + ay;
+    if (!unscaled) res = JDA_LIB_HYPOT(x, y);
+    return res;
 }
+
+#if defined(JD_LIBRARY_LIBM) && !defined(JDA_HOST_CHECK)
+// A/B build only (make -C jaero_amd/csrc ab -> gpurun_tmp/libjaero_hip_libm.so, loaded through JAERO_HIP_LIB by scripts/recording_full.py):
+// the device library's functions, as the kernels called them until round 4.  Never the product.
+#define jd_hypot(x, y) hypot(x, y)
+#define jd_atan2(y, x, T) atan2(y, x)
+#endif

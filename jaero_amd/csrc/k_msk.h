@@ -50,6 +50,7 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
     const bool dcd = flags & JF_DCD;
     int soft_cnt = LDI(I_SOFT_CNT), sym_cnt = LDI(I_SYM_CNT), overflow = LDI(I_OVERFLOW);
 
+    const JdAtanLane atl = jd_atan_lane_table(lane); // jd_atan2's table, one entry per lane (every lane of the wavefront runs the sample loop)
     const double samplerate = g.Fs;
     const int nfft_mask = g.nfft - 1;
     double2 *__restrict__ bbring = p.bbring + (size_t)ch * g.nfft;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
         // symbol timing (:387-405)
         double st_eta;
         {
-            const double x0 = hypot(q_re, q_im);
+            const double x0 = jd_hypot(q_re, q_im);
             double y = 0;
             y += res_x2 * g.res_b2; y += res_x1 * g.res_b1; y += x0 * g.res_b0;
             y -= res_y2 * g.res_a2; y -= res_y1 * g.res_a1;
@@ -199,8 +200,8 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
             const double m_re = st_eta, m_im = -d8out;
             const double o_re = so.x * m_re - so.y * m_im;
             const double o_im = so.x * m_im + so.y * m_re;
-            const double st_angle_error = atan2(o_im, o_re);
-            const double weighting = fabs(tanh(st_angle_error));
+            const double st_angle_error = jd_atan2(o_im, o_re, atl);
+            const double weighting = fabs(jd_tanh(st_angle_error));
             if (!dcd) jd_wt_advance_fraction(st_ptr, -(1.0 - weighting) * st_angle_error * (0.05 / 360.0));
             else jd_wt_advance_fraction(st_ptr, -(1.0 - weighting) * st_angle_error * (0.003 / 360.0));
         }
@@ -214,8 +215,8 @@ __global__ __launch_bounds__(64) void k_msk_samples(const JGeom g, const JPtrs p
             const double2 dt_old = dt_ring[dn]; // dt_len = SPS/2 + 1 > 1
             const double ms_old = msema_ring[msema_pos];
             // carrier tracking (:411-426)
-            const double ct_xt = tanh(sim) * sre;
-            const double ct_xt_d = tanh(ptd.x) * ptd.y;
+            const double ct_xt = jd_tanh(sim) * sre;
+            const double ct_xt_d = jd_tanh(ptd.x) * ptd.y;
             double ct_ec = ct_xt_d - ct_xt;
             if (ct_ec > M_PI) ct_ec = M_PI;
             if (ct_ec < -M_PI) ct_ec = -M_PI;

@@ -213,7 +213,7 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &
         double gain = 1.414213562 / fmax(jd_div_const(agc_sum, agc_len_d, r_agc_len), 0.000001);
         gain = fmax(gain, 0.000001);
         sre *= gain; sim *= gain;
-        const double abval = hypot(sre, sim);
+        const double abval = jd_hypot(sre, sim);
         if (abval > 2.84) { const double k = (2.84 / abval); sre = k * sre; sim = k * sim; }
         double *d = L.data + buf * 3 * 64 + lane;
         d[0] = sre; d[64] = sim; d[128] = abval;
@@ -384,6 +384,7 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, FbLds &L
     int yui = LDI(I_YUI), sig2l_init = LDI(I_SIG2L_INIT);
     int soft_cnt = LDI(I_SOFT_CNT), sym_cnt = LDI(I_SYM_CNT), overflow = LDI(I_OVERFLOW);
 
+    const JdAtanLane atl = jd_atan_lane_table(lane); // jd_atan2's table, one entry per lane (every lane of the wavefront runs the loop below)
     const double samplerate = g.Fs; // WaveTable::samplerate after SetFreq(freq,(int)Fs)
     const double r_samplerate = 1.0 / samplerate;
     const double wtsize_d = (double)JD_WTSIZE, r_wtsize = 1.0 / wtsize_d, r_360 = 1.0 / 360.0;
@@ -437,7 +438,7 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, FbLds &L
         // MSEcalc::Update (DSP.cpp:451-463)
         double av_w, e_w;
         {
-            const double av = hypot(q_re, q_im);
+            const double av = jd_hypot(q_re, q_im);
             pm_sum = pm_sum - px_pm; pm_sum = pm_sum + fabs(av); av_w = fabs(av);
             double mu = jd_div_const(pm_sum, pm_len_d, r_pm_len);
             if (mu < 0.000001) mu = 0.000001;
@@ -520,7 +521,7 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, FbLds &L
             const double m_re = st_eta, m_im = -d8out;
             const double o_re = so.x * m_re - so.y * m_im;
             const double o_im = so.x * m_im + so.y * m_re;
-            const double st_angle_error = atan2(o_im, o_re);
+            const double st_angle_error = jd_atan2(o_im, o_re, atl);
             fb_wt_setfreq(st_freq, st_step, (-st_angle_error * 0.00000001) + st_freq, samplerate, r_samplerate);
             jd_wt_advance_fraction(st_ptr, jd_div_const(-st_angle_error * 0.01, 360.0, r_360));
             if (st_freq < (g.stref_freq - 0.1)) fb_wt_setfreq(st_freq, st_step, (g.stref_freq - 0.1), samplerate, r_samplerate);

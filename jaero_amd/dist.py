@@ -41,19 +41,39 @@ def init_from_env(backend: Optional[str] = None):
     return rank, world, local
 
 
+def local_world_size() -> Optional[int]:
+    """Ranks on this node, from whichever launcher exported it: torchrun (LOCAL_WORLD_SIZE), Slurm (SLURM_NTASKS_PER_NODE, possibly
+    "8(x2)"), Open MPI (OMPI_COMM_WORLD_LOCAL_SIZE), MPICH / Intel MPI (MPI_LOCALNRANKS).  None when nobody said."""
+    for key in ("LOCAL_WORLD_SIZE", "SLURM_NTASKS_PER_NODE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS"):
+        v = os.environ.get(key)
+        if v:
+            digits = ""
+            for ch in v.strip():
+                if not ch.isdigit():
+                    break
+                digits += ch
+            if digits:
+                return int(digits)
+    return None
+
+
 def ranks_share_a_device() -> bool:
     """True when this node has fewer GPUs than local ranks (a multi-rank run squeezed onto a smaller lease: every rank then takes device
-    local_rank % device_count, and the control plane runs over gloo because RCCL refuses two ranks on one GPU)."""
+    local_rank % device_count, and the control plane runs over gloo because RCCL refuses two ranks on one GPU).
+
+    The answer picks the backend (init_from_env), so it must be the SAME on every rank of the job: it is derived only from values every
+    rank of a node sees alike -- the launcher's local world size where one is exported, otherwise the global WORLD_SIZE (conservative: a
+    multi-node job of an unknown launcher with more ranks than one node has GPUs runs its control plane over gloo; JAERO_DIST_BACKEND
+    overrides).  A per-rank guess from LOCAL_RANK (round 4) made rank 0 pick nccl and rank 1 gloo on a 2-rank / 1-GPU srun."""
     import torch
 
     n = torch.cuda.device_count() if torch.cuda.is_available() else 0
     if n == 0:
         return False
-    if "LOCAL_WORLD_SIZE" in os.environ:
-        return int(os.environ["LOCAL_WORLD_SIZE"]) > n
-    # launchers other than torchrun (srun, mpirun) do not export LOCAL_WORLD_SIZE, and WORLD_SIZE counts every node's ranks: all that is
-    # known about this node is this rank's own local index -- it shares a device exactly when that index does not name one
-    return int(os.environ.get("LOCAL_RANK", "0")) >= n
+    lws = local_world_size()
+    if lws is not None:
+        return lws > n
+    return int(os.environ.get("WORLD_SIZE", "1")) > n
 
 
 def device_index(local: int) -> int:

@@ -1,4 +1,4 @@
-// Check of jd_atan2 / jd_hypot (scripts/ubench/jd_atan2.h, compiled here for the host) against the host libm (glibc 2.35) and against
+// Check of jd_atan2 / jd_hypot (jaero_amd/csrc/jd_libm.h, compiled here for the host) against the host libm (glibc 2.35) and against
 // __float128:
 //   g++ -O2 -ffp-contract=off -fopenmp -DHYPOT -x c++ scripts/atan2_check.c -o /tmp/atan2_check -lm -lquadmath
 //   /tmp/atan2_check [millions of calls, default 320] [millions per family also against __float128, default 20]
@@ -39,7 +39,7 @@ static inline double jda_bad_rcp(double x)
 #define JDA_RCP(x) jda_bad_rcp(x)
 struct JdAtanLane;
 static inline void jda_fetch(const JdAtanLane &T, int i, double &A_hi, double &A_lo);
-#include "ubench/jd_atan2.h"
+#include "../jaero_amd/csrc/jd_libm.h"
 static inline void jda_fetch(const JdAtanLane &, int i, double &A_hi, double &A_lo) { A_hi = JD_ATAN_HI[i]; A_lo = (double)JD_ATAN_LOF[i]; }
 
 static inline uint64_t rng(uint64_t *s) { uint64_t x = *s; x ^= x << 13; x ^= x >> 7; x ^= x << 17; *s = x; return x; }

@@ -5,7 +5,7 @@ One-off validation, not a test: the decoded PCM (23 MB) is not committed.  Stage
     python scripts/recording_full.py stage            (build container: decodes with scripts/vorbis_decode.py, resamples to 48 kHz)
 then
     python scripts/recording_full.py cpu              (build container: unmodified reference against the oracle, soft bits / status / AeroL)
-    python scripts/recording_full.py gpu              (GPU box: a bank fed the recording from four starting points against the oracle, and
+    python scripts/recording_full.py gpu              (GPU box: a bank fed the recording from five starting points against the oracle, and
                                                        PCM -> demodulator bank -> Aero-L bank on the device against the oracle's chain)
 Each prints one JSON line (kept under profiles/)."""
 import json
@@ -56,7 +56,7 @@ def gpu():
 
     capi.lib()
     full = np.fromfile(STAGE, dtype=np.int16)
-    shifts = [0, 7777, 20001, 48000]
+    shifts = [0, 1234, 7777, 20001, 48000]  # four + the one that used to leave the tolerance (round 4: symbol 25 282)
     n = (len(full) - max(shifts)) // 24000 * 24000
     pcm = np.stack([full[s:s + n] for s in shifts])
     nch = len(shifts)
@@ -64,7 +64,7 @@ def gpu():
                               softbit_capacity=2 * n * 10500 // 48000 + 4096)
     for s in range(0, n, 24000):
         demod.write(pcm[:, s:s + 24000])
-    out = {"what": "GPU bank on the whole recording from four starting points, against the oracle", "samples_per_channel": int(n), "seconds": n / 48000.0, "channels": []}
+    out = {"what": "GPU bank on the whole recording from five starting points, against the oracle", "samples_per_channel": int(n), "seconds": n / 48000.0, "channels": []}
     for c in range(nch):
         ref = O.run_demod(O.oqpsk_settings(), pcm[c], chunk=24000, capture_symbols=True)
         soft, sym, log = demod.read_softbits(c, cap=1 << 22), demod.read_symbols(c, caprows=1 << 21), demod.read_status_log(c, caprows=1 << 13)
@@ -73,7 +73,9 @@ def gpu():
         out["channels"].append({"start": shifts[c], "soft_bits": int(m), "count_ok": bool(len(soft) == m + ref["pending"]),
                                 "hard_decisions_equal": bool(np.array_equal(soft[:m] >= 128, ref["soft"] >= 128)),
                                 "max_soft_byte_diff": int(np.max(np.abs(soft[:m].astype(int) - ref["soft"].astype(int)), initial=0)),
+                                "soft_bytes_differing": int((soft[:m].astype(int) != ref["soft"].astype(int)).sum()),
                                 "symbols": int(len(d)), "max_symbol_diff": float(d.max()), "symbols_over_1e-5": int((d >= 1e-5).sum()),
+                                "symbols_over_1e-5_per_1e6": float((d >= 1e-5).sum()) * 1e6 / max(1, len(d)),
                                 "status_rows": int(log.shape[0]), "status_rows_ok": bool(log.shape == ref["status"].shape and np.array_equal(log[:, [0, 5]], ref["status"][:, [0, 5]])),
                                 "max_status_diff": float(np.max(np.abs(log[:, 1:5] - ref["status"][:, 1:5]))) if log.shape == ref["status"].shape else None})
     demod.close()
@@ -94,6 +96,9 @@ def gpu():
                                    "signal_units_identical_to_oracle_chain": bool(sus.shape == osus.shape and np.array_equal(sus[:, 1:15], osus[:, 1:15]))})
     demod.close()
     aerol.close()
+    out["symbols_total"] = int(sum(c["symbols"] for c in out["channels"]))
+    out["symbols_over_1e-5_total"] = int(sum(c["symbols_over_1e-5"] for c in out["channels"]))
+    out["symbols_over_1e-5_per_1e6"] = out["symbols_over_1e-5_total"] * 1e6 / max(1, out["symbols_total"])
     print(json.dumps(out))
 
 

@@ -1,4 +1,4 @@
-// What the device library's atan2 / hypot and jd_atan2 / jd_hypot (scripts/ubench/jd_atan2.h) return against the HOST libm on the same
+// What the device library's atan2 / hypot and jd_atan2 / jd_hypot (jaero_amd/csrc/jd_libm.h) return against the HOST libm on the same
 // arguments, and what a call costs on a lone wavefront per SIMD (the sample loops' situation).  Not part of the product library.
 //   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o scripts/ubench/atan2_rates scripts/ubench/atan2_rates.hip
 //   run:   scripts/ubench/atan2_rates [millions of arguments = 64]
@@ -11,7 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
-#include "jd_atan2.h"
+#include "../../jaero_amd/csrc/jd_libm.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 

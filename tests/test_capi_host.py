@@ -107,3 +107,66 @@ def test_shard_range_matches_the_python_helper():
         assert prev == n
     lo, hi = C.c_int(), C.c_int()
     assert L.jaero_shard_range(8, 2, 2, C.byref(lo), C.byref(hi)) != 0
+
+
+def _brute_force_triggers(nfft, Fs, flags0, writes, events):
+    """Every channel on its own, sample by sample, exactly as the reference's counters move (JAERO/oqpskdemodulator.cpp:410-431):
+    ring write when coarseCounter >= Fs or not cpuReduce; fire when the ring pointer reaches a multiple of nfft (cpuReduce) or nfft/4."""
+    nch = len(flags0)
+    flags = np.array(flags0, dtype=np.int64)
+    bb = np.zeros(nch, dtype=np.int64)
+    cnt = np.zeros(nch, dtype=np.int64)
+    out = []
+    base = 0
+    for w, ns in enumerate(writes):
+        for (bw, ch, kind, val) in events:
+            if bw != w:
+                continue
+            sel = slice(None) if ch < 0 else slice(ch, ch + 1)
+            if kind == 0:
+                flags[sel] = (flags[sel] & 8) | (val & 7)
+            elif kind == 1:
+                flags[sel] = (flags[sel] & ~8) | (8 if val else 0)
+            else:
+                bb[sel] = 0
+                cnt[sel] = 0
+        for i in range(ns):
+            cpu = (flags & 4) != 0
+            fill = (cnt >= Fs) | ~cpu
+            bb = np.where(fill, (bb + 1) % nfft, bb)
+            fire = fill & (bb % np.where(cpu, nfft, nfft // 4) == 0)
+            for c in np.nonzero(fire)[0]:
+                out.append((base + i, int(c)))
+            cnt = np.where(fire, 0, cnt) + 1
+        base += ns
+    return out
+
+
+@pytest.mark.parametrize("nch,seed", [(64, 1), (130, 2), (7, 3)])
+def test_schedule_with_per_lane_flags_matches_brute_force(nch, seed):
+    """The host scheduler with channels of one bank drawing AFC / SQL / cpuReduce independently, flags toggled and setSettings called for
+    single channels between writes of odd sizes: which channel fires at which sample, against a per-channel brute-force simulation
+    (mixed cpuReduce inside one wavefront had never run anywhere)."""
+    L = capi.lib()
+    rng = np.random.default_rng(seed)
+    power, Fs = 9, 3000  # short cycles: 512-entry ring, the cpuReduce gate opens after 3000 samples
+    flags0 = rng.integers(0, 8, nch).astype(np.int32)  # AFC | SQL | cpuReduce in any combination
+    writes = [int(x) for x in rng.integers(1, 1500, 40)]
+    events = []
+    for w in sorted(rng.integers(1, len(writes), 24)):
+        kind = int(rng.integers(0, 3))
+        ch = int(rng.integers(-1, nch)) if rng.random() < 0.9 else -1
+        events.append((int(w), ch, kind, int(rng.integers(0, 8)) if kind == 0 else int(rng.integers(0, 2))))
+    ev = np.array(events, dtype=np.int32).reshape(-1, 4)
+    w = np.array(writes, dtype=np.int32)
+    cap = 1 << 16
+    out = np.zeros((cap, 2), dtype=np.int64)
+    nseg = C.c_int(0)
+    n = L.jaero_debug_schedule_lanes(power, Fs, nch, flags0.ctypes.data, w.ctypes.data, len(writes), ev.ctypes.data, len(events),
+                                     out.ctypes.data, cap, C.byref(nseg))
+    assert 0 < n <= cap
+    got = sorted((int(a), int(b)) for a, b in out[:n])
+    want = sorted(_brute_force_triggers(1 << power, Fs, flags0, writes, events))
+    assert got == want
+    both = {bool(f & 4) for f in flags0}
+    assert both == {True, False} and nseg.value >= len({s for s, _ in want})

@@ -1,5 +1,5 @@
-"""CPU: scripts/atan2_check.c still compiles and passes in a short run (the full run is quoted in DESIGN 9 item 15): scripts/ubench/jd_atan2.h -- round 4,
-NOT in the product -- is a correctly rounded atan2 checked against __float128 and glibc 2.35's hypot restated, bit-identical to libm.  And the
+"""CPU: scripts/atan2_check.c still compiles and passes in a short run (the full run is quoted in DESIGN 9 item 15): jaero_amd/csrc/jd_libm.h -- what
+the sample kernels call since round 5 -- is a correctly rounded atan2 checked against __float128 and glibc 2.35's hypot restated, bit-identical to libm.  And the
 multi-node device-sharing rule of jaero_amd/dist.py."""
 import os
 import shutil
@@ -28,23 +28,42 @@ def test_atan2_is_correctly_rounded_and_hypot_is_glibcs(tmp_path):
     assert any("differ from libm" in ln for ln in out.stdout.splitlines())
 
 
-def test_ranks_share_a_device_without_local_world_size(monkeypatch):
-    """Launchers other than torchrun export WORLD_SIZE for all nodes and no LOCAL_WORLD_SIZE: device sharing is then decided from this
-    rank's own LOCAL_RANK and the device count, not from the global world size."""
+def test_ranks_share_a_device_is_a_job_wide_decision(monkeypatch):
+    """The answer picks the backend, so every rank of a job must get the same one: it may depend on the launcher's local
+    world size (torchrun, Slurm, Open MPI, MPICH) or on WORLD_SIZE, never on this rank's own LOCAL_RANK."""
     import torch
 
     from jaero_amd import dist as jd
 
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    for k in ("LOCAL_WORLD_SIZE", "SLURM_NTASKS_PER_NODE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS"):
+        monkeypatch.delenv(k, raising=False)
+    # srun / mpirun, 2 ranks on a 1-GPU node: both ranks must say "shared" (round 4: rank 0 said nccl, rank 1 gloo)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    answers = set()
+    for lr in ("0", "1"):
+        monkeypatch.setenv("LOCAL_RANK", lr)
+        answers.add(jd.ranks_share_a_device())
+    assert answers == {True}
+    # Slurm says how many tasks a node runs: four nodes of eight on eight GPUs each share nothing, whatever this rank's index
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
-    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
-    monkeypatch.setenv("WORLD_SIZE", "32")  # four nodes of eight
-    monkeypatch.setenv("LOCAL_RANK", "5")
-    assert jd.ranks_share_a_device() is False
-    monkeypatch.setenv("LOCAL_RANK", "9")
+    monkeypatch.setenv("WORLD_SIZE", "32")
+    monkeypatch.setenv("SLURM_NTASKS_PER_NODE", "8(x4)")
+    for lr in ("0", "5", "7"):
+        monkeypatch.setenv("LOCAL_RANK", lr)
+        assert jd.ranks_share_a_device() is False
+    monkeypatch.setenv("SLURM_NTASKS_PER_NODE", "16(x2)")
     assert jd.ranks_share_a_device() is True
+    monkeypatch.delenv("SLURM_NTASKS_PER_NODE")
+    monkeypatch.setenv("OMPI_COMM_WORLD_LOCAL_SIZE", "8")
+    assert jd.ranks_share_a_device() is False
+    monkeypatch.delenv("OMPI_COMM_WORLD_LOCAL_SIZE")
+    # nobody said: conservative and the same everywhere (32 ranks > 8 devices -> gloo unless JAERO_DIST_BACKEND says otherwise)
+    for lr in ("0", "5"):
+        monkeypatch.setenv("LOCAL_RANK", lr)
+        assert jd.ranks_share_a_device() is True
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
-    monkeypatch.setenv("LOCAL_RANK", "0")
     assert jd.ranks_share_a_device() is False
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "16")
     assert jd.ranks_share_a_device() is True

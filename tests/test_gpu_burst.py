@@ -6,7 +6,7 @@ their positions), soft symbols within 1e-5; every SignalStatus / EbNo / Plottabl
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import assert_soft_bytes, load_golden
 from jaero_amd import signalgen as G
 
 pytestmark = pytest.mark.gpu
@@ -42,11 +42,16 @@ def sort_ev(ev):
     return ev[np.lexsort((ev[:, 1], ev[:, 0]))] if len(ev) else ev
 
 
-def check_soft(got, ref, tag=""):
+def check_soft(got, ref, tag="", allow=None):
+    """The burst demodulators' input passes an FFT filter (the Hilbert transform) whose round-off is not the reference FFT's, so a soft byte on
+    a rounding edge may differ by one: bounded by 1, counted in the session's ledger, and at most BURST_SOFT_ALLOW of the bytes of a stream."""
     assert len(got) == len(ref), tag
     assert np.array_equal(got == -1, ref == -1), "burst markers differ"
     assert np.array_equal(got >= 128, ref >= 128), "hard decisions differ"
-    assert np.max(np.abs(got.astype(int) - ref.astype(int)), initial=0) <= 1
+    assert_soft_bytes(got, ref, tag, allow=(max(1, int(len(ref) * BURST_SOFT_ALLOW)) if allow is None else allow))
+
+
+BURST_SOFT_ALLOW = 2e-3
 
 
 def check_events(got, ref):

@@ -7,7 +7,7 @@ writeData per message, and (b) the same bank fed directly."""
 import numpy as np
 import pytest
 
-from conftest import bank_settings, oracle_settings
+from conftest import assert_soft_bytes, bank_settings, oracle_settings
 
 pytestmark = pytest.mark.gpu
 
@@ -71,7 +71,7 @@ def test_messages_vs_oracle(B, oracle_mod, kind, nch, nsamp, chunk):
         n = len(ref["soft"])
         assert len(soft) == n + ref["pending"]
         assert np.array_equal(soft[:n] >= 128, ref["soft"] >= 128)
-        assert np.max(np.abs(soft[:n].astype(int) - ref["soft"].astype(int)), initial=0) <= 1
+        assert_soft_bytes(soft[:n], ref["soft"])
         assert log.shape == ref["status"].shape
         if len(log):
             assert np.array_equal(log[:, [0, 5]], ref["status"][:, [0, 5]])

@@ -8,7 +8,11 @@ import os
 import numpy as np
 import pytest
 
-from conftest import bank_settings, load_golden, oracle_settings
+from conftest import assert_soft_bytes, bank_settings, load_golden, oracle_settings
+
+# 8400 bps behind 15 000 samples of digital silence: the prefilter is an FFT filter here and there (round-off differs), the loops re-acquire
+# with an AGC window full of zeros; soft bytes on a rounding edge may differ by one -- counted (see conftest.assert_soft_bytes)
+SILENCE_8400_ALLOW = 64
 
 pytestmark = pytest.mark.gpu
 SYM_TOL = 1e-5  # north_star tolerance on soft symbol values
@@ -42,7 +46,7 @@ def compare(got_soft, got_sym, got_log, ref, check_ebno=True):
     n = len(ref["soft"])
     assert len(got_soft) == n + ref["pending"]
     assert np.array_equal(got_soft[:n] >= 128, ref["soft"] >= 128), "hard decisions differ"
-    assert np.max(np.abs(got_soft[:n].astype(int) - ref["soft"].astype(int)), initial=0) <= 1
+    assert_soft_bytes(got_soft[:n], ref["soft"])
     if "symbols" in ref:
         assert got_sym.shape == ref["symbols"].shape
         d = np.abs(got_sym - ref["symbols"])
@@ -70,7 +74,7 @@ def test_against_reference_golden(B, name):
     n = len(g["soft"])
     assert n <= len(soft) < n + 32
     assert np.array_equal(soft[:n] >= 128, g["soft"] >= 128)
-    assert np.max(np.abs(soft[:n].astype(int) - g["soft"].astype(int)), initial=0) <= 1
+    assert_soft_bytes(soft[:n], g["soft"])
     assert log.shape == g["status"].shape
     assert np.array_equal(log[:, [0, 5]], g["status"][:, [0, 5]])
     assert np.max(np.abs(log[:, 1:4] - g["status"][:, 1:4])) < 1e-6
@@ -93,7 +97,7 @@ def test_8400_against_reference_golden(B, name):
     n = len(g["soft"])
     assert n <= len(soft) < n + 32
     assert np.array_equal(soft[:n] >= 128, g["soft"] >= 128)
-    assert np.max(np.abs(soft[:n].astype(int) - g["soft"].astype(int)), initial=0) <= 1
+    assert_soft_bytes(soft[:n], g["soft"])
     assert log.shape == g["status"].shape
     assert np.array_equal(log[:, [0, 5]], g["status"][:, [0, 5]])
     assert np.max(np.abs(log[:, 1:4] - g["status"][:, 1:4])) < 1e-6
@@ -168,7 +172,7 @@ def test_8400_small_writes_and_digital_silence(B, oracle_mod, chunk):
     n = len(ref["soft"])
     assert len(soft) == n + ref["pending"]
     assert np.array_equal(soft[:n] >= 128, ref["soft"] >= 128), "hard decisions differ"
-    assert np.max(np.abs(soft[:n].astype(int) - ref["soft"].astype(int)), initial=0) <= 1
+    assert_soft_bytes(soft[:n], ref["soft"], allow=SILENCE_8400_ALLOW)
     assert sym.shape == ref["symbols"].shape and log.shape == ref["status"].shape
     assert np.array_equal(log[:, [0, 5]], ref["status"][:, [0, 5]])
     # soft symbols and status: the north star's 1e-5 up to the end of the silence (symbol 4812 = sample 55 000).  Behind it the loops

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import assert_soft_bytes, load_golden
 
 NAME = "recording_oqpsk_10k5"
 
@@ -71,21 +71,21 @@ def test_gpu_bank_on_the_recording(oracle_mod):
         m = len(ref["soft"])
         assert len(soft) == m + ref["pending"], c
         assert np.array_equal(soft[:m] >= 128, ref["soft"] >= 128), f"channel {c}: hard decisions differ"
-        assert np.max(np.abs(soft[:m].astype(int) - ref["soft"].astype(int)), initial=0) <= 1, c
+        assert_soft_bytes(soft[:m], ref["soft"], f"channel {c}")
         assert sym.shape == ref["symbols"].shape, c
         d = np.abs(sym - ref["symbols"]).max(axis=1)
         worst.append(float(d.max(initial=0.0)))
-        # Four of these five channels agree with the oracle to 1e-12 over all 57 749 symbols.  The one starting 1234 samples in agrees to 1e-13
-        # for 25 282 symbols, then once steps 1.6e-4 away and drifts back (4e-8 at the end): the device library's atan2 / hypot differ from the
-        # host's by one ulp in a quarter of the calls, and where that ulp decides on which side of a sample a symbol instant
-        # falls, the timing loop takes the other branch and re-converges.  Hard decisions equal, soft bytes within one (above).
-        assert d.max(initial=0.0) < 1e-3 and (d >= 1e-5).sum() <= 0.02 * len(d), c
+        # The north star's tolerance on EVERY symbol of EVERY channel.  Until round 5 the channel starting 1234 samples in stepped 1.6e-4 away at
+        # symbol 25 282 and drifted back: the device library's hypot differs from glibc's by an ulp in 14.5 % of the calls, and at that place of
+        # the recording the loops amplify it (reproduced on the CPU by perturbing the oracle's hypot: DESIGN 9 item 18).  The kernels now call
+        # glibc 2.35's hypot restated operation for operation and a correctly rounded atan2 (jaero_amd/csrc/jd_libm.h).
+        assert d.max(initial=0.0) < 1e-5, (c, float(d.max(initial=0.0)), int(d.argmax()))
         assert log.shape == ref["status"].shape and np.array_equal(log[:, [0, 5]], ref["status"][:, [0, 5]]), c
-        assert np.max(np.abs(log[:, 1:5] - ref["status"][:, 1:5])) < 1e-4, c
+        assert np.max(np.abs(log[:, 1:5] - ref["status"][:, 1:5])) < 1e-6, c
         if c == 0:
             k = min(m, len(g["soft"]))
             assert np.array_equal(soft[:k] >= 128, g["soft"][:k] >= 128)  # the unmodified reference's own decisions
-    assert sum(w < 1e-5 for w in worst) >= nch - 1, worst  # the north star's tolerance, on at least four of the five
+    assert max(worst) < 1e-5, worst  # the north star's tolerance, on all five
     demod.close()
     # PCM -> soft bits -> signal units without leaving the device, half a second per write
     demod = B.DemodulatorBank(B.OqpskSettings(), nch, device=0, max_write_samples=24000, softbit_capacity=8192)
