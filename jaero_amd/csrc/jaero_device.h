@@ -195,7 +195,9 @@ __device__ __forceinline__ int jd_softbit(double v)
 // (kind, fb, Fs) and banks of different (fb, Fs) are alive together (tests/test_gpu_scale.py::test_msk_family_banks_alive_together).
 
 // Matched-filter evaluation for one sample of 64 channels (one per lane): sum over i of taps[i] * x[n-FIRN+i], oldest first,
-// re and im chains, one fma per tap and chain (the order and the fusing of DSP.cpp's FIR::FIRUpdateAndProcess).
+// re and im chains, one multiplication and one addition per tap and chain, each rounded: FIR::FIRUpdateAndProcess (DSP.cpp:292-304) as the
+// reference's x86-64 release build executes it (mulsd, addsd: checked in the binary).  Until round 5 this was one fma per tap, the last
+// arithmetic difference between these kernels and the reference.
 // History: the oldest TAILN = FIRN-LDSN inputs in registers (tre[j] = x[n-LDSN-1-j]), the newest LDSN in an LDS ring
 // ([slot][lane], oldest at fir_slot).  The taps are read from LDS too (ltap, a wave-uniform address: a broadcast), NOT from
 // the constant segment: LDS operations return in order, so the compiler can wait for exactly the read it needs (lgkmcnt(N))
@@ -229,8 +231,8 @@ __device__ __forceinline__ void jd_fir_eval(const double *lre, const double *lim
         const int q = s % D;
         const double xr = (s < TAILN) ? tre[(TAILN - 1 - s) < 0 ? 0 : (TAILN - 1 - s)] : pr[q];
         const double xi = (s < TAILN) ? tim[(TAILN - 1 - s) < 0 ? 0 : (TAILN - 1 - s)] : pi[q];
-        are = fma(pt[q], xr, are);
-        aim = fma(pt[q], xi, aim);
+        are = are + pt[q] * xr;
+        aim = aim + pt[q] * xi;
         // keep the software pipeline as written: the empty asm orders the two fmas before the next read (without it instruction
         // selection places every pure arithmetic instruction after the last read: all 94 reads first, 260 registers of them)
         asm volatile("" : "+v"(are), "+v"(aim));
@@ -249,7 +251,7 @@ struct JTaps28 { double t[28]; };
 // versions, one per ring position, each with compile-time LDS offsets; a switch picks one.  All wavefronts of a CU are in the same one
 // or two versions at any time, so the instruction cache sees little of the ~30 KiB this unrolls to.
 typedef __attribute__((address_space(3))) const double jd_lds_cdouble;
-template <int FIRN, int LDSN, int D, int S, int TAP0>
+template <int FIRN, int LDSN, int D, int S, int TAP0, int NQ = LDSN>
 __device__ __forceinline__ void jd_fir_lds_part(jd_lds_cdouble *lre_l, jd_lds_cdouble *lim_l, const JTaps28 &tp, double &are, double &aim)
 {
     constexpr int TAILN = TAP0; // tap index that meets the oldest LDS entry
@@ -258,15 +260,15 @@ __device__ __forceinline__ void jd_fir_lds_part(jd_lds_cdouble *lre_l, jd_lds_cd
     for (int q = 0; q < D; q++) { pr[q] = lre_l[((S + q) % LDSN) * 64]; pi[q] = lim_l[((S + q) % LDSN) * 64]; }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q = 0; q < LDSN; q++)
+    for (int q = 0; q < NQ; q++)
     {
         const int s = TAILN + q;
         const double tap = tp.t[s <= 27 ? s : 54 - s];
-        are = fma(tap, pr[q % D], are);
-        aim = fma(tap, pi[q % D], aim);
+        are = are + tap * pr[q % D];
+        aim = aim + tap * pi[q % D];
         // keep the software pipeline as written (see jd_fir_eval)
         asm volatile("" : "+v"(are), "+v"(aim));
-        if (q + D < LDSN) { pr[q % D] = lre_l[((S + q + D) % LDSN) * 64]; pi[q % D] = lim_l[((S + q + D) % LDSN) * 64]; }
+        if (q + D < NQ) { pr[q % D] = lre_l[((S + q + D) % LDSN) * 64]; pi[q % D] = lim_l[((S + q + D) % LDSN) * 64]; }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -282,8 +284,8 @@ __device__ __forceinline__ void jd_fir_eval_sym(const double *lre, const double 
     for (int s = 0; s < TAILN; s++)
     {
         const double tap = tp.t[s <= 27 ? s : 54 - s];
-        are = fma(tap, tre[TAILN - 1 - s], are);
-        aim = fma(tap, tim[TAILN - 1 - s], aim);
+        are = are + tap * tre[TAILN - 1 - s];
+        aim = aim + tap * tim[TAILN - 1 - s];
     }
     int slot = fir_slot;
 #pragma unroll 1
@@ -291,8 +293,8 @@ __device__ __forceinline__ void jd_fir_eval_sym(const double *lre, const double 
     {
         const int s = TAILN + q;
         const double tap = tp.t[s <= 27 ? s : 54 - s]; // a scalar load per step: this is the once-per-launch path
-        are = fma(tap, lre[slot * 64 + lane], are);
-        aim = fma(tap, lim[slot * 64 + lane], aim);
+        are = are + tap * lre[slot * 64 + lane];
+        aim = aim + tap * lim[slot * 64 + lane];
         slot++;
         if (slot >= LDSN) slot = 0;
     }
@@ -310,11 +312,44 @@ __device__ __forceinline__ void jd_fir_eval_sym_static(const double *lre, const 
     for (int s = 0; s < TAILN; s++)
     {
         const double tap = tp.t[s <= 27 ? s : 54 - s];
-        are = fma(tap, tre[TAILN - 1 - s], are);
-        aim = fma(tap, tim[TAILN - 1 - s], aim);
+        are = are + tap * tre[TAILN - 1 - s];
+        aim = aim + tap * tim[TAILN - 1 - s];
     }
 #define JD_FIR_CASE(S) case S: if constexpr (S < LDSN) jd_fir_lds_part<FIRN, LDSN, D, (S < LDSN ? S : 0), FIRN - LDSN>(lre_l, lim_l, tp, are, aim); break;
     switch (fir_slot)
+    {
+        JD_FIR_CASE(0) JD_FIR_CASE(1) JD_FIR_CASE(2) JD_FIR_CASE(3) JD_FIR_CASE(4) JD_FIR_CASE(5) JD_FIR_CASE(6) JD_FIR_CASE(7)
+        JD_FIR_CASE(8) JD_FIR_CASE(9) JD_FIR_CASE(10) JD_FIR_CASE(11) JD_FIR_CASE(12) JD_FIR_CASE(13) JD_FIR_CASE(14) JD_FIR_CASE(15)
+        JD_FIR_CASE(16) JD_FIR_CASE(17) JD_FIR_CASE(18) JD_FIR_CASE(19) JD_FIR_CASE(20) JD_FIR_CASE(21) JD_FIR_CASE(22) JD_FIR_CASE(23)
+        JD_FIR_CASE(24) JD_FIR_CASE(25) JD_FIR_CASE(26) JD_FIR_CASE(27) JD_FIR_CASE(28) JD_FIR_CASE(29) JD_FIR_CASE(30) JD_FIR_CASE(31)
+        JD_FIR_CASE(32) JD_FIR_CASE(33) JD_FIR_CASE(34) JD_FIR_CASE(35) JD_FIR_CASE(36) JD_FIR_CASE(37) JD_FIR_CASE(38) JD_FIR_CASE(39)
+    default: break;
+    }
+#undef JD_FIR_CASE
+    ore = are; oim = aim;
+}
+
+// The same sum WITHOUT its last term (the newest input): the 54 older terms do not depend on the sample being formed, so a front half that
+// is alone on its SIMD (one pair per workgroup: banks of at most 2 x #CUs groups) evaluates them while the carrier oscillator's table value
+// for that sample is still on its way from L2, and adds tap[54] x[n] from registers when it arrives.  Call BEFORE the new input overwrites
+// LDS slot `slot_old` (which holds the oldest LDS entry; the caller has already moved it into tre[0] / tim[0]).
+template <int FIRN, int LDSN, int D, int TAILA>
+__device__ __forceinline__ void jd_fir_eval_sym_static_but_last(const double *lre, const double *lim, const JTaps28 &tp, const double (&tre)[TAILA],
+                                                                const double (&tim)[TAILA], int slot_old, int lane, double &ore, double &oim)
+{
+    static_assert(FIRN == 55 && LDSN <= 40 && LDSN >= 8, "symmetric-tap filter is the 55-tap RRC; the switch below has 40 cases");
+    constexpr int TAILN = FIRN - LDSN;
+    jd_lds_cdouble *lre_l = (jd_lds_cdouble *)lre + lane, *lim_l = (jd_lds_cdouble *)lim + lane;
+    double are = 0, aim = 0;
+#pragma unroll
+    for (int s = 0; s < TAILN; s++)
+    {
+        const double tap = tp.t[s <= 27 ? s : 54 - s];
+        are = are + tap * tre[TAILN - 1 - s];
+        aim = aim + tap * tim[TAILN - 1 - s];
+    }
+#define JD_FIR_CASE(S) case S: if constexpr (S < LDSN) jd_fir_lds_part<FIRN, LDSN, D, (S < LDSN ? (S + 1) % LDSN : 0), FIRN - LDSN, LDSN - 1>(lre_l, lim_l, tp, are, aim); break;
+    switch (slot_old)
     {
         JD_FIR_CASE(0) JD_FIR_CASE(1) JD_FIR_CASE(2) JD_FIR_CASE(3) JD_FIR_CASE(4) JD_FIR_CASE(5) JD_FIR_CASE(6) JD_FIR_CASE(7)
         JD_FIR_CASE(8) JD_FIR_CASE(9) JD_FIR_CASE(10) JD_FIR_CASE(11) JD_FIR_CASE(12) JD_FIR_CASE(13) JD_FIR_CASE(14) JD_FIR_CASE(15)

@@ -174,9 +174,13 @@ JDA_FN double jd_hypot(double x, double y)
     return res;
 }
 
-#if defined(JD_LIBRARY_LIBM) && !defined(JDA_HOST_CHECK)
-// A/B build only (make -C jaero_amd/csrc ab -> gpurun_tmp/libjaero_hip_libm.so, loaded through JAERO_HIP_LIB by scripts/recording_full.py):
-// the device library's functions, as the kernels called them until round 4.  Never the product.
+#if !defined(JDA_HOST_CHECK)
+// A/B builds only (make -C jaero_amd/csrc ab -> gpurun_tmp/libjaero_hip_libm.so / _libatan2.so, loaded through JAERO_HIP_LIB by
+// scripts/recording_full.py and bench.py): the device library's functions, as the kernels called them until round 4.  Never the product.
+#if defined(JD_LIBRARY_LIBM)
 #define jd_hypot(x, y) hypot(x, y)
+#endif
+#if defined(JD_LIBRARY_LIBM) || defined(JD_LIBRARY_ATAN2)
 #define jd_atan2(y, x, T) atan2(y, x)
+#endif
 #endif

@@ -78,8 +78,8 @@ __device__ __forceinline__ void bmsk_front(const BGeom &g, const BPtrs &p, doubl
         for (int t = 0; t < TAILN; t++)
         {
             const double tp = taps[t];
-            sre = fma(tp, tre[TAILN - 1 - t], sre);
-            sim = fma(tp, tim[TAILN - 1 - t], sim);
+            sre = sre + tp * tre[TAILN - 1 - t];
+            sim = sim + tp * tim[TAILN - 1 - t];
         }
         constexpr unsigned RING = (unsigned)LDSN * 512u;
         constexpr int NB = LDSN / 8;
@@ -106,8 +106,8 @@ __device__ __forceinline__ void bmsk_front(const BGeom &g, const BPtrs &p, doubl
             for (int u = 0; u < 8; u++)
             {
                 const double tp = taps[TAILN + 8 * b + u];
-                sre = fma(tp, xr[b & 1][u], sre);
-                sim = fma(tp, xi[b & 1][u], sim);
+                sre = sre + tp * xr[b & 1][u];
+                sim = sim + tp * xi[b & 1][u];
             }
         }
     };

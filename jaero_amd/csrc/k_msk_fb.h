@@ -83,8 +83,8 @@ __device__ __forceinline__ void mfb_fir_continue(const double *lre, const double
         const int q = s % D;
         const double xr = (s < TAILN) ? tre[(TAILN - 1 - s) < 0 ? 0 : (TAILN - 1 - s)] : pr[q];
         const double xi = (s < TAILN) ? tim[(TAILN - 1 - s) < 0 ? 0 : (TAILN - 1 - s)] : pi[q];
-        are = fma(pt[q], xr, are);
-        aim = fma(pt[q], xi, aim);
+        are = are + pt[q] * xr;
+        aim = aim + pt[q] * xi;
         asm volatile("" : "+v"(are), "+v"(aim)); // keeps the software pipeline as written (see jd_fir_eval)
         if (s + D < NT) fetch(s + D, q);
         __builtin_amdgcn_sched_barrier(0);
@@ -354,8 +354,8 @@ __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const M
         for (int t = 0; t < TB; t++)
         {
             const double tp = L.ltap[t];
-            are = fma(tp, tbr[TB - 1 - t], are);
-            aim = fma(tp, tbi[TB - 1 - t], aim);
+            are = are + tp * tbr[TB - 1 - t];
+            aim = aim + tp * tbi[TB - 1 - t];
         }
         ore = are; oim = aim;
     };
@@ -376,8 +376,8 @@ __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const M
             for (int t = 0; t < TB; t++)
             {
                 const double tp = p.taps2[t];
-                are = fma(tp, tbr[TB - 1 - t], are);
-                aim = fma(tp, tbi[TB - 1 - t], aim);
+                are = are + tp * tbr[TB - 1 - t];
+                aim = aim + tp * tbi[TB - 1 - t];
             }
             acc_last_re = are; acc_last_im = aim;
         }

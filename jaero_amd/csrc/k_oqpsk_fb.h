@@ -30,7 +30,38 @@
 #pragma once
 #include "jaero_device.h"
 
-#define FB_DEFER 16
+// The queue is ONE symbol deep, so the batch interval must not exceed the distance between two symbols of a lane (48 000 / 5 250 = 9.14
+// samples at 10.5 kbps, 11.4 at 8400 bps): with 16 (rounds 2-4) a lane's next symbol arrived before the batch in 43 % of the cases, took the
+// "a lane about to queue a second one goes first" path below, and with 64 unsynchronised lanes that path -- the whole output half for one or two
+// lanes -- ran in 95 % of the samples (the phase trace of round 5 found it: 1.03 us of the back half's 2.94 per sample).
+#define FB_DEFER 8
+
+// Phase trace of the sample loop (scripts/gpu_r5.sh trace): the trace build (make -C jaero_amd/csrc trace) reads the 100 MHz
+// clock at five points of a sample in either half, every wavefront alike (so that no wavefront waits for a slower, traced one), and one pair
+// adds its sums to g_fb_trace at the end of the launch; jaero_destroy prints them (a JSON line on stderr).  In the product build the macros are empty.
+#ifdef FB_TRACE_BUILD
+__device__ unsigned long long g_fb_trace[2][8];
+#define FB_TRACE_DECL unsigned long long tr_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long tr_prev = wall_clock64()
+#define FB_TRACE(k)                                                                                                                                           \
+    do {                                                                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                                                    \
+        const unsigned long long t_ = wall_clock64();                                                                                                         \
+        tr_acc[k] += t_ - tr_prev; tr_prev = t_;                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                                                    \
+    } while (0)
+#define FB_TRACE_FLUSH(which, nsamp)                                                                                                                          \
+    do {                                                                                                                                                      \
+        if (lane == 0 && grp == (g.ngroups > 600 ? 597 : 0))                                                                                                  \
+        {                                                                                                                                                     \
+            for (int k_ = 0; k_ < 6; k_++) atomicAdd(&g_fb_trace[which][k_], tr_acc[k_]);                                                                    \
+            atomicAdd(&g_fb_trace[which][6], (unsigned long long)(nsamp));                                                                                    \
+        }                                                                                                                                                     \
+    } while (0)
+#else
+#define FB_TRACE_DECL
+#define FB_TRACE(k)
+#define FB_TRACE_FLUSH(which, nsamp)
+#endif
 #define FB_LDSN 36 // filter history slots in LDS: 36 KiB + mailboxes (+ a spare 512 B) = 40 448 B per pair, four pairs per CU (161 792 of 163 840 B)
 
 // x / d for a positive constant d with rd = 1.0 / d (correctly rounded): q = x*rd is within an ulp, two Newton corrections through exact
@@ -98,7 +129,7 @@ __device__ __forceinline__ void fb_barrier()
 // carrier NCO's value OF THE SAME SAMPLE (oqpskdemodulator.cpp:436-448), so the front half cannot run ahead of the back half: the two
 // take turns (two barriers per sample).  What the split still buys there: the back half's code (queued output half, exact rewrites)
 // instead of the single-wavefront kernel's, and the A-part of a sample (coarse ring fill, next inputs) under the back half's work.
-template <int FIRN, int LDSN, bool EBNO, bool PRE8400>
+template <int FIRN, int LDSN, bool EBNO, bool PRE8400, bool SOLO>
 __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &L, const int16_t *__restrict__ pcm, int pcm_stride, int n,
                                          int skip_a_first, int only_a_last, int fir_slot0, int grp, int lane, const JTaps28 &tp,
                                          const double2 *__restrict__ prefilt)
@@ -276,8 +307,10 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &
     }
     FB_SYNC(L);
 
+    FB_TRACE_DECL;
     for (int i = 0; i < nB; i++)
     {
+        FB_TRACE(0); // the barrier
         // the carrier NCO's table value for sample i (index handed over by the back half): an L2 hit a few hundred ns away; the
         // register half of the history shifts meanwhile.  (Summing 54 of the 55 filter terms of the next output under that latency
         // -- jd_fir_partial_static -- was measured and is SLOWER, 15.3 against 13.7 ms per step: on the shared SIMD the front half's wait
@@ -295,14 +328,20 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &
         const double2 cc = nx_cc;
         const bool do_fill = !(i == 0 && skip_a_first) && ((coarse_cnt >= g.Fs_int) || !(flags & JF_CPUREDUCE));
         __builtin_amdgcn_sched_barrier(0);
+        // SOLO (one pair per workgroup, this wavefront alone on its SIMD): the 54 older terms of the next output under the gather's latency
+        // (on a SIMD shared with the back half the same thing is slower -- the comment above -- so the four-pair kernel does not do it)
+        double y_re = 0, y_im = 0;
+        if constexpr (SOLO)
+            if (i + 1 < nB) jd_fir_eval_sym_static_but_last<FIRN, LDSN, 6>(lre, lim, tp, tre, tim, fir_slot, lane, y_re, y_im);
+        const double cre = c_m2.x * dval, cim = c_m2.y * dval;
         {
-            const double cre = c_m2.x * dval, cim = c_m2.y * dval;
             *hre = cre;
             *him = cim;
             fir_slot++;
             if (fir_slot >= LDSN) fir_slot = 0;
         }
         __builtin_amdgcn_sched_barrier(0);
+        FB_TRACE(1); // mailbox read, gather of the carrier table value, mix, push
         if (do_fill) ring_fill(make_double2(cc.x * dval, cc.y * dval));
         coarse_cnt++; // :431
         fb_wt_next(mc_ptr, mc_step);
@@ -319,15 +358,19 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &
             if (EBNO) r2_e = win[(size_t)wslot(wn, g.ebno_len) * 64];
         }
         __builtin_amdgcn_sched_barrier(0);
+        FB_TRACE(2); // coarse ring entry, oscillator step, requests for the next samples' rows
         if (i + 1 < nB)
         {
-            double y_re, y_im;
-            jd_fir_eval_sym_static<FIRN, LDSN, 6>(lre, lim, tp, tre, tim, fir_slot, lane, y_re, y_im);
+            if constexpr (SOLO) { y_re = y_re + tp.t[0] * cre; y_im = y_im + tp.t[0] * cim; } // tap[54] == tap[0] (bitwise symmetric), x[n] from registers
+            else jd_fir_eval_sym_static<FIRN, LDSN, 6>(lre, lim, tp, tre, tim, fir_slot, lane, y_re, y_im);
+            FB_TRACE(3); // the matched filter
             front_sample(y_re, y_im, r1_agc, r1_e, i + 1, (i + 1) & 1);
             r1_agc = r2_agc; r1_e = r2_e;
+            FB_TRACE(4); // EbNo sums, AGC, clip, mailbox write
         }
         FB_SYNC(L);
     }
+    FB_TRACE_FLUSH(0, nB);
     } // !PRE8400
     if (only_a_last) // the coarse estimate runs now; the next launch resumes with this sample's B-part
     {
@@ -490,8 +533,10 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, FbLds &L
     FB_SYNC(L);
 
     double m2fsum = 0; // PRE8400: mixer2_freq_sum of this launch (:447,607)
+    FB_TRACE_DECL;
     for (int i = 0; i < nB; i++)
     {
+        if constexpr (!PRE8400) FB_TRACE(0); // the barrier
         if constexpr (PRE8400)
         {
             FB_SYNC(L); // the front half has formed this sample with the table index published one barrier ago
@@ -527,6 +572,7 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, FbLds &L
             if (st_freq < (g.stref_freq - 0.1)) fb_wt_setfreq(st_freq, st_step, (g.stref_freq - 0.1), samplerate, r_samplerate);
             if (st_freq > (g.stref_freq + 0.1)) fb_wt_setfreq(st_freq, st_step, (g.stref_freq + 0.1), samplerate, r_samplerate);
         }
+        if constexpr (!PRE8400) FB_TRACE(1); // mailbox read, symbol timing: delays, resonator, atan2, oscillator nudges
         if (need_px) request_px(); // for the symbol queued in the previous sample
 
         // ---- K10..K14 at symbol instants (:487-595) ----
@@ -536,6 +582,7 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, FbLds &L
         const bool full = inst && (yui == 0); // yui flips to 1 at this instant: the instant that closes a symbol pair
         // queued output halves: all lanes together every FB_DEFER samples; a lane about to queue a second one goes first
         if (pend && (full || (i & (FB_DEFER - 1)) == 0)) output_half();
+        if constexpr (!PRE8400) FB_TRACE(2); // record requests, instant test, queued output halves (every 16th sample)
         if (inst)
         {
             const double pt_last = frac, pt_this = 1.0 - pt_last;
@@ -585,6 +632,7 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, FbLds &L
             }
         }
         sig2l_re = sre; sig2l_im = sim;
+        if constexpr (!PRE8400) FB_TRACE(3); // the instant block: interpolation, tanh, loop filter, carrier phase and frequency
 
         // ---- advance the NCOs (:600-603) and hand the next sample's carrier table index to the front half ----
         fb_wt_next(m2_ptr, m2_step);
@@ -598,8 +646,10 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, FbLds &L
             while (((int)st_ptr) >= JD_WTSIZE) st_ptr -= JD_WTSIZE;
         }
         nx_cst = cis[jd_cisidx(st_ptr)]; // the symbol NCO's table value for the next sample: in flight across the barrier
+        if constexpr (!PRE8400) FB_TRACE(4); // oscillators advance, hand-back of the carrier table index
         FB_SYNC(L);
     }
+    if constexpr (!PRE8400) FB_TRACE_FLUSH(1, nB);
     if (need_px) request_px();
     if (pend) output_half();
 
@@ -645,5 +695,5 @@ __global__ __launch_bounds__(PAIRS * 128) void k_oqpsk_fb(const JGeom g, const J
         return;
     }
     if (back) fb_back<CAPSYM, PRE8400>(g, p, L, n, only_a_last, grp, lane);
-    else fb_front<FIRN, LDSN, EBNO, PRE8400>(g, p, L, pcm, pcm_stride, n, skip_a_first, only_a_last, fir_slot0, grp, lane, tp, prefilt);
+    else fb_front<FIRN, LDSN, EBNO, PRE8400, (PAIRS == 1 && !PRE8400)>(g, p, L, pcm, pcm_stride, n, skip_a_first, only_a_last, fir_slot0, grp, lane, tp, prefilt);
 }

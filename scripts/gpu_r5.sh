@@ -1,0 +1,57 @@
+#!/bin/bash
+# Round 5 GPU pass A: the whole GPU suite (with the flags matrix and the recording at the contract), the driver's bench command, the whole
+# recording from five starting points with the product library AND with the A/B build that calls the device library's atan2 / hypot
+# (gpurun_tmp/libjaero_hip_libm.so), and the sample loop at bank sizes 1024 .. 65536 (what sub-wavefront groups could and could not buy).
+# usage: scripts/gpu_r5.sh <tag> [what...]   what: tests bench recording recording_ab variants trace sizes
+set -u
+TAG=${1:-r5a}; shift || true
+WHAT=${*:-tests bench recording sizes}
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
+has() { [[ " $WHAT " == *" $1 "* ]]; }
+cd "$R"
+if has tests; then
+  timeout 1500 python -m pytest tests -m gpu -q --durations=15 --tb=short > "$OUT/pytest_gpu_full.log" 2>&1
+  tail -30 "$OUT/pytest_gpu_full.log" > "$OUT/pytest_gpu.log"; grep -n "^E  \|^FAILED\|passed\|failed" "$OUT/pytest_gpu_full.log" | head -30
+  cp gpurun_out/soft_byte_ledger.json "$OUT/soft_byte_ledger.json" 2>/dev/null
+fi
+if has bench; then
+  SECONDS=0; ( timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2> "$OUT/bench.err" | tail -1 ) > "$OUT/bench_line.json"
+  echo "driver bench wall: ${SECONDS}s" | tee "$OUT/bench_wall.txt"; cut -c1-400 "$OUT/bench_line.json"; echo; tail -2 "$OUT/bench.err"
+fi
+if has recording; then
+  ( timeout 900 python scripts/recording_full.py gpu 2> "$OUT/recording_full.err" | tail -1 ) > "$OUT/recording_full_gpu.json"; cut -c1-600 "$OUT/recording_full_gpu.json"; echo
+fi
+if has recording_ab; then
+  ( JAERO_HIP_LIB=$R/gpurun_tmp/libjaero_hip_libm.so timeout 900 python scripts/recording_full.py gpu 2> "$OUT/recording_full_libm.err" | tail -1 ) > "$OUT/recording_full_gpu_device_libm.json"; cut -c1-600 "$OUT/recording_full_gpu_device_libm.json"; echo
+  # the same A/B on the bench's checked channels and its kernel times
+  ( JAERO_HIP_LIB=$R/gpurun_tmp/libjaero_hip_libm.so timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --as-written 0 2> "$OUT/bench_libm.err" | tail -1 ) > "$OUT/bench_line_device_libm.json"; cut -c1-300 "$OUT/bench_line_device_libm.json"; echo
+fi
+if has variants; then
+  # sample-loop cost of the exact functions: the product against A/B builds that call the device library's atan2 (libatan2) or atan2 and hypot (libm)
+  for v in product libatan2 libm; do
+    L=$R/jaero_amd/libjaero_hip.so; [ $v != product ] && L=$R/gpurun_tmp/libjaero_hip_$v.so
+    ( JAERO_HIP_LIB=$L timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --check-channels 0 2> "$OUT/bench_var_$v.err" | tail -1 ) > "$OUT/bench_line_var_$v.json"
+    python - "$OUT/bench_line_var_$v.json" $v <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1])); c=d["config"]
+print(sys.argv[2], d["value"], d["ms_per_step"], c.get("kernel_ms_per_step"), {k:(v["msamples_per_s"], v["ms_per_step"]) for k,v in (c.get("as_written") or {}).items() if isinstance(v,dict)})
+PY
+  done
+fi
+if has trace; then
+  for n in 65536 4096; do
+    JAERO_HIP_LIB=$R/gpurun_tmp/libjaero_hip_trace.so timeout 600 python bench.py --channels $n --steps 12 --warmup 4 --no-cpu-baseline --as-written 0 --check-channels 0 > "$OUT/trace_bench_$n.json" 2> "$OUT/trace_$n.err"
+    grep fb_trace "$OUT/trace_$n.err" | tail -1 > "$OUT/fb_trace_$n.json"; cat "$OUT/fb_trace_$n.json"
+  done
+fi
+if has sizes; then
+  for n in 1024 4096 16384 32768; do
+    ( timeout 300 python bench.py --channels $n --steps 12 --warmup 4 --no-cpu-baseline --as-written 0 --check-channels 0 2> "$OUT/bench_$n.err" | tail -1 ) > "$OUT/bench_line_${n}_channels.json"
+    python - "$OUT/bench_line_${n}_channels.json" <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1])); c=d["config"]
+print(c["channels_per_gpu"], d["value"], d["ms_per_step"], c.get("kernel_ms_per_step"))
+PY
+  done
+fi
+du -sh "$OUT"

@@ -44,14 +44,14 @@ def sort_ev(ev):
 
 def check_soft(got, ref, tag="", allow=None):
     """The burst demodulators' input passes an FFT filter (the Hilbert transform) whose round-off is not the reference FFT's, so a soft byte on
-    a rounding edge may differ by one: bounded by 1, counted in the session's ledger, and at most BURST_SOFT_ALLOW of the bytes of a stream."""
+    a rounding edge may differ by one: bounded by 1, counted in the session's ledger, and at most BURST_SOFT_ALLOW bytes of a stream."""
     assert len(got) == len(ref), tag
     assert np.array_equal(got == -1, ref == -1), "burst markers differ"
     assert np.array_equal(got >= 128, ref >= 128), "hard decisions differ"
-    assert_soft_bytes(got, ref, tag, allow=(max(1, int(len(ref) * BURST_SOFT_ALLOW)) if allow is None else allow))
+    assert_soft_bytes(got, ref, tag, allow=(BURST_SOFT_ALLOW if allow is None else allow))
 
 
-BURST_SOFT_ALLOW = 2e-3
+BURST_SOFT_ALLOW = 2  # per stream; the suite sees 1 differing byte among 1.1 million burst soft bytes (profiles/r5_soft_byte_ledger.json)
 
 
 def check_events(got, ref):

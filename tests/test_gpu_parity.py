@@ -12,7 +12,7 @@ from conftest import assert_soft_bytes, bank_settings, load_golden, oracle_setti
 
 # 8400 bps behind 15 000 samples of digital silence: the prefilter is an FFT filter here and there (round-off differs), the loops re-acquire
 # with an AGC window full of zeros; soft bytes on a rounding edge may differ by one -- counted (see conftest.assert_soft_bytes)
-SILENCE_8400_ALLOW = 64
+SILENCE_8400_ALLOW = 2  # the suite sees 1 of 9 472 in one of the four write patterns (profiles/r5_soft_byte_ledger.json)
 
 pytestmark = pytest.mark.gpu
 SYM_TOL = 1e-5  # north_star tolerance on soft symbol values
