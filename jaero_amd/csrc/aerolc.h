@@ -2,9 +2,9 @@
 // SURVEY 8 row f4, second half.  Included by jaero_hip.hip after aerol_host.h; reached through jaero_aerol_create(fb = 8400).
 //
 // Written from the oracle restatement (oracle/aerol_oracle.c, c_write / c_frame_done), which is pinned against the unmodified AeroL.
-// On an MI355X a single channel reproduces the reference golden and the oracle (voice bytes, signal units, events:
-// tests/test_gpu_aerol_c.py::test_golden_single_channel); the multi-channel tests of that file have not run yet (opt-in,
-// JAERO_TEST_AEROLC=1).  Correctness first, no tuning: one lane per channel walks the soft bits.
+// Golden + banks of 5 / 70 / 65 536 channels in both Viterbi layouts are green on the GPU (tests/test_gpu_aerol_c.py, test_gpu_scale_aerol.py);
+// the bank logic also runs on the CPU (tests/host_emul/aerolc_emul.cpp).  One lane per channel walks the soft bits around the unique word;
+// the body of a frame is jumped over and copied by a whole wavefront (k_aerolc_bulk, round 5).
 //
 // A frame = 104 unique-word bits (two 52-bit words, one per arm, OQPSKPreambleDetectorAndAmbiguityCorrection :811-900, tolerance 6)
 // + 4096 channel bits = 16 interleaver blocks of 64 x 4 -> deinterleaved and depunctured (rate 3/4, every 4th coded bit an
@@ -26,8 +26,13 @@
 enum
 {
     CI_CNTR, CI_REALIMAG, CI_GSLAST, CI_INV_REAL, CI_INV_IMAG, CI_DATACD, CI_DCDCOUNT, CI_POS, CI_HAS_BLOCK, CI_NFRAMES,
-    CI_SU_CNT, CI_V_CNT, CI_EV_CNT, CI_OVERFLOW, CI_DL2_PTR, CI_NBITS_LO, CI_NBITS_HI, CI_NFIELDS
+    CI_SU_CNT, CI_V_CNT, CI_EV_CNT, CI_OVERFLOW, CI_DL2_PTR, CI_NBITS_LO, CI_NBITS_HI,
+    // the stretches k_aerolc_bits jumped over in this round, for k_aerolc_bulk: input position of the first soft bit, its (post-increment) cntr,
+    // length, and the arm / inversion state in front of it (bit 0: realimag, bit 1: inverted real arm, bit 2: inverted imaginary arm)
+    CI_BULK_N, CI_BULK0_SRC, CI_BULK0_CNTR, CI_BULK0_LEN, CI_BULK0_FLAGS, CI_BULK1_SRC, CI_BULK1_CNTR, CI_BULK1_LEN, CI_BULK1_FLAGS,
+    CI_NFIELDS
 };
+#define CC_MINRUN 32 // shorter stretches are walked
 
 struct CGeom
 {
@@ -73,7 +78,21 @@ __device__ __forceinline__ void cc_event(const CGeom &g, const CPtrs &p, int ch,
     else overflow |= 2;
 }
 
-// lane = channel: DecodeC's loop over the soft bits (:2201-2316) up to the end of the next frame
+// received index cntr (post-increment, 0 .. CC_FRAME - 1) -> position in the deinterleaved + depunctured frame buffer, or -1 (the last
+// source byte is never used, :2509): interleaver block / row / column -> deinterleaved source index -> depunctured position
+__device__ __forceinline__ int cc_dep_index(int cntr)
+{
+    const int blk = cntr >> 8, r = cntr & 255;
+    const int i = ((r >> 2) * 19) & 63; // inverse of the row permutation (i * 27) % 64
+    const int src = blk * 256 + (r & 3) * 64 + i;
+    return src < CC_FRAME - 1 ? src + src / 3 : -1;
+}
+
+// Lane = channel: DecodeC's loop over the soft bits (:2201-2316) up to the end of the next frame.  For the soft bits whose pre-increment
+// cntr lies in [1, CC_FRAME - 112] DecodeC runs no unique-word detection: it toggles the arm, inverts by the arm's flag, counts and stores
+// -- 3984 of a frame's 4200 soft bits.  Such a stretch is not walked: the lane notes it (at most two per round) and k_aerolc_bulk copies
+// it with a whole wavefront, coalesced.  A third stretch in one round (two false unique words inside detection windows) ends the lane's
+// round early; the host runs enough rounds for that (aerolc_write).
 __global__ __launch_bounds__(64) void k_aerolc_bits(const CGeom g, const CPtrs p, const int16_t *__restrict__ soft, const int *__restrict__ counts, int stride)
 {
     const int ch = blockIdx.x * 64 + threadIdx.x;
@@ -89,9 +108,26 @@ __global__ __launch_bounds__(64) void k_aerolc_bits(const CGeom g, const CPtrs p
     const long long base = ((long long)(unsigned)CLD(CI_NBITS_LO)) | ((long long)CLD(CI_NBITS_HI) << 32);
     const int16_t *s = soft + (size_t)ch * stride;
     uint8_t *dep = p.dep + (size_t)ch * CC_NSOFT;
-    int has = 0;
-    while (pos < n && !has)
+    int has = 0, nbulk = 0, yield = 0;
+    while (pos < n && !has && !yield)
     {
+        if (cntr >= 1 && cntr <= CC_FRAME - 112)
+        {
+            const int room = (CC_FRAME - 112) - cntr + 1, left = n - pos;
+            const int len = room < left ? room : left;
+            if (len >= CC_MINRUN)
+            {
+                if (nbulk == 2) { yield = 1; continue; }
+                const int f0 = CI_BULK0_SRC + 4 * nbulk;
+                p.I[(size_t)(f0 + 0) * g.nchp + ch] = pos;
+                p.I[(size_t)(f0 + 1) * g.nchp + ch] = cntr + 1;
+                p.I[(size_t)(f0 + 2) * g.nchp + ch] = len;
+                p.I[(size_t)(f0 + 3) * g.nchp + ch] = (realimag & 1) | (inv[0] ? 2 : 0) | (inv[1] ? 4 : 0);
+                nbulk++;
+                pos += len; cntr += len; realimag = (realimag + len) & 1; gslast = 0;
+                continue;
+            }
+        }
         const int sv = s[pos];
         int bit = (((unsigned char)sv) >= 128) ? 1 : 0;
         unsigned soft_bit = (unsigned)(unsigned short)sv;
@@ -121,22 +157,45 @@ __global__ __launch_bounds__(64) void k_aerolc_bits(const CGeom g, const CPtrs p
             if (cntr < 1000000000) cntr++;
             if (cntr <= CC_FRAME - 1)
             {
-                // received index cntr -> interleaver block / row / column -> deinterleaved source index -> depunctured position
-                const int blk = cntr >> 8, r = cntr & 255;
-                const int i = ((r >> 2) * 19) & 63; // inverse of the row permutation (i * 27) % 64
-                const int src = blk * 256 + (r & 3) * 64 + i;
-                if (src < CC_FRAME - 1) dep[src + src / 3] = (uint8_t)soft_bit; // the last source byte is never used (:2509)
+                const int di = cc_dep_index(cntr);
+                if (di >= 0) dep[di] = (uint8_t)soft_bit;
             }
             if (cntr == CC_FRAME - 1) has = 1;
         }
         pos++;
     }
-    CLD(CI_POS) = pos; CLD(CI_HAS_BLOCK) = has;
+    CLD(CI_POS) = pos; CLD(CI_HAS_BLOCK) = has; CLD(CI_BULK_N) = nbulk;
     CLD(CI_CNTR) = cntr; CLD(CI_REALIMAG) = realimag; CLD(CI_GSLAST) = gslast;
     CLD(CI_INV_REAL) = inv[0]; CLD(CI_INV_IMAG) = inv[1];
     CLD(CI_EV_CNT) = ev_cnt; CLD(CI_OVERFLOW) = overflow;
 #pragma unroll
     for (int k = 0; k < 4; k++) p.B[(size_t)k * g.nchp + ch] = b[k];
+}
+
+// One wavefront per channel: stretch `k` (0 or 1) of those k_aerolc_bits jumped over in this round.  Launched once per k, in stream order:
+// a later stretch overwrites an earlier one's positions (a frame abandoned for a new unique word), and the kernel boundary is what orders
+// the two for every lane.  The walked soft bits of the same round never share a position with them (their cntr values lie outside
+// [2, CC_FRAME - 111]).
+__global__ __launch_bounds__(64) void k_aerolc_bulk(const CGeom g, const CPtrs p, const int16_t *__restrict__ soft, int stride, int k)
+{
+    const int ch = blockIdx.x;
+    if (ch >= g.nch) return;
+    if (k >= CLD(CI_BULK_N)) return;
+    const int16_t *s = soft + (size_t)ch * stride;
+    uint8_t *dep = p.dep + (size_t)ch * CC_NSOFT;
+    const int f0 = CI_BULK0_SRC + 4 * k;
+    const int src = p.I[(size_t)(f0 + 0) * g.nchp + ch], c0 = p.I[(size_t)(f0 + 1) * g.nchp + ch];
+    const int len = p.I[(size_t)(f0 + 2) * g.nchp + ch], fl = p.I[(size_t)(f0 + 3) * g.nchp + ch];
+    for (int j = threadIdx.x; j < len; j += blockDim.x)
+    {
+        const int sv = s[src + j];
+        unsigned soft_bit = (unsigned)(unsigned short)sv;
+        const int realimag = ((fl & 1) + j + 1) & 1;         // toggled before the bit is used (:2207)
+        const int inverted = realimag ? (fl & 2) : (fl & 4); // realimag != 0: the real arm's detector and flag
+        if (inverted) { if (soft_bit != 128) soft_bit = 255 - soft_bit; }
+        const int di = cc_dep_index(c0 + j);
+        if (di >= 0) dep[di] = (uint8_t)soft_bit;
+    }
 }
 
 // lane = channel: the end of a frame (:2318-2490) for the channels whose frame the Viterbi just decoded
@@ -303,13 +362,17 @@ static int aerolc_write(jaero_aerol_ctx *c, const int16_t *dsoft, const int *dco
     // a round finishes at most one frame per channel.  Frame ends are at least 4098 soft bits apart: the detector window reopens at
     // cntr > CC_FRAME - 112, so a (false or real) unique word can fire two bits after a completed frame and the next frame ends
     // CC_FRAME bits after that -- not CC_FRAME + 104 as in a clean stream.
-    const int rounds = max_count / (CC_FRAME + 1) + 2;
+    // A lane's round also ends when it meets a third jumpable stretch (k_aerolc_bits): it has then consumed at least one whole frame body
+    // (CC_FRAME - 112 soft bits), so the bound below covers that too.
+    const int rounds = max_count / (CC_FRAME - 112) + 2;
     const int *valid = cs->p.I + (size_t)CI_HAS_BLOCK * g.nchp;
     const dim3 grid(g.nchp / 64), block(64);
     for (int r = 0; r < rounds; r++)
     {
         aprof_begin(c, 0, st);
         hipLaunchKernelGGL(k_aerolc_bits, grid, block, 0, st, g, cs->p, dsoft, dcounts, stride);
+        hipLaunchKernelGGL(k_aerolc_bulk, dim3(g.nch), block, 0, st, g, cs->p, dsoft, stride, 0);
+        hipLaunchKernelGGL(k_aerolc_bulk, dim3(g.nch), block, 0, st, g, cs->p, dsoft, stride, 1); // (rare: most channels return at once)
         aprof_end(c, st);
         aprof_begin(c, 1, st);
         // one block per wavefront for small banks, one per lane (k_viterbi_lanes) from 16 384 channels on, as the P-channel pipeline

@@ -259,16 +259,21 @@ __device__ __forceinline__ void jd_fir_lds_part(jd_lds_cdouble *lre_l, jd_lds_cd
 #pragma unroll
     for (int q = 0; q < D; q++) { pr[q] = lre_l[((S + q) % LDSN) * 64]; pi[q] = lim_l[((S + q) % LDSN) * 64]; }
     __builtin_amdgcn_sched_barrier(0);
+    // products one step ahead of the sums: with multiplication and addition rounded separately (round 5) a step is mul, mul, add, add, and
+    // written in that order each addition waited for the multiplication issued right in front of it
+    auto tap_of = [&](int q) { const int s = TAILN + q; return tp.t[s <= 27 ? s : 54 - s]; };
+    double mr = tap_of(0) * pr[0], mi = tap_of(0) * pi[0];
 #pragma unroll
     for (int q = 0; q < NQ; q++)
     {
-        const int s = TAILN + q;
-        const double tap = tp.t[s <= 27 ? s : 54 - s];
-        are = are + tap * pr[q % D];
-        aim = aim + tap * pi[q % D];
+        double nr = 0, ni = 0;
+        if (q + 1 < NQ) { nr = tap_of(q + 1) * pr[(q + 1) % D]; ni = tap_of(q + 1) * pi[(q + 1) % D]; }
+        are = are + mr;
+        aim = aim + mi;
         // keep the software pipeline as written (see jd_fir_eval)
         asm volatile("" : "+v"(are), "+v"(aim));
         if (q + D < NQ) { pr[q % D] = lre_l[((S + q + D) % LDSN) * 64]; pi[q % D] = lim_l[((S + q + D) % LDSN) * 64]; }
+        mr = nr; mi = ni;
         __builtin_amdgcn_sched_barrier(0);
     }
 }

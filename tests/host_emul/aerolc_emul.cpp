@@ -100,10 +100,11 @@ extern "C" void emul_write(Emul *e, const int16_t *soft, const int *counts, int 
     const CGeom &g = e->g;
     std::vector<int> cnt(g.nchp, 0);
     for (int ch = 0; ch < g.nch; ch++) cnt[ch] = counts[ch];
-    const int rounds = max_count / (CC_FRAME + 104) + 2;
+    const int rounds = max_count / (CC_FRAME - 112) + 2; // as aerolc_write
     for (int r = 0; r < rounds; r++)
     {
         launch(g.nchp / 64, 64, [&] { k_aerolc_bits(g, e->p, soft, cnt.data(), stride); });
+        for (int k = 0; k < 2; k++) launch(g.nch, 64, [&] { k_aerolc_bulk(g, e->p, soft, stride, k); });
         for (int ch = 0; ch < g.nch; ch++) // k_viterbi + k_viterbi_overlap_update for the channels with a complete frame
             if (e->p.I[(size_t)CI_HAS_BLOCK * g.nchp + ch])
             {
