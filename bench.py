@@ -227,6 +227,22 @@ def burst_traffic(pmc_file: str, kernel_that_ran: str, nch: int):
         return None, f"profiles/{pmc_file} unreadable: {e}"
 
 
+def aerol_kernel_name(cls: str, nch: int, mode: str) -> str:
+    """The kernel that does the work of an Aero-L kernel class at this bank size (the Viterbi picks its layout by size: one block per lane from
+    16 384 blocks on, one per wavefront below: jaero_hip.hip viterbi_use_lanes)."""
+    vit = "k_viterbi_lanes" if nch >= 16384 else "k_viterbi"
+    if mode == "c":
+        return {"bits": "k_aerolc_bits", "viterbi": vit, "post": "k_aerolc_post"}[cls]
+    if mode == "b":
+        return {"bits": "k_aerolb_bits", "viterbi": "k_viterbi", "post": "k_aerolb_post"}[cls]
+    return {"bits": "k_aerol_bits", "viterbi": vit, "post": "k_aerol_post_packed" if nch >= 16384 else "k_aerol_post"}[cls]
+
+
+def aerol_traffic(pmc_file: str, kernel: str, nch: int):
+    """HBM bytes per working launch of `kernel` from a committed counter summary (entries keyed by kernel name), or (None, why)."""
+    return burst_traffic(pmc_file, kernel, nch)
+
+
 def cpu_baseline(chunk: int):
     """The reference's own CPU path timed on this box's host cores: one process per core (function-local statics
     make instances unshareable), each demodulating `n` samples of the same kind of synthetic signal."""
@@ -496,8 +512,10 @@ def aerol_bench():
                        "crc_clean_units_in_first_channels": good, "channels_checked": min(4, nch),
                        "kernel_ms_per_step": {k: round(v / K, 4) for k, v in ms.items()}, "kernel_launches": nl},
             "roofline": {"bound": "hbm", "kernel": {"bits": "k_aerol_bits+k_aerol_bulk+k_aerol_deint", "viterbi": "k_viterbi_lanes", "post": "k_aerol_post"}[dom],
+                         "kernel_name": aerol_kernel_name(dom, nch, "p"),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "alg_bytes_per_softbit": alg[dom],
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": aerol_traffic("pmc_summary_aerol.json", aerol_kernel_name(dom, nch, "p"), nch)[0],
+                         "traffic_from": aerol_traffic("pmc_summary_aerol.json", aerol_kernel_name(dom, nch, "p"), nch)[1], "alg_bytes_per_softbit": alg[dom],
                          "softbits_per_launch": units, "avg_launch_ms": round(avg_ms, 4),
                          "note": "the Viterbi is integer-VALU bound, not HBM bound: 225 wave instructions per trellis step for 64 blocks, "
                                  "one wavefront per SIMD issuing one instruction per ~2.2 ns (scripts/ubench/valu_rates.hip); "
@@ -578,6 +596,14 @@ def aerol_c_bench():
     if rank == 0:
         value = float(K) * flen * nch * world / dt / 1e6
         alg = 7.2
+        # per kernel class and soft bit: bits = 2 B int16 in + 1 B into the frame buffer; viterbi = 5460 symbols in + 2714 bits out per 4200;
+        # post = 2714 bits in, the delay line read and written, rows out
+        alg_k = {"bits": 3.0, "viterbi": 1.95, "post": 2.25}
+        dom = max(names, key=lambda k: ms[k])
+        avg_ms = ms[dom] / K
+        achieved_k = alg_k[dom] * flen * nch / (avg_ms * 1e-3) / 1e9
+        kname = aerol_kernel_name(dom, nch, "c")
+        tr, tr_from = aerol_traffic("pmc_summary_aerol_c.json", kname, nch)
         line = {
             "metric": "Msoftbits/s through the Aero-L C-channel bit pipeline (two-word unique word, 64x4 deinterleave, rate-3/4 depuncture, Viterbi, "
                       "delay line, descramble, sub-band signal units + voice bytes)",
@@ -590,10 +616,13 @@ def aerol_c_bench():
                        "realtime_channel_equivalents": int(value * 1e6 / 8400),
                        "crc_clean_units_in_first_channels": good, "channels_checked": min(4, nch), "voice_frames_checked": nvoice,
                        "kernel_ms_per_step": {k: round(v / K, 4) for k, v in ms.items()}, "kernel_launches": nl},
-            "roofline": {"bound": "hbm", "kernel": "whole step (k_aerolc_bits + k_viterbi + k_aerolc_post)", "achieved": round(alg * value * 1e6 / 1e9 / world, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * value * 1e6 / 1e9 / world / HBM_PEAK_GBS, 6), "traffic": None,
-                         "alg_bytes_per_softbit": alg,
-                         "note": "integer work bound by VALU issue and per-lane byte accesses (one lane walks a channel's soft bits), two orders below the HBM roof"},
+            "roofline": {"bound": "hbm", "kernel": dom, "kernel_name": kname, "achieved": round(achieved_k, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_k / HBM_PEAK_GBS, 6), "traffic": tr, "traffic_from": tr_from,
+                         "alg_bytes_per_softbit": alg_k[dom], "softbits_per_launch": flen * nch, "avg_launch_ms": round(avg_ms, 4),
+                         "whole_step": {"alg_bytes_per_softbit": alg, "achieved": round(alg * value * 1e6 / 1e9 / world, 2), "frac": round(alg * value * 1e6 / 1e9 / world / HBM_PEAK_GBS, 6)},
+                         "note": "the dominant kernel of the step (its HIP-event time per working launch); integer work bound by VALU issue (the Viterbi: 225 wave "
+                                 "instructions per trellis step for 64 blocks) and per-lane byte accesses, far below the HBM roof -- the figure is reported "
+                                 "because the contract asks for it"},
         }
         line["config"].update(rank_fields(world, shared, dts, value * 1e6 * dt / world))
         aerol_check_or_exit(line, oc, "signal-unit / voice rows / events")
@@ -800,8 +829,9 @@ def aerol_burst_bench():
                                    f"(marker, lead-in, unique word, T packet with 7 signal units, noise; {per} entries), {nuniq} distinct streams",
                        "channels_per_gpu": nch, "total_channels": nch * world, "packets_per_s": round(float(K) * nch * world / dt, 1),
                        "packets_decoded_in_first_channels": npk, "channels_checked": min(4, nch), "expected": (K + W) * min(4, nch)},
-            "roofline": {"bound": "hbm", "kernel": "k_viterbi (trial decodes, one block per wavefront)", "achieved": round(alg * value * 1e6 / 1e9, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * value * 1e6 / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "k_viterbi (trial decodes, one block per wavefront)", "kernel_name": "k_viterbi", "achieved": round(alg * value * 1e6 / 1e9, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * value * 1e6 / 1e9 / HBM_PEAK_GBS, 6),
+                         "traffic": aerol_traffic("pmc_summary_aerol_burst.json", "k_viterbi", nch)[0], "traffic_from": aerol_traffic("pmc_summary_aerol_burst.json", "k_viterbi", nch)[1],
                          "alg_bytes_per_softbit": round(alg, 2),
                          "note": "whole-step figure (the step is launch- and latency-bound: 31 rounds of 4 small kernels); the Viterbi trials "
                                  "are integer-VALU work, see the aerol workload"},
@@ -891,14 +921,28 @@ def cpu_baseline_continuous(chunk: int, fb: float):
             return sum(n / t for t in inner) / 1e6, time.time() - t0
 
         single, w1 = run(1)
-        value, wall = run(logical)
-    return {"value": round(value, 3), "unit": "Msamples/s", "cores": logical, "kind": "reference" if use_ref else "port",
+        # one process per physical core and one per logical CPU, three repeats each (the figure moves 40-57 Msamples/s between runs of the same
+        # command on this pool: VERDICT r4 item 14); the better median is the quoted value, both sets are in the line
+        sets = {}
+        wall = 0.0
+        for nproc in sorted({max(1, physical), max(1, logical)}):
+            vals = []
+            for _ in range(3):
+                v, w = run(nproc)
+                vals.append(v); wall += w
+            vals.sort()
+            sets[nproc] = vals
+        best = max(sets, key=lambda k: sets[k][1])
+        value = sets[best][1]
+    return {"value": round(value, 3), "unit": "Msamples/s", "cores": best, "kind": "reference" if use_ref else "port",
             "sample": f"{n} samples ({n / 48000.0:.1f} s) of 48 kHz {fb / 1000:g}k OQPSK per process, {chunk}-sample writes, cpuReduce=false, "
-                      f"one process per logical CPU ({wall:.1f} s wall)",
+                      f"{best} processes at once (median of three repeats; {wall:.1f} s wall for all {3 * len(sets)} runs)",
             "logical_cpus": logical, "physical_cores": physical, "cpu_model": model,
-            "single_process_msps": round(single, 3), "per_process_msps_all_busy": round(value / logical, 3),
-            "note": "FFT inside the reference build is the JFFT stand-in (oracle/ref/shim/jfft.h), not JFFT; with every logical CPU busy "
-                    "the per-process rate drops (shared caches / SMT / 3.5 MB of rings per process)"}
+            "single_process_msps": round(single, 3), "per_process_msps_all_busy": round(value / best, 3),
+            "repeats_msps": {str(k): [round(x, 3) for x in v] for k, v in sets.items()},
+            "note": "FFT inside the reference build is the JFFT stand-in (oracle/ref/shim/jfft.h), not JFFT; with every core busy "
+                    "the per-process rate drops (shared caches / SMT / 3.5 MB of rings per process); value = the better of one process per "
+                    "physical core and one per logical CPU, repeats_msps holds the three runs of each (sorted)"}
 
 
 def spread_channels(nch: int, k: int = 16):

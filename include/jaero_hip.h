@@ -129,8 +129,11 @@ void jaero_destroy(jaero_ctx *ctx);
 /* setSettings on a live channel (channel = -1: every channel): the channel's state becomes what the reference's setSettings leaves behind
  * (JAERO/oqpskdemodulator.cpp:175-289, JAERO/mskdemodulator.cpp:135-263).
  *   - freq_center / lockingbw / signalthreshold of one or all channels: in place, enqueued on the stream of the bank's last jaero_write.
- *   - fb, Fs or the FFT power (shared by the channels of a bank), and any setSettings of an 8400 bps bank (its prefilter restarts): whole bank
- *     only (channel = -1, or a one-channel bank).  The bank is re-created behind the handle and receives what the reference keeps in the old
+ *   - one channel of an 8400 bps bank (same fb / Fs / FFT power): in place as well; that channel's prefilter restarts as JFastFir::SetKernel
+ *     leaves it (empty history, 2048 exact zeros in front of its first output, JAERO/oqpskdemodulator.cpp:278-283) while the transform blocks
+ *     stay on the bank's grid of absolute multiples of 2048 samples -- the same filtered values up to transform round-off.
+ *   - fb, Fs or the FFT power (shared by the channels of a bank), and a setSettings of a WHOLE 8400 bps bank (every prefilter restarts, the
+ *     block grid with them): whole bank only (channel = -1, or a one-channel bank).  The bank is re-created behind the handle and receives what the reference keeps in the old
  *     object: oscillator phases, loop-filter / rotator / timing states, the symbol-rate windows (MSK: msema, the first entries of dt and
  *     delayedsmpl in buffer order), the EbNo meter of the OQPSK kind, the coarse ring and the smoothed spectrum, flags, unread outputs.
  *     Control plane: allocates and synchronises the device; pointers from the *_view calls are stale afterwards.  An OQPSK bank keeps Fs.
@@ -146,7 +149,7 @@ void jaero_destroy(jaero_ctx *ctx);
  *     Burst MSK with its other bit rate (600 <-> 1200 bps; whole bank): as for the continuous kinds a sibling bank takes the old one's place and
  *     receives what the reference keeps -- the DelayThings' first min(old, new) entries in storage order, startstop, oscillator phases, msema,
  *     unread outputs.
- *     JAERO_ENOTSUP: one channel of an 8400 bps bank; another Fs for a burst bank, another fb for burst OQPSK (create a new bank; the Qt
+ *     JAERO_ENOTSUP: another Fs for a burst bank, another fb for burst OQPSK (create a new bank; the Qt
  *     adaptors of integration/qt do). */
 int jaero_set_settings(jaero_ctx *ctx, int channel, const jaero_settings *s);
 int jaero_set_flags(jaero_ctx *ctx, int channel, int afc, int sql, int cpu_reduce);

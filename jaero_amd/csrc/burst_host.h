@@ -232,7 +232,7 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
     c->m.nch = nch; c->m.nchp = nchp;
     c->m.flags.assign(nchp, 0);
     // burst OQPSK: 39 of its 55 history slots + the taps in LDS; burst MSK: 39 of 80 (1200 bps) or all 160 (600 bps) slots
-    const int lds = oq ? (2 * 39 * 64 + 64) * (int)sizeof(double) : 2 * (g.fir_n == 80 ? BMSK_FB_LDSN_80 : BMSK_FB_LDSN_160) * 64 * (int)sizeof(double) + BMSK_FB_MAIL_BYTES + BMSK_FB_WC_BYTES(g.fir_n == 80) + BMSK_FB_D8_BYTES(g.fir_n == 80, g.d8_len) + BMSK_FB_ATAN_BYTES;
+    const int lds = oq ? (2 * 39 * 64 + 64) * (int)sizeof(double) : 2 * (g.fir_n == 80 ? BMSK_FB_LDSN_80 : BMSK_FB_LDSN_160) * 64 * (int)sizeof(double) + BMSK_FB_MAIL_BYTES + BMSK_FB_WC_BYTES(g.fir_n == 80) + BMSK_FB_D8_BYTES(g.fir_n == 80, g.d8_len);
     if (oq)
     {
         HIPCHK(hipFuncSetAttribute((const void *)k_burst_oqpsk_demod<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -276,7 +276,7 @@ static int burst_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int layou
         prof_end(c, pi, st);
     }
     const bool cs = (c->flags & JAERO_FLAG_CAPTURE_SYMBOLS) != 0;
-    const int lds = g.kind == JAERO_KIND_BURST_OQPSK ? (2 * 39 * 64 + 64) * (int)sizeof(double) : 2 * (g.fir_n == 80 ? BMSK_FB_LDSN_80 : BMSK_FB_LDSN_160) * 64 * (int)sizeof(double) + BMSK_FB_MAIL_BYTES + BMSK_FB_WC_BYTES(g.fir_n == 80) + BMSK_FB_D8_BYTES(g.fir_n == 80, g.d8_len) + BMSK_FB_ATAN_BYTES;
+    const int lds = g.kind == JAERO_KIND_BURST_OQPSK ? (2 * 39 * 64 + 64) * (int)sizeof(double) : 2 * (g.fir_n == 80 ? BMSK_FB_LDSN_80 : BMSK_FB_LDSN_160) * 64 * (int)sizeof(double) + BMSK_FB_MAIL_BYTES + BMSK_FB_WC_BYTES(g.fir_n == 80) + BMSK_FB_D8_BYTES(g.fir_n == 80, g.d8_len);
     int first = 1;
     c->poisoned = true; // the history push above is idempotent (same slots if the write is repeated); from here on state advances
     for (int pos = 0; pos < nsamples;)

@@ -204,7 +204,11 @@ __device__ __forceinline__ int jd_softbit(double v)
 // while D steps are in flight; with one scalar load pending it has to drain everything (lgkmcnt(0)).  Written as a plain
 // loop, every tap was: ds_read, s_waitcnt lgkmcnt(0), 2 x v_fmac -- one LDS round trip per tap, 40 per sample, and with a
 // single wavefront per SIMD nothing else to run meanwhile (SQ_WAIT_ANY was 45 % of the wave's cycles).
-template <int FIRN, int LDSN, int D, int TAILA>
+// FUSED (one fma per tap and chain) is for the burst demodulators only: their input has passed an FFT filter (the Hilbert transform) whose
+// round-off is not the reference FFT's, and measured on a bank of bursts the op-for-op filter, glibc's hypot and the correctly rounded atan2
+// change neither a soft byte nor the distribution of soft-symbol differences there, while costing 10 % of both burst workloads
+// (profiles/r5_burst_ab.json).  The continuous demodulators, whose whole chain IS the reference's op for op, never fuse.
+template <int FIRN, int LDSN, int D, bool FUSED = false, int TAILA = 1>
 __device__ __forceinline__ void jd_fir_eval(const double *lre, const double *lim, const double *ltap, const double (&tre)[TAILA],
                                             const double (&tim)[TAILA], int fir_slot, int lane, double &ore, double &oim)
 {
@@ -231,9 +235,9 @@ __device__ __forceinline__ void jd_fir_eval(const double *lre, const double *lim
         const int q = s % D;
         const double xr = (s < TAILN) ? tre[(TAILN - 1 - s) < 0 ? 0 : (TAILN - 1 - s)] : pr[q];
         const double xi = (s < TAILN) ? tim[(TAILN - 1 - s) < 0 ? 0 : (TAILN - 1 - s)] : pi[q];
-        are = are + pt[q] * xr;
-        aim = aim + pt[q] * xi;
-        // keep the software pipeline as written: the empty asm orders the two fmas before the next read (without it instruction
+        if constexpr (FUSED) { are = fma(pt[q], xr, are); aim = fma(pt[q], xi, aim); }
+        else { are = are + pt[q] * xr; aim = aim + pt[q] * xi; }
+        // keep the software pipeline as written: the empty asm orders the two sums before the next read (without it instruction
         // selection places every pure arithmetic instruction after the last read: all 94 reads first, 260 registers of them)
         asm volatile("" : "+v"(are), "+v"(aim));
         if (s + D < FIRN) fetch(s + D, q);

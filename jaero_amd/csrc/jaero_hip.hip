@@ -607,6 +607,7 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         DA(c->pre.xring, (size_t)ring * nchp);
         DA(c->pre.cidx, (size_t)max_write_samples * nchp);
         DA(c->pre.out, (size_t)max_write_samples * nchp);
+        DA(c->pre.hold, (size_t)nchp); // zeros (DA clears): nothing held
         double *d_pre_taps = nullptr;
         DA(d_pre_taps, PRE_K);
         const std::vector<double> pt = rrc_design(0.6, 2048, g.Fs, g.fb / 2); // rrc_pre_imp (oqpskdemodulator.cpp:281)
@@ -1053,9 +1054,14 @@ extern "C" int jaero_set_settings(jaero_ctx *c, int channel, const jaero_setting
     if (c->pre8400)
     {
         // fb = 8400: setSettings also re-creates the prefilter (JFastFir::SetKernel: empty history, 2048 zeros of latency, transform blocks
-        // re-aligned to that moment), which k_pre8400_fft's bank-wide block alignment cannot do for one channel of several
-        if (!whole) return fail(JAERO_ENOTSUP, "jaero_set_settings on one channel of a live 8400 bps bank is not implemented (the prefilter restarts bank-wide): use channel = -1");
-        return rebank_with_carry_over(c, s);
+        // re-aligned to that moment).  The whole bank: re-created behind the handle, blocks re-aligned.  One channel of several: its column
+        // of the prefilter history is emptied and its outputs held at exact zeros for 2048 samples (k_pre8400_restart); the transform blocks
+        // stay on the bank's grid (round 5; refused until then)
+        if (whole) return rebank_with_carry_over(c, s);
+        HIPCHK(hipSetDevice(c->device));
+        hipLaunchKernelGGL(k_pre8400_restart, dim3(16), dim3(256), 0, c->last_stream, g, c->pre, channel, c->pre_n0);
+        HIPCHK(hipGetLastError());
+        return apply_live_settings(c, channel, channel + 1, s);
     }
     HIPCHK(hipSetDevice(c->device));
     return apply_live_settings(c, channel < 0 ? 0 : channel, channel < 0 ? g.nch : channel + 1, s);
@@ -1419,6 +1425,8 @@ extern "C" int jaero_debug_prefilter(int device, const double *in_reim, int n, d
     HIPCHK(hipMalloc((void **)&d_taps, sizeof(double) * PRE_K));
     HIPCHK(hipMemset(q.xring, 0, sizeof(double2) * (size_t)ring * 64));
     HIPCHK(hipMemset(q.cidx, 0, sizeof(unsigned short) * (size_t)n * 64));
+    HIPCHK(hipMalloc((void **)&q.hold, sizeof(long long) * 64));
+    HIPCHK(hipMemset(q.hold, 0, sizeof(long long) * 64));
     const double2 one[4] = {{1.0, 0.0}, {1.0, 0.0}, {1.0, 0.0}, {1.0, 0.0}}; // table entry 0 = cis(0): the up-mix multiplies by its conjugate
     HIPCHK(hipMemcpy(d_cis, one, sizeof one, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_taps, taps.data(), sizeof(double) * PRE_K, hipMemcpyHostToDevice));
@@ -1435,7 +1443,7 @@ extern "C" int jaero_debug_prefilter(int device, const double *in_reim, int n, d
         hipFree(dH); hipFree(dtw);
     }
     HIPCHK(hipMemcpy2D(out_reim, sizeof(double2), q.out, sizeof(double2) * 64, sizeof(double2), (size_t)n, hipMemcpyDeviceToHost));
-    hipFree(q.xring); hipFree(q.cidx); hipFree(q.out); hipFree(d_cis); hipFree(d_taps);
+    hipFree(q.xring); hipFree(q.cidx); hipFree(q.out); hipFree(q.hold); hipFree(d_cis); hipFree(d_taps);
     return 0;
 }
 

@@ -66,32 +66,6 @@ __device__ __forceinline__ void jda_fetch(const JdAtanLane &T, int i, double &A_
 }
 #endif
 
-// the table in LDS (65 leading doubles, 65 float tails: 780 B, JD_ATAN_LDS_BYTES reserved): for call sites under a DIVERGENT branch, where a
-// bpermute cannot be used (it returns nothing from lanes the exec mask has switched off).  One table per workgroup, read-only after
-// jd_atan_lds_init + a barrier.
-#define JD_ATAN_LDS_BYTES 784
-struct JdAtanLds
-{
-    const double *hi; // [65]
-    const float *lo;  // [65]
-};
-#ifndef JDA_HOST_CHECK
-__device__ __forceinline__ JdAtanLds jd_atan_lds_init(void *mem, int tid, int nthreads)
-{
-    double *hi = (double *)mem;
-    float *lo = (float *)(hi + 65);
-    for (int i = tid; i < 65; i += nthreads) { hi[i] = JD_ATAN_HI[i]; lo[i] = JD_ATAN_LOF[i]; }
-    JdAtanLds T;
-    T.hi = hi; T.lo = lo;
-    return T;
-}
-__device__ __forceinline__ void jda_fetch(const JdAtanLds &T, int i, double &A_hi, double &A_lo)
-{
-    A_hi = T.hi[i];
-    A_lo = (double)T.lo[i];
-}
-#endif
-
 template <class JDA_TBL>
 JDA_FN double jd_atan2_t(double y, double x, const JDA_TBL &T)
 {
@@ -145,9 +119,6 @@ JDA_FN double jd_atan2_t(double y, double x, const JDA_TBL &T)
 }
 
 JDA_FN double jd_atan2(double y, double x, const JdAtanLane &T) { return jd_atan2_t(y, x, T); }
-#ifndef JDA_HOST_CHECK
-JDA_FN double jd_atan2(double y, double x, const JdAtanLds &T) { return jd_atan2_t(y, x, T); }
-#endif
 
 // ---- hypot -----------------------------------------------------------------------------------------------------------------------
 // glibc 2.35 sysdeps/ieee754/dbl-64/e_hypot.c, the branch without a fast fma (the x86-64 baseline build), operation for operation:

@@ -67,7 +67,6 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
     const double2 *__restrict__ cis = p.cis;
     const double *__restrict__ taps = p.taps2; // this bank's own taps, read once into LDS
     const double SPS = g.SPS, samplerate = g.Fs;
-    const JdAtanLane atl = jd_atan_lane_table(lane); // jd_atan2's table, one entry per lane
 
     double m2_ptr = BLDF(BS_M2_PTR), m2_step = BLDF(BS_M2_STEP), m2_freq = BLDF(BS_M2_FREQ);
     double st_ptr = BLDF(BS_ST_PTR), st_step = BLDF(BS_ST_STEP), st_freq = BLDF(BS_ST_FREQ), st_last = BLDF(BS_ST_LAST);
@@ -173,7 +172,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
         double sre = 0, sim = 0;
         {
             // output from x[n-FIRN .. n-1] (FIR::FIRUpdateAndProcess excludes the sample being pushed): taps[i] <-> x[n-FIRN+i]
-            jd_fir_eval<FIRN, LDSN, 8>(lre, lim, ltap, tre, tim, fir_slot, lane, sre, sim);
+            jd_fir_eval<FIRN, LDSN, 8, true>(lre, lim, ltap, tre, tim, fir_slot, lane, sre, sim);
             // push x[n]: the oldest LDS entry moves into the register tail
 #pragma unroll
             for (int j = TAILN - 1; j > 0; j--) { tre[j] = tre[j - 1]; tim[j] = tim[j - 1]; }
@@ -195,11 +194,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
             insertpre = 0;
         }
         // ---- symbol tone in the preamble (:547-566) ----
-        // (the block's atan2 is jd_atan2, whose table lookup needs every lane of the wavefront: the block is split around it, and the call is
-        // made by all lanes whenever some lane is in its preamble)
-        const bool in_pre = (cntr > SPS * (128 + 10)) && (cntr < ((256 - 10) * SPS));
-        double pre_e_re = 1.0, pre_e_im = 0.0;
-        if (in_pre)
+        if ((cntr > SPS * (128 + 10)) && (cntr < ((256 - 10) * SPS)))
         {
             const double progress = (((double)cntr) - (SPS * (128 + 10))) / (((256 - 10) * SPS) - (SPS * (128 + 10)));
             double t_re = sre, t_im = sim;
@@ -216,24 +211,16 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
             t_im = a1out;
             const double2 cq = cis[jd_cisidx(stq_ptr)];
             const double e_re = cq.x * t_re - cq.y * (-t_im), e_im = cq.x * (-t_im) + cq.y * t_re;
-            pre_e_re = e_re; pre_e_im = e_im;
-        }
-        if (__any(in_pre)) // wave-uniform
-        {
-            double st_err = jd_atan2(pre_e_im, pre_e_re, atl);
-            if (in_pre)
-            {
-                const double progress = (((double)cntr) - (SPS * (128 + 10))) / (((256 - 10) * SPS) - (SPS * (128 + 10))); // as above: cntr has not moved
-                st_err *= 1.5 * (1.0 - progress * progress);
-                jd_wt_advance_fraction(stq_ptr, -(1.0 / (2.0 * M_PI)) * st_err * 0.1);
-                bd_set_phase_deg(st_ptr, jd_div_const(360.0 * stq_ptr, wtsize_d, r_wtsize) * 4.0 + (360.0 * g.ee));
-            }
+            double st_err = atan2(e_im, e_re);
+            st_err *= 1.5 * (1.0 - progress * progress);
+            jd_wt_advance_fraction(stq_ptr, -(1.0 / (2.0 * M_PI)) * st_err * 0.1);
+            bd_set_phase_deg(st_ptr, jd_div_const(360.0 * stq_ptr, wtsize_d, r_wtsize) * 4.0 + (360.0 * g.ee));
         }
         // ---- carrier phase correction, EbNo, AGC, clip (:570-590) ----
         bd_cmul(sre, sim, sav_re, sav_im);
         bd_cmul(rot_re, rot_im, rfc, rfs);
         bd_cmul(sre, sim, rot_re, rot_im);
-        const double sig2abs = jd_hypot(sre, sim);
+        const double sig2abs = hypot(sre, sim);
         {
             const double sq = sig2abs * sig2abs;
             double *ep = ebe_ring + (size_t)s_eb * 64;
@@ -267,7 +254,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
             gain = fmax(gain, 0.000001);
             sre *= gain; sim *= gain;
         }
-        const double abval = jd_hypot(sre, sim);
+        const double abval = hypot(sre, sim);
         if (abval > 2.84) { const double k = (2.84 / abval); sre = k * sre; sim = k * sim; }
 
         // ---- symbol timer (:592-612) ----
@@ -289,7 +276,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
             if (st_ptr != st_ptr_top) so = cis[jd_cisidx(st_ptr)];
             const double m_re = st_eta, m_im = -d8out;
             const double o_re = so.x * m_re - so.y * m_im, o_im = so.x * m_im + so.y * m_re;
-            const double st_angle_error = jd_atan2(o_im, o_re, atl);
+            const double st_angle_error = atan2(o_im, o_re);
             if (cntr > SPS * (128 + 64))
             {
                 fb_wt_setfreq(st_freq, st_step, (-st_angle_error * 0.00000001) + st_freq, samplerate, r_samplerate);

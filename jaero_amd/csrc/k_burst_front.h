@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64) void k_burst_front(const BGeom g, const BPtrs p
             const int i = i0 + k;
             if (i >= n) break;
             // agc->Update(std::abs(cval)); cval*=agc->AGCVal  (DSP.cpp:370-379)
-            const double a = jd_hypot(x_re[k], x_im[k]);
+            const double a = hypot(x_re[k], x_im[k]);
             agc_sum = agc_sum - o_agc[k];
             agc_sum = agc_sum + fabs(a);
             agc_ring[(size_t)s_agc * 64] = fabs(a);
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64) void k_burst_front(const BGeom g, const BPtrs p
             ma1_re = ma1_re - o_m1r[k]; ma1_im = ma1_im - o_m1i[k];
             ma1_re = ma1_re + pr; ma1_im = ma1_im + pi;
             ma1r[(size_t)s_ma1 * 64] = pr; ma1i[(size_t)s_ma1 * 64] = pi;
-            double fastarm = jd_hypot(ma1_re / ma1_len_d, ma1_im / ma1_len_d);
+            double fastarm = hypot(ma1_re / ma1_len_d, ma1_im / ma1_len_d);
             // mav1->UpdateSigned
             mav1_sum = mav1_sum - o_mav[k];
             mav1_sum = mav1_sum + fastarm;

@@ -40,7 +40,6 @@ struct BmskMail
     int *gate;   // [2][64]    1 = the sample is pushed (the channel's gate is open)
     double *wc;  // [3 or 4][8][64] the back half's write-combining cells
     double *d8;  // [d8_len][64] delayt8's ring where it fits (1200 bps: 21 entries), behind the cells
-    JdAtanLds atl; // jd_atan2's table (784 B), behind that
 };
 #define BMSK_FB_MAIL_BYTES (2 * 2 * 64 * 8 + 2 * 3 * 64 * 8 + 2 * 64 * 4) // 5632
 #define BMSK_FB_LDSN_80 48
@@ -49,7 +48,6 @@ struct BmskMail
 // 128 KiB of filter history); at 1200 bps delayt8's 21 entries per lane live in LDS for the launch (10.5 KiB) and cost HBM nothing per sample
 #define BMSK_FB_WC_BYTES(d8lds) (((d8lds) ? 3 : 4) * 8 * 64 * 8)
 #define BMSK_FB_D8_BYTES(d8lds, d8_len) ((d8lds) ? (d8_len) * 64 * 8 : 0)
-#define BMSK_FB_ATAN_BYTES JD_ATAN_LDS_BYTES // jd_atan2's table (jd_libm.h), behind everything else
 
 template <int FIRN, int LDSN>
 __device__ __forceinline__ void bmsk_front(const BGeom &g, const BPtrs &p, double *lre, double *lim, const BmskMail &M, int n, long long n0, int grp, int lane)
@@ -78,8 +76,8 @@ __device__ __forceinline__ void bmsk_front(const BGeom &g, const BPtrs &p, doubl
         for (int t = 0; t < TAILN; t++)
         {
             const double tp = taps[t];
-            sre = sre + tp * tre[TAILN - 1 - t];
-            sim = sim + tp * tim[TAILN - 1 - t];
+            sre = fma(tp, tre[TAILN - 1 - t], sre);
+            sim = fma(tp, tim[TAILN - 1 - t], sim);
         }
         constexpr unsigned RING = (unsigned)LDSN * 512u;
         constexpr int NB = LDSN / 8;
@@ -106,8 +104,8 @@ __device__ __forceinline__ void bmsk_front(const BGeom &g, const BPtrs &p, doubl
             for (int u = 0; u < 8; u++)
             {
                 const double tp = taps[TAILN + 8 * b + u];
-                sre = sre + tp * xr[b & 1][u];
-                sim = sim + tp * xi[b & 1][u];
+                sre = fma(tp, xr[b & 1][u], sre);
+                sim = fma(tp, xi[b & 1][u], sim);
             }
         }
     };
@@ -155,7 +153,6 @@ __device__ __forceinline__ void bmsk_front(const BGeom &g, const BPtrs &p, doubl
 template <bool CAPSYM, bool D8LDS>
 __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const BmskMail &M, int n, long long n0, int first_of_write, int grp, int lane)
 {
-    const JdAtanLds atl = M.atl; // jd_atan2's table in LDS: both calls sit under the per-lane gate, where a bpermute cannot reach the other lanes
     const int ch = grp * 64 + lane, nchp = g.nchp;
     const double2 *__restrict__ cis = p.cis;
     const double SPS = g.SPS, samplerate = g.Fs;
@@ -323,7 +320,7 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
                 progress = progress / goal;
                 const double2 cq = cis[jd_cisidx(sth_ptr)];
                 const double e_re = cq.x * t_re - cq.y * (-t_im), e_im = cq.x * (-t_im) + cq.y * t_re;
-                double st_err = jd_atan2(e_im, e_re, atl);
+                double st_err = atan2(e_im, e_re);
                 st_err *= 0.5 * (1.0 - progress * progress);
                 jd_wt_advance_fraction(sth_ptr, -(1.0 / (2.0 * M_PI)) * st_err * 0.05);
                 bd_set_phase_deg(st_ptr, (360.0 * sth_ptr / ((double)JD_WTSIZE)) + (360.0 * (1.0 - g.ee)));
@@ -331,7 +328,7 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
             bd_cmul(sre, sim, sav_re, sav_im);
             bd_cmul(rot_re, rot_im, rfc, rfs);
             bd_cmul(sre, sim, rot_re, rot_im);
-            const double sabs = jd_hypot(sre, sim);
+            const double sabs = hypot(sre, sim);
             {
                 const double sq = sabs * sabs;
                 eb_e2sum = eb_e2sum - e2_old; eb_e2sum = eb_e2sum + fabs(sq);
@@ -357,13 +354,13 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
                 gain = fmax(gain, 0.000001);
                 sre *= gain; sim *= gain;
             }
-            const double abval = jd_hypot(sre, sim);
+            const double abval = hypot(sre, sim);
             if (abval > 2.84) { const double k = (2.84 / abval); sre = k * sre; sim = k * sim; }
             // delayedsmpl.update_dont_touch(sig2)
             wc_at(WC_DX, ph) = sre; wc_at(WC_DY, ph) = sim;
             const double2 ptd = ptd_pre; // the oldest entry, not the one just written (dly_len >= 2)
             const double pm_re = sre, pm_im = ptd.y;
-            double st_eta = jd_hypot(pm_re, pm_im);
+            double st_eta = hypot(pm_re, pm_im);
             {
                 double y = 0;
                 y += res_x2 * g.res_b2; y += res_x1 * g.res_b1; y += st_eta * g.res_b0;
@@ -391,7 +388,7 @@ __device__ __forceinline__ void bmsk_back(const BGeom &g, const BPtrs &p, const 
                 if (st_ptr != st_ptr_top) so = cis[jd_cisidx(st_ptr)];
                 const double m_re = st_eta, m_im = -d8out;
                 const double o_re = so.x * m_re - so.y * m_im, o_im = so.x * m_im + so.y * m_re;
-                const double st_angle_error = jd_atan2(o_im, o_re, atl);
+                const double st_angle_error = atan2(o_im, o_re);
                 if (cntr > g.endRotation) jd_wt_advance_fraction(st_ptr, -st_angle_error * 0.002 / 360.0);
             }
             double frac;
@@ -496,8 +493,6 @@ __global__ __launch_bounds__(128) void k_burst_msk_fb(const BGeom g, const BPtrs
     constexpr bool D8LDS = FIRN == 80;
     M.wc = (double *)((char *)M.out + BMSK_FB_MAIL_BYTES);
     M.d8 = (double *)((char *)M.wc + BMSK_FB_WC_BYTES(D8LDS));
-    M.atl = jd_atan_lds_init((char *)M.d8 + BMSK_FB_D8_BYTES(D8LDS, g.d8_len), (int)threadIdx.x, 128);
-    __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, grp = blockIdx.x;
     if (n <= 0) return;
     if (wave == 0) bmsk_front<FIRN, LDSN>(g, p, lre, lim, M, n, n0, grp, lane);

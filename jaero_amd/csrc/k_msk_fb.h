@@ -27,11 +27,13 @@
 
 #define MFB_LDSN 36  // one pair per workgroup (small banks): 36 history entries of each arm in LDS, 44 in the front half's registers
 // Four pairs per workgroup (full banks): a wavefront has 256 registers at two per SIMD, the front half's 44-deep tail (176 registers)
-// does not fit.  Then the OLDEST 22 entries of each arm live in the BACK half's registers (it has room), which starts every filter
-// output -- the sum runs oldest first -- and hands the partial sum to the front half; the front half keeps 26 entries in registers
+// does not fit.  Then the OLDEST MFB4_TB entries of each arm live in the BACK half's registers (it has room), which starts every filter
+// output -- the sum runs oldest first -- and hands the partial sum to the front half; the front half keeps 80 - 32 - MFB4_TB entries in registers
 // and 32 in LDS and continues the same sum.  Same operations in the same order as the single accumulator chain.
+// (Round 5: 18, not 22 -- with 22 the back half reloaded ten spilled values inside its sample loop, every reload an s_waitcnt vmcnt(0) in
+// front of the ring entries requested ahead; with 18 neither loop touches scratch, what is left spilled is the state prologue / epilogue.)
 #define MFB4_LDSN 32
-#define MFB4_TB 22
+#define MFB4_TB 18
 // 160 taps (600 bps at 48 kHz; round 3): TWO pairs per workgroup, every wavefront alone on its SIMD (512 registers): 72 entries of each arm
 // in LDS (81 664 B per pair, 163 328 B per CU), 36 in the front half's registers, the 52 oldest in the back half's (measured splits 36/44/52/60: 5.87, 6.02, 6.03 Gsamples/s; all still spill 230-300 registers).  k_msk_samples<160,78>
 // (two wavefronts per CU, 82 entries in 256 registers) spilled ~750 registers; one wavefront per CU with the whole history in LDS and no

@@ -30,6 +30,8 @@ struct JPre
     int ring;              // power of two >= max_write + 3 * PRE_L
     const double2 *H;      // [4096] DFT of the taps (zero-padded to 4096) / 4096, natural order        (k_pre8400_fft)
     const double2 *tw;     // [4096] exp(-2 pi i k / 4096)                                               (k_pre8400_fft)
+    long long *hold;       // [nchp] absolute sample index up to which a channel's outputs are exact zeros: 2048 samples behind a
+                           // setSettings of that channel alone (JFastFir::SetKernel queues L zeros in front of the new filter's output)
 };
 
 // fields of JPtrs::S used by the prefilter (appended to the state enum in jaero_device.h): S_PRE_PTR, S_PRE_STEP, S_PRE_FSUM
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_pre8400_fft(const JGeom g, const
     const long long m0 = ((n0 >> 11) + blockIdx.y) << 11;
     const int i0 = (int)(m0 - n0); // may be negative: the part of the block that belonged to the previous write is not stored
     const int rmask = q.ring - 1;
+    const long long hold_until = q.hold[ch];
     CV<16> d;
     {
         const double2 *__restrict__ xr = q.xring + ch;
@@ -176,11 +179,24 @@ __global__ __launch_bounds__(PF_THREADS) void k_pre8400_fft(const JGeom g, const
         const int i = i0 + T + 256 * (s - 8);
         if (i >= 0 && i < n)
         {
-            const double yr = d.r[s], yi = -d.i[s];
+            const bool held = n0 + i < hold_until;
+            const double yr = held ? 0.0 : d.r[s], yi = held ? 0.0 : -d.i[s];
             // cval_prefiltered[i] *= mixer_fir_pre.WTCISValue_conj()
             const double2 cj = p.cis[q.cidx[(size_t)i * nchp + ch]];
             const double bre = cj.x, bim = -cj.y;
             q.out[(size_t)i * nchp + ch] = make_double2(yr * bre - yi * bim, yr * bim + yi * bre);
         }
     }
+}
+
+// setSettings on ONE channel of an 8400 bps bank (oqpskdemodulator.cpp:278-283: fir_pre.SetKernel): the channel's prefilter starts again --
+// empty history, and JFastFir's L = 2048 queued zeros in front of its first output.  The transform blocks stay on the bank's grid (absolute
+// multiples of 2048 samples; the reference object's own grid restarts at the call): the filtered values are the same linear convolution
+// either way, up to transform round-off; what differs is at which samples round-off takes the place of an exact zero should that channel
+// later carry digital silence.
+__global__ void k_pre8400_restart(const JGeom g, const JPre q, int ch, long long now)
+{
+    const int nchp = g.nchp;
+    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < q.ring; slot += gridDim.x * blockDim.x) q.xring[(size_t)slot * nchp + ch] = make_double2(0.0, 0.0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) q.hold[ch] = now + PRE_L;
 }

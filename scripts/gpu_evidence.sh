@@ -26,8 +26,8 @@ for wl in ${PMC_WORKLOADS:-oqpsk}; do
   SFX=""; [ "$wl" != oqpsk ] && SFX="_$wl"
   PRE=""; case $wl in oqpsk|oqpsk8400) PRE="--preroll 40";; esac
   # the burst workloads' kernel times depend on where in its burst cycle a channel is: profile the steps the bench line times
-  case $wl in burst_*) B="--no-cpu-baseline --as-written 0 --check-channels 0";; *) B="--steps 6 --warmup 2 --no-cpu-baseline --as-written 0 --check-channels 0";; esac
-  KRE='k_oqpsk|k_msk|k_coarse|k_burst|k_hilbert|k_trident|k_pre8400'
+  case $wl in burst_*|aerol*) B="--no-cpu-baseline --as-written 0 --check-channels 0";; *) B="--steps 6 --warmup 2 --no-cpu-baseline --as-written 0 --check-channels 0";; esac
+  KRE='k_oqpsk|k_msk|k_coarse|k_burst|k_hilbert|k_trident|k_pre8400|k_viterbi|k_aerol'
   cd /tmp
   if has prof; then
     timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof$SFX" -o stats -- python "$R/bench.py" --workload $wl $B $PRE > "$OUT/bench_prof_line$SFX.json" 2> "$OUT/prof$SFX.err"

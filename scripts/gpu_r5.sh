@@ -44,6 +44,32 @@ if has trace; then
     grep fb_trace "$OUT/trace_$n.err" | tail -1 > "$OUT/fb_trace_$n.json"; cat "$OUT/fb_trace_$n.json"
   done
 fi
+if has workloads; then
+  for wl in msk burst_oqpsk burst_msk aerol aerol_burst aerol_c oqpsk8400; do
+    extra=""; [ $wl = oqpsk8400 ] && extra="--as-written 0"
+    ( timeout 600 python bench.py --workload $wl $extra --no-cpu-baseline 2> "$OUT/bench_$wl.err" | tail -1 ) > "$OUT/bench_line_$wl.json"
+    python - "$OUT/bench_line_$wl.json" $wl <<'PY'
+import json,sys
+try:
+    d=json.load(open(sys.argv[1])); c=d["config"]
+    print(sys.argv[2], d["value"], d["unit"], d["ms_per_step"], c.get("kernel_ms_per_step"), (c.get("oracle_check") or {}).get("max_soft_byte_diff"))
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+    tail -2 "$OUT/bench_$wl.err"
+  done
+fi
+if has burst_ab; then
+  # burst kernels op for op (product) against an A/B build whose burst kernels keep the fused matched filter and the device library's hypot / atan2
+  for v in product burstfast; do
+    L=$R/jaero_amd/libjaero_hip.so; [ $v != product ] && L=$R/gpurun_tmp/libjaero_hip_$v.so
+    ( JAERO_HIP_LIB=$L timeout 600 python scripts/burst_ab.py 2> "$OUT/burst_ab_$v.err" | tail -1 ) > "$OUT/burst_ab_$v.json"; cat "$OUT/burst_ab_$v.json"; echo
+    for wl in burst_oqpsk burst_msk; do
+      ( JAERO_HIP_LIB=$L timeout 600 python bench.py --workload $wl --no-cpu-baseline 2> "$OUT/bench_${wl}_$v.err" | tail -1 ) > "$OUT/bench_line_${wl}_$v.json"
+      python -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[2], sys.argv[3], d['value'], d['ms_per_step'])" "$OUT/bench_line_${wl}_$v.json" $wl $v
+    done
+  done
+fi
 if has sizes; then
   for n in 1024 4096 16384 32768; do
     ( timeout 300 python bench.py --channels $n --steps 12 --warmup 4 --no-cpu-baseline --as-written 0 --check-channels 0 2> "$OUT/bench_$n.err" | tail -1 ) > "$OUT/bench_line_${n}_channels.json"

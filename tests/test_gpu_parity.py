@@ -217,12 +217,48 @@ def test_unsupported_rates_are_refused(B):
         with pytest.raises(capi.JaeroError) as e:
             B.DemodulatorBank(st, 1)
         assert e.value.code == capi.E_NOTSUP, st
-    # and what a live bank cannot take: setSettings at 8400 bps (the prefilter would have to restart for one channel)
+    # and what a live bank cannot take: another rate for one channel of several (fb is shared by a bank)
     st = B.OqpskSettings(fb=8400.0, lockingbw=8400.0, coarsefreqest_fft_power=14)
     bank = B.DemodulatorBank(st, 2)
     with pytest.raises(capi.JaeroError) as e:
-        bank.set_settings(st, channel=0)
-    assert e.value.code == capi.E_NOTSUP
+        bank.set_settings(B.OqpskSettings(), channel=0)
+    assert e.value.code == capi.E_INVAL
+    bank.close()
+
+
+def test_8400_set_settings_on_one_channel_of_a_bank(B, oracle_mod):
+    """OqpskDemodulator::setSettings on ONE object of several at 8400 bps (oqpskdemodulator.cpp:175-289; refused with JAERO_ENOTSUP until round
+    5): besides what it does at 10.5 kbps the prefilter restarts (fir_pre.SetKernel: empty history, 2048 exact zeros ahead of its first
+    output) -- here that channel's column of the prefilter history is emptied and its outputs held at zero for 2048 samples while the
+    transform blocks stay on the bank's grid.  Three channels of a 67-channel bank get the call at moments of their own (not multiples of the
+    write size or of 2048), one of them twice; they and their untouched neighbours against oracle objects that got the same calls between the
+    same writes (the oracle's setSettings at 8400 bps is pinned to the unmodified reference: tests/test_oracle_vs_ref.py)."""
+    from jaero_amd import signalgen as G
+
+    O = oracle_mod
+    nch, nsamp, chunk = 67, 150000, 3000
+    pcm, _, _ = G.channel_bank("oqpsk", nch, nsamp, ebno_db=11.0, seed0=G.SEED_BASE + 8470, fb=8400.0)
+    opts = {"fb": 8400.0, "lockingbw": 8400.0}
+    bank = B.DemodulatorBank([bank_settings("oqpsk", opts) for _ in range(nch)], ebno=True, status_log=True, capture_symbols=True,
+                             max_write_samples=chunk, softbit_capacity=nsamp)
+    events = {41011: [(3, 7990.0, 8400.0)], 77777: [(64, 8015.0, 7000.0), (3, 8004.0, 8400.0)], 101503: [(66, 7985.0, 8400.0)]}
+    cuts = [0] + sorted(events) + [nsamp]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        for (c, fc, lbw) in events.get(a, []):
+            bank.set_settings(bank_settings("oqpsk", dict(opts, freq_center=fc, lockingbw=lbw)), channel=c)
+        for s in range(a, b, chunk):
+            bank.write(pcm[:, s:min(s + chunk, b)])
+    for c in (2, 3, 4, 63, 64, 65, 66):
+        d = O.Demod(oracle_settings(O, "oqpsk", opts), capture_symbols=True)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            for (cc, fc, lbw) in events.get(a, []):
+                if cc == c:
+                    d.set_settings(oracle_settings(O, "oqpsk", dict(opts, freq_center=fc, lockingbw=lbw)))
+            for s in range(a, b, chunk):
+                d.write(pcm[c, s:min(s + chunk, b)])
+        ref = {"soft": d.take_soft(), "status": d.take_status(), "symbols": d.take_symbols(), "pending": d.pending}
+        assert len(ref["soft"]) > 10000, c
+        compare(bank.read_softbits(c), bank.read_symbols(c), bank.read_status_log(c), ref)
     bank.close()
 
 

@@ -2,7 +2,7 @@
 pairs per workgroup, MFB2_* for the 160-tap filter with two).
 
 The 80-entry matched-filter history of an arm is split three ways: the 32 newest entries in LDS and the next 26 in the front half's
-registers, the 22 oldest in the back half's registers (160 entries: 72 / 36 / 52).  The back half starts every filter sum (oldest first) two samples ahead and hands
+registers, the 18 oldest (22 until round 5) in the back half's registers (160 entries: 72 / 36 / 52).  The back half starts every filter sum (oldest first) two samples ahead and hands
 it over; the front half announces, two samples ahead, the entry that will reach the back half's tail.  Across launches the pending sum
 travels in the state (S_MFB_A0_*), the tails in firsave.  The kernel runs on the GPU only (tests/test_gpu_parity.py, test_gpu_scale.py);
 this model replays its schedule -- mailbox slots, barriers as phase boundaries, launches of 0, 1, 2 ... samples -- with integer data
@@ -10,7 +10,7 @@ this model replays its schedule -- mailbox slots, barriers as phase boundaries, 
 import numpy as np
 import pytest
 
-FIRN, L, TB = 80, 32, 22
+FIRN, L, TB = 80, 32, 18
 TF = FIRN - L - TB
 
 
@@ -71,7 +71,7 @@ class Pair:
         return y
 
 
-@pytest.mark.parametrize("firn,l,tb", [(80, 32, 22), (160, 72, 52)])
+@pytest.mark.parametrize("firn,l,tb", [(80, 32, 18), (80, 32, 22), (160, 72, 52), (160, 72, 40)])
 def test_three_way_history_matches_the_plain_filter(firn, l, tb):
     global FIRN, L, TB, TF
     FIRN, L, TB = firn, l, tb
