@@ -1017,6 +1017,11 @@ def small_bank_run(kind: str, nch: int, chunk: int, K: int, W: int, dev, local, 
         st = signalgen.OqpskTorchStream(nch, nsamp, dev, ebno_db=ARGS.ebno_db, seed=signalgen.SEED_BASE + 31 + seed_offset, nphase=ARGS.timing_phases)
         pcm = st.render(0, nsamp)
         bank = DemodulatorBank(OqpskSettings(), nch, device=local, ebno=bool(ARGS.ebno), max_write_samples=chunk, softbit_capacity=int(nsamp * 10500 / 48000) + 64)
+    elif kind == "burst_oqpsk":
+        from jaero_amd.demodulator import BurstOqpskSettings
+
+        pcm, _, _ = signalgen.burst_oqpsk_torch(nch, nsamp, dev, ebno_db=15.0, seed=signalgen.SEED_BASE + 61 + seed_offset)
+        bank = DemodulatorBank(BurstOqpskSettings(), nch, device=local, max_write_samples=chunk, softbit_capacity=int(nsamp * 10500 / 48000) + 64)
     else:
         uniq = np.stack([signalgen.msk(nsamp, fb=1200.0, fc=1000.0 + 7.0 * u, ebno_db=ARGS.ebno_db, seed=signalgen.SEED_BASE + 900 + u)[0] for u in range(32)])
         idx = torch.arange(nch, device=dev) % 32
@@ -1220,7 +1225,10 @@ def main():
             if world == 1:
                 as_written = {"configs[2] 4096-channel 10.5 kbps OQPSK": small_bank_run("oqpsk", 4096, chunk, K, W, dev, local),
                               "configs[1] 256-channel 1200 bps MSK": small_bank_run("msk", 256, chunk, K, W, dev, local),
-                              "note": "the banks as BASELINE.json words them: 64 (4) wavefronts on 1024 SIMDs -- lane-per-channel kernels are latency bound there"}
+                              "configs[3] 4096-channel 10.5 kbps burst OQPSK": small_bank_run("burst_oqpsk", 4096, chunk, K, W, dev, local),
+                              "note": "the banks as BASELINE.json words them: 64 (4) wavefronts on 1024 SIMDs -- lane-per-channel kernels are latency bound there: "
+                                      "a sample of a 64-channel group is one serial chain through two wavefronts (~1.8 us whatever the bank size: the sample loop takes "
+                                      "7.6 ms per 4096 samples at 1024, 4096 and 16384 channels alike, profiles/r5_small_bank.md), so narrower groups would not run faster"}
             else:
                 r = small_bank_run("oqpsk", 4096, chunk, K, W, dev, local, seed_offset=lo)
                 t = torch.tensor([r["ms_per_step"]], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")

@@ -62,6 +62,9 @@ __device__ unsigned long long g_fb_trace[2][8];
 #define FB_TRACE(k)
 #define FB_TRACE_FLUSH(which, nsamp)
 #endif
+#ifndef FB_SOLO_D
+#define FB_SOLO_D 6 // LDS reads in flight in the one-pair kernel's filter (A/B: 12 measured in round 5, profiles/r5_small_bank.md)
+#endif
 #define FB_LDSN 36 // filter history slots in LDS: 36 KiB + mailboxes (+ a spare 512 B) = 40 448 B per pair, four pairs per CU (161 792 of 163 840 B)
 
 // x / d for a positive constant d with rd = 1.0 / d (correctly rounded): q = x*rd is within an ulp, two Newton corrections through exact
@@ -332,7 +335,7 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &
         // (on a SIMD shared with the back half the same thing is slower -- the comment above -- so the four-pair kernel does not do it)
         double y_re = 0, y_im = 0;
         if constexpr (SOLO)
-            if (i + 1 < nB) jd_fir_eval_sym_static_but_last<FIRN, LDSN, 6>(lre, lim, tp, tre, tim, fir_slot, lane, y_re, y_im);
+            if (i + 1 < nB) jd_fir_eval_sym_static_but_last<FIRN, LDSN, FB_SOLO_D>(lre, lim, tp, tre, tim, fir_slot, lane, y_re, y_im);
         const double cre = c_m2.x * dval, cim = c_m2.y * dval;
         {
             *hre = cre;

@@ -48,7 +48,14 @@ def main():
             r["hard_equal"] &= bool(np.array_equal(soft >= 128, ref["soft"] >= 128))
             r["soft_bytes"] += int(len(soft)); r["soft_bytes_differing"] += int((soft != ref["soft"]).sum())
             d = np.abs(sym - ref["symbols"]).max(axis=1) if len(sym) else np.zeros(0)
-            r["symbols"] += int(len(d)); r["max_symbol_diff"] = max(r["max_symbol_diff"], float(d.max(initial=0.0)))
+            r["symbols"] += int(len(d))
+            if len(d) and float(d.max()) > r["max_symbol_diff"]:
+                k = int(d.argmax())
+                # where the worst symbol sits: its index counted from the start of its burst (soft bits come two per symbol; -1 marks a burst start)
+                marks = np.flatnonzero(ref["soft"] == -1)
+                r["worst"] = {"channel": c, "symbol": k, "of": int(len(d)), "gpu": [float(x) for x in sym[k]], "oracle": [float(x) for x in ref["symbols"][k]],
+                              "bursts_start_at_soft_bit": [int(m) for m in marks[:4]], "neighbours_diff": [float(x) for x in d[max(0, k - 3):k + 4]]}
+            r["max_symbol_diff"] = max(r["max_symbol_diff"], float(d.max(initial=0.0)))
             r["symbols_over_1e-12"] += int((d > 1e-12).sum()); r["symbols_over_1e-9"] += int((d > 1e-9).sum())
             r["bursts"] += int((ref["soft"] == -1).sum())
         bank.close()

@@ -70,6 +70,24 @@ if has burst_ab; then
     done
   done
 fi
+if has msk600; then
+  for v in product msk600tb40; do
+    L=$R/jaero_amd/libjaero_hip.so; [ $v != product ] && L=$R/gpurun_tmp/libjaero_hip_$v.so
+    echo "msk600 $v: $(JAERO_HIP_LIB=$L timeout 300 python scripts/time_msk600.py 65536 2>/dev/null | tail -1)" | tee -a "$OUT/msk600_ab.txt"
+  done
+fi
+if has solo; then
+  for v in product solod12; do
+    L=$R/jaero_amd/libjaero_hip.so; [ $v != product ] && L=$R/gpurun_tmp/libjaero_hip_$v.so
+    for n in 4096 16384; do
+      ( JAERO_HIP_LIB=$L timeout 300 python bench.py --channels $n --steps 12 --warmup 4 --no-cpu-baseline --as-written 0 --check-channels 0 2>/dev/null | tail -1 ) > "$OUT/bench_line_${n}_$v.json"
+      python -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[2], sys.argv[3], d['value'], d['ms_per_step'], d['config']['kernel_ms_per_step'])" "$OUT/bench_line_${n}_$v.json" $n $v | tee -a "$OUT/solo_ab.txt"
+    done
+  done
+fi
+if has burstworst; then
+  ( timeout 600 python scripts/burst_ab.py 2> "$OUT/burst_worst.err" | tail -1 ) > "$OUT/burst_worst.json"; cat "$OUT/burst_worst.json"; echo
+fi
 if has sizes; then
   for n in 1024 4096 16384 32768; do
     ( timeout 300 python bench.py --channels $n --steps 12 --warmup 4 --no-cpu-baseline --as-written 0 --check-channels 0 2> "$OUT/bench_$n.err" | tail -1 ) > "$OUT/bench_line_${n}_channels.json"
