@@ -507,14 +507,14 @@ extern "C" void jaero_destroy(jaero_ctx *c)
     if (!c->burst && c->g.kind == JAERO_KIND_OQPSK)
     {
         // trace build only: what the traced pair of this bank's sample loop accumulated, one JSON line on stderr per destroyed bank
-        unsigned long long tr[16] = {0}, z[16] = {0};
-        if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_fb_trace), sizeof(tr)) == hipSuccess && tr[6] + tr[14] > 0)
+        unsigned long long tr[20] = {0}, z[20] = {0};
+        if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_fb_trace), sizeof(tr)) == hipSuccess && tr[8] + tr[18] > 0)
         {
             fprintf(stderr, "{\"fb_trace\": {\"channels\": %d, \"clock_hz\": 100000000", c->o_nch);
             for (int h = 0; h < 2; h++)
             {
-                fprintf(stderr, ", \"%s\": {\"samples\": %llu, \"ticks\": [", h ? "back" : "front", tr[h * 8 + 6]);
-                for (int k = 0; k < 5; k++) fprintf(stderr, "%s%llu", k ? ", " : "", tr[h * 8 + k]);
+                fprintf(stderr, ", \"%s\": {\"samples\": %llu, \"ticks\": [", h ? "back" : "front", tr[h * 10 + 8]);
+                for (int k = 0; k < 8; k++) fprintf(stderr, "%s%llu", k ? ", " : "", tr[h * 10 + k]);
                 fprintf(stderr, "]}");
             }
             fprintf(stderr, "}}\n");

@@ -40,8 +40,8 @@
 // clock at five points of a sample in either half, every wavefront alike (so that no wavefront waits for a slower, traced one), and one pair
 // adds its sums to g_fb_trace at the end of the launch; jaero_destroy prints them (a JSON line on stderr).  In the product build the macros are empty.
 #ifdef FB_TRACE_BUILD
-__device__ unsigned long long g_fb_trace[2][8];
-#define FB_TRACE_DECL unsigned long long tr_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long tr_prev = wall_clock64()
+__device__ unsigned long long g_fb_trace[2][10];
+#define FB_TRACE_DECL unsigned long long tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tr_prev = wall_clock64()
 #define FB_TRACE(k)                                                                                                                                           \
     do {                                                                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                                                                    \
@@ -53,8 +53,8 @@ __device__ unsigned long long g_fb_trace[2][8];
     do {                                                                                                                                                      \
         if (lane == 0 && grp == (g.ngroups > 600 ? 597 : 0))                                                                                                  \
         {                                                                                                                                                     \
-            for (int k_ = 0; k_ < 6; k_++) atomicAdd(&g_fb_trace[which][k_], tr_acc[k_]);                                                                    \
-            atomicAdd(&g_fb_trace[which][6], (unsigned long long)(nsamp));                                                                                    \
+            for (int k_ = 0; k_ < 8; k_++) atomicAdd(&g_fb_trace[which][k_], tr_acc[k_]);                                                                    \
+            atomicAdd(&g_fb_trace[which][8], (unsigned long long)(nsamp));                                                                                    \
         }                                                                                                                                                     \
     } while (0)
 #else
@@ -577,12 +577,14 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, FbLds &L
         }
         if constexpr (!PRE8400) FB_TRACE(1); // mailbox read, symbol timing: delays, resonator, atan2, oscillator nudges
         if (need_px) request_px(); // for the symbol queued in the previous sample
+        if constexpr (!PRE8400) FB_TRACE(5); // (finer split of the third row: the record requests)
 
         // ---- K10..K14 at symbol instants (:487-595) ----
         if (!sig2l_init) { sig2l_re = sre; sig2l_im = sim; sig2l_init = 1; }
         double frac;
         const bool inst = jd_wt_passed(st_last, st_ptr, st_step, g.ee, frac);
         const bool full = inst && (yui == 0); // yui flips to 1 at this instant: the instant that closes a symbol pair
+        if constexpr (!PRE8400) FB_TRACE(6); // (the instant test)
         // queued output halves: all lanes together every FB_DEFER samples; a lane about to queue a second one goes first
         if (pend && (full || (i & (FB_DEFER - 1)) == 0)) output_half();
         if constexpr (!PRE8400) FB_TRACE(2); // record requests, instant test, queued output halves (every 16th sample)
