@@ -169,7 +169,7 @@ def issue_roofline(kernel_ms_per_step: dict, names: dict, nch: int):
     except Exception as e:
         out["reason"] = f"unreadable: {e}"
         return out
-    out["source"] = f"profiles/sq_summary.json@{sq.get('tag', 'untagged')} (rocprofv3 --pmc SQ_INSTS_VALU pass of this workload, not this run)"
+    out["source"] = f"profiles/sq_summary.json@{sq.get('tag', 'untagged')} ({same_pass(sq).replace('--pmc passes', '--pmc SQ_INSTS_VALU pass')})"
     scale = nch / float(sq.get("channels_per_gpu", nch))
     tot_floor = tot_ms = 0.0
     for cls, ms in kernel_ms_per_step.items():
@@ -205,9 +205,17 @@ def measured_traffic(pmc_file: str, cls: str, kernel_that_ran: str, nch: int):
             return None, (f"STALE: profiles/{pmc_file}@{pj.get('tag', 'untagged')} was taken on {ent.get('kernel')!r}, this run launched {kernel_that_ran!r}: "
                           f"redo the --pmc passes (scripts/gpu_evidence.sh)")
         t = ent["hbm_bytes_per_launch"] * nch / float(pj.get("channels_per_gpu", nch))
-        return t, f"profiles/{pmc_file}@{pj.get('tag', 'untagged')} (rocprofv3 --pmc passes of this command, not this run; kernel name checked)"
+        return t, f"profiles/{pmc_file}@{pj.get('tag', 'untagged')} ({same_pass(pj)}; kernel name checked)"
     except Exception as e:
         return None, f"profiles/{pmc_file} unreadable: {e}"
+
+
+def same_pass(pj) -> str:
+    """Where a counter summary comes from relative to this run: the same scripts/gpu_evidence.sh pass (it exports its tag) or an earlier one."""
+    tag = os.environ.get("JAERO_EVIDENCE_TAG")
+    if tag and str(pj.get("tag", "")).startswith(tag + "_"):
+        return "rocprofv3 --pmc passes of this command taken minutes earlier in the same scripts/gpu_evidence.sh pass on the same box, not this process"
+    return "rocprofv3 --pmc passes of this command from an earlier pass, not this run"
 
 
 def burst_traffic(pmc_file: str, kernel_that_ran: str, nch: int):
@@ -221,7 +229,7 @@ def burst_traffic(pmc_file: str, kernel_that_ran: str, nch: int):
         for k, ent in pj.items():
             if isinstance(ent, dict) and kernel_that_ran and kernel_that_ran.rstrip("<") in k and ent.get("hbm_bytes_per_launch") is not None:
                 t = ent["hbm_bytes_per_launch"] * nch / float(pj.get("channels_per_gpu", nch))
-                return t, f"profiles/{pmc_file}@{pj.get('tag', 'untagged')} (rocprofv3 --pmc passes of this command, not this run; kernel name checked)"
+                return t, f"profiles/{pmc_file}@{pj.get('tag', 'untagged')} ({same_pass(pj)}; kernel name checked)"
         return None, f"STALE: profiles/{pmc_file}@{pj.get('tag', 'untagged')} has no entry for {kernel_that_ran!r}: redo the --pmc passes (scripts/gpu_evidence.sh)"
     except Exception as e:
         return None, f"profiles/{pmc_file} unreadable: {e}"

@@ -17,10 +17,6 @@ if has tests; then
   timeout 1500 python -m pytest tests -m gpu -q --durations=10 --tb=short > "$OUT/pytest_gpu_full.log" 2>&1
   tail -22 "$OUT/pytest_gpu_full.log" > "$OUT/pytest_gpu.log"; grep -n "^E  \|^FAILED\|passed\|failed" "$OUT/pytest_gpu_full.log" | head -20
 fi
-if has bench; then
-  SECONDS=0; ( timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2> "$OUT/bench.err" | tail -1 ) > "$OUT/bench_line.json"
-  echo "driver bench wall: ${SECONDS}s" | tee "$OUT/bench_wall.txt"; cut -c1-300 "$OUT/bench_line.json"; echo; tail -2 "$OUT/bench.err"
-fi
 B="--steps 6 --warmup 2 --no-cpu-baseline --as-written 0 --check-channels 0"
 for wl in ${PMC_WORKLOADS:-oqpsk}; do
   SFX=""; [ "$wl" != oqpsk ] && SFX="_$wl"
@@ -44,6 +40,13 @@ for wl in ${PMC_WORKLOADS:-oqpsk}; do
   if has sq; then cd "$R"; SQ_TAG="${TAG}_$wl" bash scripts/pmc_sq.sh "$TAG/sq$SFX" --workload $wl $B $PRE > "$OUT/sq$SFX.log" 2>&1; cp "$OUT/sq$SFX/sq_summary.json" "$OUT/sq_summary$SFX.json" 2>/dev/null; fi
 done
 cd "$R"
+# the counter summaries of THIS pass become the ones bench.py reads, so that the lines below are annotated with traffic taken in the same pass
+export JAERO_EVIDENCE_TAG=$TAG
+for f in "$OUT"/pmc_summary*.json "$OUT"/sq_summary*.json; do [ -s "$f" ] && cp "$f" "$R/profiles/$(basename "$f")"; done
+if has bench; then
+  SECONDS=0; ( timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2> "$OUT/bench.err" | tail -1 ) > "$OUT/bench_line.json"
+  echo "driver bench wall: ${SECONDS}s" | tee "$OUT/bench_wall.txt"; cut -c1-300 "$OUT/bench_line.json"; echo; tail -2 "$OUT/bench.err"
+fi
 if has workloads; then
   for wl in msk burst_oqpsk burst_msk aerol aerol_burst aerol_c oqpsk8400; do
     extra=""; [ $wl = oqpsk8400 ] && extra="--as-written 0"
