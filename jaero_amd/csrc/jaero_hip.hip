@@ -504,7 +504,7 @@ extern "C" void jaero_destroy(jaero_ctx *c)
     hipStreamSynchronize(c->last_stream);
     hipStreamSynchronize(0);
 #ifdef FB_TRACE_BUILD
-    if (!c->burst && c->g.kind == JAERO_KIND_OQPSK)
+    if (!c->burst)
     {
         // trace build only: what the traced pair of this bank's sample loop accumulated, one JSON line on stderr per destroyed bank
         unsigned long long tr[20] = {0}, z[20] = {0};

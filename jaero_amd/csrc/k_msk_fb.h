@@ -231,8 +231,10 @@ __device__ __forceinline__ void mfb_front(const JGeom &g, const JPtrs &p, const 
     }
     fb_barrier();
 
+    FB_TRACE_DECL; // phase trace build (k_oqpsk_fb.h): empty in the product
     for (int i = 0; i < nB; i++)
     {
+        FB_TRACE(0); // the barrier
         // the carrier NCO's table value for sample i (index handed over by the back half): an L2 hit; the register half of the history
         // shifts meanwhile
         const int m2i = L.idx[(i & 1) * 64 + lane];
@@ -261,6 +263,7 @@ __device__ __forceinline__ void mfb_front(const JGeom &g, const JPtrs &p, const 
             o[0] = tre[TAILN - 2]; o[64] = tim[TAILN - 2];
         }
         __builtin_amdgcn_sched_barrier(0);
+        FB_TRACE(1); // index read, gather, mix, push, hand-over of the entry that leaves the tail
         if (do_fill) ring_fill(make_double2(cc.x * dval, cc.y * dval)); // :350-355
         coarse_cnt++;                                                   // :368
         fb_wt_next(mc_ptr, mc_step);
@@ -277,15 +280,19 @@ __device__ __forceinline__ void mfb_front(const JGeom &g, const JPtrs &p, const 
             if (EBNO) r2_e = win[(size_t)wslot(wn, g.ebno_len) * 64];
         }
         __builtin_amdgcn_sched_barrier(0);
+        FB_TRACE(2); // coarse ring, oscillator, row requests
         if (i + 1 < nB)
         {
             double y_re, y_im;
             fir_eval(i + 1, y_re, y_im);
+            FB_TRACE(3); // the matched filter (this half's share)
             front_sample(y_re, y_im, r1_agc, r1_e, i + 1, (i + 1) & 1);
             r1_agc = r2_agc; r1_e = r2_e;
+            FB_TRACE(4); // EbNo sums, AGC, clip, mailbox
         }
         fb_barrier();
     }
+    FB_TRACE_FLUSH(0, nB);
     if (only_a_last) // the coarse estimate runs now; the next launch resumes with this sample's B-part
     {
         const double dval = ((double)nx_pcm) / 32768.0;
@@ -477,8 +484,10 @@ __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const M
     if constexpr (TB > 0) fb_barrier(); // partial sums of samples 0 and 1 published; the front half forms sample 0 now
     fb_barrier();
 
+    FB_TRACE_DECL;
     for (int i = 0; i < nB; i++)
     {
+        FB_TRACE(0); // the barrier
         const double2 c_st = nx_cst;
         const double2 ptd = nx_ptd;
         const double d8out = nx_d8;
@@ -503,6 +512,7 @@ __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const M
             nx_d8 = d8_ring[(size_t)ring_next(ring_next(d8_slot, d8_len), d8_len) * 64];
         }
 
+        FB_TRACE(1); // mailbox read, this half's share of the matched filter (the TB oldest terms), ring requests
         // pt_d = delayedsmpl.update_dont_touch(sig2) (:384): SPS-sample delay on a ring of SPS+1
         {
             dly_ring[(size_t)dly_slot * 64] = make_double2(sre, sim);
@@ -536,10 +546,12 @@ __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const M
             else jd_wt_advance_fraction(st_ptr, -(1.0 - weighting) * st_angle_error * (0.003 / 360.0));
         }
 
+        FB_TRACE(2); // symbol timing: hypot, resonator, atan2, tanh, oscillator nudge
         if (need_px) request_px(); // for the symbol queued in the previous sample
         double frac;
         const bool inst = jd_wt_passed(st_last, st_ptr, st_step, g.ee, frac);
         if (pend && (inst || (i & (MFB_DEFER - 1)) == 0)) output_half();
+        FB_TRACE(5); // requests, instant test, queued output halves
         if (inst)
         {
             // carrier tracking (:411-426): the half of the symbol that feeds back
@@ -565,8 +577,10 @@ __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const M
         st_ptr += st_step;
         while (((int)st_ptr) >= JD_WTSIZE) st_ptr -= JD_WTSIZE;
         nx_cst = cis[jd_cisidx(st_ptr)]; // the symbol NCO's table value for the next sample: in flight across the barrier
+        FB_TRACE(4); // instant block (two tanh, carrier phase and frequency), oscillators, hand-back
         fb_barrier();
     }
+    FB_TRACE_FLUSH(1, nB);
     if (need_px) request_px();
     if (pend) output_half();
 

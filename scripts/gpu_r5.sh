@@ -88,6 +88,18 @@ fi
 if has burstworst; then
   ( timeout 600 python scripts/burst_ab.py 2> "$OUT/burst_worst.err" | tail -1 ) > "$OUT/burst_worst.json"; cat "$OUT/burst_worst.json"; echo
 fi
+if has msktrace; then
+  for n in 65536 256; do
+    JAERO_HIP_LIB=$R/gpurun_tmp/libjaero_hip_trace.so timeout 600 python bench.py --workload msk --channels $n --steps 12 --warmup 4 --no-cpu-baseline --as-written 0 --check-channels 0 > "$OUT/msk_trace_bench_$n.json" 2> "$OUT/msk_trace_$n.err"
+    grep fb_trace "$OUT/msk_trace_$n.err" | tail -1 > "$OUT/msk_fb_trace_$n.json"; cat "$OUT/msk_fb_trace_$n.json"
+  done
+fi
+if has recording_atan2; then
+  ( JAERO_HIP_LIB=$R/gpurun_tmp/libjaero_hip_libatan2.so timeout 900 python scripts/recording_full.py gpu 2> "$OUT/recording_full_libatan2.err" | tail -1 ) > "$OUT/recording_full_gpu_device_atan2.json"; cut -c1-400 "$OUT/recording_full_gpu_device_atan2.json"; echo
+fi
+if has big; then
+  ( timeout 600 python bench.py --channels 131072 --steps 10 --warmup 3 --no-cpu-baseline --as-written 0 2> "$OUT/bench_131072.err" | tail -1 ) > "$OUT/bench_line_131072_channels.json"; cut -c1-200 "$OUT/bench_line_131072_channels.json"; echo
+fi
 if has sizes; then
   for n in 1024 4096 16384 32768; do
     ( timeout 300 python bench.py --channels $n --steps 12 --warmup 4 --no-cpu-baseline --as-written 0 --check-channels 0 2> "$OUT/bench_$n.err" | tail -1 ) > "$OUT/bench_line_${n}_channels.json"
