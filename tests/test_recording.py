@@ -1,7 +1,9 @@
 """The reference's own sample recording of a 10.5 kbps P channel (samples/10.5k_sample.ogg) through the hot path.
 
-tests/golden/recording_oqpsk_10k5.npz holds 12 s of it as 48 kHz int16 PCM (decoded by scripts/vorbis_decode.py, resampled from 44.1 kHz:
-tests/golden/make_recording_golden.py) and what the UNMODIFIED reference made of exactly that PCM: the soft bits OqpskDemodulator handed over,
+tests/golden/recording_oqpsk_10k5.npz holds 12 s of COMMON INPUT made from it -- 48 kHz int16 PCM decoded by scripts/vorbis_decode.py (a Vorbis I
+decoder written from the specification; it cannot be checked against libvorbis here, so this is "the PCM all three sides were fed", not "the
+recording's PCM as the reference's audio stack would decode it") and resampled from 44.1 kHz: tests/golden/make_recording_golden.py -- and what
+the UNMODIFIED reference made of exactly that PCM: the soft bits OqpskDemodulator handed over,
 one status row per frequency estimate, and the signal units its AeroL printed (545, 468 of them CRC-clean; carrier found at 5757 Hz with the
 default centre of 8000 Hz).  CPU: the restatement must reproduce all three exactly.  GPU: a bank fed the recording at several time offsets
 against the oracle, and PCM -> demodulator bank -> Aero-L bank on the device must print the reference's CRC-clean signal units."""
