@@ -466,6 +466,45 @@ def test_oqpsk_live_rate_change_carries_state_over(B, oracle_mod, fb0, fb1, nch)
     bank.close()
 
 
+def test_discard_on_another_stream_is_ordered_before_a_rate_change(B, oracle_mod):
+    """jaero_discard_softbits(stream) enqueues on the caller's stream; a rate-changing jaero_set_settings right behind it synchronises the bank's
+    LAST stream and copies the unread outputs into the new bank.  The discard must have become that last stream (it had not,
+    and the 'discarded' soft bits could travel): writes on one stream, the discard on a second, the rate change, more writes -- what is read
+    afterwards is exactly what the oracle produced behind the call."""
+    import torch
+
+    from jaero_amd import capi, signalgen as G
+
+    O = oracle_mod
+    nsamp, set_at, chunk = 60000, 20480, 4096
+    pcm, _ = G.oqpsk(nsamp, fc=8003.0, ebno_db=12.0, seed=G.SEED_BASE + 7311)
+    o0, o1 = {"fb": 10500.0, "lockingbw": 10500.0}, {"fb": 8400.0, "lockingbw": 8400.0}
+    bank = B.DemodulatorBank(bank_settings("oqpsk", o0), 1, ebno=True, max_write_samples=chunk, softbit_capacity=nsamp)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    dev = torch.from_numpy(pcm[None, :].copy()).cuda()
+    for s in range(0, set_at, chunk):
+        bank.write(dev[:, s:s + chunk].contiguous(), stream=s1.cuda_stream)
+    bank.discard_softbits(s2.cuda_stream)
+    bank.set_settings(bank_settings("oqpsk", o1), channel=0)
+    for s in range(set_at, nsamp, chunk):
+        bank.write(dev[:, s:min(s + chunk, nsamp)].contiguous(), stream=s1.cuda_stream)
+    torch.cuda.synchronize()
+    got = bank.read_softbits(0)
+    d = O.Demod(oracle_settings(O, "oqpsk", o0))
+    for s in range(0, set_at, chunk):
+        d.write(pcm[s:s + chunk])
+    d.take_soft()  # what the caller had read; the reference object still holds p0 soft bits of an unfinished group of 32 (RxDataBits)
+    p0 = d.pending
+    d.set_settings(oracle_settings(O, "oqpsk", o1))
+    for s in range(set_at, nsamp, chunk):
+        d.write(pcm[s:s + chunk])
+    ref = d.take_soft()[p0:]  # the bank's discard dropped those p0 as well: everything it holds is behind the call
+    assert len(ref) > 3000 and len(got) == len(ref) + d.pending, (len(got), len(ref), p0, d.pending)
+    assert np.array_equal(got[:len(ref)] >= 128, ref >= 128)
+    assert_soft_bytes(got[:len(ref)], ref, allow=SILENCE_8400_ALLOW)
+    bank.close()
+
+
 @pytest.mark.parametrize("Fs0,fb0,Fs1,fb1", [(48000, 600, 48000, 1200), (48000, 1200, 24000, 1200), (24000, 600, 48000, 600)])
 def test_msk_live_rate_change_carries_state_over(B, oracle_mod, Fs0, fb0, Fs1, fb1):
     """MskDemodulator::setSettings with another bit / sample rate (mskdemodulator.cpp:135-263; what dataReceived does when audio arrives at
