@@ -729,7 +729,7 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
             if (c->msk_pairs == 1)
             {
                 c->msk_ldsn = MFB_LDSN;
-#define MFA(E, C) HIPCHK(hipFuncSetAttribute((const void *)k_msk_fb<80, MFB_LDSN, E, C, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, mfb_pair_doubles<80, MFB_LDSN, 0>() * (int)sizeof(double)))
+#define MFA(E, C) HIPCHK(hipFuncSetAttribute((const void *)k_msk_fb<80, MFB_LDSN, E, C, 1, MFB1_TB>, hipFuncAttributeMaxDynamicSharedMemorySize, mfb_pair_doubles<80, MFB_LDSN, MFB1_TB>() * (int)sizeof(double)))
                 MFA(false, false); MFA(false, true); MFA(true, false); MFA(true, true);
 #undef MFA
             }
@@ -1174,7 +1174,7 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
         {
             const int P = c->msk_pairs;
             const dim3 gridp((g.ngroups + P - 1) / P), blockp(P * 128);
-            const int ldsp = (P == 4 ? 4 * mfb_pair_doubles<80, MFB4_LDSN, MFB4_TB>() : (P == 2 ? 2 * mfb_pair_doubles<160, MFB2_LDSN, MFB2_TB>() : mfb_pair_doubles<80, MFB_LDSN, 0>())) * (int)sizeof(double);
+            const int ldsp = (P == 4 ? 4 * mfb_pair_doubles<80, MFB4_LDSN, MFB4_TB>() : (P == 2 ? 2 * mfb_pair_doubles<160, MFB2_LDSN, MFB2_TB>() : mfb_pair_doubles<80, MFB_LDSN, MFB1_TB>())) * (int)sizeof(double);
 #define LMF2(E, C) hipLaunchKernelGGL((k_msk_fb<160, MFB2_LDSN, E, C, 2, MFB2_TB>), gridp, blockp, ldsp, st, g, c->p, frames, stride, n, skipA, onlyA, fs, ds, d8)
             if (P == 2)
             {
@@ -1183,7 +1183,7 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
             }
 #undef LMF2
 #define LMF(E, C, PP, LL, TT) hipLaunchKernelGGL((k_msk_fb<80, LL, E, C, PP, TT>), gridp, blockp, ldsp, st, g, c->p, frames, stride, n, skipA, onlyA, fs, ds, d8)
-#define LMFP(E, C) { if (P == 4) LMF(E, C, 4, MFB4_LDSN, MFB4_TB); else LMF(E, C, 1, MFB_LDSN, 0); }
+#define LMFP(E, C) { if (P == 4) LMF(E, C, 4, MFB4_LDSN, MFB4_TB); else LMF(E, C, 1, MFB_LDSN, MFB1_TB); }
             if (eb && cs) LMFP(true, true) else if (eb) LMFP(true, false) else if (cs) LMFP(false, true) else LMFP(false, false)
 #undef LMFP
 #undef LMF

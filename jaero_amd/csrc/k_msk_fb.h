@@ -25,7 +25,13 @@
 #include "jaero_device.h"
 #include "k_oqpsk_fb.h" // fb_barrier, fb_wt_next, jd_div_const
 
-#define MFB_LDSN 36  // one pair per workgroup (small banks): 36 history entries of each arm in LDS, 44 in the front half's registers
+#define MFB_LDSN 36  // one pair per workgroup (small banks): 36 history entries of each arm in LDS, 44 in registers
+// ... of which the MFB1_TB oldest in the BACK half's (round 5): in a small bank the halves sit on different SIMDs and the front half is the long pole
+// (its 320 filter instructions: 1.5 of a sample's 2.5 us in the phase trace, the back half waiting 1.1 us at the barrier), so the back half
+// starts every filter sum as it does in the four-pair kernel
+#ifndef MFB1_TB
+#define MFB1_TB 32 // 24 / 32 / 36 / 40 measured: 256-channel bank 117.0 / 121.3 / 121.0 / 119.5 Msamples/s (103.4 with the whole tail in the front half)
+#endif
 // Four pairs per workgroup (full banks): a wavefront has 256 registers at two per SIMD, the front half's 44-deep tail (176 registers)
 // does not fit.  Then the OLDEST MFB4_TB entries of each arm live in the BACK half's registers (it has room), which starts every filter
 // output -- the sum runs oldest first -- and hands the partial sum to the front half; the front half keeps 80 - 32 - MFB4_TB entries in registers

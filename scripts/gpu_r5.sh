@@ -100,6 +100,16 @@ fi
 if has big; then
   ( timeout 600 python bench.py --channels 131072 --steps 10 --warmup 3 --no-cpu-baseline --as-written 0 2> "$OUT/bench_131072.err" | tail -1 ) > "$OUT/bench_line_131072_channels.json"; cut -c1-200 "$OUT/bench_line_131072_channels.json"; echo
 fi
+if has msksmall; then
+  for v in msk1tb32 msk1tb36 msk1tb40; do
+    L=$R/jaero_amd/libjaero_hip.so; [ $v != product ] && L=$R/gpurun_tmp/libjaero_hip_$v.so
+    for n in 256 4096; do
+      ( JAERO_HIP_LIB=$L timeout 300 python bench.py --workload msk --channels $n --steps 12 --warmup 4 --no-cpu-baseline --as-written 0 --check-channels 0 2>/dev/null | tail -1 ) > "$OUT/bench_line_msk_${n}_$v.json"
+      python -c "import json,sys; d=json.load(open(sys.argv[1])); print('msk', sys.argv[2], sys.argv[3], d['value'], d['ms_per_step'], d['config']['kernel_ms_per_step'])" "$OUT/bench_line_msk_${n}_$v.json" $n $v | tee -a "$OUT/msk_small_ab.txt"
+    done
+  done
+  [ -z "${SKIP_MSK_TESTS:-}" ] && timeout 900 python -m pytest tests -m gpu -q -k "msk" 2>&1 | tail -3
+fi
 if has sizes; then
   for n in 1024 4096 16384 32768; do
     ( timeout 300 python bench.py --channels $n --steps 12 --warmup 4 --no-cpu-baseline --as-written 0 --check-channels 0 2> "$OUT/bench_$n.err" | tail -1 ) > "$OUT/bench_line_${n}_channels.json"
