@@ -1,7 +1,8 @@
 #!/bin/bash
-# Round 5 GPU pass A: the whole GPU suite (with the flags matrix and the recording at the contract), the driver's bench command, the whole
-# recording from five starting points with the product library AND with the A/B build that calls the device library's atan2 / hypot
-# (gpurun_tmp/libjaero_hip_libm.so), and the sample loop at bank sizes 1024 .. 65536 (what sub-wavefront groups could and could not buy).
+# Round 5's GPU experiments, one stage each (the round's EVIDENCE pass is scripts/gpu_evidence.sh): the GPU suite, the driver's bench command, the
+# whole recording from five starting points (product and A/B builds: make -C jaero_amd/csrc ab), the cost of the exact arithmetic (variants), the
+# phase traces (make trace), the sample loop at bank sizes 1024 .. 32768 (sizes), burst kernels op for op against fused (burst_ab), and the
+# small-bank A/Bs.  What each decided is in profiles/r5_*.md / .json and DESIGN 9 items 18-21.
 # usage: scripts/gpu_r5.sh <tag> [what...]   what: tests bench recording recording_ab variants trace sizes
 set -u
 TAG=${1:-r5a}; shift || true
@@ -101,7 +102,7 @@ if has big; then
   ( timeout 600 python bench.py --channels 131072 --steps 10 --warmup 3 --no-cpu-baseline --as-written 0 2> "$OUT/bench_131072.err" | tail -1 ) > "$OUT/bench_line_131072_channels.json"; cut -c1-200 "$OUT/bench_line_131072_channels.json"; echo
 fi
 if has msksmall; then
-  for v in msk1tb32 msk1tb36 msk1tb40; do
+  for v in product ${MSK_SMALL_VARIANTS:-}; do   # MSK_SMALL_VARIANTS="msk1tb24 msk1tb36": A/B builds with -DMFB1_TB=.. in gpurun_tmp/
     L=$R/jaero_amd/libjaero_hip.so; [ $v != product ] && L=$R/gpurun_tmp/libjaero_hip_$v.so
     for n in 256 4096; do
       ( JAERO_HIP_LIB=$L timeout 300 python bench.py --workload msk --channels $n --steps 12 --warmup 4 --no-cpu-baseline --as-written 0 --check-channels 0 2>/dev/null | tail -1 ) > "$OUT/bench_line_msk_${n}_$v.json"
