@@ -41,14 +41,14 @@
 #define MFB4_LDSN 32
 #define MFB4_TB 18
 // 160 taps (600 bps at 48 kHz; round 3): TWO pairs per workgroup, every wavefront alone on its SIMD (512 registers): 72 entries of each arm
-// in LDS (81 664 B per pair, 163 328 B per CU), 36 in the front half's registers, the 52 oldest in the back half's (measured splits 36/44/52/60: 5.87, 6.02, 6.03 Gsamples/s; all still spill 230-300 registers).  k_msk_samples<160,78>
+// in LDS (81 664 B per pair, 163 328 B per CU), 28 in the front half's registers, the 60 oldest in the back half's (36 / 52 until round 5; round 3 measured splits 36/44/52/60: 5.87, 6.02, 6.03 Gsamples/s; all still spill 230-300 registers).  k_msk_samples<160,78>
 // (two wavefronts per CU, 82 entries in 256 registers) spilled ~750 registers; one wavefront per CU with the whole history in LDS and no
 // scratch is slower still (3.4 against 2.3 Gsamples/s at 65 536 channels): occupancy, not the scratch traffic, decides there.
 #ifndef MFB2_LDSN
 #define MFB2_LDSN 72
 #endif
 #ifndef MFB2_TB
-#define MFB2_TB 52
+#define MFB2_TB 60 // round 5, with the filter op for op: 40 / 52 / 60 / 68 measured 5 621 / 5 998 / 6 145 / 6 130 Msamples/s at 65 536 channels
 #endif
 
 struct MfbLds

@@ -71,7 +71,7 @@ class Pair:
         return y
 
 
-@pytest.mark.parametrize("firn,l,tb", [(80, 32, 18), (80, 32, 22), (80, 36, 32), (160, 72, 52), (160, 72, 40)])
+@pytest.mark.parametrize("firn,l,tb", [(80, 32, 18), (80, 32, 22), (80, 36, 32), (160, 72, 52), (160, 72, 60), (160, 72, 40)])
 def test_three_way_history_matches_the_plain_filter(firn, l, tb):
     global FIRN, L, TB, TF
     FIRN, L, TB = firn, l, tb
