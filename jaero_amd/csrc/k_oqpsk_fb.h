@@ -65,7 +65,7 @@ __device__ unsigned long long g_fb_trace[2][10];
 #ifndef FB_SOLO_D
 #define FB_SOLO_D 6 // LDS reads in flight in the one-pair kernel's filter (A/B: 12 measured in round 5, profiles/r5_small_bank.md)
 #endif
-#define FB_LDSN 36 // filter history slots in LDS: 36 KiB + mailboxes (+ a spare 512 B) = 40 448 B per pair, four pairs per CU (161 792 of 163 840 B)
+#define FB_LDSN 36 // filter history slots in LDS: 36 KiB + 3.5 KiB of mailboxes = 40 448 B per pair, four pairs per CU (161 792 of 163 840 B)
 
 // x / d for a positive constant d with rd = 1.0 / d (correctly rounded): q = x*rd is within an ulp, two Newton corrections through exact
 // fma residuals give the correctly rounded quotient (Markstein); the sign of a zero result is x's.  Checked against x / d on 2e9
@@ -111,12 +111,12 @@ __device__ __forceinline__ double fb_fmod360(double x)
 
 struct FbLds
 {
-    double *lre, *lim, *ltap; // [LDSN][64], [LDSN][64], [64]
+    double *lre, *lim;        // [LDSN][64], [LDSN][64]   (the taps are scalar kernel arguments: JTaps28)
     double *data;             // [2][3][64]  F -> B: sre, sim, abval of a sample
     int *idx;                 // [2][64]     B -> F: table index of mixer2 for a sample
 };
 template <int LDSN>
-constexpr int fb_pair_doubles() { return 2 * LDSN * 64 + 64 + 2 * 3 * 64 + 64; }
+constexpr int fb_pair_doubles() { return 2 * LDSN * 64 + 2 * 3 * 64 + 64; }
 
 // one LDS-only barrier per sample; waiting for the partner half alone through sequence words in LDS measured slower (13.9 against 12.8 ms)
 #define FB_SYNC(L) fb_barrier()
@@ -189,7 +189,7 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &
         cq_n = 0;
     };
 
-    double *lre = L.lre, *lim = L.lim, *ltap = L.ltap;
+    double *lre = L.lre, *lim = L.lim;
     if constexpr (!PRE8400)
     {
         const double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
@@ -204,7 +204,6 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &
             tre[j] = fs[(size_t)(LDSN + j) * 64];
             tim[j] = fs[(size_t)(FIRN + LDSN + j) * 64];
         }
-        if (lane < FIRN) ltap[lane] = p.taps2[lane];
     }
     int fir_slot = fir_slot0; // wave-uniform: LDS slot holding the oldest LDS entry, overwritten by the next input
 
@@ -689,8 +688,8 @@ __global__ __launch_bounds__(PAIRS * 128) void k_oqpsk_fb(const JGeom g, const J
     const int grp = blockIdx.x * PAIRS + pair;
     double *base = lds + (size_t)pair * fb_pair_doubles<LDSN>();
     FbLds L;
-    L.lre = base; L.lim = base + LDSN * 64; L.ltap = base + 2 * LDSN * 64;
-    L.data = L.ltap + 64;
+    L.lre = base; L.lim = base + LDSN * 64;
+    L.data = base + 2 * LDSN * 64;
     L.idx = (int *)(L.data + 2 * 3 * 64);
     if (grp >= g.ngroups)
     {
