@@ -232,11 +232,12 @@ class Demod:
 
 def run_demod(settings: Settings, pcm: np.ndarray, chunk=4096, afc=False, cpu_reduce=False,
               dcd_at: int = -1, capture_symbols=False, center_at: int = -1, center_hz: float = 0.0,
-              set_at: int = -1, set_settings: Settings = None):
+              set_at: int = -1, set_settings: Settings = None, sql=False, flags_events=()):
     """Convenience: feed pcm in `chunk`-sample writes (an int, or the list of successive write sizes),
     return dict(soft, status[, symbols]).  set_at / set_settings: setSettings on the live object before the write that starts at or
     after that sample."""
-    d = Demod(settings, afc=afc, cpu_reduce=cpu_reduce, capture_symbols=capture_symbols)
+    d = Demod(settings, afc=afc, sql=sql, cpu_reduce=cpu_reduce, capture_symbols=capture_symbols)
+    flags_events = sorted(list(flags_events))  # [(sample, afc, sql, cpu_reduce)]: set_flags before the write that starts at or after that sample
     n = pcm.shape[0]
     s = 0
     sizes = None if isinstance(chunk, (int, np.integer)) else list(chunk)
@@ -254,6 +255,9 @@ def run_demod(settings: Settings, pcm: np.ndarray, chunk=4096, afc=False, cpu_re
         if set_at >= 0 and s >= set_at:
             d.set_settings(set_settings)
             set_at = -1
+        while flags_events and s >= flags_events[0][0]:
+            _, fa, fs_, fc = flags_events.pop(0)
+            d.set_flags(fa, fs_, fc)
         m = min(chunk, n - s)
         d.write(pcm[s:s + m])
         s += m

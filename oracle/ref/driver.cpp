@@ -103,6 +103,9 @@ static void hook_burst(DEMOD &d, Capture &c)
 // set_at=N [set_fb= set_Fs= set_lockingbw= set_freq_center= set_power=]: setSettings on the live object before the write that starts at or
 // after sample N (a user changing the rate in the settings dialog; MskDemodulator::dataReceived on audio at another rate)
 static std::function<void()> g_set_again;
+// flags_at=N flags_afc= flags_sql= flags_cpureduce= (and flags_at2=N flags2_*): setAFC / setSQL / setCPUReduce on the live object before the write that
+// starts at or after sample N (a user ticking the boxes while it runs) -- pins the oracle's mid-stream flag changes, which the GPU flags-matrix tests build on
+static std::function<void(int)> g_flags_again;
 
 template <class DEMOD>
 static double feed(DEMOD &d, const QByteArray &pcm)
@@ -112,6 +115,7 @@ static double feed(DEMOD &d, const QByteArray &pcm)
     long dcd_at = (long)getd("dcd_at", -1);         // sample index at which DCDstatSlot(true) is called (chunk aligned)
     long dcd_off_at = (long)getd("dcd_off_at", -1);
     long cf_at = (long)getd("center_at", -1);       // sample index at which CenterFreqChangedSlot(center_hz) is called
+    long flags_at = (long)getd("flags_at", -1), flags_at2 = (long)getd("flags_at2", -1);
     double cf_hz = getd("center_hz", 0);
     long nsamp = pcm.size() / 2;
     const char *p = pcm.constData();
@@ -124,6 +128,8 @@ static double feed(DEMOD &d, const QByteArray &pcm)
         if (cf_at >= 0 && s >= cf_at) { d.CenterFreqChangedSlot(cf_hz); cf_at = -1; }
         if (set_at >= 0 && s >= set_at) { if (g_set_again) g_set_again(); set_at = -1; }
         if (set_at2 >= 0 && s >= set_at2) { if (g_set_again) g_set_again(); set_at2 = -1; }
+        if (flags_at >= 0 && s >= flags_at) { if (g_flags_again) g_flags_again(1); flags_at = -1; }
+        if (flags_at2 >= 0 && s >= flags_at2) { if (g_flags_again) g_flags_again(2); flags_at2 = -1; }
         long n = chunk;
         if (s + n > nsamp) n = nsamp - s;
         g_write_start = s;
@@ -152,8 +158,13 @@ static double run_oqpsk(const QByteArray &pcm, Capture &c)
         s.lockingbw = getd("set_lockingbw", s.lockingbw); s.coarsefreqest_fft_power = geti("set_power", s.coarsefreqest_fft_power);
         d.setSettings(s);
     };
+    g_flags_again = [&d](int which) {
+        const char *pre = which == 1 ? "flags_" : "flags2_";
+        d.setAFC(geti((std::string(pre) + "afc").c_str(), 0)); d.setSQL(geti((std::string(pre) + "sql").c_str(), 0));
+        d.setCPUReduce(geti((std::string(pre) + "cpureduce").c_str(), 0));
+    };
     const double secs = feed(d, pcm);
-    g_set_again = nullptr;
+    g_set_again = nullptr; g_flags_again = nullptr;
     return secs;
 }
 
@@ -174,8 +185,13 @@ static double run_msk(const QByteArray &pcm, Capture &c)
         s.lockingbw = getd("set_lockingbw", s.lockingbw); s.coarsefreqest_fft_power = geti("set_power", s.coarsefreqest_fft_power);
         d.setSettings(s);
     };
+    g_flags_again = [&d](int which) {
+        const char *pre = which == 1 ? "flags_" : "flags2_";
+        d.setAFC(geti((std::string(pre) + "afc").c_str(), 0)); d.setSQL(geti((std::string(pre) + "sql").c_str(), 0));
+        d.setCPUReduce(geti((std::string(pre) + "cpureduce").c_str(), 0));
+    };
     const double secs = feed(d, pcm);
-    g_set_again = nullptr;
+    g_set_again = nullptr; g_flags_again = nullptr;
     return secs;
 }
 

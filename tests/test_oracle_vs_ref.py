@@ -40,6 +40,32 @@ def test_oqpsk_8400_random(O, seed, afc, cpu, chunk, center):
          O.run_demod(O.oqpsk_settings(fb=8400.0, lockingbw=8400.0), pcm, afc=bool(afc), cpu_reduce=bool(cpu), chunk=chunk, dcd_at=100000, **kv))
 
 
+@pytest.mark.parametrize("kind,seed,f0,e1,e2,chunk", [
+    ("oqpsk", 51, (0, 0, 0), (31000, 1, 1, 1), (101000, 0, 0, 0), 1000),   # cpuReduce switched on mid-cycle, then off again
+    ("oqpsk", 52, (1, 0, 1), (42000, 0, 1, 0), (113000, 1, 0, 1), 3000),   # starts reduced, AFC toggled with it
+    ("oqpsk", 53, (0, 1, 1), (66000, 1, 0, 1), (67000, 0, 0, 0), 1000),    # two changes a thousand samples apart
+    ("msk", 54, (0, 0, 0), (25000, 1, 0, 1), (90000, 0, 1, 0), 1000),
+    ("msk", 55, (1, 1, 1), (33000, 0, 0, 0), (70500, 1, 0, 1), 1500),
+])
+def test_flags_changed_on_a_running_object(O, kind, seed, f0, e1, e2, chunk):
+    """setAFC / setSQL / setCPUReduce called between two writes of a RUNNING object, at moments that are multiples neither of nfft/4 nor of 4096
+    (oqpskdemodulator.cpp:149-163 + :399-431, mskdemodulator.cpp:105-118 + :345-368): the restatement against the unmodified reference.  What the GPU
+    flags-matrix tests (tests/test_gpu_flags_matrix.py) compare with is the restatement fed such calls: here they are pinned.  cpuReduce changes the
+    estimate cadence (ring fill gated by coarseCounter, nfft instead of nfft/4 between estimates) in the middle of a cycle."""
+    if kind == "oqpsk":
+        pcm, _ = G.oqpsk(170000, fc=8000 + 9.0 * (seed - 50), ebno_db=9.0 + seed % 4, seed=seed)
+        st, kv = O.oqpsk_settings(), {}
+    else:
+        pcm, _ = G.msk(170000, fb=1200.0, fc=1000 + 4.0 * (seed - 50), ebno_db=11.0, seed=seed)
+        st, kv = O.msk_settings(fb=1200.0, lockingbw=1800.0), dict(fb=1200, lockingbw=1800)
+    ref = O.run_ref(kind, pcm, afc=f0[0], sql=f0[1], cpureduce=f0[2], chunk=chunk, flags_at=e1[0], flags_afc=e1[1], flags_sql=e1[2], flags_cpureduce=e1[3],
+                    flags_at2=e2[0], flags2_afc=e2[1], flags2_sql=e2[2], flags2_cpureduce=e2[3], **kv)
+    got = O.run_demod(st, pcm, afc=bool(f0[0]), sql=bool(f0[1]), cpu_reduce=bool(f0[2]), chunk=chunk,
+                      flags_events=[(e1[0], bool(e1[1]), bool(e1[2]), bool(e1[3])), (e2[0], bool(e2[1]), bool(e2[2]), bool(e2[3]))])
+    _cmp(ref, got)
+    assert len(ref["status"]) >= 4  # estimates did fire on both sides of the changes
+
+
 @pytest.mark.parametrize("fb,seed", [(1200, 21), (600, 22)])
 def test_msk_random(O, fb, seed):
     pcm, _ = G.msk(60000, fb=fb, fc=1000 + seed, ebno_db=11.0, seed=seed)
@@ -81,6 +107,25 @@ def test_oqpsk_live_rate_change(O, fb0, fb1, set_at):
     new = O.oqpsk_settings(fb=float(fb1), lockingbw=float(fb1))
     _cmp(O.run_ref("oqpsk", pcm, fb=fb0, lockingbw=fb0, set_at=set_at, set_fb=fb1, set_lockingbw=fb1),
          O.run_demod(O.oqpsk_settings(fb=float(fb0), lockingbw=float(fb0)), pcm, set_at=set_at, set_settings=new))
+
+
+@pytest.mark.parametrize("kind,set_at,chunk,cpu", [("oqpsk", 31000, 1000, 0), ("oqpsk", 70500, 1500, 1), ("msk", 25000, 1000, 0), ("msk", 41000, 1000, 1)])
+def test_same_rate_set_settings_at_an_unaligned_sample(O, kind, set_at, chunk, cpu):
+    """setSettings with the SAME bit rate (another centre frequency / locking bandwidth) on a running object at a sample that is a multiple neither of nfft/4
+    nor of 4096: the coarse ring pointer restarts there, so the object's estimates fire at other samples than its neighbours' from then on -- the case
+    tests/test_gpu_flags_matrix.py builds inside one wavefront.  Restatement against the unmodified reference, with and without cpuReduce."""
+    if kind == "oqpsk":
+        pcm, _ = G.oqpsk(220000 if cpu else 150000, fc=8011.0, ebno_db=11.0, seed=81 + cpu)  # (reduced: one estimate per 64 384 samples)
+        st0, new = O.oqpsk_settings(), O.oqpsk_settings(freq_center=8025.0, lockingbw=9000.0)
+        kv = dict(set_freq_center=8025, set_lockingbw=9000)
+    else:
+        pcm, _ = G.msk(220000 if cpu else 150000, fb=1200.0, fc=1006.0, ebno_db=11.0, seed=83 + cpu)
+        st0, new = O.msk_settings(fb=1200.0, lockingbw=1800.0), O.msk_settings(fb=1200.0, lockingbw=1500.0, freq_center=1012.0)
+        kv = dict(fb=1200, lockingbw=1800, set_freq_center=1012, set_lockingbw=1500)
+    ref = O.run_ref(kind, pcm, cpureduce=cpu, chunk=chunk, set_at=set_at, **kv)
+    got = O.run_demod(st0, pcm, cpu_reduce=bool(cpu), chunk=chunk, set_at=set_at, set_settings=new)
+    _cmp(ref, got)
+    assert len(ref["status"]) >= (2 if cpu else 3)  # estimates on both sides of the call
 
 
 @pytest.mark.parametrize("Fs0,fb0,Fs1,fb1", [(48000, 600, 48000, 1200), (48000, 1200, 24000, 1200), (24000, 600, 48000, 600)])
