@@ -232,7 +232,7 @@ class Demod:
 
 def run_demod(settings: Settings, pcm: np.ndarray, chunk=4096, afc=False, cpu_reduce=False,
               dcd_at: int = -1, capture_symbols=False, center_at: int = -1, center_hz: float = 0.0,
-              set_at: int = -1, set_settings: Settings = None, sql=False, flags_events=()):
+              set_at: int = -1, set_settings: Settings = None, sql=False, flags_events=(), dcd_off_at: int = -1):
     """Convenience: feed pcm in `chunk`-sample writes (an int, or the list of successive write sizes),
     return dict(soft, status[, symbols]).  set_at / set_settings: setSettings on the live object before the write that starts at or
     after that sample."""
@@ -249,6 +249,9 @@ def run_demod(settings: Settings, pcm: np.ndarray, chunk=4096, afc=False, cpu_re
         if dcd_at >= 0 and s >= dcd_at:
             d.set_dcd(1)
             dcd_at = -1
+        if dcd_off_at >= 0 and s >= dcd_off_at:
+            d.set_dcd(0)
+            dcd_off_at = -1
         if center_at >= 0 and s >= center_at:
             d.center_freq_changed(center_hz)
             center_at = -1

@@ -109,6 +109,21 @@ def test_oqpsk_live_rate_change(O, fb0, fb1, set_at):
          O.run_demod(O.oqpsk_settings(fb=float(fb0), lockingbw=float(fb0)), pcm, set_at=set_at, set_settings=new))
 
 
+@pytest.mark.parametrize("kind,afc", [("oqpsk", 0), ("oqpsk", 1), ("msk", 1)])
+def test_dcd_raised_and_dropped_on_a_running_object(O, kind, afc):
+    """DCDstatSlot(true) and later DCDstatSlot(false) between writes (oqpskdemodulator.cpp:629-684, mskdemodulator.cpp:490-526: the flag steers
+    FreqOffsetEstimateSlot's reset logic and, for MSK, the loop gains): restatement against the unmodified reference."""
+    if kind == "oqpsk":
+        pcm, _ = G.oqpsk(150000, fc=8013.0, ebno_db=10.0, seed=91 + afc)
+        st, kv = O.oqpsk_settings(), {}
+    else:
+        pcm, _ = G.msk(150000, fb=1200.0, fc=1007.0, ebno_db=11.0, seed=93)
+        st, kv = O.msk_settings(fb=1200.0, lockingbw=1800.0), dict(fb=1200, lockingbw=1800)
+    ref = O.run_ref(kind, pcm, afc=afc, chunk=1000, dcd_at=37000, dcd_off_at=95000, **kv)
+    got = O.run_demod(st, pcm, afc=bool(afc), chunk=1000, dcd_at=37000, dcd_off_at=95000)
+    _cmp(ref, got)
+
+
 @pytest.mark.parametrize("kind,set_at,chunk,cpu", [("oqpsk", 31000, 1000, 0), ("oqpsk", 70500, 1500, 1), ("msk", 25000, 1000, 0), ("msk", 41000, 1000, 1)])
 def test_same_rate_set_settings_at_an_unaligned_sample(O, kind, set_at, chunk, cpu):
     """setSettings with the SAME bit rate (another centre frequency / locking bandwidth) on a running object at a sample that is a multiple neither of nfft/4
