@@ -202,3 +202,30 @@ def test_c_channel_oracle_vs_unmodified_aerol(R, seed, sigma, inv, lead):
     assert c_voice_equal(voice_ref, voice)
     assert printed == sus_ref
 
+
+@pytest.mark.parametrize("seed,sigma,inv,lead", [(51, 10.0, (False, False), 74), (52, 20.0, (True, False), 1501), (53, 25.0, (True, True), 11)])
+def test_c_channel_false_unique_words_vs_unmodified_aerol(R, seed, sigma, inv, lead):
+    """Copies of the unique word planted so that they lie entirely inside the detection window of a frame (body bits 3986 .. 4094, on the arm parity of
+    the real one): the unmodified AeroL::DecodeC abandons the frame for a new one (aerol.cpp:2201-2316).  The restatement must print the same voice
+    frames and signal units -- it is what tests/test_aerolc_emul.py and the GPU bank tests compare k_aerolc_bits / k_aerolc_bulk with in exactly
+    this situation (a second and third jumped stretch within one round)."""
+    rng = np.random.default_rng(seed)
+    frames, soft = AF.c_channel_case(seed, 7, sigma, inv=inv, lead=lead)
+    soft = soft.copy()
+    uw = soft[lead:lead + 104].copy()
+    planted = 0
+    for f in range(len(frames)):
+        if f % 2 == 0:
+            e = lead + f * 4200 + 104 + int(rng.integers(4089, 4094))
+            e += (e - 103 - lead) % 2
+            soft[e - 103:e + 1] = uw
+            planted += 1
+    voice_ref, sus_ref, dcd_ref, _ = R.run_ref_aerol_c(soft, 32)
+    fn, voice, sus, printed, _ = c_run(R, soft)
+    assert c_voice_equal(voice_ref, voice)
+    assert printed == sus_ref
+    a = R.AeroL(8400)
+    a.write(soft)
+    ev = a.take_events()
+    assert int((ev[:, 1] == 2).sum()) > len(fn), (planted, len(fn))  # more unique words than completed frames: the planted ones fired
+
