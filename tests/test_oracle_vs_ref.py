@@ -124,12 +124,20 @@ def test_dcd_raised_and_dropped_on_a_running_object(O, kind, afc):
     _cmp(ref, got)
 
 
-@pytest.mark.parametrize("kind,set_at,chunk,cpu", [("oqpsk", 31000, 1000, 0), ("oqpsk", 70500, 1500, 1), ("msk", 25000, 1000, 0), ("msk", 41000, 1000, 1)])
+@pytest.mark.parametrize("kind,set_at,chunk,cpu", [("oqpsk", 31000, 1000, 0), ("oqpsk", 70500, 1500, 1), ("msk", 25000, 1000, 0), ("msk", 41000, 1000, 1),
+                                                   ("oqpsk8400", 41000, 1000, 0), ("oqpsk8400", 77000, 3500, 0)])
 def test_same_rate_set_settings_at_an_unaligned_sample(O, kind, set_at, chunk, cpu):
     """setSettings with the SAME bit rate (another centre frequency / locking bandwidth) on a running object at a sample that is a multiple neither of nfft/4
     nor of 4096: the coarse ring pointer restarts there, so the object's estimates fire at other samples than its neighbours' from then on -- the case
     tests/test_gpu_flags_matrix.py builds inside one wavefront.  Restatement against the unmodified reference, with and without cpuReduce."""
-    if kind == "oqpsk":
+    if kind == "oqpsk8400":
+        # the C channel: setSettings also restarts the prefilter (fir_pre.SetKernel, :278-283) -- what jaero_set_settings does for ONE channel of an
+        # 8400 bps bank since round 5 (tests/test_gpu_parity.py::test_8400_set_settings_on_one_channel_of_a_bank compares with the restatement)
+        pcm, _ = G.oqpsk(150000, fb=8400.0, fc=8007.0, ebno_db=11.0, seed=85)
+        st0, new = O.oqpsk_settings(fb=8400.0, lockingbw=8400.0), O.oqpsk_settings(fb=8400.0, lockingbw=7000.0, freq_center=8015.0)
+        kv = dict(fb=8400, lockingbw=8400, set_freq_center=8015, set_lockingbw=7000)
+        kind = "oqpsk"
+    elif kind == "oqpsk":
         pcm, _ = G.oqpsk(220000 if cpu else 150000, fc=8011.0, ebno_db=11.0, seed=81 + cpu)  # (reduced: one estimate per 64 384 samples)
         st0, new = O.oqpsk_settings(), O.oqpsk_settings(freq_center=8025.0, lockingbw=9000.0)
         kv = dict(set_freq_center=8025, set_lockingbw=9000)
