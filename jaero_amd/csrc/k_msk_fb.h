@@ -406,7 +406,7 @@ __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const M
     // ~700 instructions of this half (two window divisions, cos, sin, the differential decode) ran in 80 % of them for one lane in 64.  A lane
     // has at most one symbol queued (instants are ~SPS >= 20 samples apart, the queue empties every 16); one about to queue a second goes first.
     // The entries leaving the three windows are requested one sample after the instant and used when the queue empties.
-    constexpr int MFB_DEFER = 16;
+    constexpr int MFB_DEFER = 32; // < 2 * Fs / fb = 40 samples between a lane's symbols (80 at 600 bps): the one-deep queue never overflows (16 until round 5)
     bool pend = false, need_px = false;
     double pd_ec = 0, pd_re = 0, pd_im = 0, px_marg = 0, px_ms = 0;
     double2 px_dt = make_double2(0.0, 0.0);
