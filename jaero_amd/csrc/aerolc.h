@@ -220,12 +220,37 @@ __global__ __launch_bounds__(64) void k_aerolc_post(const CGeom g, const CPtrs p
     // one pass over the 2714 bits: delay line (:2330), scrambler (:2333), then both extractions read the same descrambled bit h
     unsigned char info[12]; int ninfo = 0, sch = 0, scharptr = 0, kk = 0; // sub-band units (:2343-2358)
     int vch = 0, vcharptr = 0, nv = 0;                                      // voice bytes (:2454-2478)
-    for (int h = 0; h < CC_NBITS; h++)
+    // CB bits per batch (round 5): a bit's step through the delay line is a store at the ring pointer and a load one slot further -- the oldest
+    // entry, written 2708 steps ago -- so within a batch the loads touch slots ptr + 1 .. ptr + CB and the stores slots ptr .. ptr + CB - 1:
+    // issued loads first, then stores, every load still sees what the bit-by-bit order shows it (load k reads the slot store k + 1 overwrites), and
+    // the round trips to memory overlap instead of following one another (0.83 us per bit before: 2.25 ms per 65 536-channel step; batches of
+    // 8: 1.24 ms, of 16: 1.13 ms).
+    constexpr int CB = 16;
+    for (int h0 = 0; h0 < CC_NBITS; h0 += CB)
     {
-        int v = vb[h]; // positions the first call of the codec does not produce stay 0 (buffer zeroed at create)
-        p.dl2[(size_t)dl2_ptr * g.nchp + ch] = (uint8_t)v;
-        dl2_ptr++; dl2_ptr %= CC_DL2;
-        v = p.dl2[(size_t)dl2_ptr * g.nchp + ch];
+        const int nb = (CC_NBITS - h0) < CB ? (CC_NBITS - h0) : CB;
+        int vin[CB], vold[CB];
+#pragma unroll
+        for (int k = 0; k < CB; k++) vin[k] = (k < nb) ? vb[h0 + k] : 0; // positions the first call of the codec does not produce stay 0 (buffer zeroed at create)
+#pragma unroll
+        for (int k = 0; k < CB; k++)
+        {
+            int q = dl2_ptr + k + 1; if (q >= CC_DL2) q -= CC_DL2;
+            vold[k] = (k < nb) ? (int)p.dl2[(size_t)q * g.nchp + ch] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < CB; k++)
+        {
+            int q = dl2_ptr + k; if (q >= CC_DL2) q -= CC_DL2;
+            if (k < nb) p.dl2[(size_t)q * g.nchp + ch] = (uint8_t)vin[k];
+        }
+        dl2_ptr += nb; if (dl2_ptr >= CC_DL2) dl2_ptr -= CC_DL2;
+#pragma unroll
+        for (int k = 0; k < CB; k++)
+        {
+        if (k >= nb) break;
+        const int h = h0 + k;
+        int v = vold[k];
         v ^= p.scr[h];
         const int y = h / 109, o = h - y * 109; // primary field y: bit 0, 96 voice bits (1..96), 12 sub-band bits (97..108)
         if (o >= 1 && o <= 96)
@@ -260,6 +285,7 @@ __global__ __launch_bounds__(64) void k_aerolc_post(const CGeom g, const CPtrs p
                 kk++;
                 ninfo = 0;
             }
+        }
         }
     }
     CLD(CI_DL2_PTR) = dl2_ptr; CLD(CI_DATACD) = datacd; CLD(CI_DCDCOUNT) = dcdcount;
