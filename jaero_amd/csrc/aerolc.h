@@ -16,6 +16,7 @@
 #pragma once
 
 #define CC_NSOFT 5460  // depunctured soft symbols per frame
+#define CC_PITCH 5472  // distance between the rows of CcParams::dep: CC_NSOFT rounded up to 16 bytes, so that k_viterbi_lanes reads aligned 16-byte groups
 #define CC_NBITS 2714  // decoded bits kept per frame
 #define CC_DL2 2709    // DelayLine(2714 - 6): ring of length + 1
 #define CC_FRAME 4096  // channel bits per frame after the unique word
@@ -42,7 +43,7 @@ struct CPtrs
 {
     int *I;                      // [CI_NFIELDS][nchp]
     unsigned long long *B;       // [4][nchp] detector shift registers: real b1, real b2, imag b1, imag b2
-    uint8_t *dep;                // [nchp][CC_NSOFT] deinterleaved + depunctured soft symbols of the frame being received
+    uint8_t *dep;                // [nchp][CC_PITCH] (CC_NSOFT used) deinterleaved + depunctured soft symbols of the frame being received
     uint8_t *vbits;              // [nchp][CC_NSOFT / 2] Viterbi output, one byte per bit
     uint8_t *overlap;            // [nchp][64] Decode_Continuous overlap (byte 62 = length)
     uint8_t *dl2;                // [CC_DL2][nchp] delay line
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(64) void k_aerolc_bits(const CGeom g, const CPtrs p
     for (int k = 0; k < 4; k++) b[k] = p.B[(size_t)k * g.nchp + ch];
     const long long base = ((long long)(unsigned)CLD(CI_NBITS_LO)) | ((long long)CLD(CI_NBITS_HI) << 32);
     const int16_t *s = soft + (size_t)ch * stride;
-    uint8_t *dep = p.dep + (size_t)ch * CC_NSOFT;
+    uint8_t *dep = p.dep + (size_t)ch * CC_PITCH;
     int has = 0, nbulk = 0, yield = 0;
     while (pos < n && !has && !yield)
     {
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(64) void k_aerolc_bulk(const CGeom g, const CPtrs p
     if (ch >= g.nch) return;
     if (k >= CLD(CI_BULK_N)) return;
     const int16_t *s = soft + (size_t)ch * stride;
-    uint8_t *dep = p.dep + (size_t)ch * CC_NSOFT;
+    uint8_t *dep = p.dep + (size_t)ch * CC_PITCH;
     const int f0 = CI_BULK0_SRC + 4 * k;
     const int src = p.I[(size_t)(f0 + 0) * g.nchp + ch], c0 = p.I[(size_t)(f0 + 1) * g.nchp + ch];
     const int len = p.I[(size_t)(f0 + 2) * g.nchp + ch], fl = p.I[(size_t)(f0 + 3) * g.nchp + ch];
@@ -343,7 +344,7 @@ static int aerolc_create(jaero_aerol_ctx *c, int nchannels, int su_capacity)
 #define CA(ptr, count) do { if ((rc = aalloc(c, &(ptr), (size_t)(count)))) return rc; } while (0)
     CA(cs->p.I, (size_t)CI_NFIELDS * g.nchp);
     CA(cs->p.B, (size_t)4 * g.nchp);
-    CA(cs->p.dep, (size_t)g.nchp * CC_NSOFT);
+    CA(cs->p.dep, (size_t)g.nchp * CC_PITCH);
     CA(cs->p.vbits, (size_t)g.nchp * (CC_NSOFT / 2));
     CA(cs->p.overlap, (size_t)g.nchp * 64);
     CA(cs->p.dl2, (size_t)CC_DL2 * g.nchp);
@@ -367,8 +368,8 @@ static int aerolc_create(jaero_aerol_ctx *c, int nchannels, int su_capacity)
         }
         HIPCHK(hipMemcpy(d_scr, scr.data(), 5000, hipMemcpyHostToDevice));
         // the depunctured buffer: every 4th symbol an erasure, for good (the walk only writes the other three)
-        std::vector<uint8_t> dep((size_t)g.nchp * CC_NSOFT, 0);
-        for (size_t k = 0; k < dep.size(); k++) if ((k % CC_NSOFT) % 4 == 3) dep[k] = 128;
+        std::vector<uint8_t> dep((size_t)g.nchp * CC_PITCH, 0);
+        for (size_t k = 0; k < dep.size(); k++) if ((k % CC_PITCH) % 4 == 3) dep[k] = 128;
         HIPCHK(hipMemcpy(cs->p.dep, dep.data(), dep.size(), hipMemcpyHostToDevice));
         std::vector<int> I((size_t)CI_NFIELDS * g.nchp, 0);
         for (int ch = 0; ch < g.nchp; ch++)
@@ -403,8 +404,8 @@ static int aerolc_write(jaero_aerol_ctx *c, const int16_t *dsoft, const int *dco
         aprof_begin(c, 1, st);
         // one block per wavefront for small banks, one per lane (k_viterbi_lanes) from 16 384 channels on, as the P-channel pipeline
         viterbi_launch(st, (const uint8_t *)cs->p.dep, CC_NSOFT, (const uint8_t *)cs->p.overlap, 24, cs->p.vbits, CC_NSOFT / 2, 25, CC_NSOFT / 2, g.nch, valid,
-                       cs->d_vhist);
-        hipLaunchKernelGGL(k_viterbi_overlap_update, dim3(g.nch), dim3(64), 0, st, (const uint8_t *)cs->p.dep, CC_NSOFT, cs->p.overlap, g.nch, valid, 0);
+                       cs->d_vhist, 0, 0, 0, CC_PITCH);
+        hipLaunchKernelGGL(k_viterbi_overlap_update, dim3(g.nch), dim3(64), 0, st, (const uint8_t *)cs->p.dep, CC_NSOFT, cs->p.overlap, g.nch, valid, 0, CC_PITCH);
         aprof_end(c, st);
         aprof_begin(c, 2, st);
         hipLaunchKernelGGL(k_aerolc_post, grid, block, 0, st, g, cs->p);

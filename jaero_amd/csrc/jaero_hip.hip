@@ -1674,8 +1674,9 @@ static inline bool viterbi_use_lanes(int nblocks, int nsoft, int pad)
     return nblocks >= VL_MIN_BLOCKS;
 }
 static void viterbi_launch(hipStream_t st, const uint8_t *d_soft, int nsoft, const uint8_t *d_ov, int pad, uint8_t *d_out, int out_stride,
-                           int out_start, int out_want, int nblocks, const int *valid, unsigned long long *hist, int tiled = 0, int packed = 0, int force_lanes = 0)
+                           int out_start, int out_want, int nblocks, const int *valid, unsigned long long *hist, int tiled = 0, int packed = 0, int force_lanes = 0, int pitch = 0)
 {
+    if (pitch <= 0) pitch = nsoft; // distance between the rows of d_soft (row-major input only)
     if (hist && (tiled || force_lanes || viterbi_use_lanes(nblocks, nsoft, pad))) // tiled input / packed output exist only in the lane layout
     {
         const int waves = (nblocks + 63) / 64;
@@ -1683,13 +1684,13 @@ static void viterbi_launch(hipStream_t st, const uint8_t *d_soft, int nsoft, con
         hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
         if (waves <= ncu * 4) // one wavefront per SIMD is enough: use the entry point that cannot be stacked two to a SIMD
             hipLaunchKernelGGL(k_viterbi_lanes, dim3(waves), dim3(64), 0, st, d_soft, nsoft, d_ov, pad, d_out, out_stride, out_start, out_want, nblocks,
-                               valid, hist, tiled, packed);
+                               valid, hist, tiled, packed, pitch);
         else
             hipLaunchKernelGGL(k_viterbi_lanes_x2, dim3(waves), dim3(64), 0, st, d_soft, nsoft, d_ov, pad, d_out, out_stride, out_start, out_want, nblocks,
-                               valid, hist, tiled, packed);
+                               valid, hist, tiled, packed, pitch);
     }
     else
-        hipLaunchKernelGGL(k_viterbi, dim3(nblocks), dim3(64), 0, st, d_soft, nsoft, d_ov, pad, d_out, out_stride, out_start, out_want, nblocks, valid);
+        hipLaunchKernelGGL(k_viterbi, dim3(nblocks), dim3(64), 0, st, d_soft, nsoft, d_ov, pad, d_out, out_stride, out_start, out_want, nblocks, valid, (const int *)nullptr, pitch);
 }
 static int viterbi_run(int device, const uint8_t *soft, int nblocks, int nsoft, int pad, uint8_t *overlap, uint8_t *bits_out,
                        int out_stride, int out_start, int out_want, int is_device_ptr, hipStream_t st)
@@ -1735,7 +1736,7 @@ extern "C" int jaero_viterbi_decode_soft(int device, const uint8_t *soft, int nb
 }
 
 __global__ void k_viterbi_overlap_update(const uint8_t *__restrict__ soft, int nsoft, uint8_t *__restrict__ overlap, int nstreams,
-                                         const int *__restrict__ valid = nullptr, int tiled = 0)
+                                         const int *__restrict__ valid = nullptr, int tiled = 0, int pitch = 0)
 {
     // soft_bits_overlap_buffer_uchar = soft_bits_in.right(62); resize(62)  (jconvolutionalcodec.cpp:197-198)
     const int b = blockIdx.x;
@@ -1748,7 +1749,7 @@ __global__ void k_viterbi_overlap_update(const uint8_t *__restrict__ soft, int n
         uint8_t v = 0;
         // byte q of row b: row-major, or the tiled layout of k_viterbi_lanes ([wavefront][16-byte group][lane][16])
         auto at = [&](int q) -> uint8_t {
-            return tiled ? soft[(size_t)(b >> 6) * 64 * nsoft + ((size_t)(q >> 4) * 64 + (b & 63)) * 16 + (q & 15)] : soft[(size_t)b * nsoft + q];
+            return tiled ? soft[(size_t)(b >> 6) * 64 * nsoft + ((size_t)(q >> 4) * 64 + (b & 63)) * 16 + (q & 15)] : soft[(size_t)b * (pitch > 0 ? pitch : nsoft) + q];
         };
         if (nsoft >= k) v = at(nsoft - k + t);
         else if (t < nsoft) v = at(t);

@@ -64,14 +64,14 @@ __device__ __forceinline__ unsigned vt_search(unsigned pm, unsigned lane, unsign
 // Decoded bit k (k < sets-6) is written to out[b*out_stride + (k - out_start)] when 0 <= k-out_start < out_want.
 __global__ __launch_bounds__(64) void k_viterbi(const uint8_t *__restrict__ soft, int nsoft, const uint8_t *__restrict__ overlap,
                                                 int pad, uint8_t *__restrict__ out, int out_stride, int out_start, int out_want,
-                                                int nblocks, const int *__restrict__ valid = nullptr, const int *__restrict__ lens = nullptr)
+                                                int nblocks, const int *__restrict__ valid = nullptr, const int *__restrict__ lens = nullptr, int pitch = 0)
 {
     __shared__ VtHist h;
     const unsigned lane = threadIdx.x;
     const int b = blockIdx.x;
     if (b >= nblocks) return;
     if (valid && !valid[b]) return; // Aero-L pipeline: only the channels that completed a block this round
-    const uint8_t *in = soft + (size_t)b * nsoft; // rows are nsoft apart; lens (optional): this block's own length <= nsoft
+    const uint8_t *in = soft + (size_t)b * (pitch > 0 ? pitch : nsoft); // rows are pitch (default nsoft) apart; lens (optional): this block's own length <= nsoft
     if (lens) { nsoft = lens[b]; if (out_want > nsoft / 2) out_want = nsoft / 2; }
     const uint8_t *ov = overlap ? overlap + (size_t)b * 64 : nullptr;
     const int ovl = ov ? (int)ov[62] : 0;

@@ -193,7 +193,7 @@ static_assert(VL_TB_BATCH % 4 == 0, "the traceback stores four decoded bits at a
 // hist: [gridDim.x][VT_CAP][64] uint64 scratch.  Same stream convention as k_viterbi (overlap ++ soft ++ pad x 128).
 __device__ __forceinline__ void vl_decode(const uint8_t *__restrict__ soft, int nsoft, const uint8_t *__restrict__ overlap, int pad,
                                           uint8_t *__restrict__ out, int out_stride, int out_start, int out_want, int nblocks,
-                                          const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled, uint4 *lds_soft, int packed)
+                                          const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled, uint4 *lds_soft, int packed, int pitch)
 {
     const unsigned lane = threadIdx.x;
     const int b0 = blockIdx.x * 64 + (int)lane;
@@ -201,17 +201,20 @@ __device__ __forceinline__ void vl_decode(const uint8_t *__restrict__ soft, int 
     const int b = inrange ? b0 : 0;
     bool todo = inrange && (!valid || valid[b] != 0);
     if (!__any(todo)) return;
-    // input rows: row-major [block][nsoft], or (tiled; nsoft a multiple of 16) [wavefront][16-byte group][lane][16]: the 64 rows a
+    // input rows: row-major [block][pitch] (pitch >= nsoft; a pitch that is a multiple of 16 and >= nsoft rounded up to 16 keeps the
+    // fast path below for a row length that is not, e.g. the 5460 soft symbols of an Aero-L C-channel frame in rows of 5472), or
+    // (tiled; nsoft a multiple of 16) [wavefront][16-byte group][lane][16]: the 64 rows a
     // wavefront decodes interleaved in 16-byte pieces, so that every chunk load is 8 x 1 KiB contiguous (the Aero-L deinterleaver
     // writes this layout; with one row per lane a load touches 64 pages and the same kernel runs 0.85 ms slower on cold rows)
-    const uint8_t *in = tiled ? soft + (size_t)blockIdx.x * 64 * nsoft + lane * 16 : soft + (size_t)b * nsoft;
+    const uint8_t *in = tiled ? soft + (size_t)blockIdx.x * 64 * nsoft + lane * 16 : soft + (size_t)b * pitch;
     const int gstride = tiled ? 64 : 1; // distance between consecutive 16-byte groups of a row, in groups
     auto inbyte = [&](int q) -> unsigned { return in[(size_t)(q >> 4) * gstride * 16 + (q & 15)]; };
     const uint8_t *ov = overlap ? overlap + (size_t)b * 64 : in;
     const int my_ovl = overlap ? (int)ov[62] : 0;
     uint8_t *o = out + (size_t)b * out_stride;
     unsigned long long *hw = hist + (size_t)blockIdx.x * VT_CAP * 64 + lane;
-    const bool rows16 = ((((size_t)soft) | (size_t)nsoft) & 15) == 0; // every row of the bank 16-byte aligned (always so when tiled)
+    const int ngroups = (nsoft + 15) / 16; // 16-byte groups of a row; a partial last group is read whole, which the pitch must cover
+    const bool rows16 = ((((size_t)soft) | (size_t)pitch) & 15) == 0 && (tiled || pitch >= ngroups * 16); // every row 16-byte aligned (always so when tiled)
 
     while (__any(todo))
     {
@@ -231,7 +234,6 @@ __device__ __forceinline__ void vl_decode(const uint8_t *__restrict__ soft, int 
         // (lgkmcnt): the history store of every step (vmcnt) is never waited for outside the traceback.
         const int fast_lo = (ovl + 1) / 2, fast_hi = (rows16 && (ovl & 1) == 0) ? (ovl + nsoft) / 2 : 0; // steps [fast_lo, fast_hi)
         const uint4 *cp = (const uint4 *)__builtin_assume_aligned(in, 16);
-        const int ngroups = nsoft / 16;
         const unsigned short *lp = (const unsigned short *)lds_soft + lane * 8;
         // The next chunk is requested as soon as the current one is in LDS, into registers, with hand-written loads: the compiler
         // sinks an ordinary prefetch down to its use (and then every chunk costs a full memory latency, ~0.9 ms per launch when the
@@ -483,15 +485,15 @@ __device__ __forceinline__ void vl_decode(const uint8_t *__restrict__ soft, int 
 // per SIMD use the (1, 2) entry.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_viterbi_lanes(
     const uint8_t *__restrict__ soft, int nsoft, const uint8_t *__restrict__ overlap, int pad, uint8_t *__restrict__ out, int out_stride, int out_start,
-    int out_want, int nblocks, const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled, int packed)
+    int out_want, int nblocks, const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled, int packed, int pitch)
 {
     __shared__ uint4 lds_soft[8 * 64];
-    vl_decode(soft, nsoft, overlap, pad, out, out_stride, out_start, out_want, nblocks, valid, hist, tiled, lds_soft, packed);
+    vl_decode(soft, nsoft, overlap, pad, out, out_stride, out_start, out_want, nblocks, valid, hist, tiled, lds_soft, packed, pitch);
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_viterbi_lanes_x2(
     const uint8_t *__restrict__ soft, int nsoft, const uint8_t *__restrict__ overlap, int pad, uint8_t *__restrict__ out, int out_stride, int out_start,
-    int out_want, int nblocks, const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled, int packed)
+    int out_want, int nblocks, const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled, int packed, int pitch)
 {
     __shared__ uint4 lds_soft[8 * 64];
-    vl_decode(soft, nsoft, overlap, pad, out, out_stride, out_start, out_want, nblocks, valid, hist, tiled, lds_soft, packed);
+    vl_decode(soft, nsoft, overlap, pad, out, out_stride, out_start, out_want, nblocks, valid, hist, tiled, lds_soft, packed, pitch);
 }

@@ -56,7 +56,7 @@ extern "C" Emul *emul_create(int nch, int su_cap)
     g.nch = nch; g.nchp = (nch + 63) / 64 * 64; g.su_cap = su_cap > 0 ? su_cap : 192; g.v_cap = (g.su_cap + 2) / 3; g.ev_cap = 256;
     e->p.I = zalloc<int>(e, (size_t)CI_NFIELDS * g.nchp);
     e->p.B = zalloc<unsigned long long>(e, (size_t)4 * g.nchp);
-    e->p.dep = zalloc<uint8_t>(e, (size_t)g.nchp * CC_NSOFT);
+    e->p.dep = zalloc<uint8_t>(e, (size_t)g.nchp * CC_PITCH);
     e->p.vbits = zalloc<uint8_t>(e, (size_t)g.nchp * (CC_NSOFT / 2));
     e->p.overlap = zalloc<uint8_t>(e, (size_t)g.nchp * 64);
     e->p.dl2 = zalloc<uint8_t>(e, (size_t)CC_DL2 * g.nchp);
@@ -73,7 +73,7 @@ extern "C" Emul *emul_create(int nch, int su_cap)
         state[0] = val0;
     }
     e->p.scr = scr;
-    for (size_t k = 0; k < (size_t)g.nchp * CC_NSOFT; k++) if ((k % CC_NSOFT) % 4 == 3) e->p.dep[k] = 128; // as aerolc_create
+    for (size_t k = 0; k < (size_t)g.nchp * CC_PITCH; k++) if ((k % CC_PITCH) % 4 == 3) e->p.dep[k] = 128; // as aerolc_create
     for (int ch = 0; ch < g.nchp; ch++)
     {
         e->p.I[(size_t)CI_CNTR * g.nchp + ch] = 1000000000;
@@ -109,7 +109,7 @@ extern "C" void emul_write(Emul *e, const int16_t *soft, const int *counts, int 
             if (e->p.I[(size_t)CI_HAS_BLOCK * g.nchp + ch])
             {
                 uint8_t out[CC_NSOFT / 2 + 16];
-                const int nb = jo_decode_continuous(e->codec[ch], e->p.dep + (size_t)ch * CC_NSOFT, CC_NSOFT, out);
+                const int nb = jo_decode_continuous(e->codec[ch], e->p.dep + (size_t)ch * CC_PITCH, CC_NSOFT, out);
                 memcpy(e->p.vbits + (size_t)ch * (CC_NSOFT / 2), out, (size_t)(nb < CC_NSOFT / 2 ? nb : CC_NSOFT / 2)); // unwritten tail keeps its old content, as on the GPU
             }
         launch(g.nchp / 64, 64, [&] { k_aerolc_post(g, e->p); });
