@@ -170,6 +170,8 @@ static int aerol_create(int device, int nchannels, int fb, int max_softbits_per_
         g.dl2_words = (g.dl2_sz + 31) / 32 + 1;
         AA(c->p.dl2w, (size_t)g.nchp * g.dl2_words);
     }
+    // R/T packet search in a large bank: the trial decodes (each channel's own length) one block per lane as well, bits out one per byte
+    if (burst && viterbi_use_lanes(g.nch, 128, 0)) AA(c->d_vhist, viterbi_hist_bytes(g.nch) / sizeof(unsigned long long));
 #undef AA
     c->p.scr = d_scr;
     {
@@ -253,8 +255,9 @@ extern "C" int jaero_aerol_write(jaero_aerol_ctx *c, const int16_t *soft, const 
         {
             hipLaunchKernelGGL(k_aerolb_bits, grid, block, 0, st, g, c->p, dsoft, dcounts, stride);
             hipLaunchKernelGGL(k_aerolb_deint, dim3((g.nch + 3) / 4), dim3(256), 0, st, g, c->p);
-            hipLaunchKernelGGL(k_viterbi, dim3(g.nch), dim3(64), 0, st, (const uint8_t *)c->p.deint, RT_BLOCKSZ, (const uint8_t *)nullptr, 0, c->p.vbits,
-                               RT_BLOCKSZ / 2, 0, RT_BLOCKSZ / 2, g.nch, valid, lens);
+            // trial lengths are 128, 320, 512, .. (k_aerolb_bits): never below the lane layout's minimum of 4 * VT_ORDER steps
+            viterbi_launch(st, (const uint8_t *)c->p.deint, RT_BLOCKSZ, (const uint8_t *)nullptr, 0, c->p.vbits, RT_BLOCKSZ / 2, 0, RT_BLOCKSZ / 2, g.nch, valid,
+                           c->d_vhist, 0, 0, c->d_vhist != nullptr, 0, lens);
             hipLaunchKernelGGL(k_aerolb_post, grid, block, 0, st, g, c->p);
         }
         hipLaunchKernelGGL(k_aerol_end_write, grid, block, 0, st, g, c->p, dcounts);

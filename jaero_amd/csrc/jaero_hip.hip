@@ -1674,7 +1674,7 @@ static inline bool viterbi_use_lanes(int nblocks, int nsoft, int pad)
     return nblocks >= VL_MIN_BLOCKS;
 }
 static void viterbi_launch(hipStream_t st, const uint8_t *d_soft, int nsoft, const uint8_t *d_ov, int pad, uint8_t *d_out, int out_stride,
-                           int out_start, int out_want, int nblocks, const int *valid, unsigned long long *hist, int tiled = 0, int packed = 0, int force_lanes = 0, int pitch = 0)
+                           int out_start, int out_want, int nblocks, const int *valid, unsigned long long *hist, int tiled = 0, int packed = 0, int force_lanes = 0, int pitch = 0, const int *lens = nullptr)
 {
     if (pitch <= 0) pitch = nsoft; // distance between the rows of d_soft (row-major input only)
     if (hist && (tiled || force_lanes || viterbi_use_lanes(nblocks, nsoft, pad))) // tiled input / packed output exist only in the lane layout
@@ -1684,13 +1684,13 @@ static void viterbi_launch(hipStream_t st, const uint8_t *d_soft, int nsoft, con
         hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
         if (waves <= ncu * 4) // one wavefront per SIMD is enough: use the entry point that cannot be stacked two to a SIMD
             hipLaunchKernelGGL(k_viterbi_lanes, dim3(waves), dim3(64), 0, st, d_soft, nsoft, d_ov, pad, d_out, out_stride, out_start, out_want, nblocks,
-                               valid, hist, tiled, packed, pitch);
+                               valid, hist, tiled, packed, pitch, lens);
         else
             hipLaunchKernelGGL(k_viterbi_lanes_x2, dim3(waves), dim3(64), 0, st, d_soft, nsoft, d_ov, pad, d_out, out_stride, out_start, out_want, nblocks,
-                               valid, hist, tiled, packed, pitch);
+                               valid, hist, tiled, packed, pitch, lens);
     }
     else
-        hipLaunchKernelGGL(k_viterbi, dim3(nblocks), dim3(64), 0, st, d_soft, nsoft, d_ov, pad, d_out, out_stride, out_start, out_want, nblocks, valid, (const int *)nullptr, pitch);
+        hipLaunchKernelGGL(k_viterbi, dim3(nblocks), dim3(64), 0, st, d_soft, nsoft, d_ov, pad, d_out, out_stride, out_start, out_want, nblocks, valid, lens, pitch);
 }
 static int viterbi_run(int device, const uint8_t *soft, int nblocks, int nsoft, int pad, uint8_t *overlap, uint8_t *bits_out,
                        int out_stride, int out_start, int out_want, int is_device_ptr, hipStream_t st)

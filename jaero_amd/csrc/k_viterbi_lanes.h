@@ -193,7 +193,8 @@ static_assert(VL_TB_BATCH % 4 == 0, "the traceback stores four decoded bits at a
 // hist: [gridDim.x][VT_CAP][64] uint64 scratch.  Same stream convention as k_viterbi (overlap ++ soft ++ pad x 128).
 __device__ __forceinline__ void vl_decode(const uint8_t *__restrict__ soft, int nsoft, const uint8_t *__restrict__ overlap, int pad,
                                           uint8_t *__restrict__ out, int out_stride, int out_start, int out_want, int nblocks,
-                                          const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled, uint4 *lds_soft, int packed, int pitch)
+                                          const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled, uint4 *lds_soft, int packed, int pitch,
+                                          const int *__restrict__ lens)
 {
     const unsigned lane = threadIdx.x;
     const int b0 = blockIdx.x * 64 + (int)lane;
@@ -211,28 +212,34 @@ __device__ __forceinline__ void vl_decode(const uint8_t *__restrict__ soft, int 
     auto inbyte = [&](int q) -> unsigned { return in[(size_t)(q >> 4) * gstride * 16 + (q & 15)]; };
     const uint8_t *ov = overlap ? overlap + (size_t)b * 64 : in;
     const int my_ovl = overlap ? (int)ov[62] : 0;
+    // lens (optional, row-major input): block b's own length <= nsoft (an R/T packet trial, k_aerolb_bits); its decoded bits end at lens[b] / 2
+    const int my_len = lens ? lens[b] : nsoft;
     uint8_t *o = out + (size_t)b * out_stride;
     unsigned long long *hw = hist + (size_t)blockIdx.x * VT_CAP * 64 + lane;
-    const int ngroups = (nsoft + 15) / 16; // 16-byte groups of a row; a partial last group is read whole, which the pitch must cover
-    const bool rows16 = ((((size_t)soft) | (size_t)pitch) & 15) == 0 && (tiled || pitch >= ngroups * 16); // every row 16-byte aligned (always so when tiled)
+    // a partial last 16-byte group of a row is read whole, which the pitch must cover
+    const bool rows16 = ((((size_t)soft) | (size_t)pitch) & 15) == 0 && (tiled || pitch >= (nsoft + 15) / 16 * 16); // every row 16-byte aligned (always so when tiled)
 
     while (__any(todo))
     {
-        // this pass: the lanes whose overlap length equals that of the first pending lane
-        const int ovl = __builtin_amdgcn_readfirstlane(__shfl(my_ovl, __ffsll((long long)__ballot(todo)) - 1)); // SGPR: all control flow below is scalar
-        const bool mine = todo && my_ovl == ovl;
+        // this pass: the lanes whose overlap length (and block length) equal those of the first pending lane
+        const int first = __ffsll((long long)__ballot(todo)) - 1;
+        const int ovl = __builtin_amdgcn_readfirstlane(__shfl(my_ovl, first)); // SGPR: all control flow below is scalar
+        const int rowlen = lens ? __builtin_amdgcn_readfirstlane(__shfl(my_len, first)) : nsoft;
+        const int want = lens ? min(out_want, rowlen / 2) : out_want;
+        const int ngroups = (rowlen + 15) / 16; // 16-byte groups of this pass's rows
+        const bool mine = todo && my_ovl == ovl && my_len == rowlen;
         todo = todo && !mine;
-        const int total = ovl + nsoft + pad;
+        const int total = ovl + rowlen + pad;
         const int sets = total / 2;
 
         auto getpair = [&](int i, unsigned &s0, unsigned &s1) { // soft bytes 2i, 2i+1 of the stream, any position (slow)
-            auto one = [&](int q) -> unsigned { return q < ovl ? ov[q] : (q - ovl < nsoft ? inbyte(q - ovl) : 128u); };
+            auto one = [&](int q) -> unsigned { return q < ovl ? ov[q] : (q - ovl < rowlen ? inbyte(q - ovl) : 128u); };
             s0 = one(2 * i); s1 = one(2 * i + 1);
         };
         // Fast source for the steps whose two soft bytes lie inside a 16-byte aligned block: 128-byte chunks (64 steps) of every lane's
         // row are staged in LDS as [group][lane] uint4, fetched one chunk ahead into registers.  The per-step reads are then LDS reads
         // (lgkmcnt): the history store of every step (vmcnt) is never waited for outside the traceback.
-        const int fast_lo = (ovl + 1) / 2, fast_hi = (rows16 && (ovl & 1) == 0) ? (ovl + nsoft) / 2 : 0; // steps [fast_lo, fast_hi)
+        const int fast_lo = (ovl + 1) / 2, fast_hi = (rows16 && (ovl & 1) == 0) ? (ovl + rowlen) / 2 : 0; // steps [fast_lo, fast_hi)
         const uint4 *cp = (const uint4 *)__builtin_assume_aligned(in, 16);
         const unsigned short *lp = (const unsigned short *)lds_soft + lane * 8;
         // The next chunk is requested as soon as the current one is in LDS, into registers, with hand-written loads: the compiler
@@ -334,7 +341,7 @@ __device__ __forceinline__ void vl_decode(const uint8_t *__restrict__ soft, int 
                     const int j = j0 + 4 * g, klow = K0 - (j + 3);
                     if (packed)
                     {
-                        if (j >= min_tb && j + 3 < len && klow >= 0 && klow + 3 < out_want && (klow >> 5) == ((klow + 3) >> 5))
+                        if (j >= min_tb && j + 3 < len && klow >= 0 && klow + 3 < want && (klow >> 5) == ((klow + 3) >> 5))
                             pk_bits(klow, ((word * 0x00204081u) >> 21) & 15u); // bytes 0..3 of `word` -> bits 0..3
                         else
                         {
@@ -342,11 +349,11 @@ __device__ __forceinline__ void vl_decode(const uint8_t *__restrict__ soft, int 
                             for (int u = 0; u < 4; u++)
                             {
                                 const int jj = j + u, k = K0 - jj;
-                                if (jj >= min_tb && jj < len && k >= 0 && k < out_want) pk_bits(k, (word >> (8 * (3 - u))) & 1u);
+                                if (jj >= min_tb && jj < len && k >= 0 && k < want) pk_bits(k, (word >> (8 * (3 - u))) & 1u);
                             }
                         }
                     }
-                    else if (j >= min_tb && j + 3 < len && klow >= 0 && klow + 3 < out_want)
+                    else if (j >= min_tb && j + 3 < len && klow >= 0 && klow + 3 < want)
                     {
                         if (mine) __builtin_memcpy(o + klow, &word, 4);
                     }
@@ -356,7 +363,7 @@ __device__ __forceinline__ void vl_decode(const uint8_t *__restrict__ soft, int 
                         for (int u = 0; u < 4; u++)
                         {
                             const int jj = j + u, k = K0 - jj;
-                            if (jj >= min_tb && jj < len && k >= 0 && k < out_want && mine) o[k] = (uint8_t)(word >> (8 * (3 - u)));
+                            if (jj >= min_tb && jj < len && k >= 0 && k < want && mine) o[k] = (uint8_t)(word >> (8 * (3 - u)));
                         }
                     }
                 }
@@ -485,15 +492,17 @@ __device__ __forceinline__ void vl_decode(const uint8_t *__restrict__ soft, int 
 // per SIMD use the (1, 2) entry.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_viterbi_lanes(
     const uint8_t *__restrict__ soft, int nsoft, const uint8_t *__restrict__ overlap, int pad, uint8_t *__restrict__ out, int out_stride, int out_start,
-    int out_want, int nblocks, const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled, int packed, int pitch)
+    int out_want, int nblocks, const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled, int packed, int pitch,
+    const int *__restrict__ lens)
 {
     __shared__ uint4 lds_soft[8 * 64];
-    vl_decode(soft, nsoft, overlap, pad, out, out_stride, out_start, out_want, nblocks, valid, hist, tiled, lds_soft, packed, pitch);
+    vl_decode(soft, nsoft, overlap, pad, out, out_stride, out_start, out_want, nblocks, valid, hist, tiled, lds_soft, packed, pitch, lens);
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_viterbi_lanes_x2(
     const uint8_t *__restrict__ soft, int nsoft, const uint8_t *__restrict__ overlap, int pad, uint8_t *__restrict__ out, int out_stride, int out_start,
-    int out_want, int nblocks, const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled, int packed, int pitch)
+    int out_want, int nblocks, const int *__restrict__ valid, unsigned long long *__restrict__ hist, int tiled, int packed, int pitch,
+    const int *__restrict__ lens)
 {
     __shared__ uint4 lds_soft[8 * 64];
-    vl_decode(soft, nsoft, overlap, pad, out, out_stride, out_start, out_want, nblocks, valid, hist, tiled, lds_soft, packed, pitch);
+    vl_decode(soft, nsoft, overlap, pad, out, out_stride, out_start, out_want, nblocks, valid, hist, tiled, lds_soft, packed, pitch, lens);
 }

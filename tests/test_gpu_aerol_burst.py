@@ -51,9 +51,12 @@ def test_against_reference_golden(B, oracle_mod, name):
     bank.close()
 
 
-def test_bank_vs_oracle(B, oracle_mod):
+@pytest.mark.parametrize("layout", ["wave", "lanes"])
+def test_bank_vs_oracle(B, oracle_mod, force_viterbi_layout, layout):
     """70 channels (two wave groups): different packets, noise levels, arm inversions, lost tails / late unique words, ragged write
-    sizes (so trial lengths, markers and group ends fall anywhere relative to the writes)."""
+    sizes (so trial lengths, markers and group ends fall anywhere relative to the writes).  Both Viterbi layouts: banks from 16 384
+    channels on decode one trial per lane, the lanes of a wavefront grouped by trial length (k_viterbi_lanes, lens)."""
+    force_viterbi_layout(layout)
     spec = importlib.util.spec_from_file_location("mk", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
     mk = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mk)
@@ -79,13 +82,15 @@ def test_bank_vs_oracle(B, oracle_mod):
     bank.close()
 
 
+@pytest.mark.parametrize("layout", ["wave", "lanes"])
 @pytest.mark.parametrize("fb", [1200, 600])
-def test_msk_bank_vs_oracle(B, oracle_mod, fb):
+def test_msk_bank_vs_oracle(B, oracle_mod, force_viterbi_layout, fb, layout):
     """600 / 1200 bps bursts (updateMSK: R test at 5 blocks, count peek at 11, decode at the announced length): 66 channels, ragged
     writes, inverted streams, lost tails, late unique words, noise-only channels."""
     spec = importlib.util.spec_from_file_location("mk", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
     mk = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mk)
+    force_viterbi_layout(layout)
     nch = 66
     rng = np.random.default_rng(fb)
     streams = []
