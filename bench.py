@@ -242,7 +242,7 @@ def aerol_kernel_name(cls: str, nch: int, mode: str) -> str:
     if mode == "c":
         return {"bits": "k_aerolc_bits", "viterbi": vit, "post": "k_aerolc_post"}[cls]
     if mode == "b":
-        return {"bits": "k_aerolb_bits", "viterbi": "k_viterbi", "post": "k_aerolb_post"}[cls]
+        return {"bits": "k_aerolb_bits", "viterbi": vit, "post": "k_aerolb_post"}[cls]
     return {"bits": "k_aerol_bits", "viterbi": vit, "post": "k_aerol_post_packed" if nch >= 16384 else "k_aerol_post"}[cls]
 
 
@@ -815,7 +815,8 @@ def aerol_burst_bench():
         frames[i].copy_(soft[idx, i * per:(i + 1) * per])
     del soft
     counts = torch.full((nch,), per, dtype=torch.int32, device=dev)
-    bank = AeroLBank(nch, 10500, device=local, max_softbits_per_write=per, su_capacity=8 * (K + W) + 8, burst=True)
+    PROF = 4  # steps repeated after the clock and the oracle check, with the per-class events on (93 event pairs per step would weigh on the timed ones)
+    bank = AeroLBank(nch, 10500, device=local, max_softbits_per_write=per, su_capacity=8 * (K + W + PROF) + 8, burst=True)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(i):
@@ -823,6 +824,14 @@ def aerol_burst_bench():
 
     dt, dts = run_timed(step, W, K, world, dev)
     oc, npk = aerol_oracle_check("burst", bank, nch, lambda c: host[c % nuniq], 8 * (K + W) + 8)
+    bank.profile_enable(True)
+    for i in range(PROF):
+        step(W + i % K)
+    torch.cuda.synchronize()
+    ms, nl = {}, {}
+    for w, nm in enumerate(("bits", "viterbi", "post")):
+        ms[nm], nl[nm] = bank.profile_read(w)
+    vit = aerol_kernel_name("viterbi", nch, "b")
     if rank == 0:
         value = float(K) * per * nch * world / dt / 1e6
         # algorithmic bytes per soft bit: 2 (int16 in) + 1 (block write); every trial re-reads the block, deinterleaves and decodes it:
@@ -836,10 +845,13 @@ def aerol_burst_bench():
             "config": {"workload": f"{nch}-channel-per-GPU 10.5 kbps R/T bursts: per step and channel one burst as the burst demodulator emits it "
                                    f"(marker, lead-in, unique word, T packet with 7 signal units, noise; {per} entries), {nuniq} distinct streams",
                        "channels_per_gpu": nch, "total_channels": nch * world, "packets_per_s": round(float(K) * nch * world / dt, 1),
-                       "packets_decoded_in_first_channels": npk, "channels_checked": min(4, nch), "expected": (K + W) * min(4, nch)},
-            "roofline": {"bound": "hbm", "kernel": "k_viterbi (trial decodes, one block per wavefront)", "kernel_name": "k_viterbi", "achieved": round(alg * value * 1e6 / 1e9, 2),
+                       "packets_decoded_in_first_channels": npk, "channels_checked": min(4, nch), "expected": (K + W) * min(4, nch),
+                       "kernel_ms_per_step": {k: round(v / PROF, 4) for k, v in ms.items()}, "kernel_launches_per_step": {k: nl[k] // PROF for k in nl},
+                       "kernel_ms_from": f"{PROF} of the timed steps' inputs written again after the clock and the oracle check, event pairs around each class "
+                                         "(bits = k_aerolb_bits + k_aerolb_deint)"},
+            "roofline": {"bound": "hbm", "kernel": f"{vit} (trial decodes, one block per {'lane' if vit.endswith('lanes') else 'wavefront'})", "kernel_name": vit, "achieved": round(alg * value * 1e6 / 1e9, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg * value * 1e6 / 1e9 / HBM_PEAK_GBS, 6),
-                         "traffic": aerol_traffic("pmc_summary_aerol_burst.json", "k_viterbi", nch)[0], "traffic_from": aerol_traffic("pmc_summary_aerol_burst.json", "k_viterbi", nch)[1],
+                         "traffic": aerol_traffic("pmc_summary_aerol_burst.json", vit, nch)[0], "traffic_from": aerol_traffic("pmc_summary_aerol_burst.json", vit, nch)[1],
                          "alg_bytes_per_softbit": round(alg, 2),
                          "note": "whole-step figure (the step is launch- and latency-bound: 31 rounds of 4 small kernels); the Viterbi trials "
                                  "are integer-VALU work, see the aerol workload"},

@@ -253,12 +253,18 @@ extern "C" int jaero_aerol_write(jaero_aerol_ctx *c, const int16_t *soft, const 
         const dim3 grid(g.nchp / 64), block(64);
         for (int r = 0; r < rounds; r++)
         {
+            aprof_begin(c, 0, st);
             hipLaunchKernelGGL(k_aerolb_bits, grid, block, 0, st, g, c->p, dsoft, dcounts, stride);
             hipLaunchKernelGGL(k_aerolb_deint, dim3((g.nch + 3) / 4), dim3(256), 0, st, g, c->p);
+            aprof_end(c, st);
+            aprof_begin(c, 1, st);
             // trial lengths are 128, 320, 512, .. (k_aerolb_bits): never below the lane layout's minimum of 4 * VT_ORDER steps
             viterbi_launch(st, (const uint8_t *)c->p.deint, RT_BLOCKSZ, (const uint8_t *)nullptr, 0, c->p.vbits, RT_BLOCKSZ / 2, 0, RT_BLOCKSZ / 2, g.nch, valid,
                            c->d_vhist, 0, 0, c->d_vhist != nullptr, 0, lens);
+            aprof_end(c, st);
+            aprof_begin(c, 2, st);
             hipLaunchKernelGGL(k_aerolb_post, grid, block, 0, st, g, c->p);
+            aprof_end(c, st);
         }
         hipLaunchKernelGGL(k_aerol_end_write, grid, block, 0, st, g, c->p, dcounts);
         HIPCHK(hipGetLastError());

@@ -3,7 +3,8 @@
 #   smoke(), the whole GPU suite, the driver's bench command, rocprofv3 kernel stats, HBM counters (two --pmc passes) and SQ issue / wait
 #   counters of a workload, the bench lines of the other workloads, a 2-rank line on this 1-GPU box (ranks share the device, flagged).
 # usage: scripts/gpu_evidence.sh <tag> [what...]      what: smoke tests bench prof pmc sq workloads gpus2 (default: all)
-#        PMC_WORKLOADS="oqpsk msk ..." selects the workloads the counter passes run on (default: oqpsk)
+#        PMC_WORKLOADS="oqpsk msk ..." selects the workloads the counter passes run on (default: oqpsk), WORKLOADS="aerol_c ..." those of the
+#        `workloads` stage (default: all seven)
 # Everything lands in gpurun_out/<tag>/; copy what is to be judged into profiles/ (scripts/collect_evidence.py <tag>).
 set -u
 TAG=${1:-evidence}; shift || true
@@ -48,7 +49,7 @@ if has bench; then
   echo "driver bench wall: ${SECONDS}s" | tee "$OUT/bench_wall.txt"; cut -c1-300 "$OUT/bench_line.json"; echo; tail -2 "$OUT/bench.err"
 fi
 if has workloads; then
-  for wl in msk burst_oqpsk burst_msk aerol aerol_burst aerol_c oqpsk8400; do
+  for wl in ${WORKLOADS:-msk burst_oqpsk burst_msk aerol aerol_burst aerol_c oqpsk8400}; do
     extra=""; [ $wl = oqpsk8400 ] && extra="--as-written 0"
     ( timeout 600 python bench.py --workload $wl $extra 2> "$OUT/bench_$wl.err" | tail -1 ) > "$OUT/bench_line_$wl.json"; cut -c1-200 "$OUT/bench_line_$wl.json"; echo
   done
