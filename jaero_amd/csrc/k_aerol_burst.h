@@ -63,9 +63,30 @@ __global__ __launch_bounds__(64) void k_aerolb_bits(const AGeom g, const APtrs p
         pos++;
         resume = 0;
     }
+    // Soft entries in aligned groups of eight (one 16-byte load per lane, the next group requested when one is taken up): every lane walks
+    // its own row, so a 2-byte load per bit is a cache-line request per lane and bit, and the walk ran at the latency of those (1.8 ms for
+    // the 3 600 entries behind a burst).  Rows that are not 16-byte aligned (stride not a multiple of 8) keep the single loads.
+    const bool wide = ((((size_t)soft) | ((size_t)stride * 2)) & 15) == 0;
+    int4 cur = {0, 0, 0, 0}, nxt = {0, 0, 0, 0};
+    int curg = -1, nxtg = -1;
+    auto fetch = [&](int q) -> int {
+        if (!wide) return sb[q];
+        const int gq = q >> 3;
+        if (gq != curg)
+        {
+            cur = (gq == nxtg) ? nxt : ((const int4 *)sb)[gq];
+            curg = gq;
+            nxtg = gq + 1;
+            if (nxtg * 8 < n) nxt = ((const int4 *)sb)[nxtg];
+            else nxtg = -1;
+        }
+        const int k = q & 7;
+        const unsigned w = (unsigned)((k & 4) ? ((k & 2) ? cur.w : cur.z) : ((k & 2) ? cur.y : cur.x));
+        return (int)(short)(w >> ((k & 1) * 16));
+    };
     while (pos < n)
     {
-        const int v = sb[pos];
+        const int v = fetch(pos);
         const long long bitidx = nbits0 + pos;
         const bool isneg = v < 0;
         if (!isneg) pair ^= 1;
@@ -183,17 +204,29 @@ __global__ __launch_bounds__(256) void k_aerolb_deint(const AGeom g, const APtrs
     }
 }
 
-__device__ __forceinline__ bool aerolb_crc_bits(const uint8_t *bits, int numberofbits) // calcusingbitsandcheck
+// decoded bits lie one per byte (0 / 1); eight of them from one 8-byte word: bit k of the result = byte k (the first bit is the LSB)
+__device__ __forceinline__ unsigned aerolb_pack8(unsigned long long w)
 {
-    unsigned crc_rec = 0;
-    for (int i = numberofbits - 1; i >= numberofbits - 16; i--) { crc_rec <<= 1; crc_rec |= bits[i]; }
-    numberofbits -= 16;
+    return (unsigned)(((w & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
+}
+
+// calcusingbitsandcheck; bits 8-byte aligned, numberofbits a multiple of 8 (48, 96 and 152 here): one load per eight bits
+__device__ __forceinline__ bool aerolb_crc_bits(const uint8_t *bits, int numberofbits)
+{
+    const unsigned long long *b8 = (const unsigned long long *)bits;
+    const int nw = numberofbits / 8;
+    const unsigned crc_rec = aerolb_pack8(b8[nw - 2]) | (aerolb_pack8(b8[nw - 1]) << 8); // bit j = bits[numberofbits - 16 + j]
     unsigned crc = 0xFFFFu;
-    for (int i = 0; i < numberofbits; i++)
+    for (int h = 0; h < nw - 2; h++)
     {
-        const unsigned crc_bit = crc & 1u;
-        crc >>= 1;
-        if (crc_bit ^ bits[i]) crc ^= 0x8408u;
+        const unsigned v = aerolb_pack8(b8[h]);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            const unsigned crc_bit = crc & 1u;
+            crc >>= 1;
+            if (crc_bit ^ ((v >> k) & 1u)) crc ^= 0x8408u;
+        }
     }
     crc = (~crc) & 0xFFFFu;
     return crc_rec == crc;
@@ -207,8 +240,19 @@ __global__ __launch_bounds__(64) void k_aerolb_post(const AGeom g, const APtrs p
     if (!ALD(AI_HAS_BLOCK)) return;
     const int blockptr = ALD(BI_TRIAL_LEN), nd = blockptr / 2;
     uint8_t *dec = p.vbits + (size_t)ch * (RT_BLOCKSZ / 2);
-    for (int h = nd - 6; h < nd; h++) dec[h] = 0;   // the decoder leaves the last K-1 bits of its zero-initialised output untouched
-    for (int h = 0; h < nd; h++) dec[h] ^= p.scr[h]; // scrambler.reset(); scrambler.update(deconvol)   (nd <= 3040 < 5000)
+    // the decoder leaves the last K-1 bits of its zero-initialised output untouched; scrambler.reset(); scrambler.update(deconvol)
+    // (nd <= 3040 < 5000).  Eight bits per access: rows are 3040 bytes apart and nd is a multiple of 32
+    {
+        unsigned long long *d8 = (unsigned long long *)dec;
+        const unsigned long long *s8 = (const unsigned long long *)p.scr;
+        const int nw = nd / 8;
+        for (int h = 0; h < nw; h++)
+        {
+            unsigned long long w = d8[h];
+            if (h == nw - 1) w &= 0xFFFFull; // bytes nd-6 .. nd-1
+            d8[h] = w ^ s8[h];
+        }
+    }
     int result, type = 0, chop = 0;
     bool keep_last = false;
     if (!g.oqpsk)
@@ -227,7 +271,7 @@ __global__ __launch_bounds__(64) void k_aerolb_post(const AGeom g, const APtrs p
         {
             // the signal unit after the initial one announces how many there are (:709-729)
             const uint8_t *isu = dec + (8 * 6) + (8 * 12) * 1;
-            int tsus = 2 + (isu[0] * 1 + isu[1] * 2 + isu[2] * 4 + isu[3] * 8 + isu[4] * 16 + isu[5] * 32);
+            int tsus = 2 + (int)(aerolb_pack8(*(const unsigned long long *)isu) & 63u); // isu[0] + 2 isu[1] + .. + 32 isu[5]
             if (tsus >= 16) tsus = tsus / 2 + 1;
             ALD(BI_TARGET_SUS) = tsus; ALD(BI_TARGET_BLOCKS) = ((tsus + 1) * 3) + 2;
         }
@@ -264,8 +308,7 @@ __global__ __launch_bounds__(64) void k_aerolb_post(const AGeom g, const APtrs p
                 for (int j = 0; j < 12; j++)
                 {
                     int b = 0;
-                    if (c * 12 + j < ninfo)
-                        for (int k = 0; k < 8; k++) b |= (int)dec[(c * 12 + j) * 8 + k] << k; // first bit of a byte is its LSB
+                    if (c * 12 + j < ninfo) b = (int)aerolb_pack8(((const unsigned long long *)dec)[c * 12 + j]); // first bit of a byte is its LSB
                     row[2 + j] = b;
                 }
                 row[14] = ninfo; row[15] = type;

@@ -69,8 +69,10 @@ def test_bank_vs_oracle(B, oracle_mod, force_viterbi_layout, layout):
         else:
             _, x = mk.rt_case(100 + c, float(rng.uniform(8, 45)), (bool(c & 1), bool(c & 2)), cut=(c % 3 == 0))
             streams.append(x)
-    bank = B.AeroLBank(nch, 10500, max_softbits_per_write=3000, su_capacity=700, burst=True)
-    feed(bank, streams, 3000, rng)
+    # rows of 3000 entries are 16-byte aligned (k_aerolb_bits takes the soft entries eight at a time), rows of 2996 are not (one at a time)
+    width = 3000 if layout == "wave" else 2996
+    bank = B.AeroLBank(nch, 10500, max_softbits_per_write=width, su_capacity=700, burst=True)
+    feed(bank, streams, width, rng)
     npk = 0
     for c in range(nch):
         o = oracle_mod.run_aerol_burst(10500, streams[c])
@@ -100,8 +102,9 @@ def test_msk_bank_vs_oracle(B, oracle_mod, force_viterbi_layout, fb, layout):
         else:
             _, x = mk.rt_case_msk(200 + c, float(rng.uniform(8, 40)), invert=bool(c & 1), cut=(c % 3 == 0))
             streams.append(x)
-    bank = B.AeroLBank(nch, fb, max_softbits_per_write=2500, su_capacity=700, burst=True)
-    feed(bank, streams, 2500, rng)
+    width = 2500 if layout == "wave" else 2504  # single loads / groups of eight in k_aerolb_bits
+    bank = B.AeroLBank(nch, fb, max_softbits_per_write=width, su_capacity=700, burst=True)
+    feed(bank, streams, width, rng)
     npk = 0
     for c in range(nch):
         o = oracle_mod.run_aerol_burst(fb, streams[c])
