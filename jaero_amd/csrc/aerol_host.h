@@ -254,7 +254,8 @@ extern "C" int jaero_aerol_write(jaero_aerol_ctx *c, const int16_t *soft, const 
         for (int r = 0; r < rounds; r++)
         {
             aprof_begin(c, 0, st);
-            hipLaunchKernelGGL(k_aerolb_bits, grid, block, 0, st, g, c->p, dsoft, dcounts, stride);
+            if (((((size_t)dsoft) | ((size_t)stride * 2)) & 15) == 0) hipLaunchKernelGGL(k_aerolb_bits<true>, grid, block, 0, st, g, c->p, dsoft, dcounts, stride);
+            else hipLaunchKernelGGL(k_aerolb_bits<false>, grid, block, 0, st, g, c->p, dsoft, dcounts, stride);
             hipLaunchKernelGGL(k_aerolb_deint, dim3((g.nch + 3) / 4), dim3(256), 0, st, g, c->p);
             aprof_end(c, st);
             aprof_begin(c, 1, st);

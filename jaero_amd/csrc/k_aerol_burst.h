@@ -21,6 +21,8 @@ enum // burst-only fields, stored in slots the continuous pipeline uses for its 
     BI_TRIAL_LEN = AI_BULK_LEN, BI_RESUME_GEND = AI_BULK_SRC, BI_NPACKETS = AI_NFRAMES, BI_TARGET_BLOCKS = AI_BULK_DST, BI_TARGET_SUS = AI_BULK_FLAGS
 };
 
+// WIDE: the rows of soft are 16-byte aligned (base and stride): entries are taken eight at a time
+template <bool WIDE>
 __global__ __launch_bounds__(64) void k_aerolb_bits(const AGeom g, const APtrs p, const int16_t *__restrict__ soft, const int *__restrict__ counts, int stride)
 {
     const int ch = blockIdx.x * 64 + threadIdx.x;
@@ -36,6 +38,10 @@ __global__ __launch_bounds__(64) void k_aerolb_bits(const AGeom g, const APtrs p
     const int16_t *sb = soft + (size_t)ch * stride;
     uint8_t *blk = p.rx + (size_t)ch * RT_BLOCKSZ;
     int has_trial = 0, gotsync = 0, gend = 0;
+    // block bytes leave eight at a time (one store per lane and bit is a write request per lane and bit); a word begun in an earlier
+    // launch is taken up again from the row, a word unfinished at the end of this one is written as far as it goes
+    unsigned long long bacc = 0;
+    if ((blockptr & 7) && blockptr < RT_BLOCKSZ) bacc = *(const unsigned long long *)(blk + (blockptr & ~7)) & ((1ull << (8 * (blockptr & 7))) - 1ull);
 
     auto part_b = [&](long long bitidx) { // aerol.cpp:1985-2030
         if (gotsync)
@@ -63,22 +69,20 @@ __global__ __launch_bounds__(64) void k_aerolb_bits(const AGeom g, const APtrs p
         pos++;
         resume = 0;
     }
-    // Soft entries in aligned groups of eight (one 16-byte load per lane, the next group requested when one is taken up): every lane walks
-    // its own row, so a 2-byte load per bit is a cache-line request per lane and bit, and the walk ran at the latency of those (1.8 ms for
-    // the 3 600 entries behind a burst).  Rows that are not 16-byte aligned (stride not a multiple of 8) keep the single loads.
-    const bool wide = ((((size_t)soft) | ((size_t)stride * 2)) & 15) == 0;
-    int4 cur = {0, 0, 0, 0}, nxt = {0, 0, 0, 0};
-    int curg = -1, nxtg = -1;
+    // Soft entries in aligned groups of eight (WIDE: one 16-byte load per lane and group).  Every lane walks its own row, so a 2-byte load
+    // per bit is a cache-line request per lane and bit and -- worse -- a vmcnt(0) per bit, which on this target also waits for the block
+    // store of the bit before: ~1 400 cycles per bit and wavefront (1.8 ms for the 3 600 entries behind a burst).  The wait belongs inside
+    // the group switch, once per eight bits: left to the compiler it lands behind the join.
+    int4 cur = {0, 0, 0, 0};
+    int curg = -1;
     auto fetch = [&](int q) -> int {
-        if (!wide) return sb[q];
+        if (!WIDE) return sb[q];
         const int gq = q >> 3;
         if (gq != curg)
         {
-            cur = (gq == nxtg) ? nxt : ((const int4 *)sb)[gq];
+            cur = ((const int4 *)sb)[gq];
+            __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
             curg = gq;
-            nxtg = gq + 1;
-            if (nxtg * 8 < n) nxt = ((const int4 *)sb)[nxtg];
-            else nxtg = -1;
         }
         const int k = q & 7;
         const unsigned w = (unsigned)((k & 4) ? ((k & 2) ? cur.w : cur.z) : ((k & 2) ? cur.y : cur.x));
@@ -147,14 +151,15 @@ __global__ __launch_bounds__(64) void k_aerolb_bits(const AGeom g, const APtrs p
         {
             // R and T channels have no header: dummy one, and the packet collector starts over (:1281-1294; resetblockptr aerol.h:591)
             cntr = 16;
-            blockptr = 0;
+            blockptr = 0; bacc = 0;
             if (rt_last == RT_TEST_FAILED) aerol_event(g, p, ch, ev_cnt, overflow, bitidx, 3, 0); // " Bad R/T Packet"
             rt_last = RT_NOTHING;
         }
         bool trial = false;
         if (cntr >= 16 && blockptr < RT_BLOCKSZ)
         {
-            blk[blockptr] = (uint8_t)soft_bit;
+            bacc |= (unsigned long long)(soft_bit & 0xFFu) << (8 * (blockptr & 7));
+            if ((blockptr & 7) == 7) { *(unsigned long long *)(blk + (blockptr & ~7)) = bacc; bacc = 0; }
             blockptr++;
             // ((blockptr - 64*5) % (64*3)) == 0 in C: also -192, i.e. two columns
             trial = (blockptr == 128) || (blockptr >= 320 && ((blockptr - 320) % 192) == 0);
@@ -172,6 +177,7 @@ __global__ __launch_bounds__(64) void k_aerolb_bits(const AGeom g, const APtrs p
         part_b(bitidx);
         pos++;
     }
+    if ((blockptr & 7) && blockptr < RT_BLOCKSZ) *(unsigned long long *)(blk + (blockptr & ~7)) = bacc;
     ALD(AI_CNTR) = cntr; ALD(AI_DATACD) = datacd; ALD(AI_DCDCOUNT) = dcdcount; ALD(AI_GOTSYNC_LAST) = gotsync_last; ALD(AI_REALIMAG) = realimag;
     ALD(AI_MUW) = muw; ALD(AI_INV_IMAG) = inv_imag; ALD(AI_INV_REAL) = inv_real; ALD(AI_EV_CNT) = ev_cnt; ALD(AI_OVERFLOW) = overflow;
     ALD(AI_PD_IMAG) = (int)pd_imag; ALD(AI_PD_REAL) = (int)pd_real;
