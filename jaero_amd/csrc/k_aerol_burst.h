@@ -90,6 +90,37 @@ __global__ __launch_bounds__(64) void k_aerolb_bits(const AGeom g, const APtrs p
     };
     while (pos < n)
     {
+        if (WIDE && g.oqpsk)
+        {
+            // Behind a packet (the collector stopped: blockptr = RT_BLOCKSZ) and before the countdown re-arms the unique-word detectors
+            // (pre-increment cntr in [1, NumberOfBits - 68], carrier detected) a soft bit changes nothing but the counters: pair and group
+            // count, muw, cntr -- realimag and the detectors' registers come out of eight such bits as they went in.  Aligned groups of
+            // eight entries without a start-of-burst marker are taken in one go (the demodulator emits ~3 600 entries behind a packet:
+            // most of the walk).  Anything else, bit by bit below.
+            while (!skip && datacd && blockptr >= RT_BLOCKSZ && cntr >= 1 && cntr + 7 <= g.NumberOfBits - 68 && (pos & 7) == 0 && pos + 8 <= n)
+            {
+                cur = ((const int4 *)sb)[pos >> 3];
+                __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+                curg = pos >> 3;
+                if ((cur.x | cur.y | cur.z | cur.w) & (int)0x80008000u) break; // a marker: bit by bit
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                {
+                    pair ^= 1;
+                    gcnt++;
+                    gend = (pair == 0 && gcnt >= 32) ? 1 : 0;
+                    if (gend) gcnt = 0;
+                }
+                muw = min(100000, muw + 8);
+                cntr += 8;
+                gotsync = 0; gotsync_last = 0;
+                pos += 8;
+#ifdef AEROLB_EMUL_COUNT
+                g_aerolb_fast_groups++;
+#endif
+            }
+            if (pos >= n) break;
+        }
         const int v = fetch(pos);
         const long long bitidx = nbits0 + pos;
         const bool isneg = v < 0;

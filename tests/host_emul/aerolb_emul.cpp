@@ -6,6 +6,8 @@
 // Built by tests/test_aerolb_emul.py with g++ -Itests/host_emul/stub.
 #include <vector>
 
+#define AEROLB_EMUL_COUNT
+static long long g_aerolb_fast_groups = 0; // groups of eight entries k_aerolb_bits<true> took in one go
 #include "../../jaero_amd/csrc/k_aerol_burst.h"
 
 extern "C" {
@@ -152,6 +154,7 @@ extern "C" int emulb_read(EmulB *e, int ch, int which, void *rows, int cap)
     memcpy(rows, p.events + (size_t)ch * g.ev_cap * 3, (size_t)n * 3 * sizeof(long long));
     return n;
 }
+extern "C" long long emulb_fast_groups() { return g_aerolb_fast_groups; }
 extern "C" int emulb_overflow(EmulB *e, int ch)
 {
     const AGeom &g = e->g;

@@ -31,6 +31,7 @@ def E(oracle_mod):
     L.emulb_write.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.emulb_read.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.emulb_overflow.argtypes = [C.c_void_p, C.c_int]
+    L.emulb_fast_groups.restype = C.c_longlong
     return L
 
 
@@ -88,7 +89,11 @@ def test_oqpsk_bank_logic_vs_oracle(E, oracle_mod, mk, width, wide):
         else:
             _, x = mk.rt_case(100 + c, float(rng.uniform(8, 45)), (bool(c & 1), bool(c & 2)), cut=(c % 3 == 0))
             streams.append(x)
+    fast0 = E.emulb_fast_groups()
     got = run_bank(E, 10500, streams, width, rng, wide)
+    fast = E.emulb_fast_groups() - fast0
+    # behind a packet the walk takes aligned groups of eight inert entries in one go (k_aerolb_bits<true>); never from unaligned rows
+    assert (fast > 200) if wide == 1 else (fast == 0), fast
     npk = 0
     for c in range(nch):
         o = oracle_mod.run_aerol_burst(10500, streams[c])
@@ -119,3 +124,36 @@ def test_msk_bank_logic_vs_oracle(E, oracle_mod, mk, fb, width, wide):
         assert np.array_equal(got[c][1], o["events"]), c
         npk += len(want)
     assert npk > 40
+
+
+def short_gap_streams(nch, seed0=900):
+    """Bursts that follow each other while the frame countdown of the one before still runs (gap 1500 .. 3300 entries, every residue
+    modulo 8): the next start-of-burst marker arrives in the stretch the walk takes eight entries at a time."""
+    from jaero_amd import aerol_frames as AF
+
+    streams = []
+    for c in range(nch):
+        rng = np.random.default_rng(seed0 + c)
+        rb = lambda n: bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        pk = [("R", rb(17)), ("T", (rb(4), [rb(10) for _ in range(2 + c % 5)])), ("R", rb(17)), ("T", (rb(4), [rb(10) for _ in range(3)])), ("R", rb(17))]
+        x = AF.rt_burst_stream(pk, sigma=14.0 + c, seed=seed0 + c, invert_i=bool(c & 1), invert_q=bool(c & 2), gap=1500 + 113 * c, lead=80 + 2 * (c % 4))
+        streams.append(x[(c % 8):])  # the markers at every position of an aligned group
+    return streams
+
+
+@pytest.mark.parametrize("width,wide", [(4096, 1), (4096, 0), (520, 1)])
+def test_oqpsk_short_gaps_vs_oracle(E, oracle_mod, width, wide):
+    streams = short_gap_streams(16)
+    rng = np.random.default_rng(11)
+    fast0 = E.emulb_fast_groups()
+    got = run_bank(E, 10500, streams, width, rng, wide)
+    fast = E.emulb_fast_groups() - fast0
+    assert (fast > 1000) if wide == 1 else (fast == 0), fast
+    npk = 0
+    for c in range(len(streams)):
+        o = oracle_mod.run_aerol_burst(10500, streams[c])
+        want = oracle_mod.packets_from_rows(o["packets"])
+        assert oracle_mod.packets_from_rows(got[c][0]) == want, c
+        assert np.array_equal(got[c][1], o["events"]), c
+        npk += len(want)
+    assert npk >= 2 * len(streams)  # with gaps this short not every burst is found (the countdown of the one before still runs): on both sides

@@ -84,6 +84,28 @@ def test_bank_vs_oracle(B, oracle_mod, force_viterbi_layout, layout):
     bank.close()
 
 
+@pytest.mark.parametrize("width", [4096, 4100])
+def test_bank_short_gaps(B, oracle_mod, width):
+    """Bursts that follow each other while the frame countdown of the one before still runs: the next start-of-burst marker arrives in the
+    stretch k_aerolb_bits<true> takes eight entries at a time (rows of 4096 entries; rows of 4100 are not 16-byte aligned and go bit by
+    bit).  Markers at every position of an aligned group, ragged writes."""
+    from test_aerolb_emul import short_gap_streams
+
+    streams = short_gap_streams(16)
+    rng = np.random.default_rng(12)
+    bank = B.AeroLBank(len(streams), 10500, max_softbits_per_write=width, su_capacity=700, burst=True)
+    feed(bank, streams, width, rng)
+    npk = 0
+    for c in range(len(streams)):
+        o = oracle_mod.run_aerol_burst(10500, streams[c])
+        want = oracle_mod.packets_from_rows(o["packets"])
+        assert bank.read_packets(c) == want, c
+        assert np.array_equal(bank.read_events(c), o["events"]), c
+        npk += len(want)
+    assert npk >= 2 * len(streams)
+    bank.close()
+
+
 @pytest.mark.parametrize("layout", ["wave", "lanes"])
 @pytest.mark.parametrize("fb", [1200, 600])
 def test_msk_bank_vs_oracle(B, oracle_mod, force_viterbi_layout, fb, layout):
