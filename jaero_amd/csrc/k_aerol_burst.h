@@ -92,17 +92,40 @@ __global__ __launch_bounds__(64) void k_aerolb_bits(const AGeom g, const APtrs p
     {
         if (WIDE && g.oqpsk)
         {
-            // Behind a packet (the collector stopped: blockptr = RT_BLOCKSZ) and before the countdown re-arms the unique-word detectors
-            // (pre-increment cntr in [1, NumberOfBits - 68], carrier detected) a soft bit changes nothing but the counters: pair and group
-            // count, muw, cntr -- realimag and the detectors' registers come out of eight such bits as they went in.  Aligned groups of
-            // eight entries without a start-of-burst marker are taken in one go (the demodulator emits ~3 600 entries behind a packet:
-            // most of the walk).  Anything else, bit by bit below.
-            while (!skip && datacd && blockptr >= RT_BLOCKSZ && cntr >= 1 && cntr + 7 <= g.NumberOfBits - 68 && (pos & 7) == 0 && pos + 8 <= n)
+            // Between the unique word and the point where the countdown re-arms the detectors (pre-increment cntr in [1, NumberOfBits -
+            // 68], carrier detected) a soft bit changes nothing but the counters -- pair and group count, muw, cntr; realimag and the
+            // detectors' registers come out of eight such bits as they went in -- and, while the collector runs, the block.  Aligned
+            // groups of eight entries without a start-of-burst marker are taken in one go: behind a packet (collector stopped, blockptr =
+            // RT_BLOCKSZ; the demodulator emits ~3 600 entries there) and inside one as long as no trial length (a multiple of 64) lies
+            // within the eight.  Anything else, bit by bit below.
+            while (!skip && datacd && cntr >= 1 && cntr + 7 <= g.NumberOfBits - 68 && (pos & 7) == 0 && pos + 8 <= n)
             {
+                const bool collecting = blockptr < RT_BLOCKSZ;
+                if (collecting && (cntr < 16 || (blockptr & 63) + 8 >= 64)) break;
                 cur = ((const int4 *)sb)[pos >> 3];
                 __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
                 curg = pos >> 3;
                 if ((cur.x | cur.y | cur.z | cur.w) & (int)0x80008000u) break; // a marker: bit by bit
+                if (collecting)
+                {
+                    const unsigned e[4] = {(unsigned)cur.x, (unsigned)cur.y, (unsigned)cur.z, (unsigned)cur.w};
+                    unsigned long long bytes8 = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                    {
+                        const int inv = ((realimag ^ k ^ 1) & 1) ? inv_imag : inv_real; // realimag toggles before it is looked at
+                        unsigned sbk = (e[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+                        if (inv && sbk != 128u) sbk = 255u - sbk;
+                        bytes8 |= (unsigned long long)(sbk & 0xFFu) << (8 * k);
+                    }
+                    const int sh = 8 * (blockptr & 7);
+                    *(unsigned long long *)(blk + (blockptr & ~7)) = bacc | (bytes8 << sh);
+                    bacc = sh ? (bytes8 >> (64 - sh)) : 0ull;
+                    blockptr += 8;
+#ifdef AEROLB_EMUL_COUNT
+                    g_aerolb_fast_fill_groups++;
+#endif
+                }
 #pragma unroll
                 for (int k = 0; k < 8; k++)
                 {

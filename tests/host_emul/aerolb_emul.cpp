@@ -7,7 +7,7 @@
 #include <vector>
 
 #define AEROLB_EMUL_COUNT
-static long long g_aerolb_fast_groups = 0; // groups of eight entries k_aerolb_bits<true> took in one go
+static long long g_aerolb_fast_groups = 0, g_aerolb_fast_fill_groups = 0; // groups of eight entries k_aerolb_bits<true> took in one go (all / while collecting)
 #include "../../jaero_amd/csrc/k_aerol_burst.h"
 
 extern "C" {
@@ -155,6 +155,7 @@ extern "C" int emulb_read(EmulB *e, int ch, int which, void *rows, int cap)
     return n;
 }
 extern "C" long long emulb_fast_groups() { return g_aerolb_fast_groups; }
+extern "C" long long emulb_fast_fill_groups() { return g_aerolb_fast_fill_groups; }
 extern "C" int emulb_overflow(EmulB *e, int ch)
 {
     const AGeom &g = e->g;

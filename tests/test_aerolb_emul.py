@@ -32,6 +32,7 @@ def E(oracle_mod):
     L.emulb_read.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.emulb_overflow.argtypes = [C.c_void_p, C.c_int]
     L.emulb_fast_groups.restype = C.c_longlong
+    L.emulb_fast_fill_groups.restype = C.c_longlong
     return L
 
 
@@ -89,11 +90,11 @@ def test_oqpsk_bank_logic_vs_oracle(E, oracle_mod, mk, width, wide):
         else:
             _, x = mk.rt_case(100 + c, float(rng.uniform(8, 45)), (bool(c & 1), bool(c & 2)), cut=(c % 3 == 0))
             streams.append(x)
-    fast0 = E.emulb_fast_groups()
+    fast0, fill0 = E.emulb_fast_groups(), E.emulb_fast_fill_groups()
     got = run_bank(E, 10500, streams, width, rng, wide)
-    fast = E.emulb_fast_groups() - fast0
-    # behind a packet the walk takes aligned groups of eight inert entries in one go (k_aerolb_bits<true>); never from unaligned rows
-    assert (fast > 200) if wide == 1 else (fast == 0), fast
+    fast, fill = E.emulb_fast_groups() - fast0, E.emulb_fast_fill_groups() - fill0
+    # inside and behind a packet the walk takes aligned groups of eight inert entries in one go (k_aerolb_bits<true>); never from unaligned rows
+    assert (fast > 200 and fill > 200) if wide == 1 else (fast == 0), (fast, fill)
     npk = 0
     for c in range(nch):
         o = oracle_mod.run_aerol_burst(10500, streams[c])
@@ -145,10 +146,10 @@ def short_gap_streams(nch, seed0=900):
 def test_oqpsk_short_gaps_vs_oracle(E, oracle_mod, width, wide):
     streams = short_gap_streams(16)
     rng = np.random.default_rng(11)
-    fast0 = E.emulb_fast_groups()
+    fast0, fill0 = E.emulb_fast_groups(), E.emulb_fast_fill_groups()
     got = run_bank(E, 10500, streams, width, rng, wide)
-    fast = E.emulb_fast_groups() - fast0
-    assert (fast > 1000) if wide == 1 else (fast == 0), fast
+    fast, fill = E.emulb_fast_groups() - fast0, E.emulb_fast_fill_groups() - fill0
+    assert (fast > 1000 and fill > 500) if wide == 1 else (fast == 0), (fast, fill)
     npk = 0
     for c in range(len(streams)):
         o = oracle_mod.run_aerol_burst(10500, streams[c])
