@@ -6,8 +6,9 @@
 //   AeroLcrc16::calcusingbitsandcheck          JAERO/aerol.h:287-315
 // One channel per lane walks its soft bits until the block reaches a length at which the reference tries to decode it; the trial
 // (deinterleave -> k_viterbi with that channel's length -> descramble -> CRCs -> R packet / T packet / keep collecting) runs for all
-// such channels at once, then the lanes go on: rounds, as in the continuous pipeline.  Bursts are rare and short, so nothing here is
-// tuned beyond that.  The reference drops the rest of the demodulator's current group of soft bits when the one-second frame
+// such channels at once, then the lanes go on: rounds, as in the continuous pipeline.  Tuned for large banks in round 5: trials one
+// block per lane (k_viterbi_lanes with per-lane lengths), eight decoded bits per access in the post kernel, eight soft entries per load and
+// whole groups of inert entries at once in the bit walk.  The reference drops the rest of the demodulator's current group of soft bits when the one-second frame
 // countdown ends; the groups are re-derived from the stream with the demodulator's rule (a marker is one entry, soft bits come in
 // pairs, a group is complete at >= 32 entries after a pair; JAERO/burstoqpskdemodulator.cpp:546-585).
 #pragma once
