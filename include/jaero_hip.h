@@ -213,7 +213,9 @@ int jaero_viterbi_continuous(int device, const uint8_t *soft, int nstreams, int 
 typedef struct jaero_aerol_ctx jaero_aerol_ctx;
 int jaero_aerol_create(int device, int nchannels, int fb, int max_softbits_per_write, int su_capacity, jaero_aerol_ctx **out);
 void jaero_aerol_destroy(jaero_aerol_ctx *ctx);
-/* soft[ch * stride + k], k < counts[ch] <= max_count <= stride; host pointers (copied) or device pointers */
+/* soft[ch * stride + k], k < counts[ch] <= max_count <= stride; host pointers (copied) or device pointers.  Burst-mode banks read rows that are
+ * 16-byte aligned (soft 16-byte aligned, stride a multiple of 8) eight entries per load and skip through inert stretches; other rows go bit by bit:
+ * the same results, more slowly. */
 int jaero_aerol_write(jaero_aerol_ctx *ctx, const int16_t *soft, const int *counts, int stride, int max_count, int is_device_ptr, void *stream);
 int jaero_aerol_read_sus(jaero_aerol_ctx *ctx, int channel, int32_t *rows, int caprows, int *nrows);
 int jaero_aerol_read_events(jaero_aerol_ctx *ctx, int channel, long long *rows, int caprows, int *nrows);
