@@ -114,7 +114,7 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
     BGeom &g = c->bg;
     BPtrs &p = c->bp;
     if (softbit_capacity <= 0) softbit_capacity = (int)ceil(2.0 * c->max_write * g.fb / g.Fs) + 128;
-    g.soft_cap = (softbit_capacity + 1) & ~1;
+    g.soft_cap = (softbit_capacity + 7) & ~7; // 16-byte aligned rows: the burst-mode Aero-L bank reads them in place eight entries per load (k_aerolb_bits<true>)
     g.sym_cap = (c->flags & JAERO_FLAG_CAPTURE_SYMBOLS) ? g.soft_cap / 2 + 8 : 0;
     g.ev_cap = (c->flags & JAERO_FLAG_TRACE) ? 4096 : 256;
     const int nchp = g.nchp, ng = g.ngroups;
