@@ -231,7 +231,9 @@ int jaero_aerol_tick_dcd(jaero_aerol_ctx *ctx, int *dcd_out /* optional [nchanne
  *       type 1 = R packet (20 bytes: 17 + CRC + the flush byte), 2 = T packet (6 header bytes incl. CRC, then 12 per signal unit)
  *   jaero_aerol_read_events additionally reports kind 3 = the " Bad R/T Packet" notice (JAERO/aerol.cpp:1289-1293,1531)
  * The reference drops the rest of the demodulator's current group of soft bits at the end of a signal; the bank re-derives the groups
- * from the stream (a marker is one entry, soft bits come in pairs, a group is complete at >= 32 entries after a pair). */
+ * from the stream (a marker is one entry, soft bits come in pairs, a group is complete at >= 32 entries after a pair).  The input is a burst
+ * demodulator's output: a marker stands between pairs, never inside one (JAERO/burstoqpskdemodulator.cpp:546-585); for other streams the grouping,
+ * and with it what is dropped at the end of a signal, is not the reference's. */
 /* C channel (jaero_aerol_create with fb = 8400: AeroL::DecodeC aerol.cpp:2187-2502): jaero_aerol_read_sus rows are the three sub-band signal units of
  * a frame [frame, k, 12 bytes, crc_ok, 0]; jaero_aerol_read_voice rows are 304 bytes: uint32 frame number, then the 300 voice bytes
  * the reference hands to Voicesignal(data, hex). */
