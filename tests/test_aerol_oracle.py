@@ -154,8 +154,32 @@ def c_run(O, soft, group=32):
         a.write(soft[s:s + group])
     fn, voice = a.take_voice()
     sus = a.take_sus()
-    printed = [bytes(r[2:12].astype(np.uint8)) for r in sus if r[14] and r[2] != 0x01]  # crc ok and not a fill-in unit: what DecodeC prints
-    return fn, voice, sus, printed, a
+    return fn, voice, sus, c_printed(sus), a
+
+
+def c_printed(sus):
+    """What DecodeC prints of the oracle's sub-band rows [frame, k, 12 bytes, crc_ok, 0]: the units with a good CRC that are not fill-in units
+    -- of the frames at whose end the data carrier is detected: AeroL::DecodeC clears the text of a call that ends with datacd false
+    (aerol.cpp:2497-2500), and datacd follows the CRC verdicts (+2 up to 12 for a good one, -5 for a bad one, high above 2: aerol.cpp:2370-2384;
+    the 1 s timer that lowers it again never fires in the reference driver).  A frame's three units are checked within one call."""
+    cd, dcd, out, k = 0, False, [], 0
+    while k < len(sus):
+        frame, fr = int(sus[k][0]), []
+        while k < len(sus) and int(sus[k][0]) == frame:
+            r = sus[k]
+            if r[14]:
+                if cd < 12:
+                    cd += 2
+            elif cd > 0:
+                cd -= 5
+            if not dcd and cd > 2:
+                dcd = True
+            if r[14] and r[2] != 0x01:
+                fr.append(bytes(r[2:12].astype(np.uint8)))
+            k += 1
+        if dcd:
+            out += fr
+    return out
 
 
 def c_voice_equal(ref_voice, voice):
