@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fuzz the R/T packet search's device code on the CPU (tests/host_emul/aerolb_emul.cpp) against the oracle: random packets, gaps (short
 ones too: the next burst inside the countdown of the one before), noise levels, arm inversions, stray start-of-burst markers, runs of
-erasures (128), lost stretches, write sizes and row widths (aligned and not).  usage: scripts/fuzz_aerolb_emul.py [rounds] [seed]"""
+erasures (128), lost stretches, write sizes and row widths (aligned and not).  usage: tests/fuzz/fuzz_aerolb_emul.py [rounds] [seed]"""
 import ctypes as C
 import os
 import subprocess
@@ -10,7 +10,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from jaero_amd import aerol_frames as AF  # noqa: E402
 from oracle import oracle as O  # noqa: E402  (test tool)

@@ -2,7 +2,7 @@
 """Fuzz the Aero-L C-channel pipeline's device code on the CPU (tests/host_emul/aerolc_emul.cpp) against the oracle: random frame counts,
 leads, noise levels, arm inversions, copies of the unique word planted anywhere (inside and outside the detection windows), erasure runs,
 lost and doubled stretches (frames that come out short or long), write sizes from a few soft bits to several frames.
-usage: scripts/fuzz_aerolc_emul.py [rounds] [seed]"""
+usage: tests/fuzz/fuzz_aerolc_emul.py [rounds] [seed]"""
 import ctypes as C
 import os
 import subprocess
@@ -11,7 +11,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from jaero_amd import aerol_frames as AF  # noqa: E402
 from oracle import oracle as O  # noqa: E402  (test tool)

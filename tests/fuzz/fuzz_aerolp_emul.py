@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fuzz the continuous Aero-L bit pipeline's device code on the CPU (tests/host_emul/aerolp_emul.cpp: k_aerol_bits<false>, k_aerol_post)
 against the oracle: random frame counts, garbage prefixes, noise levels, arm inversions, erasure runs, lost and doubled stretches (short
-frames, unique words out of place), write sizes from a few soft bits to several blocks.  usage: scripts/fuzz_aerolp_emul.py [rounds] [seed]"""
+frames, unique words out of place), write sizes from a few soft bits to several blocks.  usage: tests/fuzz/fuzz_aerolp_emul.py [rounds] [seed]"""
 import ctypes as C
 import os
 import subprocess
@@ -10,7 +10,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from jaero_amd import aerol_frames as AF  # noqa: E402
 from oracle import oracle as O  # noqa: E402  (test tool)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fuzz the oracle's Aero-L restatement (oracle/aerol_oracle.c) against the UNMODIFIED AeroL (oracle/_ref) on the streams of the three
-emulation fuzzers (scripts/fuzz_aerol{p,b,c}_emul.py: random frames / packets, planted unique words, markers, erasures, lost and doubled
+emulation fuzzers (tests/fuzz/fuzz_aerol{p,b,c}_emul.py: random frames / packets, planted unique words, markers, erasures, lost and doubled
 stretches): what the reference prints -- signal units with their CRC verdicts, R / T packets and ' Bad R/T Packet' notices, voice frames and
 sub-band units -- against the oracle's rows.  Needs /root/reference (to build oracle/_ref).  usage: fuzz_oracle_vs_ref_aerol.py [rounds] [seed]"""
 import os
@@ -8,9 +8,9 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "scripts"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import fuzz_aerolb_emul as FB  # noqa: E402
 import fuzz_aerolc_emul as FC  # noqa: E402

@@ -2,13 +2,13 @@
 """Fuzz the oracle's burst-demodulator restatement (oracle/jaero_oracle_burst.c) against the UNMODIFIED BurstOqpskDemodulator /
 BurstMskDemodulator (oracle/_ref): random burst positions and counts, carrier offsets, Eb/N0, write sizes, AFC, and CenterFreqChangedSlot at
 a random moment.  Soft bits (with the -1 markers) and every emission must be identical.  Needs /root/reference.
-usage: scripts/fuzz_oracle_vs_ref_burst.py [rounds] [seed]"""
+usage: tests/fuzz/fuzz_oracle_vs_ref_burst.py [rounds] [seed]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from jaero_amd import signalgen as G  # noqa: E402
 from oracle import oracle as O  # noqa: E402  (test tool)

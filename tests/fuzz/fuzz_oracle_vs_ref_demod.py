@@ -3,13 +3,13 @@
 cases: kind and rate (OQPSK 10 500 / 8400, MSK 600 / 1200), carrier offset, Eb/N0, write size, initial AFC / SQL / cpuReduce, and a random subset
 of the slots a running object can receive between two writes -- DCDstatSlot on and off, CenterFreqChangedSlot, setSettings (centre frequency and
 locking bandwidth), two flag changes -- at random moments.  Soft bits and status rows must be identical.  Needs /root/reference.
-usage: scripts/fuzz_oracle_vs_ref_demod.py [rounds] [seed]"""
+usage: tests/fuzz/fuzz_oracle_vs_ref_demod.py [rounds] [seed]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from jaero_amd import signalgen as G  # noqa: E402
 from oracle import oracle as O  # noqa: E402  (test tool)
