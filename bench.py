@@ -67,6 +67,12 @@ def parse():
                     help="oqpsk = BASELINE configs[2] (continuous, the headline); msk = configs[1] shape (1200 bps MSK) scaled to a bank that fills the chip; burst_oqpsk = configs[3] (one burst per second per "
                          "channel); aerol = the 10.5 kbps P-channel bit pipeline behind the demodulator (SURVEY 8 row f1), one frame per step; "
                          "aerol_burst = the R/T channel packet search behind a burst demodulator (row f2), one burst per channel and step")
+    ap.add_argument("--sustain", type=float, default=3.0, help="continuous OQPSK workloads: seconds of untimed back-to-back steps in front of the warm-up (resident like the timed "
+                                                               "steps), so that clocks and power are in steady state when the clock starts; 0 = none")
+    ap.add_argument("--no-state", action="store_true", help="do not sample clocks / power and do not run the calibration kernels around the timed region")
+    ap.add_argument("--no-other-workloads", action="store_true", help="headline only: do not run the other workloads behind it (config.other_workloads)")
+    ap.add_argument("--other-steps", type=int, default=6, help="timed steps of each of the other workloads")
+    ap.add_argument("--fb", type=float, default=1200.0, help="msk workload: 1200 or 600 bps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=500_000, help="samples per process for the CPU baseline leg (>= 10 s of signal)")
     return ap.parse_args()
@@ -103,37 +109,157 @@ def setup_ranks():
     return rank, world, local, torch.device("cuda", di), shared
 
 
-def run_timed(step, W, K, world, dev, before_timed=None):
-    """W untimed warm-up steps, then exactly K steps between barrier + device synchronisation on both sides.  Returns (max over ranks of the
-    wall time between the barriers, every rank's time for its own K steps)."""
+MEAS = {}   # what run_timed recorded around the last timed region (gpu_state, calib, step_ms): attached to the line by emit()
+
+
+def run_timed(step, W, K, world, dev, before_timed=None, sustain=0):
+    """`sustain` + W untimed steps back to back, then exactly K steps between barrier + device synchronisation on both sides.  Returns (max over
+    ranks of the wall time between the barriers, every rank's time for its own K steps).  Around the timed region (bench_state.py): a side
+    thread samples engine clock / socket power / throttle residency, the two calibration kernels run immediately before and after it, and an
+    event behind every step gives the per-step times -- all of it lands in MEAS."""
     import torch
     import torch.distributed as dist
 
-    sync = torch.cuda.synchronize if torch.cuda.is_available() else (lambda: None)  # (no GPU: the gloo plumbing test of tests/test_dist_gloo.py)
-    for i in range(W):
+    import bench_state as BS
+
+    gpu = torch.cuda.is_available()
+    sync = torch.cuda.synchronize if gpu else (lambda: None)  # (no GPU: the gloo plumbing test of tests/test_dist_gloo.py)
+    MEAS.clear()
+    sampler = calib = None
+    cal = {}
+    stream = torch.cuda.current_stream().cuda_stream if gpu else 0
+    if gpu and not ARGS.no_state:
+        try:
+            pr = torch.cuda.get_device_properties(dev.index)
+            bdf = ("%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)) if hasattr(pr, "pci_bus_id") else None
+        except Exception:
+            bdf = None
+        sampler = BS.GpuStateSampler(pci_bus_id=bdf)
+        try:
+            calib = BS.Calib(dev.index)
+            cal["cold"] = calib.run(stream)
+        except Exception as e:
+            cal["error"] = f"{type(e).__name__}: {e}"[:200]
+            calib = None
+        sampler.start("sustain")
+    for i in range(sustain + W):
         step(i)
     sync()
     if before_timed is not None:
         before_timed()
+    if calib is not None:
+        sampler.mark("calib")
+        cal["before"] = calib.run(stream)
     if world > 1:
         dist.barrier()
     sync()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)] if gpu else None
+    if sampler is not None:
+        sampler.mark("timed")
     t0 = time.perf_counter()
-    for i in range(W, W + K):
+    if ev:
+        ev[0].record()
+    for i in range(sustain + W, sustain + W + K):
         step(i)
+        if ev:
+            ev[i - sustain - W + 1].record()
     sync()
     own = time.perf_counter() - t0      # this rank's own K steps (before it waits for the others)
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if sampler is not None:
+        sampler.mark("calib")
+    if calib is not None:
+        cal["after"] = calib.run(stream)
+        calib.close()
+    if sampler is not None:
+        sampler.stop()
+        MEAS["gpu_state"] = sampler.summary()
+    if cal:
+        ok = [cal[k] for k in ("before", "after") if k in cal]
+        if ok:
+            cal["fp64_tflops"] = round(sum(x["fp64_tflops"] for x in ok) / len(ok), 2)
+            cal["hbm_gbs"] = round(sum(x["hbm_gbs"] for x in ok) / len(ok), 1)
+            cal["fp64_frac_of_peak"] = round(cal["fp64_tflops"] / BS.FP64_PEAK_TFLOPS, 4)
+            cal["what"] = "fp64: dependent-free v_fma_f64 on every SIMD, ~10 ms; hbm: 16 B per lane copy of 2 x 4 GB; HIP events, immediately before / after the timed steps"
+        MEAS["calib"] = cal
+    if ev:
+        MEAS["step_ms"] = BS.step_stats([ev[i].elapsed_time(ev[i + 1]) for i in range(K)])
+    MEAS["sustain_steps"] = sustain
     dts = [own]
     if world > 1:
-        t = torch.tensor([dt, own], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        c = MEAS.get("calib", {})
+        g = MEAS.get("gpu_state", {})
+        t = torch.tensor([dt, own, c.get("fp64_tflops") or 0.0, c.get("hbm_gbs") or 0.0, g.get("sclk_mhz_mean") or 0.0, g.get("power_w_mean") or 0.0],
+                         dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         lst = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(lst, t)
         dt = max(float(x[0].item()) for x in lst)
         dts = [float(x[1].item()) for x in lst]
+        MEAS["per_rank"] = {"fp64_tflops": [round(float(x[2].item()), 2) for x in lst], "hbm_gbs": [round(float(x[3].item()), 1) for x in lst],
+                            "sclk_mhz_mean": [round(float(x[4].item()), 1) for x in lst], "power_w_mean": [round(float(x[5].item()), 1) for x in lst]}
     return dt, dts
+
+
+def aerol_issue_roofline(line):
+    """The Aero-L bit pipelines are integer-VALU work (unique-word correlation, deinterleave index arithmetic, add-compare-select): an HBM
+    fraction says nothing about them.  Their roofline block is priced against VALU issue instead: every wavefront
+    instruction holds its SIMD's issue port for 4 cycles, so a step cannot take less than (VALU wave-instructions of all its kernels) x 4 /
+    (1024 SIMDs x 2.4 GHz).  Instruction counts: profiles/sq_summary_<workload>.json (rocprofv3 --pmc SQ_INSTS_VALU pass of this command,
+    scripts/pmc_sq.sh); the HBM figures the line used to lead with stay under "hbm"."""
+    old = line.get("roofline") or {}
+    new = {"bound": "int_valu_issue", "kernel": old.get("kernel_name") or old.get("kernel"), "unit": "wave-instructions/s", "peak": SIMDS * CLOCK_HZ / 4.0,
+           "achieved": None, "frac": None, "traffic": old.get("traffic"), "traffic_from": old.get("traffic_from"),
+           "hbm": {k: old.get(k) for k in ("achieved", "frac", "alg_bytes_per_softbit", "avg_launch_ms", "softbits_per_launch", "whole_step") if k in old}}
+    path = os.path.join(ROOT, "profiles", f"sq_summary_{ARGS.workload}.json")
+    try:
+        sq = json.load(open(path))
+        steps = float(sq["steps_total"])
+        scale = line["config"]["channels_per_gpu"] / float(sq.get("channels_per_gpu", 65536))
+        per = {k: v["SQ_INSTS_VALU_sum"] / steps * scale for k, v in sq.items() if isinstance(v, dict) and "SQ_INSTS_VALU_sum" in v}
+        tot = sum(per.values())
+        floor = tot * 4.0 / (SIMDS * CLOCK_HZ) * 1e3
+        ms = float(line["ms_per_step"])
+        new.update({"kernel": "whole step: " + " + ".join(sorted(per, key=per.get, reverse=True)[:4]), "valu_insts_per_step": round(tot), "floor_ms": round(floor, 4), "ms": ms,
+                    "achieved": round(tot / (ms * 1e-3), 1), "frac": round(floor / ms, 5),
+                    "per_kernel_floor_ms": {k.split("(")[0][:40]: round(v * 4.0 / (SIMDS * CLOCK_HZ) * 1e3, 4) for k, v in per.items()},
+                    "source": f"profiles/sq_summary_{ARGS.workload}.json@{sq.get('tag', 'untagged')} ({same_pass(sq).replace('--pmc passes', '--pmc SQ_INSTS_VALU pass')})"})
+    except Exception as e:
+        new["reason"] = f"no instruction counts for this workload ({type(e).__name__}: {e})"[:200]
+    line["roofline"] = new
+
+
+def emit(line):
+    """Print the ONE JSON line, with what run_timed recorded around the timed region: gpu_state (clock, power, throttle residency), calib (the two
+    calibration kernels before / after), step_ms (per-step spread), and the roofline fraction also relative to the calibrated rates of THIS box."""
+    if "gpu_state" in MEAS:
+        line["gpu_state"] = MEAS["gpu_state"]
+    if "calib" in MEAS:
+        line["calib"] = MEAS["calib"]
+    if MEAS.get("step_ms"):
+        line["step_ms"] = MEAS["step_ms"]
+    if "per_rank" in MEAS:
+        line["config"]["per_rank_state"] = MEAS["per_rank"]
+    if MEAS.get("sustain_steps"):
+        line["config"]["sustain_steps"] = MEAS["sustain_steps"]
+    c = MEAS.get("calib", {})
+    r = line.get("roofline")
+    if isinstance(r, dict) and r.get("achieved") and c.get("hbm_gbs") and r.get("unit") == "GB/s":
+        r["frac_of_calib_hbm"] = round(r["achieved"] / c["hbm_gbs"], 5)
+    iss = line.get("roofline_fp64_issue")
+    if isinstance(iss, dict) and c.get("fp64_frac_of_peak") and isinstance(iss.get("step"), dict) and iss["step"].get("frac"):
+        iss["step"]["frac_at_calib_clock"] = round(iss["step"]["frac"] / c["fp64_frac_of_peak"], 4)
+    if line.get("unit") == "Msoftbits/s":
+        aerol_issue_roofline(line)
+    # the long form stays available beside the line (the driver's record keeps the tail of stdout: the line itself stays short)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_details.json"), "a") as f:
+            f.write(json.dumps(line) + "\n")
+    except OSError:
+        pass
+    print(json.dumps(line), flush=True)
 
 
 def rank_fields(world, shared, dts, units_per_rank, scale=1e6):
@@ -382,7 +508,7 @@ def burst_line(bank, rank, world, nch, chunk, K, W, dt, value, msk=False, extra=
             line["cpu_baseline"] = cpu_baseline(chunk)
         except Exception as e:
             line["cpu_baseline"] = {"value": None, "error": str(e)}
-    print(json.dumps(line), flush=True)
+    emit(line)
 
 
 
@@ -439,7 +565,7 @@ def aerol_oracle_check(kind: str, bank, nch: int, stream_of, nrows_cap: int, fir
 def aerol_check_or_exit(line, oc, what: str):
     line["config"]["oracle_check"] = oc
     if oc["channels"] and not (oc["rows_equal"] and oc["events_equal"] and oc["rows_compared"] > 0):
-        print(json.dumps(line), flush=True)
+        emit(line)
         raise SystemExit(f"bench.py: {what} of a sampled channel differ from the oracle's on the same soft bits")
 
 
@@ -555,7 +681,7 @@ def aerol_bench():
                 ct = time.perf_counter() - t1
                 line["cpu_baseline"] = {"value": round(len(x) / ct / 1e6, 3), "unit": "Msoftbits/s", "cores": 1, "kind": "port",
                                         "sample": f"{len(x)} soft bits through oracle/aerol_oracle.c (AeroL::Decode restated), 32-bit groups, one thread"}
-        print(json.dumps(line), flush=True)
+        emit(line)
     bank.close()
     finish(world)
 
@@ -659,7 +785,7 @@ def aerol_c_bench():
                 ct = time.perf_counter() - t1
                 line["cpu_baseline"] = {"value": round(len(x) / ct / 1e6, 3), "unit": "Msoftbits/s", "cores": 1, "kind": "port",
                                         "sample": f"{len(x)} soft bits through oracle/aerol_oracle.c (DecodeC restated), 32-bit groups, one thread"}
-        print(json.dumps(line), flush=True)
+        emit(line)
     bank.close()
     finish(world)
 
@@ -680,12 +806,14 @@ def msk_bench():
     local = dev.index
     nch, chunk, K, W = ARGS.channels, ARGS.chunk, ARGS.steps, ARGS.warmup
     nsamp, nuniq = (K + W) * chunk, 32
-    uniq = np.stack([signalgen.msk(nsamp, fb=1200.0, fc=1000.0 + 7.0 * u, ebno_db=ARGS.ebno_db, seed=signalgen.SEED_BASE + 900 + u + 100 * rank)[0]
+    mfb = float(ARGS.fb)
+    mbw = 1800.0 if mfb == 1200.0 else 900.0   # wide-bandwidth mode (JAERO/mainwindow.cpp:871-872) / the 600 bps default
+    uniq = np.stack([signalgen.msk(nsamp, fb=mfb, fc=1000.0 + 7.0 * u, ebno_db=ARGS.ebno_db, seed=signalgen.SEED_BASE + 900 + u + 100 * rank)[0]
                      for u in range(nuniq)])  # [nuniq, nsamp]
     idx = torch.arange(nch, device=dev) % nuniq
     pcm = torch.from_numpy(np.ascontiguousarray(uniq.T)).to(dev)[:, idx].contiguous()  # frame-major [nsamp, nch], resident before the clock starts
-    soft_cap = int(nsamp * 1200 / 48000) + 64
-    bank = DemodulatorBank(MskSettings(fb=1200.0, lockingbw=1800.0, freq_center=1000.0), nch, device=local, ebno=bool(ARGS.ebno), max_write_samples=chunk,
+    soft_cap = int(nsamp * mfb / 48000) + 64
+    bank = DemodulatorBank(MskSettings(fb=mfb, lockingbw=mbw, freq_center=1000.0), nch, device=local, ebno=bool(ARGS.ebno), max_write_samples=chunk,
                            softbit_capacity=soft_cap)
     bank.set_flags(afc=False, sql=False, cpu_reduce=False)
     stream = torch.cuda.current_stream().cuda_stream
@@ -712,10 +840,10 @@ def msk_bench():
         knames = {"sample_loop": bank.profile_kernel(0), "coarse_freq": bank.profile_kernel(1)}
         traffic, traffic_from = measured_traffic("pmc_summary_msk.json", dom, knames[dom], nch)
         line = {
-            "metric": "Msamples/s of real 48 kHz PCM through the 1200 bps MSK demodulator hot path", "value": round(value, 2), "unit": "Msamples/s",
+            "metric": f"Msamples/s of real 48 kHz PCM through the {int(mfb)} bps MSK demodulator hot path", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{nch}-channel-per-GPU synthetic 48 kHz 1200 bps MSK continuous (BASELINE configs[1] shape, scaled from 256 channels), "
+            "config": {"workload": f"{nch}-channel-per-GPU synthetic 48 kHz {int(mfb)} bps MSK continuous (BASELINE configs[1] shape, scaled from 256 channels), "
                                    f"{chunk}-sample writes, coarse 2^13 FFT every 2048 samples, AFC off, EbNo meters {'on' if ARGS.ebno else 'off'}, "
                                    f"Eb/N0 {ARGS.ebno_db} dB, {nuniq} distinct signals replicated over the channels",
                        "channels_per_gpu": nch, "total_channels": nch * world, "chunk": chunk, "realtime_channel_equivalents": int(value * 1e6 / 48000),
@@ -741,7 +869,7 @@ def msk_bench():
                 for c in spread_channels(nch, ARGS.check_channels):
                     u = c % nuniq
                     if u not in refs:
-                        refs[u] = O.run_demod(O.msk_settings(fb=1200.0, lockingbw=1800.0, freq_center=1000.0), uniq[u], chunk=chunk)
+                        refs[u] = O.run_demod(O.msk_settings(fb=mfb, lockingbw=mbw, freq_center=1000.0), uniq[u], chunk=chunk)
                     ref, got = refs[u], bank.read_softbits(c, cap=1 << 20)
                     n = len(ref["soft"])
                     ok = len(got) == n + ref["pending"] and bool(np.array_equal(got[:n] >= 128, ref["soft"] >= 128))
@@ -752,7 +880,7 @@ def msk_bench():
                     oc["bits_compared"] += n
                 line["config"]["oracle_check"] = oc
                 if not oc["hard_bits_equal"]:
-                    print(json.dumps(line), flush=True)
+                    emit(line)
                     raise SystemExit("bench.py: hard decisions of a sampled MSK channel differ from the oracle's on the same PCM")
             except SystemExit:
                 raise
@@ -762,20 +890,20 @@ def msk_bench():
             from oracle import oracle as O  # cpu_baseline leg only
             ncores = os.cpu_count() or 1
             n1 = min(ARGS.cpu_samples, 2_000_000)
-            x, _ = signalgen.msk(n1, fb=1200.0, fc=1000.0, ebno_db=ARGS.ebno_db, seed=signalgen.SEED_BASE + 77)
+            x, _ = signalgen.msk(n1, fb=mfb, fc=1000.0, ebno_db=ARGS.ebno_db, seed=signalgen.SEED_BASE + 77)
             if O.have_ref():
                 with tempfile.TemporaryDirectory() as td:
                     path = os.path.join(td, "in.s16")
                     x.tofile(path)
                     t1 = time.time()
-                    procs = [subprocess.Popen([O.REF_BIN, "time", "msk", path, f"chunk={chunk}", "fb=1200", "lockingbw=1800", "freq_center=1000"], stdout=subprocess.PIPE, env=child_env())
+                    procs = [subprocess.Popen([O.REF_BIN, "time", "msk", path, f"chunk={chunk}", f"fb={int(mfb)}", f"lockingbw={int(mbw)}", "freq_center=1000"], stdout=subprocess.PIPE, env=child_env())
                              for _ in range(ncores)]
                     inner = [float(pp.communicate()[0].split()[0]) for pp in procs]
                     wall = time.time() - t1
                 line["cpu_baseline"] = {"value": round(sum(n1 / t for t in inner) / 1e6, 3), "unit": "Msamples/s", "cores": ncores, "kind": "reference",
-                                        "sample": f"{n1} samples of 48 kHz 1200 bps MSK per core through the unmodified MskDemodulator, {chunk}-sample writes, "
+                                        "sample": f"{n1} samples of 48 kHz {int(mfb)} bps MSK per core through the unmodified MskDemodulator, {chunk}-sample writes, "
                                                   f"one process per core ({wall:.1f} s wall)"}
-        print(json.dumps(line), flush=True)
+        emit(line)
     bank.close()
     finish(world)
 
@@ -880,7 +1008,7 @@ def aerol_burst_bench():
                 ct = time.perf_counter() - t1
                 line["cpu_baseline"] = {"value": round(len(x) / ct / 1e6, 3), "unit": "Msoftbits/s", "cores": 1, "kind": "port",
                                         "sample": f"{len(x)} soft bits through oracle/aerol_oracle.c in burst mode, one thread"}
-        print(json.dumps(line), flush=True)
+        emit(line)
     bank.close()
     finish(world)
 
@@ -1138,6 +1266,142 @@ def burst_bench(msk: bool):
         raise SystemExit("bench.py: a sampled channel's soft-bit stream differs from the oracle's on the same PCM")
 
 
+def edge_c_abi_check(rank, world, dev, timeout_s=60.0):
+    """First-contact insurance for a node with one GPU per rank: the two edge operations through the C ABI itself
+    (jaero_comm_create / jaero_fan_out_pcm / jaero_gather_softbits: RCCL grouped send / recv loaded by dlopen inside libjaero_hip, not
+    torch.distributed) on a small bank of 64 channels per rank, checked value by value.  Runs in a side thread with a hard timeout AFTER the
+    timed region: a hung RCCL group then costs this entry (ok = false, "timeout"), never the measured line."""
+    import ctypes as C
+    import threading
+
+    import torch
+    import torch.distributed as dist
+
+    from jaero_amd import capi
+    from jaero_amd import dist as jd
+
+    res = {"ok": False}
+
+    def work():
+        L = capi.lib()
+        t0 = time.perf_counter()
+        ident = (C.c_char * 128)()
+        if rank == 0:
+            capi.check(L.jaero_comm_get_unique_id(ident))
+        t = torch.tensor(list(ident.raw), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, 0)
+        ident = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().tolist()))
+        comm = C.c_void_p()
+        capi.check(L.jaero_comm_create(dev.index, rank, world, ident, C.byref(comm)))
+        try:
+            per, nsamp, cap = 64, 1024, 96
+            total = per * world
+            lo, hi = jd.shard_range(total, rank, world)
+            st = torch.cuda.current_stream().cuda_stream
+            srow = torch.arange(nsamp, device=dev, dtype=torch.int32)[:, None]
+            ccol = torch.arange(total, device=dev, dtype=torch.int32)[None, :]
+            frames_all = ((srow * 31 + ccol * 7) & 0x7FFF).to(torch.int16).contiguous()   # every rank can form the whole pattern: the check is local
+            mine = torch.zeros((nsamp, hi - lo), dtype=torch.int16, device=dev)
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
+            capi.check(L.jaero_fan_out_pcm(comm, 0, frames_all.data_ptr() if rank == 0 else None, nsamp, total, mine.data_ptr(), st))
+            e1.record()
+            soft = ((torch.arange(hi - lo, device=dev, dtype=torch.int32)[:, None] + lo) * 3 + torch.arange(cap, device=dev, dtype=torch.int32)[None, :]).to(torch.int16).contiguous()
+            cnt = (torch.arange(hi - lo, device=dev, dtype=torch.int32) + lo) % cap
+            soft_all = torch.zeros((total, cap), dtype=torch.int16, device=dev)
+            cnt_all = torch.zeros((total,), dtype=torch.int32, device=dev)
+            capi.check(L.jaero_gather_softbits(comm, 0, soft.data_ptr(), cnt.data_ptr(), total, cap, soft_all.data_ptr() if rank == 0 else None,
+                                               cnt_all.data_ptr() if rank == 0 else None, st))
+            e2.record()
+            torch.cuda.synchronize()
+            ok = bool(torch.equal(mine, frames_all[:, lo:hi]))
+            if rank == 0:
+                want_soft = (torch.arange(total, device=dev, dtype=torch.int32)[:, None] * 3 + torch.arange(cap, device=dev, dtype=torch.int32)[None, :]).to(torch.int16)
+                ok = ok and bool(torch.equal(soft_all, want_soft)) and bool(torch.equal(cnt_all, (torch.arange(total, device=dev, dtype=torch.int32) % cap)))
+            res.update({"ok_this_rank": ok, "fan_out_ms": round(e0.elapsed_time(e1), 3), "gather_ms": round(e1.elapsed_time(e2), 3),
+                        "ms": round((time.perf_counter() - t0) * 1e3, 1), "channels": total, "samples": nsamp})
+        finally:
+            L.jaero_comm_destroy(comm)
+        f = torch.tensor([1 if res.get("ok_this_rank") else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        res["ok"] = bool(int(f.item()))
+
+    def guarded():
+        try:
+            work()
+        except Exception as e:
+            res["error"] = f"{type(e).__name__}: {e}"[:300]
+
+    th = threading.Thread(target=guarded, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        res.update({"ok": False, "error": f"timeout: the C-ABI edge operations did not return within {timeout_s:.0f} s"})
+        res["hung"] = True
+    return res
+
+
+# the other workloads of SURVEY 8 rows (a) / (f), run behind the headline by the ONE driver command (VERDICT r5 item 2)
+OTHER_WORKLOADS = [("msk_1200", ["--workload", "msk"], None), ("msk_600", ["--workload", "msk", "--fb", "600"], None),
+                   ("oqpsk8400", ["--workload", "oqpsk8400", "--preroll", "40"], None),
+                   # a burst OQPSK channel carries one burst per second = 11.7 writes, a burst MSK channel one per 1.5 s = 17.6 writes: the timed steps
+                   # cover one whole burst period (with fewer, the figure depends on where in its period a channel is)
+                   ("burst_oqpsk", ["--workload", "burst_oqpsk"], 12), ("burst_msk", ["--workload", "burst_msk"], 18),
+                   ("aerol", ["--workload", "aerol"], None), ("aerol_burst", ["--workload", "aerol_burst"], None), ("aerol_c", ["--workload", "aerol_c"], None)]
+
+
+def summarise_workload(d: dict) -> dict:
+    """the few figures of another workload's own line that go into the headline's line"""
+    r, c = d.get("roofline") or {}, d.get("config") or {}
+    oc = c.get("oracle_check")
+    if isinstance(oc, dict):
+        flag = [v for k, v in oc.items() if k in ("hard_bits_equal", "streams_equal", "rows_equal", "events_equal", "packets_equal", "voice_equal") and isinstance(v, bool)]
+        ocs = {"ok": bool(flag) and all(flag), "channels": len(oc.get("channels", []))}
+        for k in ("max_soft_byte_diff", "bits_compared", "softbits_compared", "rows_compared", "bursts", "error"):
+            if k in oc:
+                ocs[k] = oc[k]
+    else:
+        ocs = {"ok": False, "error": "no oracle check in the workload's line"}
+    g, cal = d.get("gpu_state") or {}, d.get("calib") or {}
+    out = {"value": d.get("value"), "unit": d.get("unit"), "ms_per_step": d.get("ms_per_step"), "steps": d.get("steps"),
+           "dominant_kernel": r.get("kernel_name") or r.get("kernel"), "kernel_ms": r.get("avg_launch_ms") or r.get("kernel_ms_per_step"),
+           "bound": r.get("bound"), "frac": r.get("frac"), "frac_of_calib_hbm": r.get("frac_of_calib_hbm"), "kernel_ms_per_step": c.get("kernel_ms_per_step") or c.get("kernel_ms_total"),
+           "oracle_check": ocs, "step_ms": d.get("step_ms"),
+           "gpu_state": {k: g.get(k) for k in ("sclk_mhz_mean", "sclk_mhz_min", "power_w_mean", "power_w_max", "throttled")},
+           "calib": {k: cal.get(k) for k in ("fp64_tflops", "hbm_gbs")}}
+    if r.get("floor_ms") is not None:
+        out["issue_floor_ms"] = r.get("floor_ms")
+    return out
+
+
+def other_workloads_pass(channels: int):
+    """Each of the other workloads as its own process on the same device (its own bank, its own resident input, its own oracle check after its
+    clock has stopped), `--other-steps` timed steps; returns {name: summary}.  The long lines go to gpurun_out/bench_details.json."""
+    out = {}
+    t_all = time.time()
+    for name, args, steps in OTHER_WORKLOADS:
+        cmd = [sys.executable, os.path.abspath(__file__)] + args + ["--steps", str(steps or ARGS.other_steps), "--warmup", "2", "--channels", str(channels), "--no-cpu-baseline",
+                                                                    "--as-written", "0", "--no-other-workloads", "--sustain", "0", "--gpus", "1"]
+        t0 = time.time()
+        try:
+            env = dict(os.environ)
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+            lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+            if not lines:
+                out[name] = {"error": ("rc %d: " % r.returncode) + (r.stderr.strip().splitlines() or ["no output"])[-1][:300]}
+            else:
+                out[name] = summarise_workload(json.loads(lines[-1]))
+                if r.returncode != 0:
+                    out[name]["rc"] = r.returncode
+        except Exception as e:
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        out[name]["wall_s"] = round(time.time() - t0, 1)
+    out["wall_s_total"] = round(time.time() - t_all, 1)
+    return out
+
+
 def main():
     """Continuous OQPSK: 10.5 kbps (the headline, BASELINE configs[2] shape; at N > 1 configs[4]) or 8400 bps (row f4)."""
     import torch
@@ -1159,8 +1423,10 @@ def main():
     # its BER settles once that window has filled ("score BER after t = 4 s"), so the bank is run to t >= 4 s before
     # the clock starts, and the bits of the timed steps are the ones scored.
     pre = ARGS.preroll if ARGS.preroll >= 0 else max(0, int(np.ceil(4.0 * 48000 / chunk)) - W)
-    total = (pre + W + K) * chunk
-    gen = signalgen.OqpskTorchStream(nch, total, dev, fb=fb, ebno_db=ARGS.ebno_db, seed=signalgen.SEED_BASE + lo, nphase=ARGS.timing_phases)
+    # Sustain: the LAST S steps of the pre-roll are resident beside the warm-up and timed steps and run back to back with
+    # them, so that the device has been at this load for ~--sustain seconds when the clock starts (a step of a 65536-channel bank is ~23 ms).
+    est_step_s = 0.023 * max(nch, 4096) / 65536.0 * (1.5 if fb == 8400 else 1.0)
+    S = int(np.ceil(ARGS.sustain / est_step_s)) if ARGS.sustain > 0 else 0
     check = spread_channels(nch, ARGS.check_channels) if ARGS.check_channels > 0 else []
     cidx = torch.tensor(check, dtype=torch.long, device=dev)
     host_pcm = {c: [] for c in check}
@@ -1171,16 +1437,21 @@ def main():
             for j, c in enumerate(check):
                 host_pcm[c].append(cols[j])
 
-    soft_cap = int((W + K) * chunk * fb / 48000) + 64
     free0, hbm_total = torch.cuda.mem_get_info(dev.index)
     bank = DemodulatorBank(OqpskSettings(fb=fb, lockingbw=fb, coarsefreqest_fft_power=14), nch, device=local,
-                           ebno=bool(ARGS.ebno), max_write_samples=chunk, softbit_capacity=soft_cap)
+                           ebno=bool(ARGS.ebno), max_write_samples=chunk, softbit_capacity=int((W + K) * chunk * fb / 48000) + 64)
     free1, _ = torch.cuda.mem_get_info(dev.index)
     bytes_per_channel = max(free0 - free1, 1) / float(nch)
+    step_bytes = chunk * nch * 2
+    # resident steps: what fits beside the bank with room for the generator's temporaries, the calibration buffers (8 GB) and the small banks
+    S = max(0, min(S, int((free1 - (24 << 30)) * 0.6 / step_bytes) - (W + K)))
+    pre = max(pre, S)
+    total = (pre + W + K) * chunk
+    gen = signalgen.OqpskTorchStream(nch, total, dev, fb=fb, ebno_db=ARGS.ebno_db, seed=signalgen.SEED_BASE + lo, nphase=ARGS.timing_phases)
     bank.set_flags(afc=False, sql=False, cpu_reduce=False)
-    PB = 8  # pre-roll rendered and consumed 8 steps at a time (the PCM of the whole pre-roll would not fit beside a 65536-channel bank)
-    for b in range(0, pre, PB):
-        nb = min(PB, pre - b)
+    PB = 8  # rendered (and, for the non-resident part of the pre-roll, consumed) 8 steps at a time
+    for b in range(0, pre - S, PB):
+        nb = min(PB, pre - S - b)
         blk = gen.render(b * chunk, nb * chunk)
         keep(blk)
         for i in range(nb):
@@ -1188,14 +1459,23 @@ def main():
         torch.cuda.synchronize()
         bank.discard_softbits(stream)
         del blk
-    pcm = gen.render(pre * chunk, (W + K) * chunk)  # warm-up + timed steps: resident in HBM before the clock starts
-    keep(pcm)
+    # sustain + warm-up + timed steps: resident in HBM before the clock starts
+    nres = S + W + K
+    pcm = torch.empty((nres * chunk, nch), dtype=torch.int16, device=dev)
+    for b in range(0, nres, PB):
+        nb = min(PB, nres - b)
+        blk = gen.render((pre - S + b) * chunk, nb * chunk)
+        pcm[b * chunk:(b + nb) * chunk] = blk
+        keep(blk)
+        del blk
     torch.cuda.synchronize()
 
     def step(i):
         bank.write(pcm[i * chunk:(i + 1) * chunk], layout=capi.PCM_FRAME_MAJOR, stream=stream)
+        if i == S - 1:
+            bank.discard_softbits(stream)  # the soft bits of the sustain steps (the warm-up's and the timed steps' are the ones kept and checked)
 
-    dt, dts = run_timed(step, W, K, world, dev, before_timed=lambda: bank.profile_enable(True))
+    dt, dts = run_timed(step, W, K, world, dev, before_timed=lambda: bank.profile_enable(True), sustain=S)
 
     samp_ms, samp_n = bank.profile_read(0)
     coarse_ms, coarse_n = bank.profile_read(1)
@@ -1235,8 +1515,14 @@ def main():
         except Exception as e:  # an edge operation that fails must not take the measured line with it
             edge = {"error": f"{type(e).__name__}: {e}"[:300]}
         dist.barrier()
+    edge_c = None
+    if world > 1 and shared:
+        edge_c = {"ok": None, "skipped": "ranks share a device (RCCL refuses two ranks on one GPU)"}
+    elif world > 1:
+        edge_c = edge_c_abi_check(rank, world, dev)
     bank.close()
     del pcm
+    torch.cuda.empty_cache()
 
     # BASELINE configs as written: configs[2] / configs[1] at N = 1, configs[4] (32768 channels over 8 GPUs = 4096 per GPU) at N > 1
     as_written = None
@@ -1246,9 +1532,7 @@ def main():
                 as_written = {"configs[2] 4096-channel 10.5 kbps OQPSK": small_bank_run("oqpsk", 4096, chunk, K, W, dev, local),
                               "configs[1] 256-channel 1200 bps MSK": small_bank_run("msk", 256, chunk, K, W, dev, local),
                               "configs[3] 4096-channel 10.5 kbps burst OQPSK": small_bank_run("burst_oqpsk", 4096, chunk, K, W, dev, local),
-                              "note": "the banks as BASELINE.json words them: 64 (4) wavefronts on 1024 SIMDs -- lane-per-channel kernels are latency bound there: "
-                                      "a sample of a 64-channel group is one serial chain through two wavefronts (~1.8 us whatever the bank size: the sample loop takes "
-                                      "7.6 ms per 4096 samples at 1024, 4096 and 16384 channels alike, profiles/r5_small_bank.md), so narrower groups would not run faster"}
+                              "note": "banks as BASELINE.json words them: 64 (4) wavefronts on 1024 SIMDs, latency bound (DESIGN 17, profiles/r5_small_bank.md)"}
             else:
                 r = small_bank_run("oqpsk", 4096, chunk, K, W, dev, local, seed_offset=lo)
                 t = torch.tensor([r["ms_per_step"]], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -1281,7 +1565,7 @@ def main():
                 "flops_per_sample": {"sample_loop": fl_samp, "coarse_freq": fl_coarse},
                 "per_kernel_frac": {"sample_loop": round(fl_samp * samples_per_step / (samp_ms / K * 1e-3) / 78.6e12, 5),
                                     "coarse_freq": round(fl_coarse * samples_per_step / (coarse_ms / K * 1e-3) / 78.6e12, 5) if coarse_ms else None},
-                "note": "ALGORITHMIC flops of the reference's arithmetic (FMA = 2), not issued instructions -- the issued-instruction roof is roofline_fp64_issue"}
+                "note": "algorithmic flops (FMA = 2), not issued instructions: see roofline_fp64_issue"}
         issue = issue_roofline({"sample_loop": samp_ms / K, "coarse_freq": coarse_ms / K}, kernel_names, nch)
         name = "10.5 kbps" if fb == 10500 else "8400 bps (C channel)"
         cfg_name = ("BASELINE configs[2] shape" if world == 1 else f"BASELINE configs[4] shape: {nch * world} channels sharded over {world} GPUs")
@@ -1290,17 +1574,15 @@ def main():
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{nch}-channel-per-GPU synthetic 48 kHz {name} OQPSK continuous ({cfg_name}, "
-                                   f"scaled to {nch} channels per GPU so every SIMD of the 256 CUs holds a wavefront of 64 channels), "
-                                   f"{chunk}-sample writes, coarse 2^14 FFT every 4096 samples, AFC off, EbNo meters {'on' if with_eb else 'off'}, "
-                                   f"Eb/N0 {ARGS.ebno_db} dB, every channel its own carrier (8000 +- 100 Hz), bits, noise and symbol-clock phase "
-                                   f"({ARGS.timing_phases} phases over two symbol periods), {pre} untimed pre-roll steps so the timed steps start at "
+            "config": {"workload": f"{nch}-channel-per-GPU synthetic 48 kHz {name} OQPSK continuous ({cfg_name}, scaled to {nch} channels per GPU = one "
+                                   f"wavefront of 64 channels per SIMD), {chunk}-sample writes, coarse 2^14 FFT every 4096 samples, AFC off, EbNo meters "
+                                   f"{'on' if with_eb else 'off'}, Eb/N0 {ARGS.ebno_db} dB, per-channel carrier (8000 +- 100 Hz), bits, noise, symbol phase; "
+                                   f"{pre} untimed pre-roll steps (the last {S} resident and back to back with the warm-up: sustain), timed steps start at "
                                    f"t = {(pre + W) * chunk / 48000.0:.2f} s of signal",
                        "channels_per_gpu": nch, "total_channels": nch * world, "chunk": chunk, "ebno_meters": with_eb,
                        "preroll_steps": pre, "timing_phases": ARGS.timing_phases,
                        "realtime_channel_equivalents": int(value / 0.048),
-                       "realtime_channel_equivalents_note": "throughput / 48 kS/s: a bank of channels_per_gpu resident channels run that many times faster than "
-                                                            "real time, NOT that many channels resident at once (see resident_channels_max)",
+                       "realtime_channel_equivalents_note": "throughput / 48 kS/s, NOT channels resident at once (see resident_channels_max)",
                        "hbm_bytes_per_resident_channel": int(bytes_per_channel),
                        "resident_channels_max": int(hbm_total / bytes_per_channel),
                        "whole_path_hbm_frac_at_163B_per_sample": round(value * 1e6 * ALG_BYTES_WHOLE_PATH / 1e9 / (HBM_PEAK_GBS * world), 5),
@@ -1312,16 +1594,22 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_from": traffic_from,
                          "alg_bytes_per_sample": per_sample, "samples_per_step": samples_per_step, "kernel_ms_per_step": round(ms_per_step, 4),
                          "launches_per_step": round((samp_n if dom == "sample_loop" else coarse_n) / float(K), 2),
-                         "note": "achieved = alg_bytes_per_sample x samples_per_step / kernel_ms_per_step; a step's sample-loop work is one full "
-                                 "launch plus a one-sample launch behind the coarse estimate (the reference runs the estimate inside that sample)"},
+                         "note": "achieved = alg_bytes_per_sample x samples_per_step / kernel_ms_per_step (HIP events on the launch stream)"},
             "roofline_fp64": fp64,
             "roofline_fp64_issue": issue,
         }
         line["config"].update(rank_fields(world, shared, dts, float(K) * chunk * nch))
         if edge:
             line["config"]["edge_collectives"] = edge
+        if edge_c:
+            line["config"]["edge_collectives_c_abi"] = edge_c
         if as_written:
             line["config"]["as_written"] = as_written
+        if world == 1 and fb == 10500 and not ARGS.no_other_workloads:
+            try:
+                line["config"]["other_workloads"] = other_workloads_pass(nch)
+            except Exception as e:
+                line["config"]["other_workloads"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if check:
             from oracle import oracle as O  # checker only, after the clock has stopped
             try:
@@ -1332,7 +1620,7 @@ def main():
                 line["config"]["oracle_check"] = oc
                 assert oc["hard_bits_equal"], "hard decisions of a sampled channel differ from the oracle's on the same PCM"
             except AssertionError:
-                print(json.dumps(line), flush=True)
+                emit(line)
                 raise
             except Exception as e:
                 line["config"]["oracle_check"] = {"error": str(e)}
@@ -1341,7 +1629,9 @@ def main():
                 line["cpu_baseline"] = cpu_baseline_continuous(chunk, fb)
             except Exception as e:  # never lose the GPU line because the CPU leg failed
                 line["cpu_baseline"] = {"value": None, "error": str(e)}
-        print(json.dumps(line), flush=True)
+        emit(line)
+    if edge_c and edge_c.get("hung"):
+        os._exit(0)  # a side thread is stuck inside RCCL: the line is out (rank 0), do not wait for a barrier that cannot complete
     finish(world)
 
 
