@@ -182,7 +182,7 @@ def run_timed(step, W, K, world, dev, before_timed=None, sustain=0):
             cal["fp64_tflops"] = round(sum(x["fp64_tflops"] for x in ok) / len(ok), 2)
             cal["hbm_gbs"] = round(sum(x["hbm_gbs"] for x in ok) / len(ok), 1)
             cal["fp64_frac_of_peak"] = round(cal["fp64_tflops"] / BS.FP64_PEAK_TFLOPS, 4)
-            cal["what"] = "fp64: dependent-free v_fma_f64 on every SIMD, ~10 ms; hbm: 16 B per lane copy of 2 x 4 GB; HIP events, immediately before / after the timed steps"
+            cal["what"] = "fp64 FMA on every SIMD ~10 ms; 16 B/lane copy 2 x 4 GB; HIP events right before / after the timed steps (jaero_amd/csrc/calib.hip)"
         MEAS["calib"] = cal
     if ev:
         MEAS["step_ms"] = BS.step_stats([ev[i].elapsed_time(ev[i + 1]) for i in range(K)])
@@ -239,6 +239,9 @@ def emit(line):
         line["calib"] = MEAS["calib"]
     if MEAS.get("step_ms"):
         line["step_ms"] = MEAS["step_ms"]
+    pw = (MEAS.get("gpu_state") or {}).get("power_w_mean")
+    if pw and line.get("value") and line.get("n_gpus") == 1:
+        line["gpu_state"]["value_per_watt"] = round(line["value"] / pw, 3)  # the metric's unit per watt of socket power during the timed steps
     if "per_rank" in MEAS:
         line["config"]["per_rank_state"] = MEAS["per_rank"]
     if MEAS.get("sustain_steps"):
@@ -1364,11 +1367,11 @@ def summarise_workload(d: dict) -> dict:
         ocs = {"ok": False, "error": "no oracle check in the workload's line"}
     g, cal = d.get("gpu_state") or {}, d.get("calib") or {}
     out = {"value": d.get("value"), "unit": d.get("unit"), "ms_per_step": d.get("ms_per_step"), "steps": d.get("steps"),
-           "dominant_kernel": r.get("kernel_name") or r.get("kernel"), "kernel_ms": r.get("avg_launch_ms") or r.get("kernel_ms_per_step"),
-           "bound": r.get("bound"), "frac": r.get("frac"), "frac_of_calib_hbm": r.get("frac_of_calib_hbm"), "kernel_ms_per_step": c.get("kernel_ms_per_step") or c.get("kernel_ms_total"),
-           "oracle_check": ocs, "step_ms": d.get("step_ms"),
-           "gpu_state": {k: g.get(k) for k in ("sclk_mhz_mean", "sclk_mhz_min", "power_w_mean", "power_w_max", "throttled")},
-           "calib": {k: cal.get(k) for k in ("fp64_tflops", "hbm_gbs")}}
+           "dominant_kernel": r.get("kernel_name") or r.get("kernel"), "kernel_ms": r.get("avg_launch_ms") or r.get("kernel_ms_per_step") or r.get("ms"),
+           "bound": r.get("bound"), "frac": r.get("frac"), "oracle_check": ocs,
+           "sclk_mhz": g.get("sclk_mhz_mean"), "power_w": g.get("power_w_mean"), "throttled": g.get("throttled"), "calib_fp64_tflops": cal.get("fp64_tflops")}
+    if r.get("frac_of_calib_hbm") is not None:
+        out["frac_of_calib_hbm"] = r.get("frac_of_calib_hbm")
     if r.get("floor_ms") is not None:
         out["issue_floor_ms"] = r.get("floor_ms")
     return out
@@ -1472,7 +1475,7 @@ def main():
 
     def step(i):
         bank.write(pcm[i * chunk:(i + 1) * chunk], layout=capi.PCM_FRAME_MAJOR, stream=stream)
-        if i == S - 1:
+        if i < S:
             bank.discard_softbits(stream)  # the soft bits of the sustain steps (the warm-up's and the timed steps' are the ones kept and checked)
 
     dt, dts = run_timed(step, W, K, world, dev, before_timed=lambda: bank.profile_enable(True), sustain=S)

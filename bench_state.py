@@ -164,11 +164,12 @@ class GpuStateSampler:
             if tot and tot > 0:
                 thr = {k.replace("_residency_acc", "_frac"): round(d(k) / tot, 4) for k in ("ppt_residency_acc", "prochot_residency_acc",
                                                                                                "socket_thm_residency_acc", "vr_thm_residency_acc", "hbm_thm_residency_acc") if d(k) is not None}
+                thr = {"ppt_frac": thr.get("ppt_frac", 0.0), **{k: v for k, v in thr.items() if v > 0 and k != "ppt_frac"}}  # ppt = the socket power limit
         out["throttle_residency"] = thr
         cap = self.power_cap_w
         mean_clk = (t or {}).get("sclk_mhz_mean")
         out["throttled"] = bool((thr and any(v > 0.02 for v in thr.values())) or (mean_clk is not None and mean_clk < 0.93 * 2400.0))
-        out["throttled_rule"] = "any throttle residency > 2 % of the timed window, or mean engine clock < 93 % of 2400 MHz"
+        out["throttled_rule"] = "a throttle residency > 2 % of the timed window, or mean sclk < 93 % of 2400 MHz"
         if t and t.get("power_w_max") and cap:
             out["power_frac_of_cap_max"] = round(t["power_w_max"] / cap, 3)
         if self.error:
