@@ -58,7 +58,8 @@ struct JRcclGroup
     explicit JRcclGroup(jaero_comm *c) : comm(c) {}
     int start() { const int r = g_rccl.GroupStart(); open = (r == 0); return r; }
     int end() { open = false; const int r = g_rccl.GroupEnd(); if (r != 0) jaero_comm_break(comm); return r; }
-    ~JRcclGroup() { if (open) { g_rccl.GroupEnd(); jaero_comm_break(comm); } }
+    // an early return between start() and end(): the communicator is aborted FIRST (its queued operations die with it), then the group is closed
+    ~JRcclGroup() { if (open) { jaero_comm_break(comm); g_rccl.GroupEnd(); } }
 };
 
 struct jaero_comm
@@ -134,7 +135,13 @@ extern "C" void jaero_comm_destroy(jaero_comm *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
-    if (c->nccl) g_rccl.CommDestroy(c->nccl);
+    if (c->nccl && c->broken)
+    {
+        // a failed group whose communicator could not be aborted (this librccl has no ncclCommAbort): ncclCommDestroy on it can wait forever for
+        // the half-queued group, which is the hang the abort was there to remove -- the handle is leaked instead, and said so
+        fail(JAERO_EHIP, "jaero_comm_destroy: the communicator had failed and librccl offers no ncclCommAbort; its RCCL handle is leaked rather than destroyed");
+    }
+    else if (c->nccl) g_rccl.CommDestroy(c->nccl);
     if (c->stage_ev) hipEventDestroy(c->stage_ev);
     if (c->stage) hipFree(c->stage);
     delete c;

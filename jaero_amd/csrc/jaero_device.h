@@ -52,7 +52,6 @@ enum
     I_YUI, I_SIG2L_INIT, I_FLAGS, I_COUNTDOWN, I_COUNTDOWN2, I_EMPTYING, I_NEST,
     I_SOFT_CNT, I_SYM_CNT, I_LOG_CNT, I_OVERFLOW,
     I_DLY_POS,   // MSK: shared slot of delayedsmpl / delayt8 rings
-    I_SYMQ_N,    // k_oqpsk_fb: symbols the back half queued for k_oqpsk_out during the current launch (0 between launches)
     I_NFIELDS
 };
 // Read-only data through the CONSTANT address space: with a wave-uniform address such a load is a scalar load (lgkmcnt) that the compiler
@@ -92,7 +91,6 @@ struct JGeom
     double correctionfactor;
     unsigned flags;
     int soft_cap, sym_cap, log_cap;
-    int symq_cap;   // k_oqpsk_fb: entries of a channel's symbol queue (symbols of the largest write + 4)
 };
 
 struct JPtrs
@@ -117,8 +115,7 @@ struct JPtrs
     double *slog;        // [nchp][log_cap][6]
     const double2 *cis;  // [19999]
     const double *taps2; // [2*fir_n] taps repeated twice
-    double *symrec;      // k_oqpsk_out: [nchp][JD_SYMREC_LEN][8] one 64-byte record per symbol pair (see k_oqpsk_out)
-    double *symq;        // k_oqpsk_fb -> k_oqpsk_out: [nchp][symq_cap][4] {ct_ec, pt_re, ptd_im, -} per symbol of the current launch
+    double *symrec;      // k_oqpsk_fb: [nchp][JD_SYMREC_LEN][8] one 64-byte record per symbol pair (see fb_back)
 };
 #define JD_SYMREC_LEN 800
 

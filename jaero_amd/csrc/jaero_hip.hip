@@ -754,10 +754,6 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         if (c->oq_pairs)
         {
             if ((rc = dalloc(c, &c->p.symrec, (size_t)nchp * JD_SYMREC_LEN * 8))) { jaero_destroy(c); return rc; }
-            // the back half's queue for k_oqpsk_out: a launch is at most one write long and symbol pairs are Fs / (fb / 2) samples apart (the symbol
-            // oscillator is held within 0.1 Hz of fb / 2: oqpskdemodulator.cpp:493-494)
-            c->g.symq_cap = (int)((double)c->max_write * (g.fb * 0.5 + 1.0) / g.Fs) + 4;
-            if ((rc = dalloc(c, &c->p.symq, (size_t)nchp * c->g.symq_cap * 4))) { jaero_destroy(c); return rc; }
 #define FBA(E, C, PP, X) HIPCHK(hipFuncSetAttribute((const void *)k_oqpsk_fb<55, FB_LDSN, E, C, PP, X>, hipFuncAttributeMaxDynamicSharedMemorySize, PP * fb_pair_doubles<FB_LDSN>() * (int)sizeof(double)))
             if (c->pre8400)
             {
@@ -1140,7 +1136,6 @@ extern "C" int jaero_profile_kernel(jaero_ctx *c, int which, char *buf, int cap)
     }
     else if (which == 1) nm = (g.nfft_log2 == 14) ? (c->pre8400 ? "k_coarse6_w8400" : "k_coarse6") : "k_coarse6_13";
     else if (which == 2) nm = "k_transpose_pcm";
-    else if (which == 3 && g.kind == JAERO_KIND_OQPSK) nm = "k_oqpsk_out<";
     snprintf(buf, (size_t)cap, "%s", nm);
     return 0;
 }
@@ -1200,15 +1195,6 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
 #undef LMS
 #undef LM
     }
-}
-
-// the output halves of the symbols a sample-loop launch queued (k_oqpsk_out, k_oqpsk_fb.h): right behind that launch, before anything reads mse
-// (the coarse estimate's slot logic does)
-static void launch_oqpsk_out(jaero_ctx *c, hipStream_t st)
-{
-    const JGeom &g = c->g;
-    if ((c->flags & JAERO_FLAG_CAPTURE_SYMBOLS) != 0) hipLaunchKernelGGL(k_oqpsk_out<true>, dim3(g.ngroups), dim3(64), 0, st, g, c->p);
-    else hipLaunchKernelGGL(k_oqpsk_out<false>, dim3(g.ngroups), dim3(64), 0, st, g, c->p);
 }
 
 static void launch_coarse(jaero_ctx *c, const int *d_list, int nlist, hipStream_t st)
@@ -1311,13 +1297,6 @@ extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int l
             launch_samples(c, frames + (size_t)pos * stride, stride, n, skip_a, only_a, st, pos);
             LAUNCHCHK("the sample loop");
             prof_end(c, pi, st);
-            if (g.kind == JAERO_KIND_OQPSK)
-            {
-                const int po = prof_begin(c, 3, st);
-                launch_oqpsk_out(c, st);
-                LAUNCHCHK("k_oqpsk_out");
-                prof_end(c, po, st);
-            }
             c->m.nB_total = nb_after;
         }
         if (only_a)

@@ -53,9 +53,17 @@ __device__ __forceinline__ JdAtanLane jd_atan_lane_table(int lane)
     t.lo_f = __float_as_int(JD_ATAN_LOF[(lane & 63) + 1]);
     return t;
 }
-// entry i (0..64) for this lane; EVERY lane of the wavefront must be active (a bpermute reads other lanes' registers)
+// entry i (0..64) for this lane.  A bpermute reads other lanes' registers and returns nothing for lanes the exec mask has switched off: when the
+// call is made with part of the wavefront inactive (no call site does today -- padding lanes run the sample loops -- but nothing else enforces it:
+// ADVICE r5), the entry comes from the table in memory instead.  The test is wave-uniform (one s_cmp, never taken in the sample loops).
 __device__ __forceinline__ void jda_fetch(const JdAtanLane &T, int i, double &A_hi, double &A_lo)
 {
+    if (__builtin_expect(__builtin_amdgcn_read_exec() != ~0ull, 0))
+    {
+        A_hi = JD_ATAN_HI[i];
+        A_lo = (double)JD_ATAN_LOF[i];
+        return;
+    }
     const int addr = (i - 1) << 2; // i = 0 reads lane 63 (address wraps) and is discarded below
     const int hh = __builtin_amdgcn_ds_bpermute(addr, T.hi_h);
     const int hl = __builtin_amdgcn_ds_bpermute(addr, T.hi_l);

@@ -22,14 +22,19 @@
 // a channel is spread over two instruction streams.  Small banks use one pair per workgroup (two SIMDs per 64 channels).
 //
 // Second change against k_oqpsk.h: the OUTPUT half of the symbol block (averages, residual rotation, MSE, soft bits -- nothing
-// of it feeds back into the signal path) does not run in this loop at all (round 6): the instant records three doubles per symbol
-// in a per-lane queue in memory and k_oqpsk_out (below) runs the output halves of the whole launch afterwards.  (Rounds 2-5: queued
-// per lane and run for all lanes together every 16, then 8 samples.)  The feedback half (tanh detector, loop filter, carrier NCO)
-// runs at the instant.
+// of it feeds back into the signal path) is queued per lane and run for all lanes together every FB_DEFER samples: with channels
+// that are not symbol-synchronous some lane is at a symbol instant in nearly every sample, and the whole block used to run each
+// time for ~5 % of the lanes.  The feedback half (tanh detector, loop filter, carrier NCO) still runs at the instant.
 // Third: divisions by constants are done with the constant's reciprocal and two fma corrections (jd_div_const), bit-identical to
 // the IEEE quotient; fmod(x, 360) takes the exact shortcut for |x| < 720.
 #pragma once
 #include "jaero_device.h"
+
+// The queue is ONE symbol deep, so the batch interval must not exceed the distance between two symbols of a lane (48 000 / 5 250 = 9.14
+// samples at 10.5 kbps, 11.4 at 8400 bps): with 16 (rounds 2-4) a lane's next symbol arrived before the batch in 43 % of the cases, took the
+// "a lane about to queue a second one goes first" path below, and with 64 unsynchronised lanes that path -- the whole output half for one or two
+// lanes -- ran in 95 % of the samples (the phase trace of round 5 found it: 1.03 us of the back half's 2.94 per sample).
+#define FB_DEFER 8
 
 // Phase trace of the sample loop (scripts/gpu_r5.sh trace): the trace build (make -C jaero_amd/csrc trace) reads the 100 MHz
 // clock at five points of a sample in either half, every wavefront alike (so that no wavefront waits for a slower, traced one), and one pair
@@ -418,31 +423,110 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, FbLds &L
     double lf_x1 = LDF(S_LF_X1), lf_x2 = LDF(S_LF_X2), lf_y1 = LDF(S_LF_Y1), lf_y2 = LDF(S_LF_Y2);
     double sig2l_re = LDF(S_SIG2L_RE), sig2l_im = LDF(S_SIG2L_IM), ptd_re = LDF(S_PTD_RE), ptd_im = LDF(S_PTD_IM);
     double ptd_th = jd_tanh(ptd_re); // kept beside ptd_re inside a launch (see the instant block); formed again here rather than stored
+    double marg_sum = LDF(S_MARG_SUM), pm_sum = LDF(S_PM_SUM), msema_sum = LDF(S_MSEMA_SUM), mse = LDF(S_MSE);
+    const double thresh = LDF(S_THRESH);
+    int marg_pos = LDI(I_MARG_POS), dt_pos = LDI(I_DT_POS), pm_pos = LDI(I_PM_POS), msema_pos = LDI(I_MSEMA_POS);
     int yui = LDI(I_YUI), sig2l_init = LDI(I_SIG2L_INIT);
-    int symq_n = LDI(I_SYMQ_N), symq_lost = 0;
+    int soft_cnt = LDI(I_SOFT_CNT), sym_cnt = LDI(I_SYM_CNT), overflow = LDI(I_OVERFLOW);
 
     const JdAtanLane atl = jd_atan_lane_table(lane); // jd_atan2's table, one entry per lane (every lane of the wavefront runs the loop below)
     const double samplerate = g.Fs; // WaveTable::samplerate after SetFreq(freq,(int)Fs)
     const double r_samplerate = 1.0 / samplerate;
     const double wtsize_d = (double)JD_WTSIZE, r_wtsize = 1.0 / wtsize_d, r_360 = 1.0 / 360.0;
+    const double marg_len_d = (double)g.marg_len, pm_len_d = (double)g.pm_len, msema_len_d = (double)g.msema_len;
+    const double r_marg_len = 1.0 / marg_len_d, r_pm_len = 1.0 / pm_len_d, r_msema_len = 1.0 / msema_len_d;
+    // Symbol-rate windows: marg (MovingAverage(800)), dt (DelayThing(400)), pointmean and msema (MovingAverage(400) each) all advance
+    // once per symbol pair from the same start, so ONE ring of 800 records {ct_ec, q_re, q_im, |q|, e} serves the four: the entry
+    // leaving marg's window is in the record about to be overwritten, those leaving the other three in the record written 400 symbols
+    // ago.  A symbol then costs two 64-byte record reads and one full-sector write; as four per-channel arrays of 8-byte entries it
+    // was four sector fills and four partial writes (measured: ~15 GB of reads and ~4 GB of writes per launch for 0.6 GB of entries).
+    double *__restrict__ symrec = p.symrec + (size_t)ch * JD_SYMREC_LEN * 8;
     const double w4 = g.w4, w4c = 1.0 - g.w4, w8 = g.w8, w8c = 1.0 - g.w8;
 
-    // The OUTPUT half of a symbol -- marg->UpdateSigned(ct_ec) .. soft bits (oqpskdemodulator.cpp:534-595): averages, residual rotation, MSE, soft
-    // bits; nothing of it feeds back into the signal path -- left this loop in round 6.  Until then it was queued per lane and run for all lanes
-    // together every 8 samples (3.2 us of sincos, hypot and divisions for 64 lanes, 0.40 us per sample: round 5's phase trace) while the front half
-    // waited 0.73 us per sample at the barrier.  Now the instant only records {ct_ec, pt_re, ptd_im} (32 bytes, half a sector, in the lane's own
-    // queue in memory: JPtrs::symq) and k_oqpsk_out below runs the output halves of the whole launch afterwards, one channel per lane and
-    // nothing else to wait for; this loop is feedback only.
-    double *__restrict__ symq = p.symq + (size_t)ch * g.symq_cap * 4;
+    // the output half of a symbol, queued at the instant: marg->UpdateSigned(ct_ec) .. soft bits (oqpskdemodulator.cpp:534-595).
+    // pd_* = what it needs from the instant; px_* = the ring entries leaving the four windows, requested when the symbol is queued.
+    // The ring entries are HBM misses; they are requested at the top of the NEXT sample, right behind the wait for the symbol
+    // NCO's table value (vmcnt retires in order: requested at the instant they would sit in front of that wait one sample later).
+    bool pend = false, need_px = false;
+    double pd_ec = 0, pd_re = 0, pd_im = 0;
+    double px_marg = 0, px_pm = 0, px_ms = 0;
+    double2 px_dt = make_double2(0.0, 0.0);
     auto queue_symbol = [&](double ct_ec, double q_re, double q_im) {
-        if (symq_n < g.symq_cap)
+        pend = true; need_px = true; pd_ec = ct_ec; pd_re = q_re; pd_im = q_im;
+    };
+    auto request_px = [&]() {
+        px_marg = symrec[marg_pos * 8]; // written 800 symbols ago
+        int o = marg_pos + JD_SYMREC_LEN / 2; if (o >= JD_SYMREC_LEN) o -= JD_SYMREC_LEN;
+        const double2 *r = (const double2 *)(symrec + o * 8); // written 400 symbols ago: {ct_ec, q_re}, {q_im, |q|}, {e, -}
+        const double2 r0 = r[0], r1 = r[1], r2 = r[2];
+        px_dt = make_double2(r0.y, r1.x); // = what dt.update returns
+        px_pm = r1.y;
+        px_ms = r2.x;
+        need_px = false;
+    };
+    auto output_half = [&]() {
+        const double ct_ec = pd_ec;
+        double q_re = pd_re, q_im = pd_im;
+        // marg->UpdateSigned(ct_ec)
+        marg_sum = marg_sum - px_marg; marg_sum = marg_sum + ct_ec;
+        const double marg_val = jd_div_const(marg_sum, marg_len_d, r_marg_len);
+        // dt.update(pt_qpsk)
+        const double in_re = q_re, in_im = q_im;
+        q_re = px_dt.x; q_im = px_dt.y;
         {
-            double2 *w = (double2 *)(symq + (size_t)symq_n * 4);
-            w[0] = make_double2(ct_ec, q_re);
-            w[1] = make_double2(q_im, 0.0);
-            symq_n++;
+            double sr, cr;
+            sincos(marg_val, &sr, &cr); // the same two values as cos() and sin() (one argument reduction, the same kernels)
+            const double nr = q_re * cr - q_im * sr;
+            const double ni = q_re * sr + q_im * cr;
+            q_re = nr; q_im = ni;
         }
-        else symq_lost = 1;
+        // MSEcalc::Update (DSP.cpp:451-463)
+        double av_w, e_w;
+        {
+            const double av = jd_hypot(q_re, q_im);
+            pm_sum = pm_sum - px_pm; pm_sum = pm_sum + fabs(av); av_w = fabs(av);
+            double mu = jd_div_const(pm_sum, pm_len_d, r_pm_len);
+            if (mu < 0.000001) mu = 0.000001;
+            const double s2 = sqrt(2.0);
+            const double t_re = (s2 * q_re) / mu, t_im = (s2 * q_im) / mu;
+            const double tda = (fabs(t_re) - 1.0), tdb = (fabs(t_im) - 1.0);
+            const double e = (tda * tda) + (tdb * tdb);
+            msema_sum = msema_sum - px_ms; msema_sum = msema_sum + fabs(e); e_w = fabs(e);
+            mse = jd_div_const(msema_sum, msema_len_d, r_msema_len);
+        }
+        // this symbol's record: one complete 64-byte sector
+        {
+            double2 *w = (double2 *)(symrec + marg_pos * 8);
+            w[0] = make_double2(ct_ec, in_re);
+            w[1] = make_double2(in_im, av_w);
+            w[2] = make_double2(e_w, 0.0);
+            w[3] = make_double2(0.0, 0.0);
+            marg_pos++; if (marg_pos >= JD_SYMREC_LEN) marg_pos = 0;
+        }
+        if (CAPSYM)
+        {
+            if (sym_cnt < g.sym_cap)
+            {
+                double *sp = p.sym + ((size_t)ch * g.sym_cap + sym_cnt) * 3;
+                sp[0] = q_re; sp[1] = q_im; sp[2] = mse;
+                sym_cnt++;
+            }
+            else overflow |= 2;
+        }
+        if (mse < thresh)
+        {
+            const int b0 = jd_softbit(0.75 * q_im * 127.0 + 128.0);
+            const int b1 = jd_softbit(0.75 * q_re * 127.0 + 128.0);
+            if (soft_cnt + 2 <= g.soft_cap)
+            {
+                int16_t *sp = p.soft + (size_t)ch * g.soft_cap + soft_cnt;
+                sp[0] = (int16_t)b0;
+                sp[1] = (int16_t)b1;
+                soft_cnt += 2;
+            }
+            else overflow |= 1;
+        }
+        pend = false;
     };
 
     // mailbox: the table index of mixer2 for sample 0
@@ -491,14 +575,18 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, FbLds &L
             if (st_freq > (g.stref_freq + 0.1)) fb_wt_setfreq(st_freq, st_step, (g.stref_freq + 0.1), samplerate, r_samplerate);
         }
         if constexpr (!PRE8400) FB_TRACE(1); // mailbox read, symbol timing: delays, resonator, atan2, oscillator nudges
-        if constexpr (!PRE8400) FB_TRACE(5);
+        if (need_px) request_px(); // for the symbol queued in the previous sample
+        if constexpr (!PRE8400) FB_TRACE(5); // (finer split of the third row: the record requests)
 
         // ---- K10..K14 at symbol instants (:487-595) ----
         if (!sig2l_init) { sig2l_re = sre; sig2l_im = sim; sig2l_init = 1; }
         double frac;
         const bool inst = jd_wt_passed(st_last, st_ptr, st_step, g.ee, frac);
+        const bool full = inst && (yui == 0); // yui flips to 1 at this instant: the instant that closes a symbol pair
         if constexpr (!PRE8400) FB_TRACE(6); // (the instant test)
-        if constexpr (!PRE8400) FB_TRACE(2);
+        // queued output halves: all lanes together every FB_DEFER samples; a lane about to queue a second one goes first
+        if (pend && (full || (i & (FB_DEFER - 1)) == 0)) output_half();
+        if constexpr (!PRE8400) FB_TRACE(2); // record requests, instant test, queued output halves (every 16th sample)
         if (inst)
         {
             const double pt_last = frac, pt_this = 1.0 - pt_last;
@@ -566,6 +654,8 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, FbLds &L
         FB_SYNC(L);
     }
     if constexpr (!PRE8400) FB_TRACE_FLUSH(1, nB);
+    if (need_px) request_px();
+    if (pend) output_half();
 
     LDF(S_M2_PTR) = m2_ptr; LDF(S_M2_STEP) = m2_step; LDF(S_M2_FREQ) = m2_freq;
     LDF(S_ST_PTR) = st_ptr; LDF(S_ST_STEP) = st_step; LDF(S_ST_FREQ) = st_freq; LDF(S_ST_LAST) = st_last;
@@ -576,138 +666,11 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, FbLds &L
     LDF(S_RES_X1) = res_x1; LDF(S_RES_X2) = res_x2; LDF(S_RES_Y1) = res_y1; LDF(S_RES_Y2) = res_y2;
     LDF(S_LF_X1) = lf_x1; LDF(S_LF_X2) = lf_x2; LDF(S_LF_Y1) = lf_y1; LDF(S_LF_Y2) = lf_y2;
     LDF(S_SIG2L_RE) = sig2l_re; LDF(S_SIG2L_IM) = sig2l_im; LDF(S_PTD_RE) = ptd_re; LDF(S_PTD_IM) = ptd_im;
-    LDI(I_YUI) = yui; LDI(I_SIG2L_INIT) = sig2l_init;
-    LDI(I_SYMQ_N) = symq_n;
-    if (symq_lost) LDI(I_OVERFLOW) = LDI(I_OVERFLOW) | 4; // cannot happen with the capacity jaero_create computes (symbols per largest write + 4); said loudly if it does
-    if constexpr (PRE8400) LDF(S_PRE_FSUM) = LDF(S_PRE_FSUM) + m2fsum;
-}
-
-// ---------------------------------------------------------------------------------------------------------- output halves (round 6)
-// One channel per lane, the symbols the back half queued during the launch in order: marg->UpdateSigned(ct_ec), dt.update, the residual
-// rotation, MSEcalc::Update, the soft bits (oqpskdemodulator.cpp:534-595, DSP.cpp:451-463) -- the reference's operations in the reference's order,
-// moved here unchanged from fb_back.  Symbol-rate windows: marg (MovingAverage(800)), dt (DelayThing(400)), pointmean and msema
-// (MovingAverage(400) each) all advance once per symbol pair from the same start, so ONE ring of 800 records {ct_ec, q_re, q_im, |q|, e}
-// serves the four: the entry leaving marg's window is in the record about to be overwritten, those leaving the other three in the record
-// written 400 symbols ago.  A symbol costs two 64-byte record reads, one half-sector queue read and one full-sector write.  The loads of
-// symbol k + OUT_PD are issued while symbol k is computed (a wavefront is alone on its SIMD here: nothing else hides an HBM miss); a record
-// read OUT_PD symbols ahead was written at least 400 - OUT_PD symbols ago, so the early read sees what the late one would.
-#define OUT_PD 4
-template <bool CAPSYM>
-__global__ __launch_bounds__(64) void k_oqpsk_out(const JGeom g, const JPtrs p)
-{
-    const int ch = blockIdx.x * 64 + threadIdx.x;
-    const int nchp = g.nchp;
-    const int n = LDI(I_SYMQ_N);
-    if (n == 0) return;
-    double marg_sum = LDF(S_MARG_SUM), pm_sum = LDF(S_PM_SUM), msema_sum = LDF(S_MSEMA_SUM), mse = LDF(S_MSE);
-    const double thresh = LDF(S_THRESH);
-    int marg_pos = LDI(I_MARG_POS);
-    int soft_cnt = LDI(I_SOFT_CNT), sym_cnt = LDI(I_SYM_CNT), overflow = LDI(I_OVERFLOW);
-    const double marg_len_d = (double)g.marg_len, pm_len_d = (double)g.pm_len, msema_len_d = (double)g.msema_len;
-    const double r_marg_len = 1.0 / marg_len_d, r_pm_len = 1.0 / pm_len_d, r_msema_len = 1.0 / msema_len_d;
-    double *__restrict__ symrec = p.symrec + (size_t)ch * JD_SYMREC_LEN * 8;
-    const double *__restrict__ symq = p.symq + (size_t)ch * g.symq_cap * 4;
-
-    double pd_ec[OUT_PD], pd_re[OUT_PD], pd_im[OUT_PD], px_marg[OUT_PD], px_pm[OUT_PD], px_ms[OUT_PD];
-    double2 px_dt[OUT_PD];
-    // positions: symbol k of this launch sits at ring position (pos0 + k) mod 800
-    const int pos0 = marg_pos;
-    auto ring_at = [&](int k) { int q = pos0 + k; while (q >= JD_SYMREC_LEN) q -= JD_SYMREC_LEN; return q; };
-    auto request = [&](int slot, int k) __attribute__((always_inline)) {
-        if (k < n)
-        {
-            const double2 *q = (const double2 *)(symq + (size_t)k * 4);
-            const double2 q0 = q[0], q1 = q[1];
-            pd_ec[slot] = q0.x; pd_re[slot] = q0.y; pd_im[slot] = q1.x;
-            const int mp = ring_at(k);
-            px_marg[slot] = symrec[mp * 8]; // written 800 symbols ago
-            int o = mp + JD_SYMREC_LEN / 2; if (o >= JD_SYMREC_LEN) o -= JD_SYMREC_LEN;
-            const double2 *r = (const double2 *)(symrec + o * 8); // written 400 symbols ago: {ct_ec, q_re}, {q_im, |q|}, {e, -}
-            const double2 r0 = r[0], r1 = r[1], r2 = r[2];
-            px_dt[slot] = make_double2(r0.y, r1.x); // = what dt.update returns
-            px_pm[slot] = r1.y;
-            px_ms[slot] = r2.x;
-        }
-    };
-#pragma unroll
-    for (int j = 0; j < OUT_PD; j++) request(j, j);
-    for (int k0 = 0; k0 < n; k0 += OUT_PD)
-    {
-#pragma unroll
-        for (int j = 0; j < OUT_PD; j++)
-        {
-            const int k = k0 + j;
-            if (k < n)
-            {
-                const double ct_ec = pd_ec[j];
-                double q_re = pd_re[j], q_im = pd_im[j];
-                // marg->UpdateSigned(ct_ec)
-                marg_sum = marg_sum - px_marg[j]; marg_sum = marg_sum + ct_ec;
-                const double marg_val = jd_div_const(marg_sum, marg_len_d, r_marg_len);
-                // dt.update(pt_qpsk)
-                const double in_re = q_re, in_im = q_im;
-                q_re = px_dt[j].x; q_im = px_dt[j].y;
-                {
-                    double sr, cr;
-                    sincos(marg_val, &sr, &cr); // the same two values as cos() and sin() (one argument reduction, the same kernels)
-                    const double nr = q_re * cr - q_im * sr;
-                    const double ni = q_re * sr + q_im * cr;
-                    q_re = nr; q_im = ni;
-                }
-                // MSEcalc::Update (DSP.cpp:451-463)
-                double av_w, e_w;
-                {
-                    const double av = jd_hypot(q_re, q_im);
-                    pm_sum = pm_sum - px_pm[j]; pm_sum = pm_sum + fabs(av); av_w = fabs(av);
-                    double mu = jd_div_const(pm_sum, pm_len_d, r_pm_len);
-                    if (mu < 0.000001) mu = 0.000001;
-                    const double s2 = sqrt(2.0);
-                    const double t_re = (s2 * q_re) / mu, t_im = (s2 * q_im) / mu;
-                    const double tda = (fabs(t_re) - 1.0), tdb = (fabs(t_im) - 1.0);
-                    const double e = (tda * tda) + (tdb * tdb);
-                    msema_sum = msema_sum - px_ms[j]; msema_sum = msema_sum + fabs(e); e_w = fabs(e);
-                    mse = jd_div_const(msema_sum, msema_len_d, r_msema_len);
-                }
-                // this symbol's record: one complete 64-byte sector
-                {
-                    double2 *w = (double2 *)(symrec + marg_pos * 8);
-                    w[0] = make_double2(ct_ec, in_re);
-                    w[1] = make_double2(in_im, av_w);
-                    w[2] = make_double2(e_w, 0.0);
-                    w[3] = make_double2(0.0, 0.0);
-                    marg_pos++; if (marg_pos >= JD_SYMREC_LEN) marg_pos = 0;
-                }
-                if (CAPSYM)
-                {
-                    if (sym_cnt < g.sym_cap)
-                    {
-                        double *sp = p.sym + ((size_t)ch * g.sym_cap + sym_cnt) * 3;
-                        sp[0] = q_re; sp[1] = q_im; sp[2] = mse;
-                        sym_cnt++;
-                    }
-                    else overflow |= 2;
-                }
-                if (mse < thresh)
-                {
-                    const int b0 = jd_softbit(0.75 * q_im * 127.0 + 128.0);
-                    const int b1 = jd_softbit(0.75 * q_re * 127.0 + 128.0);
-                    if (soft_cnt + 2 <= g.soft_cap)
-                    {
-                        int16_t *sp = p.soft + (size_t)ch * g.soft_cap + soft_cnt;
-                        sp[0] = (int16_t)b0;
-                        sp[1] = (int16_t)b1;
-                        soft_cnt += 2;
-                    }
-                    else overflow |= 1;
-                }
-            }
-            request(j, k + OUT_PD);
-        }
-    }
     LDF(S_MARG_SUM) = marg_sum; LDF(S_PM_SUM) = pm_sum; LDF(S_MSEMA_SUM) = msema_sum; LDF(S_MSE) = mse;
-    LDI(I_MARG_POS) = marg_pos;
+    LDI(I_MARG_POS) = marg_pos; LDI(I_DT_POS) = dt_pos; LDI(I_PM_POS) = pm_pos; LDI(I_MSEMA_POS) = msema_pos;
+    LDI(I_YUI) = yui; LDI(I_SIG2L_INIT) = sig2l_init;
     LDI(I_SOFT_CNT) = soft_cnt; LDI(I_SYM_CNT) = sym_cnt; LDI(I_OVERFLOW) = overflow;
-    LDI(I_SYMQ_N) = 0;
+    if constexpr (PRE8400) LDF(S_PRE_FSUM) = LDF(S_PRE_FSUM) + m2fsum;
 }
 
 // PAIRS front/back pairs per workgroup: waves 0..PAIRS-1 are the front halves of channel groups blockIdx.x*PAIRS + w, waves

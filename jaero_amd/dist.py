@@ -71,6 +71,12 @@ def ranks_share_a_device() -> bool:
     if n == 0:
         return False
     lws = local_world_size()
+    # one visible device per task under a per-task binding (srun --gpus-per-task=1 / --gpu-bind, or a launcher that sets ROCR_/HIP_VISIBLE_DEVICES per
+    # rank): every rank owns the one GPU it sees, although the node runs several tasks.  The variables are the launcher's, the same on
+    # every rank of the job, so the answer still is.
+    if n == 1 and (os.environ.get("SLURM_GPUS_PER_TASK") == "1" or os.environ.get("SLURM_TRES_PER_TASK", "").replace("gres/", "").startswith("gpu:1")
+                   or os.environ.get("JAERO_ONE_GPU_PER_RANK") == "1"):
+        return False
     if lws is not None:
         return lws > n
     return int(os.environ.get("WORLD_SIZE", "1")) > n

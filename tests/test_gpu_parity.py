@@ -324,6 +324,30 @@ def test_silence_and_full_scale(B, oracle_mod):
     bank.close()
 
 
+@pytest.mark.parametrize("kind", ["oqpsk", "msk"])
+def test_ragged_bank_with_silent_lanes(B, oracle_mod, kind):
+    """jd_atan2 (jd_libm.h) looks its table up with ds_bpermute, i.e. in OTHER lanes' registers: a lane that leaves the straight-line path must not
+    disturb its neighbours.  Digital silence puts a lane on the function's `special` path (atan2(0, 0)) in every sample; here two lanes
+    of a ragged 67-channel bank are silent -- one in the middle of the first wavefront, one next to the padding lanes of the second -- one changes
+    from signal to silence half way, and every neighbour must still equal its own oracle run."""
+    from jaero_amd import signalgen as G
+
+    O = oracle_mod
+    nch, nsamp, chunk = 67, 36000, 3000
+    pcm, _, _ = G.channel_bank(kind, nch, nsamp, ebno_db=11.0, seed0=G.SEED_BASE + 4200)
+    pcm[5] = 0
+    pcm[66] = 0
+    pcm[30, nsamp // 2:] = 0
+    opts = {} if kind == "oqpsk" else {"fb": 1200.0, "lockingbw": 1800.0}
+    bank = B.DemodulatorBank([bank_settings(kind, opts) for _ in range(nch)], ebno=True, status_log=True, capture_symbols=True,
+                             max_write_samples=chunk, softbit_capacity=nsamp)
+    feed(bank, pcm, chunk)
+    for c in (4, 5, 6, 29, 30, 31, 63, 64, 65, 66):
+        ref = O.run_demod(oracle_settings(O, kind, opts), pcm[c], chunk=chunk, capture_symbols=True)
+        compare(bank.read_softbits(c), bank.read_symbols(c), bank.read_status_log(c), ref, check_ebno=c not in (5, 30, 66))
+    bank.close()
+
+
 def test_per_channel_settings_and_live_set_settings(B, oracle_mod):
     """freq_center / lockingbw / threshold are per channel; a live setSettings retunes one channel only."""
     from jaero_amd import signalgen as G
