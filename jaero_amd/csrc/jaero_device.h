@@ -510,7 +510,7 @@ __device__ __forceinline__ double jd_tanh(double xin)
     const double R1 = one + hxs * Q1, h2 = hxs * hxs, R2 = Q2 + hxs * Q3, h4 = h2 * h2, R3 = Q4 + hxs * Q5;
     const double r1 = R1 + h2 * R2 + h4 * R3;
     const double t3 = 3.0 - r1 * hfx;
-    const double e = hxs * ((r1 - t3) / (6.0 - x * t3));
+    const double e = hxs * jd_div(r1 - t3, 6.0 - x * t3);
     const double r_k0 = x - (x * e - hxs);
     double e2 = (x * (e - c) - c);
     e2 -= hxs;
@@ -522,7 +522,7 @@ __device__ __forceinline__ double jd_tanh(double xin)
     double ym = tm - (e2 - x);
     ym = jd_with_hi(ym, __double2hiint(ym) + (k << 20));
     const double t = (k == 0) ? r_k0 : (k == -1) ? r_m1 : (k <= -2) ? r_neg : ym;
-    const double q = (big ? two : t) / (t + two);
+    const double q = jd_div(big ? two : t, t + two);
     const double z = big ? one - q : -q;
     return (jx >= 0) ? z : -z;
 }

@@ -128,6 +128,27 @@ JDA_FN double jd_atan2_t(double y, double x, const JDA_TBL &T)
 
 JDA_FN double jd_atan2(double y, double x, const JdAtanLane &T) { return jd_atan2_t(y, x, T); }
 
+// ---- division ----------------------------------------------------------------------------------------------------------------------
+// a / b for the sample loops' variable divisors (round 6).  The compiler expands an fp64 division into
+//   v_div_scale x 2, v_rcp_f64, two Newton steps on the reciprocal (4 fma), q = a r, e = fma(-b, q, a), v_div_fmas (= fma(e, r, q) plus the
+//   scaling), v_div_fixup            -- 11 instructions, the IEEE quotient.
+// v_div_scale multiplies by a power of two only when an exponent is extreme and v_div_fixup only repairs zeros, infinities, NaN and denormals;
+// for finite operands with 2^-500 <= |b| <= 2^500 and a = 0 or 2^-500 <= |a| <= 2^500 neither does anything, and the remaining EIGHT
+// instructions below are the same operations on the same values: the same bits as a / b (a zero quotient comes out as +0 where IEEE gives -0
+// for a = -0; every call site takes the magnitude of the quotient or subtracts it from a non-zero value).  Three instructions and two links of
+// the dependency chain less per division: jd_tanh has two of them on the carrier loop's critical path in every sample.
+// Checked on the device against `/`: scripts/ubench/div_check.hip, 2^33 operand pairs incl. quotients next to a rounding boundary and the
+// operands of each call site's kind: no difference.  Call sites (each with |b| far inside the range): jd_tanh (b = t + 2 in [1, 4.5e5] and
+// b = 6 - x t3 in [2, 6.1]), jd_hypot (b = 2 h, only taken for 2^-200 < h < 2^200), the AGC gain (b >= 1e-6), MSEcalc (mu >= 1e-6).
+JDA_FN double jd_div(double a, double b)
+{
+    double r = JDA_RCP(b);
+    r = JDA_FMA(JDA_FMA(-b, r, 1.0), r, r);
+    r = JDA_FMA(JDA_FMA(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return JDA_FMA(JDA_FMA(-b, q, a), r, q);
+}
+
 // ---- hypot -----------------------------------------------------------------------------------------------------------------------
 // glibc 2.35 sysdeps/ieee754/dbl-64/e_hypot.c, the branch without a fast fma (the x86-64 baseline build), operation for operation:
 // h = sqrt(ax ax + ay ay), then ONE correction step h -= (t1 + t2) / (2 h) whose t1, t2 depend on which side of 2 ay the first h fell.
@@ -147,7 +168,10 @@ JDA_FN double jd_hypot(double x, double y)
     const double t1n = ax * (2.0 * delta - ax), t2n = (delta - 2.0 * (ax - ay)) * delta;
     const double t1f = 2.0 * delta * (ax - 2.0 * ay), t2f = (4.0 * delta - ay) * ay + delta * delta;
     const double t1 = near ? t1n : t1f, t2 = near ? t2n : t2f;
-    double res = h - (t1 + t2) / (2.0 * h);
+    // (jd_div's operand range: h between 2^-200 and 2^200, i.e. everything but pathological inputs, which keep the library's division)
+    const bool mid = h > 0x1p-200 && h < 0x1p+200;
+    double res = h - jd_div(t1 + t2, 2.0 * h);
+    if (!mid) res = h - (t1 + t2) / (2.0 * h);
     if (far) res = ax + ay;
     if (!unscaled) res = JDA_LIB_HYPOT(x, y);
     return res;

@@ -209,11 +209,11 @@ __device__ __forceinline__ void mfb_front(const JGeom &g, const JPtrs &p, const 
             *ap = fabs(dabval); // the one store: the EbNo meter above pushed the same value
             agc_pos++; if (agc_pos >= g.win_len) agc_pos = 0;
         }
-        double gain = 1.414213562 / fmax(agc_sum / agc_len_d, 0.000001);
+        double gain = jd_div(1.414213562, fmax(agc_sum / agc_len_d, 0.000001));
         gain = fmax(gain, 0.000001);
         sre *= gain; sim *= gain;
         const double abval = sqrt(sre * sre + sim * sim);
-        if (abval > 2.84) { const double k = (2.84 / abval); sre = k * sre; sim = k * sim; }
+        if (abval > 2.84) { const double k = jd_div(2.84, abval); sre = k * sre; sim = k * sim; }
         double *d = L.data + buf * 2 * 64 + lane;
         d[0] = sre; d[64] = sim;
     };

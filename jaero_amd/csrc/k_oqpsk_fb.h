@@ -243,11 +243,11 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &
             *ap = fabs(dabval); // the one store: the EbNo meter above pushed the same value
             agc_pos++; if (agc_pos >= g.win_len) agc_pos = 0;
         }
-        double gain = 1.414213562 / fmax(jd_div_const(agc_sum, agc_len_d, r_agc_len), 0.000001);
+        double gain = jd_div(1.414213562, fmax(jd_div_const(agc_sum, agc_len_d, r_agc_len), 0.000001)); // (jd_libm.h: the quotient's bits with 8 instructions for 11)
         gain = fmax(gain, 0.000001);
         sre *= gain; sim *= gain;
         const double abval = jd_hypot(sre, sim);
-        if (abval > 2.84) { const double k = (2.84 / abval); sre = k * sre; sim = k * sim; }
+        if (abval > 2.84) { const double k = jd_div(2.84, abval); sre = k * sre; sim = k * sim; }
         double *d = L.data + buf * 3 * 64 + lane;
         d[0] = sre; d[64] = sim; d[128] = abval;
     };
@@ -488,7 +488,7 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, FbLds &L
             double mu = jd_div_const(pm_sum, pm_len_d, r_pm_len);
             if (mu < 0.000001) mu = 0.000001;
             const double s2 = sqrt(2.0);
-            const double t_re = (s2 * q_re) / mu, t_im = (s2 * q_im) / mu;
+            const double t_re = jd_div(s2 * q_re, mu), t_im = jd_div(s2 * q_im, mu);
             const double tda = (fabs(t_re) - 1.0), tdb = (fabs(t_im) - 1.0);
             const double e = (tda * tda) + (tdb * tdb);
             msema_sum = msema_sum - px_ms; msema_sum = msema_sum + fabs(e); e_w = fabs(e);

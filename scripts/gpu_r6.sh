@@ -25,7 +25,22 @@ if has wltime; then
     echo "$wl wall ${SECONDS}s $(cut -c1-160 "$OUT/wl_line_$wl.json")" | tee -a "$OUT/wltime.txt"
   done
 fi
-if has newtests; then timeout 900 python -m pytest tests/test_burst_recording.py -m gpu -q --tb=short 2>&1 | tail -15 | tee "$OUT/pytest_new.log"; fi
+if has divcheck; then ( ./scripts/ubench/div_check 4096 | tee "$OUT/div_check.json" ); fi
+if has boxrow; then
+  # one row of profiles/r6_box_table.md: the driver's command on this (fresh) box, headline against calibration and device state
+  ( timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 2> "$OUT/boxrow.err" | tail -1 ) > "$OUT/boxrow_line.json"
+  python - "$OUT/boxrow_line.json" <<'PY' | tee "$OUT/boxrow.json"
+import json, sys
+d = json.load(open(sys.argv[1])); c = d["config"]; g = d.get("gpu_state", {}); k = d.get("calib", {})
+ow = c.get("other_workloads", {})
+print(json.dumps({"value": d["value"], "ms_per_step": d["ms_per_step"], "step_ms": d.get("step_ms"), "kernel_ms_per_step": c["kernel_ms_per_step"], "frac": d["roofline"]["frac"],
+                  "frac_of_calib_hbm": d["roofline"].get("frac_of_calib_hbm"), "calib": {x: k.get(x) for x in ("fp64_tflops", "hbm_gbs")}, "calib_cold": k.get("cold"),
+                  "gpu_state": {x: g.get(x) for x in ("sclk_mhz_mean", "sclk_mhz_min", "power_w_mean", "power_w_max", "power_cap_w", "temp_hotspot_c_max", "throttle_residency", "throttled", "value_per_watt")},
+                  "sustain": g.get("sustain"), "other": {n: [v.get("value"), v.get("sclk_mhz"), v.get("power_w")] for n, v in ow.items() if isinstance(v, dict)},
+                  "cpu_baseline": (d.get("cpu_baseline") or {}).get("value")}))
+PY
+fi
+if has newtests; then timeout 900 python -m pytest tests/test_burst_recording.py tests/test_gpu_parity.py -k "recording or silent_lanes" -m gpu -q --tb=short 2>&1 | tail -15 | tee "$OUT/pytest_new.log"; fi
 if has sqaerol; then
   # VALU instruction counts of the Aero-L workloads (their roofline block is priced against VALU issue): STEPS_TOTAL = warm-up + timed (+ 4 re-written steps in aerol_burst)
   for wl in aerol aerol_burst aerol_c; do
