@@ -55,6 +55,19 @@ __device__ __forceinline__ void bd_cmul(double &ar, double &ai, double br, doubl
 }
 
 template <bool CAPSYM>
+// Arithmetic policy of this kernel: fused matched filter + the device library's hypot / atan2.  The A/B build
+// (make -C jaero_amd/csrc ab_burst -> gpurun_tmp/libjaero_hip_burstexact.so, -DJD_BURST_EXACT) takes the continuous kernels' arithmetic instead --
+// filter op for op, glibc's hypot, correctly rounded atan2 -- so that scripts/burst_recording_ab.py can count on the reference's own off-air
+// recording what the choice moves (round 6: profiles/r6_burst_recording_ab.json).
+#ifdef JD_BURST_EXACT
+#define BD_FUSED false
+#define BD_HYPOT(x, y) jd_hypot(x, y)
+#define BD_ATAN2(y, x) jd_atan2(y, x, bd_atl)
+#else
+#define BD_FUSED true
+#define BD_HYPOT(x, y) hypot(x, y)
+#define BD_ATAN2(y, x) atan2(y, x)
+#endif
 __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const BPtrs p, int n, long long n0, int first_of_write)
 {
     // matched-filter history as in k_oqpsk.h: the LDSN newest entries of each arm in LDS ([slot][lane]), the FIRN-LDSN oldest in a
@@ -67,6 +80,9 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
     const double2 *__restrict__ cis = p.cis;
     const double *__restrict__ taps = p.taps2; // this bank's own taps, read once into LDS
     const double SPS = g.SPS, samplerate = g.Fs;
+#ifdef JD_BURST_EXACT
+    const JdAtanLane bd_atl = jd_atan_lane_table(lane);
+#endif
 
     double m2_ptr = BLDF(BS_M2_PTR), m2_step = BLDF(BS_M2_STEP), m2_freq = BLDF(BS_M2_FREQ);
     double st_ptr = BLDF(BS_ST_PTR), st_step = BLDF(BS_ST_STEP), st_freq = BLDF(BS_ST_FREQ), st_last = BLDF(BS_ST_LAST);
@@ -172,7 +188,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
         double sre = 0, sim = 0;
         {
             // output from x[n-FIRN .. n-1] (FIR::FIRUpdateAndProcess excludes the sample being pushed): taps[i] <-> x[n-FIRN+i]
-            jd_fir_eval<FIRN, LDSN, 8, true>(lre, lim, ltap, tre, tim, fir_slot, lane, sre, sim);
+            jd_fir_eval<FIRN, LDSN, 8, BD_FUSED>(lre, lim, ltap, tre, tim, fir_slot, lane, sre, sim);
             // push x[n]: the oldest LDS entry moves into the register tail
 #pragma unroll
             for (int j = TAILN - 1; j > 0; j--) { tre[j] = tre[j - 1]; tim[j] = tim[j - 1]; }
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
             t_im = a1out;
             const double2 cq = cis[jd_cisidx(stq_ptr)];
             const double e_re = cq.x * t_re - cq.y * (-t_im), e_im = cq.x * (-t_im) + cq.y * t_re;
-            double st_err = atan2(e_im, e_re);
+            double st_err = BD_ATAN2(e_im, e_re);
             st_err *= 1.5 * (1.0 - progress * progress);
             jd_wt_advance_fraction(stq_ptr, -(1.0 / (2.0 * M_PI)) * st_err * 0.1);
             bd_set_phase_deg(st_ptr, jd_div_const(360.0 * stq_ptr, wtsize_d, r_wtsize) * 4.0 + (360.0 * g.ee));
@@ -220,7 +236,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
         bd_cmul(sre, sim, sav_re, sav_im);
         bd_cmul(rot_re, rot_im, rfc, rfs);
         bd_cmul(sre, sim, rot_re, rot_im);
-        const double sig2abs = hypot(sre, sim);
+        const double sig2abs = BD_HYPOT(sre, sim);
         {
             const double sq = sig2abs * sig2abs;
             double *ep = ebe_ring + (size_t)s_eb * 64;
@@ -254,7 +270,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
             gain = fmax(gain, 0.000001);
             sre *= gain; sim *= gain;
         }
-        const double abval = hypot(sre, sim);
+        const double abval = BD_HYPOT(sre, sim);
         if (abval > 2.84) { const double k = (2.84 / abval); sre = k * sre; sim = k * sim; }
 
         // ---- symbol timer (:592-612) ----
@@ -276,7 +292,7 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
             if (st_ptr != st_ptr_top) so = cis[jd_cisidx(st_ptr)];
             const double m_re = st_eta, m_im = -d8out;
             const double o_re = so.x * m_re - so.y * m_im, o_im = so.x * m_im + so.y * m_re;
-            const double st_angle_error = atan2(o_im, o_re);
+            const double st_angle_error = BD_ATAN2(o_im, o_re);
             if (cntr > SPS * (128 + 64))
             {
                 fb_wt_setfreq(st_freq, st_step, (-st_angle_error * 0.00000001) + st_freq, samplerate, r_samplerate);

@@ -25,6 +25,30 @@ if has wltime; then
     echo "$wl wall ${SECONDS}s $(cut -c1-160 "$OUT/wl_line_$wl.json")" | tee -a "$OUT/wltime.txt"
   done
 fi
+if has burstab; then
+  # the whole burst recording (staged by scripts/burst_recording_ab.py stage) through the product and through the A/B build of the burst OQPSK kernel
+  ( timeout 900 python scripts/burst_recording_ab.py gpu 2> "$OUT/burst_rec_product.err" | tail -1 ) > "$OUT/burst_recording_gpu_product.json"; cut -c1-500 "$OUT/burst_recording_gpu_product.json"; echo
+  ( JAERO_HIP_LIB=$R/gpurun_tmp/libjaero_hip_burstexact.so timeout 900 python scripts/burst_recording_ab.py gpu 2> "$OUT/burst_rec_exact.err" | tail -1 ) > "$OUT/burst_recording_gpu_exact.json"; cut -c1-500 "$OUT/burst_recording_gpu_exact.json"; echo
+  python - "$OUT" <<'PY'
+import json, sys
+for n in ("product", "exact"):
+    try:
+        d = json.load(open(f"{sys.argv[1]}/burst_recording_gpu_{n}.json")); print(n, d["lib"], d["total"])
+    except Exception as e: print(n, "failed", e)
+PY
+  # what the exact arithmetic costs on the burst workload
+  for v in product exact; do
+    L=$R/jaero_amd/libjaero_hip.so; [ $v = exact ] && L=$R/gpurun_tmp/libjaero_hip_burstexact.so
+    ( JAERO_HIP_LIB=$L timeout 600 python bench.py --workload burst_oqpsk --steps 12 --warmup 2 --no-cpu-baseline --as-written 0 --check-channels 0 2> "$OUT/bench_burst_$v.err" | tail -1 ) > "$OUT/bench_line_burst_$v.json"
+    python -c "import json;d=json.load(open('$OUT/bench_line_burst_$v.json'));print('$v',d['value'],d['ms_per_step'],d['config'].get('kernel_ms_total'))"
+  done
+fi
+if has trace600; then
+  # phase trace of the 600 bps MSK pair kernel (make -C jaero_amd/csrc trace): where does a sample's 4 us go?
+  for args in "--fb 600 --channels 65536" "--fb 600 --channels 32768" "--fb 1200 --channels 65536"; do
+    ( JAERO_HIP_LIB=$R/gpurun_tmp/libjaero_hip_trace.so timeout 600 python bench.py --workload msk $args --steps 12 --warmup 4 --no-cpu-baseline --as-written 0 --check-channels 0 --no-state 2> "$OUT/trace_msk.err" | tail -1 | cut -c1-200 ) ; grep fb_trace "$OUT/trace_msk.err" | tail -1 | tee -a "$OUT/trace_msk.jsonl"
+  done
+fi
 if has divcheck; then ( ./scripts/ubench/div_check 4096 | tee "$OUT/div_check.json" ); fi
 if has boxrow; then
   # one row of profiles/r6_box_table.md: the driver's command on this (fresh) box, headline against calibration and device state
