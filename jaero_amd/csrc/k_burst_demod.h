@@ -54,7 +54,6 @@ __device__ __forceinline__ void bd_cmul(double &ar, double &ai, double br, doubl
     ar = r; ai = i;
 }
 
-template <bool CAPSYM>
 // Arithmetic policy of this kernel: fused matched filter + the device library's hypot / atan2.  The A/B build
 // (make -C jaero_amd/csrc ab_burst -> gpurun_tmp/libjaero_hip_burstexact.so, -DJD_BURST_EXACT) takes the continuous kernels' arithmetic instead --
 // filter op for op, glibc's hypot, correctly rounded atan2 -- so that scripts/burst_recording_ab.py can count on the reference's own off-air
@@ -68,6 +67,7 @@ template <bool CAPSYM>
 #define BD_HYPOT(x, y) hypot(x, y)
 #define BD_ATAN2(y, x) atan2(y, x)
 #endif
+template <bool CAPSYM>
 __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const BPtrs p, int n, long long n0, int first_of_write)
 {
     // matched-filter history as in k_oqpsk.h: the LDSN newest entries of each arm in LDS ([slot][lane]), the FIRN-LDSN oldest in a

@@ -100,6 +100,50 @@ __device__ __forceinline__ void mfb_fir_continue(const double *lre, const double
     ore = are; oim = aim;
 }
 
+// mfb_fir_continue without per-term address arithmetic (round 6).  A wavefront that is alone on its SIMD issues at most one instruction of ANY kind
+// per four cycles, so the sample loops are bound by their instruction COUNT, scalar bookkeeping included (profiles/r6_msk600_trace.md): as written
+// above a term of the LDS part costs ~15 instructions, six of them useful (2 mul, 2 add, one ds_read2st64_b64 for both arms, one tap read) -- the rest
+// forms the ring address (fir_slot + k) mod LDSN (five scalar and two vector instructions) and moves the tap's constant address into a register.
+// Here the ring is seen as NB = LDSN / BS blocks of BS slots and fir_slot = a BS + BV: entry k of the LDS part lies in block ((a + m) mod NB) at slot
+// r of it, m = (BV + k) / BS and r = (BV + k) % BS -- both compile-time constants once BV is (a switch over the BS values of BV picks the version, as
+// k_oqpsk_fb's filter does over all its 36 ring positions).  The NB + 1 block addresses (per lane) are formed once per sample; every read is then
+// `base register + immediate offset`, and so are the tap reads (tapz: a zero the compiler cannot see through).  Same terms, same order, same sums.
+template <int LDSN> constexpr int mfb_bs() { return (LDSN % 8 == 0) ? 8 : 4; }
+template <int FIRN, int LDSN, int D, int T0, int BV, int TAILA, int NBA>
+__device__ __forceinline__ void mfb_fir_continue_v(const double *lre, const double *ltap, const double (&tre)[TAILA], const double (&tim)[TAILA],
+                                                   const int (&blk)[NBA], int tapz, double are0, double aim0, double &ore, double &oim)
+{
+    constexpr int NT = FIRN - T0, TAILN = NT - LDSN, BS = mfb_bs<LDSN>();
+    static_assert(LDSN % BS == 0 && NBA == LDSN / BS + 1, "ring blocks");
+    double pr[D], pi[D], pt[D];
+    auto fetch = [&](int s, int q) __attribute__((always_inline)) {
+        pt[q] = ltap[tapz + T0 + s];
+        if (s >= TAILN)
+        {
+            const int k = s - TAILN, m = (BV + k) / BS, r = (BV + k) % BS;
+            pr[q] = lre[blk[m] + r * 64];
+            pi[q] = lre[blk[m] + r * 64 + LDSN * 64]; // the other arm's ring follows this one (MfbLds)
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < D; s++) fetch(s, s);
+    __builtin_amdgcn_sched_barrier(0);
+    double are = are0, aim = aim0;
+#pragma unroll
+    for (int s = 0; s < NT; s++)
+    {
+        const int q = s % D;
+        const double xr = (s < TAILN) ? tre[(TAILN - 1 - s) < 0 ? 0 : (TAILN - 1 - s)] : pr[q];
+        const double xi = (s < TAILN) ? tim[(TAILN - 1 - s) < 0 ? 0 : (TAILN - 1 - s)] : pi[q];
+        are = are + pt[q] * xr;
+        aim = aim + pt[q] * xi;
+        asm volatile("" : "+v"(are), "+v"(aim)); // keeps the software pipeline as written (see jd_fir_eval)
+        if (s + D < NT) fetch(s + D, q);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    ore = are; oim = aim;
+}
+
 // ------------------------------------------------------------------------------------------------------------------ front half
 template <int FIRN, int LDSN, bool EBNO, int TB>
 __device__ __forceinline__ void mfb_front(const JGeom &g, const JPtrs &p, const MfbLds &L, const int16_t *__restrict__ pcm, int pcm_stride, int n,
@@ -170,12 +214,37 @@ __device__ __forceinline__ void mfb_front(const JGeom &g, const JPtrs &p, const 
         for (int k = lane; k < FIRN; k += 64) ltap[k] = p.taps2[k];
     }
     int fir_slot = fir_slot0; // wave-uniform: LDS slot holding the oldest LDS entry, overwritten by the next input
+    int tapz;                 // a zero in a vector register: tap reads become `register + immediate offset` (mfb_fir_continue_v)
+    asm volatile("v_mov_b32 %0, 0" : "=v"(tapz));
     // rel = index of the sample (within this launch) whose output is formed: its partial sum from the back half sits in acc[rel & 1]
     auto fir_eval = [&](int rel, double &ore, double &oim) __attribute__((always_inline)) {
         if constexpr (TB > 0)
         {
             const double *a = L.acc + (rel & 1) * 2 * 64 + lane;
-            mfb_fir_continue<FIRN, LDSN, 8, TB>(lre, lim, ltap, tre, tim, fir_slot, lane, a[0], a[64], ore, oim);
+            const double a0 = a[0], a1 = a[64];
+            constexpr int BS = mfb_bs<LDSN>(), NB = LDSN / BS;
+            int blk[NB + 1];
+            const int ab = fir_slot / BS; // wave-uniform
+#pragma unroll
+            for (int m = 0; m <= NB; m++)
+            {
+                int t = ab + m;
+                if (t >= NB) t -= NB;
+                if (t >= NB) t -= NB;
+                blk[m] = t * BS * 64 + lane;
+            }
+#define MFB_V(B) case B: mfb_fir_continue_v<FIRN, LDSN, 8, TB, B>(lre, ltap, tre, tim, blk, tapz, a0, a1, ore, oim); break;
+            switch (fir_slot % BS)
+            {
+                MFB_V(0) MFB_V(1) MFB_V(2) MFB_V(3)
+            default:
+                if constexpr (BS == 8)
+                {
+                    switch (fir_slot % BS) { MFB_V(4) MFB_V(5) MFB_V(6) MFB_V(7) default: break; }
+                }
+                break;
+            }
+#undef MFB_V
         }
         else jd_fir_eval<FIRN, LDSN, 8>(lre, lim, ltap, tre, tim, fir_slot, lane, ore, oim);
     };
@@ -363,12 +432,14 @@ __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const M
 
     auto ring_next = [](int pos, int len) { pos++; return pos >= len ? 0 : pos; };
     // sum over this half's entries, oldest first: taps[t] <-> tb[TB - 1 - t]
+    int tapz; // a zero in a vector register: the tap reads below become `register + immediate offset` instead of a v_mov of a constant address each (mfb_fir_continue_v)
+    asm volatile("v_mov_b32 %0, 0" : "=v"(tapz));
     auto tail_sum = [&](double &ore, double &oim) __attribute__((always_inline)) {
         double are = 0, aim = 0;
 #pragma unroll
         for (int t = 0; t < TB; t++)
         {
-            const double tp = L.ltap[t];
+            const double tp = L.ltap[tapz + t];
             are = are + tp * tbr[TB - 1 - t];
             aim = aim + tp * tbi[TB - 1 - t];
         }

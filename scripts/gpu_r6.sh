@@ -43,6 +43,21 @@ PY
     python -c "import json;d=json.load(open('$OUT/bench_line_burst_$v.json'));print('$v',d['value'],d['ms_per_step'],d['config'].get('kernel_ms_total'))"
   done
 fi
+if has msk600; then
+  timeout 1200 python -m pytest tests -m gpu -q -k "msk or Msk or MSK or golden or flags or family" --tb=short 2>&1 | tail -8 | tee "$OUT/pytest_msk.log"
+  for args in "--fb 600" "--fb 1200"; do
+    ( timeout 600 python bench.py --workload msk $args --steps 12 --warmup 4 --no-cpu-baseline --as-written 0 2> "$OUT/bench_msk.err" | tail -1 ) > "$OUT/bench_line_msk.json"
+    python -c "import json;d=json.load(open('$OUT/bench_line_msk.json'));c=d['config'];print('$args',d['value'],d['ms_per_step'],c['kernel_ms_per_step'],c.get('oracle_check',{}).get('hard_bits_equal'),c.get('oracle_check',{}).get('max_soft_byte_diff'))"
+    cp "$OUT/bench_line_msk.json" "$OUT/bench_line_msk_$(echo $args | tr -d ' -').json"
+  done
+fi
+if has tb600; then
+  for v in product tb52 tb44; do
+    L=$R/jaero_amd/libjaero_hip.so; [ $v != product ] && L=$R/gpurun_tmp/libjaero_hip_$v.so
+    ( JAERO_HIP_LIB=$L timeout 600 python bench.py --workload msk --fb 600 --steps 12 --warmup 4 --no-cpu-baseline --as-written 0 --no-state 2> "$OUT/bench_tb.err" | tail -1 ) > "$OUT/bench_line_msk600_$v.json"
+    python -c "import json;d=json.load(open('$OUT/bench_line_msk600_$v.json'));c=d['config'];print('$v',d['value'],d['ms_per_step'],c['kernel_ms_per_step'],c.get('oracle_check',{}).get('hard_bits_equal'))" | tee -a "$OUT/tb600.txt"
+  done
+fi
 if has trace600; then
   # phase trace of the 600 bps MSK pair kernel (make -C jaero_amd/csrc trace): where does a sample's 4 us go?
   for args in "--fb 600 --channels 65536" "--fb 600 --channels 32768" "--fb 1200 --channels 65536"; do
