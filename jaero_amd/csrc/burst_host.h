@@ -231,8 +231,8 @@ static int burst_create(jaero_ctx *c, const std::vector<jaero_settings> &sets, c
     c->o_nrx = p.I + (size_t)BI_NRX * nchp;
     c->m.nch = nch; c->m.nchp = nchp;
     c->m.flags.assign(nchp, 0);
-    // burst OQPSK: 39 of its 55 history slots + the taps in LDS; burst MSK: 39 of 80 (1200 bps) or all 160 (600 bps) slots
-    const int lds = oq ? (2 * 39 * 64 + 64) * (int)sizeof(double) : 2 * (g.fir_n == 80 ? BMSK_FB_LDSN_80 : BMSK_FB_LDSN_160) * 64 * (int)sizeof(double) + BMSK_FB_MAIL_BYTES + BMSK_FB_WC_BYTES(g.fir_n == 80) + BMSK_FB_D8_BYTES(g.fir_n == 80, g.d8_len);
+    // burst OQPSK: BD_LDSN (36) of its 55 history slots + the taps in LDS; burst MSK: 39 of 80 (1200 bps) or all 160 (600 bps) slots
+    const int lds = oq ? (2 * BD_LDSN * 64 + 64) * (int)sizeof(double) : 2 * (g.fir_n == 80 ? BMSK_FB_LDSN_80 : BMSK_FB_LDSN_160) * 64 * (int)sizeof(double) + BMSK_FB_MAIL_BYTES + BMSK_FB_WC_BYTES(g.fir_n == 80) + BMSK_FB_D8_BYTES(g.fir_n == 80, g.d8_len);
     if (oq)
     {
         HIPCHK(hipFuncSetAttribute((const void *)k_burst_oqpsk_demod<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));

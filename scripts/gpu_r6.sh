@@ -51,6 +51,12 @@ if has msk600; then
     cp "$OUT/bench_line_msk.json" "$OUT/bench_line_msk_$(echo $args | tr -d ' -').json"
   done
 fi
+if has burstsplit; then
+  timeout 1200 python -m pytest tests -m gpu -q -k "burst or Burst or qt or recording" --tb=short 2>&1 | tail -12 | tee "$OUT/pytest_burst.log"
+  ( timeout 600 python bench.py --workload burst_oqpsk --steps 12 --warmup 2 --no-cpu-baseline --as-written 0 2> "$OUT/bench_burst.err" | tail -1 ) > "$OUT/bench_line_burst_oqpsk.json"
+  python -c "import json;d=json.load(open('$OUT/bench_line_burst_oqpsk.json'));c=d['config'];print('burst_oqpsk',d['value'],d['ms_per_step'],c.get('kernel_ms_total'),c.get('oracle_check'))"
+  ( timeout 600 python scripts/burst_recording_ab.py gpu 2> "$OUT/burst_rec.err" | tail -1 ) > "$OUT/burst_recording_gpu.json"; python -c "import json;d=json.load(open('$OUT/burst_recording_gpu.json'));print(d['total'])"
+fi
 if has tb600; then
   for v in product tb52 tb44; do
     L=$R/jaero_amd/libjaero_hip.so; [ $v != product ] && L=$R/gpurun_tmp/libjaero_hip_$v.so

@@ -1,135 +1,113 @@
-// k_burst_demod.h -- consumer side of the burst demodulators: the tracking chains, one channel per lane.
-//   k_burst_oqpsk_demod : JAERO/burstoqpskdemodulator.cpp:488-515 (trident result applied), :517-733
-//   (burst MSK: k_burst_msk_fb.h)
-// Input is val_to_demod = real(cv[n - D1 - D2]) from the ring k_burst_front filled; the trident verdict for the event sample of
-// this segment (if any) was computed by k_trident between the two launches.
+// k_burst_oqpsk_fb.h -- the burst OQPSK tracking chain (BurstOqpskDemodulator::writeDataSlot, JAERO/burstoqpskdemodulator.cpp:488-733) as a front / back
+// wavefront pair (round 6).
+//
+// Why a split pays here although round 3 priced it at 10 %: that estimate took the kernel for a latency-bound recurrence and compiled the matched filter
+// out.  The listing says otherwise (profiles/r6_burst_split.md): the single-wavefront kernel k_burst_oqpsk_demod executed ~3 000 instructions per sample
+// of which 960 were fp64 arithmetic -- 256 re-materialised constants, 228 moves to and from accumulation registers (it held 256 + 248 registers), 107
+// scalar-register spills, 280 exec-mask instructions, 180 instructions of ring addressing for the filter -- and a wavefront that is alone on its SIMD
+// issues at most one instruction of any kind per four cycles: 5.8 us per sample.  Two wavefronts share the instruction count, and each keeps its
+// working set in 256 registers.
+//
+//   F ("front"):  val_to_demod from the ring k_burst_front filled, the trident verdict's carrier frequency / phase / volume, mix with mixer2, the
+//                 55-tap RRC (history in LDS + registers, the 28 distinct taps as scalar operands, no address arithmetic: k_oqpsk_fb's filter), mixer2's
+//                 oscillator.  NOTHING of it depends on the back half (in the burst demodulator the carrier is tracked by a rotator BEHIND the filter,
+//                 mixer2 only changes at a trident verdict), so the front half needs no mailbox from the back half at all.
+//   B ("back"):   everything behind the filter: burst timing, the preamble's symbol tone, carrier rotator, EbNo meter, AGC, symbol timer, sample
+//                 instants, soft bits, emissions.  The chain of k_burst_oqpsk_demod minus the filter.
+// One LDS-only barrier per sample (fb_barrier), F one sample ahead, {sre, sim} through a double-buffered mailbox.
+// Arithmetic: the front half's filter is the continuous kernels' (one multiplication and one addition per tap, each rounded, as the reference's
+// build executes it) -- the front half has the time; the back half keeps the device library's hypot / atan2 (on the reference's
+// own off-air recording neither choice moves a soft byte or a soft symbol beyond 1e-9, profiles/r6_burst_recording_ab.json).
 #pragma once
-#include "burst_device.h"
-#include "jaero_device.h"
-#include "k_burst_front.h"
-#include "k_oqpsk_fb.h" // jd_div_const, fb_wt_setfreq, fb_fmod360: exact rewrites (bit-identical results, fewer instructions)
+#include "k_burst_demod.h"
 
-__device__ __forceinline__ void bd_set_phase_deg(double &ptr, double phase_deg) // WaveTable::SetPhaseDeg (DSP.cpp:175-180)
-{
-    phase_deg = fb_fmod360(phase_deg);
-    while (phase_deg < 0) phase_deg += 360.0;
-    ptr = jd_div_const(phase_deg, 360.0, 1.0 / 360.0) * ((double)JD_WTSIZE);
-}
-__device__ __forceinline__ void bd_event(const BGeom &g, const BPtrs &p, int ch, int &ev_cnt, int &overflow, long long sample, int kind, double value)
-{
-    if (ev_cnt < g.ev_cap)
-    {
-        double *e = p.evlog + ((size_t)ch * g.ev_cap + ev_cnt) * 3;
-        e[0] = (double)sample; e[1] = (double)kind; e[2] = value;
-        ev_cnt++;
-    }
-    else overflow |= 4;
-}
-// BurstMskDemodulator::CenterFreqChangedSlot (JAERO/burstmskdemodulator.cpp:327-342; wired to the spectrum display, mainwindow.cpp:415)
-// for channels [ch_lo, ch_lo + n): the same lines k_burst_msk_demod runs when a trident verdict retunes it, plus the slot's Plottables
-// emission, stamped with the first sample of the write that follows.
-__global__ void k_burst_msk_center_freq(const BGeom g, const BPtrs p, int ch_lo, int n, double freq_center, long long sample)
-{
-    const int k = blockIdx.x * blockDim.x + threadIdx.x, nchp = g.nchp;
-    if (k >= n) return;
-    const int ch = ch_lo + k;
-    double m2_freq = BLDF(BS_M2_FREQ), m2_step = BLDF(BS_M2_STEP);
-    const double lockingbw = BLDF(BS_LOCKINGBW);
-    const bool afc = BLDI(BI_FLAGS) & JF_AFC;
-    int ev_cnt = BLDI(BI_EV_CNT), overflow = BLDI(BI_OVERFLOW);
-    double fc = freq_center;
-    if (fc < (0.75 * g.fb)) fc = 0.75 * g.fb;
-    if (fc > (g.Fs / 2.0 - 0.75 * g.fb)) fc = g.Fs / 2.0 - 0.75 * g.fb;
-    double mc_freq = fc; if (mc_freq < 0) mc_freq = 0; // WaveTable::SetFreq
-    if (afc) jd_wt_setfreq(m2_freq, m2_step, mc_freq, g.Fs);
-    if ((m2_freq - mc_freq) > (lockingbw / 2.0)) jd_wt_setfreq(m2_freq, m2_step, mc_freq + (lockingbw / 2.0), g.Fs);
-    if ((m2_freq - mc_freq) < (-lockingbw / 2.0)) jd_wt_setfreq(m2_freq, m2_step, mc_freq - (lockingbw / 2.0), g.Fs);
-    bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_FREQ, m2_freq);
-    BLDF(BS_MC_FREQ) = mc_freq; BLDF(BS_M2_FREQ) = m2_freq; BLDF(BS_M2_STEP) = m2_step;
-    BLDI(BI_EV_CNT) = ev_cnt; BLDI(BI_OVERFLOW) = overflow;
-}
-__device__ __forceinline__ void bd_cmul(double &ar, double &ai, double br, double bi)
-{
-    const double r = ar * br - ai * bi, i = ar * bi + ai * br;
-    ar = r; ai = i;
-}
+#define BFB_LDSN 36 // filter history slots in LDS: 36 KiB + 2 KiB of mailbox = 38 912 B per pair, four pairs per CU (155 648 of 163 840 B)
+constexpr int bfb_pair_doubles() { return 2 * BFB_LDSN * 64 + 2 * 2 * 64; }
 
-// jd_fir_eval (jaero_device.h) without per-term address arithmetic (round 6; the 600 bps MSK kernel's mfb_fir_continue_v, k_msk_fb.h, for this filter).  The
-// wavefront is alone on its SIMD and issues one instruction of any kind per four cycles, so the loop is bound by its instruction COUNT: a term of the
-// LDS part cost ~11 instructions of which four or two (fused) were arithmetic -- the rest formed the ring address (slot + k) mod LDSN and fetched the tap
-// through a v_mov of its constant address.  The ring as NB = LDSN / BS blocks of BS slots, fir_slot = a BS + BV: entry k lies in block (a + m) mod NB at
-// slot r, m = (BV + k) / BS, r = (BV + k) % BS, compile-time constants per version BV; the NB + 1 block addresses are formed once per sample and every
-// read is `register + immediate` (taps too: tapz is a zero the compiler cannot see through).  Same terms, same order, same operations.
-template <int FIRN, int LDSN, int D, bool FUSED, int BS, int BV, int TAILA, int NBA>
-__device__ __forceinline__ void bd_fir_eval_v(const double *lre, const double *ltap, const double (&tre)[TAILA], const double (&tim)[TAILA], const int (&blk)[NBA],
-                                              int tapz, double &ore, double &oim)
+// ------------------------------------------------------------------------------------------------------------------ front half
+template <int FIRN, int LDSN>
+__device__ __forceinline__ void bfb_front(const BGeom &g, const BPtrs &p, double *lre, double *lim, double *mail, int n, long long n0, int grp, int lane,
+                                          const JTaps28 &tp)
 {
     constexpr int TAILN = FIRN - LDSN;
-    static_assert(LDSN % BS == 0 && NBA == LDSN / BS + 1 && TAILA == TAILN, "ring blocks");
-    double pr[D], pi[D], pt[D];
-    auto fetch = [&](int s, int q) __attribute__((always_inline)) {
-        pt[q] = ltap[tapz + s];
-        if (s >= TAILN)
-        {
-            const int k = s - TAILN, m = (BV + k) / BS, r = (BV + k) % BS;
-            pr[q] = lre[blk[m] + r * 64];
-            pi[q] = lre[blk[m] + r * 64 + LDSN * 64]; // the other arm's ring follows this one
-        }
-    };
-#pragma unroll
-    for (int s = 0; s < D; s++) fetch(s, s);
-    __builtin_amdgcn_sched_barrier(0);
-    double are = 0, aim = 0;
-#pragma unroll
-    for (int s = 0; s < FIRN; s++)
+    double tre[TAILN], tim[TAILN]; // tre[j] = x_re[n-LDSN-j] once x[n] has been pushed
+    const int ch = grp * 64 + lane, nchp = g.nchp;
+    const double2 *__restrict__ cis = p.cis;
+    const double samplerate = g.Fs;
+    double m2_ptr = BLDF(BS_M2_PTR), m2_step = BLDF(BS_M2_STEP), m2_freq = BLDF(BS_M2_FREQ), vol_gain = BLDF(BS_VOL_GAIN);
+    const int ev_pos = BLDI(BI_EV_POS);
+    const double *__restrict__ cvre = p.cvre + (size_t)grp * g.cv_len * 64 + lane;
     {
-        const int q = s % D;
-        const double xr = (s < TAILN) ? tre[(TAILN - 1 - s) < 0 ? 0 : (TAILN - 1 - s)] : pr[q];
-        const double xi = (s < TAILN) ? tim[(TAILN - 1 - s) < 0 ? 0 : (TAILN - 1 - s)] : pi[q];
-        if constexpr (FUSED) { are = fma(pt[q], xr, are); aim = fma(pt[q], xi, aim); }
-        else { are = are + pt[q] * xr; aim = aim + pt[q] * xi; }
-        asm volatile("" : "+v"(are), "+v"(aim)); // keeps the software pipeline as written (see jd_fir_eval)
-        if (s + D < FIRN) fetch(s + D, q);
-        __builtin_amdgcn_sched_barrier(0);
+        const double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
+        for (int k = 0; k < LDSN; k++) { lre[k * 64 + lane] = fs[(size_t)k * 64]; lim[k * 64 + lane] = fs[(size_t)(FIRN + k) * 64]; }
+#pragma unroll
+        for (int j = 0; j < TAILN; j++) { tre[j] = fs[(size_t)(LDSN + j) * 64]; tim[j] = fs[(size_t)(FIRN + LDSN + j) * 64]; }
     }
-    ore = are; oim = aim;
+    int fir_slot = (int)(n0 % LDSN); // wave-uniform: LDS slot holding the oldest LDS entry, overwritten by the next input
+    int s_val = (int)((n0 - g.D1 - g.D2 + 8LL * g.cv_len) % g.cv_len);
+    double nx_val = cvre[(size_t)s_val * 64];
+
+    // sample i: trident verdict (:488-515, the carrier oscillator's part), mix + rrc (:517-521), oscillator step (:727); -> mailbox i & 1
+    auto produce = [&](int i, bool from_saved_history) __attribute__((always_inline)) {
+        const double val = nx_val;
+        s_val++; if (s_val >= g.cv_len) s_val = 0;
+        if (i + 1 < n) nx_val = cvre[(size_t)s_val * 64];
+        if (i == ev_pos)
+        {
+            const TriResult tr = p.tri[ch];
+            if (tr.ok)
+            {
+                jd_wt_setfreq(m2_freq, m2_step, tr.freq, samplerate);
+                bd_set_phase_deg(m2_ptr, tr.phase_deg);
+                vol_gain = tr.vol_gain;
+            }
+        }
+        const double2 c2 = cis[jd_cisidx(m2_ptr)];
+        const double xin = (vol_gain * val);
+        const double cre = c2.x * xin, cim = c2.y * xin;
+        double sre, sim;
+        // output from x[n-FIRN .. n-1] (FIR::FIRUpdateAndProcess excludes the sample being pushed): taps[i] <-> x[n-FIRN+i]
+        if (from_saved_history) jd_fir_eval_sym<FIRN, LDSN, 6>(lre, lim, tp, tre, tim, fir_slot, lane, sre, sim);
+        else jd_fir_eval_sym_static<FIRN, LDSN, 6>(lre, lim, tp, tre, tim, fir_slot, lane, sre, sim);
+        // push x[n]: the oldest LDS entry moves into the register tail
+#pragma unroll
+        for (int j = TAILN - 1; j > 0; j--) { tre[j] = tre[j - 1]; tim[j] = tim[j - 1]; }
+        tre[0] = lre[fir_slot * 64 + lane]; tim[0] = lim[fir_slot * 64 + lane];
+        lre[fir_slot * 64 + lane] = cre; lim[fir_slot * 64 + lane] = cim;
+        fir_slot++; if (fir_slot >= LDSN) fir_slot = 0;
+        double *d = mail + (i & 1) * 2 * 64 + lane;
+        d[0] = sre; d[64] = sim;
+        jd_wt_next(m2_ptr, m2_step);
+    };
+    if (n > 0) produce(0, true);
+    fb_barrier();
+    for (int i = 0; i < n; i++)
+    {
+        if (i + 1 < n) produce(i + 1, false);
+        fb_barrier();
+    }
+    BLDF(BS_M2_PTR) = m2_ptr; BLDF(BS_M2_STEP) = m2_step; BLDF(BS_M2_FREQ) = m2_freq; BLDF(BS_VOL_GAIN) = vol_gain;
+    {
+        double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
+        for (int k = 0; k < LDSN; k++) { fs[(size_t)k * 64] = lre[k * 64 + lane]; fs[(size_t)(FIRN + k) * 64] = lim[k * 64 + lane]; }
+#pragma unroll
+        for (int j = 0; j < TAILN; j++) { fs[(size_t)(LDSN + j) * 64] = tre[j]; fs[(size_t)(FIRN + LDSN + j) * 64] = tim[j]; }
+    }
 }
 
-// Arithmetic policy of this kernel: fused matched filter + the device library's hypot / atan2.  The A/B build
-// (make -C jaero_amd/csrc ab_burst -> gpurun_tmp/libjaero_hip_burstexact.so, -DJD_BURST_EXACT) takes the continuous kernels' arithmetic instead --
-// filter op for op, glibc's hypot, correctly rounded atan2 -- so that scripts/burst_recording_ab.py can count on the reference's own off-air
-// recording what the choice moves (round 6: profiles/r6_burst_recording_ab.json).
-#define BD_LDSN 36 // filter history slots in LDS (39 until round 6): six blocks of six for bd_fir_eval_v
-#define BD_BS 6
-#ifdef JD_BURST_EXACT
-#define BD_FUSED false
-#define BD_HYPOT(x, y) jd_hypot(x, y)
-#define BD_ATAN2(y, x) jd_atan2(y, x, bd_atl)
-#else
-#define BD_FUSED true
-#define BD_HYPOT(x, y) hypot(x, y)
-#define BD_ATAN2(y, x) atan2(y, x)
-#endif
+// ------------------------------------------------------------------------------------------------------------------- back half
 template <bool CAPSYM>
-__global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const BPtrs p, int n, long long n0, int first_of_write)
+__device__ __forceinline__ void bfb_back(const BGeom &g, const BPtrs &p, const double *mail, int n, long long n0, int first_of_write, int grp, int lane)
 {
-    // matched-filter history as in k_oqpsk.h: the LDSN newest entries of each arm in LDS ([slot][lane]), the FIRN-LDSN oldest in a
-    // VGPR shift register, plus this wavefront's copy of the taps (jd_fir_eval) -> 39.5 KiB of LDS per wavefront, four per CU
-    constexpr int FIRN = 55, LDSN = BD_LDSN, TAILN = FIRN - LDSN;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *lre = lds, *lim = lds + LDSN * 64, *ltap = lds + 2 * LDSN * 64;
-    double tre[TAILN], tim[TAILN];
-    const int lane = threadIdx.x, grp = blockIdx.x, ch = grp * 64 + lane, nchp = g.nchp;
+    const int ch = grp * 64 + lane, nchp = g.nchp;
     const double2 *__restrict__ cis = p.cis;
-    const double *__restrict__ taps = p.taps2; // this bank's own taps, read once into LDS
     const double SPS = g.SPS, samplerate = g.Fs;
 #ifdef JD_BURST_EXACT
     const JdAtanLane bd_atl = jd_atan_lane_table(lane);
 #endif
 
-    double m2_ptr = BLDF(BS_M2_PTR), m2_step = BLDF(BS_M2_STEP), m2_freq = BLDF(BS_M2_FREQ);
     double st_ptr = BLDF(BS_ST_PTR), st_step = BLDF(BS_ST_STEP), st_freq = BLDF(BS_ST_FREQ), st_last = BLDF(BS_ST_LAST);
-    double stq_ptr = BLDF(BS_STQ_PTR), vol_gain = BLDF(BS_VOL_GAIN);
+    double stq_ptr = BLDF(BS_STQ_PTR);
     double str_re = BLDF(BS_STR_RE), str_im = BLDF(BS_STR_IM), sav_re = BLDF(BS_SAV_RE), sav_im = BLDF(BS_SAV_IM);
     double rot_re = BLDF(BS_ROT_RE), rot_im = BLDF(BS_ROT_IM), rot_freq = BLDF(BS_ROT_FREQ);
     // cis(rot_freq), formed where rot_freq changes (verdict, symbol instants) instead of in every sample: the same function of the same
@@ -154,7 +132,6 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
     const int ev_pos = BLDI(BI_EV_POS);
     const bool trace = (g.flags & 8u) != 0;
 
-    const double *__restrict__ cvre = p.cvre + (size_t)grp * g.cv_len * 64 + lane;
     // ONE ring of |sig2|: ebnomeasure->Update(sig2abs) and agc2->Update(sig2abs) (:570,:576) are fed the same value in the same samples and both
     // start from empty windows at the same moments (constructor, setSettings), so AGC2's moving-average buffer is the newest agc2_len
     // entries of E's, and E2's entries are E's squared (MovingAverage::Update stores fabs(sig), DSP.cpp:408-416: fabs(x)^2 == fabs(x x))
@@ -162,38 +139,29 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
     double *msema_ring = p.msema + (size_t)ch * g.msema_len;
     int16_t *__restrict__ soft = p.soft + (size_t)ch * g.soft_cap;
 
-    {
-        const double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
-        for (int k = 0; k < LDSN; k++) { lre[k * 64 + lane] = fs[(size_t)k * 64]; lim[k * 64 + lane] = fs[(size_t)(FIRN + k) * 64]; }
-#pragma unroll
-        for (int j = 0; j < TAILN; j++) { tre[j] = fs[(size_t)(LDSN + j) * 64]; tim[j] = fs[(size_t)(FIRN + LDSN + j) * 64]; }
-    }
-    if (lane < FIRN) ltap[lane] = taps[lane];
-    int tapz; // a zero in a vector register: tap reads become `register + immediate offset` (bd_fir_eval_v)
-    asm volatile("v_mov_b32 %0, 0" : "=v"(tapz));
-    int fir_slot = (int)(n0 % LDSN), s_eb = (int)(n0 % g.win_ring);
+    int s_eb = (int)(n0 % g.win_ring);
     int s_agc2 = s_eb - g.agc2_len; if (s_agc2 < 0) s_agc2 += g.win_ring; // the entry written agc2_len samples ago (slot s_eb itself holds the one written win_ring ago)
     int s_e = s_eb - g.eb_len; if (s_e < 0) s_e += g.win_ring;             // the entry written eb_len samples ago
-    int s_val = (int)((n0 - g.D1 - g.D2 + 8LL * g.cv_len) % g.cv_len);
-    const double w4 = g.w4, w4c = 1.0 - g.w4, w8 = g.w8, w8c = 1.0 - g.w8, a1w = g.a1_w, a1wc = 1.0 - g.a1_w;
-    const double agc2_len_d = (double)g.agc2_len, eb_len_d = (double)g.eb_len;
+    // wave-uniform constants come from the geometry (scalar registers / literals): formed here they would each hold a vector register pair for the whole launch
+    const double w4 = g.w4, w4c = g.w4c, w8 = g.w8, w8c = g.w8c, a1w = g.a1_w, a1wc = g.a1_wc;
+    const double agc2_len_d = g.agc2_len_d, eb_len_d = g.eb_len_d;
     // divisions by these constants: reciprocal + two fma corrections (jd_div_const, bit-identical to the quotient)
-    const double r_agc2_len = 1.0 / agc2_len_d, r_samplerate = 1.0 / samplerate, r_360 = 1.0 / 360.0, wtsize_d = (double)JD_WTSIZE, r_wtsize = 1.0 / wtsize_d;
-    const double msema_len_d = (double)g.msema_len, r_msema_len = 1.0 / msema_len_d;
+    const double r_agc2_len = g.r_agc2_len, r_samplerate = g.r_Fs, r_360 = 1.0 / 360.0, wtsize_d = (double)JD_WTSIZE, r_wtsize = 1.0 / wtsize_d;
+    const double msema_len_d = g.msema_len_d, r_msema_len = g.r_msema_len;
 
     // ring entries of sample i+1 are requested at the top of iteration i (all slots are wave-uniform and data independent)
-    double nx_val = cvre[(size_t)s_val * 64], nx_agc2 = ebe_ring[(size_t)s_agc2 * 64];
+    double nx_agc2 = ebe_ring[(size_t)s_agc2 * 64];
     double nx_e = ebe_ring[(size_t)s_e * 64];
+    fb_barrier(); // the front half has formed sample 0
     for (int i = 0; i < n; i++)
     {
         const long long sample = n0 + i;
-        const double val = nx_val, agc2_old = nx_agc2, e_old = nx_e, e2_old = nx_e * nx_e;
+        const double agc2_old = nx_agc2, e_old = nx_e, e2_old = nx_e * nx_e;
         if (i + 1 < n)
         {
-            int sv = s_val + 1; if (sv >= g.cv_len) sv = 0;
             int sa = s_agc2 + 1; if (sa >= g.win_ring) sa = 0;
             int se = s_e + 1; if (se >= g.win_ring) se = 0;
-            nx_val = cvre[(size_t)sv * 64]; nx_agc2 = ebe_ring[(size_t)sa * 64];
+            nx_agc2 = ebe_ring[(size_t)sa * 64];
             nx_e = ebe_ring[(size_t)se * 64];
         }
         // ---- trident verdict for this sample (:488-515) ----
@@ -203,10 +171,9 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
             if (trace) bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_TRIDENT, tr.ok ? tr.metric : -tr.metric);
             if (tr.ok)
             {
-                jd_wt_setfreq(m2_freq, m2_step, tr.freq, samplerate);
-                bd_set_phase_deg(m2_ptr, tr.phase_deg);
-                bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_FREQ, m2_freq);
-                vol_gain = tr.vol_gain;
+                // (mixer2's frequency / phase and vol_gain: the front half applies them at this sample; the emission carries the frequency as
+                // WaveTable::SetFreq leaves it)
+                bd_event(g, p, ch, ev_cnt, overflow, sample, BEV_FREQ, tr.freq < 0 ? 0.0 : tr.freq);
                 jd_wt_setfreq(st_freq, st_step, g.stref_freq, samplerate);
                 bd_set_phase_deg(st_ptr, 0);
                 res_x1 = res_x2 = res_y1 = res_y2 = 0;
@@ -222,37 +189,12 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
                 msema_pos = 0; msema_sum = 0;
             }
         }
-        // ---- mix + rrc (:517-521) ----
-        const double2 c2 = cis[jd_cisidx(m2_ptr)];
-        // the symbol oscillator's table entry, needed by the timing loop far below: requested here, under the matched filter (valid unless the
-        // preamble block moves st_ptr in between; asked for where it is used it was an L2 round trip on every sample's chain)
+        // ---- mix + rrc (:517-521): the front half's; its output for this sample is in the mailbox ----
+        const double *md = mail + (i & 1) * 2 * 64 + lane;
+        double sre = md[0], sim = md[64];
+        // the symbol oscillator's table entry, needed by the timing loop far below: requested here (valid unless the preamble block moves st_ptr in between)
         const double st_ptr_top = st_ptr;
         const double2 so_pre = cis[jd_cisidx(st_ptr)];
-        const double xin = (vol_gain * val);
-        const double cre = c2.x * xin, cim = c2.y * xin;
-        double sre = 0, sim = 0;
-        {
-            // output from x[n-FIRN .. n-1] (FIR::FIRUpdateAndProcess excludes the sample being pushed): taps[i] <-> x[n-FIRN+i]
-            constexpr int NB = LDSN / BD_BS;
-            int blk[NB + 1];
-            const int ab = fir_slot / BD_BS; // wave-uniform
-#pragma unroll
-            for (int m = 0; m <= NB; m++)
-            {
-                int t = ab + m;
-                if (t >= NB) t -= NB;
-                blk[m] = t * BD_BS * 64 + lane;
-            }
-#define BD_V(B) case B: bd_fir_eval_v<FIRN, LDSN, 8, BD_FUSED, BD_BS, B>(lre, ltap, tre, tim, blk, tapz, sre, sim); break;
-            switch (fir_slot % BD_BS) { BD_V(0) BD_V(1) BD_V(2) BD_V(3) BD_V(4) BD_V(5) default: break; }
-#undef BD_V
-            // push x[n]: the oldest LDS entry moves into the register tail
-#pragma unroll
-            for (int j = TAILN - 1; j > 0; j--) { tre[j] = tre[j - 1]; tim[j] = tim[j - 1]; }
-            tre[0] = lre[fir_slot * 64 + lane]; tim[0] = lim[fir_slot * 64 + lane];
-            lre[fir_slot * 64 + lane] = cre; lim[fir_slot * 64 + lane] = cim;
-            fir_slot++; if (fir_slot >= LDSN) fir_slot = 0;
-        }
         // ---- sample counting and signal time-out (:523-544) ----
         if (startstop > 0)
         {
@@ -420,19 +362,17 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
         }
         sig2l_re = sre; sig2l_im = sim;
         // ---- advance the oscillators (:727-730) ----
-        jd_wt_next(m2_ptr, m2_step);
         if (st_step < 0) st_step = 0;
         st_last = st_ptr;
         st_ptr += st_step;
         while (((int)st_ptr) >= JD_WTSIZE) st_ptr -= JD_WTSIZE;
         stq_ptr += g.stq_step;
         while (((int)stq_ptr) >= JD_WTSIZE) stq_ptr -= JD_WTSIZE;
-        s_val++; if (s_val >= g.cv_len) s_val = 0;
+        fb_barrier();
     }
 
-    BLDF(BS_M2_PTR) = m2_ptr; BLDF(BS_M2_STEP) = m2_step; BLDF(BS_M2_FREQ) = m2_freq;
     BLDF(BS_ST_PTR) = st_ptr; BLDF(BS_ST_STEP) = st_step; BLDF(BS_ST_FREQ) = st_freq; BLDF(BS_ST_LAST) = st_last;
-    BLDF(BS_STQ_PTR) = stq_ptr; BLDF(BS_VOL_GAIN) = vol_gain;
+    BLDF(BS_STQ_PTR) = stq_ptr;
     BLDF(BS_STR_RE) = str_re; BLDF(BS_STR_IM) = str_im; BLDF(BS_SAV_RE) = sav_re; BLDF(BS_SAV_IM) = sav_im;
     BLDF(BS_ROT_RE) = rot_re; BLDF(BS_ROT_IM) = rot_im; BLDF(BS_ROT_FREQ) = rot_freq;
     BLDF(BS_A1_1) = a1_1; BLDF(BS_A1_2) = a1_2; BLDF(BS_A1_3) = a1_3; BLDF(BS_A1_4) = a1_4; BLDF(BS_A1_5) = a1_5;
@@ -445,14 +385,27 @@ __global__ __launch_bounds__(64) void k_burst_oqpsk_demod(const BGeom g, const B
     BLDI(BI_STARTSTOP) = startstop; BLDI(BI_CNTR) = cntr; BLDI(BI_YUI) = yui; BLDI(BI_INSERTPRE) = insertpre;
     BLDI(BI_MSEMA_POS) = msema_pos; BLDI(BI_NRX) = nrx;
     BLDI(BI_SOFT_CNT) = soft_cnt; BLDI(BI_SYM_CNT) = sym_cnt; BLDI(BI_EV_CNT) = ev_cnt; BLDI(BI_OVERFLOW) = overflow;
-    {
-        double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
-        for (int k = 0; k < LDSN; k++) { fs[(size_t)k * 64] = lre[k * 64 + lane]; fs[(size_t)(FIRN + k) * 64] = lim[k * 64 + lane]; }
-#pragma unroll
-        for (int j = 0; j < TAILN; j++) { fs[(size_t)(LDSN + j) * 64] = tre[j]; fs[(size_t)(FIRN + LDSN + j) * 64] = tim[j]; }
-    }
 }
 
-// ------------------------------------------------------------------------------------------------ burst MSK
-// k_burst_msk_fb.h (round 3): the tracking chain as a front / back wavefront pair.  The single-wavefront kernel k_burst_msk_demod lived here
-// (rounds 1-2: 78 -> 43 ms per 4096-sample launch of 65 536 channels; what it taught is in that header and in DESIGN 10).
+// PAIRS front/back pairs per workgroup: waves 0..PAIRS-1 are the front halves of channel groups blockIdx.x*PAIRS + w, waves PAIRS..2*PAIRS-1 the back
+// halves of the same groups (waves w and w + PAIRS of a four-pair workgroup share a SIMD).  A pair whose group lies beyond the bank only keeps the
+// barrier count.
+template <bool CAPSYM, int PAIRS>
+__global__ __launch_bounds__(PAIRS * 128) void k_burst_oqpsk_fb(const BGeom g, const BPtrs p, int n, long long n0, int first_of_write, const JTaps28 tp)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const bool back = wave >= PAIRS;
+    const int pair = back ? wave - PAIRS : wave;
+    const int grp = blockIdx.x * PAIRS + pair;
+    double *base = lds + (size_t)pair * bfb_pair_doubles();
+    double *lre = base, *lim = base + BFB_LDSN * 64, *mail = base + 2 * BFB_LDSN * 64;
+    if (grp >= g.ngroups)
+    {
+        for (int i = 0; i <= n; i++) fb_barrier();
+        return;
+    }
+    if (back) bfb_back<CAPSYM>(g, p, mail, n, n0, first_of_write, grp, lane);
+    else bfb_front<55, BFB_LDSN>(g, p, lre, lim, mail, n, n0, grp, lane, tp);
+}
