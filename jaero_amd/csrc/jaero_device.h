@@ -40,6 +40,7 @@ enum
     S_LOCKINGBW, S_THRESH,
     S_MFB_A0_RE, S_MFB_A0_IM,          // k_msk_fb with four pairs: the back half's partial filter sum for the next launch's first sample
     S_PRE_PTR, S_PRE_STEP, S_PRE_FSUM, // fb == 8400: mixer_fir_pre phase / step, sum of mixer2's frequency over the current write
+    S_PRE_PTR_NEXT, S_PRE_STEP_NEXT,   // ... as k_pre8400_mix's last stretch leaves them; k_pre8400_commit makes them current
     S_NFIELDS
 };
 // ---- int state fields (I) ----

@@ -1276,8 +1276,12 @@ extern "C" int jaero_write(jaero_ctx *c, const int16_t *pcm, int nsamples, int l
     {
         // the whole write is prefiltered first (oqpskdemodulator.cpp:343-381); its oscillator takes the mean of mixer2's frequency over
         // the previous write (:607-608)
-        hipLaunchKernelGGL(k_pre8400_mix, dim3(g.ngroups), dim3(64), 0, st, g, c->p, c->pre, frames, stride, nsamples, c->pre_n0, c->pre_nprev);
+        // eight stretches per write once there are fewer channel groups than eight per SIMD (k_pre8400.h)
+        const int ntb = (g.ngroups >= 8192 || nsamples < 512) ? 1 : 8;
+        hipLaunchKernelGGL(k_pre8400_mix, dim3(g.ngroups, ntb), dim3(64), 0, st, g, c->p, c->pre, frames, stride, nsamples, c->pre_n0, c->pre_nprev);
         LAUNCHCHK("k_pre8400_mix");
+        hipLaunchKernelGGL(k_pre8400_commit, dim3(g.ngroups), dim3(64), 0, st, g, c->p, c->pre_nprev);
+        LAUNCHCHK("k_pre8400_commit");
         launch_pre8400_filter(g, c->p, c->pre, nsamples, c->pre_n0, c->pre_direct, st);
         LAUNCHCHK("the 8400 bps prefilter");
         c->pre_n0 += nsamples;

@@ -41,6 +41,10 @@ __global__ __launch_bounds__(64) void k_pre8400_mix(const JGeom g, const JPtrs p
 {
     const int lane = threadIdx.x, ch = blockIdx.x * 64 + lane, nchp = g.nchp;
     const bool live = ch < g.nch;
+    // blockIdx.y = one of gridDim.y stretches of the write (round 6): with one wavefront per 64 channels and the whole write each, 1024 wavefronts streamed
+    // 5.4 GB with eight requests in flight apiece (3.3 ms per 4096-sample step of 65 536 channels).  A stretch starts from the oscillators' state at its
+    // first sample, which it gets by taking the steps before it without touching memory (a few thousand additions); every stretch reads the state and
+    // none writes it -- the last one leaves the state after the whole write in S_PRE_*_NEXT, k_pre8400_commit (next on the stream) makes it current.
     double ptr = p.S[(size_t)S_PRE_PTR * nchp + ch], step = p.S[(size_t)S_PRE_STEP * nchp + ch];
     if (nprev > 0)
     {
@@ -48,8 +52,10 @@ __global__ __launch_bounds__(64) void k_pre8400_mix(const JGeom g, const JPtrs p
         double freq = p.S[(size_t)S_PRE_FSUM * nchp + ch] / ((double)nprev);
         if (freq < 0) freq = 0;
         step = (freq) * ((double)JD_WTSIZE) / 48000.0;
-        p.S[(size_t)S_PRE_FSUM * nchp + ch] = 0.0;
     }
+    const int ntb = (int)gridDim.y, tb = (int)blockIdx.y;
+    const int chunk = (((n + ntb - 1) / ntb) + 7) & ~7;
+    const int lo = min(n, tb * chunk), hi = (tb == ntb - 1) ? n : min(n, lo + chunk);
     const double2 *__restrict__ cis = p.cis;
     const int rmask = q.ring - 1;
     // down (:354-364) and up (:371-379: SetPhaseDeg(savedphase), then the same number of frames): two independent oscillators with
@@ -59,11 +65,37 @@ __global__ __launch_bounds__(64) void k_pre8400_mix(const JGeom g, const JPtrs p
     while (phase < 0) phase += 360.0;
     double pd = ptr, sd = step;
     double pu = (phase / 360.0) * ((double)JD_WTSIZE), su = step;
-    short nx = (live && n > 0) ? pcm[ch] : (short)0;
-    for (int i = 0; i < n; i++)
+    // Eight samples at a time (round 6): the two oscillators advance by running sums that depend on nothing loaded, so the eight table indices of a
+    // group are known before any of its table values or PCM samples arrives.  One sample per iteration, each iteration waited for its own gather (an L2
+    // round trip): 3.6 ms per 4096-sample step of 65 536 channels, nearly all of it latency.  Same operations per sample, in the same order.
+    for (int k = 0; k < lo; k++) { jd_wt_next(pd, sd); jd_wt_next(pu, su); } // the steps of the stretches in front of this one
+    int i = lo;
+    for (; i + 8 <= hi; i += 8)
     {
-        const short s = nx;
-        if (i + 1 < n) nx = live ? pcm[(size_t)(i + 1) * pcm_stride + ch] : (short)0;
+        int id[8], iu[8];
+        short sv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+        {
+            id[u] = jd_cisidx(pd); iu[u] = jd_cisidx(pu);
+            jd_wt_next(pd, sd);
+            jd_wt_next(pu, su);
+            sv[u] = live ? pcm[(size_t)(i + u) * pcm_stride + ch] : (short)0;
+        }
+        double2 cv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) cv[u] = cis[id[u]];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+        {
+            const double dval = ((double)sv[u]) / 32768.0;
+            q.cidx[(size_t)(i + u) * nchp + ch] = (unsigned short)iu[u];
+            q.xring[(size_t)((int)((n0 + i + u) & rmask)) * nchp + ch] = make_double2(cv[u].x * dval, cv[u].y * dval);
+        }
+    }
+    for (; i < hi; i++)
+    {
+        const short s = live ? pcm[(size_t)i * pcm_stride + ch] : (short)0;
         const double dval = ((double)s) / 32768.0;
         const double2 c = cis[jd_cisidx(pd)];
         q.cidx[(size_t)i * nchp + ch] = (unsigned short)jd_cisidx(pu);
@@ -71,8 +103,18 @@ __global__ __launch_bounds__(64) void k_pre8400_mix(const JGeom g, const JPtrs p
         jd_wt_next(pd, sd);
         jd_wt_next(pu, su);
     }
-    p.S[(size_t)S_PRE_PTR * nchp + ch] = pu;
-    p.S[(size_t)S_PRE_STEP * nchp + ch] = su;
+    if (tb == ntb - 1)
+    {
+        p.S[(size_t)S_PRE_PTR_NEXT * nchp + ch] = pu;
+        p.S[(size_t)S_PRE_STEP_NEXT * nchp + ch] = su;
+    }
+}
+__global__ __launch_bounds__(64) void k_pre8400_commit(const JGeom g, const JPtrs p, int nprev)
+{
+    const int ch = blockIdx.x * 64 + threadIdx.x, nchp = g.nchp;
+    p.S[(size_t)S_PRE_PTR * nchp + ch] = p.S[(size_t)S_PRE_PTR_NEXT * nchp + ch];
+    p.S[(size_t)S_PRE_STEP * nchp + ch] = p.S[(size_t)S_PRE_STEP_NEXT * nchp + ch];
+    if (nprev > 0) p.S[(size_t)S_PRE_FSUM * nchp + ch] = 0.0; // the sum over the write that is about to be demodulated starts here (:607-608)
 }
 
 // k_pre8400_fft: the prefilter by overlap-save, i.e. the way the reference's JFastFir computes it (nfft 4096, 2049

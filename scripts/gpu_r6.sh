@@ -57,6 +57,12 @@ if has burstsplit; then
   python -c "import json;d=json.load(open('$OUT/bench_line_burst_oqpsk.json'));c=d['config'];print('burst_oqpsk',d['value'],d['ms_per_step'],c.get('kernel_ms_total'),c.get('oracle_check'))"
   ( timeout 600 python scripts/burst_recording_ab.py gpu 2> "$OUT/burst_rec.err" | tail -1 ) > "$OUT/burst_recording_gpu.json"; python -c "import json;d=json.load(open('$OUT/burst_recording_gpu.json'));print(d['total'])"
 fi
+if has pre8400; then
+  timeout 1200 python -m pytest tests -m gpu -q -k "8400" --tb=short 2>&1 | tail -6 | tee "$OUT/pytest_8400.log"
+  ( timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof8400" -o stats -- python bench.py --workload oqpsk8400 --preroll 40 --steps 6 --warmup 2 --no-cpu-baseline --as-written 0 --sustain 0 --no-state 2> "$OUT/bench_8400.err" | tail -1 ) > "$OUT/bench_line_8400.json"
+  python -c "import json;d=json.load(open('$OUT/bench_line_8400.json'));c=d['config'];print('oqpsk8400',d['value'],d['ms_per_step'],c['kernel_ms_per_step'],c.get('oracle_check',{}).get('hard_bits_equal'),c.get('oracle_check',{}).get('max_soft_byte_diff'))"
+  f=$(find "$OUT/prof8400" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/kernel_stats_8400.csv" && grep -E "k_|Name" "$f" | cut -c1-160 | head -8
+fi
 if has tb600; then
   for v in product tb52 tb44; do
     L=$R/jaero_amd/libjaero_hip.so; [ $v != product ] && L=$R/gpurun_tmp/libjaero_hip_$v.so
