@@ -22,7 +22,7 @@ enum
     AI_CNTR, AI_DATACD, AI_DCDCOUNT, AI_GOTSYNC_LAST, AI_REALIMAG, AI_BLOCKCNT, AI_MUW, AI_FRAMEINFO, AI_LASTFRAMEINFO,
     AI_PD_EXACT, AI_PD_IMAG, AI_PD_REAL, AI_INV_IMAG, AI_INV_REAL, AI_SCR_POS, AI_DL2_PTR, AI_NINFO, AI_NFRAMES,
     AI_IN_POS, AI_RESUME, AI_RESUME_GOTSYNC, AI_HAS_BLOCK, AI_VBLOCKS, AI_SU_CNT, AI_EV_CNT, AI_OVERFLOW, AI_NBITS_LO, AI_NBITS_HI, AI_ACC, AI_ACCBAD,
-    AI_MARKER, AI_BULK_LEN, AI_BULK_SRC, AI_BULK_DST, AI_BULK_FLAGS, AI_NMATCH, AI_MATCH0, AI_MATCH1, AI_MATCH2, AI_MATCH3,
+    AI_MARKER, AI_BULK_LEN, AI_BULK_SRC, AI_BULK_DST, AI_BULK_FLAGS, AI_BULK2_LEN, AI_BULK2_SRC, AI_BULK2_DST, AI_BULK2_FLAGS, AI_NMATCH, AI_MATCH0, AI_MATCH1, AI_MATCH2, AI_MATCH3,
     AI_NFIELDS
 };
 struct AGeom
@@ -166,6 +166,12 @@ __device__ __forceinline__ void aerol_bit_b(const AGeom &g, const APtrs &p, int 
 // over it and leaves a descriptor for k_aerol_bulk, which copies it with a whole wavefront.  Everything else (unique-word windows,
 // headers, unlocked channels, 600/1200 bps, writes with markers) goes bit by bit.
 #define AEROL_MINRUN 32
+#ifndef AEROL_WINDOW_JUMP
+#define AEROL_WINDOW_JUMP 1
+#endif
+#ifndef AEROL_WINDOW_FLUSH
+#define AEROL_WINDOW_FLUSH 64 // bits of a detector window walked before its stretch may be jumped (the shift registers' 32 bits per arm)
+#endif
 #define AEROL_NMATCH 4 // potential unique-word positions k_aerol_scan records per channel and write
 template <bool BULK>
 __global__ __launch_bounds__(64) void k_aerol_bits(const AGeom g, const APtrs p, const int16_t *__restrict__ soft, const int *__restrict__ counts, int stride)
@@ -188,6 +194,7 @@ __global__ __launch_bounds__(64) void k_aerol_bits(const AGeom g, const APtrs p,
     uint8_t *rx = p.rx + (size_t)ch * g.blocksz;
     const bool may_bulk = BULK && !ALD(AI_MARKER);
     int has_block = 0, gotsync = 0, bulk_len = 0, bulk_src = 0, bulk_dst = 0, bulk_flags = 0;
+    int bulk2_len = 0, bulk2_src = 0, bulk2_dst = 0, bulk2_flags = 0, njump = 0; // a round has TWO descriptor slots (round 6, below)
     if (resume && valid)
     {
         // second half of the soft bit whose block store completed a block in the previous round
@@ -225,12 +232,19 @@ __global__ __launch_bounds__(64) void k_aerol_bits(const AGeom g, const APtrs p,
             //  locked   (data carrier): pre-increment cntr in [16, NumberOfBits-68] -- no unique-word detection, header done
             //  unlocked (no carrier, detector on every bit): up to the bit before the next position at which the detector could
             //           fire (k_aerol_scan) and before the bit that completes the block; cntr >= 16 (or still saturated)
+            // Round 6: a LOCKED channel is walked bit by bit for 341 of a frame's 5250 soft bits -- the detector is on from pre-increment cntr
+            // NumberOfBits - 67 = 4925 on, 325 bits before the frame ends, because NumberOfBits (4992) counts the block's bits and cntr also the
+            // header's and the dummy bits' 194 (aerol.cpp:1256-1264).  While the detector is on a locked channel does exactly what an unlocked one
+            // does, so the unlocked jump applies -- once the detector's two shift registers hold nothing but bits of this window: they are not
+            // shifted while the detector is off, so its first 64 decisions (32 per arm) see stale bits mixed with fresh ones and are walked as the
+            // reference takes them; k_aerol_scan's positions assume registers that have seen the last 32 bits of their arm.  Walked per frame:
+            // those 64, the bit that completes the block, the unique word's 64, the header's 16.
             int L = 0;
             bool unlocked_jump = false;
-            if (may_bulk && bulk_len == 0 && s.cntr >= 16)
+            if (may_bulk && njump < 2 && s.cntr >= 16)
             {
-                if (s.datacd) { if (s.cntr <= zone_hi) L = min(zone_hi - s.cntr + 1, n - pos); }
-                else if (pos >= 64 && pos < scan_hi)
+                if (s.datacd && s.cntr <= zone_hi) L = min(zone_hi - s.cntr + 1, n - pos);
+                else if ((!s.datacd || (AEROL_WINDOW_JUMP && s.cntr >= zone_hi + AEROL_WINDOW_FLUSH + 1 && s.cntr < 1000000000)) && pos >= 64 && pos < scan_hi)
                 {
                     int lim = min(n, scan_hi) - pos;
                     if (next_match >= pos) lim = min(lim, next_match - pos);
@@ -256,12 +270,12 @@ __global__ __launch_bounds__(64) void k_aerol_bits(const AGeom g, const APtrs p,
                 const int i0 = sat ? L : max(0, g.BitsInHeader - (c + 1));
                 if (i0 < L)
                 {
-                    bulk_src = pos + i0;
-                    bulk_dst = c + 1 + i0 - g.BitsInHeader;
-                    bulk_len = L - i0;
-                    bulk_flags = ((s.realimag ^ ((i0 + 1) & 1)) & 1) | (s.inv_imag ? 2 : 0) | (s.inv_real ? 4 : 0);
+                    const int d_src = pos + i0, d_dst = c + 1 + i0 - g.BitsInHeader, d_len = L - i0;
+                    const int d_flags = ((s.realimag ^ ((i0 + 1) & 1)) & 1) | (s.inv_imag ? 2 : 0) | (s.inv_real ? 4 : 0);
+                    if (njump == 0) { bulk_src = d_src; bulk_dst = d_dst; bulk_len = d_len; bulk_flags = d_flags; }
+                    else { bulk2_src = d_src; bulk2_dst = d_dst; bulk2_len = d_len; bulk2_flags = d_flags; }
                 }
-                else bulk_len = -1; // nothing to copy, but only one jump per round (one descriptor slot)
+                njump++; // (a jump with nothing to copy takes a slot too: two jumps per round)
                 if (unlocked_jump)
                 {
                     // the detector ran over every jumped bit: bring both arms' shift registers up to date from the last 64 of them
@@ -295,6 +309,27 @@ __global__ __launch_bounds__(64) void k_aerol_bits(const AGeom g, const APtrs p,
                 {
                     aerol_bit_b(g, p, ch, s, gotsync, nbits0 + pos);
                     pos++;
+                    // The frame counter has just restarted (a unique word, or the frame length ran out): from here on block indices begin again at 0.  A
+                    // stretch jumped EARLIER in this round is copied by k_aerol_bulk AFTER this kernel -- it would overwrite what the bits that follow
+                    // store at the same indices.  So the lane copies its pending stretches itself, now, in stream order (a false unique word inside a
+                    // detector window, or a channel acquiring lock behind a jumped stretch: once per event, not per frame -- a frame's own unique word
+                    // comes in the round after its block was completed, with nothing pending), and both descriptor slots are free again.
+                    if (BULK && s.cntr == -1 && njump > 0)
+                    {
+                        auto copy_now = [&](int src0, int dst0, int len, int flags) {
+                            const int inv_first = (flags & 1) ? (flags >> 1) & 1 : (flags >> 2) & 1;
+                            const int inv_second = (flags & 1) ? (flags >> 2) & 1 : (flags >> 1) & 1;
+                            for (int k = 0; k < len; k++)
+                            {
+                                unsigned sbit = (unsigned)(int)sb[src0 + k] & 0xFFFFu;
+                                if (((k & 1) ? inv_second : inv_first) && sbit != 128u) sbit = 255u - sbit;
+                                rx[dst0 + k] = (uint8_t)(sbit & 255u);
+                            }
+                        };
+                        if (bulk_len > 0) copy_now(bulk_src, bulk_dst, bulk_len, bulk_flags);
+                        if (bulk2_len > 0) copy_now(bulk2_src, bulk2_dst, bulk2_len, bulk2_flags);
+                        bulk_len = 0; bulk2_len = 0; njump = 0;
+                    }
                 }
             }
             if (pos >= n) live = false;
@@ -309,6 +344,7 @@ __global__ __launch_bounds__(64) void k_aerol_bits(const AGeom g, const APtrs p,
     ALD(AI_IN_POS) = pos; ALD(AI_RESUME) = resume; ALD(AI_RESUME_GOTSYNC) = gotsync; ALD(AI_HAS_BLOCK) = has_block;
     ALD(AI_EV_CNT) = s.ev_cnt; ALD(AI_OVERFLOW) = s.overflow; ALD(AI_ACC) = (int)s.acc; ALD(AI_ACCBAD) = s.accbad;
     ALD(AI_BULK_LEN) = bulk_len > 0 ? bulk_len : 0; ALD(AI_BULK_SRC) = bulk_src; ALD(AI_BULK_DST) = bulk_dst; ALD(AI_BULK_FLAGS) = bulk_flags;
+    ALD(AI_BULK2_LEN) = bulk2_len > 0 ? bulk2_len : 0; ALD(AI_BULK2_SRC) = bulk2_src; ALD(AI_BULK2_DST) = bulk2_dst; ALD(AI_BULK2_FLAGS) = bulk2_flags;
 }
 
 // Per write and channel, one wavefront per channel: (1) does the input hold a start-of-burst marker (a negative soft value); (2) the
@@ -326,8 +362,9 @@ __global__ __launch_bounds__(256) void k_aerol_scan(const AGeom g, const APtrs p
     const int nall = counts[ch];
     const int n = min(nall, 32768);
     const int16_t *sb = soft + (size_t)ch * stride;
-    // only a channel without data carrier consults the positions (a carrier cannot be lost inside a write: updateDCD runs between)
-    const bool want = g.oqpsk && !ALD(AI_DATACD);
+    // a channel without data carrier consults the positions everywhere, a locked one inside its detector windows (round 6: k_aerol_bits jumps those
+    // too); until then only unlocked channels were scanned
+    const bool want = g.oqpsk != 0;
     int neg = 0;
     for (int q = n + lane; q < nall; q += 64) neg |= (sb[q] < 0) ? 1 : 0; // beyond the scanned range: markers only
     for (int base = 0; base < n; base += 64)
@@ -389,11 +426,14 @@ __global__ __launch_bounds__(256) void k_aerol_bulk(const AGeom g, const APtrs p
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ch = blockIdx.x * 4 + w;
     if (ch >= g.nch) return;
-    const int len = ALD(AI_BULK_LEN);
-    if (len <= 0) return; // wave-uniform
-    const int flags = ALD(AI_BULK_FLAGS);
-    const int16_t *src = soft + (size_t)ch * stride + ALD(AI_BULK_SRC);
-    uint8_t *dst = p.rx + (size_t)ch * g.blocksz + ALD(AI_BULK_DST);
+    // two stretches per channel and round (k_aerol_bits: the frame body and the detector window behind it); they never overlap
+    for (int d = 0; d < 2; d++)
+    {
+    const int len = d ? ALD(AI_BULK2_LEN) : ALD(AI_BULK_LEN);
+    if (len <= 0) continue; // wave-uniform
+    const int flags = d ? ALD(AI_BULK2_FLAGS) : ALD(AI_BULK_FLAGS);
+    const int16_t *src = soft + (size_t)ch * stride + (d ? ALD(AI_BULK2_SRC) : ALD(AI_BULK_SRC));
+    uint8_t *dst = p.rx + (size_t)ch * g.blocksz + (d ? ALD(AI_BULK2_DST) : ALD(AI_BULK_DST));
     const int inv_first = (flags & 1) ? (flags >> 1) & 1 : (flags >> 2) & 1;   // arm of bit 0: imag if parity 1
     const int inv_second = (flags & 1) ? (flags >> 2) & 1 : (flags >> 1) & 1;
     auto conv = [](int v, int inv) -> unsigned {
@@ -411,6 +451,7 @@ __global__ __launch_bounds__(256) void k_aerol_bulk(const AGeom g, const APtrs p
     }
     const int i = n4 + lane;
     if (i < len) dst[i] = (uint8_t)conv(src[i], (i & 1) ? inv_second : inv_first);
+    }
 }
 
 // AeroLInterleaver::deinterleave_ba (aerol.cpp:603-625) for the channels that completed a block this round, one wavefront per

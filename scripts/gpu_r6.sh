@@ -63,6 +63,13 @@ if has pre8400; then
   python -c "import json;d=json.load(open('$OUT/bench_line_8400.json'));c=d['config'];print('oqpsk8400',d['value'],d['ms_per_step'],c['kernel_ms_per_step'],c.get('oracle_check',{}).get('hard_bits_equal'),c.get('oracle_check',{}).get('max_soft_byte_diff'))"
   f=$(find "$OUT/prof8400" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/kernel_stats_8400.csv" && grep -E "k_|Name" "$f" | cut -c1-160 | head -8
 fi
+if has aerolp; then
+  timeout 1200 python -m pytest tests -m gpu -q -k "aerol or recording" --tb=short 2>&1 | tail -8 | tee "$OUT/pytest_aerol.log"
+  for wl in aerol aerol_c aerol_burst; do
+    ( timeout 600 python bench.py --workload $wl --steps 12 --warmup 4 --no-cpu-baseline --as-written 0 2> "$OUT/bench_$wl.err" | tail -1 ) > "$OUT/bench_line_$wl.json"
+    python -c "import json;d=json.load(open('$OUT/bench_line_$wl.json'));c=d['config'];print('$wl',d['value'],d['ms_per_step'],c.get('kernel_ms_per_step'),str(c.get('oracle_check'))[:160])"
+  done
+fi
 if has tb600; then
   for v in product tb52 tb44; do
     L=$R/jaero_amd/libjaero_hip.so; [ $v != product ] && L=$R/gpurun_tmp/libjaero_hip_$v.so

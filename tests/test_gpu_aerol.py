@@ -68,6 +68,60 @@ def test_bank_vs_oracle(B, oracle_mod, force_viterbi_layout, fb, layout):
     bank.close()
 
 
+def test_unique_words_planted_in_the_detector_window(B, oracle_mod):
+    """Round 6: a LOCKED 10.5 kbps channel's detector is on for the last 325 soft bits of a frame, and k_aerol_bits jumps that stretch too (after the 64 bits
+    that flush the detector's shift registers) wherever k_aerol_scan saw no possible hit.  Here possible hits are planted there: the unique word or its complement
+    on ONE arm only (a lone hit flips that arm's polarity flag for the bits that follow, aerol.cpp:781-804), on both arms one bit apart (a false sync inside the
+    window), inside the first 64 bits of the window (where the registers still hold bits from before the frame body), and straddling the point where the
+    jump may begin.  Every channel against the oracle fed the same stream in the same ragged writes; two write widths so that windows meet write boundaries."""
+    fb, nch = 10500, 66
+    rng = np.random.default_rng(66)
+    uw = np.array([(0xE15AE893 >> (31 - k)) & 1 for k in range(32)], dtype=np.uint8)
+    streams = []
+    for c in range(nch):
+        pay = AF.random_payloads(6, fb, seed=3000 + c)
+        bits, _ = AF.p_channel_bits(pay, fb, invert_i=bool(c & 1), invert_q=bool(c & 2))
+        bits = bits.copy()
+        pre = rng.integers(0, 2, size=int(rng.integers(0, 700)), dtype=np.uint8)
+        # frame f occupies bits[5250 f : 5250 (f + 1)]: 64 unique-word bits (32 per arm), then 16 + 178 + 4992; the detector window of frame f are its last
+        # 325 - 64 = 261 body bits (pre-increment cntr 4925 .. 5185 counts from the end of the unique word)
+        for f in range(1, 5):
+            body_end = 5250 * (f + 1)                   # first bit of the NEXT frame's unique word
+            win0 = body_end - 261
+            kind = (c + f) % 6
+            if kind == 0:
+                continue
+            start = {1: win0 + 70, 2: win0 + 71, 3: win0 + 10, 4: win0 + 40, 5: win0 + 150}[kind] + int(rng.integers(0, 8)) * 2
+            word = uw if (c + f) & 1 else 1 - uw
+            arm = bits[start:start + 64:2]
+            if len(arm) == 32 and start + 64 < body_end - 2:
+                bits[start:start + 64:2] = word                           # one arm
+                if kind in (2, 5):
+                    bits[start + 1:start + 65:2] = word if kind == 2 else 1 - word  # the other arm, one bit later: a false sync (either polarity)
+        streams.append(AF.to_soft(np.concatenate([pre, bits]), sigma=float(rng.uniform(0, 20)), seed=c))
+    for width in (6000, 1777):
+        bank = B.AeroLBank(nch, fb, max_softbits_per_write=width, su_capacity=400)
+        pos = np.zeros(nch, dtype=np.int64)
+        lens = np.array([len(x) for x in streams])
+        wr = np.random.default_rng(width)
+        while (pos < lens).any():
+            cnt = np.minimum(wr.integers(max(1, width // 2), width, size=nch), lens - pos).astype(np.int32)
+            buf = np.zeros((nch, width), np.int16)
+            for c in range(nch):
+                buf[c, :cnt[c]] = streams[c][pos[c]:pos[c] + cnt[c]]
+            bank.write(buf, cnt)
+            pos += cnt
+        nclean = nev = 0
+        for c in range(nch):
+            o = oracle_mod.run_aerol(fb, streams[c], 1 << 20)
+            assert np.array_equal(bank.read_sus(c), o["sus"]), (width, c)
+            assert np.array_equal(bank.read_events(c), o["events"]), (width, c)
+            nclean += int(o["sus"][:, 14].sum())
+            nev += len(o["events"])
+        assert nclean > nch * 8 and nev > nch * 8  # frames without a planted word still decode; the planted hits show up as frame-length / sync events
+        bank.close()
+
+
 def test_start_of_burst_markers(B, oracle_mod):
     """Negative soft values (the burst demodulators' start-of-burst marker, aerol.cpp:1146-1152) in some channels' input: those
     channels are walked bit by bit for that write, their neighbours in the same wavefront keep jumping over locked frame bodies."""
