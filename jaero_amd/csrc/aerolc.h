@@ -173,17 +173,27 @@ __global__ __launch_bounds__(64) void k_aerolc_bits(const CGeom g, const CPtrs p
     for (int k = 0; k < 4; k++) p.B[(size_t)k * g.nchp + ch] = b[k];
 }
 
-// One wavefront per channel: stretch `k` (0 or 1) of those k_aerolc_bits jumped over in this round.  Launched once per k, in stream order:
-// a later stretch overwrites an earlier one's positions (a frame abandoned for a new unique word), and the kernel boundary is what orders
-// the two for every lane.  The walked soft bits of the same round never share a position with them (their cntr values lie outside
-// [2, CC_FRAME - 111]).
-__global__ __launch_bounds__(64) void k_aerolc_bulk(const CGeom g, const CPtrs p, const int16_t *__restrict__ soft, int stride, int k)
+// One wavefront per channel: the (at most two) stretches k_aerolc_bits jumped over in this round, in stream order: a later stretch overwrites an
+// earlier one's positions (a frame abandoned for a new unique word).  Both in ONE launch since round 6 (the second launch was ~65 000
+// workgroups that returned at once, every round): the wavefront finishes stretch 0 -- its stores made visible to the wavefront and retired -- before
+// it starts stretch 1.  The walked soft bits of the same round never share a position with them (their cntr values lie outside [2, CC_FRAME - 111]).
+__global__ __launch_bounds__(64) void k_aerolc_bulk(const CGeom g, const CPtrs p, const int16_t *__restrict__ soft, int stride, int konly)
 {
+    // konly < 0: both stretches (the product's one launch); 0 / 1: that stretch alone (tests/host_emul runs a workgroup's threads one after the other, where
+    // only a launch boundary orders the stretches)
     const int ch = blockIdx.x;
     if (ch >= g.nch) return;
-    if (k >= CLD(CI_BULK_N)) return;
+    const int nk = CLD(CI_BULK_N); // wave-uniform
     const int16_t *s = soft + (size_t)ch * stride;
     uint8_t *dep = p.dep + (size_t)ch * CC_PITCH;
+    for (int k = 0; k < nk && k < 2; k++)
+    {
+    if (konly >= 0 && k != konly) continue;
+    if (k > 0 && konly < 0)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
+    }
     const int f0 = CI_BULK0_SRC + 4 * k;
     const int src = p.I[(size_t)(f0 + 0) * g.nchp + ch], c0 = p.I[(size_t)(f0 + 1) * g.nchp + ch];
     const int len = p.I[(size_t)(f0 + 2) * g.nchp + ch], fl = p.I[(size_t)(f0 + 3) * g.nchp + ch];
@@ -196,6 +206,7 @@ __global__ __launch_bounds__(64) void k_aerolc_bulk(const CGeom g, const CPtrs p
         if (inverted) { if (soft_bit != 128) soft_bit = 255 - soft_bit; }
         const int di = cc_dep_index(c0 + j);
         if (di >= 0) dep[di] = (uint8_t)soft_bit;
+    }
     }
 }
 
@@ -398,8 +409,7 @@ static int aerolc_write(jaero_aerol_ctx *c, const int16_t *dsoft, const int *dco
     {
         aprof_begin(c, 0, st);
         hipLaunchKernelGGL(k_aerolc_bits, grid, block, 0, st, g, cs->p, dsoft, dcounts, stride);
-        hipLaunchKernelGGL(k_aerolc_bulk, dim3(g.nch), block, 0, st, g, cs->p, dsoft, stride, 0);
-        hipLaunchKernelGGL(k_aerolc_bulk, dim3(g.nch), block, 0, st, g, cs->p, dsoft, stride, 1); // (rare: most channels return at once)
+        hipLaunchKernelGGL(k_aerolc_bulk, dim3(g.nch), block, 0, st, g, cs->p, dsoft, stride, -1); // both stretches of a round, in order
         aprof_end(c, st);
         aprof_begin(c, 1, st);
         // one block per wavefront for small banks, one per lane (k_viterbi_lanes) from 16 384 channels on, as the P-channel pipeline

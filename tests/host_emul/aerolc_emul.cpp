@@ -15,6 +15,9 @@
 struct emul_dim { int x; };
 static thread_local emul_dim blockIdx, threadIdx, blockDim;
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+// k_aerolc_bulk orders its two stretches with a wavefront fence + vmcnt(0): here a workgroup's threads run one after the other
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 // AeroLcrc16::calcusingbytes as jaero_amd/csrc/k_aerol.h:aerol_crc16 has it
 static inline unsigned aerol_crc16(const uint8_t *bytes, int n)
 {
@@ -104,7 +107,7 @@ extern "C" void emul_write(Emul *e, const int16_t *soft, const int *counts, int 
     for (int r = 0; r < rounds; r++)
     {
         launch(g.nchp / 64, 64, [&] { k_aerolc_bits(g, e->p, soft, cnt.data(), stride); });
-        for (int k = 0; k < 2; k++) launch(g.nch, 64, [&] { k_aerolc_bulk(g, e->p, soft, stride, k); });
+        for (int k = 0; k < 2; k++) launch(g.nch, 64, [&] { k_aerolc_bulk(g, e->p, soft, stride, k); }); // (the product: one launch for both, konly = -1)
         for (int ch = 0; ch < g.nch; ch++) // k_viterbi + k_viterbi_overlap_update for the channels with a complete frame
             if (e->p.I[(size_t)CI_HAS_BLOCK * g.nchp + ch])
             {
