@@ -1520,11 +1520,6 @@ def main():
         except Exception as e:  # an edge operation that fails must not take the measured line with it
             edge = {"error": f"{type(e).__name__}: {e}"[:300]}
         dist.barrier()
-    edge_c = None
-    if world > 1 and shared:
-        edge_c = {"ok": None, "skipped": "ranks share a device (RCCL refuses two ranks on one GPU)"}
-    elif world > 1:
-        edge_c = edge_c_abi_check(rank, world, dev)
     bank.close()
     del pcm
     torch.cuda.empty_cache()
@@ -1549,6 +1544,14 @@ def main():
                               "note": "BASELINE configs[4] as written (32768 channels over 8 GPUs): 64 wavefronts per GPU on 1024 SIMDs, the small-bank rate"}
         except Exception as e:
             as_written = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    # The C-ABI edge operations LAST among the things that need every rank (the as-written banks above still use the control plane): if RCCL hangs in there,
+    # every rank times out in the check's closing all-reduce, rank 0 prints the measured line with the failure in it, and all ranks leave without a barrier.
+    edge_c = None
+    if world > 1 and shared:
+        edge_c = {"ok": None, "skipped": "ranks share a device (RCCL refuses two ranks on one GPU)"}
+    elif world > 1:
+        edge_c = edge_c_abi_check(rank, world, dev)
 
     if rank == 0:
         with_eb = bool(ARGS.ebno)
