@@ -22,6 +22,7 @@
 // first four-pair version, with the whole tail in the front half, spilled 458 registers and ran at 6.6.  The 160-tap filter (600 bps
 // at 48 kHz) keeps k_msk_samples.
 #pragma once
+#include <type_traits>
 #include "jaero_device.h"
 #include "k_oqpsk_fb.h" // fb_barrier, fb_wt_next, jd_div_const
 
@@ -46,6 +47,11 @@
 // scratch is slower still (3.4 against 2.3 Gsamples/s at 65 536 channels): occupancy, not the scratch traffic, decides there.
 #ifndef MFB2_LDSN
 #define MFB2_LDSN 72
+#endif
+#ifndef MFB_LAZY_K
+#define MFB_LAZY_K 2 // the back half's register tail moves every MFB_LAZY_K-th sample, by MFB_LAZY_K places (see mfb_back): 1 / 2 / 4 / 8 measured at 600 bps =
+                     // 28.7 / 28.4 / 30.6 / 31.4 ms per step -- every further version of the 60-term sum is 3 KB more code in a loop that already fills
+                     // the instruction cache two CUs share (front half 8 versions x ~600 instructions + back half ~2 600), and that costs more than the moves
 #endif
 #ifndef MFB2_TB
 #define MFB2_TB 60 // round 5, with the filter op for op: 40 / 52 / 60 / 68 measured 5 621 / 5 998 / 6 145 / 6 130 Msamples/s at 65 536 channels
@@ -108,7 +114,11 @@ __device__ __forceinline__ void mfb_fir_continue(const double *lre, const double
 // r of it, m = (BV + k) / BS and r = (BV + k) % BS -- both compile-time constants once BV is (a switch over the BS values of BV picks the version, as
 // k_oqpsk_fb's filter does over all its 36 ring positions).  The NB + 1 block addresses (per lane) are formed once per sample; every read is then
 // `base register + immediate offset`, and so are the tap reads (tapz: a zero the compiler cannot see through).  Same terms, same order, same sums.
-template <int LDSN> constexpr int mfb_bs() { return (LDSN % 8 == 0) ? 8 : 4; }
+#ifndef MFB_BS_MAX
+#define MFB_BS_MAX 4 // ring blocks of 4 slots = 4 versions of the front half's sum: 8 / 4 / 2 measured: 600 bps 28.4 / 27.9 / 29.7 ms, 1200 bps (four pairs) 15.2 / 14.1 / 16.3 ms
+                     // per step -- half the code for nine more block addresses per sample (profiles/r6_msk600_trace.md)
+#endif
+template <int LDSN> constexpr int mfb_bs() { return (LDSN % 8 == 0 && MFB_BS_MAX >= 8) ? 8 : (MFB_BS_MAX >= 4 ? 4 : 2); }
 template <int FIRN, int LDSN, int D, int T0, int BV, int TAILA, int NBA>
 __device__ __forceinline__ void mfb_fir_continue_v(const double *lre, const double *ltap, const double (&tre)[TAILA], const double (&tim)[TAILA],
                                                    const int (&blk)[NBA], int tapz, double are0, double aim0, double &ore, double &oim)
@@ -233,7 +243,7 @@ __device__ __forceinline__ void mfb_front(const JGeom &g, const JPtrs &p, const 
                 if (t >= NB) t -= NB;
                 blk[m] = t * BS * 64 + lane;
             }
-#define MFB_V(B) case B: mfb_fir_continue_v<FIRN, LDSN, 8, TB, B>(lre, ltap, tre, tim, blk, tapz, a0, a1, ore, oim); break;
+#define MFB_V(B) case B: if constexpr (B < BS) mfb_fir_continue_v<FIRN, LDSN, 8, TB, B>(lre, ltap, tre, tim, blk, tapz, a0, a1, ore, oim); break;
             switch (fir_slot % BS)
             {
                 MFB_V(0) MFB_V(1) MFB_V(2) MFB_V(3)
@@ -401,8 +411,15 @@ template <bool CAPSYM, int FIRN, int LDSN, int TB>
 __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const MfbLds &L, int n, int only_a_last, int dly_slot0, int d8_slot0,
                                          int grp, int lane)
 {
-    constexpr int TBA = TB > 0 ? TB : 1, TF = FIRN - LDSN - TB;
-    double tbr[TBA], tbi[TBA]; // TB > 0: the TB oldest history entries of each arm, tbr[0] the newest of them
+    constexpr int TF = FIRN - LDSN - TB;
+    // TB > 0: the TB oldest history entries of each arm live in this half's registers.  They do not move one place per sample (60 entries of two arms:
+    // ~450 register moves a sample at 600 bps, most of them in and out of accumulation registers -- profiles/r6_msk600_trace.md): entry j (0 = the
+    // newest) is at tbr[tb_s + j], a new entry goes in BELOW the others (tb_s - 1), and only when tb_s is 0 do all move up, by KL places at once.
+    // tb_s is wave-uniform, the sample loop switches over it, every register index below is a compile-time one.
+    constexpr int KL = TB > 0 ? MFB_LAZY_K : 1;
+    constexpr int TBA = TB > 0 ? TB + KL - 1 : 1;
+    double tbr[TBA], tbi[TBA];
+    int tb_s = KL - 1;
     double acc_prev_re = 0, acc_prev_im = 0, acc_last_re = 0, acc_last_im = 0, xin_re = 0, xin_im = 0;
     const int ch = grp * 64 + lane;
     const int nchp = g.nchp;
@@ -434,16 +451,30 @@ __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const M
     // sum over this half's entries, oldest first: taps[t] <-> tb[TB - 1 - t]
     int tapz; // a zero in a vector register: the tap reads below become `register + immediate offset` instead of a v_mov of a constant address each (mfb_fir_continue_v)
     asm volatile("v_mov_b32 %0, 0" : "=v"(tapz));
-    auto tail_sum = [&](double &ore, double &oim) __attribute__((always_inline)) {
+    auto tail_sum = [&](auto sv, double &ore, double &oim) __attribute__((always_inline)) {
+        constexpr int SV = decltype(sv)::value;
         double are = 0, aim = 0;
 #pragma unroll
         for (int t = 0; t < TB; t++)
         {
             const double tp = L.ltap[tapz + t];
-            are = are + tp * tbr[TB - 1 - t];
-            aim = aim + tp * tbi[TB - 1 - t];
+            are = are + tp * tbr[SV + TB - 1 - t];
+            aim = aim + tp * tbi[SV + TB - 1 - t];
         }
         ore = are; oim = aim;
+    };
+    // a new entry joins the tail (the oldest drops out), then the sum over it; SV = tb_s before
+    auto tail_push_sum = [&](auto sv, double xr, double xi, double &ore, double &oim) __attribute__((always_inline)) {
+        constexpr int SV = decltype(sv)::value;
+        constexpr int SN = SV == 0 ? KL - 1 : SV - 1;
+        if constexpr (SV == 0)
+        {
+#pragma unroll
+            for (int j = TB - 2; j >= 0; j--) { tbr[j + KL] = tbr[j]; tbi[j + KL] = tbi[j]; }
+        }
+        tbr[SN] = xr; tbi[SN] = xi;
+        tail_sum(std::integral_constant<int, SN>{}, ore, oim);
+        tb_s = SN;
     };
     if constexpr (TB > 0)
     {
@@ -452,7 +483,7 @@ __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const M
         // over the tail as saved; the entry arriving during sample 0 is what the front half would have handed over: its tail entry TF - 2
         const double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
 #pragma unroll
-        for (int j = 0; j < TB; j++) { tbr[j] = fs[(size_t)(LDSN + TF + j) * 64]; tbi[j] = fs[(size_t)(FIRN + LDSN + TF + j) * 64]; }
+        for (int j = 0; j < TB; j++) { tbr[KL - 1 + j] = fs[(size_t)(LDSN + TF + j) * 64]; tbi[KL - 1 + j] = fs[(size_t)(FIRN + LDSN + TF + j) * 64]; }
         xin_re = fs[(size_t)(LDSN + TF - 2) * 64]; xin_im = fs[(size_t)(FIRN + LDSN + TF - 2) * 64];
         acc_prev_re = LDF(S_MFB_A0_RE); acc_prev_im = LDF(S_MFB_A0_IM);
         // the front half fills its LDS copy of the taps before its first barrier, this half reads them behind it: use the bank's table here
@@ -462,8 +493,8 @@ __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const M
             for (int t = 0; t < TB; t++)
             {
                 const double tp = p.taps2[t];
-                are = are + tp * tbr[TB - 1 - t];
-                aim = aim + tp * tbi[TB - 1 - t];
+                are = are + tp * tbr[KL - 1 + TB - 1 - t];
+                aim = aim + tp * tbi[KL - 1 + TB - 1 - t];
             }
             acc_last_re = are; acc_last_im = aim;
         }
@@ -575,11 +606,14 @@ __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const M
             // the entry the front half announced during the previous sample joins this tail; the sum over it is what the front half
             // starts from when it forms sample i + 2 (during sample i + 1)
             if (i > 0) { const double *o = L.oldx + (i & 1) * 2 * 64 + lane; xin_re = o[0]; xin_im = o[64]; }
-#pragma unroll
-            for (int j = TB - 1; j > 0; j--) { tbr[j] = tbr[j - 1]; tbi[j] = tbi[j - 1]; }
-            tbr[0] = xin_re; tbi[0] = xin_im;
             acc_prev_re = acc_last_re; acc_prev_im = acc_last_im;
-            tail_sum(acc_last_re, acc_last_im);
+            switch (tb_s)
+            {
+// (the marker keeps the optimiser from sinking the cases' common tails into one block that indexes the registers through a phi, i.e. through scratch memory)
+#define MFB_TC(V) case V: if constexpr (V < KL) { tail_push_sum(std::integral_constant<int, V>{}, xin_re, xin_im, acc_last_re, acc_last_im); asm volatile("; tail phase %0" ::"n"(V)); } break;
+                MFB_TC(0) MFB_TC(1) MFB_TC(2) MFB_TC(3) MFB_TC(4) MFB_TC(5) MFB_TC(6) MFB_TC(7)
+#undef MFB_TC
+            }
             double *a = L.acc + (i & 1) * 2 * 64 + lane; // (i + 2) & 1
             a[0] = acc_last_re; a[64] = acc_last_im;
         }
@@ -673,8 +707,12 @@ __device__ __forceinline__ void mfb_back(const JGeom &g, const JPtrs &p, const M
         // next launch: its sample 0 starts from the sum formed for sample nB (acc_prev after nB steps), its tail is this one
         LDF(S_MFB_A0_RE) = acc_prev_re; LDF(S_MFB_A0_IM) = acc_prev_im;
         double *fs = p.firsave + (size_t)grp * 2 * FIRN * 64 + lane;
-#pragma unroll
-        for (int j = 0; j < TB; j++) { fs[(size_t)(LDSN + TF + j) * 64] = tbr[j]; fs[(size_t)(FIRN + LDSN + TF + j) * 64] = tbi[j]; }
+        switch (tb_s)
+        {
+#define MFB_TS(V) case V: if constexpr (V < KL) { _Pragma("unroll") for (int j = 0; j < TB; j++) { fs[(size_t)(LDSN + TF + j) * 64] = tbr[V + j]; fs[(size_t)(FIRN + LDSN + TF + j) * 64] = tbi[V + j]; } } break;
+            MFB_TS(0) MFB_TS(1) MFB_TS(2) MFB_TS(3) MFB_TS(4) MFB_TS(5) MFB_TS(6) MFB_TS(7)
+#undef MFB_TS
+        }
     }
 }
 
