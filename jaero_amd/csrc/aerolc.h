@@ -18,7 +18,7 @@
 #define CC_NSOFT 5460  // depunctured soft symbols per frame
 #define CC_PITCH 5472  // distance between the rows of CcParams::dep: CC_NSOFT rounded up to 16 bytes, so that k_viterbi_lanes reads aligned 16-byte groups
 #define CC_NBITS 2714  // decoded bits kept per frame
-#define CC_DL2 2709    // DelayLine(2714 - 6): ring of length + 1
+#define CC_PREV_PITCH 2720 // distance between the rows of CPtrs::dl2 (the previous frame's CC_NBITS decoded bits: what DelayLine(2714 - 6) holds), 16-byte aligned
 #define CC_FRAME 4096  // channel bits per frame after the unique word
 #define CC_MASK52 ((1ull << 52) - 1ull)
 #define CC_UW1 216866263330005ull
@@ -46,8 +46,9 @@ struct CPtrs
     uint8_t *dep;                // [nchp][CC_PITCH] (CC_NSOFT used) deinterleaved + depunctured soft symbols of the frame being received
     uint8_t *vbits;              // [nchp][CC_NSOFT / 2] Viterbi output, one byte per bit
     uint8_t *overlap;            // [nchp][64] Decode_Continuous overlap (byte 62 = length)
-    uint8_t *dl2;                // [CC_DL2][nchp] delay line
+    uint8_t *dl2;                // [nchp][CC_PREV_PITCH] delay line = the decoded bits of the frame finished before (k_aerolc_post)
     const uint8_t *scr;          // [5000] scrambler sequence
+    const unsigned long long *scrf; // [25][2] the same by primary field: bit i of the pair y = scr[109 y + 1 + i], i < 108 (k_aerolc_post)
     int32_t *sus;                // [nchp][su_cap][16]  rows [frame, k, 12 bytes, crc_ok, 0]
     uint8_t *voice;              // [nchp][v_cap][304]  rows: uint32 frame, 300 voice bytes
     long long *events;           // [nchp][ev_cap][3]   rows [soft-bit index, kind (0 DCD, 2 sync), value]
@@ -129,41 +130,64 @@ __global__ __launch_bounds__(64) void k_aerolc_bits(const CGeom g, const CPtrs p
                 continue;
             }
         }
-        const int sv = s[pos];
-        int bit = (((unsigned char)sv) >= 128) ? 1 : 0;
-        unsigned soft_bit = (unsigned)(unsigned short)sv;
-        int gotsync = 0;
-        realimag++; realimag %= 2;
-        const int q = realimag ? 0 : 1; // realimag != 0: preambledetectorreal
-        if (cntr > CC_FRAME - 112 || cntr <= 0)
-        {
-            gotsync = q == 0 ? cc_detect(b[0], b[1], bit, inv[0]) : cc_detect(b[2], b[3], bit, inv[1]);
-            if (!gslast) { gslast = gotsync; gotsync = 0; }
-            else gslast = 0;
-        }
-        else { gotsync = 0; gslast = 0; }
-        if (inv[q])
-        {
-            bit = 1 - bit;
-            if (soft_bit > 128) soft_bit = 255 - soft_bit;
-            else if (soft_bit < 128) soft_bit = 255 - soft_bit;
-        }
-        if (gotsync)
-        {
-            cntr = -1; // index = -1, deleaveredBlock / depuncturedBlock emptied, scrambler reset: implicit (positions are absolute)
-            cc_event(g, p, ch, ev_cnt, overflow, base + pos, 2, 1);
-        }
+        // Eight soft bits per request (round 6): one 2-byte load per bit meant one wait per bit for everything in flight -- vmcnt retires in order, the
+        // frame-buffer stores included (~2 us per walked bit; a frame has ~216 of them).  The bits are then taken one by one exactly as before; a lane
+        // leaves the group early where the loop above would have done something else first (end of the write, a finished frame, a stretch to jump).
+        short v8[8];
+        if (n - pos >= 8) __builtin_memcpy(v8, s + pos, 16);
         else
         {
-            if (cntr < 1000000000) cntr++;
-            if (cntr <= CC_FRAME - 1)
-            {
-                const int di = cc_dep_index(cntr);
-                if (di >= 0) dep[di] = (uint8_t)soft_bit;
-            }
-            if (cntr == CC_FRAME - 1) has = 1;
+#pragma unroll
+            for (int k = 0; k < 8; k++) v8[k] = (pos + k < n) ? s[pos + k] : (short)0;
         }
-        pos++;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            if (k > 0)
+            {
+                if (pos >= n || has) break;
+                if (cntr >= 1 && cntr <= CC_FRAME - 112)
+                {
+                    const int room = (CC_FRAME - 112) - cntr + 1, left = n - pos;
+                    if ((room < left ? room : left) >= CC_MINRUN) break;
+                }
+            }
+            const int sv = v8[k];
+            int bit = (((unsigned char)sv) >= 128) ? 1 : 0;
+            unsigned soft_bit = (unsigned)(unsigned short)sv;
+            int gotsync = 0;
+            realimag++; realimag %= 2;
+            const int q = realimag ? 0 : 1; // realimag != 0: preambledetectorreal
+            if (cntr > CC_FRAME - 112 || cntr <= 0)
+            {
+                gotsync = q == 0 ? cc_detect(b[0], b[1], bit, inv[0]) : cc_detect(b[2], b[3], bit, inv[1]);
+                if (!gslast) { gslast = gotsync; gotsync = 0; }
+                else gslast = 0;
+            }
+            else { gotsync = 0; gslast = 0; }
+            if (inv[q])
+            {
+                bit = 1 - bit;
+                if (soft_bit > 128) soft_bit = 255 - soft_bit;
+                else if (soft_bit < 128) soft_bit = 255 - soft_bit;
+            }
+            if (gotsync)
+            {
+                cntr = -1; // index = -1, deleaveredBlock / depuncturedBlock emptied, scrambler reset: implicit (positions are absolute)
+                cc_event(g, p, ch, ev_cnt, overflow, base + pos, 2, 1);
+            }
+            else
+            {
+                if (cntr < 1000000000) cntr++;
+                if (cntr <= CC_FRAME - 1)
+                {
+                    const int di = cc_dep_index(cntr);
+                    if (di >= 0) dep[di] = (uint8_t)soft_bit;
+                }
+                if (cntr == CC_FRAME - 1) has = 1;
+            }
+            pos++;
+        }
     }
     CLD(CI_POS) = pos; CLD(CI_HAS_BLOCK) = has; CLD(CI_BULK_N) = nbulk;
     CLD(CI_CNTR) = cntr; CLD(CI_REALIMAG) = realimag; CLD(CI_GSLAST) = gslast;
@@ -173,40 +197,95 @@ __global__ __launch_bounds__(64) void k_aerolc_bits(const CGeom g, const CPtrs p
     for (int k = 0; k < 4; k++) p.B[(size_t)k * g.nchp + ch] = b[k];
 }
 
+// depunctured position's source index (0 .. CC_FRAME - 2) -> received index cntr: the inverse of cc_dep_index's first half (19 * 27 = 1 mod 64)
+__device__ __forceinline__ int cc_cntr_of_src(int src)
+{
+    const int w = src & 255;
+    return (src & ~255) + ((((w & 63) * 27) & 63) << 2) + (w >> 6);
+}
+
 // One wavefront per channel: the (at most two) stretches k_aerolc_bits jumped over in this round, in stream order: a later stretch overwrites an
 // earlier one's positions (a frame abandoned for a new unique word).  Both in ONE launch since round 6 (the second launch was ~65 000
 // workgroups that returned at once, every round): the wavefront finishes stretch 0 -- its stores made visible to the wavefront and retired -- before
 // it starts stretch 1.  The walked soft bits of the same round never share a position with them (their cntr values lie outside [2, CC_FRAME - 111]).
-__global__ __launch_bounds__(64) void k_aerolc_bulk(const CGeom g, const CPtrs p, const int16_t *__restrict__ soft, int stride, int konly)
+// Round 6, second half: driven by the OUTPUT.  Source order meant one byte store per soft bit, the 64 lanes of every store instruction in 64 different
+// 64-byte lines of the frame buffer (the interleaver spreads neighbours 85 positions apart): 4096 partial-line writes per frame, 0.97 ms per 65 536-channel
+// step.  Now the stretch is staged in LDS (16-byte loads, coalesced), and a lane forms four consecutive bytes of the frame buffer -- three soft bits
+// looked up in LDS through the inverse permutation and the erasure byte every fourth position holds (128, never anything else: aerolc_create) -- and
+// stores them as one word, 256 contiguous bytes per store instruction; words with a position outside the stretch (the 112 positions of the unique-word
+// window, and stretches cut by a write boundary) store their bytes singly.
+// phase: -1 = stage, then emit (the device); 0 / 1 = one of the two (tests/host_emul runs a workgroup's threads one after the other: every thread stages
+// before any emits); konly likewise >= 0 only there.
+#ifndef AEROLC_KERNELS_ONLY
+#define CC_BULK_SYNC() __syncthreads()
+#endif
+__global__ __launch_bounds__(64) void k_aerolc_bulk(const CGeom g, const CPtrs p, const int16_t *__restrict__ soft, int stride, int konly, int phase)
 {
-    // konly < 0: both stretches (the product's one launch); 0 / 1: that stretch alone (tests/host_emul runs a workgroup's threads one after the other, where
-    // only a launch boundary orders the stretches)
+    __shared__ __attribute__((aligned(16))) int16_t row[CC_FRAME + 8];
     const int ch = blockIdx.x;
     if (ch >= g.nch) return;
     const int nk = CLD(CI_BULK_N); // wave-uniform
     const int16_t *s = soft + (size_t)ch * stride;
     uint8_t *dep = p.dep + (size_t)ch * CC_PITCH;
+    const int tid = threadIdx.x;
     for (int k = 0; k < nk && k < 2; k++)
     {
-    if (konly >= 0 && k != konly) continue;
-    if (k > 0 && konly < 0)
-    {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
-    }
-    const int f0 = CI_BULK0_SRC + 4 * k;
-    const int src = p.I[(size_t)(f0 + 0) * g.nchp + ch], c0 = p.I[(size_t)(f0 + 1) * g.nchp + ch];
-    const int len = p.I[(size_t)(f0 + 2) * g.nchp + ch], fl = p.I[(size_t)(f0 + 3) * g.nchp + ch];
-    for (int j = threadIdx.x; j < len; j += blockDim.x)
-    {
-        const int sv = s[src + j];
-        unsigned soft_bit = (unsigned)(unsigned short)sv;
-        const int realimag = ((fl & 1) + j + 1) & 1;         // toggled before the bit is used (:2207)
-        const int inverted = realimag ? (fl & 2) : (fl & 4); // realimag != 0: the real arm's detector and flag
-        if (inverted) { if (soft_bit != 128) soft_bit = 255 - soft_bit; }
-        const int di = cc_dep_index(c0 + j);
-        if (di >= 0) dep[di] = (uint8_t)soft_bit;
-    }
+        if (konly >= 0 && k != konly) continue;
+        if (k > 0 && konly < 0)
+        {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
+            CC_BULK_SYNC(); // every lane has read what it needs of stretch 0 from LDS
+        }
+        const int f0 = CI_BULK0_SRC + 4 * k;
+        const int src = p.I[(size_t)(f0 + 0) * g.nchp + ch], c0 = p.I[(size_t)(f0 + 1) * g.nchp + ch];
+        const int len = p.I[(size_t)(f0 + 2) * g.nchp + ch], fl = p.I[(size_t)(f0 + 3) * g.nchp + ch];
+        if (phase != 1)
+        {
+            for (int j8 = tid * 8; j8 < len; j8 += 64 * 8)
+            {
+                if (j8 + 8 <= len) __builtin_memcpy(row + j8, s + src + j8, 16);
+                else for (int j = j8; j < len; j++) row[j] = s[src + j];
+            }
+        }
+        if (phase < 0) CC_BULK_SYNC();
+        if (phase != 0)
+        {
+            // the words that hold positions of [c0, c0 + len): cntr -> source index is monotonic in neither direction, so all CC_NSOFT / 4 words are looked at
+            for (int m = tid; m < CC_NSOFT / 4; m += 64)
+            {
+                unsigned word = 128u << 24;
+                int inside = 0;
+                unsigned char bytes[3];
+#pragma unroll
+                for (int e = 0; e < 3; e++)
+                {
+                    const int j = cc_cntr_of_src(3 * m + e) - c0;
+                    const bool in = j >= 0 && j < len;
+                    unsigned soft_bit = 0;
+                    if (in)
+                    {
+                        soft_bit = (unsigned)(unsigned short)row[j];
+                        const int realimag = ((fl & 1) + j + 1) & 1;         // toggled before the bit is used (:2207)
+                        const int inverted = realimag ? (fl & 2) : (fl & 4); // realimag != 0: the real arm's detector and flag
+                        if (inverted) { if (soft_bit != 128) soft_bit = 255 - soft_bit; }
+                        inside++;
+                    }
+                    bytes[e] = (unsigned char)soft_bit;
+                    word |= (soft_bit & 255u) << (8 * e);
+                }
+                if (inside == 3) *(unsigned *)(dep + 4 * m) = word;
+                else if (inside > 0)
+                {
+#pragma unroll
+                    for (int e = 0; e < 3; e++)
+                    {
+                        const int j = cc_cntr_of_src(3 * m + e) - c0;
+                        if (j >= 0 && j < len) dep[4 * m + e] = bytes[e];
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -217,7 +296,7 @@ __global__ __launch_bounds__(64) void k_aerolc_post(const CGeom g, const CPtrs p
     if (ch >= g.nch) return;
     if (!CLD(CI_HAS_BLOCK)) return;
     const uint8_t *vb = p.vbits + (size_t)ch * (CC_NSOFT / 2);
-    int dl2_ptr = CLD(CI_DL2_PTR), datacd = CLD(CI_DATACD), dcdcount = CLD(CI_DCDCOUNT);
+    int datacd = CLD(CI_DATACD), dcdcount = CLD(CI_DCDCOUNT);
     int ev_cnt = CLD(CI_EV_CNT), overflow = CLD(CI_OVERFLOW), su_cnt = CLD(CI_SU_CNT), v_cnt = CLD(CI_V_CNT);
     const int nframes = CLD(CI_NFRAMES);
     const long long bitidx = (((long long)(unsigned)CLD(CI_NBITS_LO)) | ((long long)CLD(CI_NBITS_HI) << 32)) + CLD(CI_POS) - 1;
@@ -229,57 +308,68 @@ __global__ __launch_bounds__(64) void k_aerolc_post(const CGeom g, const CPtrs p
         v_cnt++;
     }
     else overflow |= 4;
-    // one pass over the 2714 bits: delay line (:2330), scrambler (:2333), then both extractions read the same descrambled bit h
-    unsigned char info[12]; int ninfo = 0, sch = 0, scharptr = 0, kk = 0; // sub-band units (:2343-2358)
-    int vch = 0, vcharptr = 0, nv = 0;                                      // voice bytes (:2454-2478)
-    // CB bits per batch (round 5): a bit's step through the delay line is a store at the ring pointer and a load one slot further -- the oldest
-    // entry, written 2708 steps ago -- so within a batch the loads touch slots ptr + 1 .. ptr + CB and the stores slots ptr .. ptr + CB - 1:
-    // issued loads first, then stores, every load still sees what the bit-by-bit order shows it (load k reads the slot store k + 1 overwrites), and
-    // the round trips to memory overlap instead of following one another (0.83 us per bit before: 2.25 ms per 65 536-channel step; batches of
-    // 8: 1.24 ms, of 16: 1.13 ms).
-    constexpr int CB = 16;
-    for (int h0 = 0; h0 < CC_NBITS; h0 += CB)
+    // The 2714 bits of a frame are 25 primary fields of 109: bit 0 unused, 96 voice bits = 12 bytes, 12 sub-band bits (fields 0..23; the 25th ends
+    // after its sub-band bit 0, unused); a sub-band unit is 96 sub-band bits = fields 8 k .. 8 k + 7.  DecodeC goes bit by bit: delay line (:2330), scrambler
+    // (:2333), then the two extractions (:2343-2358, :2454-2478), each a shift register with a modulo-8 counter.  Here one field per iteration, its structure
+    // known at compile time -- the bit-by-bit form of this kernel, unrolled by 64 bits with every branch of the reference inside, was 150 KB of code
+    // (the instruction cache two CUs share holds 64) and ran at ~600 cycles per bit.
+    // The delay line (DelayLine(2714 - 6)) hands back, for bit h of a frame, the bit pushed 2708 steps earlier.  Only this kernel pushes, 2714 bits per
+    // finished frame, so that bit is bit h + 6 of the frame finished before this one (h < 2708) or bit h - 2708 of this frame: the line IS the previous
+    // frame's decoded bits.  Until round 6 it was a byte ring [slot][channel] with a byte load and a byte store per bit; now p.dl2 keeps the previous
+    // frame's 2714 bytes per channel (positions the codec's first call does not produce stay what they were, as in vbits), read 16 bytes at a time and
+    // replaced by this frame's after the last field.
+    uint8_t *prev = p.dl2 + (size_t)ch * CC_PREV_PITCH;
+    // four bytes that are 0 or 1 -> their four bits (byte 0 -> bit 0): the products' partial terms meet in no bit, so nothing carries into bits 28..31
+    auto nib = [](unsigned w) __attribute__((always_inline)) { return (w * 0x10204080u) >> 28; };
+    unsigned long long sb_lo = 0, sb_hi = 0; // the sub-band unit being collected, first bit in bit 0 of sb_lo
+    int kk = 0;
+#pragma unroll 1
+    for (int y = 0; y < 25; y++)
     {
-        const int nb = (CC_NBITS - h0) < CB ? (CC_NBITS - h0) : CB;
-        int vin[CB], vold[CB];
+        const int hb = 109 * y;
+        // d[i] = the delayed bits of this field from its bit 1 on (i = 0 .. 107), four to a word: frame bit hb + 1 + i <- previous frame's bit hb + 7 + i
+        unsigned d[27];
 #pragma unroll
-        for (int k = 0; k < CB; k++) vin[k] = (k < nb) ? vb[h0 + k] : 0; // positions the first call of the codec does not produce stay 0 (buffer zeroed at create)
-#pragma unroll
-        for (int k = 0; k < CB; k++)
+        for (int k = 0; k < 6; k++) __builtin_memcpy(d + 4 * k, prev + hb + 7 + 16 * k, 16);
+        __builtin_memcpy(d + 24, prev + hb + 7 + 96, 12); // (field 24: reads up to byte 2730 of a 2720-byte row; the rows are followed by 64 spare bytes)
+        if (y == 24)
         {
-            int q = dl2_ptr + k + 1; if (q >= CC_DL2) q -= CC_DL2;
-            vold[k] = (k < nb) ? (int)p.dl2[(size_t)q * g.nchp + ch] : 0;
+            // frame bits 2708 .. 2712 (field bits 92 .. 96 = d bytes 91 .. 95) come from this frame's bits 0 .. 4
+            unsigned char c5[8];
+#pragma unroll
+            for (int k = 0; k < 5; k++) c5[k] = vb[k];
+            d[22] = (d[22] & 0x00FFFFFFu) | ((unsigned)c5[0] << 24);
+            d[23] = (unsigned)c5[1] | ((unsigned)c5[2] << 8) | ((unsigned)c5[3] << 16) | ((unsigned)c5[4] << 24);
         }
+        const unsigned long long s0 = p.scrf[2 * y], s1 = p.scrf[2 * y + 1]; // the scrambler's bits for field bits 1 .. 108, bit i of the pair = field bit 1 + i
+        unsigned vw[3];
 #pragma unroll
-        for (int k = 0; k < CB; k++)
+        for (int q = 0; q < 3; q++)
         {
-            int q = dl2_ptr + k; if (q >= CC_DL2) q -= CC_DL2;
-            if (k < nb) p.dl2[(size_t)q * g.nchp + ch] = (uint8_t)vin[k];
-        }
-        dl2_ptr += nb; if (dl2_ptr >= CC_DL2) dl2_ptr -= CC_DL2;
+            unsigned w = 0;
 #pragma unroll
-        for (int k = 0; k < CB; k++)
-        {
-        if (k >= nb) break;
-        const int h = h0 + k;
-        int v = vold[k];
-        v ^= p.scr[h];
-        const int y = h / 109, o = h - y * 109; // primary field y: bit 0, 96 voice bits (1..96), 12 sub-band bits (97..108)
-        if (o >= 1 && o <= 96)
-        {
-            vch |= v * 128;
-            vcharptr++; vcharptr %= 8;
-            if (vcharptr == 0) { if (vrow && nv < 300) vrow[4 + nv] = (uint8_t)vch; nv++; vch = 0; }
-            else vch >>= 1;
+            for (int b = 0; b < 4; b++) w |= (nib(d[8 * q + 2 * b]) | (nib(d[8 * q + 2 * b + 1]) << 4)) << (8 * b);
+            const unsigned sw = (q == 0) ? (unsigned)s0 : (q == 1 ? (unsigned)(s0 >> 32) : (unsigned)s1);
+            vw[q] = w ^ sw;
         }
-        else if (o >= 97 && y < 24)
+        if (vrow)
         {
-            sch |= v * 128;
-            scharptr++; scharptr %= 8;
-            if (scharptr == 0) { info[ninfo++] = (unsigned char)sch; sch = 0; }
-            else sch >>= 1;
-            if (o == 108 && ninfo == 12)
+            unsigned *vp = (unsigned *)(vrow + 4 + 12 * y);
+            vp[0] = vw[0]; vp[1] = vw[1]; vp[2] = vw[2];
+        }
+        if (y < 24)
+        {
+            const unsigned sb12 = (nib(d[24]) | (nib(d[25]) << 4) | (nib(d[26]) << 8)) ^ ((unsigned)(s1 >> 32) & 0xFFFu);
+            const int pos = 12 * (y & 7); // wave-uniform
+            if (pos < 64) sb_lo |= (unsigned long long)sb12 << pos;
+            if (pos > 52) sb_hi |= pos >= 64 ? ((unsigned long long)sb12 << (pos - 64)) : ((unsigned long long)sb12 >> (64 - pos));
+            if ((y & 7) == 7)
             {
+                unsigned char info[12];
+#pragma unroll
+                for (int j = 0; j < 8; j++) info[j] = (unsigned char)(sb_lo >> (8 * j));
+#pragma unroll
+                for (int j = 0; j < 4; j++) info[8 + j] = (unsigned char)(sb_hi >> (8 * j));
                 const unsigned crc_calc = aerol_crc16(info, 10);
                 const unsigned crc_rec = ((unsigned)info[11] << 8) | info[10];
                 if (crc_calc == crc_rec) { if (dcdcount < 12) dcdcount += 2; }
@@ -295,12 +385,21 @@ __global__ __launch_bounds__(64) void k_aerolc_post(const CGeom g, const CPtrs p
                 }
                 else overflow |= 1;
                 kk++;
-                ninfo = 0;
+                sb_lo = 0; sb_hi = 0;
             }
         }
-        }
     }
-    CLD(CI_DL2_PTR) = dl2_ptr; CLD(CI_DATACD) = datacd; CLD(CI_DCDCOUNT) = dcdcount;
+    // this frame's bits become the delay line's content
+#pragma unroll 2
+    for (int k = 0; k < CC_PREV_PITCH; k += 80)
+    {
+        unsigned long long t[10];
+#pragma unroll
+        for (int q = 0; q < 5; q++) __builtin_memcpy(&t[2 * q], vb + k + 16 * q, 16);
+#pragma unroll
+        for (int q = 0; q < 5; q++) __builtin_memcpy(prev + k + 16 * q, &t[2 * q], 16);
+    }
+    CLD(CI_DATACD) = datacd; CLD(CI_DCDCOUNT) = dcdcount;
     CLD(CI_EV_CNT) = ev_cnt; CLD(CI_OVERFLOW) = overflow; CLD(CI_SU_CNT) = su_cnt; CLD(CI_V_CNT) = v_cnt;
     CLD(CI_NFRAMES) = nframes + 1;
     CLD(CI_HAS_BLOCK) = 0;
@@ -358,13 +457,15 @@ static int aerolc_create(jaero_aerol_ctx *c, int nchannels, int su_capacity)
     CA(cs->p.dep, (size_t)g.nchp * CC_PITCH);
     CA(cs->p.vbits, (size_t)g.nchp * (CC_NSOFT / 2));
     CA(cs->p.overlap, (size_t)g.nchp * 64);
-    CA(cs->p.dl2, (size_t)CC_DL2 * g.nchp);
+    CA(cs->p.dl2, (size_t)CC_PREV_PITCH * g.nchp + 64);
     CA(cs->p.sus, (size_t)g.nchp * g.su_cap * 16);
     CA(cs->p.voice, (size_t)g.nchp * g.v_cap * 304);
     CA(cs->p.events, (size_t)g.nchp * g.ev_cap * 3);
     if (viterbi_use_lanes(g.nch, CC_NSOFT, 24)) CA(cs->d_vhist, viterbi_hist_bytes(g.nch) / sizeof(unsigned long long));
     uint8_t *d_scr = nullptr;
     CA(d_scr, 5000);
+    unsigned long long *d_scrf = nullptr;
+    CA(d_scrf, 50);
 #undef CA
     cs->p.scr = d_scr;
     {
@@ -378,6 +479,11 @@ static int aerolc_create(jaero_aerol_ctx *c, int nchannels, int su_capacity)
             state[0] = val0;
         }
         HIPCHK(hipMemcpy(d_scr, scr.data(), 5000, hipMemcpyHostToDevice));
+        std::vector<unsigned long long> scrf(50, 0ull);
+        for (int y = 0; y < 25; y++)
+            for (int i = 0; i < 108; i++) scrf[2 * y + i / 64] |= (unsigned long long)(scr[109 * y + 1 + i] & 1) << (i % 64);
+        HIPCHK(hipMemcpy(d_scrf, scrf.data(), scrf.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        cs->p.scrf = d_scrf;
         // the depunctured buffer: every 4th symbol an erasure, for good (the walk only writes the other three)
         std::vector<uint8_t> dep((size_t)g.nchp * CC_PITCH, 0);
         for (size_t k = 0; k < dep.size(); k++) if ((k % CC_PITCH) % 4 == 3) dep[k] = 128;
@@ -409,7 +515,7 @@ static int aerolc_write(jaero_aerol_ctx *c, const int16_t *dsoft, const int *dco
     {
         aprof_begin(c, 0, st);
         hipLaunchKernelGGL(k_aerolc_bits, grid, block, 0, st, g, cs->p, dsoft, dcounts, stride);
-        hipLaunchKernelGGL(k_aerolc_bulk, dim3(g.nch), block, 0, st, g, cs->p, dsoft, stride, -1); // both stretches of a round, in order
+        hipLaunchKernelGGL(k_aerolc_bulk, dim3(g.nch), block, 0, st, g, cs->p, dsoft, stride, -1, -1); // both stretches of a round, in order
         aprof_end(c, st);
         aprof_begin(c, 1, st);
         // one block per wavefront for small banks, one per lane (k_viterbi_lanes) from 16 384 channels on, as the P-channel pipeline

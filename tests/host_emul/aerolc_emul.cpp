@@ -18,6 +18,8 @@ static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v
 // k_aerolc_bulk orders its two stretches with a wavefront fence + vmcnt(0): here a workgroup's threads run one after the other
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __shared__ static // one workgroup at a time
+#define CC_BULK_SYNC() ((void)0)
 // AeroLcrc16::calcusingbytes as jaero_amd/csrc/k_aerol.h:aerol_crc16 has it
 static inline unsigned aerol_crc16(const uint8_t *bytes, int n)
 {
@@ -60,9 +62,9 @@ extern "C" Emul *emul_create(int nch, int su_cap)
     e->p.I = zalloc<int>(e, (size_t)CI_NFIELDS * g.nchp);
     e->p.B = zalloc<unsigned long long>(e, (size_t)4 * g.nchp);
     e->p.dep = zalloc<uint8_t>(e, (size_t)g.nchp * CC_PITCH);
-    e->p.vbits = zalloc<uint8_t>(e, (size_t)g.nchp * (CC_NSOFT / 2));
+    e->p.vbits = zalloc<uint8_t>(e, (size_t)g.nchp * (CC_NSOFT / 2) + 64);
     e->p.overlap = zalloc<uint8_t>(e, (size_t)g.nchp * 64);
-    e->p.dl2 = zalloc<uint8_t>(e, (size_t)CC_DL2 * g.nchp);
+    e->p.dl2 = zalloc<uint8_t>(e, (size_t)CC_PREV_PITCH * g.nchp + 64);
     e->p.sus = zalloc<int32_t>(e, (size_t)g.nchp * g.su_cap * 16);
     e->p.voice = zalloc<uint8_t>(e, (size_t)g.nchp * g.v_cap * 304);
     e->p.events = zalloc<long long>(e, (size_t)g.nchp * g.ev_cap * 3);
@@ -76,6 +78,10 @@ extern "C" Emul *emul_create(int nch, int su_cap)
         state[0] = val0;
     }
     e->p.scr = scr;
+    unsigned long long *scrf = zalloc<unsigned long long>(e, 50);
+    for (int y = 0; y < 25; y++)
+        for (int i = 0; i < 108; i++) scrf[2 * y + i / 64] |= (unsigned long long)(scr[109 * y + 1 + i] & 1) << (i % 64);
+    e->p.scrf = scrf;
     for (size_t k = 0; k < (size_t)g.nchp * CC_PITCH; k++) if ((k % CC_PITCH) % 4 == 3) e->p.dep[k] = 128; // as aerolc_create
     for (int ch = 0; ch < g.nchp; ch++)
     {
@@ -107,7 +113,12 @@ extern "C" void emul_write(Emul *e, const int16_t *soft, const int *counts, int 
     for (int r = 0; r < rounds; r++)
     {
         launch(g.nchp / 64, 64, [&] { k_aerolc_bits(g, e->p, soft, cnt.data(), stride); });
-        for (int k = 0; k < 2; k++) launch(g.nch, 64, [&] { k_aerolc_bulk(g, e->p, soft, stride, k); }); // (the product: one launch for both, konly = -1)
+        // (the product: one launch for both stretches and both phases, konly = phase = -1; here a launch boundary per stretch and, workgroup by
+        // workgroup, every thread's staging before any thread's lookups)
+        for (int k = 0; k < 2; k++)
+            for (int b = 0; b < g.nch; b++)
+                for (int ph = 0; ph < 2; ph++)
+                    for (int t = 0; t < 64; t++) { blockDim.x = 64; blockIdx.x = b; threadIdx.x = t; k_aerolc_bulk(g, e->p, soft, stride, k, ph); }
         for (int ch = 0; ch < g.nch; ch++) // k_viterbi + k_viterbi_overlap_update for the channels with a complete frame
             if (e->p.I[(size_t)CI_HAS_BLOCK * g.nchp + ch])
             {
