@@ -213,7 +213,28 @@ __global__ __launch_bounds__(64) void k_aerol_bits(const AGeom g, const APtrs p,
 #pragma unroll
     for (int k = 0; k < AEROL_NMATCH; k++) match[k] = (BULK && k < nmatch) ? p.I[(size_t)(AI_MATCH0 + k) * g.nchp + ch] : 0x7fffffff;
     int next_match = -1;
-    int vnext = live ? (int)sb[pos] : 0;
+    // Soft bits eight per request (round 6): with one 2-byte load per walked bit -- even requested a bit ahead -- every bit waited for everything in
+    // flight, block stores included (vmcnt retires in order): ~2 us per walked bit.  The eight values sit in two 64-bit registers; a bit is a shift.
+    unsigned long long sw_lo = 0, sw_hi = 0;
+    int sw_pos = -0x40000000; // position of the first of the eight
+    auto soft_at = [&](int q) __attribute__((always_inline)) -> int {
+        if (q < sw_pos || q >= sw_pos + 8)
+        {
+            sw_pos = q;
+            if (q + 8 <= stride) { unsigned long long t[2]; __builtin_memcpy(t, sb + q, 16); sw_lo = t[0]; sw_hi = t[1]; }
+            else
+            {
+                sw_lo = 0; sw_hi = 0;
+                for (int k = 0; k < 8 && q + k < stride; k++)
+                {
+                    const unsigned long long v = (unsigned long long)(unsigned short)sb[q + k];
+                    if (k < 4) sw_lo |= v << (16 * k); else sw_hi |= v << (16 * (k - 4));
+                }
+            }
+        }
+        const int k = q - sw_pos;
+        return (int)(short)(unsigned short)((k < 4 ? sw_lo : sw_hi) >> (16 * (k & 3)));
+    };
     while (__any(live))
     {
         if (live)
@@ -284,7 +305,7 @@ __global__ __launch_bounds__(64) void k_aerol_bits(const AGeom g, const APtrs p,
                     for (int i = L - m; i < L; i++)
                     {
                         r ^= 1;
-                        const unsigned bitv = (((unsigned)(int)sb[pos + i] & 0xFFu) >= 128u) ? 1u : 0u;
+                        const unsigned bitv = (((unsigned)soft_at(pos + i) & 0xFFu) >= 128u) ? 1u : 0u; // (eight per request)
                         if (r) s.pd_imag = (s.pd_imag << 1) | bitv;
                         else s.pd_real = (s.pd_real << 1) | bitv;
                     }
@@ -297,12 +318,10 @@ __global__ __launch_bounds__(64) void k_aerol_bits(const AGeom g, const APtrs p,
                 s.accbad = 1; // the per-bit path may resume inside a group of four
                 pos += L;
                 jumped = true;
-                if (pos < n) vnext = (int)sb[pos];
             }
             if (!jumped)
             {
-                const int v = vnext;
-                if (pos + 1 < n) vnext = (int)sb[pos + 1];
+                const int v = soft_at(pos);
                 if (v < 0) { s.muw = 0; pos++; } // start-of-burst marker (aerol.cpp:1146-1152)
                 else if (aerol_bit_a(g, s, v, gotsync, rx)) { has_block = 1; resume = 1; live = false; }
                 else
@@ -367,23 +386,37 @@ __global__ __launch_bounds__(256) void k_aerol_scan(const AGeom g, const APtrs p
     const bool want = g.oqpsk != 0;
     int neg = 0;
     for (int q = n + lane; q < nall; q += 64) neg |= (sb[q] < 0) ? 1 : 0; // beyond the scanned range: markers only
-    for (int base = 0; base < n; base += 64)
+    // Eight positions per lane and request (round 6; one 2-byte load per lane and 64 positions before: 82 dependent rounds of load, ballot, LDS store per
+    // frame, 0.53 ms per 65 536-channel write against 0.19 for the bytes at HBM speed).  A lane's eight hard bits are four of either parity = a nibble of
+    // each parity stream at bit 4 (lane & 7) of word base / 64 + lane / 8: eight lanes OR their nibbles together, the first of them stores the word.
+    for (int base = 0; base < n; base += 512)
     {
-        const int q = base + lane;
-        const int v = q < n ? (int)sb[q] : 0;
-        neg |= (v < 0) ? 1 : 0;
-        if (!want) continue;
-        const unsigned long long m = __ballot((((unsigned)v & 0xFFu) >= 128u) && q < n);
-        if (lane < 2)
+        const int q0 = base + 8 * lane;
+        short v8[8];
+        if (q0 + 8 <= n) __builtin_memcpy(v8, sb + q0, 16);
+        else
         {
-            // the 32 bits of parity `lane` out of the 64 of this block, in order
-            unsigned long long x = (m >> lane) & 0x5555555555555555ull;
-            x = (x | (x >> 1)) & 0x3333333333333333ull;
-            x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
-            x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
-            x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
-            x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
-            par[w][lane][base >> 6] = (unsigned)x;
+#pragma unroll
+            for (int k = 0; k < 8; k++) v8[k] = (q0 + k < n) ? sb[q0 + k] : (short)0;
+        }
+        unsigned ev = 0, od = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            neg |= (v8[k] < 0) ? 1 : 0;
+            const unsigned h = ((((unsigned)(int)v8[k]) & 0xFFu) >= 128u && q0 + k < n) ? 1u : 0u;
+            if (k & 1) od |= h << (k >> 1); else ev |= h << (k >> 1);
+        }
+        if (!want) continue;
+        const int sh = 4 * (lane & 7);
+        unsigned long long x = ((unsigned long long)(od << sh) << 32) | (unsigned long long)(ev << sh);
+        x |= __shfl_xor(x, 1);
+        x |= __shfl_xor(x, 2);
+        x |= __shfl_xor(x, 4);
+        if ((lane & 7) == 0)
+        {
+            par[w][0][(base >> 6) + (lane >> 3)] = (unsigned)x;
+            par[w][1][(base >> 6) + (lane >> 3)] = (unsigned)(x >> 32);
         }
     }
     const int any = __any(neg) ? 1 : 0;
