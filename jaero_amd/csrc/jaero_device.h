@@ -64,6 +64,8 @@ __device__ __forceinline__ int jd_sload(const int *q) { return *(jd_cint *)q; }
 __device__ __forceinline__ double jd_sload(const double *q) { return *(jd_cdouble *)q; }
 
 // state access of the continuous sample kernels (ch, nchp in scope)
+// [channel group of 4][row][4] layout of the 8400 bps prefilter's per-sample arrays (k_pre8400.h: PRE_XI): element (row, channel) of an array of `rows` rows
+#define JD_G4(row, ch, rows) ((((size_t)((ch) >> 2)) * (size_t)(rows) + (size_t)(row)) * 4 + (size_t)((ch) & 3))
 #define LDF(f) (p.S[(size_t)(f) * nchp + ch])
 #define LDI(f) (p.I[(size_t)(f) * nchp + ch])
 

@@ -604,6 +604,7 @@ extern "C" int jaero_create(int device, int nchannels, const jaero_settings *set
         // a write's first transform block starts up to 2047 samples before the write and looks 4096 samples further back
         while (ring < max_write_samples + 3 * PRE_L) ring <<= 1;
         c->pre.ring = ring;
+        c->pre.cap = max_write_samples;
         DA(c->pre.xring, (size_t)ring * nchp);
         DA(c->pre.cidx, (size_t)max_write_samples * nchp);
         DA(c->pre.out, (size_t)max_write_samples * nchp);
@@ -1155,8 +1156,8 @@ static void launch_samples(jaero_ctx *c, const int16_t *frames, int stride, int 
             const int P = c->oq_pairs;
             const dim3 gridp((g.ngroups + P - 1) / P), blockp(P * 128);
             const int ldsp = P * fb_pair_doubles<FB_LDSN>() * (int)sizeof(double);
-            const double2 *pf = c->pre8400 ? (const double2 *)(c->pre.out + (size_t)pos * g.nchp) : nullptr;
-#define LFB(E, C, PP, X) hipLaunchKernelGGL((k_oqpsk_fb<55, FB_LDSN, E, C, PP, X>), gridp, blockp, ldsp, st, g, c->p, frames, stride, n, skipA, onlyA, fsb, c->oq_taps, pf)
+            const double2 *pf = c->pre8400 ? (const double2 *)(c->pre.out + (size_t)pos * 4) : nullptr; // row `pos` of every channel group (JD_G4)
+#define LFB(E, C, PP, X) hipLaunchKernelGGL((k_oqpsk_fb<55, FB_LDSN, E, C, PP, X>), gridp, blockp, ldsp, st, g, c->p, frames, stride, n, skipA, onlyA, fsb, c->oq_taps, pf, c->pre.cap)
 #define LFBP(E, C) { if (c->pre8400) { if (P == 4) LFB(E, C, 4, true); else LFB(E, C, 1, true); } else { if (P == 4) LFB(E, C, 4, false); else LFB(E, C, 1, false); } }
             if (eb && cs) LFBP(true, true) else if (eb) LFBP(true, false) else if (cs) LFBP(false, true) else LFBP(false, false)
 #undef LFBP
@@ -1421,6 +1422,7 @@ extern "C" int jaero_debug_prefilter(int device, const double *in_reim, int n, d
     int ring = 1;
     while (ring < n + 3 * PRE_L + 64) ring <<= 1;
     q.ring = ring;
+    q.cap = n;
     double2 *d_cis = nullptr; double *d_taps = nullptr;
     HIPCHK(hipMalloc((void **)&q.xring, sizeof(double2) * (size_t)ring * 64));
     HIPCHK(hipMalloc((void **)&q.cidx, sizeof(unsigned short) * (size_t)n * 64));
@@ -1434,7 +1436,7 @@ extern "C" int jaero_debug_prefilter(int device, const double *in_reim, int n, d
     const double2 one[4] = {{1.0, 0.0}, {1.0, 0.0}, {1.0, 0.0}, {1.0, 0.0}}; // table entry 0 = cis(0): the up-mix multiplies by its conjugate
     HIPCHK(hipMemcpy(d_cis, one, sizeof one, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_taps, taps.data(), sizeof(double) * PRE_K, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy2D(q.xring, sizeof(double2) * 64, in_reim, sizeof(double2), sizeof(double2), (size_t)n, hipMemcpyHostToDevice)); // channel 0 of every slot
+    HIPCHK(hipMemcpy2D(q.xring, sizeof(double2) * 4, in_reim, sizeof(double2), sizeof(double2), (size_t)n, hipMemcpyHostToDevice)); // channel 0 of every slot (PRE_XI)
     p.cis = d_cis; q.taps = d_taps;
     {
         double2 *dH = nullptr, *dtw = nullptr;
@@ -1446,7 +1448,7 @@ extern "C" int jaero_debug_prefilter(int device, const double *in_reim, int n, d
         HIPCHK(hipDeviceSynchronize());
         hipFree(dH); hipFree(dtw);
     }
-    HIPCHK(hipMemcpy2D(out_reim, sizeof(double2), q.out, sizeof(double2) * 64, sizeof(double2), (size_t)n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy2D(out_reim, sizeof(double2), q.out, sizeof(double2) * 4, sizeof(double2), (size_t)n, hipMemcpyDeviceToHost));
     hipFree(q.xring); hipFree(q.cidx); hipFree(q.out); hipFree(q.hold); hipFree(d_cis); hipFree(d_taps);
     return 0;
 }
@@ -1456,7 +1458,7 @@ extern "C" int jaero_debug_read_prefiltered(jaero_ctx *c, int ch, double *out_re
 {
     if (!c || !out_reim || !c->pre8400 || ch < 0 || ch >= c->g.nch || n <= 0 || n > c->pre_nprev) return fail(JAERO_EINVAL, "jaero_debug_read_prefiltered: bad arguments");
     HIPCHK(hipStreamSynchronize(c->last_stream));
-    HIPCHK(hipMemcpy2D(out_reim, sizeof(double2), c->pre.out + ch, sizeof(double2) * c->g.nchp, sizeof(double2), (size_t)n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy2D(out_reim, sizeof(double2), c->pre.out + JD_G4(0, ch, c->pre.cap), sizeof(double2) * 4, sizeof(double2), (size_t)n, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -135,7 +135,7 @@ __device__ __forceinline__ void fb_barrier()
 template <int FIRN, int LDSN, bool EBNO, bool PRE8400, bool SOLO>
 __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &L, const int16_t *__restrict__ pcm, int pcm_stride, int n,
                                          int skip_a_first, int only_a_last, int fir_slot0, int grp, int lane, const JTaps28 &tp,
-                                         const double2 *__restrict__ prefilt)
+                                         const double2 *__restrict__ prefilt, int pf_rows)
 {
     constexpr int TAILN = FIRN - LDSN;
     double tre[TAILN], tim[TAILN]; // tre[j] = x_re[n-LDSN-j] once x[n] has been pushed
@@ -264,7 +264,7 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &
 
     if constexpr (PRE8400)
     {
-        double2 nx_pf = (nB > 0) ? prefilt[ch] : make_double2(0.0, 0.0);
+        double2 nx_pf = (nB > 0) ? prefilt[JD_G4(0, ch, pf_rows)] : make_double2(0.0, 0.0); // (prefilt already points at this launch's first row)
         FB_SYNC(L); // the back half has published the carrier table index of sample 0
         for (int i = 0; i < nB; i++)
         {
@@ -286,7 +286,7 @@ __device__ __forceinline__ void fb_front(const JGeom &g, const JPtrs &p, FbLds &
             {
                 nx_pcm = live ? pcm[(size_t)(i + 1) * pcm_stride + ch] : (short)0;
                 nx_cc = cis[jd_cisidx(mc_ptr)];
-                nx_pf = prefilt[(size_t)(i + 1) * nchp + ch];
+                nx_pf = prefilt[JD_G4(i + 1, ch, pf_rows)];
             }
             if (i + 1 < nB)
             {
@@ -678,7 +678,7 @@ __device__ __forceinline__ void fb_back(const JGeom &g, const JPtrs &p, FbLds &L
 template <int FIRN, int LDSN, bool EBNO, bool CAPSYM, int PAIRS, bool PRE8400 = false>
 __global__ __launch_bounds__(PAIRS * 128) void k_oqpsk_fb(const JGeom g, const JPtrs p, const int16_t *__restrict__ pcm, int pcm_stride, int n,
                                                           int skip_a_first, int only_a_last, int fir_slot0, const JTaps28 tp,
-                                                          const double2 *__restrict__ prefilt)
+                                                          const double2 *__restrict__ prefilt, int pf_rows)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -699,5 +699,5 @@ __global__ __launch_bounds__(PAIRS * 128) void k_oqpsk_fb(const JGeom g, const J
         return;
     }
     if (back) fb_back<CAPSYM, PRE8400>(g, p, L, n, only_a_last, grp, lane);
-    else fb_front<FIRN, LDSN, EBNO, PRE8400, (PAIRS == 1 && !PRE8400)>(g, p, L, pcm, pcm_stride, n, skip_a_first, only_a_last, fir_slot0, grp, lane, tp, prefilt);
+    else fb_front<FIRN, LDSN, EBNO, PRE8400, (PAIRS == 1 && !PRE8400)>(g, p, L, pcm, pcm_stride, n, skip_a_first, only_a_last, fir_slot0, grp, lane, tp, prefilt, pf_rows);
 }

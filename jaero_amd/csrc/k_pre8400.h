@@ -23,9 +23,11 @@
 
 struct JPre
 {
-    double2 *xring;        // [ring][nchp] down-mixed history, slot = absolute sample index & (ring - 1)
-    unsigned short *cidx;  // [max_write][nchp] table index of the up-mix oscillator for every sample of the current write
-    double2 *out;          // [max_write][nchp] prefiltered samples of the current write (cval_prefiltered)
+    double2 *xring;        // [nchp / 4][ring][4] down-mixed history, slot = absolute sample index & (ring - 1): the four channels of a k_pre8400_fft workgroup are one
+                           // contiguous 64-byte row per slot and one contiguous stretch per window (round 6; [ring][nchp] until then: see PRE_XI)
+    unsigned short *cidx;  // [nchp / 4][cap][4] table index of the up-mix oscillator for every sample of the current write
+    double2 *out;          // [nchp / 4][cap][4] prefiltered samples of the current write (cval_prefiltered); k_oqpsk_fb<.., PRE8400> reads it with JD_G4
+    int cap;               // rows of cidx / out = the bank's largest write
     const double *taps;    // [PRE_K]
     int ring;              // power of two >= max_write + 3 * PRE_L
     const double2 *H;      // [4096] DFT of the taps (zero-padded to 4096) / 4096, natural order        (k_pre8400_fft)
@@ -33,6 +35,11 @@ struct JPre
     long long *hold;       // [nchp] absolute sample index up to which a channel's outputs are exact zeros: 2048 samples behind a
                            // setSettings of that channel alone (JFastFir::SetKernel queues L zeros in front of the new filter's output)
 };
+
+// index of (slot, channel) in JPre::xring.  As [ring][nchp] a transform workgroup's window was 4096 sectors a megabyte apart (65 536 channels x 16 bytes per
+// slot): every one of them its own page for the address translation.  Group-major, a window is 256 KB in one piece; k_pre8400_mix's 64 lanes write 16
+// sectors per sample, each of them the next one of its group's stream.
+#define PRE_XI(slot, ch, ring) JD_G4(slot, ch, ring)
 
 // fields of JPtrs::S used by the prefilter (appended to the state enum in jaero_device.h): S_PRE_PTR, S_PRE_STEP, S_PRE_FSUM
 
@@ -89,8 +96,8 @@ __global__ __launch_bounds__(64) void k_pre8400_mix(const JGeom g, const JPtrs p
         for (int u = 0; u < 8; u++)
         {
             const double dval = ((double)sv[u]) / 32768.0;
-            q.cidx[(size_t)(i + u) * nchp + ch] = (unsigned short)iu[u];
-            q.xring[(size_t)((int)((n0 + i + u) & rmask)) * nchp + ch] = make_double2(cv[u].x * dval, cv[u].y * dval);
+            q.cidx[PRE_XI(i + u, ch, q.cap)] = (unsigned short)iu[u];
+            q.xring[PRE_XI((int)((n0 + i + u) & rmask), ch, q.ring)] = make_double2(cv[u].x * dval, cv[u].y * dval);
         }
     }
     for (; i < hi; i++)
@@ -98,8 +105,8 @@ __global__ __launch_bounds__(64) void k_pre8400_mix(const JGeom g, const JPtrs p
         const short s = live ? pcm[(size_t)i * pcm_stride + ch] : (short)0;
         const double dval = ((double)s) / 32768.0;
         const double2 c = cis[jd_cisidx(pd)];
-        q.cidx[(size_t)i * nchp + ch] = (unsigned short)jd_cisidx(pu);
-        q.xring[(size_t)((int)((n0 + i) & rmask)) * nchp + ch] = make_double2(c.x * dval, c.y * dval);
+        q.cidx[PRE_XI(i, ch, q.cap)] = (unsigned short)jd_cisidx(pu);
+        q.xring[PRE_XI((int)((n0 + i) & rmask), ch, q.ring)] = make_double2(c.x * dval, c.y * dval);
         jd_wt_next(pd, sd);
         jd_wt_next(pu, su);
     }
@@ -194,12 +201,12 @@ __global__ __launch_bounds__(PF_THREADS) void k_pre8400_fft(const JGeom g, const
     const long long hold_until = q.hold[ch];
     CV<16> d;
     {
-        const double2 *__restrict__ xr = q.xring + ch;
+        const double2 *__restrict__ xr = q.xring;
         const long long b = m0 - 2 * PRE_L + T;
 #pragma unroll
         for (int s = 0; s < 16; s++)
         {
-            const double2 v = xr[(size_t)((int)((b + 256 * s) & rmask)) * nchp];
+            const double2 v = xr[PRE_XI((int)((b + 256 * s) & rmask), ch, q.ring)];
             d.r[s] = v.x; d.i[s] = v.y;
         }
     }
@@ -224,9 +231,9 @@ __global__ __launch_bounds__(PF_THREADS) void k_pre8400_fft(const JGeom g, const
             const bool held = n0 + i < hold_until;
             const double yr = held ? 0.0 : d.r[s], yi = held ? 0.0 : -d.i[s];
             // cval_prefiltered[i] *= mixer_fir_pre.WTCISValue_conj()
-            const double2 cj = p.cis[q.cidx[(size_t)i * nchp + ch]];
+            const double2 cj = p.cis[q.cidx[PRE_XI(i, ch, q.cap)]];
             const double bre = cj.x, bim = -cj.y;
-            q.out[(size_t)i * nchp + ch] = make_double2(yr * bre - yi * bim, yr * bim + yi * bre);
+            q.out[PRE_XI(i, ch, q.cap)] = make_double2(yr * bre - yi * bim, yr * bim + yi * bre);
         }
     }
 }
@@ -239,6 +246,6 @@ __global__ __launch_bounds__(PF_THREADS) void k_pre8400_fft(const JGeom g, const
 __global__ void k_pre8400_restart(const JGeom g, const JPre q, int ch, long long now)
 {
     const int nchp = g.nchp;
-    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < q.ring; slot += gridDim.x * blockDim.x) q.xring[(size_t)slot * nchp + ch] = make_double2(0.0, 0.0);
+    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < q.ring; slot += gridDim.x * blockDim.x) q.xring[PRE_XI(slot, ch, q.ring)] = make_double2(0.0, 0.0);
     if (blockIdx.x == 0 && threadIdx.x == 0) q.hold[ch] = now + PRE_L;
 }
