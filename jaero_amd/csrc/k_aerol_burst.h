@@ -366,12 +366,12 @@ __global__ __launch_bounds__(64) void k_aerolb_post(const AGeom g, const APtrs p
             {
                 int32_t *row = p.sus + ((size_t)ch * g.su_cap + row_cnt) * 16;
                 row[0] = npk; row[1] = c;
-                for (int j = 0; j < 12; j++)
-                {
-                    int b = 0;
-                    if (c * 12 + j < ninfo) b = (int)aerolb_pack8(((const unsigned long long *)dec)[c * 12 + j]); // first bit of a byte is its LSB
-                    row[2 + j] = b;
-                }
+                // the twelve loads first, then the stores: interleaved, every load waited for the store in front of it (vmcnt retires in order)
+                unsigned long long w8[12];
+#pragma unroll
+                for (int j = 0; j < 12; j++) w8[j] = (c * 12 + j < ninfo) ? ((const unsigned long long *)dec)[c * 12 + j] : 0ull;
+#pragma unroll
+                for (int j = 0; j < 12; j++) row[2 + j] = (c * 12 + j < ninfo) ? (int)aerolb_pack8(w8[j]) : 0; // first bit of a byte is its LSB
                 row[14] = ninfo; row[15] = type;
                 row_cnt++;
             }
