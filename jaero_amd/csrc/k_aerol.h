@@ -690,6 +690,67 @@ __global__ void k_aerol_post_packed(const AGeom g, const APtrs p)
         abits_put(ring, 0, m - m1, v >> m1);
     };
     const int nbytes = nb / 8; // bits beyond the last whole byte are dropped (charptr starts at 0 in every block)
+    // Round 6: a block is shorter than the line (the comment above), so nothing this call reads was written by this call: ALL the reads first, eight steps
+    // per wait, then the block's bits go into the ring as whole words (bit-granular only at the two ends and at the wrap).  Step by step it was two
+    // round trips per 32 bits -- the read, then the read-modify-write of the put -- 156 per 10.5 kbps frame.
+    if (nb + 64 < sz && scr_pos + nb <= 5000)
+    {
+        const int ptr0 = dl2_ptr, scr0 = scr_pos;
+        for (int h0 = 0; h0 < nb; h0 += 256)
+        {
+            unsigned outw[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+            {
+                const int h = h0 + 32 * k;
+                outw[k] = 0;
+                if (h < nb)
+                {
+                    const int m = min(32, nb - h);
+                    int rq = ptr0 + 1 + h; if (rq >= sz) rq -= sz;
+                    outw[k] = ring_get(rq, m) ^ abits_get(p.scrw, scr0 + h, m);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+            {
+                const int h = h0 + 32 * k;
+                if (h >= nb) break;
+                const int nby = min(4, nbytes - (h >> 3)); // whole bytes of this step
+                for (int b = 0; b < nby; b++)
+                    if (ninfo < g.info_cap) info[ninfo++] = (uint8_t)(outw[k] >> (8 * b));
+            }
+        }
+        // the block's bits behind the pointer: ring bits [ptr0, ptr0 + nb), wrapping at sz
+        auto put_seg = [&](int q, int sbit, int len) {
+            while (len > 0)
+            {
+                const int off = q & 31;
+                if (off == 0 && len >= 256)
+                {
+                    unsigned sw[9];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) sw[k] = vbw[(sbit >> 5) + k]; // (one spare word behind vbits' rows: abits_get reads the same)
+                    const int sh = sbit & 31;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) ring[(q >> 5) + k] = sh ? ((sw[k] >> sh) | (sw[k + 1] << (32 - sh))) : sw[k];
+                    q += 256; sbit += 256; len -= 256;
+                    continue;
+                }
+                const int m = min(32 - off, len);
+                const unsigned v = abits_get(vbw, sbit, m);
+                if (m == 32) ring[q >> 5] = v;
+                else abits_put(ring, q, m, v);
+                q += m; sbit += m; len -= m;
+            }
+        };
+        const int seg1 = min(nb, sz - ptr0);
+        put_seg(ptr0, 0, seg1);
+        if (seg1 < nb) put_seg(0, seg1, nb - seg1);
+        dl2_ptr = ptr0 + nb; if (dl2_ptr >= sz) dl2_ptr -= sz;
+        scr_pos = scr0 + nb;
+    }
+    else
     for (int h = 0; h < nb; h += 32)
     {
         const int m = min(32, nb - h);
