@@ -244,18 +244,31 @@ __global__ __launch_bounds__(64) void k_aerolb_bits(const AGeom g, const APtrs p
 // deinterleave_ba(block, cols) of the channels that reached a trial length: out[j*64 + i] = block[((i*27) % 64) * cols + j]
 __global__ __launch_bounds__(256) void k_aerolb_deint(const AGeom g, const APtrs p)
 {
-    __shared__ uint8_t blk[4][RT_BLOCKSZ];
+    __shared__ __attribute__((aligned(16))) uint8_t blk[4][RT_BLOCKSZ];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ch = blockIdx.x * 4 + w;
     if (ch >= g.nch) return;
     if (!ALD(AI_HAS_BLOCK)) return; // wave-uniform
     const int len = ALD(BI_TRIAL_LEN), cols = len / 64;
     const uint8_t *src = p.rx + (size_t)ch * RT_BLOCKSZ;
-    for (int q = lane; q < len; q += 64) blk[w][q] = src[q];
+    // (round 6) sixteen bytes per lane and request in (len is a multiple of 64, the rows of rx and blk are 16-byte aligned), a word per lane out: it was
+    // one byte per lane either way, 2 x len / 64 dependent rounds per trial
+    for (int q = lane * 16; q < len; q += 1024) *(uint4 *)(blk[w] + q) = *(const uint4 *)(src + q);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // this wavefront's LDS writes before its LDS reads (one wavefront per channel: no barrier)
     uint8_t *dst = p.deint + (size_t)ch * RT_BLOCKSZ;
     const int perm = (lane * 27) & 63;
     if (g.oqpsk)
-        for (int j = 0; j < cols; j++) dst[j * 64 + lane] = blk[w][perm * cols + j];
+    {
+        // out[j * 64 + i] = block[((i * 27) % 64) * cols + j]: lane -> (four consecutive i, one j of four): 256 contiguous bytes per store instruction
+        const int i4 = (lane & 15) * 4, jo = lane >> 4;
+        const int p0 = ((i4 + 0) * 27) & 63, p1 = ((i4 + 1) * 27) & 63, p2 = ((i4 + 2) * 27) & 63, p3 = ((i4 + 3) * 27) & 63;
+        for (int j = jo; j < cols; j += 4)
+        {
+            const unsigned v = (unsigned)blk[w][p0 * cols + j] | ((unsigned)blk[w][p1 * cols + j] << 8) | ((unsigned)blk[w][p2 * cols + j] << 16) |
+                               ((unsigned)blk[w][p3 * cols + j] << 24);
+            *(unsigned *)(dst + j * 64 + i4) = v;
+        }
+    }
     else
     {
         // deinterleaveMSK_ba (aerol.cpp:671-711): the first five columns are one 64 x 5 block, every following three a 64 x 3 block

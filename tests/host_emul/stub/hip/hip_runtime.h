@@ -32,6 +32,9 @@ static inline unsigned __brev(unsigned v)
 }
 static inline unsigned long long __ballot(int p) { return p ? 1ull : 0ull; } // one-lane "wavefront": compiles, never relied on
 static inline int __any(int p) { return p; }
+#ifndef __builtin_amdgcn_fence
+#define __builtin_amdgcn_fence(order, scope) ((void)0) // (k_aerolb_deint: compiles, never run here)
+#endif
 template <class T> static inline T __shfl_xor(T v, int) { return v; } // (k_aerol_scan: compiles, never run here)
 static inline void __syncthreads() {}
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
