@@ -46,6 +46,7 @@ cd "$R"
 # the counter summaries of THIS pass become the ones bench.py reads, so that the lines below are annotated with traffic taken in the same pass
 export JAERO_EVIDENCE_TAG=$TAG
 for f in "$OUT"/pmc_summary*.json "$OUT"/sq_summary*.json; do [ -s "$f" ] && cp "$f" "$R/profiles/$(basename "$f")"; done
+[ -s "$OUT/pmc_summary_oqpsk8400.json" ] && cp "$OUT/pmc_summary_oqpsk8400.json" "$R/profiles/pmc_summary_8400.json" # (the name bench.py reads for the 8400 bps workload)
 if has bench; then
   rm -f gpurun_out/bench_details.json
   SECONDS=0; ( timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 2> "$OUT/bench.err" | tail -1 ) > "$OUT/bench_line.json"
