@@ -216,18 +216,24 @@ __device__ __forceinline__ int cc_cntr_of_src(int src)
 // window, and stretches cut by a write boundary) store their bytes singly.
 // phase: -1 = stage, then emit (the device); 0 / 1 = one of the two (tests/host_emul runs a workgroup's threads one after the other: every thread stages
 // before any emits); konly likewise >= 0 only there.
+// Four channels per workgroup, a wavefront each (65 536 one-wavefront workgroups cost ~130 us to dispatch even when every one of them returns at once, and two
+// of a write's three rounds are like that); a wavefront only touches its own LDS row, whose accesses the LDS takes in program order: a compiler fence, no barrier.
 #ifndef AEROLC_KERNELS_ONLY
-#define CC_BULK_SYNC() __syncthreads()
+#define CC_BULK_SYNC() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront")
+#define CC_BULK_PASS 2048
+#else
+#define CC_BULK_PASS 4096 // (tests/host_emul: one pass, because there every thread stages before any emits)
 #endif
-__global__ __launch_bounds__(64) void k_aerolc_bulk(const CGeom g, const CPtrs p, const int16_t *__restrict__ soft, int stride, int konly, int phase)
+__global__ __launch_bounds__(256) void k_aerolc_bulk(const CGeom g, const CPtrs p, const int16_t *__restrict__ soft, int stride, int konly, int phase)
 {
-    __shared__ __attribute__((aligned(16))) int16_t row[CC_FRAME + 8];
-    const int ch = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) int16_t rows[4][CC_BULK_PASS + 8];
+    const int ch = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (ch >= g.nch) return;
+    int16_t *row = rows[threadIdx.x >> 6];
     const int nk = CLD(CI_BULK_N); // wave-uniform
     const int16_t *s = soft + (size_t)ch * stride;
     uint8_t *dep = p.dep + (size_t)ch * CC_PITCH;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & 63;
     for (int k = 0; k < nk && k < 2; k++)
     {
         if (konly >= 0 && k != konly) continue;
@@ -238,8 +244,17 @@ __global__ __launch_bounds__(64) void k_aerolc_bulk(const CGeom g, const CPtrs p
             CC_BULK_SYNC(); // every lane has read what it needs of stretch 0 from LDS
         }
         const int f0 = CI_BULK0_SRC + 4 * k;
-        const int src = p.I[(size_t)(f0 + 0) * g.nchp + ch], c0 = p.I[(size_t)(f0 + 1) * g.nchp + ch];
-        const int len = p.I[(size_t)(f0 + 2) * g.nchp + ch], fl = p.I[(size_t)(f0 + 3) * g.nchp + ch];
+        const int src_k = p.I[(size_t)(f0 + 0) * g.nchp + ch], c0_k = p.I[(size_t)(f0 + 1) * g.nchp + ch];
+        const int len_k = p.I[(size_t)(f0 + 2) * g.nchp + ch], fl_k = p.I[(size_t)(f0 + 3) * g.nchp + ch];
+        // In passes of CC_BULK_PASS received positions, cut at multiples of 256 (the interleaver's blocks): 4 KB of LDS per wavefront instead of 8, so that
+        // twice as many of these short-lived wavefronts -- a few dependent round trips each -- are resident (the kernel is bound by their latency, not by bytes
+        // or instructions).  A word whose three sources fall into two passes is written byte by byte by both.
+        for (int pa = (c0_k > 0 ? c0_k : 0) / CC_BULK_PASS * CC_BULK_PASS; pa < c0_k + len_k; pa += CC_BULK_PASS)
+        {
+        const int c0 = c0_k > pa ? c0_k : pa;
+        const int c1 = (c0_k + len_k) < (pa + CC_BULK_PASS) ? (c0_k + len_k) : (pa + CC_BULK_PASS);
+        const int len = c1 - c0, src = src_k + (c0 - c0_k), fl = fl_k ^ ((c0 - c0_k) & 1);
+        if (pa > (c0_k > 0 ? c0_k : 0) / CC_BULK_PASS * CC_BULK_PASS) CC_BULK_SYNC(); // the previous pass has read its entries
         if (phase != 1)
         {
             for (int j8 = tid * 8; j8 < len; j8 += 64 * 8)
@@ -251,8 +266,13 @@ __global__ __launch_bounds__(64) void k_aerolc_bulk(const CGeom g, const CPtrs p
         if (phase < 0) CC_BULK_SYNC();
         if (phase != 0)
         {
-            // the words that hold positions of [c0, c0 + len): cntr -> source index is monotonic in neither direction, so all CC_NSOFT / 4 words are looked at
-            for (int m = tid; m < CC_NSOFT / 4; m += 64)
+            // the words that can hold positions of [c0, c0 + len): the interleaver permutes inside blocks of 256 received bits = 256 source indices = words
+            // 256 b / 3 .. (256 b + 255) / 3, so only the words of the blocks the stretch touches are looked at (a write boundary cuts a frame body into two
+            // stretches, copied in two rounds: looking at all 1365 words in both made this kernel instruction-bound, 0.25 ms per round)
+            const int m_lo = (((c0 > 0 ? c0 : 0) >> 8) << 8) / 3;
+            int m_hi = ((((c0 + len - 1) >> 8) << 8) + 255) / 3 + 1;
+            if (m_hi > CC_NSOFT / 4) m_hi = CC_NSOFT / 4;
+            for (int m = m_lo + tid; m < m_hi; m += 64)
             {
                 unsigned word = 128u << 24;
                 int inside = 0;
@@ -286,6 +306,7 @@ __global__ __launch_bounds__(64) void k_aerolc_bulk(const CGeom g, const CPtrs p
                 }
             }
         }
+        } // passes
     }
 }
 
@@ -515,7 +536,7 @@ static int aerolc_write(jaero_aerol_ctx *c, const int16_t *dsoft, const int *dco
     {
         aprof_begin(c, 0, st);
         hipLaunchKernelGGL(k_aerolc_bits, grid, block, 0, st, g, cs->p, dsoft, dcounts, stride);
-        hipLaunchKernelGGL(k_aerolc_bulk, dim3(g.nch), block, 0, st, g, cs->p, dsoft, stride, -1, -1); // both stretches of a round, in order
+        hipLaunchKernelGGL(k_aerolc_bulk, dim3((g.nch + 3) / 4), dim3(256), 0, st, g, cs->p, dsoft, stride, -1, -1); // both stretches of a round, in order
         aprof_end(c, st);
         aprof_begin(c, 1, st);
         // one block per wavefront for small banks, one per lane (k_viterbi_lanes) from 16 384 channels on, as the P-channel pipeline
