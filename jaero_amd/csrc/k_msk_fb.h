@@ -38,9 +38,12 @@
 // output -- the sum runs oldest first -- and hands the partial sum to the front half; the front half keeps 80 - 32 - MFB4_TB entries in registers
 // and 32 in LDS and continues the same sum.  Same operations in the same order as the single accumulator chain.
 // (Round 5: 18, not 22 -- with 22 the back half reloaded ten spilled values inside its sample loop, every reload an s_waitcnt vmcnt(0) in
-// front of the ring entries requested ahead; with 18 neither loop touches scratch, what is left spilled is the state prologue / epilogue.)
+// front of the ring entries requested ahead; with 18 neither loop touches scratch, what is left spilled is the state prologue / epilogue.
+// Round 6, with the filter in four versions over ring blocks: 18 / 14 / 10 = 14.1 / 15.0 / 18.9 ms per step -- 18 stays.)
 #define MFB4_LDSN 32
+#ifndef MFB4_TB
 #define MFB4_TB 18
+#endif
 // 160 taps (600 bps at 48 kHz; round 3): TWO pairs per workgroup, every wavefront alone on its SIMD (512 registers): 72 entries of each arm
 // in LDS (81 664 B per pair, 163 328 B per CU), 28 in the front half's registers, the 60 oldest in the back half's (36 / 52 until round 5; round 3 measured splits 36/44/52/60: 5.87, 6.02, 6.03 Gsamples/s; all still spill 230-300 registers).  k_msk_samples<160,78>
 // (two wavefronts per CU, 82 entries in 256 registers) spilled ~750 registers; one wavefront per CU with the whole history in LDS and no
