@@ -57,7 +57,8 @@
                      // the instruction cache two CUs share (front half 8 versions x ~600 instructions + back half ~2 600), and that costs more than the moves
 #endif
 #ifndef MFB2_TB
-#define MFB2_TB 60 // round 5, with the filter op for op: 40 / 52 / 60 / 68 measured 5 621 / 5 998 / 6 145 / 6 130 Msamples/s at 65 536 channels
+#define MFB2_TB 64 // round 5, with the filter op for op: 40 / 52 / 60 / 68 measured 5 621 / 5 998 / 6 145 / 6 130 Msamples/s at 65 536 channels (60 until round 6);
+                   // round 6, with ring blocks of 4 and the tail moved every 2nd sample: 52 / 56 / 60 / 64 / 68 = 28.9 / 28.9 / 27.9 / 27.3 / 28.2 ms per step
 #endif
 
 struct MfbLds
